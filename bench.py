@@ -1,0 +1,278 @@
+#!/usr/bin/env python
+"""bench.py -- env-steps/s of the CM3 rollout hot path on MI355X (one process per GPU).
+
+    python bench.py --gpus 1 --steps 3300 --warmup 330
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one tick of the hot path over one batch: ONE launch of the particle step kernel
+(csrc/particle.hip) advancing E = 4096 environments x 4 agents of config_particle_stage2_antipodal
+(BASELINE.json configs[1]) per GPU, float32, uniform random actions drawn in-kernel
+(train_onpolicy.py:305-307), auto-reset at max_steps = 33.  Ticks are enqueued through
+cm3_particle_rollout_f32 and replayed as a hipGraph of 33 launches (one launch per tick is kept).
+Env instances shard across ranks with NO data-path collective => "weak" scaling.
+
+One JSON line on rank 0:  metric = env-steps/s summed over all GPUs;
+roofline  = algorithmic bytes per launch (400 B x E for N=4) / average launch duration
+            measured with HIP events on the launch stream, against the 8 TB/s HBM3E peak;
+cpu_baseline = the reference-shaped scalar NumPy port (oracle.particle_oracle.ParticleEnvOracle)
+            timed on one host core of this box (rank 0, N=1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+GRAPH_TICKS = 33              # one episode per graph replay
+
+
+def algorithmic_bytes_per_env_step(n_agents):
+    """16 + 48 N + 16 N max(N-1,1)  (f32/int32): 80 B (N=1), 400 B (N=4), 1296 B (N=8)."""
+    n = n_agents
+    return 16 + 48 * n + 16 * n * max(n - 1, 1)
+
+
+class ParticleStepper(object):
+    """In-place stepping of E envs through the C ABI (zero strides = every tick overwrites the same
+    live buffers), optionally replayed as a hipGraph."""
+
+    def __init__(self, cfg, n_agents, n_envs, device, seed=12341, env_id_base=0, max_steps=33, prob_random=0.2):
+        import torch
+        from cm3_amd import _lib
+        from cm3_amd.particle import VecParticleEnv
+        self.torch, self._lib_mod, self.lib = torch, _lib, _lib.lib()
+        self.env = VecParticleEnv(cfg, n_agents, prob_random, max_steps, n_envs, device=device, seed=seed,
+                                  dtype=torch.float32, auto_reset=True, env_id_base=env_id_base)
+        self.env.reset()
+        e = self.env
+        e._desc.flags = _lib.FLAG_AUTO_RESET | _lib.FLAG_GEN_ACTIONS
+        t = self.traj = _lib.ParticleTraj()
+        t.state = e._state[0].data_ptr()
+        t.goals = e._goals.data_ptr()
+        t.obs_others = e._obs_others[0].data_ptr()
+        t.actions = e._actions[0].data_ptr()
+        t.reward_n = e._reward_n[0].data_ptr()
+        t.reward = e._reward[0].data_ptr()
+        t.done = e._done[0].data_ptr()
+        t.meta = e._meta.data_ptr()
+        t.episode = e._episode.data_ptr()      # all strides stay 0: in place
+        self.device = e.device
+        self.graph = None
+        self.graph_ticks = 0
+
+    def stream(self):
+        return self._lib_mod.current_stream_handle(self.device)
+
+    def enqueue(self, n_ticks, stream=None):
+        self._lib_mod.check(self.lib.cm3_particle_rollout_f32(ctypes.byref(self.env._desc), ctypes.byref(self.traj),
+                                                              int(n_ticks), self.stream() if stream is None else stream))
+
+    def capture(self, n_ticks):
+        self.graph = self._lib_mod.capture_graph(self.device, lambda s: self.enqueue(n_ticks, s))
+        self.graph_ticks = n_ticks
+
+    def run(self, n_ticks):
+        """Enqueue n_ticks ticks: whole graph replays plus an eager remainder."""
+        s = self.stream()
+        if self.graph is not None:
+            while n_ticks >= self.graph_ticks:
+                self._lib_mod.check(self.lib.cm3_graph_launch(self.graph, s))
+                n_ticks -= self.graph_ticks
+        if n_ticks > 0:
+            self.enqueue(n_ticks)
+
+    def close(self):
+        if self.graph is not None:
+            self.lib.cm3_graph_destroy(self.graph)
+            self.graph = None
+
+
+def timed_ticks(stepper, n_ticks):
+    """HIP-event time (ms) of n_ticks ticks on the launch stream."""
+    torch = stepper.torch
+    with torch.cuda.device(stepper.device):
+        stream = torch.cuda.current_stream()
+        start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record(stream)
+        stepper.run(n_ticks)
+        stop.record(stream)
+        stop.synchronize()
+        return start.elapsed_time(stop)
+
+
+def measure_read_bandwidth(device, gib=4.0, reps=5):
+    """Streaming 16 B/lane read of a buffer far larger than the 256 MiB Infinity Cache (GB/s)."""
+    import torch
+    from cm3_amd import _lib
+    lib = _lib.lib()
+    nbytes = int(gib * (1 << 30)) // 16 * 16
+    buf = torch.empty(nbytes // 4, dtype=torch.int32, device=device)
+    buf.random_(0, 1 << 30)
+    sink = torch.zeros(lib.cm3_hbm_bench_sink_words(), dtype=torch.int32, device=device)
+    s = _lib.current_stream_handle(device)
+    _lib.check(lib.cm3_hbm_read_bench(buf.data_ptr(), nbytes, sink.data_ptr(), s))
+    torch.cuda.synchronize(device)
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(reps):
+        _lib.check(lib.cm3_hbm_read_bench(buf.data_ptr(), nbytes, sink.data_ptr(), s))
+    stop.record()
+    stop.synchronize()
+    ms = start.elapsed_time(stop) / reps
+    del buf
+    return nbytes / (ms * 1e-3) / 1e9
+
+
+def cpu_baseline(cfg, n_agents, budget_s=12.0):
+    """Reference-shaped scalar NumPy port on ONE host core: whole 33-tick episodes with uniform random
+    actions, exactly the reference's pretrain loop (train_onpolicy.py:281-350 without the buffer)."""
+    import random
+    import numpy as np
+    from oracle.particle_oracle import ParticleEnvOracle
+    env = ParticleEnvOracle(n_agents, cfg, 0.2, 33)
+    py_rng, np_rng = random.Random(12341), np.random.RandomState(12341)
+    steps, episodes = 0, 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        env.reset(py_rng, np_rng)
+        done = False
+        while not done:
+            acts = np_rng.randint(0, 5, n_agents)
+            *_, done = env.step(acts)
+            steps += 1
+        episodes += 1
+    dt = time.perf_counter() - t0
+    return dict(value=steps / dt, unit="env-steps/s", cores=1, kind="port",
+                sample="%d episodes (%d env-steps) of the same workload (antipodal, N=%d, 33 ticks, uniform actions) "
+                       "in %.1f s on 1 of %d host cores; scalar per-env NumPy port of the reference's call structure"
+                       % (episodes, steps, n_agents, dt, os.cpu_count()))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3300)
+    ap.add_argument("--warmup", type=int, default=330)
+    ap.add_argument("--envs-per-gpu", type=int, default=4096)
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the E-sweep (extra 'sweep' field)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as graft
+    import cm3_amd
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if rank == 0:
+        graft.build()
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    # everything (launches, graph replays, HIP events) goes on one explicit non-default stream
+    bench_stream = torch.cuda.Stream(device=device)
+    torch.cuda.set_stream(bench_stream)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+        dist.barrier(device_ids=[local_rank])
+    if rank != 0:
+        graft.build()
+
+    cfg = cm3_amd.load_config("particle_stage2_antipodal")
+    N = cfg["n_agents"]
+    E = args.envs_per_gpu
+    K, W = args.steps, args.warmup
+    stepper = ParticleStepper(cfg, N, E, device, env_id_base=rank * E)
+    if not args.no_graph:
+        stepper.capture(GRAPH_TICKS)
+    stepper.run(max(W, 1))
+    torch.cuda.synchronize(device)
+
+    def barrier():
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+
+    barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    ev_ms = timed_ticks(stepper, K)
+    torch.cuda.synchronize(device)
+    wall = time.perf_counter() - t0
+    barrier()
+    t = torch.tensor([wall, ev_ms * 1e-3], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall_max, ev_max = float(t[0]), float(t[1])
+
+    total_env_steps = float(E) * K * world
+    value = total_env_steps / wall_max
+    launch_s = ev_max / K
+    bytes_per_launch = algorithmic_bytes_per_env_step(N) * E
+    achieved = bytes_per_launch / launch_s / 1e9
+
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "env-steps/s (all agents, whole node)", "value": value, "unit": "env-steps/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": wall_max / K * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (uniform random actions drawn in-kernel, Philox; preset/random resets, prob_random=0.2)",
+            "config": {"workload": "config_particle_stage2_antipodal.json: 4 agents, %d vectorised envs per GPU, "
+                                   "max_steps=33, auto-reset, one step-kernel launch per tick" % E,
+                       "envs_per_gpu": E, "n_agents": N, "global_envs": E * world,
+                       "launch": "eager" if args.no_graph else "hipGraph of %d ticks" % GRAPH_TICKS,
+                       "parallelism": "env-sharded x%d, no data-path collective" % world},
+            "agent_steps_per_s": value * N,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": "k_particle_step<float,4>", "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "avg_launch_us": launch_s * 1e6},
+        }
+    if world == 1 and rank == 0:
+        bw = measure_read_bandwidth(device)
+        out["roofline"]["measured_read_GBps"] = bw
+        out["roofline"]["frac_of_measured_read"] = achieved / bw
+        if not args.no_sweep:
+            sweep = []
+            stepper.close()
+            del stepper
+            for log2e in (14, 16, 18, 20, 22):
+                Es = 1 << log2e
+                st = ParticleStepper(cfg, N, Es, device)
+                st.capture(GRAPH_TICKS)
+                st.run(GRAPH_TICKS)
+                torch.cuda.synchronize(device)
+                n = GRAPH_TICKS * (10 if log2e <= 18 else 3)
+                ms = timed_ticks(st, n)
+                per = ms * 1e-3 / n
+                gbps = algorithmic_bytes_per_env_step(N) * Es / per / 1e9
+                sweep.append({"envs": Es, "env_steps_per_s": Es / per, "avg_launch_us": per * 1e6,
+                              "achieved_GBps": gbps, "frac_of_peak": gbps / HBM_PEAK_GBPS,
+                              "frac_of_measured_read": gbps / bw})
+                st.close()
+                del st
+                torch.cuda.empty_cache()
+            out["sweep"] = sweep
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, N)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier(device_ids=[local_rank])
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

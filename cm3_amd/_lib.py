@@ -1,0 +1,171 @@
+"""ctypes binding of libcm3_hip.so (the C ABI declared in include/cm3_amd.h).
+
+The reference names a "thin C-ABI/cffi layer"; cffi is not installed in this image, so the
+stdlib ``ctypes`` is used.  There is NO CPU fallback: if the HIP library is missing or fails to
+load, importing anything that computes raises ``Cm3Error`` loudly.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcm3_hip.so")
+MAX_AGENTS = 8
+ABI_VERSION = 1
+
+FLAG_AUTO_RESET = 1
+FLAG_GEN_ACTIONS = 2
+
+
+class Cm3Error(RuntimeError):
+    pass
+
+
+c_void_p, c_int32, c_int64, c_uint32, c_uint64 = (ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64,
+                                                    ctypes.c_uint32, ctypes.c_uint64)
+c_double, c_size_t = ctypes.c_double, ctypes.c_size_t
+
+
+class ParticleDesc(ctypes.Structure):
+    _fields_ = [("n_envs", c_int32), ("n_agents", c_int32), ("max_steps", c_int32), ("flags", c_uint32),
+                ("env_id_base", c_int64), ("seed", c_uint64), ("prob_random", c_double),
+                ("initial_std", c_double),
+                ("agents_x", c_double * MAX_AGENTS), ("agents_y", c_double * MAX_AGENTS),
+                ("landmarks_x", c_double * MAX_AGENTS), ("landmarks_y", c_double * MAX_AGENTS)]
+
+
+class ParticleBufs(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in (
+        "state_in", "state_out", "goals_in", "goals_out", "meta_in", "meta_out", "episode", "actions",
+        "obs_others", "reward_n", "reward", "done", "term_state", "term_obs_others")]
+
+
+class ParticleTraj(ctypes.Structure):
+    _fields_ = [("state", c_void_p), ("state_stride", c_size_t),
+                ("goals", c_void_p), ("goals_stride", c_size_t),
+                ("obs_others", c_void_p), ("obs_others_stride", c_size_t),
+                ("actions", c_void_p), ("actions_stride", c_size_t),
+                ("reward_n", c_void_p), ("reward_n_stride", c_size_t),
+                ("reward", c_void_p), ("reward_stride", c_size_t),
+                ("done", c_void_p), ("done_stride", c_size_t),
+                ("meta", c_void_p), ("episode", c_void_p),
+                ("term_state", c_void_p), ("term_state_stride", c_size_t),
+                ("term_obs_others", c_void_p), ("term_obs_others_stride", c_size_t)]
+
+
+class CheckersDesc(ctypes.Structure):
+    _fields_ = [("n_envs", c_int32), ("n_agents", c_int32), ("n_rows", c_int32), ("n_columns", c_int32),
+                ("n_obs", c_int32), ("max_steps", c_int32), ("flags", c_uint32), ("_pad", c_int32),
+                ("env_id_base", c_int64), ("seed", c_uint64),
+                ("agents_r", c_int32 * MAX_AGENTS), ("agents_c", c_int32 * MAX_AGENTS)]
+
+
+class CheckersBufs(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in (
+        "mask", "agents", "steps", "episode", "goals", "actions", "grid", "vec", "obs_others",
+        "obs_self_t", "obs_self_v", "local_rewards", "reward", "done")]
+
+
+# every symbol include/cm3_amd.h declares: name -> (restype, argtypes)
+P = ctypes.POINTER
+SYMBOLS = {
+    "cm3_abi_version": (ctypes.c_int, []),
+    "cm3_last_error": (ctypes.c_char_p, []),
+    "cm3_device_count": (ctypes.c_int, []),
+    "cm3_device_name": (ctypes.c_int, [ctypes.c_int, ctypes.c_char_p, ctypes.c_int]),
+    "cm3_particle_step_f32": (ctypes.c_int, [P(ParticleDesc), P(ParticleBufs), c_void_p]),
+    "cm3_particle_step_f64": (ctypes.c_int, [P(ParticleDesc), P(ParticleBufs), c_void_p]),
+    "cm3_particle_reset_f32": (ctypes.c_int, [P(ParticleDesc), P(ParticleBufs), c_void_p, c_void_p]),
+    "cm3_particle_reset_f64": (ctypes.c_int, [P(ParticleDesc), P(ParticleBufs), c_void_p, c_void_p]),
+    "cm3_particle_observe_f32": (ctypes.c_int, [P(ParticleDesc), P(ParticleBufs), c_void_p]),
+    "cm3_particle_observe_f64": (ctypes.c_int, [P(ParticleDesc), P(ParticleBufs), c_void_p]),
+    "cm3_particle_rollout_f32": (ctypes.c_int, [P(ParticleDesc), P(ParticleTraj), c_int32, c_void_p]),
+    "cm3_particle_rollout_f64": (ctypes.c_int, [P(ParticleDesc), P(ParticleTraj), c_int32, c_void_p]),
+    "cm3_checkers_step": (ctypes.c_int, [P(CheckersDesc), P(CheckersBufs), c_void_p]),
+    "cm3_checkers_reset": (ctypes.c_int, [P(CheckersDesc), P(CheckersBufs), c_void_p, c_void_p]),
+    "cm3_hbm_read_bench": (ctypes.c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
+    "cm3_hbm_bench_sink_words": (ctypes.c_int, []),
+    "cm3_graph_begin": (ctypes.c_int, [c_void_p]),
+    "cm3_graph_end": (ctypes.c_int, [c_void_p, P(c_void_p)]),
+    "cm3_graph_launch": (ctypes.c_int, [c_void_p, c_void_p]),
+    "cm3_graph_destroy": (ctypes.c_int, [c_void_p]),
+    "cm3_event_create": (ctypes.c_int, [P(c_void_p)]),
+    "cm3_event_record": (ctypes.c_int, [c_void_p, c_void_p]),
+    "cm3_event_synchronize": (ctypes.c_int, [c_void_p]),
+    "cm3_event_elapsed_ms": (ctypes.c_int, [c_void_p, c_void_p, P(ctypes.c_float)]),
+    "cm3_event_destroy": (ctypes.c_int, [c_void_p]),
+    "cm3_stream_synchronize": (ctypes.c_int, [c_void_p]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library (loads on first use).  Raises Cm3Error if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    # PyTorch bundles its own libamdhip64.so.7; load it FIRST so that this library binds to the same HIP
+    # runtime that owns the tensors' memory and streams (two runtimes in one process see no device).
+    import torch  # noqa: F401
+    if not os.path.exists(LIB_PATH):
+        raise Cm3Error("HIP extension not built: %s is missing.  Run `python -c 'import __graft_entry__ as g; "
+                       "g.build()'` (or cm3_amd/csrc/build.sh).  There is no CPU fallback." % LIB_PATH)
+    try:
+        handle = ctypes.CDLL(LIB_PATH)
+    except OSError as exc:
+        raise Cm3Error("failed to load %s: %s" % (LIB_PATH, exc))
+    for name, (res, args) in SYMBOLS.items():
+        try:
+            fn = getattr(handle, name)
+        except AttributeError:
+            raise Cm3Error("libcm3_hip.so does not export %s (stale build?)" % name)
+        fn.restype = res
+        fn.argtypes = args
+    if handle.cm3_abi_version() != ABI_VERSION:
+        raise Cm3Error("ABI version mismatch: library %d, binding %d" % (handle.cm3_abi_version(), ABI_VERSION))
+    _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().cm3_last_error()
+        raise Cm3Error("libcm3_hip error %d: %s" % (rc, msg.decode("utf-8", "replace") if msg else "?"))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (0 for None)."""
+    return 0 if t is None else t.data_ptr()
+
+
+def current_stream_handle(device):
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def capture_graph(device, enqueue):
+    """Captures whatever ``enqueue(stream_handle)`` launches into a hipGraph and returns the executable
+    graph handle.  Capture happens on a private side stream (the legacy default stream cannot be captured);
+    the graph can then be launched on any stream with cm3_graph_launch."""
+    import torch
+    side = torch.cuda.Stream(device=device)
+    handle = ctypes.c_void_p()
+    check(lib().cm3_graph_begin(side.cuda_stream))
+    try:
+        enqueue(side.cuda_stream)
+    finally:
+        rc = lib().cm3_graph_end(side.cuda_stream, ctypes.byref(handle))
+    check(rc)
+    return handle
+
+
+def require_gpu(device):
+    """Fail loudly when asked to compute without a GPU: there is no CPU path in the product."""
+    import torch
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise Cm3Error("cm3_amd computes only on an AMD GPU (device=%r given); there is no CPU fallback" % (device,))
+    if not torch.cuda.is_available():
+        raise Cm3Error("no HIP device visible to PyTorch; cm3_amd has no CPU fallback")
+    lib()
+    return dev

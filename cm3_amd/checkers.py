@@ -1,0 +1,176 @@
+"""VecCheckersEnv -- E copies of the reference's Checkers grid world, one HIP launch per tick.
+
+    reference (per env, env/checkers.py)                          here (E envs)
+    ---------------------------------------------------------     --------------------------------------
+    Checkers(n_rows, n_columns, n_obs, agents_r, agents_c,        VecCheckersEnv(init, n_agents, max_steps,
+             n_agents, max_steps)                 (:5-35)            n_envs, ...)   init = config "init" block
+    reset(goals) -> ((grid, vec), obs_others, obs_self_t,         same tuple, leading E dim
+             obs_self_v, False)                   (:265-291)
+    step(actions) -> ((grid, vec), obs_others, obs_self_t,        same tuple, batched
+             obs_self_v, total, local_rewards, done) (:228-262)
+
+Value parity is exact.  Integer-valued arrays come back as integer tensors (grid / obs_self_t int8,
+vec int32); ``.double()`` gives the reference's float64 arrays bit for bit.  The live state on the
+device is compact (64-bit collected mask + one packed word per agent), see csrc/checkers.hip.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import FLAG_AUTO_RESET, FLAG_GEN_ACTIONS, Cm3Error
+
+
+class VecCheckersEnv(object):
+    def __init__(self, init, n_agents, max_steps, n_envs, device="cuda:0", seed=12341, auto_reset=False,
+                 env_id_base=0):
+        self.device = _lib.require_gpu(device)
+        self.n = self.n_agents = int(n_agents)
+        self.E = self.n_envs = int(n_envs)
+        self.max_steps = int(max_steps)
+        self.R, self.C, self.O = int(init["n_rows"]), int(init["n_columns"]), int(init["n_obs"])
+        if self.R % 2 != 1 or self.C % 2 != 0:          # checkers.py:16-17
+            raise Cm3Error("n_rows must be odd and n_columns even")
+        if len(init["agents_r"]) < self.n or len(init["agents_c"]) < self.n:
+            raise Cm3Error("init lists shorter than n_agents")
+        self.K = 2 * self.O + 1
+        self.Lo = 2 * max(self.n - 1, 1)
+        self.auto_reset = bool(auto_reset)
+        E, N, dev = self.E, self.n, self.device
+        z = lambda *shape, dt: torch.zeros(*shape, dtype=dt, device=dev)  # noqa: E731
+        self._mask = z(E, dt=torch.int64)             # uint64 bit pattern
+        self._agents = z(N, E, dt=torch.int32)        # packed r | c<<8 | green<<16 | orange<<24
+        self._steps = z(E, dt=torch.int32)
+        self._episode = z(E, dt=torch.int32)
+        self._goals = z(E, N, dt=torch.uint8)
+        self._slots = []
+        for _ in range(2):                             # double-buffered outputs
+            self._slots.append(dict(
+                actions=z(E, N, dt=torch.int32),
+                grid=z(E, self.R, self.C + 1, 2, dt=torch.int8),
+                vec=z(E, N, 4, dt=torch.int32),
+                obs_others=z(E, N, self.Lo, dt=torch.float64),
+                obs_self_t=z(E, N, self.K, self.K, 3, dt=torch.int8),
+                obs_self_v=z(E, N, 4, dt=torch.float64),
+                local_rewards=z(E, N, dt=torch.float64),
+                reward=z(E, dt=torch.float64),
+                done=z(E, dt=torch.uint8)))
+        self._cur = 0
+        d = self._desc = _lib.CheckersDesc()
+        d.n_envs, d.n_agents, d.n_rows, d.n_columns, d.n_obs = E, N, self.R, self.C, self.O
+        d.max_steps = self.max_steps
+        d.flags = 0
+        d.env_id_base = int(env_id_base)
+        d.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        for i in range(_lib.MAX_AGENTS):
+            d.agents_r[i] = int(init["agents_r"][i]) if i < N else 0
+            d.agents_c[i] = int(init["agents_c"][i]) if i < N else 0
+        self._lib = _lib.lib()
+
+    def _bufs(self, slot):
+        s = self._slots[slot]
+        b = _lib.CheckersBufs()
+        b.mask = self._mask.data_ptr()
+        b.agents = self._agents.data_ptr()
+        b.steps = self._steps.data_ptr()
+        b.episode = self._episode.data_ptr()
+        b.goals = self._goals.data_ptr()
+        for k in ("actions", "grid", "vec", "obs_others", "obs_self_t", "obs_self_v", "local_rewards",
+                  "reward", "done"):
+            setattr(b, k, s[k].data_ptr())
+        return b
+
+    def _stream(self):
+        return _lib.current_stream_handle(self.device)
+
+    def _obs_tuple(self, slot):
+        s = self._slots[slot]
+        return (s["grid"], s["vec"]), s["obs_others"], s["obs_self_t"], s["obs_self_v"]
+
+    # ---- reference surface --------------------------------------------------------------------------
+    def reset(self, goals=None, mask=None, goal_index=None):
+        """checkers.py:265-291.  ``goals``: one-hot [N,2] (np.eye(n_agents), train_onpolicy.py:293) or
+        [E,N,2]; alternatively ``goal_index`` int [E,N] (0 green, 1 orange)."""
+        if goal_index is not None:
+            g = torch.as_tensor(goal_index, device=self.device)
+        else:
+            if goals is None:
+                raise Cm3Error("reset needs goals (one-hot) or goal_index")
+            g = torch.as_tensor(goals, device=self.device)
+            if g.dim() == 2:
+                if tuple(g.shape) != (self.n, 2):
+                    raise Cm3Error("one-hot goals must be [N,2] or [E,N,2]")
+                g = g.unsqueeze(0).expand(self.E, self.n, 2)
+            g = g.argmax(dim=2)
+        if tuple(g.shape) != (self.E, self.n):
+            raise Cm3Error("goals must be [N,2] / [E,N,2] one-hot, or goal_index [E,N]")
+        if mask is None:
+            self._goals.copy_(g.to(torch.uint8))
+            m = None
+        else:
+            m = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
+            self._goals.copy_(torch.where(m.bool().unsqueeze(1), g.to(torch.uint8), self._goals))
+        self._desc.flags = 0
+        b = self._bufs(self._cur)
+        _lib.check(self._lib.cm3_checkers_reset(ctypes.byref(self._desc), ctypes.byref(b), _lib.ptr(m),
+                                                self._stream()))
+        gs, oo, ot, ov = self._obs_tuple(self._cur)
+        return gs, oo, ot, ov, torch.zeros(self.E, dtype=torch.bool, device=self.device)
+
+    def step(self, actions=None):
+        """checkers.py:228-262.  ``actions`` int [E,N]; None draws uniform actions in-kernel."""
+        dst = self._cur ^ 1
+        flags = FLAG_AUTO_RESET if self.auto_reset else 0
+        if actions is None:
+            flags |= FLAG_GEN_ACTIONS
+        else:
+            a = torch.as_tensor(actions, device=self.device)
+            if tuple(a.shape) != (self.E, self.n):
+                raise Cm3Error("actions must have shape [n_envs, n_agents]")
+            self._slots[dst]["actions"].copy_(a)
+        self._desc.flags = flags
+        b = self._bufs(dst)
+        _lib.check(self._lib.cm3_checkers_step(ctypes.byref(self._desc), ctypes.byref(b), self._stream()))
+        self._cur = dst
+        s = self._slots[dst]
+        gs, oo, ot, ov = self._obs_tuple(dst)
+        return gs, oo, ot, ov, s["reward"], s["local_rewards"], s["done"].view(torch.bool)
+
+    def get_obs(self):
+        return self._obs_tuple(self._cur)
+
+    # ---- state access ---------------------------------------------------------------------------------
+    @property
+    def goals(self):
+        """[E,N,2] one-hot goals (train_onpolicy.py:293)."""
+        return torch.nn.functional.one_hot(self._goals.long(), 2)
+
+    @property
+    def steps(self):
+        return self._steps
+
+    @property
+    def last_actions(self):
+        return self._slots[self._cur]["actions"]
+
+    def get_state(self):
+        a = self._agents
+        return dict(mask=self._mask.clone(), r=(a & 0xff).t().clone(), c=((a >> 8) & 0xff).t().clone(),
+                    n_green=((a >> 16) & 0xff).t().clone(), n_orange=((a >> 24) & 0xff).t().clone(),
+                    steps=self._steps.clone(), goals=self._goals.clone())
+
+    def set_state(self, mask, r, c, n_green, n_orange, steps, goals=None):
+        """Inject a compact state ([E] mask as int64 bit pattern; [E,N] integer arrays) and refresh obs."""
+        dev = self.device
+        self._mask.copy_(torch.as_tensor(mask, device=dev).to(torch.int64))
+        tt = lambda x: torch.as_tensor(x, device=dev).to(torch.int32).t()  # noqa: E731
+        self._agents.copy_(tt(r) | (tt(c) << 8) | (tt(n_green) << 16) | (tt(n_orange) << 24))
+        self._steps.copy_(torch.as_tensor(steps, device=dev).to(torch.int32))
+        if goals is not None:
+            self._goals.copy_(torch.as_tensor(goals, device=dev).to(torch.uint8))
+        none = torch.zeros(self.E, dtype=torch.uint8, device=dev)
+        self._desc.flags = 0
+        b = self._bufs(self._cur)
+        _lib.check(self._lib.cm3_checkers_reset(ctypes.byref(self._desc), ctypes.byref(b), none.data_ptr(),
+                                                self._stream()))
+        return self._obs_tuple(self._cur)

@@ -1,0 +1,16 @@
+#!/bin/bash
+# Builds libcm3_hip.so for gfx950 in-tree (cross-compiles without a GPU).
+set -euo pipefail
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+OUT="${HERE}/../libcm3_hip.so"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function"
+mkdir -p "${HERE}/_obj"
+pids=()
+for f in particle checkers util; do
+  "${HIPCC}" ${FLAGS} -c "${HERE}/${f}.hip" -o "${HERE}/_obj/${f}.o" &
+  pids+=($!)
+done
+for p in "${pids[@]}"; do wait "$p"; done
+"${HIPCC}" --offload-arch=gfx950 -shared -fPIC -o "${OUT}" "${HERE}/_obj/particle.o" "${HERE}/_obj/checkers.o" "${HERE}/_obj/util.o"
+echo "built ${OUT}"

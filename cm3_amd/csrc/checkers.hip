@@ -1,0 +1,446 @@
+// Checkers env (reference: /root/reference/env/checkers.py) for E environments per launch, gfx950.
+//
+// Live state per env is compact -- a 64-bit "collected" mask over the n_rows x n_columns reward cells,
+// one packed word per agent (r, c, #green, #orange) and a step counter -- instead of the reference's
+// dense float64 world[total_rows][total_columns][3] (checkers.py:267).  Everything the reference reads
+// from the dense world is a pure function of that state:
+//   channel 0/1 (green/orange): cell (k, j) of the reward band is green iff (k + j) is even
+//                               (populate_world :54-63); value -1 uncollected, +1 collected (:204-222)
+//   channel 2 (invalid):        +1 on the static wall pattern (:43-46), -1 where an agent stands
+//                               (:49-51, :168-183), 0 elsewhere.
+// (Agents can never share a cell: agent_act refuses occupied targets; distinct start cells are enforced
+// on the host.)
+//
+// Mapping: one lane per env; agents act SEQUENTIALLY in index order inside the lane, because agent i+1
+// must see agent i's move and pick-up (checkers.py:233-237).  Integer-valued outputs are written as
+// integers (int8 / int32), the normalised ones with the reference's own float64 expressions, so every
+// output is value-identical to the reference (bit-exact parity).  The two byte-granular env-major
+// outputs (grid, obs_self_t) are assembled in a wave-private LDS tile and written out as contiguous
+// 16-byte vectors.
+#include "common.h"
+#include "philox.h"
+
+namespace cm3 {
+
+struct CheckersParams {
+  int E, R, C, O, TR, TC, K, max_steps;
+  uint32_t flags;
+  int max_collectible;
+  int64_t env_id_base;
+  uint64_t seed;
+  uint64_t green_mask, orange_mask;
+  int start_r[CM3_MAX_AGENTS], start_c[CM3_MAX_AGENTS];  // expanded coordinates
+  uint64_t *mask;
+  uint32_t *agents;
+  int32_t *steps;
+  int32_t *episode;
+  uint8_t *goals;
+  int32_t *actions;
+  int8_t *grid;
+  int32_t *vec;
+  double *obs_others;
+  int8_t *obs_self_t;
+  double *obs_self_v;
+  double *local_rewards;
+  double *reward;
+  uint8_t *done;
+  const uint8_t *reset_mask;
+  int grid_rec, obst_rec;  // bytes per env of grid / obs_self_t
+};
+
+constexpr int kCkLdsBytes = 40960;  // per-wave staging tile (64 rows x up to 640 bytes)
+
+__device__ __forceinline__ bool ck_wall(const CheckersParams &p, int r, int c) {
+  return c < p.O || r < p.O || r >= p.O + p.R || c >= p.O + p.C + 1;
+}
+
+template <int N> struct CkState {
+  uint64_t mask;
+  int r[N], c[N], ng[N], no[N];
+};
+
+template <int N> __device__ __forceinline__ int ck_ch2(const CheckersParams &p, const CkState<N> &s, int r, int c) {
+  if (ck_wall(p, r, c)) return 1;
+#pragma unroll
+  for (int j = 0; j < N; ++j)
+    if (s.r[j] == r && s.c[j] == c) return -1;
+  return 0;
+}
+
+// value of channels 0 and 1 at expanded cell (r, c)
+template <int N>
+__device__ __forceinline__ void ck_ch01(const CheckersParams &p, const CkState<N> &s, int r, int c, int &g, int &o) {
+  const int k = r - p.O, j = c - p.O;
+  g = 0;
+  o = 0;
+  if (k >= 0 && k < p.R && j >= 0 && j < p.C) {
+    const int v = ((s.mask >> (k * p.C + j)) & 1ull) ? 1 : -1;
+    if (((k + j) & 1) == 0) g = v; else o = v;
+  }
+}
+
+__device__ __forceinline__ void ck_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// contiguous copy of the wave's `nbytes` staged bytes to global memory (dst 16-byte aligned)
+__device__ __forceinline__ void ck_copy_out(const int8_t *lds, int8_t *dst, int nbytes, int lane) {
+  const int nvec = nbytes >> 4;
+  const uint4 *src4 = reinterpret_cast<const uint4 *>(lds);
+  uint4 *dst4 = reinterpret_cast<uint4 *>(dst);
+  for (int f = lane; f < nvec; f += 64) dst4[f] = src4[f];
+  for (int b = (nvec << 4) + lane; b < nbytes; b += 64) dst[b] = lds[b];
+}
+
+template <int N>
+__device__ __forceinline__ void ck_emit(const CheckersParams &p, const CkState<N> &s, int8_t *lds, int lane, size_t e0,
+                                        size_t e, bool active) {
+  constexpr int NO = N > 1 ? N - 1 : 1;
+  long rows_here = (long)p.E - (long)e0;
+  rows_here = rows_here < 0 ? 0 : (rows_here > 64 ? 64 : rows_here);
+
+  // ---- grid [R][C+1][2] int8 (get_valid_grid :66-76) -------------------------------------------------
+  {
+    int8_t *row = lds + lane * p.grid_rec;
+    for (int k = 0; k < p.R; ++k)
+      for (int j = 0; j <= p.C; ++j) {
+        int g, o;
+        ck_ch01<N>(p, s, k + p.O, j + p.O, g, o);
+        const int off = (k * (p.C + 1) + j) * 2;
+        *reinterpret_cast<int16_t *>(row + off) = (int16_t)((g & 0xff) | ((o & 0xff) << 8));
+      }
+    ck_wave_sync();
+    ck_copy_out(lds, p.grid + e0 * (size_t)p.grid_rec, (int)rows_here * p.grid_rec, lane);
+    ck_wave_sync();
+  }
+  // ---- obs_self_t [N][K][K][3] int8 (get_obs :97-109) ------------------------------------------------
+  {
+    int8_t *row = lds + lane * p.obst_rec;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      for (int dr = 0; dr < p.K; ++dr)
+        for (int dc = 0; dc < p.K; ++dc) {
+          const int rr = s.r[i] - p.O + dr, cc = s.c[i] - p.O + dc;
+          int g, o;
+          ck_ch01<N>(p, s, rr, cc, g, o);
+          int inv = ck_ch2<N>(p, s, rr, cc);
+          if (dr == p.O && dc == p.O) inv = 0;  // the agent's own cell is valid (:105-107)
+          int8_t *q = row + ((i * p.K + dr) * p.K + dc) * 3;
+          q[0] = (int8_t)g;
+          q[1] = (int8_t)o;
+          q[2] = (int8_t)inv;
+        }
+    ck_wave_sync();
+    ck_copy_out(lds, p.obs_self_t + e0 * (size_t)p.obst_rec, (int)rows_here * p.obst_rec, lane);
+    ck_wave_sync();
+  }
+  if (!active) return;
+  // ---- vec (:79-94), obs_self_v / obs_others (normalize :112-125, :128-154) ----------------------------
+  double nr[N], nc[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    nr[i] = ((double)s.r[i] - (double)p.TR / 2.0) / (double)p.TR;
+    nc[i] = ((double)s.c[i] - (double)p.TC / 2.0) / (double)p.TC;
+  }
+  const double half = (double)p.max_collectible / 2.0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    int4 v;
+    v.x = s.r[i];
+    v.y = s.c[i];
+    v.z = s.ng[i];
+    v.w = s.no[i];
+    reinterpret_cast<int4 *>(p.vec)[e * N + i] = v;
+    double4 sv;
+    sv.x = nr[i];
+    sv.y = nc[i];
+    sv.z = (double)s.ng[i] / half;
+    sv.w = (double)s.no[i] / half;
+    reinterpret_cast<double4 *>(p.obs_self_v)[e * N + i] = sv;
+    double2 *oo = reinterpret_cast<double2 *>(p.obs_others) + (e * N + i) * NO;
+#pragma unroll
+    for (int k = 0; k < NO; ++k) {
+      const int j = (N > 1) ? (k < i ? k : k + 1) : 0;
+      double2 t;
+      t.x = nr[j];
+      t.y = nc[j];
+      oo[k] = t;
+    }
+  }
+}
+
+template <int N> __device__ __forceinline__ void ck_load(const CheckersParams &p, size_t ec, CkState<N> &s) {
+  s.mask = p.mask[ec];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const uint32_t w = p.agents[(size_t)i * p.E + ec];
+    s.r[i] = (int)(w & 0xff);
+    s.c[i] = (int)((w >> 8) & 0xff);
+    s.ng[i] = (int)((w >> 16) & 0xff);
+    s.no[i] = (int)((w >> 24) & 0xff);
+  }
+}
+
+template <int N> __device__ __forceinline__ void ck_store(const CheckersParams &p, size_t e, const CkState<N> &s) {
+  p.mask[e] = s.mask;
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    p.agents[(size_t)i * p.E + e] =
+        (uint32_t)s.r[i] | ((uint32_t)s.c[i] << 8) | ((uint32_t)s.ng[i] << 16) | ((uint32_t)s.no[i] << 24);
+}
+
+// reset (:265-291): empty mask, agents on their start cells; N == 1 starts on row 0 or 2 by goal (:271-276)
+template <int N> __device__ __forceinline__ void ck_init(const CheckersParams &p, const uint8_t (&goal)[N], CkState<N> &s) {
+  s.mask = 0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    s.r[i] = p.start_r[i];
+    s.c[i] = p.start_c[i];
+    s.ng[i] = 0;
+    s.no[i] = 0;
+  }
+  if (N == 1) s.r[0] = (goal[0] == 0 ? 0 : 2) + p.O;
+}
+
+template <int N> __global__ void __launch_bounds__(64) k_checkers_step(const CheckersParams p) {
+  __shared__ __attribute__((aligned(16))) int8_t lds[kCkLdsBytes];
+  const int lane = threadIdx.x;
+  const size_t e0 = (size_t)blockIdx.x * 64;
+  const size_t e = e0 + lane;
+  const bool active = e < (size_t)p.E;
+  const size_t ec = active ? e : (size_t)p.E - 1;
+
+  CkState<N> s;
+  ck_load<N>(p, ec, s);
+  int steps = p.steps[ec];
+  uint8_t goal[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) goal[i] = p.goals[ec * N + i];
+  int act[N];
+  uint32_t episode = 0;
+  const uint64_t genv = (uint64_t)(p.env_id_base + (int64_t)ec);
+  if (p.flags & (CM3_FLAG_GEN_ACTIONS | CM3_FLAG_AUTO_RESET)) episode = (uint32_t)p.episode[ec];
+  if (p.flags & CM3_FLAG_GEN_ACTIONS) {
+    uint32_t words[4 * ((N + 3) / 4)];
+#pragma unroll
+    for (int c = 0; c < (N + 3) / 4; ++c) {
+      const u32x4 w = action_words(p.seed, genv, episode, (uint32_t)steps, (uint32_t)c);
+      words[4 * c + 0] = w.x;
+      words[4 * c + 1] = w.y;
+      words[4 * c + 2] = w.z;
+      words[4 * c + 3] = w.w;
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      act[i] = rand5(words[i]);
+      if (active) p.actions[e * N + i] = act[i];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < N; ++i) act[i] = p.actions[ec * N + i];
+  }
+
+  // ---- agents act in index order (step :233-237) ---------------------------------------------------------
+  double local[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const int a = act[i];
+    double penalty = 0.0;
+    if (a != 0) {  // agent_act :157-187
+      bool moved = false;
+      if (a >= 1 && a <= 4) {
+        const int tr = s.r[i] + (a == 1 ? -1 : (a == 2 ? 1 : 0));
+        const int tc = s.c[i] + (a == 3 ? -1 : (a == 4 ? 1 : 0));
+        if (ck_ch2<N>(p, s, tr, tc) == 0) {
+          s.r[i] = tr;
+          s.c[i] = tc;
+          moved = true;
+        }
+      }
+      if (!moved) penalty = -0.1;
+    }
+    double rew = 0.0;  // get_reward :190-225
+    const int k = s.r[i] - p.O, j = s.c[i] - p.O;
+    if (k >= 0 && k < p.R && j >= 0 && j < p.C) {
+      const uint64_t bit = 1ull << (k * p.C + j);
+      if (!(s.mask & bit)) {
+        s.mask |= bit;
+        const int colour = (k + j) & 1;
+        if (colour == 0) s.ng[i] += 1; else s.no[i] += 1;
+        rew = (colour == (int)goal[i]) ? 1.0 : -0.5;
+      }
+    }
+    local[i] = penalty + rew;
+  }
+  double total = local[0];  // np.sum(local_rewards) :243 (left to right for n < 8)
+  if constexpr (N < 8) {
+#pragma unroll
+    for (int i = 1; i < N; ++i) total = total + local[i];
+  } else {
+    total = ((local[0] + local[1]) + (local[2] + local[3])) + ((local[4] + local[5]) + (local[6] + local[7]));
+  }
+  steps += 1;
+  bool done;  // :246-260
+  if (steps == p.max_steps) {
+    done = true;
+  } else if (N == 1) {
+    const uint64_t want = goal[0] == 0 ? p.green_mask : p.orange_mask;
+    done = (s.mask & want) == want;
+  } else {
+    done = __popcll(s.mask) == p.max_collectible;
+  }
+  if (active) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) p.local_rewards[e * N + i] = local[i];
+    p.reward[e] = total;
+    p.done[e] = done ? 1 : 0;
+  }
+  if ((p.flags & CM3_FLAG_AUTO_RESET) && done) {
+    episode += 1;
+    if (N == 1) {  // train_onpolicy.py:288-291: a fresh random goal per episode
+      goal[0] = (uint8_t)(reset_words(p.seed, genv, episode, 0).x & 1u);
+      if (active) p.goals[e] = goal[0];
+    }
+    ck_init<N>(p, goal, s);
+    steps = 0;
+    if (active) p.episode[e] = (int32_t)episode;
+  }
+  if (active) {
+    ck_store<N>(p, e, s);
+    p.steps[e] = steps;
+  }
+  ck_emit<N>(p, s, lds, lane, e0, e, active);
+}
+
+template <int N> __global__ void __launch_bounds__(64) k_checkers_reset(const CheckersParams p) {
+  __shared__ __attribute__((aligned(16))) int8_t lds[kCkLdsBytes];
+  const int lane = threadIdx.x;
+  const size_t e0 = (size_t)blockIdx.x * 64;
+  const size_t e = e0 + lane;
+  const bool active = e < (size_t)p.E;
+  const size_t ec = active ? e : (size_t)p.E - 1;
+  CkState<N> s;
+  const bool sel = p.reset_mask ? (p.reset_mask[ec] != 0) : true;
+  if (sel) {
+    uint8_t goal[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) goal[i] = p.goals[ec * N + i];
+    ck_init<N>(p, goal, s);
+    if (active) {
+      ck_store<N>(p, e, s);
+      p.steps[e] = 0;
+      if (p.episode) p.episode[e] = p.episode[e] + 1;
+    }
+  } else {
+    ck_load<N>(p, ec, s);
+  }
+  ck_emit<N>(p, s, lds, lane, e0, e, active);
+}
+
+static int ck_fill(const cm3_checkers_desc *d, const cm3_checkers_bufs *b, const uint8_t *mask, bool step,
+                   CheckersParams &p) {
+  CM3_REQUIRE(d && b, "null desc/bufs");
+  CM3_REQUIRE(d->n_envs > 0, "n_envs must be positive");
+  CM3_REQUIRE(d->n_agents >= 1 && d->n_agents <= CM3_MAX_AGENTS, "n_agents must be in 1..%d", CM3_MAX_AGENTS);
+  CM3_REQUIRE(d->n_rows >= 1 && d->n_rows % 2 == 1, "n_rows must be odd (checkers.py:16)");
+  CM3_REQUIRE(d->n_columns >= 2 && d->n_columns % 2 == 0, "n_columns must be even (checkers.py:17)");
+  CM3_REQUIRE(d->n_rows * d->n_columns <= 64, "n_rows*n_columns must be <= 64 (collected-mask width)");
+  CM3_REQUIRE(d->n_obs >= 0 && d->n_obs <= 8, "n_obs out of range");
+  CM3_REQUIRE(d->max_steps >= 1, "max_steps must be >= 1");
+  CM3_REQUIRE((d->flags & ~(CM3_FLAG_AUTO_RESET | CM3_FLAG_GEN_ACTIONS)) == 0, "unknown flag bits");
+  memset(&p, 0, sizeof(p));
+  p.E = d->n_envs;
+  p.R = d->n_rows;
+  p.C = d->n_columns;
+  p.O = d->n_obs;
+  p.TR = p.R + 2 * p.O;
+  p.TC = p.C + 2 * p.O + 1;
+  p.K = 2 * p.O + 1;
+  CM3_REQUIRE(p.TR <= 255 && p.TC <= 255, "grid too large for packed agent words");
+  p.max_steps = d->max_steps;
+  p.flags = d->flags;
+  p.max_collectible = p.R * p.C;
+  p.env_id_base = d->env_id_base;
+  p.seed = d->seed;
+  for (int k = 0; k < p.R; ++k)
+    for (int j = 0; j < p.C; ++j) {
+      const uint64_t bit = 1ull << (k * p.C + j);
+      if (((k + j) & 1) == 0) p.green_mask |= bit; else p.orange_mask |= bit;
+    }
+  for (int i = 0; i < d->n_agents; ++i) {
+    p.start_r[i] = d->agents_r[i] + p.O;
+    p.start_c[i] = d->agents_c[i] + p.O;
+    CM3_REQUIRE(p.start_r[i] >= p.O && p.start_r[i] < p.O + p.R && p.start_c[i] >= p.O && p.start_c[i] <= p.O + p.C,
+                "agent %d starts outside the playable band", i);
+    for (int j = 0; j < i; ++j)
+      CM3_REQUIRE(!(p.start_r[i] == p.start_r[j] && p.start_c[i] == p.start_c[j]),
+                  "agents %d and %d start on the same cell (unsupported: channel 2 is derived from agent cells)", j, i);
+  }
+  p.grid_rec = p.R * (p.C + 1) * 2;
+  p.obst_rec = d->n_agents * p.K * p.K * 3;
+  CM3_REQUIRE(64 * p.grid_rec <= kCkLdsBytes && 64 * p.obst_rec <= kCkLdsBytes,
+              "observation record too large for the staging tile");
+  CM3_REQUIRE(b->mask && b->agents && b->steps && b->goals, "state pointers (mask/agents/steps/goals) are required");
+  CM3_REQUIRE(b->grid && b->vec && b->obs_others && b->obs_self_t && b->obs_self_v, "observation outputs are required");
+  if (step) {
+    CM3_REQUIRE(b->actions && b->local_rewards && b->reward && b->done, "step outputs/actions are required");
+    if (d->flags) CM3_REQUIRE(b->episode, "episode counter is required with AUTO_RESET / GEN_ACTIONS");
+  }
+  p.mask = b->mask;
+  p.agents = b->agents;
+  p.steps = b->steps;
+  p.episode = b->episode;
+  p.goals = const_cast<uint8_t *>(b->goals);
+  p.actions = b->actions;
+  p.grid = b->grid;
+  p.vec = b->vec;
+  p.obs_others = b->obs_others;
+  p.obs_self_t = b->obs_self_t;
+  p.obs_self_v = b->obs_self_v;
+  p.local_rewards = b->local_rewards;
+  p.reward = b->reward;
+  p.done = b->done;
+  p.reset_mask = mask;
+  return CM3_OK;
+}
+
+template <int N> static int ck_launch(const CheckersParams &p, bool step, hipStream_t stream) {
+  const unsigned blocks = (unsigned)(((size_t)p.E + 63) / 64);
+  if (step)
+    hipLaunchKernelGGL((k_checkers_step<N>), dim3(blocks), dim3(64), 0, stream, p);
+  else
+    hipLaunchKernelGGL((k_checkers_reset<N>), dim3(blocks), dim3(64), 0, stream, p);
+  CM3_HIP_CHECK(hipGetLastError());
+  return CM3_OK;
+}
+
+static int ck_call(const cm3_checkers_desc *d, const cm3_checkers_bufs *b, const uint8_t *mask, bool step, void *stream) {
+  CheckersParams p;
+  int rc = ck_fill(d, b, mask, step, p);
+  if (rc != CM3_OK) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  switch (d->n_agents) {
+    case 1: return ck_launch<1>(p, step, s);
+    case 2: return ck_launch<2>(p, step, s);
+    case 3: return ck_launch<3>(p, step, s);
+    case 4: return ck_launch<4>(p, step, s);
+    case 5: return ck_launch<5>(p, step, s);
+    case 6: return ck_launch<6>(p, step, s);
+    case 7: return ck_launch<7>(p, step, s);
+    case 8: return ck_launch<8>(p, step, s);
+  }
+  return fail(CM3_ERR_INVALID, "n_agents %d unsupported", d->n_agents);
+}
+
+}  // namespace cm3
+
+extern "C" {
+int cm3_checkers_step(const cm3_checkers_desc *d, const cm3_checkers_bufs *b, void *stream) {
+  return cm3::ck_call(d, b, nullptr, true, stream);
+}
+int cm3_checkers_reset(const cm3_checkers_desc *d, const cm3_checkers_bufs *b, const uint8_t *mask, void *stream) {
+  return cm3::ck_call(d, b, mask, false, stream);
+}
+}

@@ -1,0 +1,42 @@
+// Shared host/device helpers for libcm3_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/cm3_amd.h"
+
+namespace cm3 {
+
+// ---- error plumbing ------------------------------------------------------------------------
+char *last_error_buf();  // thread-local, 512 bytes
+int fail(int code, const char *fmt, ...);
+
+#define CM3_HIP_CHECK(expr)                                                                  \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess)                                                                    \
+      return ::cm3::fail(CM3_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                         __FILE__, __LINE__);                                                \
+  } while (0)
+
+#define CM3_REQUIRE(cond, ...)                                \
+  do {                                                        \
+    if (!(cond)) return ::cm3::fail(CM3_ERR_INVALID, __VA_ARGS__); \
+  } while (0)
+
+// ---- vector types per real -------------------------------------------------------------------
+template <typename R> struct Vec;
+template <> struct Vec<float> {
+  using v2 = float2;
+  using v4 = float4;
+};
+template <> struct Vec<double> {
+  using v2 = double2;
+  using v4 = double4;
+};
+
+constexpr int kWave = 64;
+
+}  // namespace cm3

@@ -1,0 +1,630 @@
+// Particle env (MultiAgentEnv + multi-goal_spread) for E environments per launch, gfx950.
+//
+// Reference being replaced (paths relative to /root/reference/env/multiagent-particle-envs/multiagent):
+//   environment.py:81-123  step            environment.py:125-149 reset
+//   environment.py:177-225 _set_action     core.py:117-196 World.step and its pieces
+//   scenarios/multi-goal_spread.py:65-93 reset_world, :114-154 is_collision/reward/done/observation
+//
+// Mapping: ONE LANE PER ENVIRONMENT.  A lane keeps all N agents of its env in registers
+// (4 reals each), loops the C(N,2) pairs locally and never talks to another lane for the
+// dynamics, so every global load is one 16-byte vector per lane at unit stride over the env index
+// (state is [N][E][4]: 1 KiB per wave-instruction, fully coalesced).  The one env-major (AoS)
+// output that is wider than a vector per lane -- obs_others [E][N][L] -- is transposed through a
+// wave-private LDS tile so that the wave writes whole contiguous rows (16 B per lane, unit stride)
+// instead of 64 partial cache lines per store.  No MFMA: there is no contraction on this path.
+//
+// Arithmetic follows the reference's operation order exactly (compile with -ffp-contract=off):
+// the double instantiation differs from NumPy only in the last ulps of exp/log1p.
+#include "common.h"
+#include "philox.h"
+
+namespace cm3 {
+
+struct ParticleParams {
+  int E;
+  int max_steps;
+  uint32_t flags;
+  int _pad;
+  int64_t env_id_base;
+  uint64_t seed;
+  double prob_random, initial_std;
+  double ax[CM3_MAX_AGENTS], ay[CM3_MAX_AGENTS], lx[CM3_MAX_AGENTS], ly[CM3_MAX_AGENTS];
+  const void *state_in;
+  void *state_out;
+  const void *goals_in;
+  void *goals_out;
+  const int32_t *meta_in;
+  int32_t *meta_out;
+  int32_t *episode;
+  int32_t *actions;
+  void *obs_others;
+  void *reward_n;
+  void *reward;
+  uint8_t *done;
+  void *term_state;
+  void *term_obs_others;
+  const uint8_t *reset_mask;
+};
+
+// ---- scalar math per real ----------------------------------------------------------------------
+template <typename R> struct Math;
+template <> struct Math<float> {
+  static __device__ __forceinline__ float sqrt(float x) { return sqrtf(x); }
+  static __device__ __forceinline__ float exp(float x) { return expf(x); }
+  static __device__ __forceinline__ float log1p(float x) { return log1pf(x); }
+  static __device__ __forceinline__ float abs(float x) { return fabsf(x); }
+};
+template <> struct Math<double> {
+  static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
+  static __device__ __forceinline__ double exp(double x) { return ::exp(x); }
+  static __device__ __forceinline__ double log1p(double x) { return ::log1p(x); }
+  static __device__ __forceinline__ double abs(double x) { return fabs(x); }
+};
+
+// np.logaddexp(0, x) (core.py:192): NumPy's npy_logaddexp specialised to a zero first argument --
+// x == 0 -> ln 2; x < 0 -> 0 + log1p(exp(x)); x > 0 -> x + log1p(exp(-x)); NaN propagates.
+template <typename R> __device__ __forceinline__ R logaddexp0(R x) {
+  const R t = Math<R>::log1p(Math<R>::exp(-Math<R>::abs(x)));
+  R r = (x > R(0) ? x : R(0)) + t;
+  if (x == R(0)) r = R(0.693147180559945309417232121458176568);
+  return r;
+}
+
+template <typename R, typename V4> __device__ __forceinline__ V4 sub4(const V4 &a, const V4 &b) {
+  V4 r;
+  r.x = a.x - b.x;
+  r.y = a.y - b.y;
+  r.z = a.z - b.z;
+  r.w = a.w - b.w;
+  return r;
+}
+
+// np.sum(reward_n) as NumPy reduces a contiguous float64 vector (environment.py:107): left to right for
+// n < 8, eight interleaved accumulators folded as a fixed tree for n == 8 (oracle: np_list_sum).
+template <typename R, int N> __device__ __forceinline__ R sum_agents(const R (&v)[N]) {
+  if constexpr (N < 8) {
+    R acc = v[0];
+#pragma unroll
+    for (int i = 1; i < N; ++i) acc = acc + v[i];
+    return acc;
+  } else {
+    static_assert(N == 8, "CM3_MAX_AGENTS is 8");
+    return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+  }
+}
+
+// ---- small row loads / stores ([E][N] arrays, one row per lane) ---------------------------------
+template <typename T, int N> __device__ __forceinline__ void load_row(const T *base, size_t e, T (&v)[N]) {
+  const T *p = base + e * N;
+  constexpr int bytes = N * (int)sizeof(T);
+  if constexpr (bytes % 16 == 0) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    uint4 tmp[bytes / 16];
+#pragma unroll
+    for (int k = 0; k < bytes / 16; ++k) tmp[k] = q[k];
+    __builtin_memcpy(v, tmp, bytes);
+  } else if constexpr (bytes % 8 == 0) {
+    const uint2 *q = reinterpret_cast<const uint2 *>(p);
+    uint2 tmp[bytes / 8];
+#pragma unroll
+    for (int k = 0; k < bytes / 8; ++k) tmp[k] = q[k];
+    __builtin_memcpy(v, tmp, bytes);
+  } else {
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = p[k];
+  }
+}
+
+template <typename T, int N> __device__ __forceinline__ void store_row(T *base, size_t e, const T (&v)[N]) {
+  T *p = base + e * N;
+  constexpr int bytes = N * (int)sizeof(T);
+  if constexpr (bytes % 16 == 0) {
+    uint4 tmp[bytes / 16];
+    __builtin_memcpy(tmp, v, bytes);
+    uint4 *q = reinterpret_cast<uint4 *>(p);
+#pragma unroll
+    for (int k = 0; k < bytes / 16; ++k) q[k] = tmp[k];
+  } else if constexpr (bytes % 8 == 0) {
+    uint2 tmp[bytes / 8];
+    __builtin_memcpy(tmp, v, bytes);
+    uint2 *q = reinterpret_cast<uint2 *>(p);
+#pragma unroll
+    for (int k = 0; k < bytes / 8; ++k) q[k] = tmp[k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < N; ++k) p[k] = v[k];
+  }
+}
+
+// ---- obs_others geometry + LDS-staged store -------------------------------------------------------
+template <typename R, int N> struct ObsGeom {
+  static constexpr int NO = N > 1 ? N - 1 : 1;  // "others" per agent (N == 1 stores self, mgs.py:148-151)
+  static constexpr int REC = N * NO * 4;        // reals per env
+  static constexpr int STRIDE = REC + 4;        // +4 reals: spreads consecutive rows over LDS banks
+  static constexpr int kBudget = 16384;         // LDS bytes per wave
+  static constexpr int rows() {
+    int r = 64;
+    while (r > 1 && r * STRIDE * (int)sizeof(R) > kBudget) r >>= 1;
+    return r;
+  }
+  static constexpr int ROWS = rows();
+  static constexpr int LDS_REALS = ROWS * STRIDE;
+};
+
+__device__ __forceinline__ void wave_lds_sync() {
+  // LDS operations of one wave execute in issue order; this only stops the compiler from moving
+  // LDS accesses across the write -> read hand-off inside the wave.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// s[i] = (vx, vy, px, py) of agent i.  Row i of obs_others = concat_{j != i, ascending}(s[j] - s[i]).
+template <typename R, int N>
+__device__ __forceinline__ void store_obs_others_staged(const typename Vec<R>::v4 (&s)[N], R *lds, int lane,
+                                                        size_t e0, int E, R *out) {
+  using V4 = typename Vec<R>::v4;
+  using G = ObsGeom<R, N>;
+  constexpr int VPR = G::REC / 4;  // vectors per env record
+  V4 *lds4 = reinterpret_cast<V4 *>(lds);
+#pragma unroll 1
+  for (int pass = 0; pass < 64 / G::ROWS; ++pass) {
+    const int r = lane - pass * G::ROWS;
+    if (r >= 0 && r < G::ROWS) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+#pragma unroll
+        for (int k = 0; k < G::NO; ++k) {
+          const int j = (N > 1) ? (k < i ? k : k + 1) : 0;
+          lds4[(r * G::STRIDE) / 4 + i * G::NO + k] = sub4<R, V4>(s[j], s[i]);
+        }
+      }
+    }
+    wave_lds_sync();
+    const size_t row0 = e0 + (size_t)pass * G::ROWS;
+    long rows_here = (long)E - (long)row0;
+    rows_here = rows_here < 0 ? 0 : (rows_here > G::ROWS ? G::ROWS : rows_here);
+    const int nvec = (int)rows_here * VPR;
+    V4 *out4 = reinterpret_cast<V4 *>(out + row0 * G::REC);
+    for (int f = lane; f < nvec; f += 64) {
+      const int row = f / VPR, q = f - row * VPR;
+      out4[f] = lds4[(row * G::STRIDE) / 4 + q];
+    }
+    wave_lds_sync();
+  }
+}
+
+template <typename R, int N>
+__device__ __forceinline__ void store_obs_others_direct(const typename Vec<R>::v4 (&s)[N], size_t e, R *out) {
+  using V4 = typename Vec<R>::v4;
+  using G = ObsGeom<R, N>;
+  V4 *o = reinterpret_cast<V4 *>(out + e * G::REC);
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+#pragma unroll
+    for (int k = 0; k < G::NO; ++k) {
+      const int j = (N > 1) ? (k < i ? k : k + 1) : 0;
+      o[i * G::NO + k] = sub4<R, V4>(s[j], s[i]);
+    }
+}
+
+// ---- episode initialisation (multi-goal_spread.py:65-93), double arithmetic for both reals ---------
+template <typename R, int N>
+__device__ __forceinline__ void init_episode(const ParticleParams &p, uint64_t genv, uint32_t episode,
+                                             typename Vec<R>::v4 (&s)[N], typename Vec<R>::v2 (&g)[N]) {
+  const u32x4 w0 = reset_words(p.seed, genv, episode, 0);
+  const bool rnd = u01(w0.x) < p.prob_random;  // ONE draw per episode shared by agents and landmarks (:75)
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const u32x4 a = reset_words(p.seed, genv, episode, 1 + i);
+    double x, y;
+    if (rnd) {  // :77-78
+      x = 2.0 * u01(a.x) - 1.0;
+      y = 2.0 * u01(a.y) - 1.0;
+    } else {  // :80-83
+      x = p.ax[i];
+      y = p.ay[i];
+      if (p.initial_std != 0.0) {  // Box-Muller pair; std == 0 gives preset + 0 exactly as the reference
+        const double rad = ::sqrt(-2.0 * ::log(u01(a.z)));
+        const double ang = 6.283185307179586476925286766559 * u01(a.w);
+        x = x + p.initial_std * (rad * ::cos(ang));
+        y = y + p.initial_std * (rad * ::sin(ang));
+      }
+    }
+    s[i].x = R(0);
+    s[i].y = R(0);
+    s[i].z = R(x);
+    s[i].w = R(y);
+    if (rnd) {  // :88-89
+      const u32x4 l = reset_words(p.seed, genv, episode, 1 + N + i);
+      g[i].x = R(2.0 * u01(l.x) - 1.0);
+      g[i].y = R(2.0 * u01(l.y) - 1.0);
+    } else {  // :91
+      g[i].x = R(p.lx[i]);
+      g[i].y = R(p.ly[i]);
+    }
+  }
+}
+
+// ---- the step kernel --------------------------------------------------------------------------------
+template <typename R, int N, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) k_particle_step(const ParticleParams p) {
+  using V4 = typename Vec<R>::v4;
+  using V2 = typename Vec<R>::v2;
+  using G = ObsGeom<R, N>;
+  __shared__ __attribute__((aligned(32))) R lds_all[WAVES][G::LDS_REALS];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t e0 = ((size_t)blockIdx.x * WAVES + wave) * 64;
+  const size_t e = e0 + lane;
+  const bool active = e < (size_t)p.E;
+  const size_t ec = active ? e : (size_t)p.E - 1;  // clamped index for loads
+  const size_t E = (size_t)p.E;
+
+  // ---- loads: one vector per lane per array row, unit stride over e --------------------------------
+  V4 s[N];
+  V2 g[N];
+  const V4 *sin4 = reinterpret_cast<const V4 *>(p.state_in);
+  const V2 *gin2 = reinterpret_cast<const V2 *>(p.goals_in);
+#pragma unroll
+  for (int i = 0; i < N; ++i) s[i] = sin4[(size_t)i * E + ec];
+#pragma unroll
+  for (int i = 0; i < N; ++i) g[i] = gin2[(size_t)i * E + ec];
+  const int2 meta = reinterpret_cast<const int2 *>(p.meta_in)[ec];
+  int steps = meta.x, collisions = meta.y;
+
+  int act[N];
+  const bool gen = (p.flags & CM3_FLAG_GEN_ACTIONS) != 0;
+  uint32_t episode = 0;
+  if (gen || (p.flags & CM3_FLAG_AUTO_RESET)) episode = (uint32_t)p.episode[ec];
+  const uint64_t genv = (uint64_t)(p.env_id_base + (int64_t)ec);
+  if (gen) {  // train_onpolicy.py:305-307
+    uint32_t words[4 * ((N + 3) / 4)];
+#pragma unroll
+    for (int c = 0; c < (N + 3) / 4; ++c) {
+      const u32x4 w = action_words(p.seed, genv, episode, (uint32_t)steps, (uint32_t)c);
+      words[4 * c + 0] = w.x;
+      words[4 * c + 1] = w.y;
+      words[4 * c + 2] = w.z;
+      words[4 * c + 3] = w.w;
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) act[i] = rand5(words[i]);
+    if (active) store_row<int32_t, N>(p.actions, e, act);
+  } else {
+    load_row<int32_t, N>(p.actions, ec, act);
+  }
+
+  // ---- _set_action (environment.py:193-214) + apply_action_force (core.py:134-140) ------------------
+  R fx[N], fy[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    R ux = R(0), uy = R(0);
+    if (act[i] == 1) ux = R(-1);
+    if (act[i] == 2) ux = R(+1);
+    if (act[i] == 3) uy = R(-1);
+    if (act[i] == 4) uy = R(+1);
+    fx[i] = ux * R(5.0) + R(0.0);
+    fy[i] = uy * R(5.0) + R(0.0);
+  }
+
+  // ---- apply_environment_force (core.py:143-155) / get_collision_force (:180-196) -------------------
+  const R kMargin = R(1e-3), kForce = R(1e+2), kDistMin = R(0.15) + R(0.15);
+#pragma unroll
+  for (int a = 0; a < N; ++a) {
+#pragma unroll
+    for (int b = a + 1; b < N; ++b) {
+      const R dx = s[a].z - s[b].z, dy = s[a].w - s[b].w;
+      const R dist = Math<R>::sqrt(dx * dx + dy * dy);
+      const R pen = logaddexp0<R>(-(dist - kDistMin) / kMargin) * kMargin;
+      const R f_x = kForce * dx / dist * pen, f_y = kForce * dy / dist * pen;
+      fx[a] = f_x + fx[a];
+      fy[a] = f_y + fy[a];
+      fx[b] = (-f_x) + fx[b];
+      fy[b] = (-f_y) + fy[b];
+    }
+  }
+
+  // ---- integrate_state (core.py:158-169): mass 1, max_speed None -------------------------------------
+  const R kDt = R(0.1), kKeep = R(1 - 0.25);
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    s[i].x = s[i].x * kKeep;
+    s[i].y = s[i].y * kKeep;
+    s[i].x = s[i].x + (fx[i] / R(1.0)) * kDt;
+    s[i].y = s[i].y + (fy[i] / R(1.0)) * kDt;
+    s[i].z = s[i].z + s[i].x * kDt;
+    s[i].w = s[i].w + s[i].y * kDt;
+  }
+  steps += 1;  // environment.py:93
+
+  // ---- reward / reached (multi-goal_spread.py:121-143) ------------------------------------------------
+  R rew[N];
+  bool all_reached = true;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const R dx = s[i].z - g[i].x, dy = s[i].w - g[i].y;
+    rew[i] = R(0) - Math<R>::sqrt(dx * dx + dy * dy);
+    all_reached = all_reached && (rew[i] >= R(-0.05));
+  }
+#pragma unroll
+  for (int a = 0; a < N; ++a) {
+#pragma unroll
+    for (int b = a + 1; b < N; ++b) {
+      // is_collision is symmetric, so the reference's two ordered visits (j,i) and (i,j) collapse into one
+      const R dx = s[b].z - s[a].z, dy = s[b].w - s[a].w;
+      if (Math<R>::sqrt(dx * dx + dy * dy) < kDistMin) {
+        rew[a] = rew[a] - R(1);
+        rew[b] = rew[b] - R(1);
+        collisions += 2;  // double counts by design (:135-137)
+      }
+    }
+  }
+  const R reward = sum_agents<R, N>(rew);                       // environment.py:107
+  const bool done = (steps == p.max_steps) || all_reached;      // environment.py:118-121
+
+  if (active) {
+    store_row<R, N>(reinterpret_cast<R *>(p.reward_n), e, rew);
+    reinterpret_cast<R *>(p.reward)[e] = reward;
+    p.done[e] = done ? 1 : 0;
+  }
+
+  // ---- same-launch re-initialisation of finished episodes ---------------------------------------------
+  bool was_reset = false;
+  if ((p.flags & CM3_FLAG_AUTO_RESET) && done) {
+    if (active) {
+      if (p.term_state) {
+        V4 *t4 = reinterpret_cast<V4 *>(p.term_state);
+#pragma unroll
+        for (int i = 0; i < N; ++i) t4[(size_t)i * E + e] = s[i];
+      }
+      if (p.term_obs_others) store_obs_others_direct<R, N>(s, e, reinterpret_cast<R *>(p.term_obs_others));
+    }
+    episode += 1;
+    init_episode<R, N>(p, genv, episode, s, g);
+    steps = 0;
+    collisions = 0;
+    was_reset = true;
+    if (active) p.episode[e] = (int32_t)episode;
+  }
+
+  if (active) {
+    V4 *sout4 = reinterpret_cast<V4 *>(p.state_out);
+#pragma unroll
+    for (int i = 0; i < N; ++i) sout4[(size_t)i * E + e] = s[i];
+    if (p.goals_out != p.goals_in || was_reset) {
+      V2 *gout2 = reinterpret_cast<V2 *>(p.goals_out);
+#pragma unroll
+      for (int i = 0; i < N; ++i) gout2[(size_t)i * E + e] = g[i];
+    }
+    int2 m;
+    m.x = steps;
+    m.y = collisions;
+    reinterpret_cast<int2 *>(p.meta_out)[e] = m;
+  }
+
+  // ---- observation (multi-goal_spread.py:145-154), env-major rows through the wave's LDS tile ----------
+  store_obs_others_staged<R, N>(s, &lds_all[wave][0], lane, e0, p.E, reinterpret_cast<R *>(p.obs_others));
+}
+
+// ---- reset kernel (environment.py:125-149) ------------------------------------------------------------
+template <typename R, int N, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) k_particle_reset(const ParticleParams p) {
+  using V4 = typename Vec<R>::v4;
+  using V2 = typename Vec<R>::v2;
+  using G = ObsGeom<R, N>;
+  __shared__ __attribute__((aligned(32))) R lds_all[WAVES][G::LDS_REALS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t e0 = ((size_t)blockIdx.x * WAVES + wave) * 64;
+  const size_t e = e0 + lane;
+  const bool active = e < (size_t)p.E;
+  const size_t ec = active ? e : (size_t)p.E - 1;
+  const size_t E = (size_t)p.E;
+  const bool sel = p.reset_mask ? (p.reset_mask[ec] != 0) : true;
+  V4 s[N];
+  V2 g[N];
+  V4 *sout4 = reinterpret_cast<V4 *>(p.state_out);
+  V2 *gout2 = reinterpret_cast<V2 *>(p.goals_out);
+  if (sel) {
+    const uint32_t episode = (uint32_t)p.episode[ec] + 1u;
+    init_episode<R, N>(p, (uint64_t)(p.env_id_base + (int64_t)ec), episode, s, g);
+    if (active) {
+      p.episode[e] = (int32_t)episode;
+#pragma unroll
+      for (int i = 0; i < N; ++i) sout4[(size_t)i * E + e] = s[i];
+#pragma unroll
+      for (int i = 0; i < N; ++i) gout2[(size_t)i * E + e] = g[i];
+      int2 m;
+      m.x = 0;
+      m.y = 0;
+      reinterpret_cast<int2 *>(p.meta_out)[e] = m;
+    }
+  } else {
+    // unselected envs keep their state; it is re-read so the observation rows of the whole tile are rewritten
+#pragma unroll
+    for (int i = 0; i < N; ++i) s[i] = sout4[(size_t)i * E + ec];
+  }
+  store_obs_others_staged<R, N>(s, &lds_all[wave][0], lane, e0, p.E, reinterpret_cast<R *>(p.obs_others));
+}
+
+// ---- observe kernel (multi-goal_spread.py:145-154 after a state injection) -----------------------------
+template <typename R, int N, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) k_particle_observe(const ParticleParams p) {
+  using V4 = typename Vec<R>::v4;
+  using G = ObsGeom<R, N>;
+  __shared__ __attribute__((aligned(32))) R lds_all[WAVES][G::LDS_REALS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t e0 = ((size_t)blockIdx.x * WAVES + wave) * 64;
+  const size_t e = e0 + lane;
+  const size_t ec = e < (size_t)p.E ? e : (size_t)p.E - 1;
+  V4 s[N];
+  const V4 *sin4 = reinterpret_cast<const V4 *>(p.state_in);
+#pragma unroll
+  for (int i = 0; i < N; ++i) s[i] = sin4[(size_t)i * p.E + ec];
+  store_obs_others_staged<R, N>(s, &lds_all[wave][0], lane, e0, p.E, reinterpret_cast<R *>(p.obs_others));
+}
+
+// ---- host side -------------------------------------------------------------------------------------------
+enum ParticleOp { kStep = 0, kReset = 1, kObserve = 2 };
+
+static int fill_params(const cm3_particle_desc *d, const cm3_particle_bufs *b, ParticleOp op, const uint8_t *mask,
+                       ParticleParams &p) {
+  CM3_REQUIRE(d && b, "null desc/bufs");
+  CM3_REQUIRE(d->n_envs > 0, "n_envs must be positive (got %d)", d->n_envs);
+  CM3_REQUIRE(d->n_agents >= 1 && d->n_agents <= CM3_MAX_AGENTS, "n_agents must be in 1..%d (got %d)",
+              CM3_MAX_AGENTS, d->n_agents);
+  CM3_REQUIRE(d->max_steps >= 1, "max_steps must be >= 1");
+  CM3_REQUIRE((d->flags & ~(CM3_FLAG_AUTO_RESET | CM3_FLAG_GEN_ACTIONS)) == 0, "unknown flag bits 0x%x", d->flags);
+  CM3_REQUIRE(b->obs_others, "obs_others is required");
+  if (op == kStep) {
+    CM3_REQUIRE(b->state_in && b->state_out && b->goals_in && b->goals_out && b->meta_in && b->meta_out,
+                "step: state/goals/meta pointers are required");
+    CM3_REQUIRE(b->actions && b->reward_n && b->reward && b->done, "step: actions/reward_n/reward/done are required");
+    if (d->flags & (CM3_FLAG_AUTO_RESET | CM3_FLAG_GEN_ACTIONS))
+      CM3_REQUIRE(b->episode, "episode counter is required with AUTO_RESET / GEN_ACTIONS");
+  } else if (op == kReset) {
+    CM3_REQUIRE(b->state_out && b->goals_out && b->meta_out && b->episode, "reset: state_out/goals_out/meta_out/episode");
+  } else {
+    CM3_REQUIRE(b->state_in, "observe: state_in is required");
+  }
+  memset(&p, 0, sizeof(p));
+  p.E = d->n_envs;
+  p.max_steps = d->max_steps;
+  p.flags = d->flags;
+  p.env_id_base = d->env_id_base;
+  p.seed = d->seed;
+  p.prob_random = d->prob_random;
+  p.initial_std = d->initial_std;
+  for (int i = 0; i < CM3_MAX_AGENTS; ++i) {
+    p.ax[i] = d->agents_x[i];
+    p.ay[i] = d->agents_y[i];
+    p.lx[i] = d->landmarks_x[i];
+    p.ly[i] = d->landmarks_y[i];
+  }
+  p.state_in = b->state_in;
+  p.state_out = b->state_out;
+  p.goals_in = b->goals_in;
+  p.goals_out = b->goals_out;
+  p.meta_in = b->meta_in;
+  p.meta_out = b->meta_out;
+  p.episode = b->episode;
+  p.actions = b->actions;
+  p.obs_others = b->obs_others;
+  p.reward_n = b->reward_n;
+  p.reward = b->reward;
+  p.done = b->done;
+  p.term_state = b->term_state;
+  p.term_obs_others = b->term_obs_others;
+  p.reset_mask = mask;
+  return CM3_OK;
+}
+
+template <typename R, int N, int WAVES>
+static int launch_one(const ParticleParams &p, ParticleOp op, hipStream_t stream) {
+  const unsigned per_block = WAVES * 64;
+  const unsigned blocks = (unsigned)(((size_t)p.E + per_block - 1) / per_block);
+  switch (op) {
+    case kStep:
+      hipLaunchKernelGGL((k_particle_step<R, N, WAVES>), dim3(blocks), dim3(per_block), 0, stream, p);
+      break;
+    case kReset:
+      hipLaunchKernelGGL((k_particle_reset<R, N, WAVES>), dim3(blocks), dim3(per_block), 0, stream, p);
+      break;
+    case kObserve:
+      hipLaunchKernelGGL((k_particle_observe<R, N, WAVES>), dim3(blocks), dim3(per_block), 0, stream, p);
+      break;
+  }
+  CM3_HIP_CHECK(hipGetLastError());
+  return CM3_OK;
+}
+
+template <typename R, int N> static int launch_n(const ParticleParams &p, ParticleOp op, hipStream_t stream) {
+  // Small batches: one wave per workgroup so the few waves there are land on distinct CUs.
+  // Large batches: 4 waves per workgroup (one per SIMD).
+  if ((size_t)p.E <= (size_t)64 * 1024) return launch_one<R, N, 1>(p, op, stream);
+  return launch_one<R, N, 4>(p, op, stream);
+}
+
+template <typename R> static int launch(const ParticleParams &p, int n_agents, ParticleOp op, hipStream_t stream) {
+  switch (n_agents) {
+    case 1: return launch_n<R, 1>(p, op, stream);
+    case 2: return launch_n<R, 2>(p, op, stream);
+    case 3: return launch_n<R, 3>(p, op, stream);
+    case 4: return launch_n<R, 4>(p, op, stream);
+    case 5: return launch_n<R, 5>(p, op, stream);
+    case 6: return launch_n<R, 6>(p, op, stream);
+    case 7: return launch_n<R, 7>(p, op, stream);
+    case 8: return launch_n<R, 8>(p, op, stream);
+  }
+  return fail(CM3_ERR_INVALID, "n_agents %d unsupported", n_agents);
+}
+
+template <typename R>
+static int particle_call(const cm3_particle_desc *d, const cm3_particle_bufs *b, ParticleOp op, const uint8_t *mask,
+                         void *stream) {
+  ParticleParams p;
+  int rc = fill_params(d, b, op, mask, p);
+  if (rc != CM3_OK) return rc;
+  return launch<R>(p, d->n_agents, op, (hipStream_t)stream);
+}
+
+template <typename R>
+static int particle_rollout(const cm3_particle_desc *d, const cm3_particle_traj *t, int32_t n_ticks, void *stream) {
+  CM3_REQUIRE(d && t, "null desc/traj");
+  CM3_REQUIRE(n_ticks >= 1, "n_ticks must be >= 1");
+  CM3_REQUIRE(t->state && t->goals && t->obs_others && t->actions && t->reward_n && t->reward && t->done && t->meta,
+              "rollout: trajectory base pointers are required");
+  auto at = [](void *base, size_t stride, int k) -> void * {
+    return base ? (void *)((char *)base + stride * (size_t)k) : nullptr;
+  };
+  for (int k = 0; k < n_ticks; ++k) {
+    cm3_particle_bufs b;
+    memset(&b, 0, sizeof(b));
+    b.state_in = at(t->state, t->state_stride, k);
+    b.state_out = at(t->state, t->state_stride, k + 1);
+    b.goals_in = at(t->goals, t->goals_stride, k);
+    b.goals_out = at(t->goals, t->goals_stride, k + 1);
+    b.meta_in = t->meta;
+    b.meta_out = t->meta;
+    b.episode = t->episode;
+    b.actions = (int32_t *)at(t->actions, t->actions_stride, k);
+    b.obs_others = at(t->obs_others, t->obs_others_stride, k + 1);
+    b.reward_n = at(t->reward_n, t->reward_n_stride, k);
+    b.reward = at(t->reward, t->reward_stride, k);
+    b.done = (uint8_t *)at(t->done, t->done_stride, k);
+    b.term_state = at(t->term_state, t->term_state_stride, k);
+    b.term_obs_others = at(t->term_obs_others, t->term_obs_others_stride, k);
+    int rc = particle_call<R>(d, &b, kStep, nullptr, stream);
+    if (rc != CM3_OK) return rc;
+  }
+  return CM3_OK;
+}
+
+}  // namespace cm3
+
+extern "C" {
+int cm3_particle_step_f32(const cm3_particle_desc *d, const cm3_particle_bufs *b, void *s) {
+  return cm3::particle_call<float>(d, b, cm3::kStep, nullptr, s);
+}
+int cm3_particle_step_f64(const cm3_particle_desc *d, const cm3_particle_bufs *b, void *s) {
+  return cm3::particle_call<double>(d, b, cm3::kStep, nullptr, s);
+}
+int cm3_particle_reset_f32(const cm3_particle_desc *d, const cm3_particle_bufs *b, const uint8_t *m, void *s) {
+  return cm3::particle_call<float>(d, b, cm3::kReset, m, s);
+}
+int cm3_particle_reset_f64(const cm3_particle_desc *d, const cm3_particle_bufs *b, const uint8_t *m, void *s) {
+  return cm3::particle_call<double>(d, b, cm3::kReset, m, s);
+}
+int cm3_particle_observe_f32(const cm3_particle_desc *d, const cm3_particle_bufs *b, void *s) {
+  return cm3::particle_call<float>(d, b, cm3::kObserve, nullptr, s);
+}
+int cm3_particle_observe_f64(const cm3_particle_desc *d, const cm3_particle_bufs *b, void *s) {
+  return cm3::particle_call<double>(d, b, cm3::kObserve, nullptr, s);
+}
+int cm3_particle_rollout_f32(const cm3_particle_desc *d, const cm3_particle_traj *t, int32_t n, void *s) {
+  return cm3::particle_rollout<float>(d, t, n, s);
+}
+int cm3_particle_rollout_f64(const cm3_particle_desc *d, const cm3_particle_traj *t, int32_t n, void *s) {
+  return cm3::particle_rollout<double>(d, t, n, s);
+}
+}

@@ -1,0 +1,73 @@
+// Philox4x32-10 counter-based RNG (Salmon et al., SC'11), the build's own random stream.
+// The reference draws from two global MT19937 generators (multi-goal_spread.py:75-91,
+// train_onpolicy.py:307); bit-reproducing those on a GPU is neither feasible nor asked for
+//  -- parity runs inject states/actions, and this stream only has to
+// reproduce the reference's DISTRIBUTIONS.  Keying: key = seed (64 bit), counter =
+// (global env id lo, hi, episode, purpose | index) so results are independent of sharding and
+// of launch geometry.  oracle/philox.py restates this bit-for-bit for the tests.
+#pragma once
+#include <stdint.h>
+
+namespace cm3 {
+
+struct u32x4 {
+  uint32_t x, y, z, w;
+};
+
+__host__ __device__ inline uint32_t mulhi32(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __umulhi(a, b);
+#else
+  return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32);
+#endif
+}
+
+__host__ __device__ inline u32x4 philox4x32_10(u32x4 ctr, uint32_t k0, uint32_t k1) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = mulhi32(M0, ctr.x), lo0 = M0 * ctr.x;
+    const uint32_t hi1 = mulhi32(M1, ctr.z), lo1 = M1 * ctr.z;
+    u32x4 n;
+    n.x = hi1 ^ ctr.y ^ k0;
+    n.y = lo1;
+    n.z = hi0 ^ ctr.w ^ k1;
+    n.w = lo0;
+    ctr = n;
+    k0 += W0;
+    k1 += W1;
+  }
+  return ctr;
+}
+
+// purposes (top bits of counter word 3)
+constexpr uint32_t kPurposeAction = 0x00000000u;  // | step (low 24 bits) ... | call<<24
+constexpr uint32_t kPurposeReset = 0x80000000u;   // | call index
+
+// uniform in (0,1), 32-bit resolution, never 0 or 1
+__host__ __device__ inline double u01(uint32_t r) { return ((double)r + 0.5) * (1.0 / 4294967296.0); }
+
+// uniform integer on {0..4}: multiply-shift of one 32-bit word
+__host__ __device__ inline int rand5(uint32_t r) { return (int)mulhi32(r, 5u); }
+
+// actions of agents 4c..4c+3 of (env, episode, step) come from call c
+__host__ __device__ inline u32x4 action_words(uint64_t seed, uint64_t env, uint32_t episode, uint32_t step,
+                                              uint32_t call) {
+  u32x4 c;
+  c.x = (uint32_t)env;
+  c.y = (uint32_t)(env >> 32);
+  c.z = episode;
+  c.w = kPurposeAction | (call << 24) | (step & 0x00FFFFFFu);
+  return philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+
+__host__ __device__ inline u32x4 reset_words(uint64_t seed, uint64_t env, uint32_t episode, uint32_t call) {
+  u32x4 c;
+  c.x = (uint32_t)env;
+  c.y = (uint32_t)(env >> 32);
+  c.z = episode;
+  c.w = kPurposeReset | call;
+  return philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+
+}  // namespace cm3

@@ -1,0 +1,222 @@
+"""VecParticleEnv -- E copies of the reference's particle env stepped by ONE HIP launch per tick.
+
+Host-side mirror of the reference interface for this path:
+
+    reference (per env)                                           here (E envs)
+    --------------------------------------------------------      ---------------------------------
+    scenario.make_world(n_agents, config, prob_random)            VecParticleEnv(config, n_agents,
+      (multi-goal_spread.py:19-63)                                   prob_random, max_steps, n_envs, ...)
+    MultiAgentEnv(world, ..., max_steps) (environment.py:14-16)
+    env.reset() -> (global_state, obs_others_n, obs_n, done)      same tuple; leading E dim, agent lists
+      (environment.py:125-149)                                     become an N dim
+    env.step(action_n) -> (global_state, obs_others_n, obs_n,     same tuple, batched
+      reward, reward_n, done)  (environment.py:81-123)
+    env.world.landmarks[i].state.p_pos (train_onpolicy.py:285)    env.goals        [E, N, 2]
+    scenario.collisions (train_onpolicy.py:356)                   env.collisions   [E]
+
+All arithmetic happens in libcm3_hip.so (cm3_amd/csrc/particle.hip) on tensors owned by PyTorch;
+this module only allocates, binds pointers and shapes views.  No CPU fallback exists.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import FLAG_AUTO_RESET, FLAG_GEN_ACTIONS, Cm3Error
+
+
+def _fill_desc(desc, config, n_agents, prob_random, max_steps, n_envs, seed, env_id_base, flags):
+    desc.n_envs = int(n_envs)
+    desc.n_agents = int(n_agents)
+    desc.max_steps = int(max_steps)
+    desc.flags = int(flags)
+    desc.env_id_base = int(env_id_base)
+    desc.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    desc.prob_random = float(prob_random)
+    desc.initial_std = float(config["initial_std"])
+    for key in ("agents_x", "agents_y", "landmarks_x", "landmarks_y"):
+        vals = config[key]
+        if len(vals) < n_agents:
+            raise Cm3Error("config[%r] has %d entries, need n_agents=%d" % (key, len(vals), n_agents))
+        arr = getattr(desc, key)
+        for i in range(_lib.MAX_AGENTS):
+            arr[i] = float(vals[i]) if i < n_agents else 0.0
+
+
+class VecParticleEnv(object):
+    """E independent cooperative-navigation envs (multi-goal_spread) on one GPU.
+
+    dtype       torch.float32 (production) or torch.float64 (parity mode; same kernel template)
+    auto_reset  finished episodes are re-initialised inside the step launch (CM3_FLAG_AUTO_RESET)
+    env_id_base global id of local env 0 -- the RNG is keyed by global env id, so a sharded run
+                reproduces the single-GPU run
+    Tensors returned by reset()/step() are views of double-buffered device storage: they stay valid
+    until the step AFTER the next one (enough to assemble (state, next_state) transitions); clone to
+    keep them longer.
+    """
+
+    def __init__(self, config_particle, n_agents, prob_random, max_steps, n_envs, device="cuda:0",
+                 seed=12341, dtype=torch.float32, auto_reset=False, env_id_base=0):
+        self.device = _lib.require_gpu(device)
+        if dtype not in (torch.float32, torch.float64):
+            raise Cm3Error("dtype must be float32 or float64")
+        if not (1 <= n_agents <= _lib.MAX_AGENTS):
+            raise Cm3Error("n_agents must be in 1..%d" % _lib.MAX_AGENTS)
+        self.config = config_particle
+        self.n = self.n_agents = int(n_agents)
+        self.E = self.n_envs = int(n_envs)
+        self.max_steps = int(max_steps)
+        self.prob_random = float(prob_random)
+        self.dtype = dtype
+        self.seed = int(seed)
+        self.auto_reset = bool(auto_reset)
+        self.env_id_base = int(env_id_base)
+        self.L = 4 * max(self.n - 1, 1)
+        self._suffix = "f32" if dtype == torch.float32 else "f64"
+        E, N, L, dev = self.E, self.n, self.L, self.device
+        z = lambda *shape, dt=dtype: torch.zeros(*shape, dtype=dt, device=dev)  # noqa: E731
+        # double-buffered outputs (slot = tick parity)
+        self._state = [z(N, E, 4), z(N, E, 4)]
+        self._obs_others = [z(E, N, L), z(E, N, L)]
+        self._reward_n = [z(E, N), z(E, N)]
+        self._reward = [z(E), z(E)]
+        self._done = [z(E, dt=torch.uint8), z(E, dt=torch.uint8)]
+        self._actions = [z(E, N, dt=torch.int32), z(E, N, dt=torch.int32)]
+        # live, in place
+        self._goals = z(N, E, 2)
+        self._meta = z(E, 2, dt=torch.int32)
+        self._episode = z(E, dt=torch.int32)
+        self._term_state = None
+        self._term_obs_others = None
+        self._cur = 0
+        self._desc = _lib.ParticleDesc()
+        _fill_desc(self._desc, config_particle, N, prob_random, max_steps, E, seed, env_id_base, 0)
+        self._lib = _lib.lib()
+
+    # ---- plumbing --------------------------------------------------------------------------------
+    def _fn(self, op):
+        return getattr(self._lib, "cm3_particle_%s_%s" % (op, self._suffix))
+
+    def _stream(self):
+        return _lib.current_stream_handle(self.device)
+
+    def _bufs(self, src, dst):
+        b = _lib.ParticleBufs()
+        b.state_in = self._state[src].data_ptr()
+        b.state_out = self._state[dst].data_ptr()
+        b.goals_in = b.goals_out = self._goals.data_ptr()
+        b.meta_in = b.meta_out = self._meta.data_ptr()
+        b.episode = self._episode.data_ptr()
+        b.actions = self._actions[dst].data_ptr()
+        b.obs_others = self._obs_others[dst].data_ptr()
+        b.reward_n = self._reward_n[dst].data_ptr()
+        b.reward = self._reward[dst].data_ptr()
+        b.done = self._done[dst].data_ptr()
+        b.term_state = _lib.ptr(self._term_state)
+        b.term_obs_others = _lib.ptr(self._term_obs_others)
+        return b
+
+    def enable_terminal_capture(self):
+        """Allocate term_state / term_obs_others so AUTO_RESET keeps the true terminal next-state."""
+        if self._term_state is None:
+            self._term_state = torch.zeros_like(self._state[0])
+            self._term_obs_others = torch.zeros_like(self._obs_others[0])
+
+    # ---- reference surface -----------------------------------------------------------------------
+    def reset(self, mask=None):
+        """environment.py:125-149 for every env (or those selected by the uint8/bool ``mask`` [E])."""
+        cur = self._cur
+        b = self._bufs(cur, cur)
+        m = None
+        if mask is not None:
+            m = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+            if m.numel() != self.E:
+                raise Cm3Error("mask must have n_envs elements")
+        self._desc.flags = 0
+        _lib.check(self._fn("reset")(ctypes.byref(self._desc), ctypes.byref(b), _lib.ptr(m), self._stream()))
+        done = torch.zeros(self.E, dtype=torch.bool, device=self.device)   # np.any(done_n) is False after reset
+        gs = self.global_state
+        return gs, self._obs_others[cur], gs, done
+
+    def step(self, actions=None):
+        """environment.py:81-123.  ``actions`` int [E, N]; None draws uniform actions in-kernel
+        (the reference's random-action branch, train_onpolicy.py:305-307)."""
+        src, dst = self._cur, self._cur ^ 1
+        flags = FLAG_AUTO_RESET if self.auto_reset else 0
+        if actions is None:
+            flags |= FLAG_GEN_ACTIONS
+        else:
+            a = torch.as_tensor(actions, device=self.device)
+            if a.shape != (self.E, self.n):
+                raise Cm3Error("actions must have shape [n_envs, n_agents] = [%d, %d], got %s"
+                               % (self.E, self.n, tuple(a.shape)))
+            self._actions[dst].copy_(a)
+        self._desc.flags = flags
+        b = self._bufs(src, dst)
+        _lib.check(self._fn("step")(ctypes.byref(self._desc), ctypes.byref(b), self._stream()))
+        self._cur = dst
+        gs = self.global_state
+        return (gs, self._obs_others[dst], gs, self._reward[dst], self._reward_n[dst],
+                self._done[dst].view(torch.bool))
+
+    def get_obs(self):
+        """(obs_self [E,N,4], obs_others [E,N,L]) of the current state (multi-goal_spread.py:145-154)."""
+        return self.global_state, self._obs_others[self._cur]
+
+    # ---- extra surface read by the reference's callers ------------------------------------------------
+    @property
+    def global_state(self):
+        """[E, N, 4] rows (vx, vy, px, py) (environment.py:113-116): a permuted view of the SoA state."""
+        return self._state[self._cur].permute(1, 0, 2)
+
+    @property
+    def goals(self):
+        """[E, N, 2] landmark positions (train_onpolicy.py:283-285)."""
+        return self._goals.permute(1, 0, 2)
+
+    @property
+    def collisions(self):
+        """[E] scenario.collisions (multi-goal_spread.py:93,137; read at train_onpolicy.py:356)."""
+        return self._meta[:, 1]
+
+    @property
+    def steps(self):
+        return self._meta[:, 0]
+
+    @property
+    def episode(self):
+        return self._episode
+
+    @property
+    def last_actions(self):
+        return self._actions[self._cur]
+
+    @property
+    def terminal_state(self):
+        return None if self._term_state is None else self._term_state.permute(1, 0, 2)
+
+    @property
+    def terminal_obs_others(self):
+        return self._term_obs_others
+
+    # ---- state injection / checkpoint ---------------------------------------------------------------------
+    def get_state(self):
+        gs = self.global_state
+        return dict(pos=gs[..., 2:4].clone(), vel=gs[..., 0:2].clone(), landmarks=self.goals.clone(),
+                    steps=self.steps.clone(), collisions=self.collisions.clone(), episode=self._episode.clone())
+
+    def set_state(self, pos, vel, landmarks, steps=None, collisions=None, episode=None):
+        """Inject [E,N,2] positions / velocities / landmarks (parity tests, resume) and refresh obs."""
+        cur = self._cur
+        st = self._state[cur]
+        t = lambda x: torch.as_tensor(x, device=self.device).to(self.dtype)  # noqa: E731
+        st[:, :, 0:2] = t(vel).permute(1, 0, 2)
+        st[:, :, 2:4] = t(pos).permute(1, 0, 2)
+        self._goals.copy_(t(landmarks).permute(1, 0, 2))
+        self._meta[:, 0] = 0 if steps is None else torch.as_tensor(steps, device=self.device).to(torch.int32)
+        self._meta[:, 1] = 0 if collisions is None else torch.as_tensor(collisions, device=self.device).to(torch.int32)
+        if episode is not None:
+            self._episode.copy_(torch.as_tensor(episode, device=self.device).to(torch.int32))
+        b = self._bufs(cur, cur)
+        _lib.check(self._fn("observe")(ctypes.byref(self._desc), ctypes.byref(b), self._stream()))
+        return self.global_state, self._obs_others[cur]

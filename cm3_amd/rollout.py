@@ -1,0 +1,350 @@
+"""Trajectory collection -- the `while not done` loop of alg/train_onpolicy.py:281-350 for E envs.
+
+The reference appends one object-array row per tick to a Python list (replay_buffer.py:11-16):
+  particle (11 columns, train_onpolicy.py:338)
+    [global_state, obs_others, obs_self, actions, reward, local_rewards,
+     next_global_state, next_obs_others, next_obs_self, done, goals]
+  Checkers (16 columns, train_onpolicy.py:336)
+    [grid, vec, obs_others, obs_self_t, obs_self_v, actions_prev, actions, reward, local_rewards,
+     next_grid, next_vec, next_obs_others, next_obs_self_t, next_obs_self_v, done, goals]
+Here the trajectory lives on the device, time-major and de-duplicated: slot t of the state /
+observation arrays is "before tick t", slot t+1 is "after tick t", so `next_*` of transition t is
+slot t+1 (or the captured terminal state when the env was re-initialised in the same launch).  The
+step kernel writes slot t+1 directly (zero-copy, cm3_particle_rollout_*).  ``as_reference_batch``
+gathers any set of (tick, env) pairs into exactly what ``np.stack(batch[:, k])`` yields in
+alg_credit.process_batch (alg_credit.py:458-470) / alg_credit_checkers.process_batch
+(alg_credit_checkers.py:427-444), and ``as_reference_rows`` rebuilds the reference's object rows so
+the real ``process_batch`` consumes them unchanged.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import FLAG_AUTO_RESET, FLAG_GEN_ACTIONS, Cm3Error
+
+
+def rows_from_columns(cols, order):
+    """Object ndarray [B, len(order)]: row b = the reference's per-tick np.array([...fields...]) of
+    train_onpolicy.py:336/:338 (dtype=object, which NumPy >= 1.24 requires for ragged rows), so that
+    ``np.stack(rows[:, k])`` in the reference's process_batch returns cols[order[k]]."""
+    B = len(cols[order[0]])
+    rows = np.empty((B, len(order)), dtype=object)
+    for k, name in enumerate(order):
+        col = cols[name]
+        for b in range(B):
+            rows[b, k] = col[b]
+    return rows
+
+
+PARTICLE_ORDER = ("v_global", "obs_others", "v_local", "actions", "reward", "reward_local", "v_global_next",
+                  "obs_others_next", "v_local_next", "done", "goals")
+CHECKERS_ORDER = ("grid", "vec", "obs_others", "obs_self_t", "obs_self_v", "actions_prev", "actions", "reward",
+                  "local_rewards", "next_grid", "next_vec", "next_obs_others", "next_obs_self_t",
+                  "next_obs_self_v", "done", "goals")
+
+
+def _valid_from_done(done_u8):
+    """valid[t, e] = env e had not finished before tick t (episode-synchronous collection: an env that
+    finishes early stops producing transitions, like the reference's `while not done`)."""
+    d = done_u8.to(torch.int32)
+    finished_before = torch.cumsum(d, dim=0) - d
+    return finished_before == 0
+
+
+class ParticleRollout(object):
+    """T-tick trajectory over a VecParticleEnv.
+
+    env.auto_reset False: episode-synchronous -- reset all envs, run T = max_steps ticks, transitions of
+        an env after its `done` are flagged invalid (mirrors one reference episode per env).
+    env.auto_reset True: continuous -- finished envs restart inside the launch; the true terminal
+        next-state/obs are captured per tick, goals are recorded per slot; every transition is valid.
+    """
+
+    def __init__(self, env, n_ticks=None, use_graph=True):
+        self.env = env
+        self.T = int(n_ticks or env.max_steps)
+        self.use_graph = bool(use_graph)
+        E, N, L, T, dev, dt = env.E, env.n, env.L, self.T, env.device, env.dtype
+        z = lambda *s, d=dt: torch.zeros(*s, dtype=d, device=dev)  # noqa: E731
+        self.state = z(T + 1, N, E, 4)
+        self.obs_others = z(T + 1, E, N, L)
+        self.actions = z(T, E, N, d=torch.int32)
+        self.reward = z(T, E)
+        self.reward_n = z(T, E, N)
+        self.done = z(T, E, d=torch.uint8)
+        self.auto_reset = env.auto_reset
+        if self.auto_reset:
+            self.goals = z(T + 1, N, E, 2)
+            self.term_state = z(T, N, E, 4)
+            self.term_obs_others = z(T, E, N, L)
+        else:
+            self.goals = None
+            self.term_state = self.term_obs_others = None
+        self._graph = None
+        self._lib = _lib.lib()
+        self.collected = False
+
+    # ---- plumbing ------------------------------------------------------------------------------------
+    def _traj(self, t0=0):
+        env, es = self.env, self.state.element_size()
+        E, N, L = env.E, env.n, env.L
+        t = _lib.ParticleTraj()
+        t.state = self.state[t0].data_ptr()
+        t.state_stride = N * E * 4 * es
+        if self.goals is not None:
+            t.goals = self.goals[t0].data_ptr()
+            t.goals_stride = N * E * 2 * es
+        else:
+            t.goals = env._goals.data_ptr()
+            t.goals_stride = 0
+        t.obs_others = self.obs_others[t0].data_ptr()
+        t.obs_others_stride = E * N * L * es
+        t.actions = self.actions[t0].data_ptr()
+        t.actions_stride = E * N * 4
+        t.reward_n = self.reward_n[t0].data_ptr()
+        t.reward_n_stride = E * N * es
+        t.reward = self.reward[t0].data_ptr()
+        t.reward_stride = E * es
+        t.done = self.done[t0].data_ptr()
+        t.done_stride = E
+        t.meta = env._meta.data_ptr()
+        t.episode = env._episode.data_ptr()
+        if self.term_state is not None:
+            t.term_state = self.term_state[t0].data_ptr()
+            t.term_state_stride = N * E * 4 * es
+            t.term_obs_others = self.term_obs_others[t0].data_ptr()
+            t.term_obs_others_stride = E * N * L * es
+        return t
+
+    def _enqueue(self, t0, n, flags, stream=None):
+        env = self.env
+        env._desc.flags = flags
+        traj = self._traj(t0)
+        fn = getattr(self._lib, "cm3_particle_rollout_" + env._suffix)
+        _lib.check(fn(ctypes.byref(env._desc), ctypes.byref(traj), int(n),
+                      env._stream() if stream is None else stream))
+
+    def _load_slot0(self):
+        env = self.env
+        self.state[0].copy_(env._state[env._cur])
+        self.obs_others[0].copy_(env._obs_others[env._cur])
+        if self.goals is not None:
+            self.goals[0].copy_(env._goals)
+
+    def _store_back(self):
+        env = self.env
+        env._state[env._cur].copy_(self.state[self.T])
+        env._obs_others[env._cur].copy_(self.obs_others[self.T])
+        if self.goals is not None:
+            env._goals.copy_(self.goals[self.T])
+
+    # ---- collection ------------------------------------------------------------------------------------
+    def collect(self, policy=None, reset=None):
+        """Runs T ticks.  policy None = the reference's random-action branch (train_onpolicy.py:305-307,
+        drawn in-kernel; the whole rollout is one hipGraph replay); otherwise ``policy(obs_others [E,N,L],
+        obs_self [E,N,4], goals [E,N,2]) -> int actions [E,N]`` is called every tick (:311-313).
+        reset: None -> reset at the start iff the env does not auto-reset."""
+        env = self.env
+        if reset is None:
+            reset = not self.auto_reset
+        if reset:
+            env.reset()
+        self._load_slot0()
+        base = FLAG_AUTO_RESET if self.auto_reset else 0
+        if policy is None:
+            flags = base | FLAG_GEN_ACTIONS
+            if self.use_graph:
+                if self._graph is None:
+                    self._graph = _lib.capture_graph(env.device, lambda s: self._enqueue(0, self.T, flags, s))
+                _lib.check(self._lib.cm3_graph_launch(self._graph, env._stream()))
+            else:
+                self._enqueue(0, self.T, flags)
+        else:
+            for t in range(self.T):
+                goals = (self.goals[t] if self.goals is not None else env._goals).permute(1, 0, 2)
+                a = policy(self.obs_others[t], self.state[t].permute(1, 0, 2), goals)
+                self.actions[t].copy_(torch.as_tensor(a, device=env.device).reshape(env.E, env.n))
+                self._enqueue(t, 1, base)
+        self._store_back()
+        self.collected = True
+        return self
+
+    def close(self):
+        if self._graph is not None:
+            self._lib.cm3_graph_destroy(self._graph)
+            self._graph = None
+
+    # ---- views --------------------------------------------------------------------------------------------
+    @property
+    def valid(self):
+        """bool [T, E]"""
+        if self.auto_reset:
+            return torch.ones(self.T, self.env.E, dtype=torch.bool, device=self.env.device)
+        return _valid_from_done(self.done)
+
+    def episode_returns(self):
+        """(reward_global [E], reward_local [E,N]) accumulated over each env's episode
+        (train_onpolicy.py:349-350); episode-synchronous mode."""
+        v = self.valid.to(self.reward.dtype)
+        return (self.reward * v).sum(0), (self.reward_n * v.unsqueeze(2)).sum(0)
+
+    def _next(self, name, tt, ee):
+        """next_* of transitions (tt, ee): slot t+1, or the captured terminal values where the env restarted."""
+        if name == "state":
+            nxt = self.state[tt + 1, :, ee]                    # [B, N, 4]
+            if self.term_state is not None:
+                term = self.term_state[tt, :, ee]
+                d = self.done[tt, ee].bool().view(-1, 1, 1)
+                nxt = torch.where(d, term, nxt)
+            return nxt
+        nxt = self.obs_others[tt + 1, ee]
+        if self.term_obs_others is not None:
+            term = self.term_obs_others[tt, ee]
+            d = self.done[tt, ee].bool().view(-1, 1, 1)
+            nxt = torch.where(d, term, nxt)
+        return nxt
+
+    def valid_indices(self):
+        """(tt, ee) int64 tensors of all valid transitions, time-major."""
+        idx = self.valid.nonzero(as_tuple=False)
+        return idx[:, 0], idx[:, 1]
+
+    def as_reference_batch(self, tt=None, ee=None, numpy=True):
+        """Columns of the reference's transition batch for the (tick, env) pairs (tt, ee) (default: all valid
+        ones), each equal to np.stack(batch[:, k]) in alg_credit.process_batch (alg_credit.py:458-470)."""
+        if tt is None:
+            tt, ee = self.valid_indices()
+        tt = torch.as_tensor(tt, device=self.env.device, dtype=torch.long)
+        ee = torch.as_tensor(ee, device=self.env.device, dtype=torch.long)
+        state = self.state[tt, :, ee]                                   # [B, N, 4]
+        nxt_state = self._next("state", tt, ee)
+        goals = (self.goals[tt, :, ee] if self.goals is not None
+                 else self.env._goals[:, ee].permute(1, 0, 2))          # [B, N, 2]
+        cols = dict(
+            v_global=state, obs_others=self.obs_others[tt, ee], v_local=state,
+            actions=self.actions[tt, ee], reward=self.reward[tt, ee], reward_local=self.reward_n[tt, ee],
+            v_global_next=nxt_state, obs_others_next=self._next("obs_others", tt, ee), v_local_next=nxt_state,
+            done=self.done[tt, ee].bool(), goals=goals)
+        if numpy:
+            cols = {k: v.detach().cpu().numpy() for k, v in cols.items()}
+        return cols
+
+    ORDER = ("v_global", "obs_others", "v_local", "actions", "reward", "reward_local", "v_global_next",
+             "obs_others_next", "v_local_next", "done", "goals")
+
+    def as_reference_rows(self, tt=None, ee=None):
+        """Object ndarray [B, 11]: row b is the reference's np.array([...11 fields...]) of train_onpolicy.py:338
+        (dtype=object, as NumPy >= 1.24 requires for ragged rows)."""
+        return rows_from_columns(self.as_reference_batch(tt, ee), self.ORDER)
+
+    def sample_batch(self, size, generator=None):
+        """replay_buffer.sample_batch (replay_buffer.py:28-37): all transitions if there are <= size of them,
+        else `size` distinct ones uniformly at random."""
+        tt, ee = self.valid_indices()
+        n = tt.numel()
+        if n > size:
+            pick = torch.randperm(n, generator=generator, device=tt.device)[:size]
+            tt, ee = tt[pick], ee[pick]
+        return self.as_reference_batch(tt, ee)
+
+
+class CheckersRollout(object):
+    """T-tick trajectory over a VecCheckersEnv (16-column transitions, train_onpolicy.py:336).
+    Episode-synchronous (the env is reset at the start; transitions after `done` are invalid)."""
+
+    def __init__(self, env, n_ticks=None):
+        self.env = env
+        self.T = int(n_ticks or env.max_steps)
+        E, N, T, dev = env.E, env.n, self.T, env.device
+        z = lambda *s, d: torch.zeros(*s, dtype=d, device=dev)  # noqa: E731
+        self.grid = z(T + 1, E, env.R, env.C + 1, 2, d=torch.int8)
+        self.vec = z(T + 1, E, N, 4, d=torch.int32)
+        self.obs_others = z(T + 1, E, N, env.Lo, d=torch.float64)
+        self.obs_self_t = z(T + 1, E, N, env.K, env.K, 3, d=torch.int8)
+        self.obs_self_v = z(T + 1, E, N, 4, d=torch.float64)
+        self.actions = z(T, E, N, d=torch.int32)
+        self.local_rewards = z(T, E, N, d=torch.float64)
+        self.reward = z(T, E, d=torch.float64)
+        self.done = z(T, E, d=torch.uint8)
+        self._lib = _lib.lib()
+
+    def _bufs(self, t):
+        env = self.env
+        b = _lib.CheckersBufs()
+        b.mask, b.agents, b.steps = env._mask.data_ptr(), env._agents.data_ptr(), env._steps.data_ptr()
+        b.episode, b.goals = env._episode.data_ptr(), env._goals.data_ptr()
+        b.actions = self.actions[t].data_ptr()
+        b.grid, b.vec = self.grid[t + 1].data_ptr(), self.vec[t + 1].data_ptr()
+        b.obs_others = self.obs_others[t + 1].data_ptr()
+        b.obs_self_t, b.obs_self_v = self.obs_self_t[t + 1].data_ptr(), self.obs_self_v[t + 1].data_ptr()
+        b.local_rewards, b.reward, b.done = (self.local_rewards[t].data_ptr(), self.reward[t].data_ptr(),
+                                             self.done[t].data_ptr())
+        return b
+
+    def collect(self, goals, policy=None):
+        """goals: one-hot [N,2] / [E,N,2] (train_onpolicy.py:287-293).  policy None = uniform random actions
+        drawn in-kernel; else policy(actions_prev, obs_others, obs_self_t, obs_self_v, goals) -> [E,N]."""
+        env = self.env
+        (grid, vec), oo, ot, ov, _ = env.reset(goals)
+        self.grid[0].copy_(grid)
+        self.vec[0].copy_(vec)
+        self.obs_others[0].copy_(oo)
+        self.obs_self_t[0].copy_(ot)
+        self.obs_self_v[0].copy_(ov)
+        self.goals_onehot = env.goals.clone()
+        for t in range(self.T):
+            if policy is None:
+                env._desc.flags = FLAG_GEN_ACTIONS
+            else:
+                prev = self.actions[t - 1] if t > 0 else torch.zeros_like(self.actions[0])
+                a = policy(prev, self.obs_others[t], self.obs_self_t[t], self.obs_self_v[t], self.goals_onehot)
+                self.actions[t].copy_(torch.as_tensor(a, device=env.device).reshape(env.E, env.n))
+                env._desc.flags = 0
+            b = self._bufs(t)
+            _lib.check(self._lib.cm3_checkers_step(ctypes.byref(env._desc), ctypes.byref(b), env._stream()))
+        return self
+
+    @property
+    def valid(self):
+        return _valid_from_done(self.done)
+
+    def valid_indices(self):
+        idx = self.valid.nonzero(as_tuple=False)
+        return idx[:, 0], idx[:, 1]
+
+    ORDER = ("grid", "vec", "obs_others", "obs_self_t", "obs_self_v", "actions_prev", "actions", "reward",
+             "local_rewards", "next_grid", "next_vec", "next_obs_others", "next_obs_self_t", "next_obs_self_v",
+             "done", "goals")
+
+    def as_reference_batch(self, tt=None, ee=None, numpy=True):
+        """16 columns equal to np.stack(batch[:, k]) of alg_credit_checkers.process_batch
+        (alg_credit_checkers.py:427-444); integer-valued columns are cast to the reference's float64."""
+        if tt is None:
+            tt, ee = self.valid_indices()
+        dev = self.env.device
+        tt = torch.as_tensor(tt, device=dev, dtype=torch.long)
+        ee = torch.as_tensor(ee, device=dev, dtype=torch.long)
+        f = lambda x: x.to(torch.float64)  # noqa: E731
+        prev = torch.where((tt > 0).view(-1, 1), self.actions[(tt - 1).clamp(min=0), ee],
+                           torch.zeros_like(self.actions[0, ee]))       # actions_prev starts at zeros (:295)
+        cols = dict(
+            grid=f(self.grid[tt, ee]), vec=f(self.vec[tt, ee]), obs_others=self.obs_others[tt, ee],
+            obs_self_t=f(self.obs_self_t[tt, ee]), obs_self_v=self.obs_self_v[tt, ee],
+            actions_prev=prev, actions=self.actions[tt, ee], reward=self.reward[tt, ee],
+            local_rewards=self.local_rewards[tt, ee],
+            next_grid=f(self.grid[tt + 1, ee]), next_vec=f(self.vec[tt + 1, ee]),
+            next_obs_others=self.obs_others[tt + 1, ee], next_obs_self_t=f(self.obs_self_t[tt + 1, ee]),
+            next_obs_self_v=self.obs_self_v[tt + 1, ee], done=self.done[tt, ee].bool(),
+            goals=self.goals_onehot[ee])
+        if numpy:
+            cols = {k: v.detach().cpu().numpy() for k, v in cols.items()}
+        return cols
+
+    def as_reference_rows(self, tt=None, ee=None):
+        return rows_from_columns(self.as_reference_batch(tt, ee), self.ORDER)
+
+    def episode_returns(self):
+        v = self.valid.to(torch.float64)
+        return (self.reward * v).sum(0), (self.local_rewards * v.unsqueeze(2)).sum(0)

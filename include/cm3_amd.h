@@ -1,0 +1,229 @@
+/*
+ * cm3_amd.h -- C ABI of libcm3_hip.so: the MI355X (gfx950) vectorised rollout engine for the
+ * CM3 hot path (cooperative-navigation particle env, Checkers env, trajectory collection).
+ *
+ * The reference (011235813/cm3) is pure Python and has no FFI of its own; the interface the
+ * hot path sits behind is the Python env protocol (reset()/step()) used by
+ * alg/train_onpolicy.py:119,126,282,294,321,323.  Each entry point below names the reference
+ * function(s) it replaces for E environments at once.  INTEGRATION.md shows the ctypes stub a
+ * reference maintainer would add.
+ *
+ * Conventions
+ *   - Plain pointers and sizes only; no torch / HIP types in signatures (`stream` is a
+ *     hipStream_t passed as void*, NULL = the default stream).
+ *   - Every pointer is a DEVICE pointer owned by the caller unless stated otherwise.  The
+ *     library allocates nothing persistent, keeps no pointer after return, and only ENQUEUES
+ *     work on `stream` (asynchronous).
+ *   - Return value: 0 (CM3_OK) or a negative CM3_ERR_* code; cm3_last_error() returns a
+ *     thread-local message for the last failure on the calling thread.
+ *   - E = environments in this launch (this rank's shard), N = agents per environment.
+ *
+ * Device layouts (particle; `real` = float for *_f32, double for *_f64)
+ *   state       real [N][E][4]   (vx, vy, px, py) of agent i in env e at [i][e]: one 16/32-byte
+ *                                vector per lane, unit-stride over e (coalesced).  The
+ *                                reference's global_state[N,4] (environment.py:113-116) and
+ *                                obs_self (multi-goal_spread.py:154) for env e are the rows
+ *                                state[:, e, :].
+ *   goals       real [N][E][2]   landmark positions (train_onpolicy.py:283-285)
+ *   meta        int32 [E][2]     {steps, collisions}   (environment.py:93; multi-goal_spread.py:93,137)
+ *   episode     int32 [E]        episodes started so far by env e (RNG key; touched on reset only)
+ *   actions     int32 [E][N]     discrete actions 0..4 (environment.py:197-200)
+ *   obs_others  real [E][N][L]   L = 4*max(N-1,1)  (multi-goal_spread.py:145-154)
+ *   reward_n    real [E][N]      (multi-goal_spread.py:121-138)
+ *   reward      real [E]         np.sum(reward_n) (environment.py:107)
+ *   done        uint8 [E]        (environment.py:118-121)
+ */
+#ifndef CM3_AMD_H
+#define CM3_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CM3_ABI_VERSION 1
+#define CM3_MAX_AGENTS 8
+
+#define CM3_OK 0
+#define CM3_ERR_INVALID (-1)     /* bad argument / unsupported configuration */
+#define CM3_ERR_HIP (-2)         /* a HIP runtime call failed */
+#define CM3_ERR_STATE (-3)       /* call sequence error (graph capture etc.) */
+
+/* cm3_*_desc.flags */
+#define CM3_FLAG_AUTO_RESET 1u   /* an env whose episode ends is re-initialised inside the same launch:
+                                    its reward/done outputs are the terminal ones, its state/obs outputs are
+                                    those of the fresh episode (train_onpolicy.py:282 folded into :321) and
+                                    the true terminal next-state goes to term_* when those are non-NULL */
+#define CM3_FLAG_GEN_ACTIONS 2u  /* actions are drawn in-kernel, uniform on {0..4} (train_onpolicy.py:305-307),
+                                    Philox4x32-10 keyed (seed, global env id, episode, step), and WRITTEN to
+                                    `actions` */
+
+int cm3_abi_version(void);
+const char *cm3_last_error(void);
+/* Number of visible HIP devices (0 when none); fills name (<= len bytes) of device `dev` if name != NULL. */
+int cm3_device_count(void);
+int cm3_device_name(int dev, char *name, int len);
+
+/* ------------------------------------------------------------------------------------------
+ * Particle env: MultiAgentEnv + multi-goal_spread scenario
+ * ---------------------------------------------------------------------------------------- */
+typedef struct cm3_particle_desc {
+  int32_t n_envs;      /* E */
+  int32_t n_agents;    /* N, 1..CM3_MAX_AGENTS */
+  int32_t max_steps;   /* config.json:61 */
+  uint32_t flags;      /* CM3_FLAG_* */
+  int64_t env_id_base; /* global id of local env 0: RNG is keyed by GLOBAL env id, so results do not
+                          depend on how envs are sharded over GPUs */
+  uint64_t seed;
+  double prob_random;  /* multi-goal_spread.py:75 */
+  double initial_std;  /* multi-goal_spread.py:80-81 */
+  double agents_x[CM3_MAX_AGENTS], agents_y[CM3_MAX_AGENTS];       /* config_particle_*.json */
+  double landmarks_x[CM3_MAX_AGENTS], landmarks_y[CM3_MAX_AGENTS];
+} cm3_particle_desc;
+
+typedef struct cm3_particle_bufs {
+  const void *state_in; /* real [N][E][4] pre-step state */
+  void *state_out;      /* real [N][E][4] post-step state; may alias state_in */
+  const void *goals_in; /* real [N][E][2] */
+  void *goals_out;      /* real [N][E][2]; may alias goals_in (then only re-initialised envs are written) */
+  const int32_t *meta_in; /* int32 [E][2] */
+  int32_t *meta_out;      /* may alias meta_in */
+  int32_t *episode;     /* int32 [E], in/out */
+  int32_t *actions;     /* int32 [E][N]; input, or output under CM3_FLAG_GEN_ACTIONS */
+  void *obs_others;     /* real [E][N][L] out */
+  void *reward_n;       /* real [E][N] out */
+  void *reward;         /* real [E] out */
+  uint8_t *done;        /* uint8 [E] out */
+  void *term_state;      /* optional real [N][E][4]: written only for envs re-initialised by AUTO_RESET */
+  void *term_obs_others; /* optional real [E][N][L]: same */
+} cm3_particle_bufs;
+
+/* One tick for E envs in ONE kernel launch: replaces MultiAgentEnv.step (environment.py:81-123) =
+ * _set_action (:177-225) + World.step (core.py:117-131) + Scenario.observation/reward/done
+ * (multi-goal_spread.py:121-154). */
+int cm3_particle_step_f32(const cm3_particle_desc *desc, const cm3_particle_bufs *bufs, void *stream);
+int cm3_particle_step_f64(const cm3_particle_desc *desc, const cm3_particle_bufs *bufs, void *stream);
+
+/* (Re)initialise envs: replaces MultiAgentEnv.reset (environment.py:125-149) +
+ * Scenario.reset_world (multi-goal_spread.py:65-93).  Uses state_out, goals_out, meta_out, episode,
+ * obs_others of `bufs`; `mask` (uint8 [E], optional) selects the envs to reset (NULL = all).
+ * The build's own counter-based RNG reproduces the reference's DISTRIBUTIONS (one Bernoulli(prob_random)
+ * per episode shared by agents and landmarks; U(-1,1)^2, or preset + N(0, initial_std) on agents only). */
+int cm3_particle_reset_f32(const cm3_particle_desc *desc, const cm3_particle_bufs *bufs, const uint8_t *mask,
+                           void *stream);
+int cm3_particle_reset_f64(const cm3_particle_desc *desc, const cm3_particle_bufs *bufs, const uint8_t *mask,
+                           void *stream);
+
+/* Observation only (no dynamics): obs_others from state_in.  Replaces Scenario.observation
+ * (multi-goal_spread.py:145-154) after a state injection. */
+int cm3_particle_observe_f32(const cm3_particle_desc *desc, const cm3_particle_bufs *bufs, void *stream);
+int cm3_particle_observe_f64(const cm3_particle_desc *desc, const cm3_particle_bufs *bufs, void *stream);
+
+/* Trajectory collection (train_onpolicy.py:302-350): n_ticks launches of the step kernel over a
+ * time-major trajectory.  Slot t of each array is base + t*stride (strides in BYTES).  state/obs_others/
+ * goals have n_ticks+1 slots (slot t = before tick t, slot t+1 = after); the per-tick outputs have
+ * n_ticks slots.  meta/episode are live (in place).  goals_stride == 0 keeps one live goals array.
+ * term_* are optional (n_ticks slots). */
+typedef struct cm3_particle_traj {
+  void *state;        size_t state_stride;
+  void *goals;        size_t goals_stride;
+  void *obs_others;   size_t obs_others_stride;
+  int32_t *actions;   size_t actions_stride;
+  void *reward_n;     size_t reward_n_stride;
+  void *reward;       size_t reward_stride;
+  uint8_t *done;      size_t done_stride;
+  int32_t *meta;      /* int32 [E][2], live */
+  int32_t *episode;   /* int32 [E], live */
+  void *term_state;      size_t term_state_stride;
+  void *term_obs_others; size_t term_obs_others_stride;
+} cm3_particle_traj;
+
+int cm3_particle_rollout_f32(const cm3_particle_desc *desc, const cm3_particle_traj *traj, int32_t n_ticks,
+                             void *stream);
+int cm3_particle_rollout_f64(const cm3_particle_desc *desc, const cm3_particle_traj *traj, int32_t n_ticks,
+                             void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Checkers env (env/checkers.py).  Compact live state, reference-shaped outputs.
+ *   mask     uint64 [E]      bit (k*n_columns + j) set <=> reward cell (row k, col j) collected
+ *   agents   uint32 [N][E]   r | c<<8 | n_green<<16 | n_orange<<24   (expanded-grid coordinates)
+ *   steps    int32  [E]
+ *   goals    uint8  [E][N]   index of the colour the agent wants (0 green, 1 orange): argmax of the
+ *                            reference's one-hot goals (checkers.py:234)
+ *   actions  int32  [E][N]
+ * Outputs (values identical to the reference's float64 arrays; integer-valued ones are stored as
+ * integers):
+ *   grid        int8   [E][n_rows][n_columns+1][2]        get_valid_grid (checkers.py:66-76)
+ *   vec         int32  [E][N][4]                          (r, c, n_green, n_orange) (:79-94)
+ *   obs_others  double [E][N][2*max(N-1,1)]               (:128-154, normalize :112-125)
+ *   obs_self_t  int8   [E][N][2*n_obs+1][2*n_obs+1][3]    get_obs (:97-109)
+ *   obs_self_v  double [E][N][4]
+ *   local_rewards double [E][N]; reward double [E]; done uint8 [E]   (:228-262)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct cm3_checkers_desc {
+  int32_t n_envs;
+  int32_t n_agents;   /* 1..CM3_MAX_AGENTS */
+  int32_t n_rows;     /* odd  (checkers.py:16) */
+  int32_t n_columns;  /* even (checkers.py:17); n_rows*n_columns <= 64 */
+  int32_t n_obs;
+  int32_t max_steps;
+  uint32_t flags;     /* CM3_FLAG_AUTO_RESET, CM3_FLAG_GEN_ACTIONS */
+  int32_t _pad;
+  int64_t env_id_base;
+  uint64_t seed;
+  int32_t agents_r[CM3_MAX_AGENTS]; /* before expansion, as in config_checkers_*.json */
+  int32_t agents_c[CM3_MAX_AGENTS];
+} cm3_checkers_desc;
+
+typedef struct cm3_checkers_bufs {
+  uint64_t *mask;      /* in/out */
+  uint32_t *agents;    /* in/out */
+  int32_t *steps;      /* in/out */
+  int32_t *episode;    /* in/out (RNG key for GEN_ACTIONS) */
+  uint8_t *goals;      /* in; rewritten only for N == 1 under AUTO_RESET (train_onpolicy.py:288-291) */
+  int32_t *actions;    /* in, or out under GEN_ACTIONS */
+  int8_t *grid;
+  int32_t *vec;
+  double *obs_others;
+  int8_t *obs_self_t;
+  double *obs_self_v;
+  double *local_rewards;
+  double *reward;
+  uint8_t *done;
+} cm3_checkers_bufs;
+
+/* Replaces Checkers.step (checkers.py:228-262): agents act sequentially in index order inside one lane. */
+int cm3_checkers_step(const cm3_checkers_desc *desc, const cm3_checkers_bufs *bufs, void *stream);
+/* Replaces Checkers.reset (checkers.py:265-291) for the envs selected by mask (NULL = all). */
+int cm3_checkers_reset(const cm3_checkers_desc *desc, const cm3_checkers_bufs *bufs, const uint8_t *mask,
+                       void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Measurement and launch plumbing
+ * ---------------------------------------------------------------------------------------- */
+/* Streaming 16-byte-per-lane read of `bytes` bytes (multiple of 16); writes one checksum word per
+ * workgroup to sink (>= 4*cm3_hbm_bench_sink_words() bytes).  The measured read-bandwidth roofline. */
+int cm3_hbm_read_bench(const void *buf, size_t bytes, void *sink, void *stream);
+int cm3_hbm_bench_sink_words(void);
+
+/* hipGraph capture of whatever is enqueued on `stream` between begin and end (launch-bound inner
+ * loops: 33 ticks per replay). */
+int cm3_graph_begin(void *stream);
+int cm3_graph_end(void *stream, void **graph_exec);
+int cm3_graph_launch(void *graph_exec, void *stream);
+int cm3_graph_destroy(void *graph_exec);
+
+/* HIP events on the caller's stream (bench.py times the kernel on the stream it is launched on). */
+int cm3_event_create(void **event);
+int cm3_event_record(void *event, void *stream);
+int cm3_event_synchronize(void *event);
+int cm3_event_elapsed_ms(void *start, void *stop, float *ms);
+int cm3_event_destroy(void *event);
+int cm3_stream_synchronize(void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CM3_AMD_H */

@@ -1,0 +1,283 @@
+"""GPU parity: the HIP particle kernels (through the C ABI / VecParticleEnv) against
+  (a) the golden vectors recorded from the reference (tests/golden/particle_*.npz), and
+  (b) the NumPy oracle on fresh random states at BASELINE sizes.
+
+Tolerances (BASELINE.json north_star): float32 dynamics within 1e-5 PER TICK with the oracle's
+float64 state injected before every tick; samples within 2e-6 of the two
+discontinuities (collision radius 0.3, reach radius 0.05) are excluded from reward / done / collision
+comparisons and counted (item 3).  The float64 instantiation free-runs whole episodes and must stay
+within 1e-9 of the reference (only exp/log1p ulps differ).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import philox
+from oracle.particle_oracle import VecParticleOracle
+from tests.helpers import golden_names, load_cfg, load_golden
+
+pytestmark = pytest.mark.gpu
+
+TOL32 = 1e-5
+EDGE = 2e-6
+NAMES = golden_names("particle_")
+
+
+def _env(cfg, N, E, dtype=torch.float32, prob_random=0.2, max_steps=33, **kw):
+    from cm3_amd.particle import VecParticleEnv
+    return VecParticleEnv(cfg, N, prob_random, max_steps, E, device="cuda:0", dtype=dtype, **kw)
+
+
+def _np(t):
+    return t.detach().cpu().numpy().astype(np.float64)
+
+
+def _maxabs(x):
+    return float(np.abs(x).max()) if x.size else 0.0
+
+
+def _margins(pos, landmarks):
+    """distance of each env's post-step configuration from the two thresholds"""
+    E, N, _ = pos.shape
+    m_col = np.full(E, np.inf)
+    for i in range(N):
+        for j in range(i + 1, N):
+            d = np.sqrt(((pos[:, i] - pos[:, j]) ** 2).sum(-1))
+            m_col = np.minimum(m_col, np.abs(d - 0.3))
+    m_reach = np.abs(np.sqrt(((pos - landmarks) ** 2).sum(-1)) - 0.05).min(axis=1)
+    return m_col, m_reach
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_f32_teacher_forced_vs_reference_golden(name):
+    g = load_golden(name)
+    m = g["meta"]
+    N, Ep, T = m["n_agents"], len(g["ep_len"]), int(g["ep_len"].max())
+    env = _env(m["config"], N, Ep, prob_random=m["prob_random"])
+    prev_gs, prev_col = g["init_gs"], np.zeros(Ep, np.int64)
+    skipped = 0
+    for t in range(T):
+        live = g["ep_len"] > t
+        gs_in = np.where(live[:, None, None], prev_gs, 0.0)
+        gs0, oo0 = env.set_state(gs_in[..., 2:4], gs_in[..., 0:2], g["landmarks"], steps=np.full(Ep, t),
+                                 collisions=prev_col)
+        if t == 0:
+            assert _maxabs(_np(oo0) - g["init_obs_others"]) < TOL32
+        acts = np.where(live[:, None], g["actions"][:, t], 0)
+        gs, oo, os_, rew, rew_n, done = env.step(torch.as_tensor(acts))
+        gs, oo, os_, rew, rew_n = map(_np, (gs, oo, os_, rew, rew_n))
+        done = done.cpu().numpy()
+        col = env.collisions.cpu().numpy()
+        want = g["gs"][:, t]
+        assert _maxabs(gs[live] - want[live]) < TOL32, (name, t)
+        assert _maxabs(os_[live] - g["obs_self"][live, t]) < TOL32
+        assert _maxabs(oo[live] - g["obs_others"][live, t]) < 2 * TOL32
+        m_col, m_reach = _margins(want[..., 2:4], g["landmarks"])
+        safe = live & (m_col > EDGE) & (m_reach > EDGE)
+        skipped += int((live & ~safe).sum())
+        assert _maxabs(rew_n[safe] - g["reward_n"][safe, t]) < TOL32
+        assert _maxabs(rew[safe] - g["reward"][safe, t]) < N * TOL32
+        assert np.array_equal(done[safe], g["done"][safe, t]), (name, t)
+        assert np.array_equal(col[safe], g["collisions"][safe, t])
+        prev_gs = np.where(live[:, None, None], want, prev_gs)
+        prev_col = np.where(live, g["collisions"][:, t], prev_col)
+    assert skipped <= 3        # near-threshold samples are rare (SURVEY: ~1 in 100k pair-steps)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_f64_free_running_vs_reference_golden(name):
+    """Whole episodes in the float64 instantiation, no re-injection: state, rewards, done, collisions."""
+    g = load_golden(name)
+    m = g["meta"]
+    N, Ep, T = m["n_agents"], len(g["ep_len"]), int(g["ep_len"].max())
+    env = _env(m["config"], N, Ep, dtype=torch.float64, prob_random=m["prob_random"])
+    gs0 = g["init_gs"]
+    env.set_state(gs0[..., 2:4], gs0[..., 0:2], g["landmarks"])
+    for t in range(T):
+        live = g["ep_len"] > t
+        acts = np.where(live[:, None], g["actions"][:, t], 0)
+        gs, oo, os_, rew, rew_n, done = env.step(torch.as_tensor(acts))
+        gs, oo, rew, rew_n = map(_np, (gs, oo, rew, rew_n))
+        assert _maxabs(gs[live] - g["gs"][live, t]) < 1e-9, (name, t)
+        assert _maxabs(oo[live] - g["obs_others"][live, t]) < 1e-9
+        assert _maxabs(rew_n[live] - g["reward_n"][live, t]) < 1e-9
+        assert _maxabs(rew[live] - g["reward"][live, t]) < 1e-8
+        assert np.array_equal(done.cpu().numpy()[live], g["done"][live, t])
+        assert np.array_equal(env.collisions.cpu().numpy()[live], g["collisions"][live, t])
+        assert np.array_equal(env.steps.cpu().numpy()[live], np.full(live.sum(), t + 1))
+
+
+def _random_states(rng, E, N, crowd=0.5):
+    """positions in [-1,1]^2 with a fraction of envs squeezed so that contacts are common"""
+    pos = rng.uniform(-1, 1, (E, N, 2))
+    squeeze = rng.random(E) < crowd
+    pos[squeeze] *= 0.25
+    vel = rng.normal(0, 0.7, (E, N, 2))
+    lm = rng.uniform(-1, 1, (E, N, 2))
+    near = rng.random((E, N)) < 0.1           # some agents sit near their landmark
+    lm[near] = pos[near] + rng.normal(0, 0.03, (int(near.sum()), 2))
+    return pos, vel, lm
+
+
+@pytest.mark.parametrize("cfg_name,N,E", [("particle_stage1.json", 1, 1), ("particle_stage2_antipodal.json", 4, 4096),
+                                           ("particle_stage2_merge.json", 2, 1000),
+                                           ("particle_stage2_cross.json", 4, 4096 + 37),
+                                           ("particle_merge8.json", 8, 8192), ("particle_merge8.json", 3, 777),
+                                           ("particle_merge8.json", 5, 300), ("particle_merge8.json", 6, 129),
+                                           ("particle_merge8.json", 7, 64)])
+def test_f32_random_states_vs_oracle(cfg_name, N, E):
+    """BASELINE configs C1/C2/C4(per-GPU)/C5(per-GPU) + ragged sizes and every agent count."""
+    cfg = load_cfg(cfg_name)
+    rng = np.random.default_rng(1234 + N * 1000 + E)
+    env = _env(cfg, N, E)
+    orc = VecParticleOracle(N, cfg, 0.2, 33, E)
+    bad = 0
+    for it in range(3):
+        pos, vel, lm = _random_states(rng, E, N)
+        pos32, vel32, lm32 = (x.astype(np.float32).astype(np.float64) for x in (pos, vel, lm))
+        steps = rng.integers(0, 33, E)
+        col = rng.integers(0, 50, E)
+        acts = rng.integers(-1, 7, (E, N))
+        orc.set_state(pos32, vel32, lm32, steps, col)
+        w_gs, w_oo, w_os, w_rew, w_rn, w_done = orc.step(acts)
+        env.set_state(pos32, vel32, lm32, steps, col)
+        gs, oo, os_, rew, rew_n, done = env.step(torch.as_tensor(acts))
+        gs, oo, rew, rew_n = map(_np, (gs, oo, rew, rew_n))
+        assert _maxabs(gs - w_gs) < TOL32
+        assert _maxabs(oo - w_oo) < 2 * TOL32
+        m_col, m_reach = orc.pair_margins()
+        safe = (m_col > EDGE) & (m_reach > EDGE)
+        bad += int((~safe).sum())
+        assert _maxabs(rew_n[safe] - w_rn[safe]) < TOL32
+        assert _maxabs(rew[safe] - w_rew[safe]) < N * TOL32
+        assert np.array_equal(done.cpu().numpy()[safe], w_done[safe])
+        assert np.array_equal(env.collisions.cpu().numpy()[safe], orc.collisions[safe])
+        assert np.array_equal(env.steps.cpu().numpy(), orc.steps)
+    assert bad <= max(2, E * 3 // 5000)
+
+
+def test_f64_random_states_vs_oracle():
+    cfg = load_cfg("particle_stage2_antipodal.json")
+    rng = np.random.default_rng(5)
+    E, N = 2048, 4
+    env = _env(cfg, N, E, dtype=torch.float64)
+    orc = VecParticleOracle(N, cfg, 0.2, 33, E)
+    pos, vel, lm = _random_states(rng, E, N)
+    acts = rng.integers(0, 5, (E, N))
+    orc.set_state(pos, vel, lm)
+    w_gs, w_oo, _, w_rew, w_rn, w_done = orc.step(acts)
+    env.set_state(pos, vel, lm)
+    gs, oo, _, rew, rew_n, done = env.step(torch.as_tensor(acts))
+    assert _maxabs(_np(gs) - w_gs) < 1e-11
+    assert _maxabs(_np(oo) - w_oo) < 1e-11
+    assert _maxabs(_np(rew_n) - w_rn) < 1e-11
+    assert np.array_equal(done.cpu().numpy(), w_done)
+    assert np.array_equal(env.collisions.cpu().numpy(), orc.collisions)
+
+
+def test_structural_properties_full_size():
+    """Size-independent properties at the BASELINE C2 size after a 33-tick in-kernel random rollout:
+    obs rows are exact differences of state rows, reward == ordered sum of reward_n, done <=> rule."""
+    cfg = load_cfg("particle_stage2_antipodal.json")
+    E, N = 4096, 4
+    env = _env(cfg, N, E)
+    env.reset()
+    for t in range(33):
+        gs, oo, os_, rew, rew_n, done = env.step()
+    gs, oo, rew, rew_n = gs.cpu(), oo.cpu(), rew.cpu(), rew_n.cpu()
+    for i in range(N):
+        for k in range(N - 1):
+            j = k if k < i else k + 1
+            assert torch.equal(oo[:, i, 4 * k:4 * k + 4], gs[:, j] - gs[:, i])
+    acc = rew_n[:, 0].clone()
+    for i in range(1, N):
+        acc = acc + rew_n[:, i]
+    assert torch.equal(acc, rew)
+    assert bool(done.all())                      # steps == max_steps
+    assert torch.equal(env.steps.cpu(), torch.full((E,), 33, dtype=torch.int32))
+    assert torch.isfinite(gs).all()
+
+
+def test_generated_actions_and_reset_match_philox_spec_and_are_shard_invariant():
+    cfg = load_cfg("particle_stage2_merge.json")          # initial_std = 0.05: exercises Box-Muller
+    E, N, seed = 1024, 2, 99
+    full = _env(cfg, N, E, dtype=torch.float64, seed=seed)
+    full.reset()
+    pos, lm, rnd = philox.expected_reset(seed, np.arange(E), 1, cfg, N, 0.2)
+    gs = _np(full.global_state)
+    assert _maxabs(gs[..., 2:4] - pos) < 1e-12 and np.all(gs[..., 0:2] == 0)
+    assert _maxabs(_np(full.goals) - lm) < 1e-15
+    assert 0.1 < rnd.mean() < 0.3
+    full.step()
+    want = philox.expected_actions(seed, np.arange(E), 1, 0, N)
+    assert np.array_equal(full.last_actions.cpu().numpy(), want)
+    # second half of the envs as its own shard: identical results
+    half = _env(cfg, N, E // 2, dtype=torch.float64, seed=seed, env_id_base=E // 2)
+    half.reset()
+    half.step()
+    assert torch.equal(half.global_state, full.global_state[E // 2:])
+    assert torch.equal(half.last_actions, full.last_actions[E // 2:])
+    # float32 reset is the rounded float64 reset
+    f32 = _env(cfg, N, E, dtype=torch.float32, seed=seed)
+    f32.reset()
+    assert _maxabs(_np(f32.global_state)[..., 2:4] - pos) < 1e-7
+
+
+def test_auto_reset_semantics():
+    """Under AUTO_RESET a finished env returns terminal reward/done, the fresh episode's state/obs, and the
+    true terminal next-state in term_state; the step counter restarts (train_onpolicy.py:282 folded in)."""
+    cfg = load_cfg("particle_stage2_antipodal.json")
+    E, N, seed = 512, 4, 3
+    env = _env(cfg, N, E, dtype=torch.float64, seed=seed, auto_reset=True, max_steps=5)
+    ref = _env(cfg, N, E, dtype=torch.float64, seed=seed, auto_reset=False, max_steps=5)
+    env.enable_terminal_capture()
+    env.reset()
+    ref.reset()
+    for t in range(5):
+        a = env.step()
+        b = ref.step(env.last_actions)
+        assert torch.equal(a[3], b[3]) and torch.equal(a[5], b[5])
+        if t < 4:
+            assert torch.equal(a[0], b[0])
+    assert bool(a[5].all())
+    assert torch.equal(env.terminal_state, b[0])                 # true terminal next-state
+    assert torch.equal(env.terminal_obs_others, b[1])
+    pos, lm, _ = philox.expected_reset(seed, np.arange(E), 2, cfg, N, 0.2)
+    assert _maxabs(_np(env.global_state)[..., 2:4] - pos) < 1e-12
+    assert _maxabs(_np(env.goals) - lm) < 1e-15
+    assert int(env.steps.max()) == 0 and int(env.collisions.max()) == 0
+    assert torch.equal(env.episode.cpu(), torch.full((E,), 2, dtype=torch.int32))
+
+
+def test_partial_reset_mask_and_out_of_range_actions():
+    cfg = load_cfg("particle_stage2_cross.json")
+    E, N = 300, 4
+    env = _env(cfg, N, E, dtype=torch.float64)
+    env.reset()
+    for _ in range(3):
+        env.step()
+    before = env.global_state.clone()
+    mask = torch.zeros(E, dtype=torch.bool)
+    mask[::3] = True
+    env.reset(mask=mask)
+    after = env.global_state
+    assert torch.equal(after[~mask.cuda()], before[~mask.cuda()])
+    assert (after[mask.cuda()][..., 0:2] == 0).all()
+    # actions outside 1..4 apply no force (environment.py:197-200)
+    st = env.get_state()
+    a5 = torch.full((E, N), 5, dtype=torch.int32)
+    a0 = torch.zeros((E, N), dtype=torch.int32)
+    g5 = env.step(a5)[0].clone()
+    env.set_state(st["pos"], st["vel"], st["landmarks"], st["steps"], st["collisions"])
+    g0 = env.step(a0)[0]
+    assert torch.equal(g5, g0)
+
+
+def test_bad_arguments_raise():
+    from cm3_amd import Cm3Error
+    cfg = load_cfg("particle_stage2_antipodal.json")
+    env = _env(cfg, 4, 8)
+    with pytest.raises(Cm3Error):
+        env.step(torch.zeros(8, 3, dtype=torch.int32))
+    with pytest.raises(Cm3Error):
+        _env(cfg, 9, 8)
