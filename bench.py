@@ -42,16 +42,17 @@ class ParticleStepper(object):
     """In-place stepping of E envs through the C ABI (zero strides = every tick overwrites the same
     live buffers), optionally replayed as a hipGraph."""
 
-    def __init__(self, cfg, n_agents, n_envs, device, seed=12341, env_id_base=0, max_steps=33, prob_random=0.2):
+    def __init__(self, cfg, n_agents, n_envs, device, seed=12341, env_id_base=0, max_steps=33, prob_random=0.2,
+                 kernel="auto"):
         import torch
         from cm3_amd import _lib
         from cm3_amd.particle import VecParticleEnv
         self.torch, self._lib_mod, self.lib = torch, _lib, _lib.lib()
         self.env = VecParticleEnv(cfg, n_agents, prob_random, max_steps, n_envs, device=device, seed=seed,
-                                  dtype=torch.float32, auto_reset=True, env_id_base=env_id_base)
+                                  dtype=torch.float32, auto_reset=True, env_id_base=env_id_base, kernel=kernel)
         self.env.reset()
         e = self.env
-        e._desc.flags = _lib.FLAG_AUTO_RESET | _lib.FLAG_GEN_ACTIONS
+        e._desc.flags = _lib.FLAG_AUTO_RESET | _lib.FLAG_GEN_ACTIONS | e.kernel_flags
         t = self.traj = _lib.ParticleTraj()
         t.state = e._state[0].data_ptr()
         t.goals = e._goals.data_ptr()
@@ -163,6 +164,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-sweep", action="store_true", help="skip the E-sweep (extra 'sweep' field)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel", choices=["auto", "env", "pair"], default="auto",
+                    help="step-kernel mapping (auto = library heuristic)")
     args = ap.parse_args()
 
     import torch
@@ -194,7 +197,7 @@ def main():
     N = cfg["n_agents"]
     E = args.envs_per_gpu
     K, W = args.steps, args.warmup
-    stepper = ParticleStepper(cfg, N, E, device, env_id_base=rank * E)
+    stepper = ParticleStepper(cfg, N, E, device, env_id_base=rank * E, kernel=args.kernel)
     if not args.no_graph:
         stepper.capture(GRAPH_TICKS)
     stepper.run(max(W, 1))
@@ -250,7 +253,7 @@ def main():
             del stepper
             for log2e in (14, 16, 18, 20, 22):
                 Es = 1 << log2e
-                st = ParticleStepper(cfg, N, Es, device)
+                st = ParticleStepper(cfg, N, Es, device, kernel=args.kernel)
                 st.capture(GRAPH_TICKS)
                 st.run(GRAPH_TICKS)
                 torch.cuda.synchronize(device)

@@ -14,6 +14,9 @@ ABI_VERSION = 1
 
 FLAG_AUTO_RESET = 1
 FLAG_GEN_ACTIONS = 2
+FLAG_KERNEL_LANE_PER_ENV = 0x100
+FLAG_KERNEL_LANE_PER_PAIR = 0x200
+KERNEL_FLAGS = {"auto": 0, "env": FLAG_KERNEL_LANE_PER_ENV, "pair": FLAG_KERNEL_LANE_PER_PAIR}
 
 
 class Cm3Error(RuntimeError):

@@ -18,6 +18,24 @@
 #include "common.h"
 #include "philox.h"
 
+// Timeline instrumentation for tools/probes/step_timeline.hip only (never defined in the product build).
+#ifdef CM3_STAMPS
+extern __device__ long long *cm3_stamp_buf;
+#define CM3_STAMP(slot, drain)                                                                        \
+  do {                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    if (drain) __builtin_amdgcn_s_waitcnt(0);                                                         \
+    const long long _t = clock64();                                                                   \
+    if ((threadIdx.x & 63) == 0)                                                                      \
+      cm3_stamp_buf[((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + (slot)] = _t; \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+  } while (0)
+#else
+#define CM3_STAMP(slot, drain) \
+  do {                         \
+  } while (0)
+#endif
+
 namespace cm3 {
 
 struct ParticleParams {
@@ -68,6 +86,32 @@ template <typename R> __device__ __forceinline__ R logaddexp0(R x) {
   R r = (x > R(0) ? x : R(0)) + t;
   if (x == R(0)) r = R(0.693147180559945309417232121458176568);
   return r;
+}
+
+// Soft contact between two agents (core.py:180-196), own-side force for delta = p_self - p_other:
+//   dist = sqrt(dx^2 + dy^2); pen = logaddexp(0, -(dist - 0.3)/1e-3) * 1e-3; f = 100 * delta / dist * pen.
+// The reference evaluates this for every agent pair every tick.  Beyond kSkip the soft-plus underflows to
+// exactly 0 in the working precision (float: exp(x) = 0 for x <= -110, i.e. dist >= 0.41; double: x <= -750,
+// dist >= 1.05), pen == 0 and the force is (+-)0, which leaves every accumulator bit-unchanged -- so the
+// transcendental chain is skipped there.  NaN distances take the slow path (NaN propagates as in the reference).
+template <typename R> struct Contact;
+template <> struct Contact<float> {
+  static constexpr float kSkip = 0.41f;
+};
+template <> struct Contact<double> {
+  static constexpr double kSkip = 1.05;
+};
+
+template <typename R> __device__ __forceinline__ void contact_force(R dx, R dy, R &f_x, R &f_y) {
+  const R kMargin = R(1e-3), kForce = R(1e+2), kDistMin = R(0.15) + R(0.15);
+  const R dist = Math<R>::sqrt(dx * dx + dy * dy);
+  f_x = R(0);
+  f_y = R(0);
+  if (!(dist >= Contact<R>::kSkip)) {
+    const R pen = logaddexp0<R>(-(dist - kDistMin) / kMargin) * kMargin;
+    f_x = kForce * dx / dist * pen;
+    f_y = kForce * dy / dist * pen;
+  }
 }
 
 template <typename R, typename V4> __device__ __forceinline__ V4 sub4(const V4 &a, const V4 &b) {
@@ -209,41 +253,63 @@ __device__ __forceinline__ void store_obs_others_direct(const typename Vec<R>::v
 }
 
 // ---- episode initialisation (multi-goal_spread.py:65-93), double arithmetic for both reals ---------
+// One Bernoulli(prob_random) per episode shared by agents AND landmarks (:75).
+__device__ __forceinline__ bool episode_is_random(const ParticleParams &p, uint64_t genv, uint32_t episode) {
+  return u01(reset_words(p.seed, genv, episode, 0).x) < p.prob_random;
+}
+
+// Agent i (and its landmark) of the fresh episode.  `i` may be a run-time value: the config arrays are read
+// through a compare-select chain, never through a dynamically indexed private array.
+template <typename R, int N>
+__device__ __forceinline__ void init_agent(const ParticleParams &p, uint64_t genv, uint32_t episode, bool rnd, int i,
+                                           typename Vec<R>::v4 &s, typename Vec<R>::v2 &g) {
+  const u32x4 a = reset_words(p.seed, genv, episode, 1u + (uint32_t)i);
+  double x, y;
+  if (rnd) {  // :77-78
+    x = 2.0 * u01(a.x) - 1.0;
+    y = 2.0 * u01(a.y) - 1.0;
+  } else {  // :80-83
+    double cx = 0.0, cy = 0.0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      cx = (k == i) ? p.ax[k] : cx;
+      cy = (k == i) ? p.ay[k] : cy;
+    }
+    x = cx;
+    y = cy;
+    if (p.initial_std != 0.0) {  // Box-Muller pair; std == 0 gives preset + 0 exactly as the reference
+      const double rad = ::sqrt(-2.0 * ::log(u01(a.z)));
+      const double ang = 6.283185307179586476925286766559 * u01(a.w);
+      x = x + p.initial_std * (rad * ::cos(ang));
+      y = y + p.initial_std * (rad * ::sin(ang));
+    }
+  }
+  s.x = R(0);
+  s.y = R(0);
+  s.z = R(x);
+  s.w = R(y);
+  if (rnd) {  // :88-89
+    const u32x4 l = reset_words(p.seed, genv, episode, 1u + (uint32_t)N + (uint32_t)i);
+    g.x = R(2.0 * u01(l.x) - 1.0);
+    g.y = R(2.0 * u01(l.y) - 1.0);
+  } else {  // :91
+    double lx = 0.0, ly = 0.0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      lx = (k == i) ? p.lx[k] : lx;
+      ly = (k == i) ? p.ly[k] : ly;
+    }
+    g.x = R(lx);
+    g.y = R(ly);
+  }
+}
+
 template <typename R, int N>
 __device__ __forceinline__ void init_episode(const ParticleParams &p, uint64_t genv, uint32_t episode,
                                              typename Vec<R>::v4 (&s)[N], typename Vec<R>::v2 (&g)[N]) {
-  const u32x4 w0 = reset_words(p.seed, genv, episode, 0);
-  const bool rnd = u01(w0.x) < p.prob_random;  // ONE draw per episode shared by agents and landmarks (:75)
+  const bool rnd = episode_is_random(p, genv, episode);
 #pragma unroll
-  for (int i = 0; i < N; ++i) {
-    const u32x4 a = reset_words(p.seed, genv, episode, 1 + i);
-    double x, y;
-    if (rnd) {  // :77-78
-      x = 2.0 * u01(a.x) - 1.0;
-      y = 2.0 * u01(a.y) - 1.0;
-    } else {  // :80-83
-      x = p.ax[i];
-      y = p.ay[i];
-      if (p.initial_std != 0.0) {  // Box-Muller pair; std == 0 gives preset + 0 exactly as the reference
-        const double rad = ::sqrt(-2.0 * ::log(u01(a.z)));
-        const double ang = 6.283185307179586476925286766559 * u01(a.w);
-        x = x + p.initial_std * (rad * ::cos(ang));
-        y = y + p.initial_std * (rad * ::sin(ang));
-      }
-    }
-    s[i].x = R(0);
-    s[i].y = R(0);
-    s[i].z = R(x);
-    s[i].w = R(y);
-    if (rnd) {  // :88-89
-      const u32x4 l = reset_words(p.seed, genv, episode, 1 + N + i);
-      g[i].x = R(2.0 * u01(l.x) - 1.0);
-      g[i].y = R(2.0 * u01(l.y) - 1.0);
-    } else {  // :91
-      g[i].x = R(p.lx[i]);
-      g[i].y = R(p.ly[i]);
-    }
-  }
+  for (int i = 0; i < N; ++i) init_agent<R, N>(p, genv, episode, rnd, i, s[i], g[i]);
 }
 
 // ---- the step kernel --------------------------------------------------------------------------------
@@ -260,6 +326,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step(const ParticlePara
   const bool active = e < (size_t)p.E;
   const size_t ec = active ? e : (size_t)p.E - 1;  // clamped index for loads
   const size_t E = (size_t)p.E;
+  CM3_STAMP(0, false);
 
   // ---- loads: one vector per lane per array row, unit stride over e --------------------------------
   V4 s[N];
@@ -295,6 +362,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step(const ParticlePara
     load_row<int32_t, N>(p.actions, ec, act);
   }
 
+  CM3_STAMP(1, true);
   // ---- _set_action (environment.py:193-214) + apply_action_force (core.py:134-140) ------------------
   R fx[N], fy[N];
 #pragma unroll
@@ -309,15 +377,13 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step(const ParticlePara
   }
 
   // ---- apply_environment_force (core.py:143-155) / get_collision_force (:180-196) -------------------
-  const R kMargin = R(1e-3), kForce = R(1e+2), kDistMin = R(0.15) + R(0.15);
+  const R kDistMin = R(0.15) + R(0.15);
 #pragma unroll
   for (int a = 0; a < N; ++a) {
 #pragma unroll
     for (int b = a + 1; b < N; ++b) {
-      const R dx = s[a].z - s[b].z, dy = s[a].w - s[b].w;
-      const R dist = Math<R>::sqrt(dx * dx + dy * dy);
-      const R pen = logaddexp0<R>(-(dist - kDistMin) / kMargin) * kMargin;
-      const R f_x = kForce * dx / dist * pen, f_y = kForce * dy / dist * pen;
+      R f_x, f_y;
+      contact_force<R>(s[a].z - s[b].z, s[a].w - s[b].w, f_x, f_y);
       fx[a] = f_x + fx[a];
       fy[a] = f_y + fy[a];
       fx[b] = (-f_x) + fx[b];
@@ -337,6 +403,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step(const ParticlePara
     s[i].w = s[i].w + s[i].y * kDt;
   }
   steps += 1;  // environment.py:93
+  CM3_STAMP(2, false);
 
   // ---- reward / reached (multi-goal_spread.py:121-143) ------------------------------------------------
   R rew[N];
@@ -363,11 +430,13 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step(const ParticlePara
   const R reward = sum_agents<R, N>(rew);                       // environment.py:107
   const bool done = (steps == p.max_steps) || all_reached;      // environment.py:118-121
 
+  CM3_STAMP(3, false);
   if (active) {
     store_row<R, N>(reinterpret_cast<R *>(p.reward_n), e, rew);
     reinterpret_cast<R *>(p.reward)[e] = reward;
     p.done[e] = done ? 1 : 0;
   }
+  CM3_STAMP(8, false);
 
   // ---- same-launch re-initialisation of finished episodes ---------------------------------------------
   bool was_reset = false;
@@ -387,6 +456,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step(const ParticlePara
     was_reset = true;
     if (active) p.episode[e] = (int32_t)episode;
   }
+  CM3_STAMP(9, false);
 
   if (active) {
     V4 *sout4 = reinterpret_cast<V4 *>(p.state_out);
@@ -403,8 +473,178 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step(const ParticlePara
     reinterpret_cast<int2 *>(p.meta_out)[e] = m;
   }
 
+  CM3_STAMP(4, false);
   // ---- observation (multi-goal_spread.py:145-154), env-major rows through the wave's LDS tile ----------
   store_obs_others_staged<R, N>(s, &lds_all[wave][0], lane, e0, p.E, reinterpret_cast<R *>(p.obs_others));
+  CM3_STAMP(5, false);
+  CM3_STAMP(6, true);
+}
+
+// ---- the step kernel, second mapping: ONE LANE PER ORDERED AGENT PAIR -------------------------------------
+// For small and medium batches the lane-per-env kernel is latency-bound: a 4096-env tick is only 64 waves,
+// each walking all C(N,2) contact evaluations, N(N-1)/2 collision tests and N reward distances serially.
+// Here an env owns a group of G = pow2 >= N(N-1) consecutive lanes; lane (i,k) handles agent i and its k-th
+// other agent j.  It evaluates ONE contact force (own side: delta = p_i - p_j, bit-identical to the
+// reference's +-force of the unordered pair because IEEE subtraction/negation are sign-symmetric), the N-1
+// contributions of agent i are gathered with wavefront shuffles and added in the reference's order (j
+// ascending = pair order of core.py:145-147), the post-step positions of j come back by shuffle, and the
+// collision tests / reached flags are reduced with wave ballots.  No LDS: lane (i,k) writes the obs_others
+// vector (i,k), so a wave stores 64/G whole env records contiguously (16 B per lane, unit stride).
+template <int N> struct PairGeom {
+  static constexpr int NO = N - 1;
+  static constexpr int SLOTS = N * NO;
+  static constexpr int pow2ceil(int v) {
+    int r = 1;
+    while (r < v) r <<= 1;
+    return r;
+  }
+  static constexpr int G = pow2ceil(SLOTS);
+  static constexpr int EPW = 64 / G;  // envs per wave
+};
+
+template <typename R, int N, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) k_particle_step_pairs(const ParticleParams p) {
+  static_assert(N >= 2, "the pair mapping needs at least two agents");
+  using V4 = typename Vec<R>::v4;
+  using V2 = typename Vec<R>::v2;
+  using PG = PairGeom<N>;
+  constexpr int NO = PG::NO, SLOTS = PG::SLOTS, G = PG::G, EPW = PG::EPW;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int gslot = lane & (G - 1), sub = lane / G, base = lane - gslot;
+  const size_t E = (size_t)p.E;
+  const size_t e = ((size_t)blockIdx.x * WAVES + wave) * EPW + sub;
+  const bool env_ok = e < E;
+  const size_t ec = env_ok ? e : E - 1;
+  const bool slot_ok = gslot < SLOTS;
+  const int gi = slot_ok ? gslot : 0;
+  const int i = gi / NO, k = gi - i * NO, j = k < i ? k : k + 1;
+  const bool lead = slot_ok && k == 0;  // one lane per agent does the per-agent stores
+  const bool head = gslot == 0;         // one lane per env does the per-env stores
+
+  // ---- loads -----------------------------------------------------------------------------------------------
+  const V4 *sin4 = reinterpret_cast<const V4 *>(p.state_in);
+  V4 si = sin4[(size_t)i * E + ec];
+  const V4 sj_in = sin4[(size_t)j * E + ec];
+  V2 gl = reinterpret_cast<const V2 *>(p.goals_in)[(size_t)i * E + ec];
+  const int2 meta = reinterpret_cast<const int2 *>(p.meta_in)[ec];
+  int steps = meta.x, collisions = meta.y;
+  const bool gen = (p.flags & CM3_FLAG_GEN_ACTIONS) != 0;
+  uint32_t episode = 0;
+  if (gen || (p.flags & CM3_FLAG_AUTO_RESET)) episode = (uint32_t)p.episode[ec];
+  const uint64_t genv = (uint64_t)(p.env_id_base + (int64_t)ec);
+  int act;
+  if (gen) {  // train_onpolicy.py:305-307
+    const u32x4 w = action_words(p.seed, genv, episode, (uint32_t)steps, (uint32_t)(i >> 2));
+    const int q = i & 3;
+    act = rand5(q == 0 ? w.x : (q == 1 ? w.y : (q == 2 ? w.z : w.w)));
+    if (env_ok && lead) p.actions[e * N + i] = act;
+  } else {
+    act = p.actions[ec * N + i];
+  }
+
+  // ---- action force + own contact force ----------------------------------------------------------------------
+  R ux = R(0), uy = R(0);
+  if (act == 1) ux = R(-1);
+  if (act == 2) ux = R(+1);
+  if (act == 3) uy = R(-1);
+  if (act == 4) uy = R(+1);
+  R Fx = ux * R(5.0) + R(0.0), Fy = uy * R(5.0) + R(0.0);
+  R f_x, f_y;
+  contact_force<R>(si.z - sj_in.z, si.w - sj_in.w, f_x, f_y);
+#pragma unroll
+  for (int kk = 0; kk < NO; ++kk) {  // contributions of agent i in the reference's order (j ascending)
+    const int src = base + i * NO + kk;
+    Fx = __shfl(f_x, src, 64) + Fx;
+    Fy = __shfl(f_y, src, 64) + Fy;
+  }
+
+  // ---- integrate agent i (every lane of agent i computes the same values) -----------------------------------
+  const R kDt = R(0.1), kKeep = R(1 - 0.25), kDistMin = R(0.15) + R(0.15);
+  si.x = si.x * kKeep;
+  si.y = si.y * kKeep;
+  si.x = si.x + (Fx / R(1.0)) * kDt;
+  si.y = si.y + (Fy / R(1.0)) * kDt;
+  si.z = si.z + si.x * kDt;
+  si.w = si.w + si.y * kDt;
+  steps += 1;
+  V4 sj;
+  {
+    const int src = base + j * NO;  // lead lane of agent j
+    sj.x = __shfl(si.x, src, 64);
+    sj.y = __shfl(si.y, src, 64);
+    sj.z = __shfl(si.z, src, 64);
+    sj.w = __shfl(si.w, src, 64);
+  }
+
+  // ---- reward / reached / collisions (multi-goal_spread.py:114-143) ------------------------------------------
+  R rew;
+  {
+    const R dx = si.z - gl.x, dy = si.w - gl.y;
+    rew = R(0) - Math<R>::sqrt(dx * dx + dy * dy);
+  }
+  const bool reached = rew >= R(-0.05);
+  bool hit;
+  {
+    const R dx = sj.z - si.z, dy = sj.w - si.w;  // is_collision(a = j, agent = i)
+    hit = slot_ok && (Math<R>::sqrt(dx * dx + dy * dy) < kDistMin);
+  }
+  const unsigned long long hits = __ballot(hit);
+  const unsigned long long grp = (G == 64) ? hits : ((hits >> base) & ((1ull << (G & 63)) - 1ull));
+  const int c_i = __popcll((grp >> (i * NO)) & ((1ull << NO) - 1ull));
+#pragma unroll
+  for (int c = 0; c < NO; ++c)
+    if (c < c_i) rew = rew - R(1);
+  collisions += __popcll(grp);  // every ordered visit counts (:135-137)
+  const unsigned long long rb = __ballot(reached && lead);
+  const unsigned long long rgrp = (G == 64) ? rb : ((rb >> base) & ((1ull << (G & 63)) - 1ull));
+  const bool all_reached = __popcll(rgrp) == N;
+  R rews[N];
+#pragma unroll
+  for (int a = 0; a < N; ++a) rews[a] = __shfl(rew, base + a * NO, 64);
+  const R reward = sum_agents<R, N>(rews);
+  const bool done = (steps == p.max_steps) || all_reached;
+
+  if (env_ok && lead) reinterpret_cast<R *>(p.reward_n)[e * N + i] = rew;
+  if (env_ok && head) {
+    reinterpret_cast<R *>(p.reward)[e] = reward;
+    p.done[e] = done ? 1 : 0;
+  }
+
+  // ---- same-launch re-initialisation ---------------------------------------------------------------------------
+  bool was_reset = false;
+  if ((p.flags & CM3_FLAG_AUTO_RESET) && done) {
+    if (env_ok) {
+      if (p.term_state && lead) reinterpret_cast<V4 *>(p.term_state)[(size_t)i * E + e] = si;
+      if (p.term_obs_others && slot_ok)
+        reinterpret_cast<V4 *>(p.term_obs_others)[e * SLOTS + gslot] = sub4<R, V4>(sj, si);
+    }
+    episode += 1;
+    const bool rnd = episode_is_random(p, genv, episode);
+    V2 gj;
+    init_agent<R, N>(p, genv, episode, rnd, i, si, gl);
+    init_agent<R, N>(p, genv, episode, rnd, j, sj, gj);
+    steps = 0;
+    collisions = 0;
+    was_reset = true;
+    if (env_ok && head) p.episode[e] = (int32_t)episode;
+  }
+
+  // ---- stores ----------------------------------------------------------------------------------------------------
+  if (env_ok) {
+    if (lead) {
+      reinterpret_cast<V4 *>(p.state_out)[(size_t)i * E + e] = si;
+      if (p.goals_out != p.goals_in || was_reset) reinterpret_cast<V2 *>(p.goals_out)[(size_t)i * E + e] = gl;
+    }
+    if (head) {
+      int2 m;
+      m.x = steps;
+      m.y = collisions;
+      reinterpret_cast<int2 *>(p.meta_out)[e] = m;
+    }
+    // observation (multi-goal_spread.py:145-154): vector (i,k) of env e; lanes of a wave cover whole records
+    if (slot_ok) reinterpret_cast<V4 *>(p.obs_others)[e * SLOTS + gslot] = sub4<R, V4>(sj, si);
+  }
 }
 
 // ---- reset kernel (environment.py:125-149) ------------------------------------------------------------
@@ -474,7 +714,13 @@ static int fill_params(const cm3_particle_desc *d, const cm3_particle_bufs *b, P
   CM3_REQUIRE(d->n_agents >= 1 && d->n_agents <= CM3_MAX_AGENTS, "n_agents must be in 1..%d (got %d)",
               CM3_MAX_AGENTS, d->n_agents);
   CM3_REQUIRE(d->max_steps >= 1, "max_steps must be >= 1");
-  CM3_REQUIRE((d->flags & ~(CM3_FLAG_AUTO_RESET | CM3_FLAG_GEN_ACTIONS)) == 0, "unknown flag bits 0x%x", d->flags);
+  CM3_REQUIRE((d->flags & ~(CM3_FLAG_AUTO_RESET | CM3_FLAG_GEN_ACTIONS | CM3_FLAG_KERNEL_LANE_PER_ENV |
+                            CM3_FLAG_KERNEL_LANE_PER_PAIR)) == 0,
+              "unknown flag bits 0x%x", d->flags);
+  CM3_REQUIRE(!((d->flags & CM3_FLAG_KERNEL_LANE_PER_ENV) && (d->flags & CM3_FLAG_KERNEL_LANE_PER_PAIR)),
+              "both kernel-mapping flags set");
+  CM3_REQUIRE(!((d->flags & CM3_FLAG_KERNEL_LANE_PER_PAIR) && d->n_agents < 2),
+              "the lane-per-pair kernel needs n_agents >= 2");
   CM3_REQUIRE(b->obs_others, "obs_others is required");
   if (op == kStep) {
     CM3_REQUIRE(b->state_in && b->state_out && b->goals_in && b->goals_out && b->meta_in && b->meta_out,
@@ -538,9 +784,36 @@ static int launch_one(const ParticleParams &p, ParticleOp op, hipStream_t stream
   return CM3_OK;
 }
 
+template <typename R, int N, int WAVES> static int launch_pairs(const ParticleParams &p, hipStream_t stream) {
+  if constexpr (N >= 2) {
+    const size_t envs_per_block = (size_t)WAVES * PairGeom<N>::EPW;
+    const unsigned blocks = (unsigned)(((size_t)p.E + envs_per_block - 1) / envs_per_block);
+    hipLaunchKernelGGL((k_particle_step_pairs<R, N, WAVES>), dim3(blocks), dim3(WAVES * 64), 0, stream, p);
+    CM3_HIP_CHECK(hipGetLastError());
+    return CM3_OK;
+  } else {
+    return fail(CM3_ERR_INVALID, "the lane-per-pair kernel needs n_agents >= 2");
+  }
+}
+
+// Largest batch for which the lane-per-pair mapping is preferred.  Measured on MI355X (tools/kernel_sweep.py,
+// profiles/r01_kernel_sweep.txt): N=4 3.7 vs 6.1 us at E=4096, 5.3 vs 6.5 us at 16384, 8.0 vs 7.4 us at 32768;
+// N=8 6.9 vs 23.9 us at 4096, 17.4 vs 24.2 us at 16384, 29.5 vs 25.4 us at 32768; N=2 is a tie everywhere.
+constexpr size_t kPairsMaxEnvs = (size_t)1 << 14;
+
 template <typename R, int N> static int launch_n(const ParticleParams &p, ParticleOp op, hipStream_t stream) {
-  // Small batches: one wave per workgroup so the few waves there are land on distinct CUs.
-  // Large batches: 4 waves per workgroup (one per SIMD).
+  if (op == kStep) {
+    bool pairs = N >= 3 && (size_t)p.E <= kPairsMaxEnvs;
+    if (p.flags & CM3_FLAG_KERNEL_LANE_PER_ENV) pairs = false;
+    if (p.flags & CM3_FLAG_KERNEL_LANE_PER_PAIR) pairs = true;
+    if (pairs) {
+      // few envs: one wave per workgroup so that the waves spread over as many CUs as possible
+      const size_t waves = ((size_t)p.E + PairGeom<(N >= 2 ? N : 2)>::EPW - 1) / PairGeom<(N >= 2 ? N : 2)>::EPW;
+      if (waves <= 2048) return launch_pairs<R, N, 1>(p, stream);
+      return launch_pairs<R, N, 4>(p, stream);
+    }
+  }
+  // lane-per-env.  Small batches: one wave per workgroup; large: 4 waves per workgroup (one per SIMD).
   if ((size_t)p.E <= (size_t)64 * 1024) return launch_one<R, N, 1>(p, op, stream);
   return launch_one<R, N, 4>(p, op, stream);
 }

@@ -56,7 +56,7 @@ class VecParticleEnv(object):
     """
 
     def __init__(self, config_particle, n_agents, prob_random, max_steps, n_envs, device="cuda:0",
-                 seed=12341, dtype=torch.float32, auto_reset=False, env_id_base=0):
+                 seed=12341, dtype=torch.float32, auto_reset=False, env_id_base=0, kernel="auto"):
         self.device = _lib.require_gpu(device)
         if dtype not in (torch.float32, torch.float64):
             raise Cm3Error("dtype must be float32 or float64")
@@ -71,6 +71,11 @@ class VecParticleEnv(object):
         self.seed = int(seed)
         self.auto_reset = bool(auto_reset)
         self.env_id_base = int(env_id_base)
+        if kernel not in _lib.KERNEL_FLAGS:
+            raise Cm3Error("kernel must be one of %s" % sorted(_lib.KERNEL_FLAGS))
+        # step-kernel mapping: "env" = one lane per env, "pair" = one lane per ordered agent pair,
+        # "auto" = chosen from n_envs by the library.  Results are identical.
+        self.kernel_flags = _lib.KERNEL_FLAGS[kernel] if self.n >= 2 else 0
         self.L = 4 * max(self.n - 1, 1)
         self._suffix = "f32" if dtype == torch.float32 else "f64"
         E, N, L, dev = self.E, self.n, self.L, self.device
@@ -142,7 +147,7 @@ class VecParticleEnv(object):
         """environment.py:81-123.  ``actions`` int [E, N]; None draws uniform actions in-kernel
         (the reference's random-action branch, train_onpolicy.py:305-307)."""
         src, dst = self._cur, self._cur ^ 1
-        flags = FLAG_AUTO_RESET if self.auto_reset else 0
+        flags = (FLAG_AUTO_RESET if self.auto_reset else 0) | self.kernel_flags
         if actions is None:
             flags |= FLAG_GEN_ACTIONS
         else:

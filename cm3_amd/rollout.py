@@ -152,7 +152,7 @@ class ParticleRollout(object):
         if reset:
             env.reset()
         self._load_slot0()
-        base = FLAG_AUTO_RESET if self.auto_reset else 0
+        base = (FLAG_AUTO_RESET if self.auto_reset else 0) | env.kernel_flags
         if policy is None:
             flags = base | FLAG_GEN_ACTIONS
             if self.use_graph:

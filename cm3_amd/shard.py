@@ -1,0 +1,87 @@
+"""Sharding of env instances over the GPUs of a node + the one collective the path needs.
+
+Env instances are independent (nothing in environment.py / core.py / checkers.py is shared between
+envs), so stepping needs NO exchange: rank r owns the contiguous block of global env ids
+[base, base+count) and every RNG draw is keyed by the GLOBAL env id, which makes results identical
+for any number of ranks.  The reference itself has no collective -- its only
+concurrency is n_seeds independent processes (train_multiprocess.py:31-43).
+
+The single batch-wide statistic the build defines is advantage normalisation
+    A_hat = (A - mean) / (std + eps)      over the whole [world x T x E x N] batch.
+(The reference's advantage, alg_credit.py:334-357, is un-normalised: this step is optional and off for
+parity runs.)  It needs three numbers per rank -- (sum, sum of squares, count) in float64 -- exchanged
+with ONE all-gather (RCCL over xGMI when the backend is "nccl" on ROCm; 24 bytes per rank, latency
+bound) and combined in fixed rank order so every rank computes bit-identical statistics.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_global, rank, world):
+    """Contiguous block of global env ids owned by `rank`: (base, count).  Remainders go to the low ranks."""
+    if not (0 <= rank < world):
+        raise ValueError("rank %d outside world %d" % (rank, world))
+    q, r = divmod(int(n_global), int(world))
+    count = q + (1 if rank < r else 0)
+    base = rank * q + min(rank, r)
+    return base, count
+
+
+def local_moments(x, valid=None):
+    """float64 [3] = (sum, sum of squares, count) of the selected elements of x (same device as x)."""
+    x64 = x.to(torch.float64)
+    if valid is not None:
+        v = valid.to(torch.float64)
+        while v.dim() < x64.dim():
+            v = v.unsqueeze(-1)
+        v = v.expand_as(x64)
+        return torch.stack([(x64 * v).sum(), (x64 * x64 * v).sum(), v.sum()])
+    return torch.stack([x64.sum(), (x64 * x64).sum(),
+                        torch.tensor(float(x64.numel()), dtype=torch.float64, device=x.device)])
+
+
+def global_moments(x, valid=None, group=None):
+    """(mean, std, count) over all ranks.  One all_gather_into_tensor of 3 float64 per rank; the per-rank
+    triples are summed in rank order (deterministic, identical on every rank)."""
+    m = local_moments(x, valid)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        world = dist.get_world_size(group)
+        gathered = torch.empty(world * 3, dtype=torch.float64, device=m.device)
+        dist.all_gather_into_tensor(gathered, m.contiguous(), group=group)
+        parts = gathered.view(world, 3)
+        tot = parts[0].clone()
+        for r in range(1, world):
+            tot = tot + parts[r]
+    else:
+        tot = m
+    n = tot[2].clamp(min=1.0)
+    mean = tot[0] / n
+    var = (tot[1] / n - mean * mean).clamp(min=0.0)
+    return mean, var.sqrt(), tot[2]
+
+
+def normalize_advantages(adv, valid=None, eps=1e-8, group=None):
+    """A_hat = (A - mean) / (std + eps) with batch-wide (all ranks) mean / std; invalid entries -> 0."""
+    mean, std, _ = global_moments(adv, valid, group)
+    out = (adv - mean.to(adv.dtype)) / (std.to(adv.dtype) + eps)
+    if valid is not None:
+        v = valid
+        while v.dim() < out.dim():
+            v = v.unsqueeze(-1)
+        out = torch.where(v.expand_as(out), out, torch.zeros_like(out))
+    return out
+
+
+def returns_to_go(reward, done, gamma=0.99, bootstrap=None):
+    """Discounted return G_t = r_t + gamma * (1 - done_t) * G_{t+1} over a time-major trajectory
+    (reward [T, ...], done [T, E] broadcast over trailing dims).  Stays on the trajectory's device."""
+    T = reward.shape[0]
+    out = torch.empty_like(reward)
+    nxt = torch.zeros_like(reward[0]) if bootstrap is None else bootstrap
+    nd = (~done.bool()).to(reward.dtype)
+    while nd.dim() < reward.dim():
+        nd = nd.unsqueeze(-1)
+    for t in range(T - 1, -1, -1):
+        nxt = reward[t] + gamma * nd[t] * nxt
+        out[t] = nxt
+    return out

@@ -60,6 +60,10 @@ extern "C" {
                                     Philox4x32-10 keyed (seed, global env id, episode, step), and WRITTEN to
                                     `actions` */
 
+#define CM3_FLAG_KERNEL_LANE_PER_ENV 0x100u  /* particle step: force the one-lane-per-env mapping   */
+#define CM3_FLAG_KERNEL_LANE_PER_PAIR 0x200u /* particle step: force the one-lane-per-agent-pair mapping
+                                                (default: chosen from n_envs; both give identical results) */
+
 int cm3_abi_version(void);
 const char *cm3_last_error(void);
 /* Number of visible HIP devices (0 when none); fills name (<= len bytes) of device `dev` if name != NULL. */

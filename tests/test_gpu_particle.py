@@ -23,6 +23,9 @@ EDGE = 2e-6
 NAMES = golden_names("particle_")
 
 
+KERNELS = ["env", "pair"]      # both step-kernel mappings must satisfy every parity test
+
+
 def _env(cfg, N, E, dtype=torch.float32, prob_random=0.2, max_steps=33, **kw):
     from cm3_amd.particle import VecParticleEnv
     return VecParticleEnv(cfg, N, prob_random, max_steps, E, device="cuda:0", dtype=dtype, **kw)
@@ -48,12 +51,13 @@ def _margins(pos, landmarks):
     return m_col, m_reach
 
 
+@pytest.mark.parametrize("kernel", KERNELS)
 @pytest.mark.parametrize("name", NAMES)
-def test_f32_teacher_forced_vs_reference_golden(name):
+def test_f32_teacher_forced_vs_reference_golden(name, kernel):
     g = load_golden(name)
     m = g["meta"]
     N, Ep, T = m["n_agents"], len(g["ep_len"]), int(g["ep_len"].max())
-    env = _env(m["config"], N, Ep, prob_random=m["prob_random"])
+    env = _env(m["config"], N, Ep, prob_random=m["prob_random"], kernel=kernel)
     prev_gs, prev_col = g["init_gs"], np.zeros(Ep, np.int64)
     skipped = 0
     for t in range(T):
@@ -84,13 +88,14 @@ def test_f32_teacher_forced_vs_reference_golden(name):
     assert skipped <= 3        # near-threshold samples are rare (SURVEY: ~1 in 100k pair-steps)
 
 
+@pytest.mark.parametrize("kernel", KERNELS)
 @pytest.mark.parametrize("name", NAMES)
-def test_f64_free_running_vs_reference_golden(name):
+def test_f64_free_running_vs_reference_golden(name, kernel):
     """Whole episodes in the float64 instantiation, no re-injection: state, rewards, done, collisions."""
     g = load_golden(name)
     m = g["meta"]
     N, Ep, T = m["n_agents"], len(g["ep_len"]), int(g["ep_len"].max())
-    env = _env(m["config"], N, Ep, dtype=torch.float64, prob_random=m["prob_random"])
+    env = _env(m["config"], N, Ep, dtype=torch.float64, prob_random=m["prob_random"], kernel=kernel)
     gs0 = g["init_gs"]
     env.set_state(gs0[..., 2:4], gs0[..., 0:2], g["landmarks"])
     for t in range(T):
@@ -125,11 +130,12 @@ def _random_states(rng, E, N, crowd=0.5):
                                            ("particle_merge8.json", 8, 8192), ("particle_merge8.json", 3, 777),
                                            ("particle_merge8.json", 5, 300), ("particle_merge8.json", 6, 129),
                                            ("particle_merge8.json", 7, 64)])
-def test_f32_random_states_vs_oracle(cfg_name, N, E):
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_f32_random_states_vs_oracle(cfg_name, N, E, kernel):
     """BASELINE configs C1/C2/C4(per-GPU)/C5(per-GPU) + ragged sizes and every agent count."""
     cfg = load_cfg(cfg_name)
     rng = np.random.default_rng(1234 + N * 1000 + E)
-    env = _env(cfg, N, E)
+    env = _env(cfg, N, E, kernel=kernel)
     orc = VecParticleOracle(N, cfg, 0.2, 33, E)
     bad = 0
     for it in range(3):
@@ -156,11 +162,12 @@ def test_f32_random_states_vs_oracle(cfg_name, N, E):
     assert bad <= max(2, E * 3 // 5000)
 
 
-def test_f64_random_states_vs_oracle():
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_f64_random_states_vs_oracle(kernel):
     cfg = load_cfg("particle_stage2_antipodal.json")
     rng = np.random.default_rng(5)
     E, N = 2048, 4
-    env = _env(cfg, N, E, dtype=torch.float64)
+    env = _env(cfg, N, E, dtype=torch.float64, kernel=kernel)
     orc = VecParticleOracle(N, cfg, 0.2, 33, E)
     pos, vel, lm = _random_states(rng, E, N)
     acts = rng.integers(0, 5, (E, N))
@@ -175,12 +182,13 @@ def test_f64_random_states_vs_oracle():
     assert np.array_equal(env.collisions.cpu().numpy(), orc.collisions)
 
 
-def test_structural_properties_full_size():
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_structural_properties_full_size(kernel):
     """Size-independent properties at the BASELINE C2 size after a 33-tick in-kernel random rollout:
     obs rows are exact differences of state rows, reward == ordered sum of reward_n, done <=> rule."""
     cfg = load_cfg("particle_stage2_antipodal.json")
     E, N = 4096, 4
-    env = _env(cfg, N, E)
+    env = _env(cfg, N, E, kernel=kernel)
     env.reset()
     for t in range(33):
         gs, oo, os_, rew, rew_n, done = env.step()
@@ -223,13 +231,14 @@ def test_generated_actions_and_reset_match_philox_spec_and_are_shard_invariant()
     assert _maxabs(_np(f32.global_state)[..., 2:4] - pos) < 1e-7
 
 
-def test_auto_reset_semantics():
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_auto_reset_semantics(kernel):
     """Under AUTO_RESET a finished env returns terminal reward/done, the fresh episode's state/obs, and the
     true terminal next-state in term_state; the step counter restarts (train_onpolicy.py:282 folded in)."""
     cfg = load_cfg("particle_stage2_antipodal.json")
     E, N, seed = 512, 4, 3
-    env = _env(cfg, N, E, dtype=torch.float64, seed=seed, auto_reset=True, max_steps=5)
-    ref = _env(cfg, N, E, dtype=torch.float64, seed=seed, auto_reset=False, max_steps=5)
+    env = _env(cfg, N, E, dtype=torch.float64, seed=seed, auto_reset=True, max_steps=5, kernel=kernel)
+    ref = _env(cfg, N, E, dtype=torch.float64, seed=seed, auto_reset=False, max_steps=5, kernel="env")
     env.enable_terminal_capture()
     env.reset()
     ref.reset()
@@ -281,3 +290,28 @@ def test_bad_arguments_raise():
         env.step(torch.zeros(8, 3, dtype=torch.int32))
     with pytest.raises(Cm3Error):
         _env(cfg, 9, 8)
+
+
+@pytest.mark.parametrize("N,cfg_name", [(2, "particle_stage2_merge.json"), (4, "particle_stage2_cross.json"),
+                                        (8, "particle_merge8.json"), (5, "particle_merge8.json")])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_both_kernel_mappings_agree_bitwise(N, cfg_name, dtype):
+    """Same inputs, same bits: 40 free-running ticks with in-kernel actions and auto-reset (max_steps 7) through
+    the lane-per-env and the lane-per-pair kernels, including terminal capture."""
+    cfg = load_cfg(cfg_name)
+    E = 1000
+    a = _env(cfg, N, E, dtype=dtype, seed=21, auto_reset=True, max_steps=7, kernel="env")
+    b = _env(cfg, N, E, dtype=dtype, seed=21, auto_reset=True, max_steps=7, kernel="pair")
+    a.enable_terminal_capture()
+    b.enable_terminal_capture()
+    a.reset()
+    b.reset()
+    for t in range(40):
+        ra, rb = a.step(), b.step()
+        for x, y in zip(ra, rb):
+            assert torch.equal(x, y), t
+        assert torch.equal(a.last_actions, b.last_actions)
+        assert torch.equal(a.collisions, b.collisions) and torch.equal(a.steps, b.steps)
+        assert torch.equal(a.goals, b.goals) and torch.equal(a.episode, b.episode)
+    assert torch.equal(a.terminal_state, b.terminal_state)
+    assert torch.equal(a.terminal_obs_others, b.terminal_obs_others)

@@ -1,0 +1,144 @@
+"""GPU: trajectory collection (train_onpolicy.py:281-350) -- the device trajectory equals stepping the env
+tick by tick, and the exported columns follow the reference's 11-/16-column transition layout."""
+import numpy as np
+import pytest
+import torch
+
+from oracle.particle_oracle import VecParticleOracle
+from oracle.checkers_oracle import VecCheckersOracle
+from tests.helpers import load_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+def _penv(E, N=4, dtype=torch.float64, cfg="particle_stage2_antipodal.json", **kw):
+    from cm3_amd.particle import VecParticleEnv
+    return VecParticleEnv(load_cfg(cfg), N, 0.2, kw.pop("max_steps", 33), E, device="cuda:0", dtype=dtype, **kw)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_particle_rollout_equals_stepwise_env_and_oracle(use_graph):
+    from cm3_amd.rollout import ParticleRollout
+    E, N, T = 300, 4, 33
+    env = _penv(E, seed=5)
+    ro = ParticleRollout(env, use_graph=use_graph).collect()
+    ro.collect()                                   # second rollout (graph replay) must be a fresh episode
+    # replay the same actions through a second env stepped tick by tick, and through the NumPy oracle
+    ref = _penv(E, seed=5)
+    ref.set_state(ro.state[0, :, :, 2:4].permute(1, 0, 2), ro.state[0, :, :, 0:2].permute(1, 0, 2), env.goals)
+    orc = VecParticleOracle(N, load_cfg("particle_stage2_antipodal.json"), 0.2, 33, E)
+    orc.set_from_global_state(ro.state[0].permute(1, 0, 2).cpu().numpy(), env.goals.cpu().numpy())
+    for t in range(T):
+        gs, oo, os_, rew, rew_n, done = ref.step(ro.actions[t])
+        assert torch.equal(gs, ro.state[t + 1].permute(1, 0, 2))
+        assert torch.equal(oo, ro.obs_others[t + 1])
+        assert torch.equal(rew, ro.reward[t]) and torch.equal(rew_n, ro.reward_n[t])
+        assert torch.equal(done, ro.done[t].bool())
+        w = orc.step(ro.actions[t].cpu().numpy())
+        assert np.abs(gs.cpu().numpy() - w[0]).max() < 1e-9
+        assert np.array_equal(done.cpu().numpy(), w[5])
+    assert torch.equal(env.global_state, ro.state[T].permute(1, 0, 2))     # live env holds the last slot
+    assert bool(ro.done[T - 1].all())
+    ro.close()
+
+
+def test_particle_reference_batch_layout_and_valid_mask():
+    from cm3_amd.rollout import ParticleRollout, PARTICLE_ORDER
+    E, N, T = 64, 4, 33
+    env = _penv(E, seed=11)
+    ro = ParticleRollout(env, use_graph=False)
+    # a policy that walks every agent toward its landmark: some envs finish early (all reached)
+    def policy(obs_others, obs_self, goals):
+        d = goals - obs_self[..., 2:4]
+        horiz = d[..., 0].abs() > d[..., 1].abs()
+        ax = torch.where(d[..., 0] > 0, 2, 1)
+        ay = torch.where(d[..., 1] > 0, 4, 3)
+        a = torch.where(horiz, ax, ay)
+        slow = obs_self[..., 0:2].norm(dim=-1) > 0.6           # coast when fast
+        return torch.where(slow, torch.zeros_like(a), a).to(torch.int32)
+    ro.collect(policy=policy)
+    valid = ro.valid
+    d = ro.done.bool()
+    first_done = torch.where(d.any(0), d.float().argmax(0), torch.full((E,), T - 1, device=d.device))
+    assert torch.equal(valid.sum(0), first_done + 1)
+    cols = ro.as_reference_batch()
+    B = int(valid.sum())
+    shapes = dict(v_global=(B, N, 4), obs_others=(B, N, 12), v_local=(B, N, 4), actions=(B, N), reward=(B,),
+                  reward_local=(B, N), v_global_next=(B, N, 4), obs_others_next=(B, N, 12), v_local_next=(B, N, 4),
+                  done=(B,), goals=(B, N, 2))
+    assert list(cols) == list(PARTICLE_ORDER)
+    for k, shp in shapes.items():
+        assert cols[k].shape == shp, k
+    tt, ee = ro.valid_indices()
+    b = B // 2
+    t, e = int(tt[b]), int(ee[b])
+    assert np.array_equal(cols["v_global"][b], ro.state[t, :, e].cpu().numpy())
+    assert np.array_equal(cols["v_global_next"][b], ro.state[t + 1, :, e].cpu().numpy())
+    assert np.array_equal(cols["obs_others_next"][b], ro.obs_others[t + 1, e].cpu().numpy())
+    assert np.array_equal(cols["goals"][b], env.goals[e].cpu().numpy())
+    rows = ro.as_reference_rows(tt[:5], ee[:5])
+    assert rows.shape == (5, 11) and rows.dtype == object
+    assert np.array_equal(np.stack(rows[:, 1]), cols["obs_others"][:5])
+    g, l = ro.episode_returns()
+    assert np.allclose(g.cpu().numpy(), (ro.reward * valid).sum(0).cpu().numpy())
+    batch = ro.sample_batch(128, generator=torch.Generator(device="cuda").manual_seed(0))
+    assert batch["reward"].shape == (128,)
+
+
+def test_particle_auto_reset_rollout_keeps_true_terminal_next_state():
+    from cm3_amd.rollout import ParticleRollout
+    E, N, T = 128, 4, 20
+    env = _penv(E, seed=3, auto_reset=True, max_steps=7)
+    env.reset()
+    ro = ParticleRollout(env, n_ticks=T, use_graph=True).collect()
+    ref = _penv(E, seed=3, auto_reset=False, max_steps=7)
+    cols = ro.as_reference_batch(numpy=False)
+    assert cols["reward"].shape == (T * E,)
+    ep_start = 0
+    ref.set_state(ro.state[0, :, :, 2:4].permute(1, 0, 2), ro.state[0, :, :, 0:2].permute(1, 0, 2),
+                  ro.goals[0].permute(1, 0, 2))
+    for t in range(T):
+        gs, oo, _, rew, rew_n, done = ref.step(ro.actions[t])
+        sel = torch.arange(E, device="cuda") + t * E          # time-major flat index of (t, e)
+        assert torch.equal(cols["v_global_next"][sel], gs)    # true next state, also on terminal ticks
+        assert torch.equal(cols["obs_others_next"][sel], oo)
+        assert torch.equal(cols["reward"][sel], rew) and torch.equal(cols["done"][sel], done)
+        assert torch.equal(cols["goals"][sel], ref.goals)
+        if bool(done.all()):                                   # all envs end together at max_steps here
+            ref.set_state(ro.state[t + 1, :, :, 2:4].permute(1, 0, 2), ro.state[t + 1, :, :, 0:2].permute(1, 0, 2),
+                          ro.goals[t + 1].permute(1, 0, 2))
+            assert (ro.state[t + 1, :, :, 0:2] == 0).all()     # fresh episode: zero velocity
+    ro.close()
+
+
+def test_checkers_rollout_matches_oracle_and_16_column_layout():
+    from cm3_amd.checkers import VecCheckersEnv
+    from cm3_amd.rollout import CheckersRollout, CHECKERS_ORDER
+    cfg = load_cfg("checkers_stage2.json")
+    i = cfg["init"]
+    E, N, T = 200, 2, 33
+    env = VecCheckersEnv(i, N, T, E, device="cuda:0", seed=8)
+    ro = CheckersRollout(env).collect(np.eye(2))
+    orc = VecCheckersOracle(i["n_rows"], i["n_columns"], i["n_obs"], i["agents_r"], i["agents_c"], N, T, E)
+    w0 = orc.reset(np.eye(2))
+    assert np.array_equal(ro.grid[0].cpu().numpy().astype(float), w0[0])
+    for t in range(T):
+        w = orc.step(ro.actions[t].cpu().numpy())
+        assert np.array_equal(ro.grid[t + 1].cpu().numpy().astype(float), w[0])
+        assert np.array_equal(ro.obs_self_t[t + 1].cpu().numpy().astype(float), w[3])
+        assert np.array_equal(ro.reward[t].cpu().numpy(), w[5])
+        assert np.array_equal(ro.done[t].cpu().numpy().astype(bool), w[7])
+    cols = ro.as_reference_batch()
+    assert list(cols) == list(CHECKERS_ORDER)
+    B = cols["reward"].shape[0]
+    assert cols["grid"].shape == (B, 3, 9, 2) and cols["obs_self_t"].shape == (B, N, 5, 5, 3)
+    assert cols["goals"].shape == (B, N, 2) and cols["actions_prev"].shape == (B, N)
+    tt, ee = ro.valid_indices()
+    first = (tt == 0).cpu().numpy()
+    assert (cols["actions_prev"][first] == 0).all()                       # train_onpolicy.py:295
+    later = np.nonzero(~first)[0][:50]
+    for b in later:
+        t, e = int(tt[b]), int(ee[b])
+        assert np.array_equal(cols["actions_prev"][b], ro.actions[t - 1, e].cpu().numpy())
+    rows = ro.as_reference_rows(tt[:4], ee[:4])
+    assert rows.shape == (4, 16)
