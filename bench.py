@@ -94,6 +94,50 @@ class ParticleStepper(object):
             self.graph = None
 
 
+class CheckersStepper(object):
+    """In-place stepping of E Checkers envs (BASELINE configs[2]): one cm3_checkers_step launch per tick,
+    uniform actions drawn in-kernel, auto-reset; replayed as a hipGraph."""
+
+    def __init__(self, cfg, n_envs, device, seed=12341, env_id_base=0, max_steps=33):
+        import numpy as np
+        import torch
+        from cm3_amd import _lib
+        from cm3_amd.checkers import VecCheckersEnv
+        self.torch, self._lib_mod, self.lib = torch, _lib, _lib.lib()
+        self.env = VecCheckersEnv(cfg["init"], cfg["n_agents"], max_steps, n_envs, device=device, seed=seed,
+                                  auto_reset=True, env_id_base=env_id_base)
+        n = cfg["n_agents"]
+        self.env.reset(np.eye(2) if n > 1 else np.array([[1, 0]]))
+        self.env._desc.flags = _lib.FLAG_AUTO_RESET | _lib.FLAG_GEN_ACTIONS
+        self.bufs = self.env._bufs(0)
+        self.device = self.env.device
+        self.graph, self.graph_ticks = None, 0
+
+    def stream(self):
+        return self._lib_mod.current_stream_handle(self.device)
+
+    def enqueue(self, n_ticks, stream=None):
+        s = self.stream() if stream is None else stream
+        for _ in range(int(n_ticks)):
+            self._lib_mod.check(self.lib.cm3_checkers_step(ctypes.byref(self.env._desc), ctypes.byref(self.bufs), s))
+
+    capture = ParticleStepper.capture
+    run = ParticleStepper.run
+    close = ParticleStepper.close
+
+
+# SURVEY.md section 8(d): Checkers N=2 -- compact state 16 r + 16 w, actions 8, outputs 360
+CHECKERS_BYTES_PER_ENV_STEP = 400
+
+WORKLOADS = {
+    # name: (kind, config file, envs per GPU, description)
+    "c2": ("particle", "particle_stage2_antipodal", 4096, "config_particle_stage2_antipodal.json: 4 agents"),
+    "c3": ("checkers", "checkers_stage2", 8192, "config_checkers_stage2.json: 2 agents, integer grid"),
+    "c4": ("particle", "particle_stage2_cross", 4096, "config_particle_stage2_cross.json: 4 agents"),
+    "c5": ("particle", "particle_merge8", 8192, "build-defined merge8: 8 agents (SURVEY.md section 8d C5)"),
+}
+
+
 def timed_ticks(stepper, n_ticks):
     """HIP-event time (ms) of n_ticks ticks on the launch stream."""
     torch = stepper.torch
@@ -155,12 +199,49 @@ def cpu_baseline(cfg, n_agents, budget_s=12.0):
                        % (episodes, steps, n_agents, dt, os.cpu_count()))
 
 
+def cpu_baseline_checkers(cfg, budget_s=10.0):
+    """Dense scalar NumPy port of env/checkers.py on one host core, uniform random actions."""
+    import numpy as np
+    from oracle.checkers_oracle import CheckersEnvOracle
+    i, n = cfg["init"], cfg["n_agents"]
+    env = CheckersEnvOracle(i["n_rows"], i["n_columns"], i["n_obs"], i["agents_r"], i["agents_c"], n, 33)
+    rng = np.random.RandomState(12341)
+    steps, episodes = 0, 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        env.reset(np.eye(2) if n > 1 else np.array([[1, 0]]))
+        done = False
+        while not done:
+            *_, done = env.step(rng.randint(0, 5, n))
+            steps += 1
+        episodes += 1
+    dt = time.perf_counter() - t0
+    return dict(value=steps / dt, unit="env-steps/s", cores=1, kind="port",
+                sample="%d episodes (%d env-steps) of Checkers stage 2 (N=%d, 33 ticks, uniform actions) in %.1f s on 1 of "
+                       "%d host cores; scalar dense NumPy port of the reference's call structure"
+                       % (episodes, steps, n, dt, os.cpu_count()))
+
+
+def pmc_traffic(tag):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
+    (profiles/pmc_traffic.json, written by tools/pmc_run.sh + tools/pmc_summary.py); None if absent."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None, None
+    rec = json.load(open(path)).get(tag)
+    if not rec:
+        return None, None
+    return rec["hbm_bytes_per_launch"], rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3300)
     ap.add_argument("--warmup", type=int, default=330)
-    ap.add_argument("--envs-per-gpu", type=int, default=4096)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2",
+                    help="c2 (default, the configuration BASELINE.json's metric is quoted on) | c3 | c4 | c5")
+    ap.add_argument("--envs-per-gpu", type=int, default=0, help="override the workload's batch size")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-sweep", action="store_true", help="skip the E-sweep (extra 'sweep' field)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -193,11 +274,19 @@ def main():
     if rank != 0:
         graft.build()
 
-    cfg = cm3_amd.load_config("particle_stage2_antipodal")
+    kind, cfg_name, default_e, wl_desc = WORKLOADS[args.workload]
+    cfg = cm3_amd.load_config(cfg_name)
     N = cfg["n_agents"]
-    E = args.envs_per_gpu
+    E = args.envs_per_gpu or default_e
     K, W = args.steps, args.warmup
-    stepper = ParticleStepper(cfg, N, E, device, env_id_base=rank * E, kernel=args.kernel)
+    if kind == "particle":
+        stepper = ParticleStepper(cfg, N, E, device, env_id_base=rank * E, kernel=args.kernel)
+        bytes_per_env_step = algorithmic_bytes_per_env_step(N)
+        dtype_name = "f32"
+    else:
+        stepper = CheckersStepper(cfg, E, device, env_id_base=rank * E)
+        bytes_per_env_step = CHECKERS_BYTES_PER_ENV_STEP
+        dtype_name = "int8/int32 state and grids, f64 normalised outputs (bit-exact)"
     if not args.no_graph:
         stepper.capture(GRAPH_TICKS)
     stepper.run(max(W, 1))
@@ -222,7 +311,7 @@ def main():
     total_env_steps = float(E) * K * world
     value = total_env_steps / wall_max
     launch_s = ev_max / K
-    bytes_per_launch = algorithmic_bytes_per_env_step(N) * E
+    bytes_per_launch = bytes_per_env_step * E
     achieved = bytes_per_launch / launch_s / 1e9
 
     out = None
@@ -230,24 +319,32 @@ def main():
         out = {
             "metric": "env-steps/s (all agents, whole node)", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": wall_max / K * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype_name,
             "data": "synthetic (uniform random actions drawn in-kernel, Philox; preset/random resets, prob_random=0.2)",
-            "config": {"workload": "config_particle_stage2_antipodal.json: 4 agents, %d vectorised envs per GPU, "
-                                   "max_steps=33, auto-reset, one step-kernel launch per tick" % E,
+            "config": {"workload": "%s, %d vectorised envs per GPU, max_steps=33, auto-reset, one step-kernel launch "
+                                   "per tick" % (wl_desc, E),
                        "envs_per_gpu": E, "n_agents": N, "global_envs": E * world,
                        "launch": "eager" if args.no_graph else "hipGraph of %d ticks" % GRAPH_TICKS,
                        "parallelism": "env-sharded x%d, no data-path collective" % world},
             "agent_steps_per_s": value * N,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "kernel": "k_particle_step<float,4>", "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "kernel": "k_checkers_step" if kind == "checkers" else "k_particle_step(_pairs)<float,%d>" % N,
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
                          "avg_launch_us": launch_s * 1e6},
         }
+    if rank == 0 and args.workload == "c2" and E == 4096:
+        traffic, rec = pmc_traffic("c2_particle_antipodal_n4_e4096")
+        if traffic is not None:
+            out["roofline"]["traffic"] = traffic
+            out["roofline"]["traffic_source"] = ("profiles/pmc_traffic.json: %s, %d launches, FETCH_SIZE %.1f KB (x2) + "
+                                                 "WRITE_SIZE %.1f KB" % (rec["kernel"], rec["launches"],
+                                                                         rec["FETCH_SIZE_KB"], rec["WRITE_SIZE_KB"]))
     if world == 1 and rank == 0:
         bw = measure_read_bandwidth(device)
         out["roofline"]["measured_read_GBps"] = bw
         out["roofline"]["frac_of_measured_read"] = achieved / bw
-        if not args.no_sweep:
+        if not args.no_sweep and kind == "particle":
             sweep = []
             stepper.close()
             del stepper
@@ -269,7 +366,7 @@ def main():
                 torch.cuda.empty_cache()
             out["sweep"] = sweep
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, N)
+            out["cpu_baseline"] = cpu_baseline(cfg, N) if kind == "particle" else cpu_baseline_checkers(cfg)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -521,6 +521,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_pairs(const Partic
   const int i = gi / NO, k = gi - i * NO, j = k < i ? k : k + 1;
   const bool lead = slot_ok && k == 0;  // one lane per agent does the per-agent stores
   const bool head = gslot == 0;         // one lane per env does the per-env stores
+  CM3_STAMP(0, false);
 
   // ---- loads -----------------------------------------------------------------------------------------------
   const V4 *sin4 = reinterpret_cast<const V4 *>(p.state_in);
@@ -543,6 +544,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_pairs(const Partic
     act = p.actions[ec * N + i];
   }
 
+  CM3_STAMP(1, true);
   // ---- action force + own contact force ----------------------------------------------------------------------
   R ux = R(0), uy = R(0);
   if (act == 1) ux = R(-1);
@@ -559,6 +561,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_pairs(const Partic
     Fy = __shfl(f_y, src, 64) + Fy;
   }
 
+  CM3_STAMP(2, true);
   // ---- integrate agent i (every lane of agent i computes the same values) -----------------------------------
   const R kDt = R(0.1), kKeep = R(1 - 0.25), kDistMin = R(0.15) + R(0.15);
   si.x = si.x * kKeep;
@@ -577,6 +580,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_pairs(const Partic
     sj.w = __shfl(si.w, src, 64);
   }
 
+  CM3_STAMP(3, true);
   // ---- reward / reached / collisions (multi-goal_spread.py:114-143) ------------------------------------------
   R rew;
   {
@@ -605,6 +609,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_pairs(const Partic
   const R reward = sum_agents<R, N>(rews);
   const bool done = (steps == p.max_steps) || all_reached;
 
+  CM3_STAMP(4, true);
   if (env_ok && lead) reinterpret_cast<R *>(p.reward_n)[e * N + i] = rew;
   if (env_ok && head) {
     reinterpret_cast<R *>(p.reward)[e] = reward;
@@ -645,6 +650,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_pairs(const Partic
     // observation (multi-goal_spread.py:145-154): vector (i,k) of env e; lanes of a wave cover whole records
     if (slot_ok) reinterpret_cast<V4 *>(p.obs_others)[e * SLOTS + gslot] = sub4<R, V4>(sj, si);
   }
+  CM3_STAMP(5, false);
+  CM3_STAMP(6, true);
 }
 
 // ---- reset kernel (environment.py:125-149) ------------------------------------------------------------
@@ -807,9 +814,11 @@ template <typename R, int N> static int launch_n(const ParticleParams &p, Partic
     if (p.flags & CM3_FLAG_KERNEL_LANE_PER_ENV) pairs = false;
     if (p.flags & CM3_FLAG_KERNEL_LANE_PER_PAIR) pairs = true;
     if (pairs) {
-      // few envs: one wave per workgroup so that the waves spread over as many CUs as possible
+      // 4 waves per workgroup (one per SIMD of a CU) measured faster than 1 or 2 from 1024 waves up
+      // (tools/probes/step_timeline.hip: 4.38 vs 4.82 us at E=4096, 6.36 vs 7.32 us at E=16384, stamped build);
+      // below 256 waves single-wave workgroups spread the work over more CUs.
       const size_t waves = ((size_t)p.E + PairGeom<(N >= 2 ? N : 2)>::EPW - 1) / PairGeom<(N >= 2 ? N : 2)>::EPW;
-      if (waves <= 2048) return launch_pairs<R, N, 1>(p, stream);
+      if (waves < 256) return launch_pairs<R, N, 1>(p, stream);
       return launch_pairs<R, N, 4>(p, stream);
     }
   }

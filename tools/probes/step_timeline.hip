@@ -14,7 +14,7 @@ int main(int argc, char **argv) {
   hipMalloc(&rewn, (size_t)E * N * 4); hipMalloc(&rew, (size_t)E * 4); hipMalloc((void **)&meta, (size_t)E * 8);
   hipMalloc((void **)&episode, (size_t)E * 4); hipMalloc((void **)&actions, (size_t)E * N * 4); hipMalloc((void **)&done, E);
   const int waves = (E + 63) / 64;
-  hipMalloc((void **)&stamps, (size_t)waves * 16 * 8);
+  hipMalloc((void **)&stamps, (size_t)(E + 3) / 4 * 16 * 8 + 4096);
   hipMemset(episode, 0, (size_t)E * 4);
   hipMemcpyToSymbol(HIP_SYMBOL(cm3_stamp_buf), &stamps, sizeof(stamps));
   cm3_particle_desc d; memset(&d, 0, sizeof(d));
@@ -27,29 +27,45 @@ int main(int argc, char **argv) {
   hipStream_t s; hipStreamCreate(&s);
   d.flags = 0;
   if (cm3_particle_reset_f32(&d, &b, nullptr, s)) { printf("reset: %s\n", cm3_last_error()); return 1; }
-  d.flags = CM3_FLAG_AUTO_RESET | CM3_FLAG_GEN_ACTIONS | CM3_FLAG_KERNEL_LANE_PER_ENV;
-  for (int t = 0; t < 40; ++t) cm3_particle_step_f32(&d, &b, s);
-  hipStreamSynchronize(s);
-  std::vector<long long> h((size_t)waves * 16);
-  const char *names[] = {"entry->loads done", "contact forces+integrate", "reward/collisions", "small stores issue+reset", "obs_others LDS staging", "final drain"};
-  for (int t = 0; t < 3; ++t) {
-    cm3_particle_step_f32(&d, &b, s);
+  d.flags = CM3_FLAG_AUTO_RESET | CM3_FLAG_GEN_ACTIONS;
+  cm3::ParticleParams pp;
+  cm3::fill_params(&d, &b, cm3::kStep, nullptr, pp);
+  const char *variant[] = {"lane-per-env W=1", "pairs W=1", "pairs W=2", "pairs W=4"};
+  for (int v = 0; v < 4; ++v) {
+    auto launch = [&]() {
+      switch (v) {
+        case 0: cm3::launch_one<float, 4, 1>(pp, cm3::kStep, s); break;
+        case 1: cm3::launch_pairs<float, 4, 1>(pp, s); break;
+        case 2: cm3::launch_pairs<float, 4, 2>(pp, s); break;
+        case 3: cm3::launch_pairs<float, 4, 4>(pp, s); break;
+      }
+    };
+    const int nw = v == 0 ? waves : (E + 3) / 4;
+    for (int t = 0; t < 40; ++t) launch();
     hipStreamSynchronize(s);
+    // graph of 33 launches, replayed: average launch time like the bench measures it
+    hipGraph_t g; hipGraphExec_t ge;
+    hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+    for (int t = 0; t < 33; ++t) launch();
+    hipStreamEndCapture(s, &g); hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    hipGraphLaunch(ge, s); hipStreamSynchronize(s);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0, s);
+    for (int r = 0; r < 30; ++r) hipGraphLaunch(ge, s);
+    hipEventRecord(e1, s); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    std::vector<long long> h((size_t)nw * 16);
+    launch(); hipStreamSynchronize(s);
     hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost);
-    long long tmin = h[0], tmax = 0;
-    double seg[6] = {0, 0, 0, 0, 0, 0};
-    double sub[3] = {0, 0, 0};
-    for (int w = 0; w < waves; ++w) {
+    long long tmin = h[0], tmax = 0; double seg[6] = {0, 0, 0, 0, 0, 0};
+    for (int w = 0; w < nw; ++w) {
       tmin = std::min(tmin, h[w * 16]); tmax = std::max(tmax, h[w * 16 + 6]);
-      for (int k = 0; k < 6; ++k) seg[k] += (double)(h[w * 16 + k + 1] - h[w * 16 + k]) / waves;
-      sub[0] += (double)(h[w * 16 + 8] - h[w * 16 + 3]) / waves;
-      sub[1] += (double)(h[w * 16 + 9] - h[w * 16 + 8]) / waves;
-      sub[2] += (double)(h[w * 16 + 4] - h[w * 16 + 9]) / waves;
+      for (int k = 0; k < 6; ++k) seg[k] += (double)(h[w * 16 + k + 1] - h[w * 16 + k]) / nw;
     }
-    printf("tick %d: waves=%d first-entry -> last-exit = %lld cycles; mean per-wave segments (cycles):\n", t, waves, tmax - tmin);
-    for (int k = 0; k < 6; ++k) printf("   %-28s %9.0f\n", names[k], seg[k]);
-    printf("      [3->4 split] reward stores %.0f | reset branch %.0f | state/goal/meta stores %.0f\n", sub[0], sub[1], sub[2]);
-    printf("      wall: %.2f us at 2.4 GHz\n", (double)(tmax - tmin) / 2400.0);
+    printf("%-18s E=%d: %.3f us/launch (graph); waves=%d first-entry->last-exit %.2f us; per-wave segments (cycles):",
+           variant[v], E, ms * 1e3 / (33 * 30), nw, (double)(tmax - tmin) / 100.0 * 1.0);
+    for (int k = 0; k < 6; ++k) printf(" %.0f", seg[k]);
+    printf("\n");
   }
   return 0;
 }
