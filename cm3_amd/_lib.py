@@ -57,7 +57,8 @@ class ParticleTraj(ctypes.Structure):
 
 class CheckersDesc(ctypes.Structure):
     _fields_ = [("n_envs", c_int32), ("n_agents", c_int32), ("n_rows", c_int32), ("n_columns", c_int32),
-                ("n_obs", c_int32), ("max_steps", c_int32), ("flags", c_uint32), ("_pad", c_int32),
+                ("n_obs", c_int32), ("max_steps", c_int32), ("flags", c_uint32), ("grid_stride", c_int32),
+                ("obs_self_t_stride", c_int32), ("_pad", c_int32),
                 ("env_id_base", c_int64), ("seed", c_uint64),
                 ("agents_r", c_int32 * MAX_AGENTS), ("agents_c", c_int32 * MAX_AGENTS)]
 

@@ -23,7 +23,7 @@ from ._lib import FLAG_AUTO_RESET, FLAG_GEN_ACTIONS, Cm3Error
 
 class VecCheckersEnv(object):
     def __init__(self, init, n_agents, max_steps, n_envs, device="cuda:0", seed=12341, auto_reset=False,
-                 env_id_base=0):
+                 env_id_base=0, padded_records=None):
         self.device = _lib.require_gpu(device)
         self.n = self.n_agents = int(n_agents)
         self.E = self.n_envs = int(n_envs)
@@ -43,14 +43,24 @@ class VecCheckersEnv(object):
         self._steps = z(E, dt=torch.int32)
         self._episode = z(E, dt=torch.int32)
         self._goals = z(E, N, dt=torch.uint8)
+        # env records of the two byte grids; the reference geometry gets 4-byte padded records (54 -> 56,
+        # 75 N -> multiple of 4), which selects the multi-lane fast kernel.  Views hide the padding.
+        self.grid_rec = self.R * (self.C + 1) * 2
+        self.obst_rec = N * self.K * self.K * 3
+        fast = (self.R, self.C, self.O) == (3, 8, 2) if padded_records is None else bool(padded_records)
+        pad4 = lambda n: (n + 3) // 4 * 4 if fast else n  # noqa: E731
+        self.grid_stride, self.obst_stride = pad4(self.grid_rec), pad4(self.obst_rec)
         self._slots = []
         for _ in range(2):                             # double-buffered outputs
+            grid_raw = z(E, self.grid_stride, dt=torch.int8)
+            obst_raw = z(E, self.obst_stride, dt=torch.int8)
             self._slots.append(dict(
                 actions=z(E, N, dt=torch.int32),
-                grid=z(E, self.R, self.C + 1, 2, dt=torch.int8),
+                grid_raw=grid_raw, obs_self_t_raw=obst_raw,
+                grid=self.grid_view(grid_raw),
                 vec=z(E, N, 4, dt=torch.int32),
                 obs_others=z(E, N, self.Lo, dt=torch.float64),
-                obs_self_t=z(E, N, self.K, self.K, 3, dt=torch.int8),
+                obs_self_t=self.obst_view(obst_raw),
                 obs_self_v=z(E, N, 4, dt=torch.float64),
                 local_rewards=z(E, N, dt=torch.float64),
                 reward=z(E, dt=torch.float64),
@@ -59,6 +69,7 @@ class VecCheckersEnv(object):
         d = self._desc = _lib.CheckersDesc()
         d.n_envs, d.n_agents, d.n_rows, d.n_columns, d.n_obs = E, N, self.R, self.C, self.O
         d.max_steps = self.max_steps
+        d.grid_stride, d.obs_self_t_stride = self.grid_stride, self.obst_stride
         d.flags = 0
         d.env_id_base = int(env_id_base)
         d.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
@@ -66,6 +77,13 @@ class VecCheckersEnv(object):
             d.agents_r[i] = int(init["agents_r"][i]) if i < N else 0
             d.agents_c[i] = int(init["agents_c"][i]) if i < N else 0
         self._lib = _lib.lib()
+
+    def grid_view(self, raw):
+        """[..., E, grid_stride] int8 storage -> [..., E, R, C+1, 2] view without the padding bytes."""
+        return raw[..., :self.grid_rec].unflatten(-1, (self.R, self.C + 1, 2))
+
+    def obst_view(self, raw):
+        return raw[..., :self.obst_rec].unflatten(-1, (self.n, self.K, self.K, 3))
 
     def _bufs(self, slot):
         s = self._slots[slot]
@@ -75,9 +93,10 @@ class VecCheckersEnv(object):
         b.steps = self._steps.data_ptr()
         b.episode = self._episode.data_ptr()
         b.goals = self._goals.data_ptr()
-        for k in ("actions", "grid", "vec", "obs_others", "obs_self_t", "obs_self_v", "local_rewards",
-                  "reward", "done"):
+        for k in ("actions", "vec", "obs_others", "obs_self_v", "local_rewards", "reward", "done"):
             setattr(b, k, s[k].data_ptr())
+        b.grid = s["grid_raw"].data_ptr()
+        b.obs_self_t = s["obs_self_t_raw"].data_ptr()
         return b
 
     def _stream(self):

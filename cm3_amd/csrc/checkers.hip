@@ -45,7 +45,8 @@ struct CheckersParams {
   double *reward;
   uint8_t *done;
   const uint8_t *reset_mask;
-  int grid_rec, obst_rec;  // bytes per env of grid / obs_self_t
+  int grid_rec, obst_rec;        // payload bytes per env of grid / obs_self_t
+  int grid_stride, obst_stride;  // bytes between consecutive env records (>= payload)
 };
 
 constexpr int kCkLdsBytes = 40960;  // per-wave staging tile (64 rows x up to 640 bytes)
@@ -204,15 +205,11 @@ template <int N> __device__ __forceinline__ void ck_init(const CheckersParams &p
   if (N == 1) s.r[0] = (goal[0] == 0 ? 0 : 2) + p.O;
 }
 
-template <int N> __global__ void __launch_bounds__(64) k_checkers_step(const CheckersParams p) {
-  __shared__ __attribute__((aligned(16))) int8_t lds[kCkLdsBytes];
-  const int lane = threadIdx.x;
-  const size_t e0 = (size_t)blockIdx.x * 64;
-  const size_t e = e0 + lane;
-  const bool active = e < (size_t)p.E;
-  const size_t ec = active ? e : (size_t)p.E - 1;
-
-  CkState<N> s;
+// One tick of one env (checkers.py:228-262), executed by every lane that maps to env `ec`; `writer` selects the
+// single lane that performs the per-env stores.  Leaves the post-step (or freshly reset) state in `s`.
+template <int N>
+__device__ __forceinline__ void ck_step_env(const CheckersParams &p, size_t e, size_t ec, bool writer, CkState<N> &s) {
+  const bool active = writer;
   ck_load<N>(p, ec, s);
   int steps = p.steps[ec];
   uint8_t goal[N];
@@ -311,6 +308,187 @@ template <int N> __global__ void __launch_bounds__(64) k_checkers_step(const Che
     ck_store<N>(p, e, s);
     p.steps[e] = steps;
   }
+}
+
+
+// ---- fast path: the reference geometry (3 x 8 band, n_obs 2), 16 lanes per env ----------------------------
+// The generic kernel above is latency-bound at the BASELINE batch (8192 envs = 128 waves, each lane filling
+// ~200 bytes one at a time).  Here an env owns 16 consecutive lanes: every lane redundantly runs the (short)
+// sequential state update -- lanes of a wave execute in lockstep, so that costs nothing and needs no shuffle --
+// and then produces a 1/16 share of the env's outputs: one dword of the (4-byte padded) grid record, up to
+// three dwords of the padded obs_self_t record, and one of the small vector outputs.  No LDS; a wave stores
+// 4 whole env records contiguously.
+template <int N> struct CkFast {
+  static constexpr int R = 3, C = 8, O = 2, K = 5, TR = 7, TC = 13;
+  static constexpr int GRID_REC = R * (C + 1) * 2;  // 54
+  static constexpr int OBST_REC = N * K * K * 3;    // 75 N
+  static constexpr int G = 16;
+};
+
+template <int N>
+__device__ __forceinline__ int ckf_ch2(const CkState<N> &s, int r, int c) {
+  using F = CkFast<N>;
+  if (c < F::O || r < F::O || r >= F::O + F::R || c >= F::O + F::C + 1) return 1;
+#pragma unroll
+  for (int j = 0; j < N; ++j)
+    if (s.r[j] == r && s.c[j] == c) return -1;
+  return 0;
+}
+
+// channel ch (0 green, 1 orange) at expanded cell (r, c)
+template <int N> __device__ __forceinline__ int ckf_ch01(const CkState<N> &s, int r, int c, int ch) {
+  using F = CkFast<N>;
+  const int k = r - F::O, j = c - F::O;
+  if (k < 0 || k >= F::R || j < 0 || j >= F::C) return 0;
+  if (((k + j) & 1) != ch) return 0;
+  return ((s.mask >> (k * F::C + j)) & 1ull) ? 1 : -1;
+}
+
+template <int N> __device__ __forceinline__ uint32_t ckf_grid_dword(const CkState<N> &s, int d) {
+  using F = CkFast<N>;
+  uint32_t w = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int b = 4 * d + q;
+    int v = 0;
+    if (b < F::GRID_REC) {
+      const int cell = b >> 1, ch = b & 1;
+      const int k = cell / (F::C + 1), j = cell - k * (F::C + 1);
+      v = ckf_ch01<N>(s, k + F::O, j + F::O, ch);
+    }
+    w |= (uint32_t)(v & 0xff) << (8 * q);
+  }
+  return w;
+}
+
+template <int N> __device__ __forceinline__ uint32_t ckf_obst_dword(const CkState<N> &s, int d) {
+  using F = CkFast<N>;
+  uint32_t w = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int b = 4 * d + q;
+    int v = 0;
+    if (b < F::OBST_REC) {
+      const int i = b / (F::K * F::K * 3), rem = b - i * (F::K * F::K * 3);
+      const int cell = rem / 3, ch = rem - cell * 3;
+      const int dr = cell / F::K, dc = cell - dr * F::K;
+      int ar = s.r[0], ac = s.c[0];
+#pragma unroll
+      for (int a = 1; a < N; ++a) {
+        ar = (i == a) ? s.r[a] : ar;
+        ac = (i == a) ? s.c[a] : ac;
+      }
+      const int rr = ar - F::O + dr, cc = ac - F::O + dc;
+      if (ch < 2) {
+        v = ckf_ch01<N>(s, rr, cc, ch);
+      } else {
+        v = (dr == F::O && dc == F::O) ? 0 : ckf_ch2<N>(s, rr, cc);  // own cell is valid (:105-107)
+      }
+    }
+    w |= (uint32_t)(v & 0xff) << (8 * q);
+  }
+  return w;
+}
+
+template <int N>
+__device__ __forceinline__ void ckf_emit(const CheckersParams &p, const CkState<N> &s, int g, size_t e, bool env_ok) {
+  using F = CkFast<N>;
+  constexpr int NO = N > 1 ? N - 1 : 1;
+  if (!env_ok) return;
+  // grid record: dword g
+  const int gd = p.grid_stride >> 2;
+  if (g < gd) reinterpret_cast<uint32_t *>(p.grid + e * (size_t)p.grid_stride)[g] = ckf_grid_dword<N>(s, g);
+  // obs_self_t record: dwords g, g+16, ...
+  const int od = p.obst_stride >> 2;
+  uint32_t *o32 = reinterpret_cast<uint32_t *>(p.obs_self_t + e * (size_t)p.obst_stride);
+  for (int d = g; d < od; d += F::G) o32[d] = ckf_obst_dword<N>(s, d);
+  // small vector outputs: lane i (< N) writes agent i's rows
+  if (g < N) {
+    int ri = s.r[0], ci = s.c[0], gi = s.ng[0], oi = s.no[0];
+#pragma unroll
+    for (int a = 1; a < N; ++a) {
+      ri = (g == a) ? s.r[a] : ri;
+      ci = (g == a) ? s.c[a] : ci;
+      gi = (g == a) ? s.ng[a] : gi;
+      oi = (g == a) ? s.no[a] : oi;
+    }
+    int4 v;
+    v.x = ri;
+    v.y = ci;
+    v.z = gi;
+    v.w = oi;
+    reinterpret_cast<int4 *>(p.vec)[e * N + g] = v;
+    const double half = (double)(F::R * F::C) / 2.0;
+    double4 sv;
+    sv.x = ((double)ri - (double)F::TR / 2.0) / (double)F::TR;
+    sv.y = ((double)ci - (double)F::TC / 2.0) / (double)F::TC;
+    sv.z = (double)gi / half;
+    sv.w = (double)oi / half;
+    reinterpret_cast<double4 *>(p.obs_self_v)[e * N + g] = sv;
+    double2 *oo = reinterpret_cast<double2 *>(p.obs_others) + (e * N + g) * NO;
+#pragma unroll
+    for (int k = 0; k < NO; ++k) {
+      // k-th other agent of agent g (N == 1: itself)
+      int rj = s.r[0], cj = s.c[0];
+      const int j = (N > 1) ? (k < g ? k : k + 1) : 0;
+#pragma unroll
+      for (int a = 1; a < N; ++a) {
+        rj = (j == a) ? s.r[a] : rj;
+        cj = (j == a) ? s.c[a] : cj;
+      }
+      double2 t;
+      t.x = ((double)rj - (double)F::TR / 2.0) / (double)F::TR;
+      t.y = ((double)cj - (double)F::TC / 2.0) / (double)F::TC;
+      oo[k] = t;
+    }
+  }
+}
+
+template <int N> __global__ void __launch_bounds__(256) k_checkers_step_fast(const CheckersParams p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane & 15, sub = lane >> 4;
+  const size_t e = ((size_t)blockIdx.x * 4 + wave) * 4 + sub;
+  const bool env_ok = e < (size_t)p.E;
+  const size_t ec = env_ok ? e : (size_t)p.E - 1;
+  CkState<N> s;
+  ck_step_env<N>(p, e, ec, env_ok && g == 0, s);
+  ckf_emit<N>(p, s, g, e, env_ok);
+}
+
+template <int N> __global__ void __launch_bounds__(256) k_checkers_reset_fast(const CheckersParams p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane & 15, sub = lane >> 4;
+  const size_t e = ((size_t)blockIdx.x * 4 + wave) * 4 + sub;
+  const bool env_ok = e < (size_t)p.E;
+  const size_t ec = env_ok ? e : (size_t)p.E - 1;
+  CkState<N> s;
+  const bool sel = p.reset_mask ? (p.reset_mask[ec] != 0) : true;
+  if (sel) {
+    uint8_t goal[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) goal[i] = p.goals[ec * N + i];
+    ck_init<N>(p, goal, s);
+    if (env_ok && g == 0) {
+      ck_store<N>(p, e, s);
+      p.steps[e] = 0;
+      if (p.episode) p.episode[e] = p.episode[e] + 1;
+    }
+  } else {
+    ck_load<N>(p, ec, s);
+  }
+  ckf_emit<N>(p, s, g, e, env_ok);
+}
+
+template <int N> __global__ void __launch_bounds__(64) k_checkers_step(const CheckersParams p) {
+  __shared__ __attribute__((aligned(16))) int8_t lds[kCkLdsBytes];
+  const int lane = threadIdx.x;
+  const size_t e0 = (size_t)blockIdx.x * 64;
+  const size_t e = e0 + lane;
+  const bool active = e < (size_t)p.E;
+  const size_t ec = active ? e : (size_t)p.E - 1;
+
+  CkState<N> s;
+  ck_step_env<N>(p, e, ec, active, s);
   ck_emit<N>(p, s, lds, lane, e0, e, active);
 }
 
@@ -337,6 +515,11 @@ template <int N> __global__ void __launch_bounds__(64) k_checkers_reset(const Ch
     ck_load<N>(p, ec, s);
   }
   ck_emit<N>(p, s, lds, lane, e0, e, active);
+}
+
+// the multi-lane kernel handles the reference geometry with dword-aligned env records
+static bool ck_fast_ok(const CheckersParams &p) {
+  return p.R == 3 && p.C == 8 && p.O == 2 && (p.grid_stride % 4) == 0 && (p.obst_stride % 4) == 0;
 }
 
 static int ck_fill(const cm3_checkers_desc *d, const cm3_checkers_bufs *b, const uint8_t *mask, bool step,
@@ -380,8 +563,15 @@ static int ck_fill(const cm3_checkers_desc *d, const cm3_checkers_bufs *b, const
   }
   p.grid_rec = p.R * (p.C + 1) * 2;
   p.obst_rec = d->n_agents * p.K * p.K * 3;
-  CM3_REQUIRE(64 * p.grid_rec <= kCkLdsBytes && 64 * p.obst_rec <= kCkLdsBytes,
-              "observation record too large for the staging tile");
+  p.grid_stride = d->grid_stride ? d->grid_stride : p.grid_rec;
+  p.obst_stride = d->obs_self_t_stride ? d->obs_self_t_stride : p.obst_rec;
+  CM3_REQUIRE(p.grid_stride >= p.grid_rec && p.obst_stride >= p.obst_rec, "record strides smaller than the records");
+  if (!ck_fast_ok(p)) {
+    CM3_REQUIRE(p.grid_stride == p.grid_rec && p.obst_stride == p.obst_rec,
+                "padded records are only supported by the fast kernel (3x8 band, n_obs 2, strides multiple of 4)");
+    CM3_REQUIRE(64 * p.grid_rec <= kCkLdsBytes && 64 * p.obst_rec <= kCkLdsBytes,
+                "observation record too large for the staging tile");
+  }
   CM3_REQUIRE(b->mask && b->agents && b->steps && b->goals, "state pointers (mask/agents/steps/goals) are required");
   CM3_REQUIRE(b->grid && b->vec && b->obs_others && b->obs_self_t && b->obs_self_v, "observation outputs are required");
   if (step) {
@@ -407,6 +597,15 @@ static int ck_fill(const cm3_checkers_desc *d, const cm3_checkers_bufs *b, const
 }
 
 template <int N> static int ck_launch(const CheckersParams &p, bool step, hipStream_t stream) {
+  if (ck_fast_ok(p)) {
+    const unsigned fblocks = (unsigned)(((size_t)p.E + 15) / 16);  // 4 waves x 4 envs per workgroup
+    if (step)
+      hipLaunchKernelGGL((k_checkers_step_fast<N>), dim3(fblocks), dim3(256), 0, stream, p);
+    else
+      hipLaunchKernelGGL((k_checkers_reset_fast<N>), dim3(fblocks), dim3(256), 0, stream, p);
+    CM3_HIP_CHECK(hipGetLastError());
+    return CM3_OK;
+  }
   const unsigned blocks = (unsigned)(((size_t)p.E + 63) / 64);
   if (step)
     hipLaunchKernelGGL((k_checkers_step<N>), dim3(blocks), dim3(64), 0, stream, p);

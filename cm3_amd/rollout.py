@@ -259,10 +259,12 @@ class CheckersRollout(object):
         self.T = int(n_ticks or env.max_steps)
         E, N, T, dev = env.E, env.n, self.T, env.device
         z = lambda *s, d: torch.zeros(*s, dtype=d, device=dev)  # noqa: E731
-        self.grid = z(T + 1, E, env.R, env.C + 1, 2, d=torch.int8)
+        self._grid_raw = z(T + 1, E, env.grid_stride, d=torch.int8)
+        self._obst_raw = z(T + 1, E, env.obst_stride, d=torch.int8)
+        self.grid = env.grid_view(self._grid_raw)              # [T+1, E, R, C+1, 2] view (padding hidden)
         self.vec = z(T + 1, E, N, 4, d=torch.int32)
         self.obs_others = z(T + 1, E, N, env.Lo, d=torch.float64)
-        self.obs_self_t = z(T + 1, E, N, env.K, env.K, 3, d=torch.int8)
+        self.obs_self_t = env.obst_view(self._obst_raw)        # [T+1, E, N, K, K, 3] view
         self.obs_self_v = z(T + 1, E, N, 4, d=torch.float64)
         self.actions = z(T, E, N, d=torch.int32)
         self.local_rewards = z(T, E, N, d=torch.float64)
@@ -276,9 +278,9 @@ class CheckersRollout(object):
         b.mask, b.agents, b.steps = env._mask.data_ptr(), env._agents.data_ptr(), env._steps.data_ptr()
         b.episode, b.goals = env._episode.data_ptr(), env._goals.data_ptr()
         b.actions = self.actions[t].data_ptr()
-        b.grid, b.vec = self.grid[t + 1].data_ptr(), self.vec[t + 1].data_ptr()
+        b.grid, b.vec = self._grid_raw[t + 1].data_ptr(), self.vec[t + 1].data_ptr()
         b.obs_others = self.obs_others[t + 1].data_ptr()
-        b.obs_self_t, b.obs_self_v = self.obs_self_t[t + 1].data_ptr(), self.obs_self_v[t + 1].data_ptr()
+        b.obs_self_t, b.obs_self_v = self._obst_raw[t + 1].data_ptr(), self.obs_self_v[t + 1].data_ptr()
         b.local_rewards, b.reward, b.done = (self.local_rewards[t].data_ptr(), self.reward[t].data_ptr(),
                                              self.done[t].data_ptr())
         return b

@@ -159,7 +159,8 @@ int cm3_particle_rollout_f64(const cm3_particle_desc *desc, const cm3_particle_t
  *   actions  int32  [E][N]
  * Outputs (values identical to the reference's float64 arrays; integer-valued ones are stored as
  * integers):
- *   grid        int8   [E][n_rows][n_columns+1][2]        get_valid_grid (checkers.py:66-76)
+ *   grid        int8   [E][n_rows][n_columns+1][2]        get_valid_grid (checkers.py:66-76); env records may be
+ *                                                         padded, see grid_stride / obs_self_t_stride
  *   vec         int32  [E][N][4]                          (r, c, n_green, n_orange) (:79-94)
  *   obs_others  double [E][N][2*max(N-1,1)]               (:128-154, normalize :112-125)
  *   obs_self_t  int8   [E][N][2*n_obs+1][2*n_obs+1][3]    get_obs (:97-109)
@@ -174,6 +175,10 @@ typedef struct cm3_checkers_desc {
   int32_t n_obs;
   int32_t max_steps;
   uint32_t flags;     /* CM3_FLAG_AUTO_RESET, CM3_FLAG_GEN_ACTIONS */
+  int32_t grid_stride;       /* bytes between consecutive envs' grid records; 0 = packed (n_rows*(n_columns+1)*2) */
+  int32_t obs_self_t_stride; /* bytes between consecutive envs' obs_self_t records; 0 = packed (N*K*K*3).
+                                Records padded to a multiple of 4 bytes (56 / 152 for the reference geometry with
+                                N = 2) enable the multi-lane fast kernel; padding bytes are written as 0 */
   int32_t _pad;
   int64_t env_id_base;
   uint64_t seed;

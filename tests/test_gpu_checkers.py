@@ -31,12 +31,13 @@ def _check_obs(got, want, sel=slice(None)):
     assert np.array_equal(_f64(ov)[sel], w_ov[sel])
 
 
+@pytest.mark.parametrize("padded", [True, False])     # fast multi-lane kernel / generic lane-per-env kernel
 @pytest.mark.parametrize("name", NAMES)
-def test_bit_exact_vs_reference_golden(name):
+def test_bit_exact_vs_reference_golden(name, padded):
     g = load_golden(name)
     m = g["meta"]
     Ep, T = len(g["ep_len"]), int(g["ep_len"].max())
-    env = _env(m["config"], Ep)
+    env = _env(m["config"], Ep, padded_records=padded)
     out = env.reset(torch.as_tensor(g["goals"]))
     _check_obs(out[:4], (g["init_grid"], g["init_vec"], g["init_obs_others"], g["init_obs_self_t"],
                          g["init_obs_self_v"]))
@@ -54,7 +55,8 @@ def test_bit_exact_vs_reference_golden(name):
 
 @pytest.mark.parametrize("cfg_name,E,lo,hi", [("checkers_stage2.json", 8192, 0, 5), ("checkers_stage2.json", 1000, -1, 7),
                                               ("checkers_stage1.json", 4096 + 13, 0, 5), ("checkers_stage1.json", 1, 0, 5)])
-def test_bit_exact_vs_oracle_full_episodes(cfg_name, E, lo, hi):
+@pytest.mark.parametrize("padded", [True, False])
+def test_bit_exact_vs_oracle_full_episodes(cfg_name, E, lo, hi, padded):
     """BASELINE C3 (N=2, E=8192) and ragged sizes: 33 free-running ticks, 100 % of ticks compared."""
     cfg = load_cfg(cfg_name)
     N = cfg["n_agents"]
@@ -63,7 +65,7 @@ def test_bit_exact_vs_oracle_full_episodes(cfg_name, E, lo, hi):
     goal_idx = rng.integers(0, 2, (E, N)) if N == 1 else np.tile(np.arange(N) % 2, (E, 1))
     orc = VecCheckersOracle(i["n_rows"], i["n_columns"], i["n_obs"], i["agents_r"], i["agents_c"], N, 33, E)
     want = orc.reset(goal_idx)
-    env = _env(cfg, E)
+    env = _env(cfg, E, padded_records=padded)
     out = env.reset(goal_index=torch.as_tensor(goal_idx))
     _check_obs(out[:4], want)
     for t in range(33):
