@@ -43,7 +43,7 @@ class ParticleStepper(object):
     live buffers), optionally replayed as a hipGraph."""
 
     def __init__(self, cfg, n_agents, n_envs, device, seed=12341, env_id_base=0, max_steps=33, prob_random=0.2,
-                 kernel="auto"):
+                 kernel="auto", fused=False):
         import torch
         from cm3_amd import _lib
         from cm3_amd.particle import VecParticleEnv
@@ -53,6 +53,9 @@ class ParticleStepper(object):
         self.env.reset()
         e = self.env
         e._desc.flags = _lib.FLAG_AUTO_RESET | _lib.FLAG_GEN_ACTIONS | e.kernel_flags
+        self.fused = bool(fused)
+        if self.fused:       # all ticks of an enqueue() in ONE launch (state in registers)
+            e._desc.flags |= _lib.FLAG_FUSED_TICKS
         t = self.traj = _lib.ParticleTraj()
         t.state = e._state[0].data_ptr()
         t.goals = e._goals.data_ptr()
@@ -245,6 +248,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-sweep", action="store_true", help="skip the E-sweep (extra 'sweep' field)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fused", action="store_true",
+                    help="random-action rollouts with all 33 ticks of an episode in ONE launch "
+                         "(CM3_FLAG_FUSED_TICKS); the default keeps one launch per tick")
     ap.add_argument("--kernel", choices=["auto", "env", "pair"], default="auto",
                     help="step-kernel mapping (auto = library heuristic)")
     args = ap.parse_args()
@@ -280,8 +286,10 @@ def main():
     E = args.envs_per_gpu or default_e
     K, W = args.steps, args.warmup
     if kind == "particle":
-        stepper = ParticleStepper(cfg, N, E, device, env_id_base=rank * E, kernel=args.kernel)
+        stepper = ParticleStepper(cfg, N, E, device, env_id_base=rank * E, kernel=args.kernel, fused=args.fused)
         bytes_per_env_step = algorithmic_bytes_per_env_step(N)
+        if args.fused:   # state, goals and counters are read once per launch, not once per tick
+            bytes_per_env_step -= (16 * N + 8 * N + 8) * (GRAPH_TICKS - 1) / float(GRAPH_TICKS)
         dtype_name = "f32"
     else:
         stepper = CheckersStepper(cfg, E, device, env_id_base=rank * E)
@@ -310,8 +318,9 @@ def main():
 
     total_env_steps = float(E) * K * world
     value = total_env_steps / wall_max
-    launch_s = ev_max / K
-    bytes_per_launch = bytes_per_env_step * E
+    ticks_per_launch = GRAPH_TICKS if (kind == "particle" and args.fused) else 1
+    launch_s = ev_max / (K / float(ticks_per_launch))
+    bytes_per_launch = bytes_per_env_step * E * ticks_per_launch
     achieved = bytes_per_launch / launch_s / 1e9
 
     out = None
@@ -321,10 +330,12 @@ def main():
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": wall_max / K * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype_name,
             "data": "synthetic (uniform random actions drawn in-kernel, Philox; preset/random resets, prob_random=0.2)",
-            "config": {"workload": "%s, %d vectorised envs per GPU, max_steps=33, auto-reset, one step-kernel launch "
-                                   "per tick" % (wl_desc, E),
+            "config": {"workload": "%s, %d vectorised envs per GPU, max_steps=33, auto-reset, %s"
+                                   % (wl_desc, E, "one step-kernel launch per tick" if ticks_per_launch == 1 else
+                                      "%d ticks fused per launch (random-action branch)" % ticks_per_launch),
                        "envs_per_gpu": E, "n_agents": N, "global_envs": E * world,
                        "launch": "eager" if args.no_graph else "hipGraph of %d ticks" % GRAPH_TICKS,
+                       "ticks_per_launch": ticks_per_launch,
                        "parallelism": "env-sharded x%d, no data-path collective" % world},
             "agent_steps_per_s": value * N,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -340,6 +351,24 @@ def main():
             out["roofline"]["traffic_source"] = ("profiles/pmc_traffic.json: %s, %d launches, FETCH_SIZE %.1f KB (x2) + "
                                                  "WRITE_SIZE %.1f KB" % (rec["kernel"], rec["launches"],
                                                                          rec["FETCH_SIZE_KB"], rec["WRITE_SIZE_KB"]))
+    if world == 1 and rank == 0 and kind == "particle" and not args.fused:
+        # Extra (not the headline): the same workload with all 33 ticks of an episode fused into ONE launch
+        # (CM3_FLAG_FUSED_TICKS) -- legal for the random-action branch only, where nothing acts between ticks.
+        fs = ParticleStepper(cfg, N, E, device, kernel=args.kernel, fused=True)
+        fs.capture(GRAPH_TICKS)
+        fs.run(GRAPH_TICKS * 4)
+        torch.cuda.synchronize(device)
+        f_ms = timed_ticks(fs, K)
+        f_bytes = (algorithmic_bytes_per_env_step(N) - (24 * N + 8) * (GRAPH_TICKS - 1) / float(GRAPH_TICKS)) * E * GRAPH_TICKS
+        f_launch_s = f_ms * 1e-3 / (K / float(GRAPH_TICKS))
+        out["fused_rollout"] = {
+            "note": "extra, not the headline: %d ticks per launch, state in registers, bit-identical trajectories "
+                    "(tests/test_gpu_rollout.py::test_fused_rollout_equals_per_tick_rollout)" % GRAPH_TICKS,
+            "value": E * K / (f_ms * 1e-3), "unit": "env-steps/s", "avg_launch_us": f_launch_s * 1e6,
+            "algorithmic_bytes_per_launch": f_bytes, "achieved_GBps": f_bytes / f_launch_s / 1e9,
+            "frac_of_peak": f_bytes / f_launch_s / 1e9 / HBM_PEAK_GBPS}
+        fs.close()
+        del fs
     if world == 1 and rank == 0:
         bw = measure_read_bandwidth(device)
         out["roofline"]["measured_read_GBps"] = bw
@@ -350,14 +379,14 @@ def main():
             del stepper
             for log2e in (14, 16, 18, 20, 22):
                 Es = 1 << log2e
-                st = ParticleStepper(cfg, N, Es, device, kernel=args.kernel)
+                st = ParticleStepper(cfg, N, Es, device, kernel=args.kernel, fused=args.fused)
                 st.capture(GRAPH_TICKS)
                 st.run(GRAPH_TICKS)
                 torch.cuda.synchronize(device)
                 n = GRAPH_TICKS * (10 if log2e <= 18 else 3)
                 ms = timed_ticks(st, n)
                 per = ms * 1e-3 / n
-                gbps = algorithmic_bytes_per_env_step(N) * Es / per / 1e9
+                gbps = bytes_per_env_step * Es / per / 1e9
                 sweep.append({"envs": Es, "env_steps_per_s": Es / per, "avg_launch_us": per * 1e6,
                               "achieved_GBps": gbps, "frac_of_peak": gbps / HBM_PEAK_GBPS,
                               "frac_of_measured_read": gbps / bw})

@@ -15,6 +15,7 @@ ABI_VERSION = 1
 FLAG_AUTO_RESET = 1
 FLAG_GEN_ACTIONS = 2
 FLAG_KERNEL_LANE_PER_ENV = 0x100
+FLAG_FUSED_TICKS = 0x400
 FLAG_KERNEL_LANE_PER_PAIR = 0x200
 KERNEL_FLAGS = {"auto": 0, "env": FLAG_KERNEL_LANE_PER_ENV, "pair": FLAG_KERNEL_LANE_PER_PAIR}
 

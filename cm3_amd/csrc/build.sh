@@ -7,10 +7,15 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function"
 mkdir -p "${HERE}/_obj"
 pids=()
-for f in particle checkers util; do
+"${HIPCC}" ${FLAGS} -DCM3_PARTICLE_F32 -c "${HERE}/particle.hip" -o "${HERE}/_obj/particle_f32.o" &
+pids+=($!)
+"${HIPCC}" ${FLAGS} -DCM3_PARTICLE_F64 -c "${HERE}/particle.hip" -o "${HERE}/_obj/particle_f64.o" &
+pids+=($!)
+for f in checkers util; do
   "${HIPCC}" ${FLAGS} -c "${HERE}/${f}.hip" -o "${HERE}/_obj/${f}.o" &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait "$p"; done
-"${HIPCC}" --offload-arch=gfx950 -shared -fPIC -o "${OUT}" "${HERE}/_obj/particle.o" "${HERE}/_obj/checkers.o" "${HERE}/_obj/util.o"
+"${HIPCC}" --offload-arch=gfx950 -shared -fPIC -o "${OUT}" "${HERE}/_obj/particle_f32.o" "${HERE}/_obj/particle_f64.o" \
+  "${HERE}/_obj/checkers.o" "${HERE}/_obj/util.o"
 echo "built ${OUT}"

@@ -62,7 +62,20 @@ struct ParticleParams {
   void *term_state;
   void *term_obs_others;
   const uint8_t *reset_mask;
+  // tick loop inside one launch (CM3_FLAG_FUSED_TICKS): tick t uses <pointer> + t * <stride in bytes> for the
+  // per-tick arrays (state_out / goals_out / obs_others / term_* point at slot 1 of their trajectories);
+  // n_ticks == 1 with zero strides is the plain one-launch-per-tick step.
+  int n_ticks;
+  int _pad2;
+  size_t st_state, st_goals, st_obs, st_actions, st_reward_n, st_reward, st_done, st_term_state, st_term_obs;
 };
+
+template <typename T> __device__ __forceinline__ T *tick_ptr(T *base, size_t stride, int t) {
+  return reinterpret_cast<T *>(reinterpret_cast<char *>(base) + stride * (size_t)t);
+}
+template <> __device__ __forceinline__ void *tick_ptr<void>(void *base, size_t stride, int t) {
+  return base ? (void *)(reinterpret_cast<char *>(base) + stride * (size_t)t) : nullptr;
+}
 
 // ---- scalar math per real ----------------------------------------------------------------------
 template <typename R> struct Math;
@@ -313,7 +326,7 @@ __device__ __forceinline__ void init_episode(const ParticleParams &p, uint64_t g
 }
 
 // ---- the step kernel --------------------------------------------------------------------------------
-template <typename R, int N, int WAVES>
+template <typename R, int N, int WAVES, bool FUSED>
 __global__ void __launch_bounds__(WAVES * 64) k_particle_step(const ParticleParams p) {
   using V4 = typename Vec<R>::v4;
   using V2 = typename Vec<R>::v2;
@@ -340,143 +353,158 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step(const ParticlePara
   const int2 meta = reinterpret_cast<const int2 *>(p.meta_in)[ec];
   int steps = meta.x, collisions = meta.y;
 
-  int act[N];
   const bool gen = (p.flags & CM3_FLAG_GEN_ACTIONS) != 0;
   uint32_t episode = 0;
   if (gen || (p.flags & CM3_FLAG_AUTO_RESET)) episode = (uint32_t)p.episode[ec];
+  const uint32_t episode_in = episode;
   const uint64_t genv = (uint64_t)(p.env_id_base + (int64_t)ec);
-  if (gen) {  // train_onpolicy.py:305-307
-    uint32_t words[4 * ((N + 3) / 4)];
-#pragma unroll
-    for (int c = 0; c < (N + 3) / 4; ++c) {
-      const u32x4 w = action_words(p.seed, genv, episode, (uint32_t)steps, (uint32_t)c);
-      words[4 * c + 0] = w.x;
-      words[4 * c + 1] = w.y;
-      words[4 * c + 2] = w.z;
-      words[4 * c + 3] = w.w;
-    }
-#pragma unroll
-    for (int i = 0; i < N; ++i) act[i] = rand5(words[i]);
-    if (active) store_row<int32_t, N>(p.actions, e, act);
-  } else {
-    load_row<int32_t, N>(p.actions, ec, act);
-  }
-
+  const R kDistMin = R(0.15) + R(0.15), kDt = R(0.1), kKeep = R(1 - 0.25);
   CM3_STAMP(1, true);
-  // ---- _set_action (environment.py:193-214) + apply_action_force (core.py:134-140) ------------------
-  R fx[N], fy[N];
-#pragma unroll
-  for (int i = 0; i < N; ++i) {
-    R ux = R(0), uy = R(0);
-    if (act[i] == 1) ux = R(-1);
-    if (act[i] == 2) ux = R(+1);
-    if (act[i] == 3) uy = R(-1);
-    if (act[i] == 4) uy = R(+1);
-    fx[i] = ux * R(5.0) + R(0.0);
-    fy[i] = uy * R(5.0) + R(0.0);
-  }
 
-  // ---- apply_environment_force (core.py:143-155) / get_collision_force (:180-196) -------------------
-  const R kDistMin = R(0.15) + R(0.15);
+  // The state stays in registers across the ticks of this launch (n_ticks == 1: plain one-launch-per-tick step).
+  // FUSED == false: exactly one tick, the loop and every per-tick pointer offset fold away at compile time
+  const int n_ticks = FUSED ? p.n_ticks : 1;
+#pragma unroll 1
+  for (int t = 0; t < n_ticks; ++t) {
+    int act[N];
+    int32_t *actions_t = tick_ptr(p.actions, p.st_actions, t);
+    if (gen) {  // train_onpolicy.py:305-307
+      uint32_t words[4 * ((N + 3) / 4)];
 #pragma unroll
-  for (int a = 0; a < N; ++a) {
+      for (int c = 0; c < (N + 3) / 4; ++c) {
+        const u32x4 w = action_words(p.seed, genv, episode, (uint32_t)steps, (uint32_t)c);
+        words[4 * c + 0] = w.x;
+        words[4 * c + 1] = w.y;
+        words[4 * c + 2] = w.z;
+        words[4 * c + 3] = w.w;
+      }
 #pragma unroll
-    for (int b = a + 1; b < N; ++b) {
-      R f_x, f_y;
-      contact_force<R>(s[a].z - s[b].z, s[a].w - s[b].w, f_x, f_y);
-      fx[a] = f_x + fx[a];
-      fy[a] = f_y + fy[a];
-      fx[b] = (-f_x) + fx[b];
-      fy[b] = (-f_y) + fy[b];
+      for (int i = 0; i < N; ++i) act[i] = rand5(words[i]);
+      if (active) store_row<int32_t, N>(actions_t, e, act);
+    } else {
+      load_row<int32_t, N>(actions_t, ec, act);
     }
-  }
 
-  // ---- integrate_state (core.py:158-169): mass 1, max_speed None -------------------------------------
-  const R kDt = R(0.1), kKeep = R(1 - 0.25);
+    // ---- _set_action (environment.py:193-214) + apply_action_force (core.py:134-140) ----------------
+    R fx[N], fy[N];
 #pragma unroll
-  for (int i = 0; i < N; ++i) {
-    s[i].x = s[i].x * kKeep;
-    s[i].y = s[i].y * kKeep;
-    s[i].x = s[i].x + (fx[i] / R(1.0)) * kDt;
-    s[i].y = s[i].y + (fy[i] / R(1.0)) * kDt;
-    s[i].z = s[i].z + s[i].x * kDt;
-    s[i].w = s[i].w + s[i].y * kDt;
-  }
-  steps += 1;  // environment.py:93
-  CM3_STAMP(2, false);
+    for (int i = 0; i < N; ++i) {
+      R ux = R(0), uy = R(0);
+      if (act[i] == 1) ux = R(-1);
+      if (act[i] == 2) ux = R(+1);
+      if (act[i] == 3) uy = R(-1);
+      if (act[i] == 4) uy = R(+1);
+      fx[i] = ux * R(5.0) + R(0.0);
+      fy[i] = uy * R(5.0) + R(0.0);
+    }
 
-  // ---- reward / reached (multi-goal_spread.py:121-143) ------------------------------------------------
-  R rew[N];
-  bool all_reached = true;
+    // ---- apply_environment_force (core.py:143-155) / get_collision_force (:180-196) -----------------
 #pragma unroll
-  for (int i = 0; i < N; ++i) {
-    const R dx = s[i].z - g[i].x, dy = s[i].w - g[i].y;
-    rew[i] = R(0) - Math<R>::sqrt(dx * dx + dy * dy);
-    all_reached = all_reached && (rew[i] >= R(-0.05));
-  }
+    for (int a = 0; a < N; ++a) {
 #pragma unroll
-  for (int a = 0; a < N; ++a) {
-#pragma unroll
-    for (int b = a + 1; b < N; ++b) {
-      // is_collision is symmetric, so the reference's two ordered visits (j,i) and (i,j) collapse into one
-      const R dx = s[b].z - s[a].z, dy = s[b].w - s[a].w;
-      if (Math<R>::sqrt(dx * dx + dy * dy) < kDistMin) {
-        rew[a] = rew[a] - R(1);
-        rew[b] = rew[b] - R(1);
-        collisions += 2;  // double counts by design (:135-137)
+      for (int b = a + 1; b < N; ++b) {
+        R f_x, f_y;
+        contact_force<R>(s[a].z - s[b].z, s[a].w - s[b].w, f_x, f_y);
+        fx[a] = f_x + fx[a];
+        fy[a] = f_y + fy[a];
+        fx[b] = (-f_x) + fx[b];
+        fy[b] = (-f_y) + fy[b];
       }
     }
-  }
-  const R reward = sum_agents<R, N>(rew);                       // environment.py:107
-  const bool done = (steps == p.max_steps) || all_reached;      // environment.py:118-121
 
-  CM3_STAMP(3, false);
-  if (active) {
-    store_row<R, N>(reinterpret_cast<R *>(p.reward_n), e, rew);
-    reinterpret_cast<R *>(p.reward)[e] = reward;
-    p.done[e] = done ? 1 : 0;
-  }
-  CM3_STAMP(8, false);
+    // ---- integrate_state (core.py:158-169): mass 1, max_speed None -----------------------------------
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      s[i].x = s[i].x * kKeep;
+      s[i].y = s[i].y * kKeep;
+      s[i].x = s[i].x + (fx[i] / R(1.0)) * kDt;
+      s[i].y = s[i].y + (fy[i] / R(1.0)) * kDt;
+      s[i].z = s[i].z + s[i].x * kDt;
+      s[i].w = s[i].w + s[i].y * kDt;
+    }
+    steps += 1;  // environment.py:93
+    CM3_STAMP(2, false);
 
-  // ---- same-launch re-initialisation of finished episodes ---------------------------------------------
-  bool was_reset = false;
-  if ((p.flags & CM3_FLAG_AUTO_RESET) && done) {
+    // ---- reward / reached (multi-goal_spread.py:121-143) ----------------------------------------------
+    R rew[N];
+    bool all_reached = true;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const R dx = s[i].z - g[i].x, dy = s[i].w - g[i].y;
+      rew[i] = R(0) - Math<R>::sqrt(dx * dx + dy * dy);
+      all_reached = all_reached && (rew[i] >= R(-0.05));
+    }
+#pragma unroll
+    for (int a = 0; a < N; ++a) {
+#pragma unroll
+      for (int b = a + 1; b < N; ++b) {
+        // is_collision is symmetric, so the reference's two ordered visits (j,i) and (i,j) collapse into one
+        const R dx = s[b].z - s[a].z, dy = s[b].w - s[a].w;
+        if (Math<R>::sqrt(dx * dx + dy * dy) < kDistMin) {
+          rew[a] = rew[a] - R(1);
+          rew[b] = rew[b] - R(1);
+          collisions += 2;  // double counts by design (:135-137)
+        }
+      }
+    }
+    const R reward = sum_agents<R, N>(rew);                   // environment.py:107
+    const bool done = (steps == p.max_steps) || all_reached;  // environment.py:118-121
+
+    CM3_STAMP(3, false);
     if (active) {
-      if (p.term_state) {
-        V4 *t4 = reinterpret_cast<V4 *>(p.term_state);
-#pragma unroll
-        for (int i = 0; i < N; ++i) t4[(size_t)i * E + e] = s[i];
-      }
-      if (p.term_obs_others) store_obs_others_direct<R, N>(s, e, reinterpret_cast<R *>(p.term_obs_others));
+      store_row<R, N>(reinterpret_cast<R *>(tick_ptr(p.reward_n, p.st_reward_n, t)), e, rew);
+      reinterpret_cast<R *>(tick_ptr(p.reward, p.st_reward, t))[e] = reward;
+      tick_ptr(p.done, p.st_done, t)[e] = done ? 1 : 0;
     }
-    episode += 1;
-    init_episode<R, N>(p, genv, episode, s, g);
-    steps = 0;
-    collisions = 0;
-    was_reset = true;
-    if (active) p.episode[e] = (int32_t)episode;
-  }
-  CM3_STAMP(9, false);
+    CM3_STAMP(8, false);
 
-  if (active) {
-    V4 *sout4 = reinterpret_cast<V4 *>(p.state_out);
+    // ---- same-launch re-initialisation of finished episodes -------------------------------------------
+    bool was_reset = false;
+    if ((p.flags & CM3_FLAG_AUTO_RESET) && done) {
+      if (active) {
+        void *term_state = tick_ptr(p.term_state, p.st_term_state, t);
+        void *term_obs = tick_ptr(p.term_obs_others, p.st_term_obs, t);
+        if (term_state) {
+          V4 *t4 = reinterpret_cast<V4 *>(term_state);
 #pragma unroll
-    for (int i = 0; i < N; ++i) sout4[(size_t)i * E + e] = s[i];
-    if (p.goals_out != p.goals_in || was_reset) {
-      V2 *gout2 = reinterpret_cast<V2 *>(p.goals_out);
-#pragma unroll
-      for (int i = 0; i < N; ++i) gout2[(size_t)i * E + e] = g[i];
+          for (int i = 0; i < N; ++i) t4[(size_t)i * E + e] = s[i];
+        }
+        if (term_obs) store_obs_others_direct<R, N>(s, e, reinterpret_cast<R *>(term_obs));
+      }
+      episode += 1;
+      init_episode<R, N>(p, genv, episode, s, g);
+      steps = 0;
+      collisions = 0;
+      was_reset = true;
     }
+    CM3_STAMP(9, false);
+
+    if (active) {
+      V4 *sout4 = reinterpret_cast<V4 *>(tick_ptr(p.state_out, p.st_state, t));
+#pragma unroll
+      for (int i = 0; i < N; ++i) sout4[(size_t)i * E + e] = s[i];
+      if (p.goals_out != p.goals_in || was_reset) {
+        V2 *gout2 = reinterpret_cast<V2 *>(tick_ptr(p.goals_out, p.st_goals, t));
+#pragma unroll
+        for (int i = 0; i < N; ++i) gout2[(size_t)i * E + e] = g[i];
+      }
+    }
+
+    CM3_STAMP(4, false);
+    // ---- observation (multi-goal_spread.py:145-154), env-major rows through the wave's LDS tile --------
+    store_obs_others_staged<R, N>(s, &lds_all[wave][0], lane, e0, p.E,
+                                  reinterpret_cast<R *>(tick_ptr(p.obs_others, p.st_obs, t)));
+    CM3_STAMP(5, false);
+  }
+
+  // ---- live counters, once per launch ----------------------------------------------------------------------
+  if (active) {
     int2 m;
     m.x = steps;
     m.y = collisions;
     reinterpret_cast<int2 *>(p.meta_out)[e] = m;
+    if (episode != episode_in) p.episode[e] = (int32_t)episode;
   }
-
-  CM3_STAMP(4, false);
-  // ---- observation (multi-goal_spread.py:145-154), env-major rows through the wave's LDS tile ----------
-  store_obs_others_staged<R, N>(s, &lds_all[wave][0], lane, e0, p.E, reinterpret_cast<R *>(p.obs_others));
-  CM3_STAMP(5, false);
   CM3_STAMP(6, true);
 }
 
@@ -502,7 +530,7 @@ template <int N> struct PairGeom {
   static constexpr int EPW = 64 / G;  // envs per wave
 };
 
-template <typename R, int N, int WAVES>
+template <typename R, int N, int WAVES, bool FUSED>
 __global__ void __launch_bounds__(WAVES * 64) k_particle_step_pairs(const ParticleParams p) {
   static_assert(N >= 2, "the pair mapping needs at least two agents");
   using V4 = typename Vec<R>::v4;
@@ -521,137 +549,142 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_pairs(const Partic
   const int i = gi / NO, k = gi - i * NO, j = k < i ? k : k + 1;
   const bool lead = slot_ok && k == 0;  // one lane per agent does the per-agent stores
   const bool head = gslot == 0;         // one lane per env does the per-env stores
-  CM3_STAMP(0, false);
 
-  // ---- loads -----------------------------------------------------------------------------------------------
+  // ---- loads (once per launch; the state then lives in registers across the ticks of this launch) -------------
   const V4 *sin4 = reinterpret_cast<const V4 *>(p.state_in);
   V4 si = sin4[(size_t)i * E + ec];
-  const V4 sj_in = sin4[(size_t)j * E + ec];
+  V4 sj = sin4[(size_t)j * E + ec];
   V2 gl = reinterpret_cast<const V2 *>(p.goals_in)[(size_t)i * E + ec];
   const int2 meta = reinterpret_cast<const int2 *>(p.meta_in)[ec];
   int steps = meta.x, collisions = meta.y;
   const bool gen = (p.flags & CM3_FLAG_GEN_ACTIONS) != 0;
   uint32_t episode = 0;
   if (gen || (p.flags & CM3_FLAG_AUTO_RESET)) episode = (uint32_t)p.episode[ec];
+  const uint32_t episode_in = episode;
   const uint64_t genv = (uint64_t)(p.env_id_base + (int64_t)ec);
-  int act;
-  if (gen) {  // train_onpolicy.py:305-307
-    const u32x4 w = action_words(p.seed, genv, episode, (uint32_t)steps, (uint32_t)(i >> 2));
-    const int q = i & 3;
-    act = rand5(q == 0 ? w.x : (q == 1 ? w.y : (q == 2 ? w.z : w.w)));
-    if (env_ok && lead) p.actions[e * N + i] = act;
-  } else {
-    act = p.actions[ec * N + i];
-  }
-
-  CM3_STAMP(1, true);
-  // ---- action force + own contact force ----------------------------------------------------------------------
-  R ux = R(0), uy = R(0);
-  if (act == 1) ux = R(-1);
-  if (act == 2) ux = R(+1);
-  if (act == 3) uy = R(-1);
-  if (act == 4) uy = R(+1);
-  R Fx = ux * R(5.0) + R(0.0), Fy = uy * R(5.0) + R(0.0);
-  R f_x, f_y;
-  contact_force<R>(si.z - sj_in.z, si.w - sj_in.w, f_x, f_y);
-#pragma unroll
-  for (int kk = 0; kk < NO; ++kk) {  // contributions of agent i in the reference's order (j ascending)
-    const int src = base + i * NO + kk;
-    Fx = __shfl(f_x, src, 64) + Fx;
-    Fy = __shfl(f_y, src, 64) + Fy;
-  }
-
-  CM3_STAMP(2, true);
-  // ---- integrate agent i (every lane of agent i computes the same values) -----------------------------------
   const R kDt = R(0.1), kKeep = R(1 - 0.25), kDistMin = R(0.15) + R(0.15);
-  si.x = si.x * kKeep;
-  si.y = si.y * kKeep;
-  si.x = si.x + (Fx / R(1.0)) * kDt;
-  si.y = si.y + (Fy / R(1.0)) * kDt;
-  si.z = si.z + si.x * kDt;
-  si.w = si.w + si.y * kDt;
-  steps += 1;
-  V4 sj;
-  {
-    const int src = base + j * NO;  // lead lane of agent j
-    sj.x = __shfl(si.x, src, 64);
-    sj.y = __shfl(si.y, src, 64);
-    sj.z = __shfl(si.z, src, 64);
-    sj.w = __shfl(si.w, src, 64);
-  }
 
-  CM3_STAMP(3, true);
-  // ---- reward / reached / collisions (multi-goal_spread.py:114-143) ------------------------------------------
-  R rew;
-  {
-    const R dx = si.z - gl.x, dy = si.w - gl.y;
-    rew = R(0) - Math<R>::sqrt(dx * dx + dy * dy);
-  }
-  const bool reached = rew >= R(-0.05);
-  bool hit;
-  {
-    const R dx = sj.z - si.z, dy = sj.w - si.w;  // is_collision(a = j, agent = i)
-    hit = slot_ok && (Math<R>::sqrt(dx * dx + dy * dy) < kDistMin);
-  }
-  const unsigned long long hits = __ballot(hit);
-  const unsigned long long grp = (G == 64) ? hits : ((hits >> base) & ((1ull << (G & 63)) - 1ull));
-  const int c_i = __popcll((grp >> (i * NO)) & ((1ull << NO) - 1ull));
+  // FUSED == false: exactly one tick, the loop and every per-tick pointer offset fold away at compile time
+  const int n_ticks = FUSED ? p.n_ticks : 1;
+#pragma unroll 1
+  for (int t = 0; t < n_ticks; ++t) {
+    int32_t *actions_t = tick_ptr(p.actions, p.st_actions, t);
+    int act;
+    if (gen) {  // train_onpolicy.py:305-307
+      const u32x4 w = action_words(p.seed, genv, episode, (uint32_t)steps, (uint32_t)(i >> 2));
+      const int q = i & 3;
+      act = rand5(q == 0 ? w.x : (q == 1 ? w.y : (q == 2 ? w.z : w.w)));
+      if (env_ok && lead) actions_t[e * N + i] = act;
+    } else {
+      act = actions_t[ec * N + i];
+    }
+
+    // ---- action force + own contact force --------------------------------------------------------------------
+    R ux = R(0), uy = R(0);
+    if (act == 1) ux = R(-1);
+    if (act == 2) ux = R(+1);
+    if (act == 3) uy = R(-1);
+    if (act == 4) uy = R(+1);
+    R Fx = ux * R(5.0) + R(0.0), Fy = uy * R(5.0) + R(0.0);
+    R f_x, f_y;
+    contact_force<R>(si.z - sj.z, si.w - sj.w, f_x, f_y);
 #pragma unroll
-  for (int c = 0; c < NO; ++c)
-    if (c < c_i) rew = rew - R(1);
-  collisions += __popcll(grp);  // every ordered visit counts (:135-137)
-  const unsigned long long rb = __ballot(reached && lead);
-  const unsigned long long rgrp = (G == 64) ? rb : ((rb >> base) & ((1ull << (G & 63)) - 1ull));
-  const bool all_reached = __popcll(rgrp) == N;
-  R rews[N];
+    for (int kk = 0; kk < NO; ++kk) {  // contributions of agent i in the reference's order (j ascending)
+      const int src = base + i * NO + kk;
+      Fx = __shfl(f_x, src, 64) + Fx;
+      Fy = __shfl(f_y, src, 64) + Fy;
+    }
+
+    // ---- integrate agent i (every lane of agent i computes the same values) ---------------------------------
+    si.x = si.x * kKeep;
+    si.y = si.y * kKeep;
+    si.x = si.x + (Fx / R(1.0)) * kDt;
+    si.y = si.y + (Fy / R(1.0)) * kDt;
+    si.z = si.z + si.x * kDt;
+    si.w = si.w + si.y * kDt;
+    steps += 1;
+    {
+      const int src = base + j * NO;  // lead lane of agent j
+      sj.x = __shfl(si.x, src, 64);
+      sj.y = __shfl(si.y, src, 64);
+      sj.z = __shfl(si.z, src, 64);
+      sj.w = __shfl(si.w, src, 64);
+    }
+
+    // ---- reward / reached / collisions (multi-goal_spread.py:114-143) ----------------------------------------
+    R rew;
+    {
+      const R dx = si.z - gl.x, dy = si.w - gl.y;
+      rew = R(0) - Math<R>::sqrt(dx * dx + dy * dy);
+    }
+    const bool reached = rew >= R(-0.05);
+    bool hit;
+    {
+      const R dx = sj.z - si.z, dy = sj.w - si.w;  // is_collision(a = j, agent = i)
+      hit = slot_ok && (Math<R>::sqrt(dx * dx + dy * dy) < kDistMin);
+    }
+    const unsigned long long hits = __ballot(hit);
+    const unsigned long long grp = (G == 64) ? hits : ((hits >> base) & ((1ull << (G & 63)) - 1ull));
+    const int c_i = __popcll((grp >> (i * NO)) & ((1ull << NO) - 1ull));
 #pragma unroll
-  for (int a = 0; a < N; ++a) rews[a] = __shfl(rew, base + a * NO, 64);
-  const R reward = sum_agents<R, N>(rews);
-  const bool done = (steps == p.max_steps) || all_reached;
+    for (int c = 0; c < NO; ++c)
+      if (c < c_i) rew = rew - R(1);
+    collisions += __popcll(grp);  // every ordered visit counts (:135-137)
+    const unsigned long long rb = __ballot(reached && lead);
+    const unsigned long long rgrp = (G == 64) ? rb : ((rb >> base) & ((1ull << (G & 63)) - 1ull));
+    const bool all_reached = __popcll(rgrp) == N;
+    R rews[N];
+#pragma unroll
+    for (int a = 0; a < N; ++a) rews[a] = __shfl(rew, base + a * NO, 64);
+    const R reward = sum_agents<R, N>(rews);
+    const bool done = (steps == p.max_steps) || all_reached;
 
-  CM3_STAMP(4, true);
-  if (env_ok && lead) reinterpret_cast<R *>(p.reward_n)[e * N + i] = rew;
-  if (env_ok && head) {
-    reinterpret_cast<R *>(p.reward)[e] = reward;
-    p.done[e] = done ? 1 : 0;
-  }
+    if (env_ok && lead) reinterpret_cast<R *>(tick_ptr(p.reward_n, p.st_reward_n, t))[e * N + i] = rew;
+    if (env_ok && head) {
+      reinterpret_cast<R *>(tick_ptr(p.reward, p.st_reward, t))[e] = reward;
+      tick_ptr(p.done, p.st_done, t)[e] = done ? 1 : 0;
+    }
 
-  // ---- same-launch re-initialisation ---------------------------------------------------------------------------
-  bool was_reset = false;
-  if ((p.flags & CM3_FLAG_AUTO_RESET) && done) {
+    // ---- same-launch re-initialisation -------------------------------------------------------------------------
+    bool was_reset = false;
+    if ((p.flags & CM3_FLAG_AUTO_RESET) && done) {
+      if (env_ok) {
+        void *term_state = tick_ptr(p.term_state, p.st_term_state, t);
+        void *term_obs = tick_ptr(p.term_obs_others, p.st_term_obs, t);
+        if (term_state && lead) reinterpret_cast<V4 *>(term_state)[(size_t)i * E + e] = si;
+        if (term_obs && slot_ok) reinterpret_cast<V4 *>(term_obs)[e * SLOTS + gslot] = sub4<R, V4>(sj, si);
+      }
+      episode += 1;
+      const bool rnd = episode_is_random(p, genv, episode);
+      V2 gj;
+      init_agent<R, N>(p, genv, episode, rnd, i, si, gl);
+      init_agent<R, N>(p, genv, episode, rnd, j, sj, gj);
+      steps = 0;
+      collisions = 0;
+      was_reset = true;
+    }
+
+    // ---- per-tick stores ------------------------------------------------------------------------------------------
     if (env_ok) {
-      if (p.term_state && lead) reinterpret_cast<V4 *>(p.term_state)[(size_t)i * E + e] = si;
-      if (p.term_obs_others && slot_ok)
-        reinterpret_cast<V4 *>(p.term_obs_others)[e * SLOTS + gslot] = sub4<R, V4>(sj, si);
+      if (lead) {
+        reinterpret_cast<V4 *>(tick_ptr(p.state_out, p.st_state, t))[(size_t)i * E + e] = si;
+        if (p.goals_out != p.goals_in || was_reset)
+          reinterpret_cast<V2 *>(tick_ptr(p.goals_out, p.st_goals, t))[(size_t)i * E + e] = gl;
+      }
+      // observation (multi-goal_spread.py:145-154): vector (i,k) of env e; lanes of a wave cover whole records
+      if (slot_ok)
+        reinterpret_cast<V4 *>(tick_ptr(p.obs_others, p.st_obs, t))[e * SLOTS + gslot] = sub4<R, V4>(sj, si);
     }
-    episode += 1;
-    const bool rnd = episode_is_random(p, genv, episode);
-    V2 gj;
-    init_agent<R, N>(p, genv, episode, rnd, i, si, gl);
-    init_agent<R, N>(p, genv, episode, rnd, j, sj, gj);
-    steps = 0;
-    collisions = 0;
-    was_reset = true;
-    if (env_ok && head) p.episode[e] = (int32_t)episode;
   }
 
-  // ---- stores ----------------------------------------------------------------------------------------------------
-  if (env_ok) {
-    if (lead) {
-      reinterpret_cast<V4 *>(p.state_out)[(size_t)i * E + e] = si;
-      if (p.goals_out != p.goals_in || was_reset) reinterpret_cast<V2 *>(p.goals_out)[(size_t)i * E + e] = gl;
-    }
-    if (head) {
-      int2 m;
-      m.x = steps;
-      m.y = collisions;
-      reinterpret_cast<int2 *>(p.meta_out)[e] = m;
-    }
-    // observation (multi-goal_spread.py:145-154): vector (i,k) of env e; lanes of a wave cover whole records
-    if (slot_ok) reinterpret_cast<V4 *>(p.obs_others)[e * SLOTS + gslot] = sub4<R, V4>(sj, si);
+  // ---- live counters, once per launch -------------------------------------------------------------------------------
+  if (env_ok && head) {
+    int2 m;
+    m.x = steps;
+    m.y = collisions;
+    reinterpret_cast<int2 *>(p.meta_out)[e] = m;
+    if (episode != episode_in) p.episode[e] = (int32_t)episode;
   }
-  CM3_STAMP(5, false);
-  CM3_STAMP(6, true);
 }
 
 // ---- reset kernel (environment.py:125-149) ------------------------------------------------------------
@@ -722,7 +755,7 @@ static int fill_params(const cm3_particle_desc *d, const cm3_particle_bufs *b, P
               CM3_MAX_AGENTS, d->n_agents);
   CM3_REQUIRE(d->max_steps >= 1, "max_steps must be >= 1");
   CM3_REQUIRE((d->flags & ~(CM3_FLAG_AUTO_RESET | CM3_FLAG_GEN_ACTIONS | CM3_FLAG_KERNEL_LANE_PER_ENV |
-                            CM3_FLAG_KERNEL_LANE_PER_PAIR)) == 0,
+                            CM3_FLAG_KERNEL_LANE_PER_PAIR | CM3_FLAG_FUSED_TICKS)) == 0,
               "unknown flag bits 0x%x", d->flags);
   CM3_REQUIRE(!((d->flags & CM3_FLAG_KERNEL_LANE_PER_ENV) && (d->flags & CM3_FLAG_KERNEL_LANE_PER_PAIR)),
               "both kernel-mapping flags set");
@@ -741,9 +774,10 @@ static int fill_params(const cm3_particle_desc *d, const cm3_particle_bufs *b, P
     CM3_REQUIRE(b->state_in, "observe: state_in is required");
   }
   memset(&p, 0, sizeof(p));
+  p.n_ticks = 1;
   p.E = d->n_envs;
   p.max_steps = d->max_steps;
-  p.flags = d->flags;
+  p.flags = d->flags & ~CM3_FLAG_FUSED_TICKS;
   p.env_id_base = d->env_id_base;
   p.seed = d->seed;
   p.prob_random = d->prob_random;
@@ -778,7 +812,10 @@ static int launch_one(const ParticleParams &p, ParticleOp op, hipStream_t stream
   const unsigned blocks = (unsigned)(((size_t)p.E + per_block - 1) / per_block);
   switch (op) {
     case kStep:
-      hipLaunchKernelGGL((k_particle_step<R, N, WAVES>), dim3(blocks), dim3(per_block), 0, stream, p);
+      if (p.n_ticks > 1)
+        hipLaunchKernelGGL((k_particle_step<R, N, WAVES, true>), dim3(blocks), dim3(per_block), 0, stream, p);
+      else
+        hipLaunchKernelGGL((k_particle_step<R, N, WAVES, false>), dim3(blocks), dim3(per_block), 0, stream, p);
       break;
     case kReset:
       hipLaunchKernelGGL((k_particle_reset<R, N, WAVES>), dim3(blocks), dim3(per_block), 0, stream, p);
@@ -795,7 +832,10 @@ template <typename R, int N, int WAVES> static int launch_pairs(const ParticlePa
   if constexpr (N >= 2) {
     const size_t envs_per_block = (size_t)WAVES * PairGeom<N>::EPW;
     const unsigned blocks = (unsigned)(((size_t)p.E + envs_per_block - 1) / envs_per_block);
-    hipLaunchKernelGGL((k_particle_step_pairs<R, N, WAVES>), dim3(blocks), dim3(WAVES * 64), 0, stream, p);
+    if (p.n_ticks > 1)
+      hipLaunchKernelGGL((k_particle_step_pairs<R, N, WAVES, true>), dim3(blocks), dim3(WAVES * 64), 0, stream, p);
+    else
+      hipLaunchKernelGGL((k_particle_step_pairs<R, N, WAVES, false>), dim3(blocks), dim3(WAVES * 64), 0, stream, p);
     CM3_HIP_CHECK(hipGetLastError());
     return CM3_OK;
   } else {
@@ -859,6 +899,42 @@ static int particle_rollout(const cm3_particle_desc *d, const cm3_particle_traj 
   auto at = [](void *base, size_t stride, int k) -> void * {
     return base ? (void *)((char *)base + stride * (size_t)k) : nullptr;
   };
+  if (d->flags & CM3_FLAG_FUSED_TICKS) {
+    // ONE launch runs all n_ticks ticks with the state in registers (no per-tick launch, no state re-load).
+    // Only possible when no host/policy step is needed between ticks: actions are drawn in-kernel, or all
+    // n_ticks action slots were filled beforehand.
+    CM3_REQUIRE((d->flags & CM3_FLAG_GEN_ACTIONS) || n_ticks == 1 || t->actions_stride != 0,
+                "fused rollout needs in-kernel actions or one pre-filled action slot per tick");
+    cm3_particle_bufs b;
+    memset(&b, 0, sizeof(b));
+    b.state_in = t->state;
+    b.state_out = at(t->state, t->state_stride, 1);
+    b.goals_in = t->goals;
+    b.goals_out = at(t->goals, t->goals_stride, 1);
+    b.meta_in = b.meta_out = t->meta;
+    b.episode = t->episode;
+    b.actions = t->actions;
+    b.obs_others = at(t->obs_others, t->obs_others_stride, 1);
+    b.reward_n = t->reward_n;
+    b.reward = t->reward;
+    b.done = t->done;
+    b.term_state = t->term_state;
+    b.term_obs_others = t->term_obs_others;
+    ParticleParams p;
+    int rc = fill_params(d, &b, kStep, nullptr, p);
+    if (rc != CM3_OK) return rc;
+    p.n_ticks = n_ticks;
+    p.st_state = t->state_stride;
+    p.st_goals = t->goals_stride;
+    p.st_obs = t->obs_others_stride;
+    p.st_actions = t->actions_stride;
+    p.st_reward_n = t->reward_n_stride;
+    p.st_reward = t->reward_stride;
+    p.st_done = t->done_stride;
+    p.st_term_state = t->term_state_stride;
+    p.st_term_obs = t->term_obs_others_stride;
+    return launch<R>(p, d->n_agents, kStep, (hipStream_t)stream);
+  }
   for (int k = 0; k < n_ticks; ++k) {
     cm3_particle_bufs b;
     memset(&b, 0, sizeof(b));
@@ -884,29 +960,40 @@ static int particle_rollout(const cm3_particle_desc *d, const cm3_particle_traj 
 
 }  // namespace cm3
 
+// The library compiles this file twice (build.sh): -DCM3_PARTICLE_F32 and -DCM3_PARTICLE_F64 each instantiate one
+// real type, which halves the wall-clock of the build.  Without either macro both are instantiated.
+#if !defined(CM3_PARTICLE_F32) && !defined(CM3_PARTICLE_F64)
+#define CM3_PARTICLE_F32 1
+#define CM3_PARTICLE_F64 1
+#endif
+
 extern "C" {
+#ifdef CM3_PARTICLE_F32
 int cm3_particle_step_f32(const cm3_particle_desc *d, const cm3_particle_bufs *b, void *s) {
   return cm3::particle_call<float>(d, b, cm3::kStep, nullptr, s);
-}
-int cm3_particle_step_f64(const cm3_particle_desc *d, const cm3_particle_bufs *b, void *s) {
-  return cm3::particle_call<double>(d, b, cm3::kStep, nullptr, s);
 }
 int cm3_particle_reset_f32(const cm3_particle_desc *d, const cm3_particle_bufs *b, const uint8_t *m, void *s) {
   return cm3::particle_call<float>(d, b, cm3::kReset, m, s);
 }
-int cm3_particle_reset_f64(const cm3_particle_desc *d, const cm3_particle_bufs *b, const uint8_t *m, void *s) {
-  return cm3::particle_call<double>(d, b, cm3::kReset, m, s);
-}
 int cm3_particle_observe_f32(const cm3_particle_desc *d, const cm3_particle_bufs *b, void *s) {
   return cm3::particle_call<float>(d, b, cm3::kObserve, nullptr, s);
-}
-int cm3_particle_observe_f64(const cm3_particle_desc *d, const cm3_particle_bufs *b, void *s) {
-  return cm3::particle_call<double>(d, b, cm3::kObserve, nullptr, s);
 }
 int cm3_particle_rollout_f32(const cm3_particle_desc *d, const cm3_particle_traj *t, int32_t n, void *s) {
   return cm3::particle_rollout<float>(d, t, n, s);
 }
+#endif
+#ifdef CM3_PARTICLE_F64
+int cm3_particle_step_f64(const cm3_particle_desc *d, const cm3_particle_bufs *b, void *s) {
+  return cm3::particle_call<double>(d, b, cm3::kStep, nullptr, s);
+}
+int cm3_particle_reset_f64(const cm3_particle_desc *d, const cm3_particle_bufs *b, const uint8_t *m, void *s) {
+  return cm3::particle_call<double>(d, b, cm3::kReset, m, s);
+}
+int cm3_particle_observe_f64(const cm3_particle_desc *d, const cm3_particle_bufs *b, void *s) {
+  return cm3::particle_call<double>(d, b, cm3::kObserve, nullptr, s);
+}
 int cm3_particle_rollout_f64(const cm3_particle_desc *d, const cm3_particle_traj *t, int32_t n, void *s) {
   return cm3::particle_rollout<double>(d, t, n, s);
 }
+#endif
 }

@@ -62,10 +62,13 @@ class ParticleRollout(object):
         next-state/obs are captured per tick, goals are recorded per slot; every transition is valid.
     """
 
-    def __init__(self, env, n_ticks=None, use_graph=True):
+    def __init__(self, env, n_ticks=None, use_graph=True, fused=False):
         self.env = env
         self.T = int(n_ticks or env.max_steps)
         self.use_graph = bool(use_graph)
+        # fused: the random-action branch runs all T ticks in ONE launch (CM3_FLAG_FUSED_TICKS; state in
+        # registers, identical results).  Policy-driven collection always launches once per tick.
+        self.fused = bool(fused)
         E, N, L, T, dev, dt = env.E, env.n, env.L, self.T, env.device, env.dtype
         z = lambda *s, d=dt: torch.zeros(*s, dtype=d, device=dev)  # noqa: E731
         self.state = z(T + 1, N, E, 4)
@@ -155,7 +158,9 @@ class ParticleRollout(object):
         base = (FLAG_AUTO_RESET if self.auto_reset else 0) | env.kernel_flags
         if policy is None:
             flags = base | FLAG_GEN_ACTIONS
-            if self.use_graph:
+            if self.fused:
+                self._enqueue(0, self.T, flags | _lib.FLAG_FUSED_TICKS)
+            elif self.use_graph:
                 if self._graph is None:
                     self._graph = _lib.capture_graph(env.device, lambda s: self._enqueue(0, self.T, flags, s))
                 _lib.check(self._lib.cm3_graph_launch(self._graph, env._stream()))

@@ -60,6 +60,9 @@ extern "C" {
                                     Philox4x32-10 keyed (seed, global env id, episode, step), and WRITTEN to
                                     `actions` */
 
+#define CM3_FLAG_FUSED_TICKS 0x400u  /* cm3_particle_rollout_* only: run all n_ticks ticks in ONE launch with the
+                                       state in registers (identical results).  Needs CM3_FLAG_GEN_ACTIONS or one
+                                       pre-filled action slot per tick: nothing can act between the ticks */
 #define CM3_FLAG_KERNEL_LANE_PER_ENV 0x100u  /* particle step: force the one-lane-per-env mapping   */
 #define CM3_FLAG_KERNEL_LANE_PER_PAIR 0x200u /* particle step: force the one-lane-per-agent-pair mapping
                                                 (default: chosen from n_envs; both give identical results) */

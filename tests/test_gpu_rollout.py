@@ -142,3 +142,30 @@ def test_checkers_rollout_matches_oracle_and_16_column_layout():
         assert np.array_equal(cols["actions_prev"][b], ro.actions[t - 1, e].cpu().numpy())
     rows = ro.as_reference_rows(tt[:4], ee[:4])
     assert rows.shape == (4, 16)
+
+
+@pytest.mark.parametrize("kernel", ["env", "pair"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("auto_reset", [False, True])
+def test_fused_rollout_equals_per_tick_rollout(kernel, dtype, auto_reset):
+    """CM3_FLAG_FUSED_TICKS (all ticks in one launch, state in registers) is bit-identical to one launch per tick."""
+    from cm3_amd.rollout import ParticleRollout
+    E, T = 777, 40
+    outs = []
+    for fused in (False, True):
+        env = _penv(E, dtype=dtype, cfg="particle_stage2_cross.json", seed=4, auto_reset=auto_reset, max_steps=9,
+                    kernel=kernel)
+        env.reset()
+        ro = ParticleRollout(env, n_ticks=T, use_graph=False, fused=fused).collect(reset=False)
+        outs.append((ro, env))
+    a, b = outs[0][0], outs[1][0]
+    for name in ("state", "obs_others", "actions", "reward", "reward_n", "done"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    if auto_reset:
+        assert torch.equal(a.goals, b.goals)
+        d = a.done.bool()
+        assert torch.equal(a.term_state.permute(0, 2, 1, 3)[d], b.term_state.permute(0, 2, 1, 3)[d])
+        assert torch.equal(a.term_obs_others[d], b.term_obs_others[d])
+    ea, eb = outs[0][1], outs[1][1]
+    assert torch.equal(ea.steps, eb.steps) and torch.equal(ea.collisions, eb.collisions)
+    assert torch.equal(ea.episode, eb.episode) and torch.equal(ea.global_state, eb.global_state)
