@@ -129,6 +129,37 @@ class CheckersStepper(object):
     close = ParticleStepper.close
 
 
+class RolloutAdvStepper(object):
+    """BASELINE configs[3] (C4): 33-tick trajectory collection (ParticleRollout: slot copies + 33 step launches as
+    one hipGraph replay) followed by the advantage-normalisation step -- discounted returns + moments kernel, ONE
+    all-gather of 3 float64 per rank (RCCL), normalise kernel."""
+
+    def __init__(self, cfg, n_agents, n_envs, device, env_id_base=0, kernel="auto", fused=False):
+        import torch
+        from cm3_amd.particle import VecParticleEnv
+        from cm3_amd.rollout import ParticleRollout
+        self.torch = torch
+        self.env = VecParticleEnv(cfg, n_agents, 0.2, 33, n_envs, device=device, dtype=torch.float32, auto_reset=True,
+                                  env_id_base=env_id_base, kernel=kernel)
+        self.env.reset()
+        self.ro = ParticleRollout(self.env, n_ticks=GRAPH_TICKS, use_graph=True, fused=fused)
+        self.device = self.env.device
+        self.last = None
+
+    def capture(self, n_ticks):
+        pass                                    # ParticleRollout captures its own graph on first use
+
+    def run(self, n_ticks):
+        from cm3_amd.shard import normalized_returns
+        assert n_ticks % GRAPH_TICKS == 0, "c4 runs whole 33-tick rollouts"
+        for _ in range(n_ticks // GRAPH_TICKS):
+            self.ro.collect(reset=False)
+            self.last = normalized_returns(self.ro.reward_n, self.ro.done, None, gamma=0.99)
+
+    def close(self):
+        self.ro.close()
+
+
 # SURVEY.md section 8(d): Checkers N=2 -- compact state 16 r + 16 w, actions 8, outputs 360
 CHECKERS_BYTES_PER_ENV_STEP = 400
 
@@ -136,7 +167,8 @@ WORKLOADS = {
     # name: (kind, config file, envs per GPU, description)
     "c2": ("particle", "particle_stage2_antipodal", 4096, "config_particle_stage2_antipodal.json: 4 agents"),
     "c3": ("checkers", "checkers_stage2", 8192, "config_checkers_stage2.json: 2 agents, integer grid"),
-    "c4": ("particle", "particle_stage2_cross", 4096, "config_particle_stage2_cross.json: 4 agents"),
+    "c4": ("particle_adv", "particle_stage2_cross", 4096,
+           "config_particle_stage2_cross.json: 4 agents, trajectory + advantage normalisation (1 moments all-gather per rollout)"),
     "c5": ("particle", "particle_merge8", 8192, "build-defined merge8: 8 agents (SURVEY.md section 8d C5)"),
 }
 
@@ -273,8 +305,12 @@ def main():
     # everything (launches, graph replays, HIP events) goes on one explicit non-default stream
     bench_stream = torch.cuda.Stream(device=device)
     torch.cuda.set_stream(bench_stream)
-    if world > 1:
+    # Under torchrun (WORLD_SIZE set) the RCCL process group is always created -- also for one rank, so the
+    # barrier / max-over-ranks path is the same code at every N.
+    use_dist = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group(backend="nccl", device_id=device)
         dist.barrier(device_ids=[local_rank])
     if rank != 0:
@@ -285,7 +321,13 @@ def main():
     N = cfg["n_agents"]
     E = args.envs_per_gpu or default_e
     K, W = args.steps, args.warmup
-    if kind == "particle":
+    if kind == "particle_adv":
+        K = max(K // GRAPH_TICKS, 1) * GRAPH_TICKS
+        W = max(W // GRAPH_TICKS, 1) * GRAPH_TICKS
+        stepper = RolloutAdvStepper(cfg, N, E, device, env_id_base=rank * E, kernel=args.kernel, fused=args.fused)
+        bytes_per_env_step = algorithmic_bytes_per_env_step(N)
+        dtype_name = "f32"
+    elif kind == "particle":
         stepper = ParticleStepper(cfg, N, E, device, env_id_base=rank * E, kernel=args.kernel, fused=args.fused)
         bytes_per_env_step = algorithmic_bytes_per_env_step(N)
         if args.fused:   # state, goals and counters are read once per launch, not once per tick
@@ -301,7 +343,7 @@ def main():
     torch.cuda.synchronize(device)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier(device_ids=[local_rank])
 
     barrier()
@@ -312,7 +354,7 @@ def main():
     wall = time.perf_counter() - t0
     barrier()
     t = torch.tensor([wall, ev_ms * 1e-3], dtype=torch.float64, device=device)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall_max, ev_max = float(t[0]), float(t[1])
 
@@ -340,7 +382,7 @@ def main():
             "agent_steps_per_s": value * N,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "kernel": "k_checkers_step" if kind == "checkers" else "k_particle_step(_pairs)<float,%d>" % N,
+                         "kernel": "k_checkers_step_fast" if kind == "checkers" else "k_particle_step(_pairs)<float,%d>" % N,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "avg_launch_us": launch_s * 1e6},
         }
@@ -395,10 +437,10 @@ def main():
                 torch.cuda.empty_cache()
             out["sweep"] = sweep
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, N) if kind == "particle" else cpu_baseline_checkers(cfg)
+            out["cpu_baseline"] = cpu_baseline_checkers(cfg) if kind == "checkers" else cpu_baseline(cfg, N)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
 

@@ -87,6 +87,13 @@ SYMBOLS = {
     "cm3_particle_rollout_f64": (ctypes.c_int, [P(ParticleDesc), P(ParticleTraj), c_int32, c_void_p]),
     "cm3_checkers_step": (ctypes.c_int, [P(CheckersDesc), P(CheckersBufs), c_void_p]),
     "cm3_checkers_reset": (ctypes.c_int, [P(CheckersDesc), P(CheckersBufs), c_void_p, c_void_p]),
+    "cm3_returns_scratch_bytes": (c_size_t, []),
+    "cm3_returns_moments_f32": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                               c_int32, c_int32, c_int32, c_double, c_void_p]),
+    "cm3_returns_moments_f64": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                               c_int32, c_int32, c_int32, c_double, c_void_p]),
+    "cm3_normalize_f32": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int32, c_double, c_void_p]),
+    "cm3_normalize_f64": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int32, c_double, c_void_p]),
     "cm3_hbm_read_bench": (ctypes.c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
     "cm3_hbm_bench_sink_words": (ctypes.c_int, []),
     "cm3_graph_begin": (ctypes.c_int, [c_void_p]),

@@ -85,3 +85,47 @@ def returns_to_go(reward, done, gamma=0.99, bootstrap=None):
         nxt = reward[t] + gamma * nd[t] * nxt
         out[t] = nxt
     return out
+
+
+def normalized_returns(reward, done, valid=None, gamma=0.99, eps=1e-8, group=None, normalize=True):
+    """GPU path of the advantage-normalisation step over a device trajectory.
+
+    reward [T,E] or [T,E,C] (float32/float64, contiguous, on the GPU), done / valid uint8-or-bool [T,E].
+    Three launches and ONE collective per rollout: cm3_returns_moments_* (discounted returns + this rank's
+    float64 moments, deterministic), all_gather_into_tensor of the 3 moments (RCCL), cm3_normalize_* with the
+    rank-ordered global sums.  Returns (returns_or_normalised [same shape], (mean, std, count))."""
+    import ctypes
+    from . import _lib
+    if reward.device.type != "cuda":
+        raise _lib.Cm3Error("normalized_returns runs on the GPU; use returns_to_go / normalize_advantages for host tensors")
+    lib = _lib.lib()
+    x = reward.contiguous()
+    T, E = x.shape[0], x.shape[1]
+    C = 1 if x.dim() == 2 else int(x.shape[2])
+    suffix = {torch.float32: "f32", torch.float64: "f64"}[x.dtype]
+    d8 = done.to(torch.uint8).contiguous()
+    v8 = None if valid is None else valid.to(torch.uint8).contiguous()
+    out = torch.empty_like(x)
+    scratch = torch.empty(lib.cm3_returns_scratch_bytes() // 8, dtype=torch.float64, device=x.device)
+    moments = torch.zeros(3, dtype=torch.float64, device=x.device)
+    stream = _lib.current_stream_handle(x.device)
+    _lib.check(getattr(lib, "cm3_returns_moments_" + suffix)(
+        x.data_ptr(), d8.data_ptr(), _lib.ptr(v8), out.data_ptr(), scratch.data_ptr(), moments.data_ptr(),
+        T, E, C, float(gamma), stream))
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        world = dist.get_world_size(group)
+        gathered = torch.empty(world * 3, dtype=torch.float64, device=x.device)
+        dist.all_gather_into_tensor(gathered, moments, group=group)
+        parts = gathered.view(world, 3)
+        tot = parts[0].clone()
+        for r in range(1, world):
+            tot = tot + parts[r]
+    else:
+        tot = moments
+    n = tot[2].clamp(min=1.0)
+    mean = tot[0] / n
+    std = (tot[1] / n - mean * mean).clamp(min=0.0).sqrt()
+    if normalize:
+        _lib.check(getattr(lib, "cm3_normalize_" + suffix)(
+            out.data_ptr(), _lib.ptr(v8), tot.data_ptr(), out.numel(), C, float(eps), stream))
+    return out, (mean, std, tot[2])

@@ -213,6 +213,26 @@ int cm3_checkers_reset(const cm3_checkers_desc *desc, const cm3_checkers_bufs *b
                        void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Advantage normalisation (build-defined; the reference's advantage, alg_credit.py:334-357, is not normalised).
+ * Discounted return-to-go over a time-major trajectory, G[t] = x[t] + gamma * (1 - done[t]) * G[t+1], G[T] = 0:
+ *   x, out  real [T][E][C]   (C = N for reward_n, 1 for the team reward); out may alias x
+ *   done    uint8 [T][E];  valid uint8 [T][E] optional (invalid entries: out = 0, excluded from the moments)
+ *   scratch >= cm3_returns_scratch_bytes() bytes;  moments double[3] = (sum, sum of squares, count) of this
+ *   rank's valid returns, computed deterministically (no atomics).  The host all-gathers the three numbers over
+ *   the ranks (RCCL) and sums them in rank order; cm3_normalize_* then applies
+ *   x = (x - mean) / (std + eps) with the GLOBAL moments (x real [n_elem], valid indexed by element / C).
+ * ---------------------------------------------------------------------------------------- */
+size_t cm3_returns_scratch_bytes(void);
+int cm3_returns_moments_f32(const void *x, const uint8_t *done, const uint8_t *valid, void *out, void *scratch,
+                            double *moments, int32_t T, int32_t E, int32_t C, double gamma, void *stream);
+int cm3_returns_moments_f64(const void *x, const uint8_t *done, const uint8_t *valid, void *out, void *scratch,
+                            double *moments, int32_t T, int32_t E, int32_t C, double gamma, void *stream);
+int cm3_normalize_f32(void *x, const uint8_t *valid, const double *moments, size_t n_elem, int32_t C, double eps,
+                      void *stream);
+int cm3_normalize_f64(void *x, const uint8_t *valid, const double *moments, size_t n_elem, int32_t C, double eps,
+                      void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Measurement and launch plumbing
  * ---------------------------------------------------------------------------------------- */
 /* Streaming 16-byte-per-lane read of `bytes` bytes (multiple of 16); writes one checksum word per

@@ -169,3 +169,30 @@ def test_fused_rollout_equals_per_tick_rollout(kernel, dtype, auto_reset):
     ea, eb = outs[0][1], outs[1][1]
     assert torch.equal(ea.steps, eb.steps) and torch.equal(ea.collisions, eb.collisions)
     assert torch.equal(ea.episode, eb.episode) and torch.equal(ea.global_state, eb.global_state)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("C", [1, 4])
+def test_returns_moments_and_normalisation_kernels(dtype, C):
+    """HIP returns/moments/normalise kernels against the plain torch formulation in cm3_amd/shard.py."""
+    from cm3_amd.shard import global_moments, normalize_advantages, normalized_returns, returns_to_go
+    T, E = 33, 1000
+    g = torch.Generator(device="cuda").manual_seed(1)
+    shape = (T, E) if C == 1 else (T, E, C)
+    x = torch.randn(shape, generator=g, device="cuda", dtype=dtype) * 2 - 1
+    done = torch.rand(T, E, generator=g, device="cuda") < 0.05
+    valid = torch.rand(T, E, generator=g, device="cuda") > 0.1
+    want_ret = returns_to_go(x, done, gamma=0.97)
+    vmask = valid if C == 1 else valid.unsqueeze(-1).expand_as(want_ret)
+    want_ret = torch.where(vmask, want_ret, torch.zeros_like(want_ret))
+    ret, (mean, std, cnt) = normalized_returns(x, done, valid, gamma=0.97, normalize=False)
+    tol = 1e-5 if dtype == torch.float32 else 1e-12
+    assert torch.allclose(ret, want_ret, atol=tol, rtol=tol)
+    m2, s2, n2 = global_moments(want_ret, valid)
+    assert int(cnt) == int(n2) and abs(float(mean) - float(m2)) < 1e-6 and abs(float(std) - float(s2)) < 1e-6
+    norm, _ = normalized_returns(x, done, valid, gamma=0.97)
+    want = normalize_advantages(want_ret, valid)
+    assert torch.allclose(norm, want, atol=10 * tol, rtol=10 * tol)
+    # deterministic: two runs give identical bits
+    again, (mean_b, std_b, _) = normalized_returns(x, done, valid, gamma=0.97)
+    assert torch.equal(again, norm) and float(mean_b) == float(mean) and float(std_b) == float(std)
