@@ -26,4 +26,7 @@ def __getattr__(name):
     if name == "VecCheckersEnv":
         from .checkers import VecCheckersEnv
         return VecCheckersEnv
+    if name == "ParticleActor":
+        from .actor import ParticleActor
+        return ParticleActor
     raise AttributeError(name)

@@ -70,6 +70,21 @@ class CheckersBufs(ctypes.Structure):
         "obs_self_t", "obs_self_v", "local_rewards", "reward", "done")]
 
 
+class ActorParticleDesc(ctypes.Structure):
+    _fields_ = [("n_envs", c_int32), ("n_agents", c_int32), ("stage", c_int32), ("n_h1_self", c_int32),
+                ("n_h1_others", c_int32), ("n_h2", c_int32), ("n_actions", c_int32), ("epsilon", ctypes.c_float),
+                ("env_id_base", c_int64), ("seed", c_uint64)]
+
+
+class ActorParticleWeights(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in ("w_self", "b_self", "w_self_h2", "w_others", "b_others", "w_others_h2",
+                                        "b_h2", "w_out", "b_out")]
+
+
+class ActorParticleBufs(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in ("obs_others", "state", "goals", "meta", "episode", "actions", "probs")]
+
+
 # every symbol include/cm3_amd.h declares: name -> (restype, argtypes)
 P = ctypes.POINTER
 SYMBOLS = {
@@ -87,6 +102,8 @@ SYMBOLS = {
     "cm3_particle_rollout_f64": (ctypes.c_int, [P(ParticleDesc), P(ParticleTraj), c_int32, c_void_p]),
     "cm3_checkers_step": (ctypes.c_int, [P(CheckersDesc), P(CheckersBufs), c_void_p]),
     "cm3_checkers_reset": (ctypes.c_int, [P(CheckersDesc), P(CheckersBufs), c_void_p, c_void_p]),
+    "cm3_actor_particle_f32": (ctypes.c_int, [P(ActorParticleDesc), P(ActorParticleWeights), P(ActorParticleBufs),
+                                              c_void_p]),
     "cm3_returns_scratch_bytes": (c_size_t, []),
     "cm3_returns_moments_f32": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                c_int32, c_int32, c_int32, c_double, c_void_p]),

@@ -1,0 +1,97 @@
+"""ParticleActor -- the reference's particle policy evaluated on the device.
+
+    reference                                                    here
+    ---------------------------------------------------------   -----------------------------------------
+    networks.actor_particle(obs_others, v_obs, v_goal, ...)      ParticleActor(weights, n_agents, stage)
+      (networks.py:517-538)                                        weights: dict keyed by the TF variable names
+    probs = (1-eps) probs + eps/l_action; multinomial            actor.act(env, epsilon) -> actions [E, N]
+      (alg_credit.py:119-120)                                      (one launch: forward + mixing + sampling)
+    alg.run_actor(local_others, local_self, goals, eps, sess)    ParticleRollout.collect(policy=actor, epsilon=..)
+      (alg_credit.py:249-270, called at train_onpolicy.py:313)     step and actor launches alternate inside ONE
+                                                                   hipGraph; nothing returns to the host
+
+Weights stay float32 [in][out] as TensorFlow shapes them, so a checkpoint exported with
+``{v.name: sess.run(v)}`` loads unchanged (names below; a "Policy_main/" prefix and ":0" suffix are ignored).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import Cm3Error
+
+H1_SELF, H1_OTHERS, H2, N_ACTIONS = 64, 128, 64, 5
+_NAMES = {
+    "w_self": "actor_branch_self/kernel", "b_self": "actor_branch_self/bias", "w_self_h2": "W_branch_self_h2",
+    "w_others": "stage-2/actor_others/kernel", "b_others": "stage-2/actor_others/bias",
+    "w_others_h2": "stage-2/W_others_h2", "b_h2": "b", "w_out": "actor_out/kernel", "b_out": "actor_out/bias"}
+
+
+def _canon(name):
+    name = name.split(":")[0]
+    for prefix in ("Policy_main/", "Policy_target/"):
+        if name.startswith(prefix):
+            name = name[len(prefix):]
+    return name
+
+
+class ParticleActor(object):
+    def __init__(self, weights, n_agents, stage=2, device="cuda:0", seed=12341, env_id_base=0):
+        self.device = _lib.require_gpu(device)
+        self.n = int(n_agents)
+        self.stage = int(stage)
+        self.L = 4 * max(self.n - 1, 1)
+        self.seed = int(seed)
+        self.env_id_base = int(env_id_base)
+        src = {_canon(k): v for k, v in weights.items()}
+        shapes = {"w_self": (6, H1_SELF), "b_self": (H1_SELF,), "w_self_h2": (H1_SELF, H2), "b_h2": (H2,),
+                  "w_out": (H2, N_ACTIONS), "b_out": (N_ACTIONS,)}
+        if self.stage > 1:
+            shapes.update({"w_others": (self.L, H1_OTHERS), "b_others": (H1_OTHERS,), "w_others_h2": (H1_OTHERS, H2)})
+        self.w = {}
+        for short, shape in shapes.items():
+            name = _NAMES[short]
+            if name not in src:
+                raise Cm3Error("missing actor weight %r" % name)
+            t = torch.as_tensor(np.asarray(src[name]), dtype=torch.float32).contiguous()
+            if tuple(t.shape) != shape:
+                raise Cm3Error("actor weight %r has shape %s, expected %s" % (name, tuple(t.shape), shape))
+            self.w[short] = t.to(self.device)
+        self._wt = _lib.ActorParticleWeights()
+        for short in _NAMES:
+            setattr(self._wt, short, _lib.ptr(self.w.get(short)))
+        self._lib = _lib.lib()
+
+    def _desc(self, n_envs, epsilon, env_id_base):
+        d = _lib.ActorParticleDesc()
+        d.n_envs, d.n_agents, d.stage = int(n_envs), self.n, self.stage
+        d.n_h1_self, d.n_h1_others, d.n_h2, d.n_actions = H1_SELF, H1_OTHERS, H2, N_ACTIONS
+        d.epsilon = float(epsilon)
+        d.env_id_base = int(env_id_base)
+        d.seed = self.seed & 0xFFFFFFFFFFFFFFFF
+        return d
+
+    def enqueue(self, n_envs, obs_others, state, goals, meta, episode, actions, epsilon, probs=None, stream=None,
+                env_id_base=None):
+        """Raw launch on device pointers/tensors (float32 env buffers)."""
+        b = _lib.ActorParticleBufs()
+        b.obs_others, b.state, b.goals = _lib.ptr(obs_others), _lib.ptr(state), _lib.ptr(goals)
+        b.meta, b.episode, b.actions, b.probs = _lib.ptr(meta), _lib.ptr(episode), _lib.ptr(actions), _lib.ptr(probs)
+        d = self._desc(n_envs, epsilon, self.env_id_base if env_id_base is None else env_id_base)
+        s = _lib.current_stream_handle(self.device) if stream is None else stream
+        _lib.check(self._lib.cm3_actor_particle_f32(ctypes.byref(d), ctypes.byref(self._wt), ctypes.byref(b), s))
+
+    def act(self, env, epsilon, return_probs=False):
+        """Actions [E, N] int32 for the env's CURRENT observation (alg.run_actor); optionally the mixed
+        probabilities [E, N, 5]."""
+        if env.dtype != torch.float32:
+            raise Cm3Error("the device actor reads float32 env buffers")
+        if env.n != self.n:
+            raise Cm3Error("actor built for %d agents, env has %d" % (self.n, env.n))
+        cur = env._cur
+        actions = torch.empty(env.E, env.n, dtype=torch.int32, device=self.device)
+        probs = torch.empty(env.E, env.n, N_ACTIONS, dtype=torch.float32, device=self.device) if return_probs else None
+        self.enqueue(env.E, env._obs_others[cur], env._state[cur], env._goals, env._meta, env._episode, actions,
+                     epsilon, probs, env_id_base=env.env_id_base)
+        return (actions, probs) if return_probs else actions

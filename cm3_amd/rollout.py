@@ -144,7 +144,17 @@ class ParticleRollout(object):
             env._goals.copy_(self.goals[self.T])
 
     # ---- collection ------------------------------------------------------------------------------------
-    def collect(self, policy=None, reset=None):
+    def _enqueue_actor_rollout(self, actor, epsilon, base_flags, stream):
+        """T x (actor launch, step launch) on `stream`: the policy reads slot t, writes actions[t]; the step kernel
+        consumes them and writes slot t+1 (train_onpolicy.py:311-323 without leaving the device)."""
+        env = self.env
+        for t in range(self.T):
+            goals = self.goals[t] if self.goals is not None else env._goals
+            actor.enqueue(env.E, self.obs_others[t], self.state[t], goals, env._meta, env._episode, self.actions[t],
+                          epsilon, stream=stream, env_id_base=env.env_id_base)
+            self._enqueue(t, 1, base_flags, stream)
+
+    def collect(self, policy=None, reset=None, epsilon=0.0):
         """Runs T ticks.  policy None = the reference's random-action branch (train_onpolicy.py:305-307,
         drawn in-kernel; the whole rollout is one hipGraph replay); otherwise ``policy(obs_others [E,N,L],
         obs_self [E,N,4], goals [E,N,2]) -> int actions [E,N]`` is called every tick (:311-313).
@@ -166,6 +176,20 @@ class ParticleRollout(object):
                 _lib.check(self._lib.cm3_graph_launch(self._graph, env._stream()))
             else:
                 self._enqueue(0, self.T, flags)
+        elif hasattr(policy, "enqueue") and hasattr(policy, "act"):      # on-device actor (cm3_amd.actor)
+            if env.dtype != torch.float32:
+                raise Cm3Error("the device actor reads float32 env buffers")
+            if self.use_graph:
+                key = ("actor", id(policy), float(epsilon))
+                if getattr(self, "_actor_graph_key", None) != key:
+                    if getattr(self, "_actor_graph", None) is not None:
+                        self._lib.cm3_graph_destroy(self._actor_graph)
+                    self._actor_graph = _lib.capture_graph(
+                        env.device, lambda s: self._enqueue_actor_rollout(policy, epsilon, base, s))
+                    self._actor_graph_key = key
+                _lib.check(self._lib.cm3_graph_launch(self._actor_graph, env._stream()))
+            else:
+                self._enqueue_actor_rollout(policy, epsilon, base, env._stream())
         else:
             for t in range(self.T):
                 goals = (self.goals[t] if self.goals is not None else env._goals).permute(1, 0, 2)
@@ -180,6 +204,9 @@ class ParticleRollout(object):
         if self._graph is not None:
             self._lib.cm3_graph_destroy(self._graph)
             self._graph = None
+        if getattr(self, "_actor_graph", None) is not None:
+            self._lib.cm3_graph_destroy(self._actor_graph)
+            self._actor_graph = None
 
     # ---- views --------------------------------------------------------------------------------------------
     @property

@@ -213,6 +213,47 @@ int cm3_checkers_reset(const cm3_checkers_desc *desc, const cm3_checkers_bufs *b
                        void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * On-device particle actor: networks.actor_particle (networks.py:517-538) + the epsilon-mixed categorical
+ * sampling of alg_credit.py:119-120 / run_actor :249-270, for all E*N agent rows in one launch.
+ * Weights are float32, row-major [in][out] exactly as the TF variables are shaped:
+ *   w_self [6][64] + b_self [64]            "actor_branch_self" (input = concat(v_obs[4], v_goal[2]))
+ *   w_self_h2 [64][64]                      "W_branch_self_h2"
+ *   w_others [L][128] + b_others [128]      "stage-2/actor_others"    (stage > 1 only; L = 4*max(N-1,1))
+ *   w_others_h2 [128][64]                   "stage-2/W_others_h2"
+ *   b_h2 [64]                               "b"
+ *   w_out [64][5] + b_out [5]               "actor_out"
+ * Inputs are the env's own buffers (obs_others [E][N][L], state [N][E][4], goals [N][E][2], meta, episode);
+ * outputs actions int32 [E][N] (what cm3_particle_step_* consumes) and optionally the mixed probabilities
+ * float [E][N][5].  Sampling inverts the CDF in action order with one uniform per agent-step from the Philox
+ * stream keyed (seed, global env id, episode, step).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct cm3_actor_particle_desc {
+  int32_t n_envs, n_agents;
+  int32_t stage;       /* 1: self branch only; 2: + others branch */
+  int32_t n_h1_self, n_h1_others, n_h2, n_actions; /* 64, 128, 64, 5 */
+  float epsilon;
+  int64_t env_id_base;
+  uint64_t seed;
+} cm3_actor_particle_desc;
+
+typedef struct cm3_actor_particle_weights {
+  const float *w_self, *b_self, *w_self_h2, *w_others, *b_others, *w_others_h2, *b_h2, *w_out, *b_out;
+} cm3_actor_particle_weights;
+
+typedef struct cm3_actor_particle_bufs {
+  const void *obs_others;
+  const void *state;
+  const void *goals;
+  const int32_t *meta;
+  const int32_t *episode;
+  int32_t *actions;
+  float *probs; /* optional */
+} cm3_actor_particle_bufs;
+
+int cm3_actor_particle_f32(const cm3_actor_particle_desc *desc, const cm3_actor_particle_weights *weights,
+                           const cm3_actor_particle_bufs *bufs, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Advantage normalisation (build-defined; the reference's advantage, alg_credit.py:334-357, is not normalised).
  * Discounted return-to-go over a time-major trajectory, G[t] = x[t] + gamma * (1 - done[t]) * G[t+1], G[T] = 0:
  *   x, out  real [T][E][C]   (C = N for reward_n, 1 for the team reward); out may alias x

@@ -1,0 +1,84 @@
+"""GPU: the device actor (cm3_amd/csrc/actor.hip) against the NumPy restatement of networks.actor_particle +
+the epsilon-mixed sampling of alg_credit.py:119-120 (oracle/actor_oracle.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import actor_oracle as AO
+from tests.helpers import load_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+def _env(E, N, cfg, **kw):
+    from cm3_amd.particle import VecParticleEnv
+    return VecParticleEnv(load_cfg(cfg), N, 0.2, 33, E, device="cuda:0", dtype=torch.float32, **kw)
+
+
+@pytest.mark.parametrize("N,cfg,stage", [(4, "particle_stage2_antipodal.json", 2), (2, "particle_stage2_merge.json", 2),
+                                         (1, "particle_stage1.json", 1), (8, "particle_merge8.json", 2)])
+@pytest.mark.parametrize("eps", [0.0, 0.3])
+def test_actor_probs_and_samples_match_oracle(N, cfg, stage, eps):
+    from cm3_amd.actor import ParticleActor
+    E, seed = 1000, 77
+    rng = np.random.default_rng(N * 10 + stage)
+    w = AO.init_weights(rng, N, stage=stage)
+    env = _env(E, N, cfg, seed=seed)
+    env.reset()
+    for _ in range(3):
+        env.step()
+    actor = ParticleActor(w, N, stage=stage, device="cuda:0", seed=seed)
+    actions, probs = actor.act(env, eps, return_probs=True)
+    gs, oo = env.get_obs()
+    rows = E * N
+    want = AO.mixed_probs(AO.actor_probs(w, oo.reshape(rows, -1).cpu().numpy(), gs.reshape(rows, 4).cpu().numpy(),
+                                         env.goals.reshape(rows, 2).cpu().numpy()), eps)
+    got = probs.reshape(rows, 5).cpu().numpy()
+    assert np.abs(got - want).max() < 2e-5
+    assert np.abs(got.sum(1) - 1).max() < 1e-5
+    u = AO.policy_uniforms(seed, np.arange(E), env.episode.cpu().numpy(), env.steps.cpu().numpy(), N).reshape(rows)
+    want_a = AO.sample_actions(want, u)
+    cdf = np.cumsum(want, axis=1)
+    safe = np.abs(cdf - u[:, None]).min(axis=1) > 1e-4         # u not on a CDF boundary
+    assert safe.mean() > 0.99
+    assert np.array_equal(actions.reshape(rows).cpu().numpy()[safe], want_a[safe])
+    # empirical action frequencies follow the probabilities
+    freq = np.bincount(actions.reshape(rows).cpu().numpy(), minlength=5) / rows
+    assert np.abs(freq - want.mean(0)).max() < 0.05
+
+
+def test_policy_rollout_on_device_equals_host_driven_policy():
+    """ParticleRollout.collect(policy=actor): alternate actor/step launches in one hipGraph == calling the actor and
+    the env from the host tick by tick."""
+    from cm3_amd.actor import ParticleActor
+    from cm3_amd.rollout import ParticleRollout
+    N, E, seed = 4, 512, 5
+    w = AO.init_weights(np.random.default_rng(3), N)
+    actor = ParticleActor(w, N, device="cuda:0", seed=seed)
+    env_a = _env(E, N, "particle_stage2_cross.json", seed=seed)
+    ro = ParticleRollout(env_a, use_graph=True).collect(policy=actor, epsilon=0.2)
+    ro.collect(policy=actor, epsilon=0.2)                       # second replay = a fresh episode
+    env_b = _env(E, N, "particle_stage2_cross.json", seed=seed)
+    env_b.reset()
+    env_b.reset()                                               # same episode index as the second collect()
+    assert torch.equal(env_b.global_state, ro.state[0].permute(1, 0, 2))
+    for t in range(33):
+        a = actor.act(env_b, 0.2)
+        assert torch.equal(a, ro.actions[t]), t
+        gs, oo, _, rew, rew_n, done = env_b.step(a)
+        assert torch.equal(gs, ro.state[t + 1].permute(1, 0, 2))
+        assert torch.equal(rew, ro.reward[t])
+    ro.close()
+
+
+def test_actor_rejects_bad_weights():
+    from cm3_amd import Cm3Error
+    from cm3_amd.actor import ParticleActor
+    w = AO.init_weights(np.random.default_rng(0), 4)
+    del w["actor_out/bias"]
+    with pytest.raises(Cm3Error):
+        ParticleActor(w, 4, device="cuda:0")
+    w = AO.init_weights(np.random.default_rng(0), 4)
+    w["W_branch_self_h2"] = w["W_branch_self_h2"][:, :32]
+    with pytest.raises(Cm3Error):
+        ParticleActor(w, 4, device="cuda:0")

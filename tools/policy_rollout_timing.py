@@ -1,0 +1,45 @@
+#!/usr/bin/env python
+"""Times policy-driven collection on the device: T x (actor launch + step launch) as one hipGraph replay."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import cm3_amd  # noqa: E402
+from cm3_amd.actor import ParticleActor  # noqa: E402
+from cm3_amd.particle import VecParticleEnv  # noqa: E402
+from cm3_amd.rollout import ParticleRollout  # noqa: E402
+from oracle.actor_oracle import init_weights  # noqa: E402  (random weights with the reference's shapes)
+
+
+def main():
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_stream(torch.cuda.Stream(device=dev))
+    cfg = cm3_amd.load_config("particle_stage2_antipodal")
+    for E in (4096, 65536, 1 << 20):
+        env = VecParticleEnv(cfg, 4, 0.2, 33, E, device=dev, auto_reset=True)
+        env.reset()
+        actor = ParticleActor(init_weights(np.random.default_rng(0), 4), 4, device=dev)
+        ro = ParticleRollout(env, use_graph=True)
+        for _ in range(3):
+            ro.collect(policy=actor, epsilon=0.1, reset=False)
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 20 if E <= 65536 else 3
+        a.record()
+        for _ in range(reps):
+            ro.collect(policy=actor, epsilon=0.1, reset=False)
+        b.record()
+        b.synchronize()
+        us = a.elapsed_time(b) * 1e3 / (reps * 33)
+        print(json.dumps({"envs": E, "us_per_tick_actor_plus_step": round(us, 2), "env_steps_per_s": E / us * 1e6}))
+        ro.close()
+        del ro, env
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
