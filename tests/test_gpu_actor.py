@@ -82,3 +82,47 @@ def test_actor_rejects_bad_weights():
     w["W_branch_self_h2"] = w["W_branch_self_h2"][:, :32]
     with pytest.raises(Cm3Error):
         ParticleActor(w, 4, device="cuda:0")
+
+
+def test_batched_evaluation_matches_host_driven_episodes():
+    """cm3_amd.evaluate.test_particle (evaluate.py:87-123 for E episodes at once) == stepping the env with the actor
+    from the host and accumulating rewards until each env's first `done`."""
+    from cm3_amd.actor import ParticleActor
+    from cm3_amd.evaluate import test_particle
+    N, E, seed = 4, 256, 9
+    w = AO.init_weights(np.random.default_rng(1), N)
+    actor = ParticleActor(w, N, device="cuda:0", seed=seed)
+    env = _env(E, N, "particle_stage2_antipodal.json", seed=seed)
+    r_local, r_global, n = test_particle(env, actor, n_rounds=1)
+    assert n == E and r_local.shape == (N,)
+    ref = _env(E, N, "particle_stage2_antipodal.json", seed=seed)
+    ref.reset()
+    alive = torch.ones(E, dtype=torch.bool, device="cuda")
+    acc_l = torch.zeros(E, N, dtype=torch.float64, device="cuda")
+    acc_g = torch.zeros(E, dtype=torch.float64, device="cuda")
+    for t in range(33):
+        a = actor.act(ref, 0.0)
+        _, _, _, rew, rew_n, done = ref.step(a)
+        acc_l += torch.where(alive.unsqueeze(1), rew_n.double(), torch.zeros_like(acc_l))
+        acc_g += torch.where(alive, rew.double(), torch.zeros_like(acc_g))
+        alive = alive & ~done
+    assert np.allclose(r_local, acc_l.mean(0).cpu().numpy(), rtol=1e-6, atol=1e-6)
+    assert abs(r_global - float(acc_g.mean())) < 1e-5
+
+
+def test_replay_buffers_take_device_rollouts():
+    from cm3_amd.replay import DeviceDualReplayBuffer, DeviceReplayBuffer
+    from cm3_amd.rollout import ParticleRollout
+    env = _env(64, 4, "particle_stage2_cross.json", seed=2)
+    ro = ParticleRollout(env, use_graph=False).collect()
+    cols = ro.as_reference_batch(numpy=False)
+    buf = DeviceReplayBuffer(size=1000, device="cuda:0")
+    buf.add(cols)
+    assert len(buf) == 1000                                           # 64 x 33 = 2112 > capacity: newest 1000 kept
+    b = buf.sample_batch(128, generator=torch.Generator(device="cuda").manual_seed(0))
+    assert b["obs_others"].shape == (128, 4, 12) and b["reward"].shape == (128,)
+    dual = DeviceDualReplayBuffer(size=5000, device="cuda:0")
+    tt, ee = ro.valid_indices()
+    dual.add(cols, (env.collisions != 0)[ee])                          # train_onpolicy.py:356
+    assert len(dual.mem1) + len(dual.mem2) == tt.numel()
+    ro.close()
