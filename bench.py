@@ -228,10 +228,29 @@ def cpu_baseline(cfg, n_agents, budget_s=12.0):
             steps += 1
         episodes += 1
     dt = time.perf_counter() - t0
-    return dict(value=steps / dt, unit="env-steps/s", cores=1, kind="port",
-                sample="%d episodes (%d env-steps) of the same workload (antipodal, N=%d, 33 ticks, uniform actions) "
-                       "in %.1f s on 1 of %d host cores; scalar per-env NumPy port of the reference's call structure"
-                       % (episodes, steps, n_agents, dt, os.cpu_count()))
+    out = dict(value=steps / dt, unit="env-steps/s", cores=1, kind="port",
+               sample="%d episodes (%d env-steps) of the same workload (antipodal, N=%d, 33 ticks, uniform actions) "
+                      "in %.1f s on 1 of %d host cores; scalar per-env NumPy port of the reference's call structure"
+                      % (episodes, steps, n_agents, dt, os.cpu_count()))
+    # second, stronger CPU line: the vectorised [E,N,...] NumPy restatement, one process
+    try:
+        from oracle.particle_oracle import VecParticleOracle
+        E = 4096
+        vec = VecParticleOracle(n_agents, cfg, 0.2, 33, E)
+        rng = np.random.default_rng(0)
+        pos0 = np.stack([np.array(cfg["agents_x"][:n_agents]), np.array(cfg["agents_y"][:n_agents])], axis=1)
+        lm0 = np.stack([np.array(cfg["landmarks_x"][:n_agents]), np.array(cfg["landmarks_y"][:n_agents])], axis=1)
+        vec.set_state(np.broadcast_to(pos0, (E, n_agents, 2)).copy(), np.zeros((E, n_agents, 2)),
+                      np.broadcast_to(lm0, (E, n_agents, 2)).copy())
+        t0, ticks = time.perf_counter(), 0
+        while time.perf_counter() - t0 < 3.0:
+            vec.step(rng.integers(0, 5, (E, n_agents)))
+            ticks += 1
+        out["vectorised_numpy"] = {"value": E * ticks / (time.perf_counter() - t0), "unit": "env-steps/s", "cores": 1,
+                                   "sample": "%d ticks of %d envs, float64 [E,N,...] NumPy restatement" % (ticks, E)}
+    except Exception as exc:          # the extra line must never break the bench
+        out["vectorised_numpy"] = {"error": repr(exc)}
+    return out
 
 
 def cpu_baseline_checkers(cfg, budget_s=10.0):

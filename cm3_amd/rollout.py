@@ -286,9 +286,11 @@ class CheckersRollout(object):
     """T-tick trajectory over a VecCheckersEnv (16-column transitions, train_onpolicy.py:336).
     Episode-synchronous (the env is reset at the start; transitions after `done` are invalid)."""
 
-    def __init__(self, env, n_ticks=None):
+    def __init__(self, env, n_ticks=None, use_graph=True):
         self.env = env
         self.T = int(n_ticks or env.max_steps)
+        self.use_graph = bool(use_graph)
+        self._graph = None
         E, N, T, dev = env.E, env.n, self.T, env.device
         z = lambda *s, d: torch.zeros(*s, dtype=d, device=dev)  # noqa: E731
         self._grid_raw = z(T + 1, E, env.grid_stride, d=torch.int8)
@@ -328,6 +330,17 @@ class CheckersRollout(object):
         self.obs_self_t[0].copy_(ot)
         self.obs_self_v[0].copy_(ov)
         self.goals_onehot = env.goals.clone()
+        if policy is None and self.use_graph:
+            # random-action branch: the T step launches (each bound to its trajectory slots) replay as one hipGraph
+            if self._graph is None:
+                def enqueue(stream):
+                    env._desc.flags = FLAG_GEN_ACTIONS
+                    for t in range(self.T):
+                        b = self._bufs(t)
+                        _lib.check(self._lib.cm3_checkers_step(ctypes.byref(env._desc), ctypes.byref(b), stream))
+                self._graph = _lib.capture_graph(env.device, enqueue)
+            _lib.check(self._lib.cm3_graph_launch(self._graph, env._stream()))
+            return self
         for t in range(self.T):
             if policy is None:
                 env._desc.flags = FLAG_GEN_ACTIONS
@@ -339,6 +352,11 @@ class CheckersRollout(object):
             b = self._bufs(t)
             _lib.check(self._lib.cm3_checkers_step(ctypes.byref(env._desc), ctypes.byref(b), env._stream()))
         return self
+
+    def close(self):
+        if self._graph is not None:
+            self._lib.cm3_graph_destroy(self._graph)
+            self._graph = None
 
     @property
     def valid(self):

@@ -119,6 +119,9 @@ def test_checkers_rollout_matches_oracle_and_16_column_layout():
     E, N, T = 200, 2, 33
     env = VecCheckersEnv(i, N, T, E, device="cuda:0", seed=8)
     ro = CheckersRollout(env).collect(np.eye(2))
+    first = ro.actions.clone()
+    ro.collect(np.eye(2))                            # hipGraph replay: a fresh episode (new episode index => new actions)
+    assert not torch.equal(first, ro.actions)
     orc = VecCheckersOracle(i["n_rows"], i["n_columns"], i["n_obs"], i["agents_r"], i["agents_c"], N, T, E)
     w0 = orc.reset(np.eye(2))
     assert np.array_equal(ro.grid[0].cpu().numpy().astype(float), w0[0])
