@@ -151,6 +151,8 @@ class VecParticleEnv(object):
         (the reference's random-action branch, train_onpolicy.py:305-307)."""
         src, dst = self._cur, self._cur ^ 1
         flags = (FLAG_AUTO_RESET if self.auto_reset else 0) | self.kernel_flags
+        direct = None
+        self._last_actions = self._actions[dst]
         if actions is None:
             flags |= FLAG_GEN_ACTIONS
         else:
@@ -158,9 +160,15 @@ class VecParticleEnv(object):
             if a.shape != (self.E, self.n):
                 raise Cm3Error("actions must have shape [n_envs, n_agents] = [%d, %d], got %s"
                                % (self.E, self.n, tuple(a.shape)))
-            self._actions[dst].copy_(a)
+            if a.dtype == torch.int32 and a.is_contiguous():
+                direct = a                      # device int32 actions (e.g. from ParticleActor.act): no staging copy
+                self._last_actions = a
+            else:
+                self._actions[dst].copy_(a)
         self._desc.flags = flags
         b = self._bufs(src, dst)
+        if direct is not None:
+            b.actions = direct.data_ptr()
         _lib.check(self._fn("step")(ctypes.byref(self._desc), ctypes.byref(b), self._stream()))
         self._cur = dst
         gs = self.global_state
@@ -197,7 +205,8 @@ class VecParticleEnv(object):
 
     @property
     def last_actions(self):
-        return self._actions[self._cur]
+        """int32 [E, N] actions consumed (or drawn in-kernel) by the most recent step()."""
+        return getattr(self, "_last_actions", self._actions[self._cur])
 
     @property
     def terminal_state(self):
