@@ -5,11 +5,11 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one tick of the hot path over one batch: ONE launch of the particle step kernel
-(csrc/particle.hip) advancing E = 4096 environments x 4 agents of config_particle_stage2_antipodal
-(BASELINE.json configs[1]) per GPU, float32, uniform random actions drawn in-kernel
-(train_onpolicy.py:305-307), auto-reset at max_steps = 33.  Ticks are enqueued through
-cm3_particle_rollout_f32 and replayed as a hipGraph of 33 launches (one launch per tick is kept).
+A "step" is one pass of the hot path over one batch: one 33-tick episode (config.json max_steps) of the
+trajectory-collection loop for E = 4096 environments x 4 agents of config_particle_stage2_antipodal
+(BASELINE.json configs[1]) per GPU -- i.e. 33 launches of the particle step kernel (csrc/particle.hip; ONE launch
+per tick, replayed as one hipGraph), float32, uniform random actions drawn in-kernel (train_onpolicy.py:305-307),
+auto-reset at max_steps.  --steps K times exactly K such rollouts (K x 33 ticks) after --warmup W rollouts.
 Env instances shard across ranks with NO data-path collective => "weak" scaling.
 
 One JSON line on rank 0:  metric = env-steps/s summed over all GPUs;
@@ -291,8 +291,8 @@ def pmc_traffic(tag):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3300)
-    ap.add_argument("--warmup", type=int, default=330)
+    ap.add_argument("--steps", type=int, default=100, help="timed steps; one step = one %d-tick rollout of the batch" % GRAPH_TICKS)
+    ap.add_argument("--warmup", type=int, default=10, help="untimed warm-up steps (rollouts)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2",
                     help="c2 (default, the configuration BASELINE.json's metric is quoted on) | c3 | c4 | c5")
     ap.add_argument("--envs-per-gpu", type=int, default=0, help="override the workload's batch size")
@@ -339,10 +339,9 @@ def main():
     cfg = cm3_amd.load_config(cfg_name)
     N = cfg["n_agents"]
     E = args.envs_per_gpu or default_e
-    K, W = args.steps, args.warmup
+    steps, warm = max(args.steps, 1), max(args.warmup, 0)
+    K, W = steps * GRAPH_TICKS, max(warm, 1) * GRAPH_TICKS      # in ticks
     if kind == "particle_adv":
-        K = max(K // GRAPH_TICKS, 1) * GRAPH_TICKS
-        W = max(W // GRAPH_TICKS, 1) * GRAPH_TICKS
         stepper = RolloutAdvStepper(cfg, N, E, device, env_id_base=rank * E, kernel=args.kernel, fused=args.fused)
         bytes_per_env_step = algorithmic_bytes_per_env_step(N)
         dtype_name = "f32"
@@ -388,7 +387,8 @@ def main():
     if rank == 0:
         out = {
             "metric": "env-steps/s (all agents, whole node)", "value": value, "unit": "env-steps/s",
-            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": wall_max / K * 1e3,
+            "n_gpus": world, "steps": steps, "warmup": warm, "ms_per_step": wall_max / steps * 1e3,
+            "ticks_per_step": GRAPH_TICKS, "ticks_timed": K,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype_name,
             "data": "synthetic (uniform random actions drawn in-kernel, Philox; preset/random resets, prob_random=0.2)",
             "config": {"workload": "%s, %d vectorised envs per GPU, max_steps=33, auto-reset, %s"

@@ -84,12 +84,18 @@ template <> struct Math<float> {
   static __device__ __forceinline__ float exp(float x) { return expf(x); }
   static __device__ __forceinline__ float log1p(float x) { return log1pf(x); }
   static __device__ __forceinline__ float abs(float x) { return fabsf(x); }
+  static __device__ __forceinline__ float log(float x) { return logf(x); }
+  static __device__ __forceinline__ float cos(float x) { return cosf(x); }
+  static __device__ __forceinline__ float sin(float x) { return sinf(x); }
 };
 template <> struct Math<double> {
   static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
   static __device__ __forceinline__ double exp(double x) { return ::exp(x); }
   static __device__ __forceinline__ double log1p(double x) { return ::log1p(x); }
   static __device__ __forceinline__ double abs(double x) { return fabs(x); }
+  static __device__ __forceinline__ double log(double x) { return ::log(x); }
+  static __device__ __forceinline__ double cos(double x) { return ::cos(x); }
+  static __device__ __forceinline__ double sin(double x) { return ::sin(x); }
 };
 
 // np.logaddexp(0, x) (core.py:192): NumPy's npy_logaddexp specialised to a zero first argument --
@@ -291,10 +297,13 @@ __device__ __forceinline__ void init_agent(const ParticleParams &p, uint64_t gen
     x = cx;
     y = cy;
     if (p.initial_std != 0.0) {  // Box-Muller pair; std == 0 gives preset + 0 exactly as the reference
-      const double rad = ::sqrt(-2.0 * ::log(u01(a.z)));
-      const double ang = 6.283185307179586476925286766559 * u01(a.w);
-      x = x + p.initial_std * (rad * ::cos(ang));
-      y = y + p.initial_std * (rad * ::sin(ang));
+      // evaluated in the working precision: the float instantiation keeps the (rare) reset path free of
+      // double-precision transcendentals (685 v_add_f64 in the first version)
+      const R u1 = (R)u01(a.z), u2 = (R)u01(a.w);
+      const R rad = Math<R>::sqrt(R(-2.0) * Math<R>::log(u1));
+      const R ang = R(6.283185307179586476925286766559) * u2;
+      x = x + p.initial_std * (double)(rad * Math<R>::cos(ang));
+      y = y + p.initial_std * (double)(rad * Math<R>::sin(ang));
     }
   }
   s.x = R(0);
@@ -460,6 +469,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step(const ParticlePara
 
     // ---- same-launch re-initialisation of finished episodes -------------------------------------------
     bool was_reset = false;
+#ifndef CM3_EXPERIMENT_NO_RESET
     if ((p.flags & CM3_FLAG_AUTO_RESET) && done) {
       if (active) {
         void *term_state = tick_ptr(p.term_state, p.st_term_state, t);
@@ -477,6 +487,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step(const ParticlePara
       collisions = 0;
       was_reset = true;
     }
+#endif
     CM3_STAMP(9, false);
 
     if (active) {
@@ -647,6 +658,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_pairs(const Partic
 
     // ---- same-launch re-initialisation -------------------------------------------------------------------------
     bool was_reset = false;
+#ifndef CM3_EXPERIMENT_NO_RESET
     if ((p.flags & CM3_FLAG_AUTO_RESET) && done) {
       if (env_ok) {
         void *term_state = tick_ptr(p.term_state, p.st_term_state, t);
@@ -663,6 +675,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_pairs(const Partic
       collisions = 0;
       was_reset = true;
     }
+#endif
 
     // ---- per-tick stores ------------------------------------------------------------------------------------------
     if (env_ok) {

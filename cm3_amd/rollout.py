@@ -271,7 +271,7 @@ class ParticleRollout(object):
         (dtype=object, as NumPy >= 1.24 requires for ragged rows)."""
         return rows_from_columns(self.as_reference_batch(tt, ee), self.ORDER)
 
-    def sample_batch(self, size, generator=None):
+    def sample_batch(self, size, generator=None, numpy=True):
         """replay_buffer.sample_batch (replay_buffer.py:28-37): all transitions if there are <= size of them,
         else `size` distinct ones uniformly at random."""
         tt, ee = self.valid_indices()
@@ -279,7 +279,15 @@ class ParticleRollout(object):
         if n > size:
             pick = torch.randperm(n, generator=generator, device=tt.device)[:size]
             tt, ee = tt[pick], ee[pick]
-        return self.as_reference_batch(tt, ee)
+        return self.as_reference_batch(tt, ee, numpy=numpy)
+
+    def on_policy_minibatches(self, epochs=24, batch_size=128, generator=None, numpy=False):
+        """The on-policy cadence of train_onpolicy.py:359-377: after a collection phase, `epochs` minibatches of
+        `batch_size` transitions are sampled from the freshly collected buffer, which is then discarded (the next
+        collect() overwrites the trajectory).  The reference collects episodes_per_train = 10 episodes (<= 330
+        transitions) per phase; a vectorised phase holds n_envs episodes."""
+        for _ in range(int(epochs)):
+            yield self.sample_batch(batch_size, generator=generator, numpy=numpy)
 
 
 class CheckersRollout(object):

@@ -83,6 +83,13 @@ def test_particle_reference_batch_layout_and_valid_mask():
     assert np.allclose(g.cpu().numpy(), (ro.reward * valid).sum(0).cpu().numpy())
     batch = ro.sample_batch(128, generator=torch.Generator(device="cuda").manual_seed(0))
     assert batch["reward"].shape == (128,)
+    from cm3_amd import batch as BR
+    n = 0
+    for mb in ro.on_policy_minibatches(epochs=24, batch_size=128, generator=torch.Generator(device="cuda").manual_seed(1)):
+        out = BR.process_batch(mb)                      # device columns straight into the device reshapers
+        assert out[0] == 128 and out[2].shape == (128 * N, 12) and out[4].shape == (128 * N, 5)
+        n += 1
+    assert n == 24
 
 
 def test_particle_auto_reset_rollout_keeps_true_terminal_next_state():

@@ -1,7 +1,8 @@
 // Diagnostic: per-wave timeline (shader-clock stamps) of the lane-per-env particle step kernel at the C2
 // size, launched back to back like the bench does.  Build: hipcc -DCM3_STAMPS ... ; run on the GPU box.
-#define CM3_STAMPS 1
+#ifdef CM3_STAMPS
 __device__ long long *cm3_stamp_buf;
+#endif
 #include "../../cm3_amd/csrc/particle.hip"
 #include "../../cm3_amd/csrc/util.hip"
 #include <algorithm>
@@ -16,7 +17,9 @@ int main(int argc, char **argv) {
   const int waves = (E + 63) / 64;
   hipMalloc((void **)&stamps, (size_t)(E + 3) / 4 * 16 * 8 + 4096);
   hipMemset(episode, 0, (size_t)E * 4);
+#ifdef CM3_STAMPS
   hipMemcpyToSymbol(HIP_SYMBOL(cm3_stamp_buf), &stamps, sizeof(stamps));
+#endif
   cm3_particle_desc d; memset(&d, 0, sizeof(d));
   d.n_envs = E; d.n_agents = N; d.max_steps = 33; d.seed = 12341; d.prob_random = argc > 2 ? atof(argv[2]) : 0.2;
   double ax[4] = {-0.9, 0.9, -0.9, 0.9}, ay[4] = {-0.9, 0.9, 0.9, -0.9}, lx[4] = {0.9, -0.9, 0.9, -0.9}, ly[4] = {0.9, -0.9, -0.9, 0.9};
