@@ -101,7 +101,7 @@ class CheckersStepper(object):
     """In-place stepping of E Checkers envs (BASELINE configs[2]): one cm3_checkers_step launch per tick,
     uniform actions drawn in-kernel, auto-reset; replayed as a hipGraph."""
 
-    def __init__(self, cfg, n_envs, device, seed=12341, env_id_base=0, max_steps=33):
+    def __init__(self, cfg, n_envs, device, seed=12341, env_id_base=0, max_steps=33, fused=False):
         import numpy as np
         import torch
         from cm3_amd import _lib
@@ -115,12 +115,24 @@ class CheckersStepper(object):
         self.bufs = self.env._bufs(0)
         self.device = self.env.device
         self.graph, self.graph_ticks = None, 0
+        self.fused = bool(fused)
+        if self.fused:                 # in-place trajectory (zero strides): all ticks of an enqueue() in ONE launch
+            b, t = self.bufs, _lib.CheckersTraj()
+            for name in ("mask", "agents", "steps", "episode", "goals", "actions", "grid", "vec", "obs_others",
+                         "obs_self_t", "obs_self_v", "local_rewards", "reward", "done"):
+                setattr(t, name, getattr(b, name))
+            self.traj = t
+            self.env._desc.flags |= _lib.FLAG_FUSED_TICKS
 
     def stream(self):
         return self._lib_mod.current_stream_handle(self.device)
 
     def enqueue(self, n_ticks, stream=None):
         s = self.stream() if stream is None else stream
+        if self.fused:
+            self._lib_mod.check(self.lib.cm3_checkers_rollout(ctypes.byref(self.env._desc), ctypes.byref(self.traj),
+                                                              int(n_ticks), s))
+            return
         for _ in range(int(n_ticks)):
             self._lib_mod.check(self.lib.cm3_checkers_step(ctypes.byref(self.env._desc), ctypes.byref(self.bufs), s))
 
@@ -352,7 +364,7 @@ def main():
             bytes_per_env_step -= (16 * N + 8 * N + 8) * (GRAPH_TICKS - 1) / float(GRAPH_TICKS)
         dtype_name = "f32"
     else:
-        stepper = CheckersStepper(cfg, E, device, env_id_base=rank * E)
+        stepper = CheckersStepper(cfg, E, device, env_id_base=rank * E, fused=args.fused)
         bytes_per_env_step = CHECKERS_BYTES_PER_ENV_STEP
         dtype_name = "int8/int32 state and grids, f64 normalised outputs (bit-exact)"
     if not args.no_graph:
@@ -378,7 +390,7 @@ def main():
 
     total_env_steps = float(E) * K * world
     value = total_env_steps / wall_max
-    ticks_per_launch = GRAPH_TICKS if (kind == "particle" and args.fused) else 1
+    ticks_per_launch = GRAPH_TICKS if (kind in ("particle", "checkers") and args.fused) else 1
     launch_s = ev_max / (K / float(ticks_per_launch))
     bytes_per_launch = bytes_per_env_step * E * ticks_per_launch
     achieved = bytes_per_launch / launch_s / 1e9
@@ -412,19 +424,26 @@ def main():
             out["roofline"]["traffic_source"] = ("profiles/pmc_traffic.json: %s, %d launches, FETCH_SIZE %.1f KB (x2) + "
                                                  "WRITE_SIZE %.1f KB" % (rec["kernel"], rec["launches"],
                                                                          rec["FETCH_SIZE_KB"], rec["WRITE_SIZE_KB"]))
-    if world == 1 and rank == 0 and kind == "particle" and not args.fused:
+    if world == 1 and rank == 0 and kind in ("particle", "checkers") and not args.fused:
         # Extra (not the headline): the same workload with all 33 ticks of an episode fused into ONE launch
         # (CM3_FLAG_FUSED_TICKS) -- legal for the random-action branch only, where nothing acts between ticks.
-        fs = ParticleStepper(cfg, N, E, device, kernel=args.kernel, fused=True)
+        if kind == "particle":
+            fs = ParticleStepper(cfg, N, E, device, kernel=args.kernel, fused=True)
+            f_bps = algorithmic_bytes_per_env_step(N) - (24 * N + 8) * (GRAPH_TICKS - 1) / float(GRAPH_TICKS)
+            where = "tests/test_gpu_rollout.py::test_fused_rollout_equals_per_tick_rollout"
+        else:
+            fs = CheckersStepper(cfg, E, device, fused=True)
+            f_bps = CHECKERS_BYTES_PER_ENV_STEP - 32 * (GRAPH_TICKS - 1) / float(GRAPH_TICKS)   # compact state r/w once
+            where = "tests/test_gpu_rollout.py::test_checkers_fused_rollout_equals_per_tick"
         fs.capture(GRAPH_TICKS)
         fs.run(GRAPH_TICKS * 4)
         torch.cuda.synchronize(device)
         f_ms = timed_ticks(fs, K)
-        f_bytes = (algorithmic_bytes_per_env_step(N) - (24 * N + 8) * (GRAPH_TICKS - 1) / float(GRAPH_TICKS)) * E * GRAPH_TICKS
+        f_bytes = f_bps * E * GRAPH_TICKS
         f_launch_s = f_ms * 1e-3 / (K / float(GRAPH_TICKS))
         out["fused_rollout"] = {
-            "note": "extra, not the headline: %d ticks per launch, state in registers, bit-identical trajectories "
-                    "(tests/test_gpu_rollout.py::test_fused_rollout_equals_per_tick_rollout)" % GRAPH_TICKS,
+            "note": "extra, not the headline: %d ticks per launch, state in registers, bit-identical trajectories (%s)"
+                    % (GRAPH_TICKS, where),
             "value": E * K / (f_ms * 1e-3), "unit": "env-steps/s", "avg_launch_us": f_launch_s * 1e6,
             "algorithmic_bytes_per_launch": f_bytes, "achieved_GBps": f_bytes / f_launch_s / 1e9,
             "frac_of_peak": f_bytes / f_launch_s / 1e9 / HBM_PEAK_GBPS}

@@ -70,6 +70,16 @@ class CheckersBufs(ctypes.Structure):
         "obs_self_t", "obs_self_v", "local_rewards", "reward", "done")]
 
 
+class CheckersTraj(ctypes.Structure):
+    _fields_ = ([(n, c_void_p) for n in ("mask", "agents", "steps", "episode", "goals")] +
+                [("actions", c_void_p), ("actions_stride", c_size_t), ("grid", c_void_p), ("grid_slot_stride", c_size_t),
+                 ("vec", c_void_p), ("vec_stride", c_size_t), ("obs_others", c_void_p), ("obs_others_stride", c_size_t),
+                 ("obs_self_t", c_void_p), ("obs_self_t_slot_stride", c_size_t),
+                 ("obs_self_v", c_void_p), ("obs_self_v_stride", c_size_t),
+                 ("local_rewards", c_void_p), ("local_rewards_stride", c_size_t),
+                 ("reward", c_void_p), ("reward_stride", c_size_t), ("done", c_void_p), ("done_stride", c_size_t)])
+
+
 class ActorParticleDesc(ctypes.Structure):
     _fields_ = [("n_envs", c_int32), ("n_agents", c_int32), ("stage", c_int32), ("n_h1_self", c_int32),
                 ("n_h1_others", c_int32), ("n_h2", c_int32), ("n_actions", c_int32), ("epsilon", ctypes.c_float),
@@ -101,6 +111,7 @@ SYMBOLS = {
     "cm3_particle_rollout_f32": (ctypes.c_int, [P(ParticleDesc), P(ParticleTraj), c_int32, c_void_p]),
     "cm3_particle_rollout_f64": (ctypes.c_int, [P(ParticleDesc), P(ParticleTraj), c_int32, c_void_p]),
     "cm3_checkers_step": (ctypes.c_int, [P(CheckersDesc), P(CheckersBufs), c_void_p]),
+    "cm3_checkers_rollout": (ctypes.c_int, [P(CheckersDesc), P(CheckersTraj), c_int32, c_void_p]),
     "cm3_checkers_reset": (ctypes.c_int, [P(CheckersDesc), P(CheckersBufs), c_void_p, c_void_p]),
     "cm3_actor_particle_f32": (ctypes.c_int, [P(ActorParticleDesc), P(ActorParticleWeights), P(ActorParticleBufs),
                                               c_void_p]),

@@ -47,7 +47,17 @@ struct CheckersParams {
   const uint8_t *reset_mask;
   int grid_rec, obst_rec;        // payload bytes per env of grid / obs_self_t
   int grid_stride, obst_stride;  // bytes between consecutive env records (>= payload)
+  // tick loop inside one launch (CM3_FLAG_FUSED_TICKS, fast kernel only): tick t uses <pointer> + t * <stride in
+  // bytes>; the observation pointers then address slot 1 of their trajectories.  n_ticks == 1 with zero strides
+  // is the plain one-launch-per-tick step.
+  int n_ticks;
+  int _pad2;
+  size_t st_actions, st_grid, st_vec, st_obs_others, st_obs_self_t, st_obs_self_v, st_local, st_reward, st_done;
 };
+
+template <typename T> __device__ __forceinline__ T *ck_tick_ptr(T *base, size_t stride, int t) {
+  return reinterpret_cast<T *>(reinterpret_cast<char *>(base) + stride * (size_t)t);
+}
 
 constexpr int kCkLdsBytes = 40960;  // per-wave staging tile (64 rows x up to 640 bytes)
 
@@ -205,20 +215,45 @@ template <int N> __device__ __forceinline__ void ck_init(const CheckersParams &p
   if (N == 1) s.r[0] = (goal[0] == 0 ? 0 : 2) + p.O;
 }
 
-// One tick of one env (checkers.py:228-262), executed by every lane that maps to env `ec`; `writer` selects the
-// single lane that performs the per-env stores.  Leaves the post-step (or freshly reset) state in `s`.
+// Live per-env scalars that travel with the compact state across the ticks of a launch.
+template <int N> struct CkLive {
+  int steps;
+  uint32_t episode, episode_in;
+  uint8_t goal[N];
+};
+
 template <int N>
-__device__ __forceinline__ void ck_step_env(const CheckersParams &p, size_t e, size_t ec, bool writer, CkState<N> &s) {
-  const bool active = writer;
+__device__ __forceinline__ void ck_load_env(const CheckersParams &p, size_t ec, CkState<N> &s, CkLive<N> &lv) {
   ck_load<N>(p, ec, s);
-  int steps = p.steps[ec];
+  lv.steps = p.steps[ec];
+#pragma unroll
+  for (int i = 0; i < N; ++i) lv.goal[i] = p.goals[ec * N + i];
+  lv.episode = 0;
+  if (p.flags & (CM3_FLAG_GEN_ACTIONS | CM3_FLAG_AUTO_RESET)) lv.episode = (uint32_t)p.episode[ec];
+  lv.episode_in = lv.episode;
+}
+
+template <int N>
+__device__ __forceinline__ void ck_store_env(const CheckersParams &p, size_t e, const CkState<N> &s, const CkLive<N> &lv) {
+  ck_store<N>(p, e, s);
+  p.steps[e] = lv.steps;
+  if (lv.episode != lv.episode_in) p.episode[e] = (int32_t)lv.episode;
+}
+
+// One tick of one env (checkers.py:228-262), executed by every lane that maps to env `ec`; `writer` selects the
+// single lane that performs the per-env stores of tick t.  Leaves the post-step (or freshly reset) state in `s`.
+template <int N>
+__device__ __forceinline__ void ck_tick_env(const CheckersParams &p, int t, size_t e, size_t ec, bool writer, CkState<N> &s,
+                                            CkLive<N> &lv) {
+  const bool active = writer;
+  int steps = lv.steps;
+  uint32_t episode = lv.episode;
   uint8_t goal[N];
 #pragma unroll
-  for (int i = 0; i < N; ++i) goal[i] = p.goals[ec * N + i];
+  for (int i = 0; i < N; ++i) goal[i] = lv.goal[i];
   int act[N];
-  uint32_t episode = 0;
   const uint64_t genv = (uint64_t)(p.env_id_base + (int64_t)ec);
-  if (p.flags & (CM3_FLAG_GEN_ACTIONS | CM3_FLAG_AUTO_RESET)) episode = (uint32_t)p.episode[ec];
+  int32_t *actions_t = ck_tick_ptr(p.actions, p.st_actions, t);
   if (p.flags & CM3_FLAG_GEN_ACTIONS) {
     uint32_t words[4 * ((N + 3) / 4)];
 #pragma unroll
@@ -232,11 +267,11 @@ __device__ __forceinline__ void ck_step_env(const CheckersParams &p, size_t e, s
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       act[i] = rand5(words[i]);
-      if (active) p.actions[e * N + i] = act[i];
+      if (active) actions_t[e * N + i] = act[i];
     }
   } else {
 #pragma unroll
-    for (int i = 0; i < N; ++i) act[i] = p.actions[ec * N + i];
+    for (int i = 0; i < N; ++i) act[i] = actions_t[ec * N + i];
   }
 
   // ---- agents act in index order (step :233-237) ---------------------------------------------------------
@@ -289,10 +324,11 @@ __device__ __forceinline__ void ck_step_env(const CheckersParams &p, size_t e, s
     done = __popcll(s.mask) == p.max_collectible;
   }
   if (active) {
+    double *local_t = ck_tick_ptr(p.local_rewards, p.st_local, t);
 #pragma unroll
-    for (int i = 0; i < N; ++i) p.local_rewards[e * N + i] = local[i];
-    p.reward[e] = total;
-    p.done[e] = done ? 1 : 0;
+    for (int i = 0; i < N; ++i) local_t[e * N + i] = local[i];
+    ck_tick_ptr(p.reward, p.st_reward, t)[e] = total;
+    ck_tick_ptr(p.done, p.st_done, t)[e] = done ? 1 : 0;
   }
   if ((p.flags & CM3_FLAG_AUTO_RESET) && done) {
     episode += 1;
@@ -302,12 +338,20 @@ __device__ __forceinline__ void ck_step_env(const CheckersParams &p, size_t e, s
     }
     ck_init<N>(p, goal, s);
     steps = 0;
-    if (active) p.episode[e] = (int32_t)episode;
   }
-  if (active) {
-    ck_store<N>(p, e, s);
-    p.steps[e] = steps;
-  }
+  lv.steps = steps;
+  lv.episode = episode;
+#pragma unroll
+  for (int i = 0; i < N; ++i) lv.goal[i] = goal[i];
+}
+
+// plain one-tick step: load, tick 0, store
+template <int N>
+__device__ __forceinline__ void ck_step_env(const CheckersParams &p, size_t e, size_t ec, bool writer, CkState<N> &s) {
+  CkLive<N> lv;
+  ck_load_env<N>(p, ec, s, lv);
+  ck_tick_env<N>(p, 0, e, ec, writer, s, lv);
+  if (writer) ck_store_env<N>(p, e, s, lv);
 }
 
 
@@ -391,16 +435,18 @@ template <int N> __device__ __forceinline__ uint32_t ckf_obst_dword(const CkStat
 }
 
 template <int N>
-__device__ __forceinline__ void ckf_emit(const CheckersParams &p, const CkState<N> &s, int g, size_t e, bool env_ok) {
+__device__ __forceinline__ void ckf_emit(const CheckersParams &p, const CkState<N> &s, int g, size_t e, bool env_ok,
+                                         int t = 0) {
   using F = CkFast<N>;
   constexpr int NO = N > 1 ? N - 1 : 1;
   if (!env_ok) return;
   // grid record: dword g
   const int gd = p.grid_stride >> 2;
-  if (g < gd) reinterpret_cast<uint32_t *>(p.grid + e * (size_t)p.grid_stride)[g] = ckf_grid_dword<N>(s, g);
+  int8_t *grid_t = ck_tick_ptr(p.grid, p.st_grid, t);
+  if (g < gd) reinterpret_cast<uint32_t *>(grid_t + e * (size_t)p.grid_stride)[g] = ckf_grid_dword<N>(s, g);
   // obs_self_t record: dwords g, g+16, ...
   const int od = p.obst_stride >> 2;
-  uint32_t *o32 = reinterpret_cast<uint32_t *>(p.obs_self_t + e * (size_t)p.obst_stride);
+  uint32_t *o32 = reinterpret_cast<uint32_t *>(ck_tick_ptr(p.obs_self_t, p.st_obs_self_t, t) + e * (size_t)p.obst_stride);
   for (int d = g; d < od; d += F::G) o32[d] = ckf_obst_dword<N>(s, d);
   // small vector outputs: lane i (< N) writes agent i's rows
   if (g < N) {
@@ -417,15 +463,15 @@ __device__ __forceinline__ void ckf_emit(const CheckersParams &p, const CkState<
     v.y = ci;
     v.z = gi;
     v.w = oi;
-    reinterpret_cast<int4 *>(p.vec)[e * N + g] = v;
+    reinterpret_cast<int4 *>(ck_tick_ptr(p.vec, p.st_vec, t))[e * N + g] = v;
     const double half = (double)(F::R * F::C) / 2.0;
     double4 sv;
     sv.x = ((double)ri - (double)F::TR / 2.0) / (double)F::TR;
     sv.y = ((double)ci - (double)F::TC / 2.0) / (double)F::TC;
     sv.z = (double)gi / half;
     sv.w = (double)oi / half;
-    reinterpret_cast<double4 *>(p.obs_self_v)[e * N + g] = sv;
-    double2 *oo = reinterpret_cast<double2 *>(p.obs_others) + (e * N + g) * NO;
+    reinterpret_cast<double4 *>(ck_tick_ptr(p.obs_self_v, p.st_obs_self_v, t))[e * N + g] = sv;
+    double2 *oo = reinterpret_cast<double2 *>(ck_tick_ptr(p.obs_others, p.st_obs_others, t)) + (e * N + g) * NO;
 #pragma unroll
     for (int k = 0; k < NO; ++k) {
       // k-th other agent of agent g (N == 1: itself)
@@ -444,15 +490,24 @@ __device__ __forceinline__ void ckf_emit(const CheckersParams &p, const CkState<
   }
 }
 
-template <int N> __global__ void __launch_bounds__(256) k_checkers_step_fast(const CheckersParams p) {
+template <int N, bool FUSED> __global__ void __launch_bounds__(256) k_checkers_step_fast(const CheckersParams p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane & 15, sub = lane >> 4;
   const size_t e = ((size_t)blockIdx.x * 4 + wave) * 4 + sub;
   const bool env_ok = e < (size_t)p.E;
   const size_t ec = env_ok ? e : (size_t)p.E - 1;
+  const bool writer = env_ok && g == 0;
   CkState<N> s;
-  ck_step_env<N>(p, e, ec, env_ok && g == 0, s);
-  ckf_emit<N>(p, s, g, e, env_ok);
+  CkLive<N> lv;
+  ck_load_env<N>(p, ec, s, lv);
+  // FUSED == false: exactly one tick; the loop and the per-tick offsets fold away
+  const int n_ticks = FUSED ? p.n_ticks : 1;
+#pragma unroll 1
+  for (int t = 0; t < n_ticks; ++t) {
+    ck_tick_env<N>(p, t, e, ec, writer, s, lv);
+    ckf_emit<N>(p, s, g, e, env_ok, t);
+  }
+  if (writer) ck_store_env<N>(p, e, s, lv);
 }
 
 template <int N> __global__ void __launch_bounds__(256) k_checkers_reset_fast(const CheckersParams p) {
@@ -532,8 +587,9 @@ static int ck_fill(const cm3_checkers_desc *d, const cm3_checkers_bufs *b, const
   CM3_REQUIRE(d->n_rows * d->n_columns <= 64, "n_rows*n_columns must be <= 64 (collected-mask width)");
   CM3_REQUIRE(d->n_obs >= 0 && d->n_obs <= 8, "n_obs out of range");
   CM3_REQUIRE(d->max_steps >= 1, "max_steps must be >= 1");
-  CM3_REQUIRE((d->flags & ~(CM3_FLAG_AUTO_RESET | CM3_FLAG_GEN_ACTIONS)) == 0, "unknown flag bits");
+  CM3_REQUIRE((d->flags & ~(CM3_FLAG_AUTO_RESET | CM3_FLAG_GEN_ACTIONS | CM3_FLAG_FUSED_TICKS)) == 0, "unknown flag bits");
   memset(&p, 0, sizeof(p));
+  p.n_ticks = 1;
   p.E = d->n_envs;
   p.R = d->n_rows;
   p.C = d->n_columns;
@@ -543,7 +599,7 @@ static int ck_fill(const cm3_checkers_desc *d, const cm3_checkers_bufs *b, const
   p.K = 2 * p.O + 1;
   CM3_REQUIRE(p.TR <= 255 && p.TC <= 255, "grid too large for packed agent words");
   p.max_steps = d->max_steps;
-  p.flags = d->flags;
+  p.flags = d->flags & ~CM3_FLAG_FUSED_TICKS;
   p.max_collectible = p.R * p.C;
   p.env_id_base = d->env_id_base;
   p.seed = d->seed;
@@ -599,8 +655,10 @@ static int ck_fill(const cm3_checkers_desc *d, const cm3_checkers_bufs *b, const
 template <int N> static int ck_launch(const CheckersParams &p, bool step, hipStream_t stream) {
   if (ck_fast_ok(p)) {
     const unsigned fblocks = (unsigned)(((size_t)p.E + 15) / 16);  // 4 waves x 4 envs per workgroup
-    if (step)
-      hipLaunchKernelGGL((k_checkers_step_fast<N>), dim3(fblocks), dim3(256), 0, stream, p);
+    if (step && p.n_ticks > 1)
+      hipLaunchKernelGGL((k_checkers_step_fast<N, true>), dim3(fblocks), dim3(256), 0, stream, p);
+    else if (step)
+      hipLaunchKernelGGL((k_checkers_step_fast<N, false>), dim3(fblocks), dim3(256), 0, stream, p);
     else
       hipLaunchKernelGGL((k_checkers_reset_fast<N>), dim3(fblocks), dim3(256), 0, stream, p);
     CM3_HIP_CHECK(hipGetLastError());
@@ -615,12 +673,8 @@ template <int N> static int ck_launch(const CheckersParams &p, bool step, hipStr
   return CM3_OK;
 }
 
-static int ck_call(const cm3_checkers_desc *d, const cm3_checkers_bufs *b, const uint8_t *mask, bool step, void *stream) {
-  CheckersParams p;
-  int rc = ck_fill(d, b, mask, step, p);
-  if (rc != CM3_OK) return rc;
-  hipStream_t s = (hipStream_t)stream;
-  switch (d->n_agents) {
+static int ck_dispatch(const CheckersParams &p, int n_agents, bool step, hipStream_t s) {
+  switch (n_agents) {
     case 1: return ck_launch<1>(p, step, s);
     case 2: return ck_launch<2>(p, step, s);
     case 3: return ck_launch<3>(p, step, s);
@@ -630,12 +684,74 @@ static int ck_call(const cm3_checkers_desc *d, const cm3_checkers_bufs *b, const
     case 7: return ck_launch<7>(p, step, s);
     case 8: return ck_launch<8>(p, step, s);
   }
-  return fail(CM3_ERR_INVALID, "n_agents %d unsupported", d->n_agents);
+  return fail(CM3_ERR_INVALID, "n_agents %d unsupported", n_agents);
+}
+
+static int ck_call(const cm3_checkers_desc *d, const cm3_checkers_bufs *b, const uint8_t *mask, bool step, void *stream) {
+  CheckersParams p;
+  int rc = ck_fill(d, b, mask, step, p);
+  if (rc != CM3_OK) return rc;
+  return ck_dispatch(p, d->n_agents, step, (hipStream_t)stream);
+}
+
+static int ck_rollout(const cm3_checkers_desc *d, const cm3_checkers_traj *t, int32_t n_ticks, void *stream) {
+  CM3_REQUIRE(d && t, "null desc/traj");
+  CM3_REQUIRE(n_ticks >= 1, "n_ticks must be >= 1");
+  auto at = [](void *base, size_t stride, int k) -> void * {
+    return base ? (void *)((char *)base + stride * (size_t)k) : nullptr;
+  };
+  auto bufs_for = [&](int k, cm3_checkers_bufs &b) {
+    memset(&b, 0, sizeof(b));
+    b.mask = t->mask;
+    b.agents = t->agents;
+    b.steps = t->steps;
+    b.episode = t->episode;
+    b.goals = t->goals;
+    b.actions = (int32_t *)at(t->actions, t->actions_stride, k);
+    b.grid = (int8_t *)at(t->grid, t->grid_slot_stride, k + 1);
+    b.vec = (int32_t *)at(t->vec, t->vec_stride, k + 1);
+    b.obs_others = (double *)at(t->obs_others, t->obs_others_stride, k + 1);
+    b.obs_self_t = (int8_t *)at(t->obs_self_t, t->obs_self_t_slot_stride, k + 1);
+    b.obs_self_v = (double *)at(t->obs_self_v, t->obs_self_v_stride, k + 1);
+    b.local_rewards = (double *)at(t->local_rewards, t->local_rewards_stride, k);
+    b.reward = (double *)at(t->reward, t->reward_stride, k);
+    b.done = (uint8_t *)at(t->done, t->done_stride, k);
+  };
+  cm3_checkers_bufs b;
+  if (d->flags & CM3_FLAG_FUSED_TICKS) {
+    CM3_REQUIRE((d->flags & CM3_FLAG_GEN_ACTIONS) || n_ticks == 1 || t->actions_stride != 0,
+                "fused rollout needs in-kernel actions or one pre-filled action slot per tick");
+    bufs_for(0, b);
+    CheckersParams p;
+    int rc = ck_fill(d, &b, nullptr, true, p);
+    if (rc != CM3_OK) return rc;
+    CM3_REQUIRE(ck_fast_ok(p), "fused Checkers rollouts need the fast kernel (3x8 band, n_obs 2, 4-byte padded records)");
+    p.n_ticks = n_ticks;
+    p.st_actions = t->actions_stride;
+    p.st_grid = t->grid_slot_stride;
+    p.st_vec = t->vec_stride;
+    p.st_obs_others = t->obs_others_stride;
+    p.st_obs_self_t = t->obs_self_t_slot_stride;
+    p.st_obs_self_v = t->obs_self_v_stride;
+    p.st_local = t->local_rewards_stride;
+    p.st_reward = t->reward_stride;
+    p.st_done = t->done_stride;
+    return ck_dispatch(p, d->n_agents, true, (hipStream_t)stream);
+  }
+  for (int k = 0; k < n_ticks; ++k) {
+    bufs_for(k, b);
+    int rc = ck_call(d, &b, nullptr, true, stream);
+    if (rc != CM3_OK) return rc;
+  }
+  return CM3_OK;
 }
 
 }  // namespace cm3
 
 extern "C" {
+int cm3_checkers_rollout(const cm3_checkers_desc *d, const cm3_checkers_traj *t, int32_t n_ticks, void *stream) {
+  return cm3::ck_rollout(d, t, n_ticks, stream);
+}
 int cm3_checkers_step(const cm3_checkers_desc *d, const cm3_checkers_bufs *b, void *stream) {
   return cm3::ck_call(d, b, nullptr, true, stream);
 }

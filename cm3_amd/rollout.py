@@ -294,10 +294,11 @@ class CheckersRollout(object):
     """T-tick trajectory over a VecCheckersEnv (16-column transitions, train_onpolicy.py:336).
     Episode-synchronous (the env is reset at the start; transitions after `done` are invalid)."""
 
-    def __init__(self, env, n_ticks=None, use_graph=True):
+    def __init__(self, env, n_ticks=None, use_graph=True, fused=False):
         self.env = env
         self.T = int(n_ticks or env.max_steps)
         self.use_graph = bool(use_graph)
+        self.fused = bool(fused)      # random-action branch in ONE launch (CM3_FLAG_FUSED_TICKS; fast kernel only)
         self._graph = None
         E, N, T, dev = env.E, env.n, self.T, env.device
         z = lambda *s, d: torch.zeros(*s, dtype=d, device=dev)  # noqa: E731
@@ -327,6 +328,31 @@ class CheckersRollout(object):
                                              self.done[t].data_ptr())
         return b
 
+    def _traj(self):
+        env = self.env
+        t = _lib.CheckersTraj()
+        t.mask, t.agents, t.steps = env._mask.data_ptr(), env._agents.data_ptr(), env._steps.data_ptr()
+        t.episode, t.goals = env._episode.data_ptr(), env._goals.data_ptr()
+        def slot(x):
+            return x.data_ptr(), x[0].numel() * x.element_size()
+        t.actions, t.actions_stride = slot(self.actions)
+        t.grid, t.grid_slot_stride = slot(self._grid_raw)
+        t.vec, t.vec_stride = slot(self.vec)
+        t.obs_others, t.obs_others_stride = slot(self.obs_others)
+        t.obs_self_t, t.obs_self_t_slot_stride = slot(self._obst_raw)
+        t.obs_self_v, t.obs_self_v_stride = slot(self.obs_self_v)
+        t.local_rewards, t.local_rewards_stride = slot(self.local_rewards)
+        t.reward, t.reward_stride = slot(self.reward)
+        t.done, t.done_stride = slot(self.done)
+        return t
+
+    def _enqueue_random(self, stream, fused):
+        env = self.env
+        env._desc.flags = FLAG_GEN_ACTIONS | (_lib.FLAG_FUSED_TICKS if fused else 0)
+        traj = self._traj()
+        _lib.check(self._lib.cm3_checkers_rollout(ctypes.byref(env._desc), ctypes.byref(traj), self.T, stream))
+        env._desc.flags = 0
+
     def collect(self, goals, policy=None):
         """goals: one-hot [N,2] / [E,N,2] (train_onpolicy.py:287-293).  policy None = uniform random actions
         drawn in-kernel; else policy(actions_prev, obs_others, obs_self_t, obs_self_v, goals) -> [E,N]."""
@@ -338,16 +364,17 @@ class CheckersRollout(object):
         self.obs_self_t[0].copy_(ot)
         self.obs_self_v[0].copy_(ov)
         self.goals_onehot = env.goals.clone()
-        if policy is None and self.use_graph:
-            # random-action branch: the T step launches (each bound to its trajectory slots) replay as one hipGraph
-            if self._graph is None:
-                def enqueue(stream):
-                    env._desc.flags = FLAG_GEN_ACTIONS
-                    for t in range(self.T):
-                        b = self._bufs(t)
-                        _lib.check(self._lib.cm3_checkers_step(ctypes.byref(env._desc), ctypes.byref(b), stream))
-                self._graph = _lib.capture_graph(env.device, enqueue)
-            _lib.check(self._lib.cm3_graph_launch(self._graph, env._stream()))
+        if policy is None:
+            # random-action branch (train_onpolicy.py:305-307): cm3_checkers_rollout -- one fused launch, or T step
+            # launches bound to their trajectory slots and replayed as one hipGraph
+            if self.fused:
+                self._enqueue_random(env._stream(), True)
+            elif self.use_graph:
+                if self._graph is None:
+                    self._graph = _lib.capture_graph(env.device, lambda st: self._enqueue_random(st, False))
+                _lib.check(self._lib.cm3_graph_launch(self._graph, env._stream()))
+            else:
+                self._enqueue_random(env._stream(), False)
             return self
         for t in range(self.T):
             if policy is None:

@@ -206,6 +206,24 @@ typedef struct cm3_checkers_bufs {
   uint8_t *done;
 } cm3_checkers_bufs;
 
+/* Trajectory collection for Checkers (train_onpolicy.py:302-350, 16-column transitions): n_ticks step launches over
+ * a time-major trajectory, or ONE launch with CM3_FLAG_FUSED_TICKS (fast kernel only).  Observation arrays have
+ * n_ticks+1 slots (slot t = before tick t); per-tick outputs n_ticks slots; strides in BYTES between slots. */
+typedef struct cm3_checkers_traj {
+  uint64_t *mask; uint32_t *agents; int32_t *steps; int32_t *episode; uint8_t *goals; /* live, in place */
+  int32_t *actions;      size_t actions_stride;
+  int8_t *grid;          size_t grid_slot_stride;
+  int32_t *vec;          size_t vec_stride;
+  double *obs_others;    size_t obs_others_stride;
+  int8_t *obs_self_t;    size_t obs_self_t_slot_stride;
+  double *obs_self_v;    size_t obs_self_v_stride;
+  double *local_rewards; size_t local_rewards_stride;
+  double *reward;        size_t reward_stride;
+  uint8_t *done;         size_t done_stride;
+} cm3_checkers_traj;
+
+int cm3_checkers_rollout(const cm3_checkers_desc *desc, const cm3_checkers_traj *traj, int32_t n_ticks, void *stream);
+
 /* Replaces Checkers.step (checkers.py:228-262): agents act sequentially in index order inside one lane. */
 int cm3_checkers_step(const cm3_checkers_desc *desc, const cm3_checkers_bufs *bufs, void *stream);
 /* Replaces Checkers.reset (checkers.py:265-291) for the envs selected by mask (NULL = all). */

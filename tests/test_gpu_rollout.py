@@ -206,3 +206,25 @@ def test_returns_moments_and_normalisation_kernels(dtype, C):
     # deterministic: two runs give identical bits
     again, (mean_b, std_b, _) = normalized_returns(x, done, valid, gamma=0.97)
     assert torch.equal(again, norm) and float(mean_b) == float(mean) and float(std_b) == float(std)
+
+
+@pytest.mark.parametrize("cfg_name", ["checkers_stage2.json", "checkers_stage1.json"])
+def test_checkers_fused_rollout_equals_per_tick(cfg_name):
+    from cm3_amd.checkers import VecCheckersEnv
+    from cm3_amd.rollout import CheckersRollout
+    cfg = load_cfg(cfg_name)
+    N, E, T = cfg["n_agents"], 333, 40
+    goals = np.eye(2) if N == 2 else np.array([[0, 1]])
+    outs = []
+    for fused, graph in ((False, False), (False, True), (True, False)):
+        env = VecCheckersEnv(cfg["init"], N, 9, E, device="cuda:0", seed=6, auto_reset=True)
+        ro = CheckersRollout(env, n_ticks=T, use_graph=graph, fused=fused).collect(goals)
+        outs.append((ro, env))
+    a = outs[0][0]
+    for ro, env in outs[1:]:
+        for name in ("grid", "vec", "obs_others", "obs_self_t", "obs_self_v", "actions", "local_rewards", "reward", "done"):
+            assert torch.equal(getattr(a, name), getattr(ro, name)), name
+        assert torch.equal(outs[0][1].steps, env.steps) and torch.equal(outs[0][1]._mask, env._mask)
+        assert torch.equal(outs[0][1]._episode, env._episode) and torch.equal(outs[0][1]._goals, env._goals)
+        ro.close()
+    assert int(a.done.sum()) > 0            # episodes of 9 ticks: several auto-resets inside the 40-tick rollout
