@@ -100,6 +100,11 @@ class VecParticleEnv(object):
         self._desc = _lib.ParticleDesc()
         _fill_desc(self._desc, config_particle, N, prob_random, max_steps, E, seed, env_id_base, 0)
         self._lib = _lib.lib()
+        # hot-path caches for step(): bound C functions, argument structs and result tuples per buffer parity
+        self._step_fn = self._fn("step")
+        self._desc_ref = ctypes.byref(self._desc)
+        self._step_bufs = {}
+        self._step_out = {}
 
     # ---- plumbing --------------------------------------------------------------------------------
     def _fn(self, op):
@@ -129,6 +134,7 @@ class VecParticleEnv(object):
         if self._term_state is None:
             self._term_state = torch.zeros_like(self._state[0])
             self._term_obs_others = torch.zeros_like(self._obs_others[0])
+            self._step_bufs.clear()
 
     # ---- reference surface -----------------------------------------------------------------------
     def reset(self, mask=None):
@@ -166,14 +172,18 @@ class VecParticleEnv(object):
             else:
                 self._actions[dst].copy_(a)
         self._desc.flags = flags
-        b = self._bufs(src, dst)
-        if direct is not None:
-            b.actions = direct.data_ptr()
-        _lib.check(self._fn("step")(ctypes.byref(self._desc), ctypes.byref(b), self._stream()))
+        b = self._step_bufs.get(dst)
+        if b is None:
+            b = self._step_bufs[dst] = self._bufs(src, dst)
+            gs = self._state[dst].permute(1, 0, 2)
+            self._step_out[dst] = (gs, self._obs_others[dst], gs, self._reward[dst], self._reward_n[dst],
+                                   self._done[dst].view(torch.bool))
+        b.actions = direct.data_ptr() if direct is not None else self._actions[dst].data_ptr()
+        rc = self._step_fn(self._desc_ref, ctypes.byref(b), torch.cuda.current_stream(self.device).cuda_stream)
+        if rc:
+            _lib.check(rc)
         self._cur = dst
-        gs = self.global_state
-        return (gs, self._obs_others[dst], gs, self._reward[dst], self._reward_n[dst],
-                self._done[dst].view(torch.bool))
+        return self._step_out[dst]
 
     def get_obs(self):
         """(obs_self [E,N,4], obs_others [E,N,L]) of the current state (multi-goal_spread.py:145-154)."""

@@ -142,3 +142,25 @@ def test_state_roundtrip_and_bad_configs():
     with pytest.raises(Cm3Error):
         bad = dict(n_agents=2, init=dict(n_rows=4, n_columns=8, n_obs=2, agents_r=[0, 2], agents_c=[8, 8]))
         _env(bad, 4)
+
+
+def test_single_agent_auto_reset_draws_goal_and_start_row():
+    """N = 1: every fresh episode draws a goal (train_onpolicy.py:288-291) and starts on row 0 (green) or 2 (orange)
+    accordingly (checkers.py:271-276)."""
+    cfg = load_cfg("checkers_stage1.json")
+    E = 4096
+    env = _env(cfg, E, max_steps=4, seed=3, auto_reset=True)
+    env.reset(goal_index=torch.zeros(E, 1, dtype=torch.int64))
+    seen = []
+    for t in range(12):
+        out = env.step()
+        done = out[6]
+        if bool(done.all()):                                   # all envs restart together every 4 ticks
+            st_ = env.get_state()
+            g = st_["goals"][:, 0].long()
+            assert torch.equal(st_["r"][:, 0].long(), torch.where(g == 0, 2, 4))     # expanded rows 0+2 / 2+2
+            assert int(st_["steps"].max()) == 0 and int(st_["mask"].abs().max()) == 0
+            seen.append(g.float().mean().item())
+            want = philox.reset_words(3, np.arange(E), int(env._episode[0]), 0)[0] & 1
+            assert np.array_equal(g.cpu().numpy(), want.astype(np.int64))
+    assert len(seen) == 3 and all(0.4 < m < 0.6 for m in seen)
