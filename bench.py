@@ -221,6 +221,35 @@ def measure_read_bandwidth(device, gib=4.0, reps=5):
     return nbytes / (ms * 1e-3) / 1e9
 
 
+def cfg_name_of(cfg):
+    """Name of the cm3_amd/configs file a loaded particle config came from (for the worker command line)."""
+    import cm3_amd
+    for name in ("particle_stage1", "particle_stage2_antipodal", "particle_stage2_cross", "particle_stage2_merge",
+                 "particle_merge8"):
+        if cm3_amd.load_config(name) == cfg:
+            return name
+    raise ValueError("unknown particle config")
+
+
+def _scalar_port_worker(args):
+    """One host process of the all-cores CPU line: whole episodes of the scalar port for `budget_s` seconds."""
+    cfg, n_agents, budget_s, seed = args
+    import random
+    import numpy as np
+    from oracle.particle_oracle import ParticleEnvOracle
+    env = ParticleEnvOracle(n_agents, cfg, 0.2, 33)
+    py_rng, np_rng = random.Random(seed), np.random.RandomState(seed)
+    steps = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        env.reset(py_rng, np_rng)
+        done = False
+        while not done:
+            *_, done = env.step(np_rng.randint(0, 5, n_agents))
+            steps += 1
+    return steps / (time.perf_counter() - t0)
+
+
 def cpu_baseline(cfg, n_agents, budget_s=12.0):
     """Reference-shaped scalar NumPy port on ONE host core: whole 33-tick episodes with uniform random
     actions, exactly the reference's pretrain loop (train_onpolicy.py:281-350 without the buffer)."""
@@ -262,6 +291,27 @@ def cpu_baseline(cfg, n_agents, budget_s=12.0):
                                    "sample": "%d ticks of %d envs, float64 [E,N,...] NumPy restatement" % (ticks, E)}
     except Exception as exc:          # the extra line must never break the bench
         out["vectorised_numpy"] = {"error": repr(exc)}
+    # third line: the scalar port on many host cores, one env stream per process
+    # (plain subprocesses with a hard timeout: nothing here can hang or outlive the bench)
+    try:
+        import subprocess
+        procs = max(1, min(os.cpu_count() or 1, 32))
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", cfg_name_of(cfg), str(n_agents), "3.0"]
+        children = [subprocess.Popen(cmd + [str(1000 + k)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+                    for k in range(procs)]
+        rates = []
+        deadline = time.time() + 60.0
+        for ch in children:
+            try:
+                o, _ = ch.communicate(timeout=max(1.0, deadline - time.time()))
+                rates.append(float(o.decode().strip().splitlines()[-1]))
+            except Exception:
+                ch.kill()
+        out["scalar_port_multiprocess"] = {"value": float(sum(rates)), "unit": "env-steps/s", "cores": len(rates),
+                                           "sample": "%d processes x 3 s of the scalar port (host has %d cores)"
+                                                     % (len(rates), os.cpu_count() or 0)}
+    except Exception as exc:
+        out["scalar_port_multiprocess"] = {"error": repr(exc)}
     return out
 
 
@@ -301,6 +351,10 @@ def pmc_traffic(tag):
 
 
 def main():
+    if len(sys.argv) >= 6 and sys.argv[1] == "--cpu-worker":      # child of cpu_baseline(): prints its env-steps/s
+        import cm3_amd
+        print(_scalar_port_worker((cm3_amd.load_config(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4]), int(sys.argv[5]))))
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100, help="timed steps; one step = one %d-tick rollout of the batch" % GRAPH_TICKS)
