@@ -83,7 +83,7 @@ class CheckersTraj(ctypes.Structure):
 class ActorParticleDesc(ctypes.Structure):
     _fields_ = [("n_envs", c_int32), ("n_agents", c_int32), ("stage", c_int32), ("n_h1_self", c_int32),
                 ("n_h1_others", c_int32), ("n_h2", c_int32), ("n_actions", c_int32), ("epsilon", ctypes.c_float),
-                ("env_id_base", c_int64), ("seed", c_uint64)]
+                ("precision", c_int32), ("_pad", c_int32), ("env_id_base", c_int64), ("seed", c_uint64)]
 
 
 class ActorParticleWeights(ctypes.Structure):

@@ -26,7 +26,7 @@ constexpr uint32_t kPurposePolicy = 0x40000000u;
 struct ActorParams {
   int E, stage;
   float eps;
-  int _pad;
+  int bf16;  // second layer on the bf16 matrix cores (f32 accumulate); 0 = exact f32 MFMA
   int64_t env_id_base;
   uint64_t seed;
   const float *obs_others, *state, *goals;
@@ -107,14 +107,25 @@ __device__ __forceinline__ void actor_head(const ActorParams &p, const float (*h
 //       C  col = l&15, row = 4 (l>>4) + reg  -> relu(C + b) to LDS h2s, where wave 0 picks up whole rows.
 //   (A version that evaluated the first layer directly in the A-operand layout needed no h1s but recomputed it in
 //    all four waves: 2750 VALU instructions per wave, 14.5 us per workgroup -- PMC run in profiles/.)
-template <int N> __global__ void __launch_bounds__(256) k_actor_particle(const ActorParams p) {
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// BF16 == true (opt-in, cm3_actor_particle_desc.precision = 1): the first-layer activations are stored as bf16 and
+// the second layer runs on v_mfma_f32_16x16x32_bf16 (f32 accumulate): 6 k-steps instead of 48, 16x the MFMA rate.
+//       A[i = l&15][k = 8 (l>>4) + q] = h1b[16t + (l&15)][32s + 8 (l>>4) + q],  q = 0..7   one ds_read_b128 per MFMA
+//       B[k = 8 (l>>4) + q][j = l&15] = bf16(W2[32s + 8 (l>>4) + q][16w + (l&15)])          24 VGPRs per lane
+// Inputs and W2 are rounded to bf16 (relative 2^-9): probabilities move by up to ~1e-2, so this is NOT the parity
+// path; everything else (first layers, output layer, softmax, sampling) stays float32.
+template <int N, bool BF16> __global__ void __launch_bounds__(256) k_actor_particle(const ActorParams p) {
   constexpr int L = 4 * (N > 1 ? N - 1 : 1);
   constexpr int SW = 8;                  // ws_self row: 6 weights, bias, pad
   constexpr int OW = L + 4;              // ws_oth row: L weights, bias, pad (multiple of 4 floats)
   constexpr int KU = kH1S + kH1O;        // 192 first-layer units = K of the second layer
+  constexpr int HB = KU + 8;             // bf16 row: 200 halfwords = 400 B (16-byte aligned rows)
   __shared__ __attribute__((aligned(16))) float ws_self[kH1S][SW];
   __shared__ __attribute__((aligned(16))) float ws_oth[kH1O][OW];
-  __shared__ float h1s[64][KU + 1];
+  __shared__ __attribute__((aligned(16))) float h1raw[BF16 ? (64 * HB) / 2 : 64 * (KU + 1)];
+  float (*h1s)[KU + 1] = reinterpret_cast<float (*)[KU + 1]>(h1raw);       // f32 view  [64][193]
+  __bf16 (*h1b)[HB] = reinterpret_cast<__bf16 (*)[HB]>(h1raw);             // bf16 view [64][200]
   __shared__ float h2s[64][kH2 + 1];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -156,11 +167,24 @@ template <int N> __global__ void __launch_bounds__(256) k_actor_particle(const A
     }
   }
   // ---- B: this wave's slice of W2 = [W_branch_self_h2 ; W_others_h2], unit k = 4s + hi, column c0 + col --------------
-  float bw[KU / 4];
+  float bw[BF16 ? 1 : KU / 4];
+  bf16x8 bwb[BF16 ? KU / 32 : 1];
+  if constexpr (BF16) {
 #pragma unroll
-  for (int s = 0; s < kH1S / 4; ++s) bw[s] = p.w_self_h2[(4 * s + hi) * kH2 + c0 + col];
+    for (int s = 0; s < KU / 32; ++s)
 #pragma unroll
-  for (int s = 0; s < kH1O / 4; ++s) bw[kH1S / 4 + s] = stage2 ? p.w_oth_h2[(4 * s + hi) * kH2 + c0 + col] : 0.0f;
+      for (int q = 0; q < 8; ++q) {
+        const int k = 32 * s + 8 * hi + q;  // unit index in [W_branch_self_h2 ; W_others_h2]
+        const float wv = k < kH1S ? p.w_self_h2[k * kH2 + c0 + col]
+                                  : (stage2 ? p.w_oth_h2[(k - kH1S) * kH2 + c0 + col] : 0.0f);
+        bwb[s][q] = (__bf16)wv;
+      }
+  } else {
+#pragma unroll
+    for (int s = 0; s < kH1S / 4; ++s) bw[s] = p.w_self_h2[(4 * s + hi) * kH2 + c0 + col];
+#pragma unroll
+    for (int s = 0; s < kH1O / 4; ++s) bw[kH1S / 4 + s] = stage2 ? p.w_oth_h2[(4 * s + hi) * kH2 + c0 + col] : 0.0f;
+  }
   __syncthreads();
 
   // ---- phase A: dense(6 -> 64, relu) units [16w, 16w+16) and dense(L -> 128, relu) units [32w, 32w+32) ---------------
@@ -176,7 +200,7 @@ template <int N> __global__ void __launch_bounds__(256) k_actor_particle(const A
     a = fmaf(x[3], wa.w, a);
     a = fmaf(x[4], wb.x, a);
     a = fmaf(x[5], wb.y, a);
-    h1s[lane][k] = fmaxf(a, 0.0f);
+    if constexpr (BF16) h1b[lane][k] = (__bf16)fmaxf(a, 0.0f); else h1s[lane][k] = fmaxf(a, 0.0f);
   }
   if (stage2) {
 #pragma unroll 4
@@ -191,11 +215,13 @@ template <int N> __global__ void __launch_bounds__(256) k_actor_particle(const A
       float a = wv[L];  // bias
 #pragma unroll
       for (int c = 0; c < L; ++c) a = fmaf(xo[c], wv[c], a);
-      h1s[lane][kH1S + k] = fmaxf(a, 0.0f);
+      if constexpr (BF16) h1b[lane][kH1S + k] = (__bf16)fmaxf(a, 0.0f); else h1s[lane][kH1S + k] = fmaxf(a, 0.0f);
     }
   } else {
 #pragma unroll 4
-    for (int q = 0; q < kH1O / 4; ++q) h1s[lane][kH1S + 32 * w + q] = 0.0f;
+    for (int q = 0; q < kH1O / 4; ++q) {
+      if constexpr (BF16) h1b[lane][kH1S + 32 * w + q] = (__bf16)0.0f; else h1s[lane][kH1S + 32 * w + q] = 0.0f;
+    }
   }
   __syncthreads();
 
@@ -203,11 +229,22 @@ template <int N> __global__ void __launch_bounds__(256) k_actor_particle(const A
   f32x4 acc[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  if constexpr (BF16) {
 #pragma unroll
-  for (int s = 0; s < KU / 4; ++s) {
+    for (int s = 0; s < KU / 32; ++s) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(h1s[16 * t + col][4 * s + hi], bw[s], acc[t], 0, 0, 0);
+      for (int t = 0; t < 4; ++t) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8 *>(&h1b[16 * t + col][32 * s + 8 * hi]);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bwb[s], acc[t], 0, 0, 0);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < KU / 4; ++s) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(h1s[16 * t + col][4 * s + hi], bw[s], acc[t], 0, 0, 0);
+    }
   }
   // ---- h2 = relu(add_n + b) (networks.py:533-534): C tile -> LDS rows ---------------------------------------------------
   {
@@ -225,7 +262,10 @@ template <int N> __global__ void __launch_bounds__(256) k_actor_particle(const A
 template <int N> static int actor_launch(const ActorParams &p, hipStream_t s) {
   const size_t rows = (size_t)p.E * N;
   const unsigned blocks = (unsigned)((rows + 63) / 64);
-  hipLaunchKernelGGL((k_actor_particle<N>), dim3(blocks), dim3(256), 0, s, p);
+  if (p.bf16)
+    hipLaunchKernelGGL((k_actor_particle<N, true>), dim3(blocks), dim3(256), 0, s, p);
+  else
+    hipLaunchKernelGGL((k_actor_particle<N, false>), dim3(blocks), dim3(256), 0, s, p);
   CM3_HIP_CHECK(hipGetLastError());
   return CM3_OK;
 }
@@ -242,6 +282,7 @@ extern "C" int cm3_actor_particle_f32(const cm3_actor_particle_desc *d, const cm
               "supported actor widths are 64/128/64/5 (config.json nn block); got %d/%d/%d/%d", d->n_h1_self,
               d->n_h1_others, d->n_h2, d->n_actions);
   CM3_REQUIRE(d->epsilon >= 0.0f && d->epsilon <= 1.0f, "epsilon must be in [0,1]");
+  CM3_REQUIRE(d->precision == 0 || d->precision == 1, "precision must be 0 (float32) or 1 (bf16 second layer)");
   CM3_REQUIRE(wt->w_self && wt->b_self && wt->w_self_h2 && wt->b_h2 && wt->w_out && wt->b_out, "missing weights");
   if (d->stage > 1) CM3_REQUIRE(wt->w_others && wt->b_others && wt->w_others_h2, "stage 2 needs the others branch");
   CM3_REQUIRE(b->obs_others && b->state && b->goals && b->meta && b->episode && b->actions, "missing buffers");
@@ -250,6 +291,7 @@ extern "C" int cm3_actor_particle_f32(const cm3_actor_particle_desc *d, const cm
   p.E = d->n_envs;
   p.stage = d->stage;
   p.eps = d->epsilon;
+  p.bf16 = d->precision == 1 ? 1 : 0;
   p.env_id_base = d->env_id_base;
   p.seed = d->seed;
   p.obs_others = (const float *)b->obs_others;

@@ -250,6 +250,10 @@ typedef struct cm3_actor_particle_desc {
   int32_t stage;       /* 1: self branch only; 2: + others branch */
   int32_t n_h1_self, n_h1_others, n_h2, n_actions; /* 64, 128, 64, 5 */
   float epsilon;
+  int32_t precision;   /* 0: float32 throughout (parity path; exact-f32 MFMA).  1: second layer on the bf16 matrix
+                          cores with float32 accumulation (activations and W2 rounded to bf16; probabilities move by
+                          up to ~1e-2) */
+  int32_t _pad;
   int64_t env_id_base;
   uint64_t seed;
 } cm3_actor_particle_desc;

@@ -126,3 +126,26 @@ def test_replay_buffers_take_device_rollouts():
     dual.add(cols, (env.collisions != 0)[ee])                          # train_onpolicy.py:356
     assert len(dual.mem1) + len(dual.mem2) == tt.numel()
     ro.close()
+
+
+@pytest.mark.parametrize("N,cfg", [(4, "particle_stage2_antipodal.json"), (8, "particle_merge8.json")])
+def test_bf16_second_layer_is_close_to_float32(N, cfg):
+    """Opt-in precision="bf16": same actor with the 192->64 layer on the bf16 matrix cores.  Not the parity path --
+    probabilities must stay close to the float32 oracle (max 0.1, mean 5e-3 with deliberately large test weights) and the sampled actions agree except near CDF edges."""
+    from cm3_amd.actor import ParticleActor
+    E, seed = 2000, 11
+    w = AO.init_weights(np.random.default_rng(5), N)
+    env = _env(E, N, cfg, seed=seed)
+    env.reset()
+    env.step()
+    a32, p32 = ParticleActor(w, N, device="cuda:0", seed=seed).act(env, 0.1, return_probs=True)
+    a16, p16 = ParticleActor(w, N, device="cuda:0", seed=seed, precision="bf16").act(env, 0.1, return_probs=True)
+    gs, oo = env.get_obs()
+    rows = E * N
+    want = AO.mixed_probs(AO.actor_probs(w, oo.reshape(rows, -1).cpu().numpy(), gs.reshape(rows, 4).cpu().numpy(),
+                                         env.goals.reshape(rows, 2).cpu().numpy()), 0.1)
+    diff = np.abs(p16.reshape(rows, 5).cpu().numpy() - want)
+    # really different arithmetic (test weights are 50x the reference's initial scale, so logits are large), but close
+    assert 1e-6 < diff.max() < 0.1 and diff.mean() < 5e-3, (diff.max(), diff.mean())
+    assert np.abs(p16.sum(-1).cpu().numpy() - 1).max() < 1e-5
+    assert float((a32 == a16).float().mean()) > 0.97
