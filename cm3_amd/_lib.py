@@ -88,7 +88,7 @@ class ActorParticleDesc(ctypes.Structure):
 
 class ActorParticleWeights(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in ("w_self", "b_self", "w_self_h2", "w_others", "b_others", "w_others_h2",
-                                        "b_h2", "w_out", "b_out")]
+                                        "b_h2", "w_out", "b_out", "packed")]
 
 
 class ActorParticleBufs(ctypes.Structure):
@@ -113,6 +113,8 @@ SYMBOLS = {
     "cm3_checkers_step": (ctypes.c_int, [P(CheckersDesc), P(CheckersBufs), c_void_p]),
     "cm3_checkers_rollout": (ctypes.c_int, [P(CheckersDesc), P(CheckersTraj), c_int32, c_void_p]),
     "cm3_checkers_reset": (ctypes.c_int, [P(CheckersDesc), P(CheckersBufs), c_void_p, c_void_p]),
+    "cm3_actor_particle_packed_bytes": (c_size_t, [c_int32]),
+    "cm3_actor_particle_pack": (ctypes.c_int, [P(ActorParticleDesc), P(ActorParticleWeights), c_void_p, c_void_p]),
     "cm3_actor_particle_f32": (ctypes.c_int, [P(ActorParticleDesc), P(ActorParticleWeights), P(ActorParticleBufs),
                                               c_void_p]),
     "cm3_returns_scratch_bytes": (c_size_t, []),

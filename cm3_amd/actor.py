@@ -67,6 +67,16 @@ class ParticleActor(object):
         for short in _NAMES:
             setattr(self._wt, short, _lib.ptr(self.w.get(short)))
         self._lib = _lib.lib()
+        nbytes = self._lib.cm3_actor_particle_packed_bytes(self.n)
+        self._packed = torch.zeros(nbytes // 4, dtype=torch.float32, device=self.device)
+        self._wt.packed = self._packed.data_ptr()
+        self.repack()
+
+    def repack(self):
+        """Re-arrange the (possibly updated in place) TF-shaped weights into the forward kernel's layout."""
+        d = self._desc(1, 0.0, 0)
+        _lib.check(self._lib.cm3_actor_particle_pack(ctypes.byref(d), ctypes.byref(self._wt), self._packed.data_ptr(),
+                                                     _lib.current_stream_handle(self.device)))
 
     def _desc(self, n_envs, epsilon, env_id_base):
         d = _lib.ActorParticleDesc()

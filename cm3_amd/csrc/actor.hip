@@ -33,24 +33,89 @@ struct ActorParams {
   const int32_t *meta, *episode;
   int32_t *actions;
   float *probs;
-  const float *w_self, *b_self, *w_self_h2, *w_oth, *b_oth, *w_oth_h2, *b_h2, *w_out, *b_out;
+  const float *w_self, *b_self, *w_self_h2, *w_oth, *b_oth, *w_oth_h2, *b_h2, *w_out, *b_out;  // pack kernel only
+  const float *packed;  // kernel-layout weights (PackLayout), written by k_actor_pack
 };
+
+// Kernel-layout weight buffer (floats), produced once per weight update by cm3_actor_particle_pack so that the forward
+// kernel fills its LDS tables with straight 16-byte copies and loads its W2 slice with 12 (f32) or 6 (bf16) vector loads
+// per lane instead of ~65 scalar loads and a bank-conflicted in-kernel transpose (8k cycles -> see DESIGN.md).
+template <int N> struct PackLayout {
+  static constexpr int L = 4 * (N > 1 ? N - 1 : 1);
+  static constexpr int SW = 8, OW = L + 4, KU = kH1S + kH1O;
+  static constexpr int kSelf = 0;                       // [64][8]   unit-major: 6 weights, bias, pad
+  static constexpr int kOth = kSelf + kH1S * SW;         // [128][OW] unit-major: L weights, bias, pad
+  static constexpr int kOut = kOth + kH1O * OW;          // [64*5] w_out, [5] b_out, pad to 328
+  static constexpr int kOutSize = 328;
+  static constexpr int kTables = kOut + kOutSize;        // everything above is copied to LDS verbatim
+  static constexpr int kBh2 = kTables;                   // [64]
+  static constexpr int kW2f = kBh2 + kH2;                // [4 waves][64 lanes][48 k-steps] f32 B operands
+  static constexpr int kW2b = kW2f + 4 * 64 * (KU / 4);  // [4][64][6][8] bf16 B operands (stored in float slots)
+  static constexpr int kTotal = kW2b + 4 * 64 * (KU / 4) / 2;
+};
+
+template <int N> __global__ void __launch_bounds__(256) k_actor_pack(const ActorParams p, float *out) {
+  using PL = PackLayout<N>;
+  const bool stage2 = p.stage > 1;
+  for (int t = blockIdx.x * 256 + threadIdx.x; t < PL::kTotal; t += gridDim.x * 256) {
+    float v = 0.0f;
+    if (t < PL::kOth) {
+      const int k = t / PL::SW, in = t - k * PL::SW;
+      v = in < 6 ? p.w_self[in * kH1S + k] : (in == 6 ? p.b_self[k] : 0.0f);
+    } else if (t < PL::kOut) {
+      const int u = t - PL::kOth, k = u / PL::OW, in = u - k * PL::OW;
+      if (stage2) v = in < PL::L ? p.w_oth[in * kH1O + k] : (in == PL::L ? p.b_oth[k] : 0.0f);
+    } else if (t < PL::kTables) {
+      const int u = t - PL::kOut;
+      v = u < kH2 * kA ? p.w_out[u] : (u < kH2 * kA + kA ? p.b_out[u - kH2 * kA] : 0.0f);
+    } else if (t < PL::kW2f) {
+      v = p.b_h2[t - PL::kBh2];
+    } else if (t < PL::kW2b) {
+      const int u = t - PL::kW2f, s = u % (PL::KU / 4), lane = (u / (PL::KU / 4)) & 63, w = u / (PL::KU / 4) / 64;
+      const int k = 4 * s + (lane >> 4), j = 16 * w + (lane & 15);  // B[k = l>>4][j = l&15] of k-step s
+      v = k < kH1S ? p.w_self_h2[k * kH2 + j] : (stage2 ? p.w_oth_h2[(k - kH1S) * kH2 + j] : 0.0f);
+    } else {
+      // two bf16 per float slot: element index eidx = 2 (t - kW2b) + {0,1} in [w][lane][s(6)][q(8)]
+      __bf16 pair[2];
+      for (int h = 0; h < 2; ++h) {
+        const int eidx = 2 * (t - PL::kW2b) + h;
+        const int q = eidx & 7, s = (eidx >> 3) % (PL::KU / 32), lane = ((eidx >> 3) / (PL::KU / 32)) & 63;
+        const int w = (eidx >> 3) / (PL::KU / 32) / 64;
+        const int k = 32 * s + 8 * (lane >> 4) + q, j = 16 * w + (lane & 15);
+        const float wv = k < kH1S ? p.w_self_h2[k * kH2 + j] : (stage2 ? p.w_oth_h2[(k - kH1S) * kH2 + j] : 0.0f);
+        pair[h] = (__bf16)wv;
+      }
+      __builtin_memcpy(&v, pair, 4);
+    }
+    out[t] = v;
+  }
+}
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// Final layer for one row per lane (wave 0 of the workgroup): actor_out + softmax (networks.py:536-537),
-// epsilon mix (alg_credit.py:119) and inverse-CDF sampling (:120) from the build's Philox stream.
+// Final layer, all four waves: wave w finishes rows [16w, 16w+16).  Lane l takes row 16w + (l&15) and a quarter of
+// the 64 second-layer units (part = l>>4): 16 x 5 FMAs, then the four partial logit vectors are summed across the
+// parts with two xor-shuffles (same order in every lane, so all four copies are identical).  actor_out + softmax
+// (networks.py:536-537), epsilon mix (alg_credit.py:119) and inverse-CDF sampling (:120) from the Philox stream.
 template <int N>
-__device__ __forceinline__ void actor_head(const ActorParams &p, const float (*h2s)[kH2 + 1], int lane, size_t r,
-                                           bool row_ok, size_t e, int i) {
+__device__ __forceinline__ void actor_head(const ActorParams &p, const float (*h2s)[kH2 + 1], const float *wout, int w,
+                                           int lane, size_t row_base, size_t rows, int steps, uint32_t episode) {
+  const int rl = 16 * w + (lane & 15), part = lane >> 4;
   float o[kA];
 #pragma unroll
-  for (int a = 0; a < kA; ++a) o[a] = p.b_out[a];
-#pragma unroll 4
-  for (int k = 0; k < kH2; ++k) {
-    const float hk = h2s[lane][k];
+  for (int a = 0; a < kA; ++a) o[a] = 0.0f;
 #pragma unroll
-    for (int a = 0; a < kA; ++a) o[a] = fmaf(hk, p.w_out[k * kA + a], o[a]);
+  for (int kk = 0; kk < kH2 / 4; ++kk) {
+    const int k = 16 * part + kk;
+    const float hk = h2s[rl][k];
+#pragma unroll
+    for (int a = 0; a < kA; ++a) o[a] = fmaf(hk, wout[k * kA + a], o[a]);
+  }
+#pragma unroll
+  for (int a = 0; a < kA; ++a) {
+    o[a] += __shfl_xor(o[a], 16, 64);
+    o[a] += __shfl_xor(o[a], 32, 64);
+    o[a] += wout[kH2 * kA + a];  // bias
   }
   float m = o[0];
 #pragma unroll
@@ -62,11 +127,15 @@ __device__ __forceinline__ void actor_head(const ActorParams &p, const float (*h
     sum += o[a];
   }
   float pr[kA];
+  const float inv = 1.0f / sum;
 #pragma unroll
-  for (int a = 0; a < kA; ++a) pr[a] = (1.0f - p.eps) * (o[a] / sum) + p.eps / (float)kA;
+  for (int a = 0; a < kA; ++a) pr[a] = (1.0f - p.eps) * (o[a] * inv) + p.eps / (float)kA;
 
-  const int steps = p.meta[2 * e];
-  const uint32_t episode = (uint32_t)p.episode[e];
+  const size_t r = row_base + rl;
+  const bool row_ok = r < rows && part == 0;
+  const size_t rc = r < rows ? r : rows - 1;
+  const size_t e = rc / N;
+  const int i = (int)(rc - e * N);
   const uint64_t genv = (uint64_t)(p.env_id_base + (int64_t)e);
   u32x4 ctr;
   ctr.x = (uint32_t)genv;
@@ -97,14 +166,14 @@ __device__ __forceinline__ void actor_head(const ActorParams &p, const float (*h
 }
 
 // Workgroup = 4 waves = 64 rows.
-//   Phase A (VALU, one row per lane): wave w evaluates a quarter of the first-layer units -- 16 of branch_self and
-//     32 of actor_others -- for all 64 rows; the unit weights are uniform across lanes and come from a transposed
-//     LDS copy as broadcast reads.  Results go to LDS h1s[row][unit] (unit index = k of the second layer).
+//   Phase A (matrix cores): wave w evaluates a quarter of the first-layer units -- 16 of branch_self and 32 of
+//     actor_others -- for all 64 rows (K = 6 -> 8 and K = L); results go to LDS h1s[row][unit] (unit = k of layer 2).
+//     (A VALU version with one row per lane and broadcast weight reads took 7.0k cycles; this one ~2k.)
 //   Phase B (matrix cores): wave w owns columns [16w, 16w+16) of the 192 -> 64 second layer,
 //     v_mfma_f32_16x16x4_f32 (exact f32, k-ordered fma chain), 4 row tiles x 48 k-steps:
 //       A[i = l&15][k = l>>4]  = h1s[16t + (l&15)][4s + (l>>4)]        one ds_read_b32 per MFMA
 //       B[k = l>>4][j = l&15]  = W2[4s + (l>>4)][16w + (l&15)]         48 VGPRs per lane, loaded once
-//       C  col = l&15, row = 4 (l>>4) + reg  -> relu(C + b) to LDS h2s, where wave 0 picks up whole rows.
+//       C  col = l&15, row = 4 (l>>4) + reg  -> relu(C + b) to LDS h2s; each wave then finishes 16 whole rows.
 //   (A version that evaluated the first layer directly in the A-operand layout needed no h1s but recomputed it in
 //    all four waves: 2750 VALU instructions per wave, 14.5 us per workgroup -- PMC run in profiles/.)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -121,12 +190,19 @@ template <int N, bool BF16> __global__ void __launch_bounds__(256) k_actor_parti
   constexpr int OW = L + 4;              // ws_oth row: L weights, bias, pad (multiple of 4 floats)
   constexpr int KU = kH1S + kH1O;        // 192 first-layer units = K of the second layer
   constexpr int HB = KU + 8;             // bf16 row: 200 halfwords = 400 B (16-byte aligned rows)
-  __shared__ __attribute__((aligned(16))) float ws_self[kH1S][SW];
-  __shared__ __attribute__((aligned(16))) float ws_oth[kH1O][OW];
+  using PL = PackLayout<N>;
+  __shared__ __attribute__((aligned(16))) float tables[PL::kTables];       // packed prefix, verbatim
+  float (*ws_self)[SW] = reinterpret_cast<float (*)[SW]>(&tables[PL::kSelf]);
+  float (*ws_oth)[OW] = reinterpret_cast<float (*)[OW]>(&tables[PL::kOth]);
+  const float *wout_s = &tables[PL::kOut];
   __shared__ __attribute__((aligned(16))) float h1raw[BF16 ? (64 * HB) / 2 : 64 * (KU + 1)];
   float (*h1s)[KU + 1] = reinterpret_cast<float (*)[KU + 1]>(h1raw);       // f32 view  [64][193]
   __bf16 (*h1b)[HB] = reinterpret_cast<__bf16 (*)[HB]>(h1raw);             // bf16 view [64][200]
-  __shared__ float h2s[64][kH2 + 1];
+  // h2 [64][65] reuses the h1 storage once every wave is done reading h1 (extra barrier below): keeps the workgroup
+  // at 66 KB of LDS (f32) / 42 KB (bf16) so that two workgroups fit a CU
+  float (*h2s)[kH2 + 1] = reinterpret_cast<float (*)[kH2 + 1]>(h1raw);
+  static_assert(64 * (kH2 + 1) <= (BF16 ? (64 * HB) / 2 : 64 * (KU + 1)), "h2 must fit into the h1 storage");
+  __shared__ float xs[64][6 + L + 1];  // input tile, odd row stride (conflict-free column reads)
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col = lane & 15, hi = lane >> 4;
@@ -134,19 +210,23 @@ template <int N, bool BF16> __global__ void __launch_bounds__(256) k_actor_parti
   const size_t rows = (size_t)p.E * N;
   const size_t row_base = (size_t)blockIdx.x * 64;
   const bool stage2 = p.stage > 1;
+  CM3_STAMP(0, false);
 
-  // ---- first-layer weights -> LDS, transposed to [unit][input] --------------------------------------------------
-  for (int idx = tid; idx < 6 * kH1S; idx += 256) ws_self[idx % kH1S][idx / kH1S] = p.w_self[idx];
-  for (int k = tid; k < kH1S; k += 256) {
-    ws_self[k][6] = p.b_self[k];
-    ws_self[k][7] = 0.0f;
+  // RNG key of the row this lane finishes in the head (row 16w + (l&15)): fetched now, used ~20k cycles later
+  int head_steps;
+  uint32_t head_episode;
+  {
+    size_t hr = row_base + 16 * w + col;
+    hr = hr < rows ? hr : rows - 1;
+    const size_t he = hr / N;
+    head_steps = p.meta[2 * he];
+    head_episode = (uint32_t)p.episode[he];
   }
-  if (stage2) {
-    for (int idx = tid; idx < L * kH1O; idx += 256) ws_oth[idx % kH1O][idx / kH1O] = p.w_oth[idx];
-    for (int k = tid; k < kH1O; k += 256) {
-      ws_oth[k][L] = p.b_oth[k];
-      ws_oth[k][L + 1] = ws_oth[k][L + 2] = ws_oth[k][L + 3] = 0.0f;
-    }
+  // ---- first-layer tables + output layer -> LDS: straight 16-byte copies of the packed prefix -------------------------
+  {
+    const float4 *src = reinterpret_cast<const float4 *>(p.packed);
+    float4 *dst = reinterpret_cast<float4 *>(tables);
+    for (int t = tid; t < PL::kTables / 4; t += 256) dst[t] = src[t];
   }
   // ---- this lane's row: concat(v_obs, v_goal) and obs_others -----------------------------------------------------------
   const size_t r = row_base + lane;
@@ -154,76 +234,95 @@ template <int N, bool BF16> __global__ void __launch_bounds__(256) k_actor_parti
   const size_t rc = row_ok ? r : rows - 1;
   const size_t e = rc / N;
   const int i = (int)(rc - e * N);
-  float x[6], xo[L];
-  {
+  if (w == 0) {  // wave 0 stages the 64 input rows [v_obs(4) | v_goal(2) | obs_others(L)] into LDS, one row per lane
     const float4 s = reinterpret_cast<const float4 *>(p.state)[(size_t)i * p.E + e];
     const float2 g = reinterpret_cast<const float2 *>(p.goals)[(size_t)i * p.E + e];
-    x[0] = s.x; x[1] = s.y; x[2] = s.z; x[3] = s.w; x[4] = g.x; x[5] = g.y;
+    xs[lane][0] = s.x; xs[lane][1] = s.y; xs[lane][2] = s.z; xs[lane][3] = s.w; xs[lane][4] = g.x; xs[lane][5] = g.y;
     const float4 *o4 = reinterpret_cast<const float4 *>(p.obs_others + rc * L);
 #pragma unroll
     for (int k = 0; k < L / 4; ++k) {
       const float4 v = o4[k];
-      xo[4 * k + 0] = v.x; xo[4 * k + 1] = v.y; xo[4 * k + 2] = v.z; xo[4 * k + 3] = v.w;
+      xs[lane][6 + 4 * k + 0] = v.x; xs[lane][6 + 4 * k + 1] = v.y; xs[lane][6 + 4 * k + 2] = v.z; xs[lane][6 + 4 * k + 3] = v.w;
     }
   }
   // ---- B: this wave's slice of W2 = [W_branch_self_h2 ; W_others_h2], unit k = 4s + hi, column c0 + col --------------
   float bw[BF16 ? 1 : KU / 4];
   bf16x8 bwb[BF16 ? KU / 32 : 1];
   if constexpr (BF16) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(p.packed + PL::kW2b) + (size_t)(w * 64 + lane) * (KU / 32);
 #pragma unroll
-    for (int s = 0; s < KU / 32; ++s)
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int k = 32 * s + 8 * hi + q;  // unit index in [W_branch_self_h2 ; W_others_h2]
-        const float wv = k < kH1S ? p.w_self_h2[k * kH2 + c0 + col]
-                                  : (stage2 ? p.w_oth_h2[(k - kH1S) * kH2 + c0 + col] : 0.0f);
-        bwb[s][q] = (__bf16)wv;
-      }
+    for (int s = 0; s < KU / 32; ++s) {
+      const uint4 v = src[s];
+      __builtin_memcpy(&bwb[s], &v, 16);
+    }
   } else {
+    const float4 *src = reinterpret_cast<const float4 *>(p.packed + PL::kW2f) + (size_t)(w * 64 + lane) * (KU / 16);
 #pragma unroll
-    for (int s = 0; s < kH1S / 4; ++s) bw[s] = p.w_self_h2[(4 * s + hi) * kH2 + c0 + col];
-#pragma unroll
-    for (int s = 0; s < kH1O / 4; ++s) bw[kH1S / 4 + s] = stage2 ? p.w_oth_h2[(4 * s + hi) * kH2 + c0 + col] : 0.0f;
+    for (int s4 = 0; s4 < KU / 16; ++s4) {
+      const float4 v = src[s4];
+      bw[4 * s4 + 0] = v.x; bw[4 * s4 + 1] = v.y; bw[4 * s4 + 2] = v.z; bw[4 * s4 + 3] = v.w;
+    }
   }
+  const float bias_h2 = p.packed[PL::kBh2 + c0 + col];
+  CM3_STAMP(1, true);
   __syncthreads();
+  CM3_STAMP(2, false);
 
-  // ---- phase A: dense(6 -> 64, relu) units [16w, 16w+16) and dense(L -> 128, relu) units [32w, 32w+32) ---------------
-#pragma unroll 4
-  for (int q = 0; q < kH1S / 4; ++q) {  // networks.py:520-521
-    const int k = 16 * w + q;
-    const float4 wa = *reinterpret_cast<const float4 *>(&ws_self[k][0]);
-    const float4 wb = *reinterpret_cast<const float4 *>(&ws_self[k][4]);
-    float a = wb.z;  // bias
-    a = fmaf(x[0], wa.x, a);
-    a = fmaf(x[1], wa.y, a);
-    a = fmaf(x[2], wa.z, a);
-    a = fmaf(x[3], wa.w, a);
-    a = fmaf(x[4], wb.x, a);
-    a = fmaf(x[5], wb.y, a);
-    if constexpr (BF16) h1b[lane][k] = (__bf16)fmaxf(a, 0.0f); else h1s[lane][k] = fmaxf(a, 0.0f);
-  }
-  if (stage2) {
-#pragma unroll 4
-    for (int q = 0; q < kH1O / 4; ++q) {  // networks.py:527-529
-      const int k = 32 * w + q;
-      float wv[OW];
+  // ---- phase A on the matrix cores too: dense(6 -> 64) units [16w, 16w+16) and dense(L -> 128) units [32w, 32w+32) for
+  // all 64 rows (networks.py:520-521, :527-529).  A[i = l&15][k = l>>4] = input k of row 16t + (l&15) (from the xs tile),
+  // B[k = l>>4][j = l&15] = weight of input k for unit j (from the unit-major LDS tables); bias + relu are applied to the
+  // C tile (col = unit, row = 4 (l>>4) + reg) on its way into h1.
+  {
+    float ax[4][2], ao[4][L / 4];
 #pragma unroll
-      for (int c = 0; c < OW / 4; ++c) {
-        const float4 v = *reinterpret_cast<const float4 *>(&ws_oth[k][4 * c]);
-        wv[4 * c + 0] = v.x; wv[4 * c + 1] = v.y; wv[4 * c + 2] = v.z; wv[4 * c + 3] = v.w;
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) ax[t][s] = (4 * s + hi < 6) ? xs[16 * t + col][4 * s + hi] : 0.0f;
+#pragma unroll
+      for (int s = 0; s < L / 4; ++s) ao[t][s] = xs[16 * t + col][6 + 4 * s + hi];
+    }
+    {  // branch_self
+      const int unit = 16 * w + col;
+      float bs[2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) bs[s] = (4 * s + hi < 6) ? ws_self[unit][4 * s + hi] : 0.0f;
+      const float bias = ws_self[unit][6];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        f32x4 c = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int s = 0; s < 2; ++s) c = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[t][s], bs[s], c, 0, 0, 0);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const float h = fmaxf(c[reg] + bias, 0.0f);
+          if constexpr (BF16) h1b[16 * t + 4 * hi + reg][unit] = (__bf16)h; else h1s[16 * t + 4 * hi + reg][unit] = h;
+        }
       }
-      float a = wv[L];  // bias
-#pragma unroll
-      for (int c = 0; c < L; ++c) a = fmaf(xo[c], wv[c], a);
-      if constexpr (BF16) h1b[lane][kH1S + k] = (__bf16)fmaxf(a, 0.0f); else h1s[lane][kH1S + k] = fmaxf(a, 0.0f);
     }
-  } else {
-#pragma unroll 4
-    for (int q = 0; q < kH1O / 4; ++q) {
-      if constexpr (BF16) h1b[lane][kH1S + 32 * w + q] = (__bf16)0.0f; else h1s[lane][kH1S + 32 * w + q] = 0.0f;
+#pragma unroll
+    for (int cq = 0; cq < 2; ++cq) {  // actor_others: two 16-unit column tiles
+      const int unit = 32 * w + 16 * cq + col;
+      float bo[L / 4];
+#pragma unroll
+      for (int s = 0; s < L / 4; ++s) bo[s] = stage2 ? ws_oth[unit][4 * s + hi] : 0.0f;
+      const float bias = stage2 ? ws_oth[unit][L] : 0.0f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        f32x4 c = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int s = 0; s < L / 4; ++s) c = __builtin_amdgcn_mfma_f32_16x16x4f32(ao[t][s], bo[s], c, 0, 0, 0);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const float h = fmaxf(c[reg] + bias, 0.0f);   // stage 1: exactly 0, the others branch is absent
+          if constexpr (BF16) h1b[16 * t + 4 * hi + reg][kH1S + unit] = (__bf16)h;
+          else h1s[16 * t + 4 * hi + reg][kH1S + unit] = h;
+        }
+      }
     }
   }
+  CM3_STAMP(3, true);
   __syncthreads();
+  CM3_STAMP(4, false);
 
   // ---- phase B: second layer on the matrix cores (networks.py:522-531: both matmuls, add_n) ---------------------------------
   f32x4 acc[4];
@@ -246,17 +345,20 @@ template <int N, bool BF16> __global__ void __launch_bounds__(256) k_actor_parti
         acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(h1s[16 * t + col][4 * s + hi], bw[s], acc[t], 0, 0, 0);
     }
   }
+  CM3_STAMP(5, true);
+  __syncthreads();  // all waves have consumed h1: its storage becomes h2
   // ---- h2 = relu(add_n + b) (networks.py:533-534): C tile -> LDS rows ---------------------------------------------------
   {
-    const float bias = p.b_h2[c0 + col];
+    const float bias = bias_h2;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) h2s[16 * t + 4 * hi + reg][c0 + col] = fmaxf(acc[t][reg] + bias, 0.0f);
   }
   __syncthreads();
-  if (w != 0) return;
-  actor_head<N>(p, h2s, lane, r, row_ok, e, i);
+  CM3_STAMP(6, false);
+  actor_head<N>(p, h2s, wout_s, w, lane, row_base, rows, head_steps, head_episode);
+  CM3_STAMP(7, true);
 }
 
 template <int N> static int actor_launch(const ActorParams &p, hipStream_t s) {
@@ -272,6 +374,68 @@ template <int N> static int actor_launch(const ActorParams &p, hipStream_t s) {
 
 }  // namespace cm3
 
+namespace cm3 {
+static int actor_check_desc(const cm3_actor_particle_desc *d) {
+  CM3_REQUIRE(d, "null desc");
+  CM3_REQUIRE(d->n_agents >= 1 && d->n_agents <= CM3_MAX_AGENTS, "n_agents must be in 1..%d", CM3_MAX_AGENTS);
+  CM3_REQUIRE(d->n_h1_self == kH1S && d->n_h1_others == kH1O && d->n_h2 == kH2 && d->n_actions == kA,
+              "supported actor widths are 64/128/64/5 (config.json nn block); got %d/%d/%d/%d", d->n_h1_self,
+              d->n_h1_others, d->n_h2, d->n_actions);
+  return CM3_OK;
+}
+template <int N> static size_t packed_floats() { return (size_t)PackLayout<N>::kTotal; }
+static size_t packed_floats_for(int n) {
+  switch (n) {
+    case 1: return packed_floats<1>();
+    case 2: return packed_floats<2>();
+    case 3: return packed_floats<3>();
+    case 4: return packed_floats<4>();
+    case 5: return packed_floats<5>();
+    case 6: return packed_floats<6>();
+    case 7: return packed_floats<7>();
+    case 8: return packed_floats<8>();
+  }
+  return 0;
+}
+template <int N> static int pack_launch(const ActorParams &p, float *out, hipStream_t s) {
+  hipLaunchKernelGGL((k_actor_pack<N>), dim3(32), dim3(256), 0, s, p, out);
+  CM3_HIP_CHECK(hipGetLastError());
+  return CM3_OK;
+}
+}  // namespace cm3
+
+extern "C" size_t cm3_actor_particle_packed_bytes(int32_t n_agents) {
+  return cm3::packed_floats_for(n_agents) * sizeof(float);
+}
+
+extern "C" int cm3_actor_particle_pack(const cm3_actor_particle_desc *d, const cm3_actor_particle_weights *wt,
+                                       void *packed, void *stream) {
+  using namespace cm3;
+  int rc = actor_check_desc(d);
+  if (rc != CM3_OK) return rc;
+  CM3_REQUIRE(wt && packed, "null weights / packed buffer");
+  CM3_REQUIRE(wt->w_self && wt->b_self && wt->w_self_h2 && wt->b_h2 && wt->w_out && wt->b_out, "missing weights");
+  if (d->stage > 1) CM3_REQUIRE(wt->w_others && wt->b_others && wt->w_others_h2, "stage 2 needs the others branch");
+  ActorParams p;
+  memset(&p, 0, sizeof(p));
+  p.stage = d->stage;
+  p.w_self = wt->w_self; p.b_self = wt->b_self; p.w_self_h2 = wt->w_self_h2;
+  p.w_oth = wt->w_others; p.b_oth = wt->b_others; p.w_oth_h2 = wt->w_others_h2;
+  p.b_h2 = wt->b_h2; p.w_out = wt->w_out; p.b_out = wt->b_out;
+  hipStream_t s = (hipStream_t)stream;
+  switch (d->n_agents) {
+    case 1: return pack_launch<1>(p, (float *)packed, s);
+    case 2: return pack_launch<2>(p, (float *)packed, s);
+    case 3: return pack_launch<3>(p, (float *)packed, s);
+    case 4: return pack_launch<4>(p, (float *)packed, s);
+    case 5: return pack_launch<5>(p, (float *)packed, s);
+    case 6: return pack_launch<6>(p, (float *)packed, s);
+    case 7: return pack_launch<7>(p, (float *)packed, s);
+    case 8: return pack_launch<8>(p, (float *)packed, s);
+  }
+  return fail(CM3_ERR_INVALID, "n_agents %d unsupported", d->n_agents);
+}
+
 extern "C" int cm3_actor_particle_f32(const cm3_actor_particle_desc *d, const cm3_actor_particle_weights *wt,
                                       const cm3_actor_particle_bufs *b, void *stream) {
   using namespace cm3;
@@ -283,8 +447,7 @@ extern "C" int cm3_actor_particle_f32(const cm3_actor_particle_desc *d, const cm
               d->n_h1_others, d->n_h2, d->n_actions);
   CM3_REQUIRE(d->epsilon >= 0.0f && d->epsilon <= 1.0f, "epsilon must be in [0,1]");
   CM3_REQUIRE(d->precision == 0 || d->precision == 1, "precision must be 0 (float32) or 1 (bf16 second layer)");
-  CM3_REQUIRE(wt->w_self && wt->b_self && wt->w_self_h2 && wt->b_h2 && wt->w_out && wt->b_out, "missing weights");
-  if (d->stage > 1) CM3_REQUIRE(wt->w_others && wt->b_others && wt->w_others_h2, "stage 2 needs the others branch");
+  CM3_REQUIRE(wt->packed, "weights->packed is NULL: run cm3_actor_particle_pack once per weight update");
   CM3_REQUIRE(b->obs_others && b->state && b->goals && b->meta && b->episode && b->actions, "missing buffers");
   ActorParams p;
   memset(&p, 0, sizeof(p));
@@ -301,9 +464,7 @@ extern "C" int cm3_actor_particle_f32(const cm3_actor_particle_desc *d, const cm
   p.episode = b->episode;
   p.actions = b->actions;
   p.probs = b->probs;
-  p.w_self = wt->w_self; p.b_self = wt->b_self; p.w_self_h2 = wt->w_self_h2;
-  p.w_oth = wt->w_others; p.b_oth = wt->b_others; p.w_oth_h2 = wt->w_others_h2;
-  p.b_h2 = wt->b_h2; p.w_out = wt->w_out; p.b_out = wt->b_out;
+  p.packed = (const float *)wt->packed;
   hipStream_t s = (hipStream_t)stream;
   switch (d->n_agents) {
     case 1: return actor_launch<1>(p, s);

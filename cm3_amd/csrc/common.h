@@ -7,6 +7,24 @@
 
 #include "../../include/cm3_amd.h"
 
+// Timeline instrumentation for the diagnostic probes under tools/probes only (never defined in the product build).
+#ifdef CM3_STAMPS
+extern __device__ long long *cm3_stamp_buf;
+#define CM3_STAMP(slot, drain)                                                                        \
+  do {                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    if (drain) __builtin_amdgcn_s_waitcnt(0);                                                         \
+    const long long _t = clock64();                                                                   \
+    if ((threadIdx.x & 63) == 0)                                                                      \
+      cm3_stamp_buf[((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + (slot)] = _t; \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+  } while (0)
+#else
+#define CM3_STAMP(slot, drain) \
+  do {                         \
+  } while (0)
+#endif
+
 namespace cm3 {
 
 // ---- error plumbing ------------------------------------------------------------------------

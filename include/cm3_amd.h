@@ -260,6 +260,8 @@ typedef struct cm3_actor_particle_desc {
 
 typedef struct cm3_actor_particle_weights {
   const float *w_self, *b_self, *w_self_h2, *w_others, *b_others, *w_others_h2, *b_h2, *w_out, *b_out;
+  const void *packed; /* kernel-layout copy written by cm3_actor_particle_pack (cm3_actor_particle_packed_bytes()
+                         bytes); the forward launch reads ONLY this buffer, re-pack after every weight update */
 } cm3_actor_particle_weights;
 
 typedef struct cm3_actor_particle_bufs {
@@ -272,6 +274,11 @@ typedef struct cm3_actor_particle_bufs {
   float *probs; /* optional */
 } cm3_actor_particle_bufs;
 
+size_t cm3_actor_particle_packed_bytes(int32_t n_agents);
+/* Re-arranges the TensorFlow-shaped weights into the forward kernel's layout (unit-major first-layer tables, per-lane
+ * MFMA B operands in f32 and bf16) -- one small launch per weight update; only desc->n_agents / stage are read. */
+int cm3_actor_particle_pack(const cm3_actor_particle_desc *desc, const cm3_actor_particle_weights *weights,
+                            void *packed, void *stream);
 int cm3_actor_particle_f32(const cm3_actor_particle_desc *desc, const cm3_actor_particle_weights *weights,
                            const cm3_actor_particle_bufs *bufs, void *stream);
 

@@ -41,7 +41,7 @@ def test_struct_sizes_match_header(built):
     assert ctypes.sizeof(built.CheckersDesc) == 10 * 4 + 8 + 8 + 2 * 8 * 4
     assert ctypes.sizeof(built.CheckersBufs) == 14 * 8
     assert ctypes.sizeof(built.ActorParticleDesc) == 10 * 4 + 8 + 8
-    assert ctypes.sizeof(built.ActorParticleWeights) == 9 * 8
+    assert ctypes.sizeof(built.ActorParticleWeights) == 10 * 8
     assert ctypes.sizeof(built.ActorParticleBufs) == 7 * 8
 
 
