@@ -92,14 +92,204 @@ template <int N> __global__ void __launch_bounds__(256) k_actor_pack(const Actor
 }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// Final layer, all four waves: wave w finishes rows [16w, 16w+16).  Lane l takes row 16w + (l&15) and a quarter of
-// the 64 second-layer units (part = l>>4): 16 x 5 FMAs, then the four partial logit vectors are summed across the
-// parts with two xor-shuffles (same order in every lane, so all four copies are identical).  actor_out + softmax
-// (networks.py:536-537), epsilon mix (alg_credit.py:119) and inverse-CDF sampling (:120) from the Philox stream.
-template <int N>
-__device__ __forceinline__ void actor_head(const ActorParams &p, const float (*h2s)[kH2 + 1], const float *wout, int w,
-                                           int lane, size_t row_base, size_t rows, int steps, uint32_t episode) {
+// ---- building blocks shared by k_actor_particle (one tick) and k_policy_rollout (policy.hip: a whole policy-driven
+// episode in one launch).  A workgroup = 4 waves (one per SIMD of a CU) = 64 agent rows (row r = e*N + i).
+//   Phase A (matrix cores): wave w evaluates a quarter of the first-layer units -- 16 of branch_self and 32 of
+//     actor_others -- for all 64 rows (K = 6 -> 8 and K = L); bias + relu on the C tile; results go to LDS h1[row][unit]
+//     (unit = k of layer 2).  A[i = l&15][k = l>>4] = input k of row 16t + (l&15) from the xs tile,
+//     B[k = l>>4][j = l&15] = weight of input k for unit j from the unit-major LDS tables.
+//     (A VALU version with one row per lane and broadcast weight reads took 7.0k cycles; this one 3.7k.)
+//   Phase B (matrix cores): wave w owns columns [16w, 16w+16) of the 192 -> 64 second layer,
+//     v_mfma_f32_16x16x4_f32 (exact f32, k-ordered fma chain), 4 row tiles x 48 k-steps:
+//       A[i = l&15][k = l>>4]  = h1s[16t + (l&15)][4s + (l>>4)]        one ds_read_b32 per MFMA
+//       B[k = l>>4][j = l&15]  = W2[4s + (l>>4)][16w + (l&15)]         48 VGPRs per lane, loaded once
+//       C  col = l&15, row = 4 (l>>4) + reg  -> relu(C + b) to LDS h2s; each wave then finishes 16 whole rows.
+//   BF16 == true (opt-in, cm3_actor_particle_desc.precision = 1): the first-layer activations are stored as bf16 and the
+//     second layer runs on v_mfma_f32_16x16x32_bf16 (f32 accumulate): 6 k-steps instead of 48, 16x the MFMA rate.
+//       A[i = l&15][k = 8 (l>>4) + q] = h1b[16t + (l&15)][32s + 8 (l>>4) + q],  q = 0..7   one ds_read_b128 per MFMA
+//       B[k = 8 (l>>4) + q][j = l&15] = bf16(W2[32s + 8 (l>>4) + q][16w + (l&15)])          24 VGPRs per lane
+//     Activations and W2 are rounded to bf16 (relative 2^-9): probabilities move by up to ~1e-2, so this is NOT the
+//     parity path; everything else (first layers, output layer, softmax, sampling) stays float32.
+//   History: weights streamed through SGPRs into VALU FMAs: 23 us per tick at 4096 envs x 4 agents; first layer
+//   evaluated directly in the A-operand layout in all four waves: 2750 VALU instructions per wave, 14.5 us (PMC runs in
+//   profiles/); this structure: 9.5 us.
+template <int N, bool BF16> struct ActorGeom {
+  static constexpr int L = 4 * (N > 1 ? N - 1 : 1);
+  static constexpr int SW = 8;            // ws_self row: 6 weights, bias, pad
+  static constexpr int OW = L + 4;        // ws_oth row: L weights, bias, pad (multiple of 4 floats)
+  static constexpr int KU = kH1S + kH1O;  // 192 first-layer units = K of the second layer
+  static constexpr int HB = KU + 8;       // bf16 row: 200 halfwords = 400 B (16-byte aligned rows)
+  static constexpr int XW = 6 + L + 1;    // input tile row: [v_obs(4) | v_goal(2) | obs_others(L)], odd stride
+  static constexpr int kH1Floats = BF16 ? (64 * HB) / 2 : 64 * (KU + 1);
+  static_assert(64 * (kH2 + 1) <= kH1Floats, "h2 must fit into the h1 storage");
+};
+
+// Views into the workgroup's LDS (declared by the kernel with CM3_ACTOR_LDS).  h2 reuses the h1 storage once every wave
+// is done reading h1, which keeps the workgroup at 66 KB (f32) / 42 KB (bf16) so that two workgroups fit a CU.
+template <int N, bool BF16> struct ActorLds {
+  using G = ActorGeom<N, BF16>;
+  float (*ws_self)[G::SW];
+  float (*ws_oth)[G::OW];
+  const float *wout;
+  float (*h1s)[G::KU + 1];
+  __bf16 (*h1b)[G::HB];
+  float (*h2s)[kH2 + 1];
+  float (*xs)[G::XW];
+  float *tables;
+};
+
+#define CM3_ACTOR_LDS(N_, BF16_, name)                                                                         \
+  __shared__ __attribute__((aligned(16))) float name##_tables[PackLayout<N_>::kTables];                        \
+  __shared__ __attribute__((aligned(16))) float name##_h1raw[ActorGeom<N_, BF16_>::kH1Floats];                 \
+  __shared__ float name##_xs[64][ActorGeom<N_, BF16_>::XW];                                                    \
+  ActorLds<N_, BF16_> name;                                                                                    \
+  name.tables = name##_tables;                                                                                 \
+  name.ws_self = reinterpret_cast<float (*)[ActorGeom<N_, BF16_>::SW]>(&name##_tables[PackLayout<N_>::kSelf]); \
+  name.ws_oth = reinterpret_cast<float (*)[ActorGeom<N_, BF16_>::OW]>(&name##_tables[PackLayout<N_>::kOth]);   \
+  name.wout = &name##_tables[PackLayout<N_>::kOut];                                                            \
+  name.h1s = reinterpret_cast<float (*)[ActorGeom<N_, BF16_>::KU + 1]>(name##_h1raw);                          \
+  name.h1b = reinterpret_cast<__bf16 (*)[ActorGeom<N_, BF16_>::HB]>(name##_h1raw);                             \
+  name.h2s = reinterpret_cast<float (*)[kH2 + 1]>(name##_h1raw);                                               \
+  name.xs = name##_xs
+
+// first-layer tables + output layer -> LDS: straight 16-byte copies of the packed prefix
+template <int N, bool BF16>
+__device__ __forceinline__ void actor_stage_tables(const ActorLds<N, BF16> &lds, const float *packed, int tid) {
+  const float4 *src = reinterpret_cast<const float4 *>(packed);
+  float4 *dst = reinterpret_cast<float4 *>(lds.tables);
+  for (int t = tid; t < PackLayout<N>::kTables / 4; t += 256) dst[t] = src[t];
+}
+
+// B operands of this wave's 16 columns of W2 = [W_branch_self_h2 ; W_others_h2] and their bias, kept in VGPRs
+template <int N, bool BF16> struct ActorB {
+  using G = ActorGeom<N, BF16>;
+  float bw[BF16 ? 1 : G::KU / 4];
+  bf16x8 bwb[BF16 ? G::KU / 32 : 1];
+  float bias_h2;
+};
+
+template <int N, bool BF16>
+__device__ __forceinline__ void actor_load_b(const float *packed, int w, int lane, ActorB<N, BF16> &b) {
+  using G = ActorGeom<N, BF16>;
+  using PL = PackLayout<N>;
+  if constexpr (BF16) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(packed + PL::kW2b) + (size_t)(w * 64 + lane) * (G::KU / 32);
+#pragma unroll
+    for (int s = 0; s < G::KU / 32; ++s) {
+      const uint4 v = src[s];
+      __builtin_memcpy(&b.bwb[s], &v, 16);
+    }
+  } else {
+    const float4 *src = reinterpret_cast<const float4 *>(packed + PL::kW2f) + (size_t)(w * 64 + lane) * (G::KU / 16);
+#pragma unroll
+    for (int s4 = 0; s4 < G::KU / 16; ++s4) {
+      const float4 v = src[s4];
+      b.bw[4 * s4 + 0] = v.x; b.bw[4 * s4 + 1] = v.y; b.bw[4 * s4 + 2] = v.z; b.bw[4 * s4 + 3] = v.w;
+    }
+  }
+  b.bias_h2 = packed[PL::kBh2 + 16 * w + (lane & 15)];
+}
+
+// xs tile + tables ready and synchronised on entry; h2s ready and synchronised on exit (3 barriers inside).
+template <int N, bool BF16>
+__device__ __forceinline__ void actor_mlp(const ActorLds<N, BF16> &lds, const ActorB<N, BF16> &b, int w, int lane,
+                                          bool stage2) {
+  using G = ActorGeom<N, BF16>;
+  constexpr int L = G::L, KU = G::KU;
+  const int col = lane & 15, hi = lane >> 4, c0 = 16 * w;
+  // ---- phase A: dense(6 -> 64) units [16w, 16w+16) and dense(L -> 128) units [32w, 32w+32) (networks.py:520-529) ------
+  {
+    float ax[4][2], ao[4][L / 4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) ax[t][s] = (4 * s + hi < 6) ? lds.xs[16 * t + col][4 * s + hi] : 0.0f;
+#pragma unroll
+      for (int s = 0; s < L / 4; ++s) ao[t][s] = lds.xs[16 * t + col][6 + 4 * s + hi];
+    }
+    {  // branch_self
+      const int unit = 16 * w + col;
+      float bs[2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) bs[s] = (4 * s + hi < 6) ? lds.ws_self[unit][4 * s + hi] : 0.0f;
+      const float bias = lds.ws_self[unit][6];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        f32x4 c = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int s = 0; s < 2; ++s) c = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[t][s], bs[s], c, 0, 0, 0);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const float h = fmaxf(c[reg] + bias, 0.0f);
+          if constexpr (BF16) lds.h1b[16 * t + 4 * hi + reg][unit] = (__bf16)h;
+          else lds.h1s[16 * t + 4 * hi + reg][unit] = h;
+        }
+      }
+    }
+#pragma unroll
+    for (int cq = 0; cq < 2; ++cq) {  // actor_others: two 16-unit column tiles
+      const int unit = 32 * w + 16 * cq + col;
+      float bo[L / 4];
+#pragma unroll
+      for (int s = 0; s < L / 4; ++s) bo[s] = stage2 ? lds.ws_oth[unit][4 * s + hi] : 0.0f;
+      const float bias = stage2 ? lds.ws_oth[unit][L] : 0.0f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        f32x4 c = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int s = 0; s < L / 4; ++s) c = __builtin_amdgcn_mfma_f32_16x16x4f32(ao[t][s], bo[s], c, 0, 0, 0);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const float h = fmaxf(c[reg] + bias, 0.0f);  // stage 1: exactly 0, the others branch is absent
+          if constexpr (BF16) lds.h1b[16 * t + 4 * hi + reg][kH1S + unit] = (__bf16)h;
+          else lds.h1s[16 * t + 4 * hi + reg][kH1S + unit] = h;
+        }
+      }
+    }
+  }
+  CM3_STAMP(3, true);
+  __syncthreads();
+  CM3_STAMP(4, false);
+  // ---- phase B: second layer on the matrix cores (networks.py:522-531: both matmuls, add_n) ---------------------------
+  f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  if constexpr (BF16) {
+#pragma unroll
+    for (int s = 0; s < KU / 32; ++s) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8 *>(&lds.h1b[16 * t + col][32 * s + 8 * hi]);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b.bwb[s], acc[t], 0, 0, 0);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < KU / 4; ++s) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(lds.h1s[16 * t + col][4 * s + hi], b.bw[s], acc[t], 0, 0, 0);
+    }
+  }
+  CM3_STAMP(5, true);
+  __syncthreads();  // all waves have consumed h1: its storage becomes h2
+  // ---- h2 = relu(add_n + b) (networks.py:533-534): C tile -> LDS rows --------------------------------------------------
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) lds.h2s[16 * t + 4 * hi + reg][c0 + col] = fmaxf(acc[t][reg] + b.bias_h2, 0.0f);
+  __syncthreads();
+  CM3_STAMP(6, false);
+}
+
+// Final layer, all four waves: wave w finishes rows [16w, 16w+16).  Lane l takes row 16w + (l&15) and a quarter of the
+// 64 second-layer units (part = l>>4): 16 x 5 FMAs, then the four partial logit vectors are summed across the parts
+// with two xor-shuffles (same order in every lane, so all four copies are identical).  actor_out + softmax
+// (networks.py:536-537), epsilon mix (alg_credit.py:119): returns the mixed probabilities of row 16w + (l&15).
+__device__ __forceinline__ void actor_head_probs(const float (*h2s)[kH2 + 1], const float *wout, int w, int lane,
+                                                 float eps, float (&pr)[kA]) {
   const int rl = 16 * w + (lane & 15), part = lane >> 4;
   float o[kA];
 #pragma unroll
@@ -126,24 +316,22 @@ __device__ __forceinline__ void actor_head(const ActorParams &p, const float (*h
     o[a] = expf(o[a] - m);
     sum += o[a];
   }
-  float pr[kA];
   const float inv = 1.0f / sum;
 #pragma unroll
-  for (int a = 0; a < kA; ++a) pr[a] = (1.0f - p.eps) * (o[a] * inv) + p.eps / (float)kA;
+  for (int a = 0; a < kA; ++a) pr[a] = (1.0f - eps) * (o[a] * inv) + eps / (float)kA;
+}
 
-  const size_t r = row_base + rl;
-  const bool row_ok = r < rows && part == 0;
-  const size_t rc = r < rows ? r : rows - 1;
-  const size_t e = rc / N;
-  const int i = (int)(rc - e * N);
-  const uint64_t genv = (uint64_t)(p.env_id_base + (int64_t)e);
+// action ~ multinomial(probs) (alg_credit.py:120): inverse CDF in action order, one uniform from the Philox stream
+// keyed (seed, global env id, episode, step | agent)
+__device__ __forceinline__ int actor_sample(const float (&pr)[kA], uint64_t seed, uint64_t genv, uint32_t episode,
+                                            int steps, int agent) {
   u32x4 ctr;
   ctr.x = (uint32_t)genv;
   ctr.y = (uint32_t)(genv >> 32);
   ctr.z = episode;
-  ctr.w = kPurposePolicy | ((uint32_t)(i >> 2) << 24) | ((uint32_t)steps & 0x00FFFFFFu);
-  const u32x4 wd = philox4x32_10(ctr, (uint32_t)p.seed, (uint32_t)(p.seed >> 32));
-  const int q = i & 3;
+  ctr.w = kPurposePolicy | ((uint32_t)(agent >> 2) << 24) | ((uint32_t)steps & 0x00FFFFFFu);
+  const u32x4 wd = philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
+  const int q = agent & 3;
   const float u = (float)u01(q == 0 ? wd.x : (q == 1 ? wd.y : (q == 2 ? wd.z : wd.w)));
   int act = kA - 1;
   float cdf = 0.0f;
@@ -156,208 +344,62 @@ __device__ __forceinline__ void actor_head(const ActorParams &p, const float (*h
       chosen = true;
     }
   }
-  if (row_ok) {
-    p.actions[r] = act;
-    if (p.probs) {
-#pragma unroll
-      for (int a = 0; a < kA; ++a) p.probs[r * kA + a] = pr[a];
-    }
-  }
+  return act;
 }
 
-// Workgroup = 4 waves = 64 rows.
-//   Phase A (matrix cores): wave w evaluates a quarter of the first-layer units -- 16 of branch_self and 32 of
-//     actor_others -- for all 64 rows (K = 6 -> 8 and K = L); results go to LDS h1s[row][unit] (unit = k of layer 2).
-//     (A VALU version with one row per lane and broadcast weight reads took 7.0k cycles; this one ~2k.)
-//   Phase B (matrix cores): wave w owns columns [16w, 16w+16) of the 192 -> 64 second layer,
-//     v_mfma_f32_16x16x4_f32 (exact f32, k-ordered fma chain), 4 row tiles x 48 k-steps:
-//       A[i = l&15][k = l>>4]  = h1s[16t + (l&15)][4s + (l>>4)]        one ds_read_b32 per MFMA
-//       B[k = l>>4][j = l&15]  = W2[4s + (l>>4)][16w + (l&15)]         48 VGPRs per lane, loaded once
-//       C  col = l&15, row = 4 (l>>4) + reg  -> relu(C + b) to LDS h2s; each wave then finishes 16 whole rows.
-//   (A version that evaluated the first layer directly in the A-operand layout needed no h1s but recomputed it in
-//    all four waves: 2750 VALU instructions per wave, 14.5 us per workgroup -- PMC run in profiles/.)
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-// BF16 == true (opt-in, cm3_actor_particle_desc.precision = 1): the first-layer activations are stored as bf16 and
-// the second layer runs on v_mfma_f32_16x16x32_bf16 (f32 accumulate): 6 k-steps instead of 48, 16x the MFMA rate.
-//       A[i = l&15][k = 8 (l>>4) + q] = h1b[16t + (l&15)][32s + 8 (l>>4) + q],  q = 0..7   one ds_read_b128 per MFMA
-//       B[k = 8 (l>>4) + q][j = l&15] = bf16(W2[32s + 8 (l>>4) + q][16w + (l&15)])          24 VGPRs per lane
-// Inputs and W2 are rounded to bf16 (relative 2^-9): probabilities move by up to ~1e-2, so this is NOT the parity
-// path; everything else (first layers, output layer, softmax, sampling) stays float32.
 template <int N, bool BF16> __global__ void __launch_bounds__(256) k_actor_particle(const ActorParams p) {
-  constexpr int L = 4 * (N > 1 ? N - 1 : 1);
-  constexpr int SW = 8;                  // ws_self row: 6 weights, bias, pad
-  constexpr int OW = L + 4;              // ws_oth row: L weights, bias, pad (multiple of 4 floats)
-  constexpr int KU = kH1S + kH1O;        // 192 first-layer units = K of the second layer
-  constexpr int HB = KU + 8;             // bf16 row: 200 halfwords = 400 B (16-byte aligned rows)
-  using PL = PackLayout<N>;
-  __shared__ __attribute__((aligned(16))) float tables[PL::kTables];       // packed prefix, verbatim
-  float (*ws_self)[SW] = reinterpret_cast<float (*)[SW]>(&tables[PL::kSelf]);
-  float (*ws_oth)[OW] = reinterpret_cast<float (*)[OW]>(&tables[PL::kOth]);
-  const float *wout_s = &tables[PL::kOut];
-  __shared__ __attribute__((aligned(16))) float h1raw[BF16 ? (64 * HB) / 2 : 64 * (KU + 1)];
-  float (*h1s)[KU + 1] = reinterpret_cast<float (*)[KU + 1]>(h1raw);       // f32 view  [64][193]
-  __bf16 (*h1b)[HB] = reinterpret_cast<__bf16 (*)[HB]>(h1raw);             // bf16 view [64][200]
-  // h2 [64][65] reuses the h1 storage once every wave is done reading h1 (extra barrier below): keeps the workgroup
-  // at 66 KB of LDS (f32) / 42 KB (bf16) so that two workgroups fit a CU
-  float (*h2s)[kH2 + 1] = reinterpret_cast<float (*)[kH2 + 1]>(h1raw);
-  static_assert(64 * (kH2 + 1) <= (BF16 ? (64 * HB) / 2 : 64 * (KU + 1)), "h2 must fit into the h1 storage");
-  __shared__ float xs[64][6 + L + 1];  // input tile, odd row stride (conflict-free column reads)
+  using G = ActorGeom<N, BF16>;
+  constexpr int L = G::L;
+  CM3_ACTOR_LDS(N, BF16, lds);
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int col = lane & 15, hi = lane >> 4;
-  const int c0 = w * 16;
   const size_t rows = (size_t)p.E * N;
   const size_t row_base = (size_t)blockIdx.x * 64;
-  const bool stage2 = p.stage > 1;
   CM3_STAMP(0, false);
 
   // RNG key of the row this lane finishes in the head (row 16w + (l&15)): fetched now, used ~20k cycles later
-  int head_steps;
-  uint32_t head_episode;
-  {
-    size_t hr = row_base + 16 * w + col;
-    hr = hr < rows ? hr : rows - 1;
-    const size_t he = hr / N;
-    head_steps = p.meta[2 * he];
-    head_episode = (uint32_t)p.episode[he];
-  }
-  // ---- first-layer tables + output layer -> LDS: straight 16-byte copies of the packed prefix -------------------------
-  {
-    const float4 *src = reinterpret_cast<const float4 *>(p.packed);
-    float4 *dst = reinterpret_cast<float4 *>(tables);
-    for (int t = tid; t < PL::kTables / 4; t += 256) dst[t] = src[t];
-  }
-  // ---- this lane's row: concat(v_obs, v_goal) and obs_others -----------------------------------------------------------
-  const size_t r = row_base + lane;
-  const bool row_ok = r < rows;
-  const size_t rc = row_ok ? r : rows - 1;
-  const size_t e = rc / N;
-  const int i = (int)(rc - e * N);
+  size_t hr = row_base + 16 * w + (lane & 15);
+  const bool head_ok = hr < rows && (lane >> 4) == 0;
+  hr = hr < rows ? hr : rows - 1;
+  const size_t he = hr / N;
+  const int hi_agent = (int)(hr - he * N);
+  const int head_steps = p.meta[2 * he];
+  const uint32_t head_episode = (uint32_t)p.episode[he];
+
+  actor_stage_tables<N, BF16>(lds, p.packed, tid);
   if (w == 0) {  // wave 0 stages the 64 input rows [v_obs(4) | v_goal(2) | obs_others(L)] into LDS, one row per lane
+    const size_t r = row_base + lane;
+    const size_t rc = r < rows ? r : rows - 1;
+    const size_t e = rc / N;
+    const int i = (int)(rc - e * N);
     const float4 s = reinterpret_cast<const float4 *>(p.state)[(size_t)i * p.E + e];
     const float2 g = reinterpret_cast<const float2 *>(p.goals)[(size_t)i * p.E + e];
-    xs[lane][0] = s.x; xs[lane][1] = s.y; xs[lane][2] = s.z; xs[lane][3] = s.w; xs[lane][4] = g.x; xs[lane][5] = g.y;
+    lds.xs[lane][0] = s.x; lds.xs[lane][1] = s.y; lds.xs[lane][2] = s.z; lds.xs[lane][3] = s.w;
+    lds.xs[lane][4] = g.x; lds.xs[lane][5] = g.y;
     const float4 *o4 = reinterpret_cast<const float4 *>(p.obs_others + rc * L);
 #pragma unroll
     for (int k = 0; k < L / 4; ++k) {
       const float4 v = o4[k];
-      xs[lane][6 + 4 * k + 0] = v.x; xs[lane][6 + 4 * k + 1] = v.y; xs[lane][6 + 4 * k + 2] = v.z; xs[lane][6 + 4 * k + 3] = v.w;
+      lds.xs[lane][6 + 4 * k + 0] = v.x; lds.xs[lane][6 + 4 * k + 1] = v.y;
+      lds.xs[lane][6 + 4 * k + 2] = v.z; lds.xs[lane][6 + 4 * k + 3] = v.w;
     }
   }
-  // ---- B: this wave's slice of W2 = [W_branch_self_h2 ; W_others_h2], unit k = 4s + hi, column c0 + col --------------
-  float bw[BF16 ? 1 : KU / 4];
-  bf16x8 bwb[BF16 ? KU / 32 : 1];
-  if constexpr (BF16) {
-    const uint4 *src = reinterpret_cast<const uint4 *>(p.packed + PL::kW2b) + (size_t)(w * 64 + lane) * (KU / 32);
-#pragma unroll
-    for (int s = 0; s < KU / 32; ++s) {
-      const uint4 v = src[s];
-      __builtin_memcpy(&bwb[s], &v, 16);
-    }
-  } else {
-    const float4 *src = reinterpret_cast<const float4 *>(p.packed + PL::kW2f) + (size_t)(w * 64 + lane) * (KU / 16);
-#pragma unroll
-    for (int s4 = 0; s4 < KU / 16; ++s4) {
-      const float4 v = src[s4];
-      bw[4 * s4 + 0] = v.x; bw[4 * s4 + 1] = v.y; bw[4 * s4 + 2] = v.z; bw[4 * s4 + 3] = v.w;
-    }
-  }
-  const float bias_h2 = p.packed[PL::kBh2 + c0 + col];
+  ActorB<N, BF16> b;
+  actor_load_b<N, BF16>(p.packed, w, lane, b);
   CM3_STAMP(1, true);
   __syncthreads();
   CM3_STAMP(2, false);
-
-  // ---- phase A on the matrix cores too: dense(6 -> 64) units [16w, 16w+16) and dense(L -> 128) units [32w, 32w+32) for
-  // all 64 rows (networks.py:520-521, :527-529).  A[i = l&15][k = l>>4] = input k of row 16t + (l&15) (from the xs tile),
-  // B[k = l>>4][j = l&15] = weight of input k for unit j (from the unit-major LDS tables); bias + relu are applied to the
-  // C tile (col = unit, row = 4 (l>>4) + reg) on its way into h1.
-  {
-    float ax[4][2], ao[4][L / 4];
+  actor_mlp<N, BF16>(lds, b, w, lane, p.stage > 1);
+  float pr[kA];
+  actor_head_probs(lds.h2s, lds.wout, w, lane, p.eps, pr);
+  const int act = actor_sample(pr, p.seed, (uint64_t)(p.env_id_base + (int64_t)he), head_episode, head_steps, hi_agent);
+  if (head_ok) {
+    p.actions[hr] = act;
+    if (p.probs) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-#pragma unroll
-      for (int s = 0; s < 2; ++s) ax[t][s] = (4 * s + hi < 6) ? xs[16 * t + col][4 * s + hi] : 0.0f;
-#pragma unroll
-      for (int s = 0; s < L / 4; ++s) ao[t][s] = xs[16 * t + col][6 + 4 * s + hi];
-    }
-    {  // branch_self
-      const int unit = 16 * w + col;
-      float bs[2];
-#pragma unroll
-      for (int s = 0; s < 2; ++s) bs[s] = (4 * s + hi < 6) ? ws_self[unit][4 * s + hi] : 0.0f;
-      const float bias = ws_self[unit][6];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        f32x4 c = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int s = 0; s < 2; ++s) c = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[t][s], bs[s], c, 0, 0, 0);
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const float h = fmaxf(c[reg] + bias, 0.0f);
-          if constexpr (BF16) h1b[16 * t + 4 * hi + reg][unit] = (__bf16)h; else h1s[16 * t + 4 * hi + reg][unit] = h;
-        }
-      }
-    }
-#pragma unroll
-    for (int cq = 0; cq < 2; ++cq) {  // actor_others: two 16-unit column tiles
-      const int unit = 32 * w + 16 * cq + col;
-      float bo[L / 4];
-#pragma unroll
-      for (int s = 0; s < L / 4; ++s) bo[s] = stage2 ? ws_oth[unit][4 * s + hi] : 0.0f;
-      const float bias = stage2 ? ws_oth[unit][L] : 0.0f;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        f32x4 c = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int s = 0; s < L / 4; ++s) c = __builtin_amdgcn_mfma_f32_16x16x4f32(ao[t][s], bo[s], c, 0, 0, 0);
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const float h = fmaxf(c[reg] + bias, 0.0f);   // stage 1: exactly 0, the others branch is absent
-          if constexpr (BF16) h1b[16 * t + 4 * hi + reg][kH1S + unit] = (__bf16)h;
-          else h1s[16 * t + 4 * hi + reg][kH1S + unit] = h;
-        }
-      }
+      for (int a = 0; a < kA; ++a) p.probs[hr * kA + a] = pr[a];
     }
   }
-  CM3_STAMP(3, true);
-  __syncthreads();
-  CM3_STAMP(4, false);
-
-  // ---- phase B: second layer on the matrix cores (networks.py:522-531: both matmuls, add_n) ---------------------------------
-  f32x4 acc[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-  if constexpr (BF16) {
-#pragma unroll
-    for (int s = 0; s < KU / 32; ++s) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8 *>(&h1b[16 * t + col][32 * s + 8 * hi]);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bwb[s], acc[t], 0, 0, 0);
-      }
-    }
-  } else {
-#pragma unroll
-    for (int s = 0; s < KU / 4; ++s) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(h1s[16 * t + col][4 * s + hi], bw[s], acc[t], 0, 0, 0);
-    }
-  }
-  CM3_STAMP(5, true);
-  __syncthreads();  // all waves have consumed h1: its storage becomes h2
-  // ---- h2 = relu(add_n + b) (networks.py:533-534): C tile -> LDS rows ---------------------------------------------------
-  {
-    const float bias = bias_h2;
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) h2s[16 * t + 4 * hi + reg][c0 + col] = fmaxf(acc[t][reg] + bias, 0.0f);
-  }
-  __syncthreads();
-  CM3_STAMP(6, false);
-  actor_head<N>(p, h2s, wout_s, w, lane, row_base, rows, head_steps, head_episode);
   CM3_STAMP(7, true);
 }
 
