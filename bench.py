@@ -503,6 +503,44 @@ def main():
             "frac_of_peak": f_bytes / f_launch_s / 1e9 / HBM_PEAK_GBPS}
         fs.close()
         del fs
+    if world == 1 and rank == 0 and kind == "particle" and N in (1, 2, 4, 8) and not args.fused:
+        # Extra (not the headline): POLICY-driven collection, the branch the reference takes for 49 950 of its 50 000
+        # episodes (train_onpolicy.py:311-313): on-device actor (random float32 weights of the reference's shapes,
+        # epsilon 0.1) + env step per tick, (a) alternating launches in one hipGraph, (b) the whole episode in ONE
+        # launch (csrc/policy.hip).  Trajectory mode: every tick's state / obs / goals / rewards are stored.
+        import numpy as np
+        from cm3_amd.actor import ParticleActor
+        from cm3_amd.particle import VecParticleEnv
+        from cm3_amd.rollout import ParticleRollout
+        rng = np.random.default_rng(0)
+        Lo = 4 * max(N - 1, 1)
+        shapes = {"actor_branch_self/kernel": (6, 64), "actor_branch_self/bias": (64,), "W_branch_self_h2": (64, 64),
+                  "stage-2/actor_others/kernel": (Lo, 128), "stage-2/actor_others/bias": (128,),
+                  "stage-2/W_others_h2": (128, 64), "b": (64,), "actor_out/kernel": (64, 5), "actor_out/bias": (5,)}
+        wts = {k: (rng.standard_normal(v) * 0.1).astype(np.float32) for k, v in shapes.items()}
+        pol = {}
+        for label, fused in (("launch_per_tick", False), ("one_launch_per_episode", True)):
+            penv = VecParticleEnv(cfg, N, 0.2, 33, E, device=device, auto_reset=True)
+            penv.reset()
+            actor = ParticleActor(wts, N, stage=2, device=device)
+            ro = ParticleRollout(penv, n_ticks=GRAPH_TICKS, use_graph=True, fused=fused)
+            for _ in range(3):
+                ro.collect(policy=actor, epsilon=0.1, reset=False)
+            torch.cuda.synchronize(device)
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = max(steps // 2, 5)
+            ev0.record()
+            for _ in range(reps):
+                ro.collect(policy=actor, epsilon=0.1, reset=False)
+            ev1.record()
+            ev1.synchronize()
+            us = ev0.elapsed_time(ev1) * 1e3 / (reps * GRAPH_TICKS)
+            pol[label] = {"us_per_tick": us, "env_steps_per_s": E / us * 1e6}
+            ro.close()
+        pol["note"] = ("extra, not the headline: actor (networks.actor_particle, float32, exact-f32 MFMA) + step per tick with "
+                       "full trajectory storage; the two variants are bit-identical "
+                       "(tests/test_gpu_actor.py::test_fused_policy_rollout_equals_launch_per_tick)")
+        out["policy_rollout"] = pol
     if world == 1 and rank == 0:
         bw = measure_read_bandwidth(device)
         out["roofline"]["measured_read_GBps"] = bw

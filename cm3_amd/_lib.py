@@ -117,6 +117,8 @@ SYMBOLS = {
     "cm3_actor_particle_pack": (ctypes.c_int, [P(ActorParticleDesc), P(ActorParticleWeights), c_void_p, c_void_p]),
     "cm3_actor_particle_f32": (ctypes.c_int, [P(ActorParticleDesc), P(ActorParticleWeights), P(ActorParticleBufs),
                                               c_void_p]),
+    "cm3_policy_rollout_f32": (ctypes.c_int, [P(ParticleDesc), P(ParticleTraj), P(ActorParticleDesc),
+                                              P(ActorParticleWeights), c_void_p, c_size_t, c_int32, c_void_p]),
     "cm3_returns_scratch_bytes": (c_size_t, []),
     "cm3_returns_moments_f32": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                c_int32, c_int32, c_int32, c_double, c_void_p]),

@@ -446,6 +446,7 @@ template <int N> static int pack_launch(const ActorParams &p, float *out, hipStr
 }
 }  // namespace cm3
 
+#ifndef CM3_NO_ENTRY_POINTS
 extern "C" size_t cm3_actor_particle_packed_bytes(int32_t n_agents) {
   return cm3::packed_floats_for(n_agents) * sizeof(float);
 }
@@ -520,3 +521,4 @@ extern "C" int cm3_actor_particle_f32(const cm3_actor_particle_desc *d, const cm
   }
   return fail(CM3_ERR_INVALID, "n_agents %d unsupported", d->n_agents);
 }
+#endif  // CM3_NO_ENTRY_POINTS

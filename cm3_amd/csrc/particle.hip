@@ -963,6 +963,7 @@ static int particle_rollout(const cm3_particle_desc *d, const cm3_particle_traj 
 #define CM3_PARTICLE_F64 1
 #endif
 
+#ifndef CM3_NO_ENTRY_POINTS
 extern "C" {
 #ifdef CM3_PARTICLE_F32
 int cm3_particle_step_f32(const cm3_particle_desc *d, const cm3_particle_bufs *b, void *s) {
@@ -993,3 +994,4 @@ int cm3_particle_rollout_f64(const cm3_particle_desc *d, const cm3_particle_traj
 }
 #endif
 }
+#endif  // CM3_NO_ENTRY_POINTS

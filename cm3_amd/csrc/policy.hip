@@ -1,0 +1,314 @@
+// A whole POLICY-DRIVEN episode in one launch: actor forward pass (matrix cores) + epsilon-mixed sampling + physics
+// step + observation, tick after tick, with the network weights, the input tile and the env state resident in
+// LDS / registers.
+//
+// Reference loop being replaced (alg/train_onpolicy.py:302-350, the branch taken for 49 950 of its 50 000 episodes):
+//     actions = alg.run_actor(local_others, local_self, goals, epsilon, sess)      :313   (alg_credit.py:249-270)
+//     next_... = env.step(actions)                                                 :323   (environment.py:81-123)
+//     buf.add(transition) ; roll state forward                                     :338-347
+// The unfused device path (ParticleRollout.collect(policy=actor)) alternates k_actor_particle and
+// k_particle_step_pairs launches inside a hipGraph: 12.9 us per tick at 4096 envs x 4 agents, of which ~3.8k cycles
+// re-stage the weights, ~3 us are launch boundaries and ~2 us re-load state/observations.  Here a workgroup owns
+// 64 agent rows = 64/N whole envs for all T ticks:
+//   * weights: first-layer tables + output layer in LDS, W2 B-operands in VGPRs -- staged ONCE per launch;
+//   * per tick: actor_mlp (phase A / phase B on the matrix cores, 3 barriers) -> head: probabilities + action of row
+//     16w + (l&15) in the 16 "part 0" lanes of wave w -> the same lanes advance their agent: own-side contact forces
+//     against the other agents of the env (positions read from the LDS input tile), integration, reward / collision /
+//     reached, per-env reductions with wave shuffles, optional same-tick re-initialisation, and the next observation is
+//     written both to the trajectory (global) and back into the LDS tile that feeds the next tick's phase A.
+// Arithmetic per agent is the reference's operation order, so trajectories are bit-identical to the unfused path
+// (tests/test_gpu_actor.py::test_fused_policy_rollout_equals_launch_per_tick).
+#define CM3_NO_ENTRY_POINTS 1
+#define CM3_PARTICLE_F32 1
+#include "particle.hip"
+#include "actor.hip"
+
+namespace cm3 {
+
+struct PolicyParams {
+  ParticleParams p;  // trajectory pointers/strides of the fused rollout (state_in = slot 0, *_out = slot 1 ...)
+  const float *obs_in;  // obs_others slot 0
+  const float *packed;
+  float *probs;         // optional [T][E][N][5]
+  size_t st_probs;
+  float eps;
+  int stage;
+};
+
+template <int N, bool BF16> __global__ void __launch_bounds__(256) k_policy_rollout(const PolicyParams q) {
+  using G = ActorGeom<N, BF16>;
+  using V4 = float4;
+  using V2 = float2;
+  constexpr int L = G::L, NO = N > 1 ? N - 1 : 1;
+  const ParticleParams &p = q.p;
+  CM3_ACTOR_LDS(N, BF16, lds);
+  __shared__ float ns[64][4];  // post-step (vx, vy, px, py) of every row, exchanged inside a wave
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const size_t E = (size_t)p.E;
+  const size_t rows = E * N;
+  const size_t row_base = (size_t)blockIdx.x * 64;
+
+  // the row this lane owns in the head and in the physics: rl = 16w + (l&15); only part 0 (l < 16) writes
+  const int rl = 16 * w + (lane & 15);
+  const bool part0 = (lane >> 4) == 0;
+  size_t r = row_base + rl;
+  const bool row_ok = r < rows;
+  r = row_ok ? r : rows - 1;
+  const size_t e = r / N;
+  const int i = (int)(r - e * N);
+  const int env_lane0 = (lane & 15) - i;  // lane (within the wave's part 0) of agent 0 of this env
+  const uint64_t genv = (uint64_t)(p.env_id_base + (int64_t)e);
+  const bool writer = row_ok && part0;
+  const bool head_lane = writer && i == 0;
+
+  // ---- once per launch: weights, live counters, the input tile ---------------------------------------------------------
+  actor_stage_tables<N, BF16>(lds, q.packed, tid);
+  ActorB<N, BF16> b;
+  actor_load_b<N, BF16>(q.packed, w, lane, b);
+  const int2 meta = reinterpret_cast<const int2 *>(p.meta_in)[e];
+  int steps = meta.x, collisions = meta.y;
+  uint32_t episode = (uint32_t)p.episode[e];
+  const uint32_t episode_in = episode;
+  if (part0) {
+    const V4 s0 = reinterpret_cast<const V4 *>(p.state_in)[(size_t)i * E + e];
+    const V2 g0 = reinterpret_cast<const V2 *>(p.goals_in)[(size_t)i * E + e];
+    lds.xs[rl][0] = s0.x; lds.xs[rl][1] = s0.y; lds.xs[rl][2] = s0.z; lds.xs[rl][3] = s0.w;
+    lds.xs[rl][4] = g0.x; lds.xs[rl][5] = g0.y;
+    const V4 *o4 = reinterpret_cast<const V4 *>(q.obs_in + r * L);
+#pragma unroll
+    for (int k = 0; k < L / 4; ++k) {
+      const V4 v = o4[k];
+      lds.xs[rl][6 + 4 * k + 0] = v.x; lds.xs[rl][6 + 4 * k + 1] = v.y;
+      lds.xs[rl][6 + 4 * k + 2] = v.z; lds.xs[rl][6 + 4 * k + 3] = v.w;
+    }
+  }
+  __syncthreads();
+
+  const float kDt = 0.1f, kKeep = 1.0f - 0.25f, kDistMin = 0.15f + 0.15f;
+#pragma unroll 1
+  for (int t = 0; t < p.n_ticks; ++t) {
+    // ---- policy: forward pass, probabilities and the sampled action of row rl (alg_credit.py:113-122) -----------------
+    actor_mlp<N, BF16>(lds, b, w, lane, q.stage > 1);
+    float pr[kA];
+    actor_head_probs(lds.h2s, lds.wout, w, lane, q.eps, pr);
+    const int act = actor_sample(pr, p.seed, genv, episode, steps, i);
+    if (writer) {
+      tick_ptr(p.actions, p.st_actions, t)[r] = act;
+      if (q.probs) {
+        float *pt = tick_ptr(q.probs, q.st_probs, t) + r * kA;
+#pragma unroll
+        for (int a = 0; a < kA; ++a) pt[a] = pr[a];
+      }
+    }
+
+    // ---- physics of agent i (environment.py:81-123), lanes of part 0 ------------------------------------------------------
+    V4 si;
+    si.x = lds.xs[rl][0]; si.y = lds.xs[rl][1]; si.z = lds.xs[rl][2]; si.w = lds.xs[rl][3];
+    V2 gl;
+    gl.x = lds.xs[rl][4]; gl.y = lds.xs[rl][5];
+    float ux = 0.0f, uy = 0.0f;
+    if (act == 1) ux = -1.0f;
+    if (act == 2) ux = +1.0f;
+    if (act == 3) uy = -1.0f;
+    if (act == 4) uy = +1.0f;
+    float Fx = ux * 5.0f + 0.0f, Fy = uy * 5.0f + 0.0f;
+#pragma unroll
+    for (int k = 0; k < N - 1; ++k) {  // the reference's accumulation order: other agents ascending (core.py:145-155)
+      const int j = k < i ? k : k + 1;
+      const int rj = rl - i + j;
+      float f_x, f_y;
+      contact_force<float>(si.z - lds.xs[rj][2], si.w - lds.xs[rj][3], f_x, f_y);
+      Fx = f_x + Fx;
+      Fy = f_y + Fy;
+    }
+    si.x = si.x * kKeep;
+    si.y = si.y * kKeep;
+    si.x = si.x + (Fx / 1.0f) * kDt;
+    si.y = si.y + (Fy / 1.0f) * kDt;
+    si.z = si.z + si.x * kDt;
+    si.w = si.w + si.y * kDt;
+    steps += 1;
+    ns[rl][0] = si.x; ns[rl][1] = si.y; ns[rl][2] = si.z; ns[rl][3] = si.w;
+    wave_lds_sync();  // the other agents of this env live in the same wave
+
+    // ---- reward / reached / collisions (multi-goal_spread.py:114-143) ----------------------------------------------------------
+    float rew;
+    {
+      const float dx = si.z - gl.x, dy = si.w - gl.y;
+      rew = 0.0f - sqrtf(dx * dx + dy * dy);
+    }
+    const bool reached = rew >= -0.05f;
+    int hits = 0;
+#pragma unroll
+    for (int k = 0; k < N - 1; ++k) {
+      const int j = k < i ? k : k + 1;
+      const int rj = rl - i + j;
+      const float dx = ns[rj][2] - si.z, dy = ns[rj][3] - si.w;  // is_collision(a = j, agent = i)
+      if (sqrtf(dx * dx + dy * dy) < kDistMin) {
+        rew = rew - 1.0f;
+        hits += 1;
+      }
+    }
+    float rews[N];
+    int hit_sum = 0;
+    bool all_reached = true;
+#pragma unroll
+    for (int a = 0; a < N; ++a) {  // per-env reductions over the N part-0 lanes of this env
+      rews[a] = __shfl(rew, env_lane0 + a, 64);
+      hit_sum += __shfl(hits, env_lane0 + a, 64);
+      all_reached = all_reached && (__shfl((int)reached, env_lane0 + a, 64) != 0);
+    }
+    collisions += hit_sum;
+    const float reward = sum_agents<float, N>(rews);
+    const bool done = (steps == p.max_steps) || all_reached;
+    if (writer) reinterpret_cast<float *>(tick_ptr(p.reward_n, p.st_reward_n, t))[r] = rew;
+    if (head_lane) {
+      reinterpret_cast<float *>(tick_ptr(p.reward, p.st_reward, t))[e] = reward;
+      tick_ptr(p.done, p.st_done, t)[e] = done ? 1 : 0;
+    }
+
+    // ---- same-tick re-initialisation of finished episodes (CM3_FLAG_AUTO_RESET) ------------------------------------------------
+    bool was_reset = false;
+    if ((p.flags & CM3_FLAG_AUTO_RESET) && done) {
+      void *term_state = tick_ptr(p.term_state, p.st_term_state, t);
+      void *term_obs = tick_ptr(p.term_obs_others, p.st_term_obs, t);
+      if (writer && term_state) reinterpret_cast<V4 *>(term_state)[(size_t)i * E + e] = si;
+      if (writer && term_obs) {
+        V4 *o = reinterpret_cast<V4 *>(term_obs) + r * NO;
+#pragma unroll
+        for (int k = 0; k < NO; ++k) {
+          const int j = (N > 1) ? (k < i ? k : k + 1) : 0;
+          const int rj = rl - i + j;
+          V4 d;
+          d.x = ns[rj][0] - si.x; d.y = ns[rj][1] - si.y; d.z = ns[rj][2] - si.z; d.w = ns[rj][3] - si.w;
+          o[k] = d;
+        }
+      }
+      wave_lds_sync();  // every lane of the env has read the terminal states before they are overwritten
+      episode += 1;
+      const bool rnd = episode_is_random(p, genv, episode);
+      init_agent<float, N>(p, genv, episode, rnd, i, si, gl);
+      steps = 0;
+      collisions = 0;
+      was_reset = true;
+      ns[rl][0] = si.x; ns[rl][1] = si.y; ns[rl][2] = si.z; ns[rl][3] = si.w;
+      wave_lds_sync();
+    }
+
+    // ---- trajectory stores + the LDS tile of the next tick ---------------------------------------------------------------------
+    if (part0) {
+      if (row_ok) {
+        reinterpret_cast<V4 *>(tick_ptr(p.state_out, p.st_state, t))[(size_t)i * E + e] = si;
+        if (p.goals_out != p.goals_in || was_reset)
+          reinterpret_cast<V2 *>(tick_ptr(p.goals_out, p.st_goals, t))[(size_t)i * E + e] = gl;
+      }
+      V4 *o = reinterpret_cast<V4 *>(tick_ptr(p.obs_others, p.st_obs, t)) + r * NO;
+#pragma unroll
+      for (int k = 0; k < NO; ++k) {  // observation (multi-goal_spread.py:145-154)
+        const int j = (N > 1) ? (k < i ? k : k + 1) : 0;
+        const int rj = rl - i + j;
+        V4 d;
+        d.x = ns[rj][0] - si.x; d.y = ns[rj][1] - si.y; d.z = ns[rj][2] - si.z; d.w = ns[rj][3] - si.w;
+        if (row_ok) o[k] = d;
+        lds.xs[rl][6 + 4 * k + 0] = d.x; lds.xs[rl][6 + 4 * k + 1] = d.y;
+        lds.xs[rl][6 + 4 * k + 2] = d.z; lds.xs[rl][6 + 4 * k + 3] = d.w;
+      }
+      lds.xs[rl][0] = si.x; lds.xs[rl][1] = si.y; lds.xs[rl][2] = si.z; lds.xs[rl][3] = si.w;
+      lds.xs[rl][4] = gl.x; lds.xs[rl][5] = gl.y;
+    }
+    __syncthreads();  // the tile (and the h1/h2 storage) is free for the next tick's phase A
+  }
+
+  if (head_lane) {
+    int2 m;
+    m.x = steps;
+    m.y = collisions;
+    reinterpret_cast<int2 *>(p.meta_out)[e] = m;
+    if (episode != episode_in) p.episode[e] = (int32_t)episode;
+  }
+}
+
+template <int N> static int policy_launch(const PolicyParams &q, bool bf16, hipStream_t s) {
+  const size_t rows = (size_t)q.p.E * N;
+  const unsigned blocks = (unsigned)((rows + 63) / 64);
+  if (bf16)
+    hipLaunchKernelGGL((k_policy_rollout<N, true>), dim3(blocks), dim3(256), 0, s, q);
+  else
+    hipLaunchKernelGGL((k_policy_rollout<N, false>), dim3(blocks), dim3(256), 0, s, q);
+  CM3_HIP_CHECK(hipGetLastError());
+  return CM3_OK;
+}
+
+}  // namespace cm3
+
+extern "C" int cm3_policy_rollout_f32(const cm3_particle_desc *d, const cm3_particle_traj *t,
+                                      const cm3_actor_particle_desc *ad, const cm3_actor_particle_weights *wt,
+                                      float *probs, size_t probs_stride, int32_t n_ticks, void *stream) {
+  using namespace cm3;
+  CM3_REQUIRE(d && t && ad && wt, "null argument");
+  CM3_REQUIRE(n_ticks >= 1, "n_ticks must be >= 1");
+  CM3_REQUIRE(d->n_agents == 1 || d->n_agents == 2 || d->n_agents == 4 || d->n_agents == 8,
+              "the fused policy rollout needs n_agents in {1, 2, 4, 8} (whole envs per 16-row wave tile); got %d",
+              d->n_agents);
+  CM3_REQUIRE(ad->n_agents == d->n_agents && ad->n_envs == d->n_envs, "actor / env descriptors disagree");
+  CM3_REQUIRE(!(d->flags & CM3_FLAG_GEN_ACTIONS), "the policy draws the actions: CM3_FLAG_GEN_ACTIONS is meaningless here");
+  int rc = actor_check_desc(ad);
+  if (rc != CM3_OK) return rc;
+  CM3_REQUIRE(ad->seed == d->seed && ad->env_id_base == d->env_id_base,
+              "actor and env must share seed and env_id_base (one Philox key; the streams differ by purpose bits)");
+  CM3_REQUIRE(ad->epsilon >= 0.0f && ad->epsilon <= 1.0f, "epsilon must be in [0,1]");
+  CM3_REQUIRE(wt->packed, "weights->packed is NULL: run cm3_actor_particle_pack once per weight update");
+  CM3_REQUIRE(t->state && t->goals && t->obs_others && t->actions && t->reward_n && t->reward && t->done && t->meta &&
+                  t->episode,
+              "trajectory base pointers are required");
+  auto at = [](void *base, size_t stride, int k) -> void * {
+    return base ? (void *)((char *)base + stride * (size_t)k) : nullptr;
+  };
+  cm3_particle_bufs b;
+  memset(&b, 0, sizeof(b));
+  b.state_in = t->state;
+  b.state_out = at(t->state, t->state_stride, 1);
+  b.goals_in = t->goals;
+  b.goals_out = at(t->goals, t->goals_stride, 1);
+  b.meta_in = b.meta_out = t->meta;
+  b.episode = t->episode;
+  b.actions = t->actions;
+  b.obs_others = at(t->obs_others, t->obs_others_stride, 1);
+  b.reward_n = t->reward_n;
+  b.reward = t->reward;
+  b.done = t->done;
+  b.term_state = t->term_state;
+  b.term_obs_others = t->term_obs_others;
+  cm3_particle_desc dd = *d;
+  dd.flags &= CM3_FLAG_AUTO_RESET;
+  PolicyParams q;
+  memset(&q, 0, sizeof(q));
+  rc = fill_params(&dd, &b, kStep, nullptr, q.p);
+  if (rc != CM3_OK) return rc;
+  q.p.n_ticks = n_ticks;
+  q.p.st_state = t->state_stride;
+  q.p.st_goals = t->goals_stride;
+  q.p.st_obs = t->obs_others_stride;
+  q.p.st_actions = t->actions_stride;
+  q.p.st_reward_n = t->reward_n_stride;
+  q.p.st_reward = t->reward_stride;
+  q.p.st_done = t->done_stride;
+  q.p.st_term_state = t->term_state_stride;
+  q.p.st_term_obs = t->term_obs_others_stride;
+  q.obs_in = (const float *)t->obs_others;
+  q.packed = (const float *)wt->packed;
+  q.probs = probs;
+  q.st_probs = probs_stride;
+  q.eps = ad->epsilon;
+  q.stage = ad->stage;
+  hipStream_t s = (hipStream_t)stream;
+  const bool bf16 = ad->precision == 1;
+  switch (d->n_agents) {
+    case 1: return policy_launch<1>(q, bf16, s);
+    case 2: return policy_launch<2>(q, bf16, s);
+    case 4: return policy_launch<4>(q, bf16, s);
+    case 8: return policy_launch<8>(q, bf16, s);
+  }
+  return fail(CM3_ERR_INVALID, "n_agents %d unsupported", d->n_agents);
+}

@@ -179,7 +179,17 @@ class ParticleRollout(object):
         elif hasattr(policy, "enqueue") and hasattr(policy, "act"):      # on-device actor (cm3_amd.actor)
             if env.dtype != torch.float32:
                 raise Cm3Error("the device actor reads float32 env buffers")
-            if self.use_graph:
+            if self.fused:
+                # the whole policy-driven episode in ONE launch (csrc/policy.hip): weights, observation tile and env
+                # state stay in LDS / registers for all T ticks; bit-identical to alternating actor / step launches
+                if policy.seed != env.seed:
+                    raise Cm3Error("fused policy rollouts need actor.seed == env.seed (one Philox key)")
+                env._desc.flags = base & FLAG_AUTO_RESET
+                traj = self._traj(0)
+                ad = policy._desc(env.E, epsilon, env.env_id_base)
+                _lib.check(self._lib.cm3_policy_rollout_f32(ctypes.byref(env._desc), ctypes.byref(traj), ctypes.byref(ad),
+                                                            ctypes.byref(policy._wt), None, 0, self.T, env._stream()))
+            elif self.use_graph:
                 key = ("actor", id(policy), float(epsilon))
                 if getattr(self, "_actor_graph_key", None) != key:
                     if getattr(self, "_actor_graph", None) is not None:

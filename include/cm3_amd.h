@@ -282,6 +282,17 @@ int cm3_actor_particle_pack(const cm3_actor_particle_desc *desc, const cm3_actor
 int cm3_actor_particle_f32(const cm3_actor_particle_desc *desc, const cm3_actor_particle_weights *weights,
                            const cm3_actor_particle_bufs *bufs, void *stream);
 
+/* A whole policy-driven episode in ONE launch: for every tick, actor forward pass + sampling (as cm3_actor_particle_f32)
+ * followed by the env step (as cm3_particle_step_f32), with the network weights, the observation tile and the env
+ * state resident in LDS / registers.  Same trajectory layout and flags as cm3_particle_rollout_f32 (AUTO_RESET honoured;
+ * GEN_ACTIONS rejected: the policy draws the actions, written to traj->actions).  probs (optional) receives the mixed
+ * probabilities per tick, float [n_ticks][E][N][5] with probs_stride bytes between ticks.  n_agents in {1,2,4,8};
+ * actor_desc and desc must agree on n_envs / n_agents / seed / env_id_base.  Bit-identical to alternating
+ * cm3_actor_particle_f32 and cm3_particle_step_f32 launches. */
+int cm3_policy_rollout_f32(const cm3_particle_desc *desc, const cm3_particle_traj *traj,
+                           const cm3_actor_particle_desc *actor_desc, const cm3_actor_particle_weights *weights,
+                           float *probs, size_t probs_stride, int32_t n_ticks, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Advantage normalisation (build-defined; the reference's advantage, alg_credit.py:334-357, is not normalised).
  * Discounted return-to-go over a time-major trajectory, G[t] = x[t] + gamma * (1 - done[t]) * G[t+1], G[T] = 0:

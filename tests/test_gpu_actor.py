@@ -10,9 +10,9 @@ from tests.helpers import load_cfg
 pytestmark = pytest.mark.gpu
 
 
-def _env(E, N, cfg, **kw):
+def _env(E, N, cfg, max_steps=33, **kw):
     from cm3_amd.particle import VecParticleEnv
-    return VecParticleEnv(load_cfg(cfg), N, 0.2, 33, E, device="cuda:0", dtype=torch.float32, **kw)
+    return VecParticleEnv(load_cfg(cfg), N, 0.2, max_steps, E, device="cuda:0", dtype=torch.float32, **kw)
 
 
 @pytest.mark.parametrize("N,cfg,stage", [(4, "particle_stage2_antipodal.json", 2), (2, "particle_stage2_merge.json", 2),
@@ -149,3 +149,36 @@ def test_bf16_second_layer_is_close_to_float32(N, cfg):
     assert 1e-6 < diff.max() < 0.1 and diff.mean() < 5e-3, (diff.max(), diff.mean())
     assert np.abs(p16.sum(-1).cpu().numpy() - 1).max() < 1e-5
     assert float((a32 == a16).float().mean()) > 0.97
+
+
+@pytest.mark.parametrize("N,cfg", [(4, "particle_stage2_cross.json"), (2, "particle_stage2_merge.json"),
+                                    (8, "particle_merge8.json"), (1, "particle_stage1.json")])
+@pytest.mark.parametrize("auto_reset", [False, True])
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_fused_policy_rollout_equals_launch_per_tick(N, cfg, auto_reset, precision):
+    """csrc/policy.hip (a whole policy-driven episode in one launch) is bit-identical to alternating actor / step
+    launches: trajectories, sampled actions, terminal captures, live counters."""
+    from cm3_amd.actor import ParticleActor
+    from cm3_amd.rollout import ParticleRollout
+    E, T, seed = 333, 40, 13
+    stage = 1 if N == 1 else 2
+    w = AO.init_weights(np.random.default_rng(N), N, stage=stage)
+    outs = []
+    for fused in (False, True):
+        env = _env(E, N, cfg, seed=seed, auto_reset=auto_reset, max_steps=9)
+        env.reset()
+        actor = ParticleActor(w, N, stage=stage, device="cuda:0", seed=seed, precision=precision)
+        ro = ParticleRollout(env, n_ticks=T, use_graph=False, fused=fused).collect(policy=actor, epsilon=0.15, reset=False)
+        outs.append((ro, env))
+    a, b = outs[0][0], outs[1][0]
+    for name in ("actions", "state", "obs_others", "reward", "reward_n", "done"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    if auto_reset:
+        assert torch.equal(a.goals, b.goals)
+        d = a.done.bool()
+        assert int(d.sum()) > 0
+        assert torch.equal(a.term_state.permute(0, 2, 1, 3)[d], b.term_state.permute(0, 2, 1, 3)[d])
+        assert torch.equal(a.term_obs_others[d], b.term_obs_others[d])
+    ea, eb = outs[0][1], outs[1][1]
+    assert torch.equal(ea.steps, eb.steps) and torch.equal(ea.collisions, eb.collisions)
+    assert torch.equal(ea.episode, eb.episode) and torch.equal(ea.global_state, eb.global_state)

@@ -19,11 +19,11 @@ def main():
     dev = torch.device("cuda", 0)
     torch.cuda.set_stream(torch.cuda.Stream(device=dev))
     cfg = cm3_amd.load_config("particle_stage2_antipodal")
-    for E, prec in [(e, pr) for e in (4096, 65536, 1 << 20) for pr in ("f32", "bf16")]:
+    for E, prec, fused in [(e, pr, fu) for e in (4096, 65536, 1 << 20) for pr in ("f32", "bf16") for fu in (False, True)]:
         env = VecParticleEnv(cfg, 4, 0.2, 33, E, device=dev, auto_reset=True)
         env.reset()
         actor = ParticleActor(init_weights(np.random.default_rng(0), 4), 4, device=dev, precision=prec)
-        ro = ParticleRollout(env, use_graph=True)
+        ro = ParticleRollout(env, use_graph=True, fused=fused)
         for _ in range(3):
             ro.collect(policy=actor, epsilon=0.1, reset=False)
         torch.cuda.synchronize()
@@ -35,7 +35,7 @@ def main():
         b.record()
         b.synchronize()
         us = a.elapsed_time(b) * 1e3 / (reps * 33)
-        print(json.dumps({"envs": E, "actor_precision": prec, "us_per_tick_actor_plus_step": round(us, 2), "env_steps_per_s": E / us * 1e6}))
+        print(json.dumps({"envs": E, "actor_precision": prec, "one_launch_per_episode": fused, "us_per_tick_actor_plus_step": round(us, 2), "env_steps_per_s": E / us * 1e6}))
         ro.close()
         del ro, env
         torch.cuda.empty_cache()
