@@ -451,7 +451,6 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step(const ParticlePara
 
     // ---- same-launch re-initialisation of finished episodes -------------------------------------------
     bool was_reset = false;
-#ifndef CM3_EXPERIMENT_NO_RESET
     if ((p.flags & CM3_FLAG_AUTO_RESET) && done) {
       if (active) {
         void *term_state = tick_ptr(p.term_state, p.st_term_state, t);
@@ -469,7 +468,6 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step(const ParticlePara
       collisions = 0;
       was_reset = true;
     }
-#endif
     CM3_STAMP(9, false);
 
     if (active) {
@@ -640,7 +638,6 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_pairs(const Partic
 
     // ---- same-launch re-initialisation -------------------------------------------------------------------------
     bool was_reset = false;
-#ifndef CM3_EXPERIMENT_NO_RESET
     if ((p.flags & CM3_FLAG_AUTO_RESET) && done) {
       if (env_ok) {
         void *term_state = tick_ptr(p.term_state, p.st_term_state, t);
@@ -657,7 +654,6 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_pairs(const Partic
       collisions = 0;
       was_reset = true;
     }
-#endif
 
     // ---- per-tick stores ------------------------------------------------------------------------------------------
     if (env_ok) {
