@@ -315,3 +315,35 @@ def test_both_kernel_mappings_agree_bitwise(N, cfg_name, dtype):
         assert torch.equal(a.goals, b.goals) and torch.equal(a.episode, b.episode)
     assert torch.equal(a.terminal_state, b.terminal_state)
     assert torch.equal(a.terminal_obs_others, b.terminal_obs_others)
+
+
+@pytest.mark.parametrize("N", [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_f64_free_running_random_configs_all_agent_counts(N, kernel):
+    """33 free-running ticks in float64 from random crowded states, random (also out-of-range) actions, for every
+    agent count and both kernel mappings: state / obs / rewards / done / collisions against the NumPy oracle."""
+    if N == 1 and kernel == "pair":
+        pytest.skip("the pair mapping needs at least two agents")
+    rng = np.random.default_rng(100 + N)
+    cfg = dict(n_agents=N, agents_x=rng.uniform(-1, 1, N).tolist(), agents_y=rng.uniform(-1, 1, N).tolist(),
+               landmarks_x=rng.uniform(-1, 1, N).tolist(), landmarks_y=rng.uniform(-1, 1, N).tolist(), initial_std=0.1)
+    E = 500
+    env = _env(cfg, N, E, dtype=torch.float64, kernel=kernel, max_steps=20)
+    orc = VecParticleOracle(N, cfg, 0.2, 20, E)
+    pos, vel, lm = _random_states(rng, E, N, crowd=0.7)
+    env.set_state(pos, vel, lm)
+    orc.set_state(pos, vel, lm)
+    for t in range(33):
+        acts = rng.integers(-1, 7, (E, N))
+        w_gs, w_oo, _, w_rew, w_rn, w_done = orc.step(acts)
+        gs, oo, _, rew, rew_n, done = env.step(torch.as_tensor(acts))
+        scale = 1.0 + np.abs(w_gs).max()
+        assert _maxabs(_np(gs) - w_gs) < 1e-9 * scale, (N, t)
+        assert _maxabs(_np(oo) - w_oo) < 2e-9 * scale
+        m_col, m_reach = orc.pair_margins()
+        safe = (m_col > 1e-9) & (m_reach > 1e-9)
+        assert safe.mean() > 0.99
+        assert _maxabs(_np(rew_n)[safe] - w_rn[safe]) < 1e-9 * scale
+        assert _maxabs(_np(rew)[safe] - w_rew[safe]) < 1e-8 * scale
+        assert np.array_equal(done.cpu().numpy()[safe], w_done[safe])
+        assert np.array_equal(env.steps.cpu().numpy(), orc.steps)
