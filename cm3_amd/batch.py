@@ -73,3 +73,29 @@ def repeat_indexed_by_n(x, n_agents):
 def repeat_indexed_by_m(x, n_agents):
     """[B*N, d] -> [B*N*N, d]: every row repeated N times consecutively (alg_credit.py:628-629, :651-652)."""
     return x.repeat_interleave(n_agents, dim=0)
+
+
+# ---- Checkers (alg_credit_checkers.py:375-535) ---------------------------------------------------------------------------
+
+def process_batch_checkers(cols, l_action=5):
+    """Columns of CheckersRollout.as_reference_batch(numpy=False) -> the 18-tuple of
+    alg_credit_checkers.Alg.process_batch (alg_credit_checkers.py:414-482): per-agent rows; grid and done repeated N
+    times, `reward` left per time step (unlike the particle variant), both action columns one-hot."""
+    vec = cols["vec"]
+    B, N = vec.shape[0], vec.shape[1]
+    rep = lambda x: x.repeat_interleave(N, dim=0)              # noqa: E731
+    rows = lambda x: x.reshape(B * N, *x.shape[2:])            # noqa: E731
+    a1, ao = process_actions(cols["actions"], l_action)
+    prev1 = torch.nn.functional.one_hot(cols["actions_prev"].long(), l_action).reshape(B * N, l_action)
+    return (B, rep(cols["grid"]), vec, rows(cols["obs_others"]), rows(cols["obs_self_t"]), rows(cols["obs_self_v"]),
+            prev1, a1, ao, cols["reward"], cols["local_rewards"].reshape(B * N), rep(cols["next_grid"]),
+            cols["next_vec"], rows(cols["next_obs_others"]), rows(cols["next_obs_self_t"]),
+            rows(cols["next_obs_self_v"]), rep(cols["done"]), cols["goals"])
+
+
+CHECKERS_BATCH_NAMES = ("n_steps", "state_env", "state_agents", "obs_others", "obs_self_t", "obs_self_v",
+                        "actions_prev_1hot", "actions_1hot", "actions_others_1hot", "reward", "reward_local",
+                        "state_env_next", "state_agents_next", "obs_others_next", "obs_self_t_next", "obs_self_v_next",
+                        "done", "goals")
+# process_goals / process_global_state of alg_credit_checkers.py:484-535 are the particle functions above, verbatim
+# in behaviour (l_goal = 2, l_state_one_agent = 4): use process_goals(goals) and process_global_state(state_agents).

@@ -64,6 +64,48 @@ def main():
     rec["reward_local_rep"] = np.reshape(np.repeat(np.reshape(out[7], [-1, n]), n, axis=0), [-1])
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "batch_particle.npz"), **rec)
     print("wrote batch_particle.npz:", {k: v.shape for k, v in rec.items() if hasattr(v, "shape")})
+    checkers()
+
+
+def checkers():
+    """alg_credit_checkers.Alg.process_batch / process_goals / process_global_state (alg_credit_checkers.py:414-535) on one
+    recorded Checkers episode -> tests/golden/batch_checkers.npz."""
+    from cm3_amd.rollout import CHECKERS_ORDER, rows_from_columns
+    import json
+    import alg_credit_checkers as mod
+    g = np.load(os.path.join(ROOT, "tests", "golden", "checkers_stage2_uniform.npz"))
+    d = json.loads(str(g["meta"]))["config"]["dimensions"]
+    ep, N = 1, 2
+    T = int(g["ep_len"][ep])
+
+    def seq(init, per_tick):
+        return np.concatenate([g[init][ep][None], g[per_tick][ep, :T]])
+    grid, vec = seq("init_grid", "grid"), seq("init_vec", "vec")
+    oo, ot, ov = seq("init_obs_others", "obs_others"), seq("init_obs_self_t", "obs_self_t"), seq("init_obs_self_v", "obs_self_v")
+    acts = g["actions"][ep, :T]
+    prev = np.concatenate([np.zeros((1, N), acts.dtype), acts[:-1]])
+    cols = dict(grid=grid[:-1], vec=vec[:-1], obs_others=oo[:-1], obs_self_t=ot[:-1], obs_self_v=ov[:-1],
+                actions_prev=prev, actions=acts, reward=g["reward"][ep, :T], local_rewards=g["local_rewards"][ep, :T],
+                next_grid=grid[1:], next_vec=vec[1:], next_obs_others=oo[1:], next_obs_self_t=ot[1:],
+                next_obs_self_v=ov[1:], done=g["done"][ep, :T],
+                goals=np.repeat(g["goals"][ep][None], T, axis=0).astype(float))
+    alg = mod.Alg.__new__(mod.Alg)
+    alg.n_agents, alg.l_action, alg.experiment = N, d["l_action"], "checkers"
+    alg.l_obs_others, alg.l_obs_self, alg.l_goal = d["l_obs_others"], d["l_obs_self"], d["l_goal"]
+    alg.rows_obs, alg.columns_obs, alg.channels_obs = d["rows_obs"], d["columns_obs"], d["channels_obs"]
+    alg.l_state_one_agent, alg.l_state = d["l_state_one"], N * d["l_state_one"]
+    out = alg.process_batch(rows_from_columns({k: np.array(v) for k, v in cols.items()}, CHECKERS_ORDER))
+    names = ("n_steps", "state_env", "state_agents", "obs_others", "obs_self_t", "obs_self_v", "actions_prev_1hot",
+             "actions_1hot", "actions_others_1hot", "reward", "reward_local", "state_env_next", "state_agents_next",
+             "obs_others_next", "obs_self_t_next", "obs_self_v_next", "done", "goals")
+    rec = {"in_" + k: v for k, v in cols.items()}
+    for k, v in zip(names, out):
+        rec["pb_" + k] = np.asarray(v)
+    gself, gothers = alg.process_goals(out[17], out[0])
+    one, others, state = alg.process_global_state(out[2], out[0])
+    rec.update(goals_self=gself, goals_others=gothers, vg_one=one, vg_others=others, vg_state=state)
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "batch_checkers.npz"), **rec)
+    print("wrote batch_checkers.npz:", {k: (v.shape, v.dtype) for k, v in rec.items() if hasattr(v, "shape")})
 
 
 if __name__ == "__main__":

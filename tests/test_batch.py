@@ -47,3 +47,53 @@ def test_batch_reformatting_matches_reference_cpu_tensors():
 @pytest.mark.gpu
 def test_batch_reformatting_matches_reference_on_device():
     _check("cuda:0")
+
+
+GOLD_CK = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "batch_checkers.npz")
+
+
+def _check_checkers(device):
+    """alg_credit_checkers.Alg.process_batch / process_goals / process_global_state (recorded from the REAL reference)."""
+    z = np.load(GOLD_CK)
+    cols = {k[3:]: torch.as_tensor(z[k]).to(device) for k in z.files if k.startswith("in_")}
+    out = B.process_batch_checkers(cols)
+    assert out[0] == int(z["pb_n_steps"]) and len(out) == len(B.CHECKERS_BATCH_NAMES)
+    for name, got in zip(B.CHECKERS_BATCH_NAMES[1:], out[1:]):
+        want = z["pb_" + name]
+        g = got.cpu().numpy()
+        assert g.shape == want.shape, (name, g.shape, want.shape)
+        assert np.array_equal(g, want), name
+        assert g.dtype == want.dtype, (name, g.dtype, want.dtype)
+    gs, go = B.process_goals(out[17])
+    assert np.array_equal(gs.cpu().numpy(), z["goals_self"]) and np.array_equal(go.cpu().numpy(), z["goals_others"])
+    one, others, state = B.process_global_state(out[2])
+    assert np.array_equal(one.cpu().numpy(), z["vg_one"])
+    assert np.array_equal(others.cpu().numpy(), z["vg_others"])
+    assert np.array_equal(state.cpu().numpy(), z["vg_state"])
+
+
+def test_checkers_batch_reformatting_matches_reference_cpu_tensors():
+    _check_checkers("cpu")
+
+
+@pytest.mark.gpu
+def test_checkers_batch_reformatting_matches_reference_on_device():
+    _check_checkers("cuda:0")
+
+
+@pytest.mark.gpu
+def test_checkers_rollout_columns_feed_process_batch():
+    """Device columns of a real CheckersRollout go through process_batch_checkers with the documented shapes/dtypes."""
+    from cm3_amd.checkers import VecCheckersEnv
+    from cm3_amd.rollout import CheckersRollout
+    from tests.helpers import load_cfg
+    cfg = load_cfg("checkers_stage2.json")
+    env = VecCheckersEnv(cfg["init"], 2, 33, 64, device="cuda:0", seed=5)
+    ro = CheckersRollout(env).collect(np.eye(2))
+    cols = ro.as_reference_batch(numpy=False)
+    out = B.process_batch_checkers(cols)
+    n = out[0]
+    assert n == int(ro.valid.sum())
+    assert out[1].shape == (2 * n, 3, 9, 2) and out[4].shape == (2 * n, 5, 5, 3) and out[9].shape == (n,)
+    assert out[6].dtype == torch.int64 and out[8].dtype == torch.float64 and out[16].dtype == torch.bool
+    assert torch.equal(out[7].argmax(1), cols["actions"].reshape(-1).long())
