@@ -95,6 +95,23 @@ class ActorParticleBufs(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in ("obs_others", "state", "goals", "meta", "episode", "actions", "probs")]
 
 
+class ActorCheckersDesc(ctypes.Structure):
+    _fields_ = [("n_envs", c_int32), ("n_agents", c_int32), ("stage", c_int32), ("n_obs", c_int32),
+                ("conv_f", c_int32), ("n_conv_linear", c_int32), ("n_h1", c_int32), ("n_h2", c_int32),
+                ("n_actions", c_int32), ("epsilon", ctypes.c_float), ("precision", c_int32),
+                ("obs_self_t_stride", c_int32), ("env_id_base", c_int64), ("seed", c_uint64)]
+
+
+class ActorCheckersWeights(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in ("conv_w", "conv_b", "lin_w", "lin_b", "self_w", "self_b", "w_self_h2",
+                                        "others_w", "others_b", "w_others_h2", "b_h2", "out_w", "out_b", "packed")]
+
+
+class ActorCheckersBufs(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in ("obs_self_t", "obs_self_v", "obs_others", "goals", "actions_prev", "steps",
+                                        "episode", "actions", "probs")]
+
+
 # every symbol include/cm3_amd.h declares: name -> (restype, argtypes)
 P = ctypes.POINTER
 SYMBOLS = {
@@ -119,6 +136,10 @@ SYMBOLS = {
                                               c_void_p]),
     "cm3_policy_rollout_f32": (ctypes.c_int, [P(ParticleDesc), P(ParticleTraj), P(ActorParticleDesc),
                                               P(ActorParticleWeights), c_void_p, c_size_t, c_int32, c_void_p]),
+    "cm3_actor_checkers_packed_bytes": (c_size_t, []),
+    "cm3_actor_checkers_pack": (ctypes.c_int, [P(ActorCheckersDesc), P(ActorCheckersWeights), c_void_p, c_void_p]),
+    "cm3_actor_checkers_f32": (ctypes.c_int, [P(ActorCheckersDesc), P(ActorCheckersWeights), P(ActorCheckersBufs),
+                                              c_void_p]),
     "cm3_returns_scratch_bytes": (c_size_t, []),
     "cm3_returns_moments_f32": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                c_int32, c_int32, c_int32, c_double, c_void_p]),

@@ -111,3 +111,104 @@ class ParticleActor(object):
         self.enqueue(env.E, env._obs_others[cur], env._state[cur], env._goals, env._meta, env._episode, actions,
                      epsilon, probs, env_id_base=env.env_id_base)
         return (actions, probs) if return_probs else actions
+
+
+_CK_NAMES = {
+    "conv_w": "conv/Conv/weights", "conv_b": "conv/Conv/biases", "lin_w": "conv_linear/kernel",
+    "lin_b": "conv_linear/bias", "self_w": "branch_self/kernel", "self_b": "branch_self/bias", "w_self_h2": "W_self_h2",
+    "others_w": "stage-2/branch_others/kernel", "others_b": "stage-2/branch_others/bias",
+    "w_others_h2": "stage-2/W_others_h2", "b_h2": "b", "out_w": "actor_out/kernel", "out_b": "actor_out/bias"}
+CK_CONV_F, CK_CONV_LIN, CK_H1, CK_H2 = 6, 32, 256, 256
+
+
+class CheckersActor(object):
+    """The reference's Checkers policy evaluated on the device.
+
+        reference                                                        here
+        -------------------------------------------------------------   ----------------------------------------
+        networks.actor_checkers(a_prev, t_obs_self, v_obs_self,          CheckersActor(weights, n_agents, stage)
+            v_obs_others, v_goal, f1=6, k1=[3,3], n_h1=256, n_h2=256)      weights: dict keyed by the TF variable names
+            (networks.py:549-578; conv: convnet_1 :67-75)
+        probs = (1-eps) probs + eps/5; multinomial                       actor.act(env, epsilon, actions_prev)
+            (alg_credit_checkers.py:112-113)                               -> actions [E, N] (one launch)
+        alg.run_actor(actions_prev, obs_others, obs_self_t, obs_self_v,  CheckersRollout.collect(goals, policy=actor,
+            goals, eps, sess)  (alg_credit_checkers.py:229-253)            epsilon=..): actor and step launches alternate
+                                                                           inside ONE hipGraph
+    """
+
+    def __init__(self, weights, n_agents, stage=2, device="cuda:0", seed=12341, env_id_base=0):
+        self.device = _lib.require_gpu(device)
+        self.n = int(n_agents)
+        self.stage = int(stage)
+        self.Lo = 2 * max(self.n - 1, 1)
+        self.seed = int(seed)
+        self.env_id_base = int(env_id_base)
+        src = {_canon(k): v for k, v in weights.items()}
+        cat = CK_CONV_LIN + 4 + N_ACTIONS + 2
+        shapes = {"conv_w": (3, 3, 3, CK_CONV_F), "conv_b": (CK_CONV_F,), "lin_w": (25 * CK_CONV_F, CK_CONV_LIN),
+                  "lin_b": (CK_CONV_LIN,), "self_w": (cat, CK_H1), "self_b": (CK_H1,), "w_self_h2": (CK_H1, CK_H2),
+                  "b_h2": (CK_H2,), "out_w": (CK_H2, N_ACTIONS), "out_b": (N_ACTIONS,)}
+        if self.stage > 1:
+            shapes.update({"others_w": (self.Lo, CK_H1), "others_b": (CK_H1,), "w_others_h2": (CK_H1, CK_H2)})
+        self.w = {}
+        for short, shape in shapes.items():
+            name = _CK_NAMES[short]
+            if name not in src:
+                raise Cm3Error("missing actor weight %r" % name)
+            t = torch.as_tensor(np.asarray(src[name]), dtype=torch.float32).contiguous()
+            if tuple(t.shape) != shape:
+                raise Cm3Error("actor weight %r has shape %s, expected %s" % (name, tuple(t.shape), shape))
+            self.w[short] = t.to(self.device)
+        self._wt = _lib.ActorCheckersWeights()
+        for short in _CK_NAMES:
+            setattr(self._wt, short, _lib.ptr(self.w.get(short)))
+        self._lib = _lib.lib()
+        nbytes = self._lib.cm3_actor_checkers_packed_bytes()
+        self._packed = torch.zeros(nbytes // 4, dtype=torch.float32, device=self.device)
+        self._wt.packed = self._packed.data_ptr()
+        self.repack()
+
+    def _desc(self, n_envs, epsilon, env_id_base, obst_stride):
+        d = _lib.ActorCheckersDesc()
+        d.n_envs, d.n_agents, d.stage, d.n_obs = int(n_envs), self.n, self.stage, 2
+        d.conv_f, d.n_conv_linear, d.n_h1, d.n_h2, d.n_actions = CK_CONV_F, CK_CONV_LIN, CK_H1, CK_H2, N_ACTIONS
+        d.epsilon = float(epsilon)
+        d.precision = 0
+        d.obs_self_t_stride = int(obst_stride)
+        d.env_id_base = int(env_id_base)
+        d.seed = self.seed & 0xFFFFFFFFFFFFFFFF
+        return d
+
+    def repack(self):
+        d = self._desc(1, 0.0, 0, 75 * self.n)
+        _lib.check(self._lib.cm3_actor_checkers_pack(ctypes.byref(d), ctypes.byref(self._wt), self._packed.data_ptr(),
+                                                     _lib.current_stream_handle(self.device)))
+
+    def enqueue(self, n_envs, obs_self_t_raw, obst_stride, obs_self_v, obs_others, goals, actions_prev, steps, episode,
+                actions, epsilon, probs=None, stream=None, env_id_base=None):
+        """Raw launch on the env's device buffers (obs_self_t_raw: the int8 storage with obst_stride bytes per env)."""
+        b = _lib.ActorCheckersBufs()
+        b.obs_self_t, b.obs_self_v, b.obs_others = _lib.ptr(obs_self_t_raw), _lib.ptr(obs_self_v), _lib.ptr(obs_others)
+        b.goals, b.actions_prev, b.steps, b.episode = (_lib.ptr(goals), _lib.ptr(actions_prev), _lib.ptr(steps),
+                                                       _lib.ptr(episode))
+        b.actions, b.probs = _lib.ptr(actions), _lib.ptr(probs)
+        d = self._desc(n_envs, epsilon, self.env_id_base if env_id_base is None else env_id_base, obst_stride)
+        s = _lib.current_stream_handle(self.device) if stream is None else stream
+        _lib.check(self._lib.cm3_actor_checkers_f32(ctypes.byref(d), ctypes.byref(self._wt), ctypes.byref(b), s))
+
+    def act(self, env, epsilon, actions_prev=None, return_probs=False):
+        """Actions [E, N] int32 for the env's CURRENT observation (alg.run_actor); actions_prev None = zeros
+        (train_onpolicy.py:295)."""
+        if env.n != self.n:
+            raise Cm3Error("actor built for %d agents, env has %d" % (self.n, env.n))
+        if env.K != 5:
+            raise Cm3Error("the device actor reads 5x5 windows (n_obs = 2)")
+        s = env._slots[env._cur]
+        prev = None
+        if actions_prev is not None:
+            prev = torch.as_tensor(actions_prev, device=self.device).to(torch.int32).reshape(env.E, env.n).contiguous()
+        actions = torch.empty(env.E, env.n, dtype=torch.int32, device=self.device)
+        probs = torch.empty(env.E, env.n, N_ACTIONS, dtype=torch.float32, device=self.device) if return_probs else None
+        self.enqueue(env.E, s["obs_self_t_raw"], env.obst_stride, s["obs_self_v"], s["obs_others"], env._goals, prev,
+                     env._steps, env._episode, actions, epsilon, probs, env_id_base=env._desc.env_id_base)
+        return (actions, probs) if return_probs else actions

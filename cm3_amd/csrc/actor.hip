@@ -15,13 +15,11 @@
 // stream.  float32 throughout, like the reference graph.  (A first version streamed the weights through the scalar
 // cache into SGPR operands of VALU FMAs: correct, but SGPR capacity made it latency-bound -- 23 us per tick at
 // 4096 envs x 4 agents.)
-#include "common.h"
-#include "philox.h"
+#include "actor_common.h"
 
 namespace cm3 {
 
-constexpr int kH1S = 64, kH1O = 128, kH2 = 64, kA = 5;
-constexpr uint32_t kPurposePolicy = 0x40000000u;
+constexpr int kH1S = 64, kH1O = 128, kH2 = 64;
 
 struct ActorParams {
   int E, stage;
@@ -91,8 +89,6 @@ template <int N> __global__ void __launch_bounds__(256) k_actor_pack(const Actor
   }
 }
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // ---- building blocks shared by k_actor_particle (one tick) and k_policy_rollout (policy.hip: a whole policy-driven
 // episode in one launch).  A workgroup = 4 waves (one per SIMD of a CU) = 64 agent rows (row r = e*N + i).
@@ -319,32 +315,6 @@ __device__ __forceinline__ void actor_head_probs(const float (*h2s)[kH2 + 1], co
   const float inv = 1.0f / sum;
 #pragma unroll
   for (int a = 0; a < kA; ++a) pr[a] = (1.0f - eps) * (o[a] * inv) + eps / (float)kA;
-}
-
-// action ~ multinomial(probs) (alg_credit.py:120): inverse CDF in action order, one uniform from the Philox stream
-// keyed (seed, global env id, episode, step | agent)
-__device__ __forceinline__ int actor_sample(const float (&pr)[kA], uint64_t seed, uint64_t genv, uint32_t episode,
-                                            int steps, int agent) {
-  u32x4 ctr;
-  ctr.x = (uint32_t)genv;
-  ctr.y = (uint32_t)(genv >> 32);
-  ctr.z = episode;
-  ctr.w = kPurposePolicy | ((uint32_t)(agent >> 2) << 24) | ((uint32_t)steps & 0x00FFFFFFu);
-  const u32x4 wd = philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
-  const int q = agent & 3;
-  const float u = (float)u01(q == 0 ? wd.x : (q == 1 ? wd.y : (q == 2 ? wd.z : wd.w)));
-  int act = kA - 1;
-  float cdf = 0.0f;
-  bool chosen = false;
-#pragma unroll
-  for (int a = 0; a < kA - 1; ++a) {
-    cdf += pr[a];
-    if (!chosen && u < cdf) {
-      act = a;
-      chosen = true;
-    }
-  }
-  return act;
 }
 
 template <int N, bool BF16> __global__ void __launch_bounds__(256) k_actor_particle(const ActorParams p) {

@@ -1,0 +1,415 @@
+// On-device actor for Checkers: forward pass + epsilon-mixed categorical sampling for all E*N agent rows in one launch
+// (Checkers variant).
+//
+// Reference being replaced:
+//   networks.convnet_1 + networks.actor_checkers   /root/reference/alg/networks.py:67-75, :549-578
+//   probs = (1-eps) probs + eps/5, multinomial     /root/reference/alg/alg_credit_checkers.py:107-113
+//   Alg.run_actor (actions_prev -> one-hot)        /root/reference/alg/alg_credit_checkers.py:229-253
+// Widths (config_checkers_stage{1,2}.json "nn"): conv 3x3x3 -> 6 filters over the 5x5x3 window, conv_linear 150 -> 32,
+// concat(32 + 4 + 5 + 2 = 43) -> 256, [256 | 256] -> 256, 256 -> 5.  153 k MACs per agent row, 86 % of them in the
+// 512 -> 256 layer: unlike the env kernels this IS contraction work, so every layer runs on the matrix cores with the
+// exact-f32 MFMA (v_mfma_f32_16x16x4_f32; float32 products and accumulation like the TF graph).
+//
+// Mapping: a 256-thread workgroup (4 waves, one per SIMD of a CU) owns 64 agent rows (row = e*N + i); activations live in
+// LDS as [64][K + 4] float tiles (row stride = 4 mod 64 words: the 16-byte A-operand reads of 16 rows hit 16 distinct
+// bank quads).  Every layer is the same tile loop (gemm_tiles): for a k-group of 16 inputs, one ds_read_b128 per 16-row
+// tile gives the A operands of four MFMA k-steps, one 16-byte global load per 16-column tile gives the matching B
+// operands from the PACKED weights (cm3_actor_checkers_pack: per-lane MFMA order, so a wave's load is one contiguous
+// KB; the packed weights are 0.7 MB and stay in L2).  k-step j of group g contracts inputs {16g + 4h + j : h = 0..3} --
+// any partition of K into fours is a valid summation order.
+//   conv      : the 3x3 SAME convolution as a [80 x 160] Toeplitz matrix (zeros for out-of-window taps and padding)
+//   wave tiles: conv 2 row x 5 col tiles, conv_linear 2 x 1, branch_self / branch_others / h2: 4 x 4 (all 64 rows x 64
+//               columns per wave, 64 accumulator VGPRs), actor_out: wave w finishes rows [16w, 16w+16).
+#include "actor_common.h"
+
+namespace cm3 {
+
+namespace ck_actor {
+constexpr int kConvF = 6, kLin = 32, kH1 = 256, kH2 = 256;
+constexpr int kObs = 75;                       // 5 x 5 x 3 window
+constexpr int kKConv = 80, kNConv = 160;       // 75 -> 80 inputs, 150 -> 160 outputs
+constexpr int kKLin = 160, kNLin = 32;
+constexpr int kKSelf = 48, kCat = 43;          // 32 + 4 + 5 + 2 -> 48
+constexpr int kKOth = 16;                      // 2 (N-1) <= 14 -> 16
+// LDS row strides (floats): K + 4
+constexpr int kLdX0 = kKConv + 4, kLdC1 = kNConv + 4, kLdX2 = kKSelf + 4, kLdXO = kKOth + 4, kLdH = kH1 + 4;
+
+// packed weights (floats).  B tiles: [col tile][k group][lane][4]; biases follow each matrix, padded to the tile width.
+constexpr int tiles(int k, int n) { return (n / 16) * (k / 16) * 256; }
+constexpr int kPConv = 0;
+constexpr int kPConvB = kPConv + tiles(kKConv, kNConv);
+constexpr int kPLin = kPConvB + kNConv;
+constexpr int kPLinB = kPLin + tiles(kKLin, kNLin);
+constexpr int kPSelf = kPLinB + kNLin;
+constexpr int kPSelfB = kPSelf + tiles(kKSelf, kH1);
+constexpr int kPOth = kPSelfB + kH1;
+constexpr int kPOthB = kPOth + tiles(kKOth, kH1);
+constexpr int kPH2S = kPOthB + kH1;
+constexpr int kPH2O = kPH2S + tiles(kH1, kH2);
+constexpr int kPH2B = kPH2O + tiles(kH1, kH2);
+constexpr int kPOut = kPH2B + kH2;
+constexpr int kPOutB = kPOut + tiles(kH2, 16);
+constexpr int kPTotal = kPOutB + 16;
+}  // namespace ck_actor
+
+struct CkActorParams {
+  int E, N, stage, Lo;
+  float eps;
+  int64_t env_id_base;
+  uint64_t seed;
+  int obst_stride;  // bytes between envs of obs_self_t
+  const int8_t *obs_self_t;
+  const double *obs_self_v, *obs_others;
+  const uint8_t *goals;
+  const int32_t *actions_prev, *steps, *episode;
+  int32_t *actions;
+  float *probs;
+  const float *packed;
+  // pack kernel only (TensorFlow shapes)
+  const float *conv_w, *conv_b, *lin_w, *lin_b, *self_w, *self_b, *w_self_h2, *oth_w, *oth_b, *w_oth_h2, *b_h2, *out_w,
+      *out_b;
+};
+
+// ---- pack: TF-shaped weights -> per-lane MFMA order ------------------------------------------------------------------
+// element (k, n) of the logical [K][Ncols] matrix of each layer, zero outside the real extent
+__device__ __forceinline__ float ck_conv_toeplitz(const CkActorParams &p, int k, int n) {
+  using namespace ck_actor;
+  if (k >= kObs || n >= 25 * kConvF) return 0.0f;
+  const int pin = k / 3, ch = k - 3 * pin, r = pin / 5, c = pin - 5 * r;          // input (r, c, ch)
+  const int pout = n / kConvF, f = n - kConvF * pout, ro = pout / 5, co = pout - 5 * ro;  // output (ro, co, f)
+  const int dr = r - ro + 1, dc = c - co + 1;  // out[ro][co] += x[ro + dr - 1][co + dc - 1] w[dr][dc]
+  if (dr < 0 || dr > 2 || dc < 0 || dc > 2) return 0.0f;
+  return p.conv_w[((dr * 3 + dc) * 3 + ch) * kConvF + f];
+}
+
+__global__ void __launch_bounds__(256) k_ck_actor_pack(const CkActorParams p, float *out) {
+  using namespace ck_actor;
+  const bool stage2 = p.stage > 1;
+  for (int t = blockIdx.x * 256 + threadIdx.x; t < kPTotal; t += gridDim.x * 256) {
+    // which section?
+    int base, K, layer;
+    if (t < kPConvB) { base = kPConv; K = kKConv; layer = 0; }
+    else if (t < kPLin) { base = kPConvB; K = 0; layer = 10; }
+    else if (t < kPLinB) { base = kPLin; K = kKLin; layer = 1; }
+    else if (t < kPSelf) { base = kPLinB; K = 0; layer = 11; }
+    else if (t < kPSelfB) { base = kPSelf; K = kKSelf; layer = 2; }
+    else if (t < kPOth) { base = kPSelfB; K = 0; layer = 12; }
+    else if (t < kPOthB) { base = kPOth; K = kKOth; layer = 3; }
+    else if (t < kPH2S) { base = kPOthB; K = 0; layer = 13; }
+    else if (t < kPH2O) { base = kPH2S; K = kH1; layer = 4; }
+    else if (t < kPH2B) { base = kPH2O; K = kH1; layer = 5; }
+    else if (t < kPOut) { base = kPH2B; K = 0; layer = 14; }
+    else if (t < kPOutB) { base = kPOut; K = kH2; layer = 6; }
+    else { base = kPOutB; K = 0; layer = 15; }
+    const int u = t - base;
+    float v = 0.0f;
+    if (layer < 10) {
+      const int j = u & 3, lane = (u >> 2) & 63, gi = u >> 8, KG = K / 16, g = gi % KG, ct = gi / KG;
+      const int k = 16 * g + 4 * (lane >> 4) + j, n = 16 * ct + (lane & 15);
+      switch (layer) {
+        case 0: v = ck_conv_toeplitz(p, k, n); break;
+        case 1: v = k < 25 * kConvF ? p.lin_w[k * kLin + n] : 0.0f; break;
+        case 2: v = k < kCat ? p.self_w[k * kH1 + n] : 0.0f; break;
+        case 3: v = (stage2 && k < p.Lo) ? p.oth_w[k * kH1 + n] : 0.0f; break;
+        case 4: v = p.w_self_h2[k * kH2 + n]; break;
+        case 5: v = stage2 ? p.w_oth_h2[k * kH2 + n] : 0.0f; break;
+        default: v = n < kA ? p.out_w[k * kA + n] : 0.0f; break;
+      }
+    } else {
+      switch (layer) {
+        case 10: v = u < 25 * kConvF ? p.conv_b[u % kConvF] : 0.0f; break;
+        case 11: v = p.lin_b[u]; break;
+        case 12: v = p.self_b[u]; break;
+        case 13: v = stage2 ? p.oth_b[u] : 0.0f; break;
+        case 14: v = p.b_h2[u]; break;
+        default: v = u < kA ? p.out_b[u] : 0.0f; break;
+      }
+    }
+    out[t] = v;
+  }
+}
+
+// ---- the tile loop -----------------------------------------------------------------------------------------------------
+// acc[t][c] += A[16 (rt0 + t) .. +16][0 .. 16 KG) x B[.., 16 (ct0 + c) .. +16].  A: LDS, row stride lda floats;
+// Bp: packed tiles of this layer.  B operands of group g + 1 are requested before the MFMAs of group g issue.
+template <int RT, int CT, int KG>
+__device__ __forceinline__ void gemm_tiles(const float *A, int lda, int rt0, const float *Bp, int ct0, int lane,
+                                           f32x4 (&acc)[RT][CT]) {
+  const int col = lane & 15, hi = lane >> 4;
+  const float4 *bsrc[CT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c) bsrc[c] = reinterpret_cast<const float4 *>(Bp) + ((size_t)(ct0 + c) * KG) * 64 + lane;
+  const float *arow[RT];
+#pragma unroll
+  for (int t = 0; t < RT; ++t) arow[t] = A + (16 * (rt0 + t) + col) * lda + 4 * hi;
+  float4 bcur[CT], bnext[CT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c) bcur[c] = bsrc[c][0];
+#pragma unroll
+  for (int g = 0; g < KG; ++g) {
+    if (g + 1 < KG) {
+#pragma unroll
+      for (int c = 0; c < CT; ++c) bnext[c] = bsrc[c][(g + 1) * 64];
+    }
+    float4 a[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) a[t] = *reinterpret_cast<const float4 *>(arow[t] + 16 * g);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int t = 0; t < RT; ++t) {
+        const float av = j == 0 ? a[t].x : (j == 1 ? a[t].y : (j == 2 ? a[t].z : a[t].w));
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+          const float bv = j == 0 ? bcur[c].x : (j == 1 ? bcur[c].y : (j == 2 ? bcur[c].z : bcur[c].w));
+          acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[t][c], 0, 0, 0);
+        }
+      }
+    }
+    if (g + 1 < KG) {
+#pragma unroll
+      for (int c = 0; c < CT; ++c) bcur[c] = bnext[c];
+    }
+  }
+}
+
+template <int RT, int CT> __device__ __forceinline__ void zero_tiles(f32x4 (&acc)[RT][CT]) {
+#pragma unroll
+  for (int t = 0; t < RT; ++t)
+#pragma unroll
+    for (int c = 0; c < CT; ++c) acc[t][c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+}
+
+// O[row][col] = relu(acc + bias[col]); C layout: col = l & 15, row = 4 (l >> 4) + reg
+template <int RT, int CT>
+__device__ __forceinline__ void store_relu(float *O, int ldo, int rt0, int ct0, const float *bias, int lane,
+                                           const f32x4 (&acc)[RT][CT]) {
+  const int col = lane & 15, hi = lane >> 4;
+#pragma unroll
+  for (int c = 0; c < CT; ++c) {
+    const float b = bias[16 * (ct0 + c) + col];
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg)
+        O[(16 * (rt0 + t) + 4 * hi + reg) * ldo + 16 * (ct0 + c) + col] = fmaxf(acc[t][c][reg] + b, 0.0f);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_ck_actor(const CkActorParams p) {
+  using namespace ck_actor;
+  // H: [64][260] first-layer activations / h2; before that it holds X0 [64][84] and C1 [64][164]
+  __shared__ __attribute__((aligned(16))) float sH[64 * kLdH];
+  __shared__ __attribute__((aligned(16))) float sX2[64 * kLdX2];
+  __shared__ __attribute__((aligned(16))) float sXO[64 * kLdXO];
+  __shared__ float sLG[64][8];
+  float *sX0 = sH, *sC1 = sH + 64 * kLdX0;
+  static_assert(64 * kLdX0 + 64 * kLdC1 <= 64 * kLdH, "X0 and C1 must fit into the H storage");
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int N = p.N;
+  const size_t rows = (size_t)p.E * N;
+  const size_t row_base = (size_t)blockIdx.x * 64;
+  const float *pk = p.packed;
+
+  // ---- stage the inputs ------------------------------------------------------------------------------------------------
+  for (int idx = tid; idx < 64 * kKConv; idx += 256) {  // window bytes -> floats (t_obs_self; values in {-1, 0, 1})
+    const int r = idx / kKConv, k = idx - r * kKConv;
+    size_t row = row_base + r;
+    row = row < rows ? row : rows - 1;
+    const size_t e = row / N;
+    const int i = (int)(row - e * N);
+    sX0[r * kLdX0 + k] = k < kObs ? (float)p.obs_self_t[e * (size_t)p.obst_stride + (size_t)i * kObs + k] : 0.0f;
+  }
+  if (tid < 64) {  // concat tail: v_obs_self (4), a_prev one-hot (5), v_goal one-hot (2); pad; v_obs_others
+    size_t row = row_base + tid;
+    row = row < rows ? row : rows - 1;
+    const size_t e = row / N;
+    const int i = (int)(row - e * N);
+    float *x = &sX2[tid * kLdX2 + kLin];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = (float)p.obs_self_v[row * 4 + k];
+    const int ap = p.actions_prev ? p.actions_prev[row] : 0;
+#pragma unroll
+    for (int k = 0; k < kA; ++k) x[4 + k] = ap == k ? 1.0f : 0.0f;
+    const int gl = p.goals[row];
+    x[9] = gl == 0 ? 1.0f : 0.0f;
+    x[10] = gl == 0 ? 0.0f : 1.0f;
+#pragma unroll
+    for (int k = kCat - kLin; k < kKSelf - kLin; ++k) x[k] = 0.0f;
+    float *xo = &sXO[tid * kLdXO];
+    for (int k = 0; k < kKOth; ++k) xo[k] = k < p.Lo ? (float)p.obs_others[row * p.Lo + k] : 0.0f;
+    (void)i;
+  }
+  __syncthreads();
+
+  // ---- conv (Toeplitz) : X0 [64][80] -> C1 [64][160], relu -----------------------------------------------------------------
+  {
+    f32x4 acc[2][5];
+    zero_tiles(acc);
+    gemm_tiles<2, 5, kKConv / 16>(sX0, kLdX0, 2 * (w & 1), pk + kPConv, 5 * (w >> 1), lane, acc);
+    store_relu<2, 5>(sC1, kLdC1, 2 * (w & 1), 5 * (w >> 1), pk + kPConvB, lane, acc);
+  }
+  __syncthreads();
+  // ---- conv_linear : C1 [64][160] -> X2[:, 0:32], relu ---------------------------------------------------------------------
+  {
+    f32x4 acc[2][1];
+    zero_tiles(acc);
+    gemm_tiles<2, 1, kKLin / 16>(sC1, kLdC1, 2 * (w & 1), pk + kPLin, w >> 1, lane, acc);
+    store_relu<2, 1>(sX2, kLdX2, 2 * (w & 1), w >> 1, pk + kPLinB, lane, acc);
+  }
+  __syncthreads();
+  // ---- branch_self : X2 [64][48] -> H [64][256], relu; wave w owns columns [64w, 64w + 64) from here on ----------------------
+  {
+    f32x4 acc[4][4];
+    zero_tiles(acc);
+    gemm_tiles<4, 4, kKSelf / 16>(sX2, kLdX2, 0, pk + kPSelf, 4 * w, lane, acc);
+    store_relu<4, 4>(sH, kLdH, 0, 4 * w, pk + kPSelfB, lane, acc);
+  }
+  __syncthreads();
+  // ---- h2 = relu(branch_self W_self_h2 + branch_others W_others_h2 + b) -------------------------------------------------------
+  f32x4 acc2[4][4];
+  zero_tiles(acc2);
+  gemm_tiles<4, 4, kH1 / 16>(sH, kLdH, 0, pk + kPH2S, 4 * w, lane, acc2);
+  __syncthreads();  // every wave is done reading branch_self
+  if (p.stage > 1) {
+    {
+      f32x4 acc[4][4];
+      zero_tiles(acc);
+      gemm_tiles<4, 4, kKOth / 16>(sXO, kLdXO, 0, pk + kPOth, 4 * w, lane, acc);
+      store_relu<4, 4>(sH, kLdH, 0, 4 * w, pk + kPOthB, lane, acc);
+    }
+    __syncthreads();
+    gemm_tiles<4, 4, kH1 / 16>(sH, kLdH, 0, pk + kPH2O, 4 * w, lane, acc2);
+    __syncthreads();
+  }
+  store_relu<4, 4>(sH, kLdH, 0, 4 * w, pk + kPH2B, lane, acc2);
+  __syncthreads();
+  // ---- actor_out : wave w finishes rows [16w, 16w + 16) -------------------------------------------------------------------------
+  {
+    f32x4 acc[1][1];
+    zero_tiles(acc);
+    gemm_tiles<1, 1, kH2 / 16>(sH, kLdH, w, pk + kPOut, 0, lane, acc);
+    const int col = lane & 15, hi = lane >> 4;
+    if (col < 8) {
+      const float b = pk[kPOutB + col];
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) sLG[16 * w + 4 * hi + reg][col] = acc[0][0][reg] + b;
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_wave_barrier();
+  // softmax (networks.py:576), epsilon mix (alg_credit_checkers.py:112), sampling (:113): lane l < 16 takes row 16w + l
+  if (lane < 16) {
+    const size_t row = row_base + 16 * w + lane;
+    if (row < rows) {
+      float o[kA], pr[kA];
+#pragma unroll
+      for (int a = 0; a < kA; ++a) o[a] = sLG[16 * w + lane][a];
+      float m = o[0];
+#pragma unroll
+      for (int a = 1; a < kA; ++a) m = fmaxf(m, o[a]);
+      float sum = 0.0f;
+#pragma unroll
+      for (int a = 0; a < kA; ++a) {
+        o[a] = expf(o[a] - m);
+        sum += o[a];
+      }
+      const float inv = 1.0f / sum;
+#pragma unroll
+      for (int a = 0; a < kA; ++a) pr[a] = (1.0f - p.eps) * (o[a] * inv) + p.eps / (float)kA;
+      const size_t e = row / N;
+      const int i = (int)(row - e * N);
+      const int act = actor_sample(pr, p.seed, (uint64_t)(p.env_id_base + (int64_t)e), (uint32_t)p.episode[e], p.steps[e], i);
+      p.actions[row] = act;
+      if (p.probs) {
+#pragma unroll
+        for (int a = 0; a < kA; ++a) p.probs[row * kA + a] = pr[a];
+      }
+    }
+  }
+}
+
+static int ck_actor_check(const cm3_actor_checkers_desc *d) {
+  using namespace ck_actor;
+  CM3_REQUIRE(d, "null desc");
+  CM3_REQUIRE(d->n_agents >= 1 && d->n_agents <= CM3_MAX_AGENTS, "n_agents must be in 1..%d", CM3_MAX_AGENTS);
+  CM3_REQUIRE(d->conv_f == kConvF && d->n_conv_linear == kLin && d->n_h1 == kH1 && d->n_h2 == kH2 && d->n_actions == kA,
+              "supported Checkers actor widths are conv_f 6 / conv_linear 32 / h1 256 / h2 256 / 5 actions "
+              "(config_checkers_stage*.json nn block); got %d/%d/%d/%d/%d",
+              d->conv_f, d->n_conv_linear, d->n_h1, d->n_h2, d->n_actions);
+  CM3_REQUIRE(d->n_obs == 2, "the actor reads 5x5x3 windows (n_obs = 2); got n_obs = %d", d->n_obs);
+  return CM3_OK;
+}
+
+static void ck_actor_weights(CkActorParams &p, const cm3_actor_checkers_weights *wt) {
+  p.conv_w = wt->conv_w; p.conv_b = wt->conv_b; p.lin_w = wt->lin_w; p.lin_b = wt->lin_b;
+  p.self_w = wt->self_w; p.self_b = wt->self_b; p.w_self_h2 = wt->w_self_h2;
+  p.oth_w = wt->others_w; p.oth_b = wt->others_b; p.w_oth_h2 = wt->w_others_h2;
+  p.b_h2 = wt->b_h2; p.out_w = wt->out_w; p.out_b = wt->out_b;
+}
+
+}  // namespace cm3
+
+extern "C" size_t cm3_actor_checkers_packed_bytes(void) { return (size_t)cm3::ck_actor::kPTotal * sizeof(float); }
+
+extern "C" int cm3_actor_checkers_pack(const cm3_actor_checkers_desc *d, const cm3_actor_checkers_weights *wt,
+                                       void *packed, void *stream) {
+  using namespace cm3;
+  int rc = ck_actor_check(d);
+  if (rc != CM3_OK) return rc;
+  CM3_REQUIRE(wt && packed, "null weights / packed buffer");
+  CM3_REQUIRE(wt->conv_w && wt->conv_b && wt->lin_w && wt->lin_b && wt->self_w && wt->self_b && wt->w_self_h2 &&
+                  wt->b_h2 && wt->out_w && wt->out_b, "missing weights");
+  if (d->stage > 1) CM3_REQUIRE(wt->others_w && wt->others_b && wt->w_others_h2, "stage 2 needs the others branch");
+  CkActorParams p;
+  memset(&p, 0, sizeof(p));
+  p.N = d->n_agents;
+  p.stage = d->stage;
+  p.Lo = 2 * (d->n_agents > 1 ? d->n_agents - 1 : 1);
+  ck_actor_weights(p, wt);
+  hipLaunchKernelGGL(k_ck_actor_pack, dim3(128), dim3(256), 0, (hipStream_t)stream, p, (float *)packed);
+  CM3_HIP_CHECK(hipGetLastError());
+  return CM3_OK;
+}
+
+extern "C" int cm3_actor_checkers_f32(const cm3_actor_checkers_desc *d, const cm3_actor_checkers_weights *wt,
+                                      const cm3_actor_checkers_bufs *b, void *stream) {
+  using namespace cm3;
+  int rc = ck_actor_check(d);
+  if (rc != CM3_OK) return rc;
+  CM3_REQUIRE(wt && b, "null weights/bufs");
+  CM3_REQUIRE(d->n_envs > 0, "n_envs must be positive");
+  CM3_REQUIRE(d->epsilon >= 0.0f && d->epsilon <= 1.0f, "epsilon must be in [0,1]");
+  CM3_REQUIRE(d->precision == 0, "precision must be 0 (float32)");
+  CM3_REQUIRE(wt->packed, "weights->packed is NULL: run cm3_actor_checkers_pack once per weight update");
+  CM3_REQUIRE(b->obs_self_t && b->obs_self_v && b->obs_others && b->goals && b->steps && b->episode && b->actions,
+              "missing buffers");
+  CM3_REQUIRE(d->obs_self_t_stride >= d->n_agents * ck_actor::kObs, "obs_self_t_stride %d smaller than one env record",
+              d->obs_self_t_stride);
+  CkActorParams p;
+  memset(&p, 0, sizeof(p));
+  p.E = d->n_envs;
+  p.N = d->n_agents;
+  p.stage = d->stage;
+  p.Lo = 2 * (d->n_agents > 1 ? d->n_agents - 1 : 1);
+  p.eps = d->epsilon;
+  p.env_id_base = d->env_id_base;
+  p.seed = d->seed;
+  p.obst_stride = d->obs_self_t_stride;
+  p.obs_self_t = b->obs_self_t;
+  p.obs_self_v = b->obs_self_v;
+  p.obs_others = b->obs_others;
+  p.goals = b->goals;
+  p.actions_prev = b->actions_prev;
+  p.steps = b->steps;
+  p.episode = b->episode;
+  p.actions = b->actions;
+  p.probs = b->probs;
+  p.packed = (const float *)wt->packed;
+  const size_t rows = (size_t)p.E * p.N;
+  hipLaunchKernelGGL(k_ck_actor, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, (hipStream_t)stream, p);
+  CM3_HIP_CHECK(hipGetLastError());
+  return CM3_OK;
+}

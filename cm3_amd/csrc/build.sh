@@ -11,11 +11,11 @@ pids=()
 pids+=($!)
 "${HIPCC}" ${FLAGS} -DCM3_PARTICLE_F64 -c "${HERE}/particle.hip" -o "${HERE}/_obj/particle_f64.o" &
 pids+=($!)
-for f in checkers util advantage actor policy; do
+for f in checkers util advantage actor actor_checkers policy; do
   "${HIPCC}" ${FLAGS} -c "${HERE}/${f}.hip" -o "${HERE}/_obj/${f}.o" &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait "$p"; done
 "${HIPCC}" --offload-arch=gfx950 -shared -fPIC -o "${OUT}" "${HERE}/_obj/particle_f32.o" "${HERE}/_obj/particle_f64.o" \
-  "${HERE}/_obj/checkers.o" "${HERE}/_obj/util.o" "${HERE}/_obj/advantage.o" "${HERE}/_obj/actor.o" "${HERE}/_obj/policy.o"
+  "${HERE}/_obj/checkers.o" "${HERE}/_obj/util.o" "${HERE}/_obj/advantage.o" "${HERE}/_obj/actor.o" "${HERE}/_obj/actor_checkers.o" "${HERE}/_obj/policy.o"
 echo "built ${OUT}"

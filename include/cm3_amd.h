@@ -294,6 +294,60 @@ int cm3_policy_rollout_f32(const cm3_particle_desc *desc, const cm3_particle_tra
                            float *probs, size_t probs_stride, int32_t n_ticks, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * On-device Checkers actor: networks.convnet_1 + networks.actor_checkers (networks.py:67-75, :549-578) + the
+ * epsilon-mixed categorical sampling of alg_credit_checkers.py:107-113 / run_actor :229-253, for all E*N agent rows in
+ * one launch; every layer on the matrix cores (exact-f32 MFMA).  Weights are float32, shaped as the TF variables:
+ *   conv_w [3][3][3][6] + conv_b [6]        "conv/Conv/weights", "conv/Conv/biases"  (3x3, stride 1, SAME, relu; NHWC)
+ *   lin_w [150][32] + lin_b [32]            "conv_linear"
+ *   self_w [43][256] + self_b [256]         "branch_self"  (input = concat(conv_linear 32, v_obs_self 4, a_prev 5, goal 2))
+ *   w_self_h2 [256][256]                    "W_self_h2"
+ *   others_w [2(N-1)][256] + others_b       "stage-2/branch_others"   (stage > 1 only)
+ *   w_others_h2 [256][256]                  "stage-2/W_others_h2"
+ *   b_h2 [256]                              "b"
+ *   out_w [256][5] + out_b [5]              "actor_out"
+ * Inputs are the env's own output buffers: obs_self_t int8 (env records of obs_self_t_stride bytes, agent i at byte
+ * 75 i), obs_self_v double [E][N][4], obs_others double [E][N][2 max(N-1,1)] (cast to float32 like a TF feed), goals uint8
+ * [E][N] (0 green / 1 orange -> one-hot), actions_prev int32 [E][N] (NULL = zeros, train_onpolicy.py:295), steps, episode.
+ * Outputs: actions int32 [E][N] (what cm3_checkers_step consumes), optional mixed probabilities float [E][N][5].
+ * ---------------------------------------------------------------------------------------- */
+typedef struct cm3_actor_checkers_desc {
+  int32_t n_envs, n_agents;
+  int32_t stage;  /* 1: self branch only; 2: + others branch */
+  int32_t n_obs;  /* 2 (5x5 window) */
+  int32_t conv_f, n_conv_linear, n_h1, n_h2, n_actions; /* 6, 32, 256, 256, 5 */
+  float epsilon;
+  int32_t precision;         /* 0: float32 */
+  int32_t obs_self_t_stride; /* bytes between env records of obs_self_t (cm3_checkers_desc.obs_self_t_stride) */
+  int64_t env_id_base;
+  uint64_t seed;
+} cm3_actor_checkers_desc;
+
+typedef struct cm3_actor_checkers_weights {
+  const float *conv_w, *conv_b, *lin_w, *lin_b, *self_w, *self_b, *w_self_h2, *others_w, *others_b, *w_others_h2, *b_h2,
+      *out_w, *out_b;
+  const void *packed; /* written by cm3_actor_checkers_pack (cm3_actor_checkers_packed_bytes() bytes); the forward launch
+                         reads ONLY this buffer */
+} cm3_actor_checkers_weights;
+
+typedef struct cm3_actor_checkers_bufs {
+  const int8_t *obs_self_t;
+  const double *obs_self_v;
+  const double *obs_others;
+  const uint8_t *goals;
+  const int32_t *actions_prev; /* optional */
+  const int32_t *steps;
+  const int32_t *episode;
+  int32_t *actions;
+  float *probs; /* optional */
+} cm3_actor_checkers_bufs;
+
+size_t cm3_actor_checkers_packed_bytes(void);
+int cm3_actor_checkers_pack(const cm3_actor_checkers_desc *desc, const cm3_actor_checkers_weights *weights, void *packed,
+                            void *stream);
+int cm3_actor_checkers_f32(const cm3_actor_checkers_desc *desc, const cm3_actor_checkers_weights *weights,
+                           const cm3_actor_checkers_bufs *bufs, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Advantage normalisation (build-defined; the reference's advantage, alg_credit.py:334-357, is not normalised).
  * Discounted return-to-go over a time-major trajectory, G[t] = x[t] + gamma * (1 - done[t]) * G[t+1], G[T] = 0:
  *   x, out  real [T][E][C]   (C = N for reward_n, 1 for the team reward); out may alias x

@@ -1,0 +1,110 @@
+"""GPU: the Checkers device actor (cm3_amd/csrc/actor_checkers.hip) against the NumPy restatement of
+networks.actor_checkers + the epsilon-mixed sampling of alg_credit_checkers.py:112-113
+(oracle/actor_checkers_oracle.py).  float32 tolerance: probabilities within 2e-5 (different summation order on the
+matrix cores), sampled actions equal wherever the uniform is not within 1e-4 of a CDF boundary."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import actor_checkers_oracle as AO
+from tests.helpers import load_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+def _env(E, stage, seed=12341, max_steps=33, **kw):
+    from cm3_amd.checkers import VecCheckersEnv
+    cfg = load_cfg("checkers_stage%d.json" % stage)
+    return VecCheckersEnv(cfg["init"], cfg["n_agents"], max_steps, E, device="cuda:0", seed=seed, **kw), cfg["n_agents"]
+
+
+def _goals(rng, E, N):
+    return np.eye(2)[rng.integers(0, 2, (E, N))] if N == 1 else np.broadcast_to(np.eye(N), (E, N, 2)).copy()
+
+
+def _oracle_probs(w, env, prev, eps):
+    (grid, vec), oo, ot, ov = env.get_obs()
+    rows = env.E * env.n
+    return AO.mixed_probs(AO.actor_probs(
+        w, prev.reshape(rows), ot.reshape(rows, 5, 5, 3).cpu().numpy().astype(np.float64),
+        ov.reshape(rows, 4).cpu().numpy(), oo.reshape(rows, -1).cpu().numpy(),
+        env.goals.reshape(rows, 2).cpu().numpy()), eps)
+
+
+@pytest.mark.parametrize("stage", [1, 2])
+@pytest.mark.parametrize("eps", [0.0, 0.3])
+@pytest.mark.parametrize("E", [1000, 33])
+def test_actor_probs_and_samples_match_oracle(stage, eps, E):
+    from cm3_amd.actor import CheckersActor
+    seed = 91
+    rng = np.random.default_rng(stage * 7 + E)
+    env, N = _env(E, stage, seed=seed)
+    w = AO.init_weights(rng, N, stage=stage)
+    env.reset(_goals(rng, E, N))
+    for _ in range(5):
+        env.step()                       # in-kernel uniform actions: agents spread out, pick cells up
+    actor = CheckersActor(w, N, stage=stage, device="cuda:0", seed=seed)
+    prev = rng.integers(0, 5, (E, N))
+    actions, probs = actor.act(env, eps, actions_prev=prev, return_probs=True)
+    rows = E * N
+    want = _oracle_probs(w, env, prev, eps)
+    got = probs.reshape(rows, 5).cpu().numpy()
+    assert np.abs(got - want).max() < 2e-5
+    assert np.abs(got.sum(1) - 1).max() < 1e-5
+    assert np.ptp(want, axis=1).mean() > 0.05
+    u = AO.policy_uniforms(seed, np.arange(E), env._episode.cpu().numpy(), env.steps.cpu().numpy(), N).reshape(rows)
+    want_a = AO.sample_actions(want, u)
+    safe = np.abs(np.cumsum(want, axis=1) - u[:, None]).min(axis=1) > 1e-4
+    assert safe.mean() > 0.98
+    assert np.array_equal(actions.reshape(rows).cpu().numpy()[safe], want_a[safe])
+
+
+def test_actions_prev_none_means_zeros_and_inputs_matter():
+    from cm3_amd.actor import CheckersActor
+    rng = np.random.default_rng(5)
+    env, N = _env(256, 2)
+    env.reset(np.eye(2))
+    w = AO.init_weights(rng, N)
+    actor = CheckersActor(w, N, device="cuda:0")
+    _, p_none = actor.act(env, 0.0, return_probs=True)
+    _, p_zero = actor.act(env, 0.0, actions_prev=np.zeros((256, N), int), return_probs=True)
+    _, p_four = actor.act(env, 0.0, actions_prev=np.full((256, N), 4), return_probs=True)
+    assert torch.equal(p_none, p_zero)
+    assert not torch.equal(p_zero, p_four)
+    want = _oracle_probs(w, env, np.zeros((256, N), int), 0.0)
+    assert np.abs(p_none.reshape(-1, 5).cpu().numpy() - want).max() < 2e-5
+
+
+def test_each_weight_tensor_reaches_the_output():
+    """Perturbing any one weight tensor changes the probabilities exactly as the oracle says (guards the packing of every
+    layer, the Toeplitz expansion of the convolution included)."""
+    from cm3_amd.actor import CheckersActor
+    rng = np.random.default_rng(11)
+    env, N = _env(128, 2)
+    env.reset(np.eye(2))
+    for _ in range(4):
+        env.step()
+    w = AO.init_weights(rng, N)
+    prev = rng.integers(0, 5, (128, N))
+    for name in sorted(w):
+        w2 = dict(w)
+        w2[name] = (w[name] + rng.standard_normal(w[name].shape).astype(np.float32) * 0.3).astype(np.float32)
+        _, probs = CheckersActor(w2, N, device="cuda:0").act(env, 0.1, actions_prev=prev, return_probs=True)
+        want = _oracle_probs(w2, env, prev, 0.1)
+        base = _oracle_probs(w, env, prev, 0.1)
+        assert np.abs(want - base).max() > 1e-3, name
+        assert np.abs(probs.reshape(-1, 5).cpu().numpy() - want).max() < 3e-5, name
+
+
+def test_actor_rejects_bad_weights():
+    from cm3_amd import Cm3Error
+    from cm3_amd.actor import CheckersActor
+    w = AO.init_weights(np.random.default_rng(0), 2)
+    bad = dict(w)
+    del bad["conv_linear/bias"]
+    with pytest.raises(Cm3Error):
+        CheckersActor(bad, 2, device="cuda:0")
+    bad = dict(w)
+    bad["W_self_h2"] = np.zeros((64, 64), np.float32)
+    with pytest.raises(Cm3Error):
+        CheckersActor(bad, 2, device="cuda:0")
