@@ -363,9 +363,23 @@ class CheckersRollout(object):
         _lib.check(self._lib.cm3_checkers_rollout(ctypes.byref(env._desc), ctypes.byref(traj), self.T, stream))
         env._desc.flags = 0
 
-    def collect(self, goals, policy=None):
+    def _enqueue_actor_rollout(self, actor, epsilon, stream):
+        """T x (actor launch, step launch) on `stream`: the policy reads trajectory slot t (+ actions[t-1] as
+        actions_prev, zeros at t = 0: train_onpolicy.py:295,345) and writes actions[t]; the step kernel consumes them and
+        writes slot t+1 (train_onpolicy.py:309-321 without leaving the device)."""
+        env = self.env
+        env._desc.flags = 0
+        for t in range(self.T):
+            actor.enqueue(env.E, self._obst_raw[t], env.obst_stride, self.obs_self_v[t], self.obs_others[t], env._goals,
+                          self.actions[t - 1] if t > 0 else None, env._steps, env._episode, self.actions[t], epsilon,
+                          stream=stream, env_id_base=env._desc.env_id_base)
+            b = self._bufs(t)
+            _lib.check(self._lib.cm3_checkers_step(ctypes.byref(env._desc), ctypes.byref(b), stream))
+
+    def collect(self, goals, policy=None, epsilon=0.0):
         """goals: one-hot [N,2] / [E,N,2] (train_onpolicy.py:287-293).  policy None = uniform random actions
-        drawn in-kernel; else policy(actions_prev, obs_others, obs_self_t, obs_self_v, goals) -> [E,N]."""
+        drawn in-kernel; a cm3_amd.actor.CheckersActor = the on-device policy (actor and step launches alternate inside
+        one hipGraph); else policy(actions_prev, obs_others, obs_self_t, obs_self_v, goals) -> [E,N] on the host."""
         env = self.env
         (grid, vec), oo, ot, ov, _ = env.reset(goals)
         self.grid[0].copy_(grid)
@@ -386,6 +400,19 @@ class CheckersRollout(object):
             else:
                 self._enqueue_random(env._stream(), False)
             return self
+        if hasattr(policy, "enqueue") and hasattr(policy, "act"):            # on-device actor
+            if self.use_graph:
+                key = (id(policy), float(epsilon))
+                if getattr(self, "_actor_graph_key", None) != key:
+                    if getattr(self, "_actor_graph", None) is not None:
+                        self._lib.cm3_graph_destroy(self._actor_graph)
+                    self._actor_graph = _lib.capture_graph(
+                        env.device, lambda st: self._enqueue_actor_rollout(policy, epsilon, st))
+                    self._actor_graph_key = key
+                _lib.check(self._lib.cm3_graph_launch(self._actor_graph, env._stream()))
+            else:
+                self._enqueue_actor_rollout(policy, epsilon, env._stream())
+            return self
         for t in range(self.T):
             if policy is None:
                 env._desc.flags = FLAG_GEN_ACTIONS
@@ -402,6 +429,9 @@ class CheckersRollout(object):
         if self._graph is not None:
             self._lib.cm3_graph_destroy(self._graph)
             self._graph = None
+        if getattr(self, "_actor_graph", None) is not None:
+            self._lib.cm3_graph_destroy(self._actor_graph)
+            self._actor_graph = self._actor_graph_key = None
 
     @property
     def valid(self):

@@ -108,3 +108,114 @@ def test_actor_rejects_bad_weights():
     bad["W_self_h2"] = np.zeros((64, 64), np.float32)
     with pytest.raises(Cm3Error):
         CheckersActor(bad, 2, device="cuda:0")
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_policy_rollout_on_device_equals_host_driven_policy(use_graph):
+    """CheckersRollout.collect(goals, policy=actor): alternate actor/step launches (one hipGraph) == calling the actor and
+    the env from the host tick by tick with actions_prev rolled forward (train_onpolicy.py:295,309-345)."""
+    from cm3_amd.actor import CheckersActor
+    from cm3_amd.rollout import CheckersRollout
+    E, seed = 300, 17
+    env_a, N = _env(E, 2, seed=seed)
+    w = AO.init_weights(np.random.default_rng(2), N)
+    actor = CheckersActor(w, N, device="cuda:0", seed=seed)
+    ro = CheckersRollout(env_a, use_graph=use_graph)
+    ro.collect(np.eye(2), policy=actor, epsilon=0.2)
+    ro.collect(np.eye(2), policy=actor, epsilon=0.2)            # second replay = a fresh episode
+    env_b, _ = _env(E, 2, seed=seed)
+    env_b.reset(np.eye(2))
+    env_b.reset(np.eye(2))
+    assert torch.equal(env_b._episode, env_a._episode)
+    prev = None
+    for t in range(33):
+        a = actor.act(env_b, 0.2, actions_prev=prev)
+        assert torch.equal(a, ro.actions[t]), t
+        (grid, vec), oo, ot, ov, rew, lrew, done = env_b.step(a)
+        assert torch.equal(grid, ro.grid[t + 1]) and torch.equal(vec, ro.vec[t + 1])
+        assert torch.equal(ot, ro.obs_self_t[t + 1]) and torch.equal(ov, ro.obs_self_v[t + 1])
+        assert torch.equal(rew, ro.reward[t]) and torch.equal(lrew, ro.local_rewards[t])
+        assert torch.equal(done, ro.done[t].bool())
+        prev = a
+    ro.close()
+
+
+def test_policy_rollout_against_oracle_env_and_oracle_actor():
+    """Whole policy-driven episodes against the two oracles chained on the host: oracle actor probabilities + the
+    build's Philox uniforms -> actions -> VecCheckersOracle.step.  Envs whose uniform ever falls within 1e-4 of a CDF
+    boundary are excluded from the exact comparison."""
+    from cm3_amd.actor import CheckersActor
+    from cm3_amd.rollout import CheckersRollout
+    from oracle.checkers_oracle import VecCheckersOracle
+    E, seed, eps = 200, 23, 0.1
+    env, N = _env(E, 2, seed=seed)
+    cfg = load_cfg("checkers_stage2.json")
+    w = AO.init_weights(np.random.default_rng(4), N)
+    actor = CheckersActor(w, N, device="cuda:0", seed=seed)
+    ro = CheckersRollout(env).collect(np.eye(2), policy=actor, epsilon=eps)
+    i = cfg["init"]
+    orc = VecCheckersOracle(i["n_rows"], i["n_columns"], i["n_obs"], i["agents_r"], i["agents_c"], N, 33, E)
+    goals = np.broadcast_to(np.eye(2), (E, 2, 2))
+    grid, vec, oo, ot, ov = orc.reset(goals)
+    prev = np.zeros((E, N), int)
+    episode = env._episode.cpu().numpy()                       # constant over the rollout (no auto-reset)
+    ok = np.ones(E, bool)
+    alive = np.ones(E, bool)
+    rows = E * N
+    for t in range(33):
+        p = AO.mixed_probs(AO.actor_probs(w, prev.reshape(rows), ot.reshape(rows, 5, 5, 3), ov.reshape(rows, 4),
+                                          oo.reshape(rows, -1), goals.reshape(rows, 2)), eps)
+        u = AO.policy_uniforms(seed, np.arange(E), episode, np.full(E, t), N).reshape(rows)
+        a = AO.sample_actions(p, u).reshape(E, N)
+        near = (np.abs(np.cumsum(p, axis=1) - u[:, None]).min(axis=1) <= 1e-4).reshape(E, N).any(1)
+        ok &= ~(near & alive)
+        sel = ok & alive
+        assert np.array_equal(ro.actions[t].cpu().numpy()[sel], a[sel]), t
+        grid, vec, oo, ot, ov, rew, lrew, done = orc.step(a)
+        assert np.array_equal(ro.grid[t + 1].cpu().numpy()[sel], grid[sel])
+        assert np.array_equal(ro.obs_self_t[t + 1].cpu().numpy()[sel], ot[sel])
+        assert np.array_equal(ro.reward[t].cpu().numpy()[sel], rew[sel])
+        assert np.array_equal(ro.done[t].cpu().numpy().astype(bool)[sel], done[sel])
+        alive &= ~done
+        prev = a
+    assert ok.mean() > 0.9
+    ro.close()
+
+
+def test_batched_evaluation_matches_stepwise_sums():
+    """cm3_amd.evaluate.test_checkers (evaluate.py:159-203 for E episodes at once) == stepping the env with the actor
+    from the host and summing rewards until each env's done."""
+    from cm3_amd.actor import CheckersActor
+    from cm3_amd.evaluate import test_checkers
+    E, seed = 256, 31
+    env, N = _env(E, 2, seed=seed)
+    w = AO.init_weights(np.random.default_rng(6), N)
+    actor = CheckersActor(w, N, device="cuda:0", seed=seed)
+    r_local, r_global, n, dist = test_checkers(env, actor, n_rounds=1)
+    assert n == E and dist.shape == (N, 5) and abs(dist.sum() - 1) < 1e-12
+    env_b, _ = _env(E, 2, seed=seed)
+    env_b.reset(np.eye(2))
+    tot_l = torch.zeros(E, N, dtype=torch.float64, device="cuda:0")
+    tot_g = torch.zeros(E, dtype=torch.float64, device="cuda:0")
+    alive = torch.ones(E, dtype=torch.bool, device="cuda:0")
+    prev = None
+    for t in range(33):
+        a = actor.act(env_b, 0.0, actions_prev=prev)
+        _, _, _, _, rew, lrew, done = env_b.step(a)
+        tot_l += lrew * alive[:, None]
+        tot_g += rew * alive
+        alive &= ~done
+        prev = a
+    assert np.allclose(r_local, tot_l.mean(0).cpu().numpy(), atol=1e-12)
+    assert abs(r_global - float(tot_g.mean())) < 1e-12
+
+
+def test_batched_evaluation_single_agent_random_goals():
+    from cm3_amd.actor import CheckersActor
+    from cm3_amd.evaluate import test_checkers
+    env, N = _env(128, 1, seed=3)
+    actor = CheckersActor(AO.init_weights(np.random.default_rng(8), 1, stage=1), 1, stage=1, device="cuda:0", seed=3)
+    g = torch.Generator(device="cuda:0").manual_seed(0)
+    r_local, r_global, n, dist = test_checkers(env, actor, n_rounds=2, generator=g)
+    assert n == 256 and r_local.shape == (1,) and abs(r_local[0] - r_global) < 1e-12
+    assert 0 < int(env._goals.sum()) < 128               # both goals occur
