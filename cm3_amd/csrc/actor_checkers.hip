@@ -110,7 +110,11 @@ __global__ void __launch_bounds__(256) k_ck_actor_pack(const CkActorParams p, fl
         case 0: v = ck_conv_toeplitz(p, k, n); break;
         case 1: v = k < 25 * kConvF ? p.lin_w[k * kLin + n] : 0.0f; break;
         case 2: v = k < kCat ? p.self_w[k * kH1 + n] : 0.0f; break;
-        case 3: v = (stage2 && k < p.Lo) ? p.oth_w[k * kH1 + n] : 0.0f; break;
+        case 3: {  // position k holds input 4 (k & 3) + (k >> 2): k-step j of the MFMA group contracts inputs 4j .. 4j+3
+          const int kin = 4 * (k & 3) + (k >> 2);
+          v = (stage2 && kin < p.Lo) ? p.oth_w[kin * kH1 + n] : 0.0f;
+          break;
+        }
         case 4: v = p.w_self_h2[k * kH2 + n]; break;
         case 5: v = stage2 ? p.w_oth_h2[k * kH2 + n] : 0.0f; break;
         default: v = n < kA ? p.out_w[k * kA + n] : 0.0f; break;
@@ -131,10 +135,18 @@ __global__ void __launch_bounds__(256) k_ck_actor_pack(const CkActorParams p, fl
 
 // ---- the tile loop -----------------------------------------------------------------------------------------------------
 // acc[t][c] += A[16 (rt0 + t) .. +16][0 .. 16 KG) x B[.., 16 (ct0 + c) .. +16].  A: LDS, row stride lda floats;
-// Bp: packed tiles of this layer.  B operands of group g + 1 are requested before the MFMAs of group g issue.
+// Bp: packed tiles of this layer.  B operands of group g + 1 are requested before the MFMAs of group g issue; those of
+// group 0 (b0) are requested by the caller with load_b0 BEFORE the previous layer's epilogue and barrier, so that their
+// L2 latency hides behind the LDS stores (1.5-3 k cycles per layer when it was exposed).
+template <int CT, int KG>
+__device__ __forceinline__ void load_b0(const float *Bp, int ct0, int lane, float4 (&b0)[CT]) {
+#pragma unroll
+  for (int c = 0; c < CT; ++c) b0[c] = (reinterpret_cast<const float4 *>(Bp) + ((size_t)(ct0 + c) * KG) * 64 + lane)[0];
+}
+
 template <int RT, int CT, int KG>
 __device__ __forceinline__ void gemm_tiles(const float *A, int lda, int rt0, const float *Bp, int ct0, int lane,
-                                           f32x4 (&acc)[RT][CT]) {
+                                           const float4 (&b0)[CT], f32x4 (&acc)[RT][CT]) {
   const int col = lane & 15, hi = lane >> 4;
   const float4 *bsrc[CT];
 #pragma unroll
@@ -144,7 +156,7 @@ __device__ __forceinline__ void gemm_tiles(const float *A, int lda, int rt0, con
   for (int t = 0; t < RT; ++t) arow[t] = A + (16 * (rt0 + t) + col) * lda + 4 * hi;
   float4 bcur[CT], bnext[CT];
 #pragma unroll
-  for (int c = 0; c < CT; ++c) bcur[c] = bsrc[c][0];
+  for (int c = 0; c < CT; ++c) bcur[c] = b0[c];
 #pragma unroll
   for (int g = 0; g < KG; ++g) {
     if (g + 1 < KG) {
@@ -180,14 +192,21 @@ template <int RT, int CT> __device__ __forceinline__ void zero_tiles(f32x4 (&acc
     for (int c = 0; c < CT; ++c) acc[t][c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 }
 
+// this lane's bias values (column l & 15 of each column tile); requested before the layer's MFMAs so that the epilogue
+// does not wait for them
+template <int CT> __device__ __forceinline__ void load_bias(const float *bias, int ct0, int lane, float (&b)[CT]) {
+#pragma unroll
+  for (int c = 0; c < CT; ++c) b[c] = bias[16 * (ct0 + c) + (lane & 15)];
+}
+
 // O[row][col] = relu(acc + bias[col]); C layout: col = l & 15, row = 4 (l >> 4) + reg
 template <int RT, int CT>
-__device__ __forceinline__ void store_relu(float *O, int ldo, int rt0, int ct0, const float *bias, int lane,
+__device__ __forceinline__ void store_relu(float *O, int ldo, int rt0, int ct0, const float (&bias)[CT], int lane,
                                            const f32x4 (&acc)[RT][CT]) {
   const int col = lane & 15, hi = lane >> 4;
 #pragma unroll
   for (int c = 0; c < CT; ++c) {
-    const float b = bias[16 * (ct0 + c) + col];
+    const float b = bias[c];
 #pragma unroll
     for (int t = 0; t < RT; ++t)
 #pragma unroll
@@ -212,15 +231,44 @@ __global__ void __launch_bounds__(256) k_ck_actor(const CkActorParams p) {
   const size_t rows = (size_t)p.E * N;
   const size_t row_base = (size_t)blockIdx.x * 64;
   const float *pk = p.packed;
+  CM3_STAMP(0, false);
 
+  float4 b_conv[5];
+  load_b0<5, kKConv / 16>(pk + kPConv, 5 * (w >> 1), lane, b_conv);
   // ---- stage the inputs ------------------------------------------------------------------------------------------------
-  for (int idx = tid; idx < 64 * kKConv; idx += 256) {  // window bytes -> floats (t_obs_self; values in {-1, 0, 1})
-    const int r = idx / kKConv, k = idx - r * kKConv;
-    size_t row = row_base + r;
-    row = row < rows ? row : rows - 1;
-    const size_t e = row / N;
-    const int i = (int)(row - e * N);
-    sX0[r * kLdX0 + k] = k < kObs ? (float)p.obs_self_t[e * (size_t)p.obst_stride + (size_t)i * kObs + k] : 0.0f;
+  // window bytes -> floats (t_obs_self; values in {-1, 0, 1})
+  if ((p.obst_stride & 3) == 0 && (64 % N) == 0) {
+    // env records are dword-aligned and the 64 rows are whole envs: read each record as dwords (38 per env at N = 2
+    // instead of 150 byte loads), scatter the four bytes to their (row, k) slots.  (Byte loads: 14 k cycles.)
+    const int epw = 64 / N, dpe = p.obst_stride >> 2, rec = N * kObs;
+    const size_t e0 = row_base / N;
+    for (int d = tid; d < epw * dpe; d += 256) {
+      const int el = d / dpe, dd = d - el * dpe;
+      size_t e = e0 + el;
+      e = e < (size_t)p.E ? e : (size_t)p.E - 1;
+      const uint32_t v = reinterpret_cast<const uint32_t *>(p.obs_self_t + e * (size_t)p.obst_stride)[dd];
+#pragma unroll
+      for (int sb = 0; sb < 4; ++sb) {
+        const int bb = 4 * dd + sb;
+        if (bb < rec) {
+          const int i = bb / kObs, k = bb - i * kObs;
+          sX0[(el * N + i) * kLdX0 + k] = (float)(int8_t)(v >> (8 * sb));
+        }
+      }
+    }
+    for (int idx = tid; idx < 64 * (kKConv - kObs); idx += 256) {
+      const int r = idx / (kKConv - kObs), k = kObs + idx - r * (kKConv - kObs);
+      sX0[r * kLdX0 + k] = 0.0f;
+    }
+  } else {
+    for (int idx = tid; idx < 64 * kKConv; idx += 256) {
+      const int r = idx / kKConv, k = idx - r * kKConv;
+      size_t row = row_base + r;
+      row = row < rows ? row : rows - 1;
+      const size_t e = row / N;
+      const int i = (int)(row - e * N);
+      sX0[r * kLdX0 + k] = k < kObs ? (float)p.obs_self_t[e * (size_t)p.obst_stride + (size_t)i * kObs + k] : 0.0f;
+    }
   }
   if (tid < 64) {  // concat tail: v_obs_self (4), a_prev one-hot (5), v_goal one-hot (2); pad; v_obs_others
     size_t row = row_base + tid;
@@ -238,59 +286,107 @@ __global__ void __launch_bounds__(256) k_ck_actor(const CkActorParams p) {
     x[10] = gl == 0 ? 0.0f : 1.0f;
 #pragma unroll
     for (int k = kCat - kLin; k < kKSelf - kLin; ++k) x[k] = 0.0f;
+    // v_obs_others: input k sits at position 4 (k & 3) + (k >> 2), so that MFMA k-step j contracts inputs 4j .. 4j+3 and
+    // only ceil(Lo / 4) of the four steps of the group are issued
     float *xo = &sXO[tid * kLdXO];
-    for (int k = 0; k < kKOth; ++k) xo[k] = k < p.Lo ? (float)p.obs_others[row * p.Lo + k] : 0.0f;
+    for (int q = 0; q < kKOth; ++q) {
+      const int k = 4 * (q & 3) + (q >> 2);
+      xo[q] = k < p.Lo ? (float)p.obs_others[row * p.Lo + k] : 0.0f;
+    }
     (void)i;
   }
+  CM3_STAMP(1, true);
   __syncthreads();
+  CM3_STAMP(2, false);
 
   // ---- conv (Toeplitz) : X0 [64][80] -> C1 [64][160], relu -----------------------------------------------------------------
+  float4 b_lin[1], b_self[4], b_h2[4], b_oth[4], b_out[1];
   {
     f32x4 acc[2][5];
+    float bias[5];
+    load_bias<5>(pk + kPConvB, 5 * (w >> 1), lane, bias);
     zero_tiles(acc);
-    gemm_tiles<2, 5, kKConv / 16>(sX0, kLdX0, 2 * (w & 1), pk + kPConv, 5 * (w >> 1), lane, acc);
-    store_relu<2, 5>(sC1, kLdC1, 2 * (w & 1), 5 * (w >> 1), pk + kPConvB, lane, acc);
+    gemm_tiles<2, 5, kKConv / 16>(sX0, kLdX0, 2 * (w & 1), pk + kPConv, 5 * (w >> 1), lane, b_conv, acc);
+    load_b0<1, kKLin / 16>(pk + kPLin, w >> 1, lane, b_lin);
+    store_relu<2, 5>(sC1, kLdC1, 2 * (w & 1), 5 * (w >> 1), bias, lane, acc);
   }
   __syncthreads();
+  CM3_STAMP(3, false);
   // ---- conv_linear : C1 [64][160] -> X2[:, 0:32], relu ---------------------------------------------------------------------
   {
     f32x4 acc[2][1];
+    float bias[1];
+    load_bias<1>(pk + kPLinB, w >> 1, lane, bias);
     zero_tiles(acc);
-    gemm_tiles<2, 1, kKLin / 16>(sC1, kLdC1, 2 * (w & 1), pk + kPLin, w >> 1, lane, acc);
-    store_relu<2, 1>(sX2, kLdX2, 2 * (w & 1), w >> 1, pk + kPLinB, lane, acc);
+    gemm_tiles<2, 1, kKLin / 16>(sC1, kLdC1, 2 * (w & 1), pk + kPLin, w >> 1, lane, b_lin, acc);
+    load_b0<4, kKSelf / 16>(pk + kPSelf, 4 * w, lane, b_self);
+    store_relu<2, 1>(sX2, kLdX2, 2 * (w & 1), w >> 1, bias, lane, acc);
   }
   __syncthreads();
+  CM3_STAMP(4, false);
   // ---- branch_self : X2 [64][48] -> H [64][256], relu; wave w owns columns [64w, 64w + 64) from here on ----------------------
   {
     f32x4 acc[4][4];
+    float bias[4];
+    load_bias<4>(pk + kPSelfB, 4 * w, lane, bias);
     zero_tiles(acc);
-    gemm_tiles<4, 4, kKSelf / 16>(sX2, kLdX2, 0, pk + kPSelf, 4 * w, lane, acc);
-    store_relu<4, 4>(sH, kLdH, 0, 4 * w, pk + kPSelfB, lane, acc);
+    gemm_tiles<4, 4, kKSelf / 16>(sX2, kLdX2, 0, pk + kPSelf, 4 * w, lane, b_self, acc);
+    load_b0<4, kH1 / 16>(pk + kPH2S, 4 * w, lane, b_h2);
+    store_relu<4, 4>(sH, kLdH, 0, 4 * w, bias, lane, acc);
   }
   __syncthreads();
+  CM3_STAMP(5, false);
   // ---- h2 = relu(branch_self W_self_h2 + branch_others W_others_h2 + b) -------------------------------------------------------
   f32x4 acc2[4][4];
   zero_tiles(acc2);
-  gemm_tiles<4, 4, kH1 / 16>(sH, kLdH, 0, pk + kPH2S, 4 * w, lane, acc2);
+  gemm_tiles<4, 4, kH1 / 16>(sH, kLdH, 0, pk + kPH2S, 4 * w, lane, b_h2, acc2);
+  const bool stage2 = p.stage > 1;
+  float bias_oth[4], bias_h2[4];
+  load_bias<4>(pk + kPOthB, 4 * w, lane, bias_oth);
+  load_bias<4>(pk + kPH2B, 4 * w, lane, bias_h2);
+  if (stage2) load_b0<4, 1>(pk + kPOth, 4 * w, lane, b_oth);
+  else load_b0<1, kH2 / 16>(pk + kPOut, 0, lane, b_out);
+  CM3_STAMP(6, true);
   __syncthreads();  // every wave is done reading branch_self
-  if (p.stage > 1) {
-    {
+  CM3_STAMP(7, false);
+  if (stage2) {
+    {  // branch_others: K = Lo <= 14 real inputs, ceil(Lo / 4) k-steps (see the staging of sXO)
       f32x4 acc[4][4];
       zero_tiles(acc);
-      gemm_tiles<4, 4, kKOth / 16>(sXO, kLdXO, 0, pk + kPOth, 4 * w, lane, acc);
-      store_relu<4, 4>(sH, kLdH, 0, 4 * w, pk + kPOthB, lane, acc);
+      const int col = lane & 15, hi = lane >> 4, steps = (p.Lo + 3) >> 2;
+      float4 a[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) a[t] = *reinterpret_cast<const float4 *>(&sXO[(16 * t + col) * kLdXO + 4 * hi]);
+      for (int j = 0; j < steps; ++j) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float av = j == 0 ? a[t].x : (j == 1 ? a[t].y : (j == 2 ? a[t].z : a[t].w));
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float bv = j == 0 ? b_oth[c].x : (j == 1 ? b_oth[c].y : (j == 2 ? b_oth[c].z : b_oth[c].w));
+            acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[t][c], 0, 0, 0);
+          }
+        }
+      }
+      load_b0<4, kH1 / 16>(pk + kPH2O, 4 * w, lane, b_h2);
+      store_relu<4, 4>(sH, kLdH, 0, 4 * w, bias_oth, lane, acc);
     }
     __syncthreads();
-    gemm_tiles<4, 4, kH1 / 16>(sH, kLdH, 0, pk + kPH2O, 4 * w, lane, acc2);
+    CM3_STAMP(8, false);
+    gemm_tiles<4, 4, kH1 / 16>(sH, kLdH, 0, pk + kPH2O, 4 * w, lane, b_h2, acc2);
+    load_b0<1, kH2 / 16>(pk + kPOut, 0, lane, b_out);
+    CM3_STAMP(9, true);
     __syncthreads();
   }
-  store_relu<4, 4>(sH, kLdH, 0, 4 * w, pk + kPH2B, lane, acc2);
+  CM3_STAMP(10, false);
+  store_relu<4, 4>(sH, kLdH, 0, 4 * w, bias_h2, lane, acc2);
   __syncthreads();
+  CM3_STAMP(11, false);
   // ---- actor_out : wave w finishes rows [16w, 16w + 16) -------------------------------------------------------------------------
   {
     f32x4 acc[1][1];
     zero_tiles(acc);
-    gemm_tiles<1, 1, kH2 / 16>(sH, kLdH, w, pk + kPOut, 0, lane, acc);
+    gemm_tiles<1, 1, kH2 / 16>(sH, kLdH, w, pk + kPOut, 0, lane, b_out, acc);
     const int col = lane & 15, hi = lane >> 4;
     if (col < 8) {
       const float b = pk[kPOutB + col];
@@ -329,6 +425,7 @@ __global__ void __launch_bounds__(256) k_ck_actor(const CkActorParams p) {
       }
     }
   }
+  CM3_STAMP(12, true);
 }
 
 static int ck_actor_check(const cm3_actor_checkers_desc *d) {

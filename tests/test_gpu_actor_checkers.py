@@ -59,6 +59,25 @@ def test_actor_probs_and_samples_match_oracle(stage, eps, E):
     assert np.array_equal(actions.reshape(rows).cpu().numpy()[safe], want_a[safe])
 
 
+def test_unpadded_env_records_take_the_byte_path():
+    """obs_self_t records of 150 bytes (not dword-aligned) go through the generic staging loop: same probabilities."""
+    from cm3_amd.actor import CheckersActor
+    rng = np.random.default_rng(9)
+    w = AO.init_weights(rng, 2)
+    out = []
+    for padded in (True, False):
+        env, N = _env(500, 2, seed=4, padded_records=padded)
+        assert (env.obst_stride % 4 == 0) == padded
+        env.reset(np.eye(2))
+        for _ in range(6):
+            env.step()
+        prev = np.random.default_rng(1).integers(0, 5, (500, N))
+        a, pr = CheckersActor(w, N, device="cuda:0", seed=4).act(env, 0.05, actions_prev=prev, return_probs=True)
+        assert np.abs(pr.reshape(-1, 5).cpu().numpy() - _oracle_probs(w, env, prev, 0.05)).max() < 2e-5
+        out.append((a, pr))
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+
+
 def test_actions_prev_none_means_zeros_and_inputs_matter():
     from cm3_amd.actor import CheckersActor
     rng = np.random.default_rng(5)
