@@ -29,6 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3  # same guide: v_mfma_f32_16x16x4_f32 / 32x32x2_f32, dense (= the FP32 vector peak)
 GRAPH_TICKS = 33              # one episode per graph replay
 
 
@@ -541,6 +542,60 @@ def main():
                        "full trajectory storage; the two variants are bit-identical "
                        "(tests/test_gpu_actor.py::test_fused_policy_rollout_equals_launch_per_tick)")
         out["policy_rollout"] = pol
+    if world == 1 and rank == 0 and kind == "checkers" and cfg["n_agents"] in (1, 2) and not args.fused:
+        # Extra (not the headline): POLICY-driven Checkers collection (train_onpolicy.py:309-321): the on-device actor
+        # (networks.actor_checkers: conv + dense chain, 153 k MACs per agent row, every layer on the exact-f32 MFMA) and the
+        # env step alternate inside one hipGraph; full trajectory storage.  The actor is contraction work: its roofline is
+        # the float32 matrix-core peak, not HBM.
+        import numpy as np
+        from cm3_amd.actor import CheckersActor
+        from cm3_amd.checkers import VecCheckersEnv
+        from cm3_amd.rollout import CheckersRollout
+        rng = np.random.default_rng(0)
+        Nc = cfg["n_agents"]
+        shapes = {"conv/Conv/weights": (3, 3, 3, 6), "conv/Conv/biases": (6,), "conv_linear/kernel": (150, 32),
+                  "conv_linear/bias": (32,), "branch_self/kernel": (43, 256), "branch_self/bias": (256,),
+                  "W_self_h2": (256, 256), "stage-2/branch_others/kernel": (2 * max(Nc - 1, 1), 256),
+                  "stage-2/branch_others/bias": (256,), "stage-2/W_others_h2": (256, 256), "b": (256,),
+                  "actor_out/kernel": (256, 5), "actor_out/bias": (5,)}
+        wts = {k: (rng.standard_normal(v) * 0.1).astype(np.float32) for k, v in shapes.items()}
+        cenv = VecCheckersEnv(cfg["init"], Nc, 33, E, device=device)
+        goals = np.eye(2) if Nc > 1 else np.array([[1, 0]])
+        cenv.reset(goals)
+        actor = CheckersActor(wts, Nc, stage=2 if Nc > 1 else 1, device=device)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(3):
+            actor.act(cenv, 0.1)
+        torch.cuda.synchronize(device)
+        reps = max(steps, 20)
+        ev0.record()
+        for _ in range(reps):
+            actor.act(cenv, 0.1)
+        ev1.record()
+        ev1.synchronize()
+        a_us = ev0.elapsed_time(ev1) * 1e3 / reps
+        macs = 25 * 6 * 27 + 150 * 32 + 43 * 256 + (2 * max(Nc - 1, 1) * 256 + 256 * 256 if Nc > 1 else 0) + 256 * 256 + 256 * 5
+        tflops = 2.0 * macs * E * Nc / (a_us * 1e-6) / 1e12
+        ro = CheckersRollout(cenv, n_ticks=GRAPH_TICKS, use_graph=True)
+        for _ in range(2):
+            ro.collect(goals, policy=actor, epsilon=0.1)
+        torch.cuda.synchronize(device)
+        reps = max(steps // 4, 5)
+        ev0.record()
+        for _ in range(reps):
+            ro.collect(goals, policy=actor, epsilon=0.1)
+        ev1.record()
+        ev1.synchronize()
+        us = ev0.elapsed_time(ev1) * 1e3 / (reps * GRAPH_TICKS)
+        ro.close()
+        out["policy_rollout"] = {
+            "launch_per_tick": {"us_per_tick": us, "env_steps_per_s": E / us * 1e6},
+            "actor_kernel": {"kernel": "k_ck_actor", "avg_launch_us": a_us, "rows": E * Nc, "macs_per_row": macs,
+                             "roofline": {"bound": "mfma", "achieved": tflops, "peak": MFMA_F32_PEAK_TFLOPS,
+                                          "unit": "TFLOP/s", "frac": tflops / MFMA_F32_PEAK_TFLOPS}},
+            "note": "extra, not the headline: actor (networks.actor_checkers, float32, exact-f32 MFMA; FLOPs counted for the "
+                    "network itself, zero padding of the MFMA tiles excluded) + reset + step per tick with full trajectory "
+                    "storage (tests/test_gpu_actor_checkers.py)"}
     if world == 1 and rank == 0:
         bw = measure_read_bandwidth(device)
         out["roofline"]["measured_read_GBps"] = bw

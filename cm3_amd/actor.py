@@ -136,8 +136,13 @@ class CheckersActor(object):
                                                                            inside ONE hipGraph
     """
 
-    def __init__(self, weights, n_agents, stage=2, device="cuda:0", seed=12341, env_id_base=0):
+    def __init__(self, weights, n_agents, stage=2, device="cuda:0", seed=12341, env_id_base=0, precision="f32"):
+        """precision "f32" (default, the parity path) or "bf16" (the two 256x256 layers on the bf16 matrix cores, float32
+        accumulation: 2.4x faster, probabilities within ~1e-2 of the float32 ones)."""
         self.device = _lib.require_gpu(device)
+        if precision not in ("f32", "bf16"):
+            raise Cm3Error("precision must be 'f32' or 'bf16'")
+        self.precision = precision
         self.n = int(n_agents)
         self.stage = int(stage)
         self.Lo = 2 * max(self.n - 1, 1)
@@ -173,7 +178,7 @@ class CheckersActor(object):
         d.n_envs, d.n_agents, d.stage, d.n_obs = int(n_envs), self.n, self.stage, 2
         d.conv_f, d.n_conv_linear, d.n_h1, d.n_h2, d.n_actions = CK_CONV_F, CK_CONV_LIN, CK_H1, CK_H2, N_ACTIONS
         d.epsilon = float(epsilon)
-        d.precision = 0
+        d.precision = 1 if self.precision == "bf16" else 0
         d.obs_self_t_stride = int(obst_stride)
         d.env_id_base = int(env_id_base)
         d.seed = self.seed & 0xFFFFFFFFFFFFFFFF

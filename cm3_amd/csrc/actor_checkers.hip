@@ -18,6 +18,8 @@
 // KB; the packed weights are 0.7 MB and stay in L2).  k-step j of group g contracts inputs {16g + 4h + j : h = 0..3} --
 // any partition of K into fours is a valid summation order.
 //   conv      : the 3x3 SAME convolution as a [80 x 160] Toeplitz matrix (zeros for out-of-window taps and padding)
+//   precision = 1 (opt-in, not the parity path): the first-layer activations are stored as bf16 and the two 256 x 256
+//               matrices run on v_mfma_f32_16x16x32_bf16 (f32 accumulation, 16x the f32 MFMA rate); everything else stays f32.
 //   wave tiles: conv 2 row x 5 col tiles, conv_linear 2 x 1, branch_self / branch_others / h2: 4 x 4 (all 64 rows x 64
 //               columns per wave, 64 accumulator VGPRs), actor_out: wave w finishes rows [16w, 16w+16).
 #include "actor_common.h"
@@ -49,7 +51,12 @@ constexpr int kPH2O = kPH2S + tiles(kH1, kH2);
 constexpr int kPH2B = kPH2O + tiles(kH1, kH2);
 constexpr int kPOut = kPH2B + kH2;
 constexpr int kPOutB = kPOut + tiles(kH2, 16);
-constexpr int kPTotal = kPOutB + 16;
+constexpr int kPF32 = kPOutB + 16;
+// bf16 copies of the two 256 x 256 matrices for precision = 1: [col tile 16][k-step 8][lane 64][8 bf16], two per float slot
+constexpr int kPH2Sb = kPF32;
+constexpr int kPH2Ob = kPH2Sb + kH1 * kH2 / 2;
+constexpr int kPTotal = kPH2Ob + kH1 * kH2 / 2;
+constexpr int kLdHb = kH1 + 8;  // bf16 activation row: 264 halfwords = 528 B (= 4 mod 64 words, 16-byte aligned rows)
 }  // namespace ck_actor
 
 struct CkActorParams {
@@ -86,6 +93,21 @@ __global__ void __launch_bounds__(256) k_ck_actor_pack(const CkActorParams p, fl
   using namespace ck_actor;
   const bool stage2 = p.stage > 1;
   for (int t = blockIdx.x * 256 + threadIdx.x; t < kPTotal; t += gridDim.x * 256) {
+    if (t >= kPF32) {  // bf16 B operands of v_mfma_f32_16x16x32_bf16: B[k = 32 s + 8 (l >> 4) + q][n = 16 ct + (l & 15)]
+      const bool oth = t >= kPH2Ob;
+      const float *src = oth ? p.w_oth_h2 : p.w_self_h2;
+      __bf16 pair[2];
+      for (int h = 0; h < 2; ++h) {
+        const int eidx = 2 * (t - (oth ? kPH2Ob : kPH2Sb)) + h;
+        const int q = eidx & 7, lane = (eidx >> 3) & 63, st = (eidx >> 9) & 7, ct = eidx >> 12;
+        const int k = 32 * st + 8 * (lane >> 4) + q, n = 16 * ct + (lane & 15);
+        pair[h] = (__bf16)((oth && !stage2) ? 0.0f : src[k * kH2 + n]);
+      }
+      float v;
+      __builtin_memcpy(&v, pair, 4);
+      out[t] = v;
+      continue;
+    }
     // which section?
     int base, K, layer;
     if (t < kPConvB) { base = kPConv; K = kKConv; layer = 0; }
@@ -215,7 +237,64 @@ __device__ __forceinline__ void store_relu(float *O, int ldo, int rt0, int ct0, 
   }
 }
 
-__global__ void __launch_bounds__(256) k_ck_actor(const CkActorParams p) {
+// ---- precision = 1: the two 256 x 256 layers (86 % of the FLOPs) on v_mfma_f32_16x16x32_bf16, f32 accumulation ----------
+// first-layer activations rounded to bf16 on their way to LDS
+template <int RT, int CT>
+__device__ __forceinline__ void store_relu_bf16(__bf16 *O, int ldo, int rt0, int ct0, const float (&bias)[CT], int lane,
+                                                const f32x4 (&acc)[RT][CT]) {
+  const int col = lane & 15, hi = lane >> 4;
+#pragma unroll
+  for (int c = 0; c < CT; ++c) {
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg)
+        O[(16 * (rt0 + t) + 4 * hi + reg) * ldo + 16 * (ct0 + c) + col] = (__bf16)fmaxf(acc[t][c][reg] + bias[c], 0.0f);
+  }
+}
+
+template <int CT> __device__ __forceinline__ void load_b0_bf16(const float *Bp, int ct0, int lane, uint4 (&b0)[CT]) {
+#pragma unroll
+  for (int c = 0; c < CT; ++c) b0[c] = (reinterpret_cast<const uint4 *>(Bp) + ((size_t)(ct0 + c) * 8) * 64 + lane)[0];
+}
+
+// acc[t][c] += A[64 rows][256] x B[256][16 (ct0 + c) .. +16]: A[i = l & 15][k = 32 s + 8 (l >> 4) + q] one ds_read_b128 per
+// row tile and k-step, B one 16-byte load per column tile and k-step (next step requested before this step's MFMAs)
+template <int CT>
+__device__ __forceinline__ void gemm_tiles_bf16(const __bf16 *A, int lda, const float *Bp, int ct0, int lane,
+                                                const uint4 (&b0)[CT], f32x4 (&acc)[4][CT]) {
+  const int col = lane & 15, hi = lane >> 4;
+  const uint4 *bsrc[CT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c) bsrc[c] = reinterpret_cast<const uint4 *>(Bp) + ((size_t)(ct0 + c) * 8) * 64 + lane;
+  uint4 bcur[CT], bnext[CT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c) bcur[c] = b0[c];
+#pragma unroll
+  for (int st = 0; st < 8; ++st) {
+    if (st + 1 < 8) {
+#pragma unroll
+      for (int c = 0; c < CT; ++c) bnext[c] = bsrc[c][(st + 1) * 64];
+    }
+    bf16x8 a[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a[t] = *reinterpret_cast<const bf16x8 *>(A + (16 * t + col) * lda + 32 * st + 8 * hi);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        bf16x8 bv;
+        __builtin_memcpy(&bv, &bcur[c], 16);
+        acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], bv, acc[t][c], 0, 0, 0);
+      }
+    if (st + 1 < 8) {
+#pragma unroll
+      for (int c = 0; c < CT; ++c) bcur[c] = bnext[c];
+    }
+  }
+}
+
+template <bool BF16> __global__ void __launch_bounds__(256) k_ck_actor(const CkActorParams p) {
   using namespace ck_actor;
   // H: [64][260] first-layer activations / h2; before that it holds X0 [64][84] and C1 [64][164]
   __shared__ __attribute__((aligned(16))) float sH[64 * kLdH];
@@ -223,6 +302,7 @@ __global__ void __launch_bounds__(256) k_ck_actor(const CkActorParams p) {
   __shared__ __attribute__((aligned(16))) float sXO[64 * kLdXO];
   __shared__ float sLG[64][8];
   float *sX0 = sH, *sC1 = sH + 64 * kLdX0;
+  __bf16 *sHb = reinterpret_cast<__bf16 *>(sH);  // BF16: first-layer activations [64][264] bf16
   static_assert(64 * kLdX0 + 64 * kLdC1 <= 64 * kLdH, "X0 and C1 must fit into the H storage");
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -301,6 +381,7 @@ __global__ void __launch_bounds__(256) k_ck_actor(const CkActorParams p) {
 
   // ---- conv (Toeplitz) : X0 [64][80] -> C1 [64][160], relu -----------------------------------------------------------------
   float4 b_lin[1], b_self[4], b_h2[4], b_oth[4], b_out[1];
+  uint4 b_h2b[4];
   {
     f32x4 acc[2][5];
     float bias[5];
@@ -331,15 +412,21 @@ __global__ void __launch_bounds__(256) k_ck_actor(const CkActorParams p) {
     load_bias<4>(pk + kPSelfB, 4 * w, lane, bias);
     zero_tiles(acc);
     gemm_tiles<4, 4, kKSelf / 16>(sX2, kLdX2, 0, pk + kPSelf, 4 * w, lane, b_self, acc);
-    load_b0<4, kH1 / 16>(pk + kPH2S, 4 * w, lane, b_h2);
-    store_relu<4, 4>(sH, kLdH, 0, 4 * w, bias, lane, acc);
+    if constexpr (BF16) {
+      load_b0_bf16<4>(pk + kPH2Sb, 4 * w, lane, b_h2b);
+      store_relu_bf16<4, 4>(sHb, kLdHb, 0, 4 * w, bias, lane, acc);
+    } else {
+      load_b0<4, kH1 / 16>(pk + kPH2S, 4 * w, lane, b_h2);
+      store_relu<4, 4>(sH, kLdH, 0, 4 * w, bias, lane, acc);
+    }
   }
   __syncthreads();
   CM3_STAMP(5, false);
   // ---- h2 = relu(branch_self W_self_h2 + branch_others W_others_h2 + b) -------------------------------------------------------
   f32x4 acc2[4][4];
   zero_tiles(acc2);
-  gemm_tiles<4, 4, kH1 / 16>(sH, kLdH, 0, pk + kPH2S, 4 * w, lane, b_h2, acc2);
+  if constexpr (BF16) gemm_tiles_bf16<4>(sHb, kLdHb, pk + kPH2Sb, 4 * w, lane, b_h2b, acc2);
+  else gemm_tiles<4, 4, kH1 / 16>(sH, kLdH, 0, pk + kPH2S, 4 * w, lane, b_h2, acc2);
   const bool stage2 = p.stage > 1;
   float bias_oth[4], bias_h2[4];
   load_bias<4>(pk + kPOthB, 4 * w, lane, bias_oth);
@@ -368,12 +455,18 @@ __global__ void __launch_bounds__(256) k_ck_actor(const CkActorParams p) {
           }
         }
       }
-      load_b0<4, kH1 / 16>(pk + kPH2O, 4 * w, lane, b_h2);
-      store_relu<4, 4>(sH, kLdH, 0, 4 * w, bias_oth, lane, acc);
+      if constexpr (BF16) {
+        load_b0_bf16<4>(pk + kPH2Ob, 4 * w, lane, b_h2b);
+        store_relu_bf16<4, 4>(sHb, kLdHb, 0, 4 * w, bias_oth, lane, acc);
+      } else {
+        load_b0<4, kH1 / 16>(pk + kPH2O, 4 * w, lane, b_h2);
+        store_relu<4, 4>(sH, kLdH, 0, 4 * w, bias_oth, lane, acc);
+      }
     }
     __syncthreads();
     CM3_STAMP(8, false);
-    gemm_tiles<4, 4, kH1 / 16>(sH, kLdH, 0, pk + kPH2O, 4 * w, lane, b_h2, acc2);
+    if constexpr (BF16) gemm_tiles_bf16<4>(sHb, kLdHb, pk + kPH2Ob, 4 * w, lane, b_h2b, acc2);
+    else gemm_tiles<4, 4, kH1 / 16>(sH, kLdH, 0, pk + kPH2O, 4 * w, lane, b_h2, acc2);
     load_b0<1, kH2 / 16>(pk + kPOut, 0, lane, b_out);
     CM3_STAMP(9, true);
     __syncthreads();
@@ -479,7 +572,7 @@ extern "C" int cm3_actor_checkers_f32(const cm3_actor_checkers_desc *d, const cm
   CM3_REQUIRE(wt && b, "null weights/bufs");
   CM3_REQUIRE(d->n_envs > 0, "n_envs must be positive");
   CM3_REQUIRE(d->epsilon >= 0.0f && d->epsilon <= 1.0f, "epsilon must be in [0,1]");
-  CM3_REQUIRE(d->precision == 0, "precision must be 0 (float32)");
+  CM3_REQUIRE(d->precision == 0 || d->precision == 1, "precision must be 0 (float32) or 1 (bf16 256x256 layers)");
   CM3_REQUIRE(wt->packed, "weights->packed is NULL: run cm3_actor_checkers_pack once per weight update");
   CM3_REQUIRE(b->obs_self_t && b->obs_self_v && b->obs_others && b->goals && b->steps && b->episode && b->actions,
               "missing buffers");
@@ -506,7 +599,9 @@ extern "C" int cm3_actor_checkers_f32(const cm3_actor_checkers_desc *d, const cm
   p.probs = b->probs;
   p.packed = (const float *)wt->packed;
   const size_t rows = (size_t)p.E * p.N;
-  hipLaunchKernelGGL(k_ck_actor, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, (hipStream_t)stream, p);
+  const dim3 grid((unsigned)((rows + 63) / 64));
+  if (d->precision == 1) hipLaunchKernelGGL(k_ck_actor<true>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(k_ck_actor<false>, grid, dim3(256), 0, (hipStream_t)stream, p);
   CM3_HIP_CHECK(hipGetLastError());
   return CM3_OK;
 }

@@ -316,7 +316,9 @@ typedef struct cm3_actor_checkers_desc {
   int32_t n_obs;  /* 2 (5x5 window) */
   int32_t conv_f, n_conv_linear, n_h1, n_h2, n_actions; /* 6, 32, 256, 256, 5 */
   float epsilon;
-  int32_t precision;         /* 0: float32 */
+  int32_t precision;         /* 0: float32 throughout (parity path).  1: the two 256x256 layers on the bf16 matrix cores with
+                                float32 accumulation (first-layer activations and those weights rounded to bf16; probabilities
+                                move by up to ~1e-2) */
   int32_t obs_self_t_stride; /* bytes between env records of obs_self_t (cm3_checkers_desc.obs_self_t_stride) */
   int64_t env_id_base;
   uint64_t seed;

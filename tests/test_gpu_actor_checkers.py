@@ -238,3 +238,25 @@ def test_batched_evaluation_single_agent_random_goals():
     r_local, r_global, n, dist = test_checkers(env, actor, n_rounds=2, generator=g)
     assert n == 256 and r_local.shape == (1,) and abs(r_local[0] - r_global) < 1e-12
     assert 0 < int(env._goals.sum()) < 128               # both goals occur
+
+
+@pytest.mark.parametrize("stage", [1, 2])
+def test_bf16_layers_are_close_to_float32(stage):
+    """Opt-in precision="bf16": the two 256x256 layers on the bf16 matrix cores.  Not the parity path -- activations and
+    those weights are rounded to bf16 (relative 2^-9), so probabilities move by up to a few 1e-2; the tolerance documents it."""
+    from cm3_amd.actor import CheckersActor
+    rng = np.random.default_rng(21)
+    env, N = _env(2000, stage, seed=8)
+    env.reset(_goals(rng, 2000, N))
+    for _ in range(5):
+        env.step()
+    w = AO.init_weights(rng, N, stage=stage)
+    prev = rng.integers(0, 5, (2000, N))
+    a32, p32 = CheckersActor(w, N, stage=stage, device="cuda:0", seed=8).act(env, 0.1, actions_prev=prev, return_probs=True)
+    a16, p16 = CheckersActor(w, N, stage=stage, device="cuda:0", seed=8, precision="bf16").act(
+        env, 0.1, actions_prev=prev, return_probs=True)
+    d = (p32 - p16).abs()
+    assert float(d.max()) < 0.1 and float(d.mean()) < 5e-3
+    assert float(d.max()) > 0                                     # it is a different kernel
+    assert (p16.sum(-1) - 1).abs().max() < 1e-5
+    assert float((a32 == a16).float().mean()) > 0.97              # same uniforms, nearly the same CDFs

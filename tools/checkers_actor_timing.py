@@ -34,8 +34,8 @@ def main():
     torch.cuda.set_stream(torch.cuda.Stream(device=dev))
     cfg = cm3_amd.load_config("checkers_stage2")
     N = 2
-    actor = CheckersActor(random_weights(np.random.default_rng(0), N), N, device=dev)
-    for E in (8192, 65536, 524288):
+    for prec, E in [(pr, e) for pr in ("f32", "bf16") for e in (8192, 65536, 524288)]:
+        actor = CheckersActor(random_weights(np.random.default_rng(0), N), N, device=dev, precision=prec)
         env = VecCheckersEnv(cfg["init"], N, 33, E, device=dev)
         env.reset(np.eye(2))
         for _ in range(3):
@@ -50,7 +50,7 @@ def main():
         b.synchronize()
         us = a.elapsed_time(b) * 1e3 / reps
         rows = E * N
-        print(json.dumps({"what": "actor launch", "envs": E, "rows": rows, "us": round(us, 2),
+        print(json.dumps({"what": "actor launch", "precision": prec, "envs": E, "rows": rows, "us": round(us, 2),
                           "tflops_executed": round(2 * MACS_PER_ROW * rows / us * 1e-6, 2),
                           "tflops_network": round(2 * MACS_PER_ROW_ALG * rows / us * 1e-6, 2)}), flush=True)
         if E <= 65536:
@@ -65,7 +65,7 @@ def main():
             b.record()
             b.synchronize()
             us = a.elapsed_time(b) * 1e3 / (reps * 33)
-            print(json.dumps({"what": "policy rollout (reset + 33 x (actor + step), hipGraph)", "envs": E,
+            print(json.dumps({"what": "policy rollout (reset + 33 x (actor + step), hipGraph)", "precision": prec, "envs": E,
                               "us_per_tick": round(us, 2), "env_steps_per_s": E / us * 1e6}), flush=True)
             ro.close()
         del env
