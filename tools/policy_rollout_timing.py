@@ -12,7 +12,15 @@ import cm3_amd  # noqa: E402
 from cm3_amd.actor import ParticleActor  # noqa: E402
 from cm3_amd.particle import VecParticleEnv  # noqa: E402
 from cm3_amd.rollout import ParticleRollout  # noqa: E402
-from oracle.actor_oracle import init_weights  # noqa: E402  (random weights with the reference's shapes)
+
+
+def init_weights(rng, n_agents):
+    """Random float32 weights with the reference's variable names / shapes (networks.py:517-538)."""
+    lo = 4 * max(n_agents - 1, 1)
+    shapes = {"actor_branch_self/kernel": (6, 64), "actor_branch_self/bias": (64,), "W_branch_self_h2": (64, 64),
+              "stage-2/actor_others/kernel": (lo, 128), "stage-2/actor_others/bias": (128,),
+              "stage-2/W_others_h2": (128, 64), "b": (64,), "actor_out/kernel": (64, 5), "actor_out/bias": (5,)}
+    return {k: (rng.standard_normal(v) * 0.5).astype(np.float32) for k, v in shapes.items()}
 
 
 def main():
