@@ -369,69 +369,63 @@ template <int N> struct CkFast {
   static constexpr int G = 16;
 };
 
-template <int N>
-__device__ __forceinline__ int ckf_ch2(const CkState<N> &s, int r, int c) {
+// One window / grid cell as packed bytes, branch-free.  (A first version decoded and evaluated every output BYTE with
+// nested ifs: 1022 VALU instructions and ~50 exec-mask branches per wave.)
+//   value of channel 0 (green) / 1 (orange) at expanded cell (rr, cc): 0 outside the 3 x 8 band or on the other colour,
+//   else +1 collected / -1 still there (checkers.py:54-63, :203-224); the band cell (kk, jj) is green iff kk + jj is even.
+template <int N> __device__ __forceinline__ uint32_t ckf_colour16(uint32_t m32, int kk, int jj) {
   using F = CkFast<N>;
-  if (c < F::O || r < F::O || r >= F::O + F::R || c >= F::O + F::C + 1) return 1;
+  const bool inband = (unsigned)kk < (unsigned)F::R && (unsigned)jj < (unsigned)F::C;
+  const uint32_t bit = (m32 >> ((kk * F::C + jj) & 31)) & 1u;
+  const uint32_t sgn = bit ? 0x01u : 0xffu;          // +1 / -1 as a byte
+  const uint32_t par = (uint32_t)(kk + jj) & 1u;     // 0 green -> byte 0, 1 orange -> byte 1
+  return inband ? (sgn << (8u * par)) : 0u;
+}
+
+// the three channel bytes (ch0 | ch1 << 8 | ch2 << 16) of global window cell cg = 25 i + 5 dr + dc of agent i's 5 x 5
+// window (get_obs, checkers.py:97-109); cells past the last agent's record (padding) are 0
+template <int N> __device__ __forceinline__ uint32_t ckf_cell3(const CkState<N> &s, uint32_t m32, int cg) {
+  using F = CkFast<N>;
+  constexpr int KK = F::K * F::K;
+  const int i = cg / KK, cell = cg - KK * i;
+  const int dr = cell / F::K, dc = cell - F::K * dr;
+  int ar = s.r[0], ac = s.c[0];
 #pragma unroll
-  for (int j = 0; j < N; ++j)
-    if (s.r[j] == r && s.c[j] == c) return -1;
-  return 0;
+  for (int a = 1; a < N; ++a) {
+    ar = (i == a) ? s.r[a] : ar;
+    ac = (i == a) ? s.c[a] : ac;
+  }
+  const int rr = ar - F::O + dr, cc = ac - F::O + dc;
+  const int kk = rr - F::O, jj = cc - F::O;
+  const uint32_t v01 = ckf_colour16<N>(m32, kk, jj);
+  // channel 2: walls +1 (2-wide border and right of the start column), agents -1, own cell 0 (:43-51, :105-107)
+  const bool wall = (unsigned)kk >= (unsigned)F::R || (unsigned)jj >= (unsigned)(F::C + 1);
+  bool agent = false;
+#pragma unroll
+  for (int a = 0; a < N; ++a) agent = agent || (s.r[a] == rr && s.c[a] == cc);
+  const uint32_t v2 = (cell == KK / 2) ? 0u : (wall ? 0x01u : (agent ? 0xffu : 0u));
+  return cg < N * KK ? (v01 | (v2 << 16)) : 0u;
 }
 
-// channel ch (0 green, 1 orange) at expanded cell (r, c)
-template <int N> __device__ __forceinline__ int ckf_ch01(const CkState<N> &s, int r, int c, int ch) {
-  using F = CkFast<N>;
-  const int k = r - F::O, j = c - F::O;
-  if (k < 0 || k >= F::R || j < 0 || j >= F::C) return 0;
-  if (((k + j) & 1) != ch) return 0;
-  return ((s.mask >> (k * F::C + j)) & 1ull) ? 1 : -1;
-}
-
-template <int N> __device__ __forceinline__ uint32_t ckf_grid_dword(const CkState<N> &s, int d) {
+// dword d of the grid record: cells 2d and 2d + 1 of get_valid_grid (world[2:5, 2:11, 0:2], checkers.py:66-76)
+template <int N> __device__ __forceinline__ uint32_t ckf_grid_dword(uint32_t m32, int d) {
   using F = CkFast<N>;
   uint32_t w = 0;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int b = 4 * d + q;
-    int v = 0;
-    if (b < F::GRID_REC) {
-      const int cell = b >> 1, ch = b & 1;
-      const int k = cell / (F::C + 1), j = cell - k * (F::C + 1);
-      v = ckf_ch01<N>(s, k + F::O, j + F::O, ch);
-    }
-    w |= (uint32_t)(v & 0xff) << (8 * q);
+  for (int h = 0; h < 2; ++h) {
+    const int cl = 2 * d + h;
+    const int k = cl / (F::C + 1), j = cl - k * (F::C + 1);
+    const uint32_t v = cl < F::R * (F::C + 1) ? ckf_colour16<N>(m32, k, j) : 0u;
+    w |= v << (16 * h);
   }
   return w;
 }
 
-template <int N> __device__ __forceinline__ uint32_t ckf_obst_dword(const CkState<N> &s, int d) {
-  using F = CkFast<N>;
-  uint32_t w = 0;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int b = 4 * d + q;
-    int v = 0;
-    if (b < F::OBST_REC) {
-      const int i = b / (F::K * F::K * 3), rem = b - i * (F::K * F::K * 3);
-      const int cell = rem / 3, ch = rem - cell * 3;
-      const int dr = cell / F::K, dc = cell - dr * F::K;
-      int ar = s.r[0], ac = s.c[0];
-#pragma unroll
-      for (int a = 1; a < N; ++a) {
-        ar = (i == a) ? s.r[a] : ar;
-        ac = (i == a) ? s.c[a] : ac;
-      }
-      const int rr = ar - F::O + dr, cc = ac - F::O + dc;
-      if (ch < 2) {
-        v = ckf_ch01<N>(s, rr, cc, ch);
-      } else {
-        v = (dr == F::O && dc == F::O) ? 0 : ckf_ch2<N>(s, rr, cc);  // own cell is valid (:105-107)
-      }
-    }
-    w |= (uint32_t)(v & 0xff) << (8 * q);
-  }
-  return w;
+// dword d of the obs_self_t record: bytes 4d .. 4d+3 = parts of window cells ca = 4d / 3 and ca + 1
+template <int N> __device__ __forceinline__ uint32_t ckf_obst_dword(const CkState<N> &s, uint32_t m32, int d) {
+  const int b0 = 4 * d, ca = b0 / 3, sh = 8 * (b0 - 3 * ca);
+  const uint64_t t = (uint64_t)ckf_cell3<N>(s, m32, ca) | ((uint64_t)ckf_cell3<N>(s, m32, ca + 1) << 24);
+  return (uint32_t)(t >> sh);
 }
 
 template <int N>
@@ -443,11 +437,12 @@ __device__ __forceinline__ void ckf_emit(const CheckersParams &p, const CkState<
   // grid record: dword g
   const int gd = p.grid_stride >> 2;
   int8_t *grid_t = ck_tick_ptr(p.grid, p.st_grid, t);
-  if (g < gd) reinterpret_cast<uint32_t *>(grid_t + e * (size_t)p.grid_stride)[g] = ckf_grid_dword<N>(s, g);
+  const uint32_t m32 = (uint32_t)s.mask;  // 24 collected bits
+  if (g < gd) reinterpret_cast<uint32_t *>(grid_t + e * (size_t)p.grid_stride)[g] = ckf_grid_dword<N>(m32, g);
   // obs_self_t record: dwords g, g+16, ...
   const int od = p.obst_stride >> 2;
   uint32_t *o32 = reinterpret_cast<uint32_t *>(ck_tick_ptr(p.obs_self_t, p.st_obs_self_t, t) + e * (size_t)p.obst_stride);
-  for (int d = g; d < od; d += F::G) o32[d] = ckf_obst_dword<N>(s, d);
+  for (int d = g; d < od; d += F::G) o32[d] = ckf_obst_dword<N>(s, m32, d);
   // small vector outputs: lane i (< N) writes agent i's rows
   if (g < N) {
     int ri = s.r[0], ci = s.c[0], gi = s.ng[0], oi = s.no[0];
