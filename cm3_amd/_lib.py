@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcm3_hip.so")
 MAX_AGENTS = 8
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 FLAG_AUTO_RESET = 1
 FLAG_GEN_ACTIONS = 2
@@ -145,8 +145,11 @@ SYMBOLS = {
                                                c_int32, c_int32, c_int32, c_double, c_void_p]),
     "cm3_returns_moments_f64": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                c_int32, c_int32, c_int32, c_double, c_void_p]),
-    "cm3_normalize_f32": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int32, c_double, c_void_p]),
-    "cm3_normalize_f64": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int32, c_double, c_void_p]),
+    "cm3_normalize_f32": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_size_t, c_int32, c_double,
+                                         c_int32, c_void_p]),
+    "cm3_normalize_f64": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_size_t, c_int32, c_double,
+                                         c_int32, c_void_p]),
+    "cm3_copy_list": (ctypes.c_int, [c_int32, P(c_void_p), P(c_void_p), P(c_size_t), c_void_p]),
     "cm3_hbm_read_bench": (ctypes.c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
     "cm3_hbm_bench_sink_words": (ctypes.c_int, []),
     "cm3_graph_begin": (ctypes.c_int, [c_void_p]),
@@ -201,6 +204,15 @@ def check(rc):
 def ptr(t):
     """Device pointer of a torch tensor (0 for None)."""
     return 0 if t is None else t.data_ptr()
+
+
+def copy_list(pairs, stream):
+    """ONE launch copying every (dst tensor, src tensor) pair (cm3_copy_list; 16-byte aligned contiguous tensors)."""
+    n = len(pairs)
+    dst = (c_void_p * n)(*[d.data_ptr() for d, _ in pairs])
+    src = (c_void_p * n)(*[s.data_ptr() for _, s in pairs])
+    nb = (c_size_t * n)(*[d.numel() * d.element_size() for d, _ in pairs])
+    check(lib().cm3_copy_list(n, dst, src, nb, stream))
 
 
 def current_stream_handle(device):

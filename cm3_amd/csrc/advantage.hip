@@ -14,26 +14,47 @@ constexpr int kAdvMaxBlocks = 1024;
 
 // One thread per (env, channel) column, walking time backwards:
 //   G[t] = x[t] + gamma * (1 - done[t]) * G[t+1],   G[T] = 0.
+// The column is read in chunks of kAdvChunk time steps: all loads of a chunk are in flight before the (serial) recurrence
+// consumes them -- 33 ticks cost 5 memory trips instead of 33 (15.5 -> see DESIGN.md us at 4096 envs x 4 agents).
+// The block that finishes last (ticket from one atomic counter at the end of `scratch`, which it resets) folds the
+// per-block partials in block order, so the result does not depend on which block that is: deterministic, one launch.
+constexpr int kAdvChunk = 8;
+
 template <typename R>
 __global__ void __launch_bounds__(kAdvBlock) k_returns_moments(const R *__restrict__ x, const uint8_t *__restrict__ done,
                                                                const uint8_t *__restrict__ valid, R *__restrict__ out,
-                                                               double *__restrict__ partials, int T, int E, int C, R gamma) {
+                                                               double *__restrict__ partials, double *__restrict__ moments,
+                                                               int T, int E, int C, R gamma) {
   const size_t cols = (size_t)E * C;
   double s = 0.0, s2 = 0.0, n = 0.0;
   for (size_t col = (size_t)blockIdx.x * kAdvBlock + threadIdx.x; col < cols; col += (size_t)gridDim.x * kAdvBlock) {
     const size_t e = col / C;
     R g = R(0);
-    for (int t = T - 1; t >= 0; --t) {
-      const size_t idx = (size_t)t * cols + col;
-      const bool d = done[(size_t)t * E + e] != 0;
-      g = x[idx] + (d ? R(0) : gamma * g);
-      const bool v = valid ? (valid[(size_t)t * E + e] != 0) : true;
-      out[idx] = v ? g : R(0);
-      if (v) {
-        const double gd = (double)g;
-        s += gd;
-        s2 += gd * gd;
-        n += 1.0;
+    for (int t_hi = T; t_hi > 0; t_hi -= kAdvChunk) {
+      R xs[kAdvChunk];
+      uint8_t ds[kAdvChunk], vs[kAdvChunk];
+#pragma unroll
+      for (int k = 0; k < kAdvChunk; ++k) {
+        const int t = t_hi - 1 - k;
+        const int tc = t >= 0 ? t : 0;
+        xs[k] = x[(size_t)tc * cols + col];
+        ds[k] = done[(size_t)tc * E + e];
+        vs[k] = valid ? valid[(size_t)tc * E + e] : (uint8_t)1;
+      }
+#pragma unroll
+      for (int k = 0; k < kAdvChunk; ++k) {
+        const int t = t_hi - 1 - k;
+        if (t >= 0) {
+          g = xs[k] + (ds[k] != 0 ? R(0) : gamma * g);
+          const bool v = vs[k] != 0;
+          out[(size_t)t * cols + col] = v ? g : R(0);
+          if (v) {
+            const double gd = (double)g;
+            s += gd;
+            s2 += gd * gd;
+            n += 1.0;
+          }
+        }
       }
     }
   }
@@ -45,12 +66,14 @@ __global__ void __launch_bounds__(kAdvBlock) k_returns_moments(const R *__restri
     n += __shfl_down(n, off, 64);
   }
   __shared__ double part[kAdvBlock / 64][3];
+  __shared__ unsigned ticket;
   if ((threadIdx.x & 63) == 0) {
     part[threadIdx.x >> 6][0] = s;
     part[threadIdx.x >> 6][1] = s2;
     part[threadIdx.x >> 6][2] = n;
   }
   __syncthreads();
+  unsigned *counter = reinterpret_cast<unsigned *>(partials + 3 * kAdvMaxBlocks);
   if (threadIdx.x == 0) {
     double a = 0.0, b = 0.0, c = 0.0;
     for (int w = 0; w < kAdvBlock / 64; ++w) {
@@ -61,42 +84,82 @@ __global__ void __launch_bounds__(kAdvBlock) k_returns_moments(const R *__restri
     partials[3 * blockIdx.x + 0] = a;
     partials[3 * blockIdx.x + 1] = b;
     partials[3 * blockIdx.x + 2] = c;
+    __threadfence();
+    ticket = atomicAdd(counter, 1u);
   }
-}
-
-// one wave folds the per-block partials in a fixed order
-__global__ void __launch_bounds__(64) k_fold_partials(const double *__restrict__ partials, int n_blocks,
-                                                      double *__restrict__ moments) {
-  double s = 0.0, s2 = 0.0, n = 0.0;
-  for (int b = threadIdx.x; b < n_blocks; b += 64) {
-    s += partials[3 * b + 0];
-    s2 += partials[3 * b + 1];
-    n += partials[3 * b + 2];
-  }
+  __syncthreads();
+  if (ticket != gridDim.x - 1) return;
+  // last block: every other block's partials are visible (fence before its ticket); wave 0 folds them in block order
+  if (threadIdx.x < 64) {
+    __threadfence();
+    double fs = 0.0, fs2 = 0.0, fn = 0.0;
+    const volatile double *pv = partials;
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += 64) {
+      fs += pv[3 * b + 0];
+      fs2 += pv[3 * b + 1];
+      fn += pv[3 * b + 2];
+    }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    s += __shfl_down(s, off, 64);
-    s2 += __shfl_down(s2, off, 64);
-    n += __shfl_down(n, off, 64);
-  }
-  if (threadIdx.x == 0) {
-    moments[0] = s;
-    moments[1] = s2;
-    moments[2] = n;
+    for (int off = 32; off > 0; off >>= 1) {
+      fs += __shfl_down(fs, off, 64);
+      fs2 += __shfl_down(fs2, off, 64);
+      fn += __shfl_down(fn, off, 64);
+    }
+    if (threadIdx.x == 0) {
+      moments[0] = fs;
+      moments[1] = fs2;
+      moments[2] = fn;
+      *counter = 0u;  // ready for the next call
+    }
   }
 }
 
+// x <- (x - mean) / (std + eps) with the statistics of ALL ranks: `parts` holds n_parts (sum, sum of squares, count)
+// triples (this rank's, or the all-gathered ones), summed here in rank order -- every rank computes identical values.
+// stats (optional) receives (mean, std, count).
 template <typename R>
 __global__ void __launch_bounds__(kAdvBlock) k_normalize(R *__restrict__ x, const uint8_t *__restrict__ valid,
-                                                         const double *__restrict__ moments, size_t n_elem, int C, double eps) {
-  const double cnt = moments[2] > 1.0 ? moments[2] : 1.0;
-  const double mean = moments[0] / cnt;
-  double var = moments[1] / cnt - mean * mean;
+                                                         const double *__restrict__ parts, int n_parts,
+                                                         double *__restrict__ stats, size_t n_elem, int C, double eps,
+                                                         int apply) {
+  double tot0 = parts[0], tot1 = parts[1], tot2 = parts[2];
+  for (int r = 1; r < n_parts; ++r) {
+    tot0 = tot0 + parts[3 * r + 0];
+    tot1 = tot1 + parts[3 * r + 1];
+    tot2 = tot2 + parts[3 * r + 2];
+  }
+  const double cnt = tot2 > 1.0 ? tot2 : 1.0;
+  const double mean = tot0 / cnt;
+  double var = tot1 / cnt - mean * mean;
   var = var > 0.0 ? var : 0.0;
-  const R m = (R)mean, inv = (R)(1.0 / (::sqrt(var) + eps));
+  const double sd = ::sqrt(var);
+  if (stats && blockIdx.x == 0 && threadIdx.x == 0) {
+    stats[0] = mean;
+    stats[1] = sd;
+    stats[2] = tot2;
+  }
+  if (!apply) return;
+  const R m = (R)mean, inv = (R)(1.0 / (sd + eps));
   for (size_t i = (size_t)blockIdx.x * kAdvBlock + threadIdx.x; i < n_elem; i += (size_t)gridDim.x * kAdvBlock) {
     const bool v = valid ? (valid[i / C] != 0) : true;
     x[i] = v ? (x[i] - m) * inv : R(0);
+  }
+}
+
+// several small device-to-device copies in ONE launch (trajectory slot <-> live env buffers): block b copies a slice of
+// every region
+struct CopyList {
+  int n;
+  void *dst[8];
+  const void *src[8];
+  size_t bytes[8];  // multiples of 16
+};
+__global__ void __launch_bounds__(256) k_copy_list(const CopyList c) {
+  for (int r = 0; r < c.n; ++r) {
+    const size_t n16 = c.bytes[r] >> 4;
+    const uint4 *s = reinterpret_cast<const uint4 *>(c.src[r]);
+    uint4 *d = reinterpret_cast<uint4 *>(c.dst[r]);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) d[i] = s[i];
   }
 }
 
@@ -110,21 +173,21 @@ static int returns_moments(const void *x, const uint8_t *done, const uint8_t *va
   if (blocks > kAdvMaxBlocks) blocks = kAdvMaxBlocks;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL((k_returns_moments<R>), dim3(blocks), dim3(kAdvBlock), 0, s, (const R *)x, done, valid, (R *)out,
-                     (double *)scratch, T, E, C, (R)gamma);
-  CM3_HIP_CHECK(hipGetLastError());
-  hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(64), 0, s, (const double *)scratch, blocks, moments);
+                     (double *)scratch, moments, T, E, C, (R)gamma);
   CM3_HIP_CHECK(hipGetLastError());
   return CM3_OK;
 }
 
 template <typename R>
-static int normalize(void *x, const uint8_t *valid, const double *moments, size_t n_elem, int C, double eps, void *stream) {
-  CM3_REQUIRE(x && moments, "null pointer");
+static int normalize(void *x, const uint8_t *valid, const double *parts, int n_parts, double *stats, size_t n_elem, int C,
+                     double eps, int apply, void *stream) {
+  CM3_REQUIRE(parts && n_parts >= 1, "null moments / n_parts < 1");
+  CM3_REQUIRE(!apply || x, "null pointer");
   CM3_REQUIRE(n_elem >= 1 && C >= 1, "n_elem and C must be positive");
-  size_t blocks = (n_elem + kAdvBlock - 1) / kAdvBlock;
+  size_t blocks = apply ? (n_elem + kAdvBlock - 1) / kAdvBlock : 1;
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL((k_normalize<R>), dim3((unsigned)blocks), dim3(kAdvBlock), 0, (hipStream_t)stream, (R *)x, valid,
-                     moments, n_elem, C, eps);
+                     parts, n_parts, stats, n_elem, C, eps, apply);
   CM3_HIP_CHECK(hipGetLastError());
   return CM3_OK;
 }
@@ -132,7 +195,7 @@ static int normalize(void *x, const uint8_t *valid, const double *moments, size_
 }  // namespace cm3
 
 extern "C" {
-size_t cm3_returns_scratch_bytes(void) { return (size_t)cm3::kAdvMaxBlocks * 3 * sizeof(double); }
+size_t cm3_returns_scratch_bytes(void) { return (size_t)cm3::kAdvMaxBlocks * 3 * sizeof(double) + 16; }
 int cm3_returns_moments_f32(const void *x, const uint8_t *done, const uint8_t *valid, void *out, void *scratch,
                             double *moments, int32_t T, int32_t E, int32_t C, double gamma, void *stream) {
   return cm3::returns_moments<float>(x, done, valid, out, scratch, moments, T, E, C, gamma, stream);
@@ -141,10 +204,33 @@ int cm3_returns_moments_f64(const void *x, const uint8_t *done, const uint8_t *v
                             double *moments, int32_t T, int32_t E, int32_t C, double gamma, void *stream) {
   return cm3::returns_moments<double>(x, done, valid, out, scratch, moments, T, E, C, gamma, stream);
 }
-int cm3_normalize_f32(void *x, const uint8_t *valid, const double *moments, size_t n_elem, int32_t C, double eps, void *stream) {
-  return cm3::normalize<float>(x, valid, moments, n_elem, C, eps, stream);
+int cm3_normalize_f32(void *x, const uint8_t *valid, const double *parts, int32_t n_parts, double *stats, size_t n_elem,
+                      int32_t C, double eps, int32_t apply, void *stream) {
+  return cm3::normalize<float>(x, valid, parts, n_parts, stats, n_elem, C, eps, apply, stream);
 }
-int cm3_normalize_f64(void *x, const uint8_t *valid, const double *moments, size_t n_elem, int32_t C, double eps, void *stream) {
-  return cm3::normalize<double>(x, valid, moments, n_elem, C, eps, stream);
+int cm3_normalize_f64(void *x, const uint8_t *valid, const double *parts, int32_t n_parts, double *stats, size_t n_elem,
+                      int32_t C, double eps, int32_t apply, void *stream) {
+  return cm3::normalize<double>(x, valid, parts, n_parts, stats, n_elem, C, eps, apply, stream);
+}
+int cm3_copy_list(int32_t n, void *const *dst, const void *const *src, const size_t *bytes, void *stream) {
+  using namespace cm3;
+  CM3_REQUIRE(n >= 1 && n <= 8 && dst && src && bytes, "copy list: 1..8 regions");
+  CopyList c;
+  size_t most = 0;
+  c.n = n;
+  for (int r = 0; r < n; ++r) {
+    CM3_REQUIRE(dst[r] && src[r], "copy list: null region %d", r);
+    CM3_REQUIRE(bytes[r] % 16 == 0 && ((uintptr_t)dst[r] % 16) == 0 && ((uintptr_t)src[r] % 16) == 0,
+                "copy list: region %d is not 16-byte aligned / sized", r);
+    c.dst[r] = dst[r];
+    c.src[r] = src[r];
+    c.bytes[r] = bytes[r];
+    most = bytes[r] > most ? bytes[r] : most;
+  }
+  size_t blocks = (most / 16 + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+  hipLaunchKernelGGL(k_copy_list, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, c);
+  CM3_HIP_CHECK(hipGetLastError());
+  return CM3_OK;
 }
 }

@@ -129,19 +129,29 @@ class ParticleRollout(object):
         _lib.check(fn(ctypes.byref(env._desc), ctypes.byref(traj), int(n),
                       env._stream() if stream is None else stream))
 
+    def _copy(self, pairs):
+        """(dst, src) tensor pairs: one cm3_copy_list launch when every region is 16-byte sized / aligned."""
+        ok = all((d.numel() * d.element_size()) % 16 == 0 and d.data_ptr() % 16 == 0 and s_.data_ptr() % 16 == 0
+                 and d.is_contiguous() and s_.is_contiguous() for d, s_ in pairs)
+        if ok:
+            _lib.copy_list(pairs, self.env._stream())
+        else:
+            for d, s_ in pairs:
+                d.copy_(s_)
+
     def _load_slot0(self):
         env = self.env
-        self.state[0].copy_(env._state[env._cur])
-        self.obs_others[0].copy_(env._obs_others[env._cur])
+        pairs = [(self.state[0], env._state[env._cur]), (self.obs_others[0], env._obs_others[env._cur])]
         if self.goals is not None:
-            self.goals[0].copy_(env._goals)
+            pairs.append((self.goals[0], env._goals))
+        self._copy(pairs)
 
     def _store_back(self):
         env = self.env
-        env._state[env._cur].copy_(self.state[self.T])
-        env._obs_others[env._cur].copy_(self.obs_others[self.T])
+        pairs = [(env._state[env._cur], self.state[self.T]), (env._obs_others[env._cur], self.obs_others[self.T])]
         if self.goals is not None:
-            env._goals.copy_(self.goals[self.T])
+            pairs.append((env._goals, self.goals[self.T]))
+        self._copy(pairs)
 
     # ---- collection ------------------------------------------------------------------------------------
     def _enqueue_actor_rollout(self, actor, epsilon, base_flags, stream):

@@ -91,9 +91,9 @@ def normalized_returns(reward, done, valid=None, gamma=0.99, eps=1e-8, group=Non
     """GPU path of the advantage-normalisation step over a device trajectory.
 
     reward [T,E] or [T,E,C] (float32/float64, contiguous, on the GPU), done / valid uint8-or-bool [T,E].
-    Three launches and ONE collective per rollout: cm3_returns_moments_* (discounted returns + this rank's
-    float64 moments, deterministic), all_gather_into_tensor of the 3 moments (RCCL), cm3_normalize_* with the
-    rank-ordered global sums.  Returns (returns_or_normalised [same shape], (mean, std, count))."""
+    Two launches and ONE collective per rollout: cm3_returns_moments_* (discounted returns + this rank's
+    float64 moments, deterministic), all_gather_into_tensor of the 3 moments (RCCL), cm3_normalize_* (rank-ordered
+    global sums, mean / std, normalisation).  Returns (returns_or_normalised [same shape], (mean, std, count))."""
     import ctypes
     from . import _lib
     if reward.device.type != "cuda":
@@ -106,26 +106,32 @@ def normalized_returns(reward, done, valid=None, gamma=0.99, eps=1e-8, group=Non
     d8 = done.to(torch.uint8).contiguous()
     v8 = None if valid is None else valid.to(torch.uint8).contiguous()
     out = torch.empty_like(x)
-    scratch = torch.empty(lib.cm3_returns_scratch_bytes() // 8, dtype=torch.float64, device=x.device)
-    moments = torch.zeros(3, dtype=torch.float64, device=x.device)
     stream = _lib.current_stream_handle(x.device)
+    scratch = _scratch(lib, x.device, stream)
+    buf = torch.empty(6, dtype=torch.float64, device=x.device)      # [0:3] this rank's moments, [3:6] (mean, std, count)
+    moments, stats = buf[0:3], buf[3:6]
     _lib.check(getattr(lib, "cm3_returns_moments_" + suffix)(
         x.data_ptr(), d8.data_ptr(), _lib.ptr(v8), out.data_ptr(), scratch.data_ptr(), moments.data_ptr(),
         T, E, C, float(gamma), stream))
+    parts, n_parts = moments, 1
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        world = dist.get_world_size(group)
-        gathered = torch.empty(world * 3, dtype=torch.float64, device=x.device)
-        dist.all_gather_into_tensor(gathered, moments, group=group)
-        parts = gathered.view(world, 3)
-        tot = parts[0].clone()
-        for r in range(1, world):
-            tot = tot + parts[r]
-    else:
-        tot = moments
-    n = tot[2].clamp(min=1.0)
-    mean = tot[0] / n
-    std = (tot[1] / n - mean * mean).clamp(min=0.0).sqrt()
-    if normalize:
-        _lib.check(getattr(lib, "cm3_normalize_" + suffix)(
-            out.data_ptr(), _lib.ptr(v8), tot.data_ptr(), out.numel(), C, float(eps), stream))
-    return out, (mean, std, tot[2])
+        n_parts = dist.get_world_size(group)
+        parts = torch.empty(n_parts * 3, dtype=torch.float64, device=x.device)
+        dist.all_gather_into_tensor(parts, moments, group=group)
+    # rank-ordered sum of the triples, mean / std and the normalisation itself: one launch
+    _lib.check(getattr(lib, "cm3_normalize_" + suffix)(
+        out.data_ptr(), _lib.ptr(v8), parts.data_ptr(), n_parts, stats.data_ptr(), out.numel(), C, float(eps),
+        1 if normalize else 0, stream))
+    return out, (stats[0], stats[1], stats[2])
+
+
+_SCRATCH = {}
+
+
+def _scratch(lib, device, stream):
+    """Scratch of cm3_returns_moments_* per (device, stream): zero-filled once, every launch leaves it ready for the next
+    (launches on one stream are ordered, so they can share it)."""
+    key = (device.type, device.index, int(stream or 0))
+    if key not in _SCRATCH:
+        _SCRATCH[key] = torch.zeros(lib.cm3_returns_scratch_bytes() // 8, dtype=torch.float64, device=device)
+    return _SCRATCH[key]

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define CM3_ABI_VERSION 1
+#define CM3_ABI_VERSION 2
 #define CM3_MAX_AGENTS 8
 
 #define CM3_OK 0
@@ -354,20 +354,25 @@ int cm3_actor_checkers_f32(const cm3_actor_checkers_desc *desc, const cm3_actor_
  * Discounted return-to-go over a time-major trajectory, G[t] = x[t] + gamma * (1 - done[t]) * G[t+1], G[T] = 0:
  *   x, out  real [T][E][C]   (C = N for reward_n, 1 for the team reward); out may alias x
  *   done    uint8 [T][E];  valid uint8 [T][E] optional (invalid entries: out = 0, excluded from the moments)
- *   scratch >= cm3_returns_scratch_bytes() bytes;  moments double[3] = (sum, sum of squares, count) of this
- *   rank's valid returns, computed deterministically (no atomics).  The host all-gathers the three numbers over
- *   the ranks (RCCL) and sums them in rank order; cm3_normalize_* then applies
- *   x = (x - mean) / (std + eps) with the GLOBAL moments (x real [n_elem], valid indexed by element / C).
+ *   scratch >= cm3_returns_scratch_bytes() bytes, ZERO-FILLED before its first use (the launch leaves it ready for the
+ *   next call: the last block to finish folds the per-block partials in block order and resets the ticket counter);
+ *   moments double[3] = (sum, sum of squares, count) of this rank's valid returns, computed deterministically.
+ *   The host all-gathers the three numbers over the ranks (RCCL); cm3_normalize_* sums the n_parts triples in rank order
+ *   and applies x = (x - mean) / (std + eps) with the GLOBAL moments (x real [n_elem], valid indexed by element / C);
+ *   stats (optional) receives (mean, std, count); apply = 0 only computes stats.
  * ---------------------------------------------------------------------------------------- */
 size_t cm3_returns_scratch_bytes(void);
 int cm3_returns_moments_f32(const void *x, const uint8_t *done, const uint8_t *valid, void *out, void *scratch,
                             double *moments, int32_t T, int32_t E, int32_t C, double gamma, void *stream);
 int cm3_returns_moments_f64(const void *x, const uint8_t *done, const uint8_t *valid, void *out, void *scratch,
                             double *moments, int32_t T, int32_t E, int32_t C, double gamma, void *stream);
-int cm3_normalize_f32(void *x, const uint8_t *valid, const double *moments, size_t n_elem, int32_t C, double eps,
-                      void *stream);
-int cm3_normalize_f64(void *x, const uint8_t *valid, const double *moments, size_t n_elem, int32_t C, double eps,
-                      void *stream);
+int cm3_normalize_f32(void *x, const uint8_t *valid, const double *parts, int32_t n_parts, double *stats, size_t n_elem,
+                      int32_t C, double eps, int32_t apply, void *stream);
+int cm3_normalize_f64(void *x, const uint8_t *valid, const double *parts, int32_t n_parts, double *stats, size_t n_elem,
+                      int32_t C, double eps, int32_t apply, void *stream);
+/* Up to 8 device-to-device copies (16-byte aligned pointers and sizes) in ONE launch: trajectory slot <-> live env buffers
+ * of the collection loop (train_onpolicy.py:340-343 "state = next_state" across rollouts). */
+int cm3_copy_list(int32_t n, void *const *dst, const void *const *src, const size_t *bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Measurement and launch plumbing
