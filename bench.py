@@ -464,7 +464,8 @@ def main():
                        "envs_per_gpu": E, "n_agents": N, "global_envs": E * world,
                        "launch": "eager" if args.no_graph else "hipGraph of %d ticks" % GRAPH_TICKS,
                        "ticks_per_launch": ticks_per_launch,
-                       "parallelism": "env-sharded x%d, no data-path collective" % world},
+                       "parallelism": ("env-sharded x%d, one 24-byte moments all-gather (RCCL) per rollout" % world
+                                       if kind == "particle_adv" else "env-sharded x%d, no data-path collective" % world)},
             "agent_steps_per_s": value * N,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
