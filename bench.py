@@ -369,7 +369,7 @@ def main():
     ap.add_argument("--fused", action="store_true",
                     help="random-action rollouts with all 33 ticks of an episode in ONE launch "
                          "(CM3_FLAG_FUSED_TICKS); the default keeps one launch per tick")
-    ap.add_argument("--kernel", choices=["auto", "env", "pair"], default="auto",
+    ap.add_argument("--kernel", choices=["auto", "env", "pair", "agent"], default="auto",
                     help="step-kernel mapping (auto = library heuristic)")
     args = ap.parse_args()
 

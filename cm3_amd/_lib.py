@@ -17,7 +17,9 @@ FLAG_GEN_ACTIONS = 2
 FLAG_KERNEL_LANE_PER_ENV = 0x100
 FLAG_FUSED_TICKS = 0x400
 FLAG_KERNEL_LANE_PER_PAIR = 0x200
-KERNEL_FLAGS = {"auto": 0, "env": FLAG_KERNEL_LANE_PER_ENV, "pair": FLAG_KERNEL_LANE_PER_PAIR}
+FLAG_KERNEL_LANE_PER_AGENT = 0x800
+KERNEL_FLAGS = {"auto": 0, "env": FLAG_KERNEL_LANE_PER_ENV, "pair": FLAG_KERNEL_LANE_PER_PAIR,
+                "agent": FLAG_KERNEL_LANE_PER_AGENT}
 
 
 class Cm3Error(RuntimeError):

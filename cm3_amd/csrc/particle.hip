@@ -678,6 +678,239 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_pairs(const Partic
   }
 }
 
+// ---- the step kernel, third mapping: ONE LANE PER AGENT -----------------------------------------------------
+// With many agents the pair mapping spends its time on per-lane overhead that every one of the N(N-1) lanes of an env
+// repeats (action draw, integration, reward, bookkeeping): at N = 8 it is VALU-bound (531 VALU instructions on each of
+// 8192 waves at 8192 envs = 7 us of issue time) and over-fetches 2.6x (a wave = one env touches a separate cache line
+// per agent row).  Here an env owns G = pow2 >= N consecutive lanes, lane i = agent i: it walks its N-1 contact forces
+// itself (other agents' positions by wavefront shuffle, contributions added in the reference's order), integrates once,
+// counts its own collisions, and a wave covers 64/G consecutive envs -- agent-row loads and stores are whole cache lines.
+// obs_others rows (N-1 vectors per lane) are transposed through a wave-private LDS tile laid out exactly like the
+// 64/G env records in memory, so the wave stores them as contiguous 16-byte-per-lane rows.
+// Bit-identical to the other two mappings (same expressions, same summation orders).
+template <int N> struct AgentGeom {
+  static constexpr int NO = N - 1;
+  static constexpr int G = PairGeom<N>::pow2ceil(N);
+  static constexpr int EPW = 64 / G;        // envs per wave
+  static constexpr int VPE = N * NO;        // obs vectors per env record
+};
+
+template <typename R, int N, int WAVES, bool FUSED>
+__global__ void __launch_bounds__(WAVES * 64) k_particle_step_agents(const ParticleParams p) {
+  static_assert(N >= 2, "the agent mapping needs at least two agents");
+  using V4 = typename Vec<R>::v4;
+  using V2 = typename Vec<R>::v2;
+  using AG = AgentGeom<N>;
+  constexpr int NO = AG::NO, G = AG::G, EPW = AG::EPW, VPE = AG::VPE;
+  __shared__ __attribute__((aligned(32))) R lds_all[WAVES][EPW * VPE * 4];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int gi = lane & (G - 1), sub = lane / G, base = lane - gi;
+  const size_t E = (size_t)p.E;
+  const size_t e0 = ((size_t)blockIdx.x * WAVES + wave) * EPW;
+  const size_t e = e0 + sub;
+  const bool env_ok = e < E;
+  const size_t ec = env_ok ? e : E - 1;
+  const bool agent_ok = gi < N;
+  const int i = agent_ok ? gi : 0;
+  const bool mine = env_ok && agent_ok;  // this lane owns agent i of env e
+  const bool head = env_ok && gi == 0;   // one lane per env does the per-env stores
+  V4 *lds4 = reinterpret_cast<V4 *>(&lds_all[wave][0]);
+
+  // ---- loads (once per launch; the state then lives in registers across the ticks of this launch) -------------
+  V4 si = reinterpret_cast<const V4 *>(p.state_in)[(size_t)i * E + ec];
+  V2 gl = reinterpret_cast<const V2 *>(p.goals_in)[(size_t)i * E + ec];
+  const int2 meta = reinterpret_cast<const int2 *>(p.meta_in)[ec];
+  int steps = meta.x, collisions = meta.y;
+  const bool gen = (p.flags & CM3_FLAG_GEN_ACTIONS) != 0;
+  uint32_t episode = 0;
+  if (gen || (p.flags & CM3_FLAG_AUTO_RESET)) episode = (uint32_t)p.episode[ec];
+  const uint32_t episode_in = episode;
+  const uint64_t genv = (uint64_t)(p.env_id_base + (int64_t)ec);
+  const R kDt = R(0.1), kKeep = R(1 - 0.25), kDistMin = R(0.15) + R(0.15);
+
+  // rows of the wave's obs tile that exist (envs past E are not stored)
+  long envs_here = (long)E - (long)e0;
+  envs_here = envs_here < 0 ? 0 : (envs_here > EPW ? EPW : envs_here);
+  const int nvec = (int)envs_here * VPE;
+
+  // obs rows of this lane (vector k of agent i = s_j - s_i, j the k-th other agent) -> LDS tile -> contiguous rows at dst
+  auto store_obs = [&](const V4 (&oj)[N], void *dst) {
+    if (agent_ok) {
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        if (j != i) lds4[sub * VPE + i * NO + (j < i ? j : j - 1)] = sub4<R, V4>(oj[j], si);
+      }
+    }
+    wave_lds_sync();
+    V4 *out4 = reinterpret_cast<V4 *>(dst) + e0 * VPE;
+    for (int f = lane; f < nvec; f += 64) out4[f] = lds4[f];
+    wave_lds_sync();
+  };
+
+  const int n_ticks = FUSED ? p.n_ticks : 1;
+#pragma unroll 1
+  for (int t = 0; t < n_ticks; ++t) {
+    int32_t *actions_t = tick_ptr(p.actions, p.st_actions, t);
+    int act;
+    if (gen) {  // train_onpolicy.py:305-307
+      const u32x4 w = action_words(p.seed, genv, episode, (uint32_t)steps, (uint32_t)(i >> 2));
+      const int q = i & 3;
+      act = rand5(q == 0 ? w.x : (q == 1 ? w.y : (q == 2 ? w.z : w.w)));
+      if (mine) actions_t[e * N + i] = act;
+    } else {
+      act = actions_t[ec * N + i];
+    }
+
+    // ---- action force + contact forces of agent i, other agents in ascending order (core.py:143-155) ------------
+    R ux = R(0), uy = R(0);
+    if (act == 1) ux = R(-1);
+    if (act == 2) ux = R(+1);
+    if (act == 3) uy = R(-1);
+    if (act == 4) uy = R(+1);
+    R Fx = ux * R(5.0) + R(0.0), Fy = uy * R(5.0) + R(0.0);
+    // Beyond Contact<R>::kSkip the force is exactly (+-)0 and leaves Fx / Fy bit-unchanged (see contact_force), so only
+    // the agents within reach are visited, in ascending order; the wave iterates max-over-lanes(#neighbours in reach)
+    // times (typically 0-2) instead of running the transcendental chain N-1 times because SOME lane needs it.
+    R dxs[N], dys[N];
+    unsigned near_mask = 0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      dxs[j] = si.z - __shfl(si.z, base + j, 64);
+      dys[j] = si.w - __shfl(si.w, base + j, 64);
+      const R dist = Math<R>::sqrt(dxs[j] * dxs[j] + dys[j] * dys[j]);
+      if (j != i && !(dist >= Contact<R>::kSkip)) near_mask |= 1u << j;
+    }
+    while (__any(near_mask != 0u)) {
+      const int jn = near_mask ? (__ffs((int)near_mask) - 1) : 0;
+      R dx = dxs[0], dy = dys[0];
+#pragma unroll
+      for (int j = 1; j < N; ++j) {
+        dx = (jn == j) ? dxs[j] : dx;
+        dy = (jn == j) ? dys[j] : dy;
+      }
+      if (near_mask) {
+        R f_x, f_y;
+        contact_force<R>(dx, dy, f_x, f_y);
+        Fx = f_x + Fx;
+        Fy = f_y + Fy;
+      }
+      near_mask &= near_mask - 1u;
+    }
+
+    // ---- integrate agent i (core.py:158-169) ---------------------------------------------------------------------
+    si.x = si.x * kKeep;
+    si.y = si.y * kKeep;
+    si.x = si.x + (Fx / R(1.0)) * kDt;
+    si.y = si.y + (Fy / R(1.0)) * kDt;
+    si.z = si.z + si.x * kDt;
+    si.w = si.w + si.y * kDt;
+    steps += 1;
+    V4 oj[N];  // post-step state of every agent of this env
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      oj[j].x = __shfl(si.x, base + j, 64);
+      oj[j].y = __shfl(si.y, base + j, 64);
+      oj[j].z = __shfl(si.z, base + j, 64);
+      oj[j].w = __shfl(si.w, base + j, 64);
+    }
+
+    // ---- reward / reached / collisions (multi-goal_spread.py:114-143) ----------------------------------------
+    R rew;
+    {
+      const R dx = si.z - gl.x, dy = si.w - gl.y;
+      rew = R(0) - Math<R>::sqrt(dx * dx + dy * dy);
+    }
+    const bool reached = rew >= R(-0.05);
+    int c_i = 0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const R dx = oj[j].z - si.z, dy = oj[j].w - si.w;  // is_collision(a = j, agent = i)
+      c_i += (j != i && Math<R>::sqrt(dx * dx + dy * dy) < kDistMin) ? 1 : 0;
+    }
+    c_i = agent_ok ? c_i : 0;
+#pragma unroll
+    for (int c = 0; c < NO; ++c)
+      if (c < c_i) rew = rew - R(1);
+    int c_env = c_i;  // every ordered visit counts (:135-137)
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) c_env += __shfl_xor(c_env, off, 64);
+    collisions += c_env;
+    const unsigned long long rb = __ballot(reached && agent_ok);
+    const unsigned long long rgrp = (G == 64) ? rb : ((rb >> base) & ((1ull << (G & 63)) - 1ull));
+    const bool all_reached = __popcll(rgrp) == N;
+    R rews[N];
+#pragma unroll
+    for (int a = 0; a < N; ++a) rews[a] = __shfl(rew, base + a, 64);
+    const R reward = sum_agents<R, N>(rews);
+    const bool done = (steps == p.max_steps) || all_reached;
+
+    if (mine) reinterpret_cast<R *>(tick_ptr(p.reward_n, p.st_reward_n, t))[e * N + i] = rew;
+    if (head) {
+      reinterpret_cast<R *>(tick_ptr(p.reward, p.st_reward, t))[e] = reward;
+      tick_ptr(p.done, p.st_done, t)[e] = done ? 1 : 0;
+    }
+
+    // ---- same-launch re-initialisation -------------------------------------------------------------------------
+    bool was_reset = false;
+    if (p.flags & CM3_FLAG_AUTO_RESET) {
+      void *term_state = tick_ptr(p.term_state, p.st_term_state, t);
+      void *term_obs = tick_ptr(p.term_obs_others, p.st_term_obs, t);
+      if (__any(done)) {  // wave-uniform: the tile store needs every lane
+        if (term_state && done && mine) reinterpret_cast<V4 *>(term_state)[(size_t)i * E + e] = si;
+        if (term_obs) {
+          // terminal observations of the finished envs; rows of unfinished envs in the tile are not written out
+          if (agent_ok) {
+#pragma unroll
+            for (int j = 0; j < N; ++j)
+              if (j != i) lds4[sub * VPE + i * NO + (j < i ? j : j - 1)] = sub4<R, V4>(oj[j], si);
+          }
+          wave_lds_sync();
+          V4 *out4 = reinterpret_cast<V4 *>(term_obs) + e0 * VPE;
+          const unsigned long long done_bits = __ballot(done);
+          for (int f = lane; f < nvec; f += 64) {
+            const int row = f / VPE;
+            if ((done_bits >> (row * G)) & 1ull) out4[f] = lds4[f];
+          }
+          wave_lds_sync();
+        }
+        if (done) {
+          episode += 1;
+          const bool rnd = episode_is_random(p, genv, episode);
+          init_agent<R, N>(p, genv, episode, rnd, i, si, gl);
+          steps = 0;
+          collisions = 0;
+          was_reset = true;
+        }
+#pragma unroll
+        for (int j = 0; j < N; ++j) {  // fresh episodes: the observation is that of the reset state
+          oj[j].x = __shfl(si.x, base + j, 64);
+          oj[j].y = __shfl(si.y, base + j, 64);
+          oj[j].z = __shfl(si.z, base + j, 64);
+          oj[j].w = __shfl(si.w, base + j, 64);
+        }
+      }
+    }
+
+    // ---- per-tick stores ------------------------------------------------------------------------------------------
+    if (mine) {
+      reinterpret_cast<V4 *>(tick_ptr(p.state_out, p.st_state, t))[(size_t)i * E + e] = si;
+      if (p.goals_out != p.goals_in || was_reset)
+        reinterpret_cast<V2 *>(tick_ptr(p.goals_out, p.st_goals, t))[(size_t)i * E + e] = gl;
+    }
+    store_obs(oj, tick_ptr(p.obs_others, p.st_obs, t));  // observation (multi-goal_spread.py:145-154)
+  }
+
+  // ---- live counters, once per launch -------------------------------------------------------------------------------
+  if (head) {
+    int2 m;
+    m.x = steps;
+    m.y = collisions;
+    reinterpret_cast<int2 *>(p.meta_out)[e] = m;
+    if (episode != episode_in) p.episode[e] = (int32_t)episode;
+  }
+}
+
 // ---- reset kernel (environment.py:125-149) ------------------------------------------------------------
 template <typename R, int N, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) k_particle_reset(const ParticleParams p) {
@@ -746,12 +979,14 @@ static int fill_params(const cm3_particle_desc *d, const cm3_particle_bufs *b, P
               CM3_MAX_AGENTS, d->n_agents);
   CM3_REQUIRE(d->max_steps >= 1, "max_steps must be >= 1");
   CM3_REQUIRE((d->flags & ~(CM3_FLAG_AUTO_RESET | CM3_FLAG_GEN_ACTIONS | CM3_FLAG_KERNEL_LANE_PER_ENV |
-                            CM3_FLAG_KERNEL_LANE_PER_PAIR | CM3_FLAG_FUSED_TICKS)) == 0,
+                            CM3_FLAG_KERNEL_LANE_PER_PAIR | CM3_FLAG_KERNEL_LANE_PER_AGENT | CM3_FLAG_FUSED_TICKS)) == 0,
               "unknown flag bits 0x%x", d->flags);
-  CM3_REQUIRE(!((d->flags & CM3_FLAG_KERNEL_LANE_PER_ENV) && (d->flags & CM3_FLAG_KERNEL_LANE_PER_PAIR)),
-              "both kernel-mapping flags set");
-  CM3_REQUIRE(!((d->flags & CM3_FLAG_KERNEL_LANE_PER_PAIR) && d->n_agents < 2),
-              "the lane-per-pair kernel needs n_agents >= 2");
+  {
+    const uint32_t k = d->flags & (CM3_FLAG_KERNEL_LANE_PER_ENV | CM3_FLAG_KERNEL_LANE_PER_PAIR | CM3_FLAG_KERNEL_LANE_PER_AGENT);
+    CM3_REQUIRE((k & (k - 1)) == 0, "more than one kernel-mapping flag set");
+  }
+  CM3_REQUIRE(!((d->flags & (CM3_FLAG_KERNEL_LANE_PER_PAIR | CM3_FLAG_KERNEL_LANE_PER_AGENT)) && d->n_agents < 2),
+              "the lane-per-pair / lane-per-agent kernels need n_agents >= 2");
   CM3_REQUIRE(b->obs_others, "obs_others is required");
   if (op == kStep) {
     CM3_REQUIRE(b->state_in && b->state_out && b->goals_in && b->goals_out && b->meta_in && b->meta_out,
@@ -839,11 +1074,36 @@ template <typename R, int N, int WAVES> static int launch_pairs(const ParticlePa
 // N=8 6.9 vs 23.9 us at 4096, 17.4 vs 24.2 us at 16384, 29.5 vs 25.4 us at 32768; N=2 is a tie everywhere.
 constexpr size_t kPairsMaxEnvs = (size_t)1 << 14;
 
+template <typename R, int N, int WAVES> static int launch_agents(const ParticleParams &p, hipStream_t stream) {
+  if constexpr (N >= 2) {
+    const size_t envs_per_block = (size_t)WAVES * AgentGeom<N>::EPW;
+    const unsigned blocks = (unsigned)(((size_t)p.E + envs_per_block - 1) / envs_per_block);
+    if (p.n_ticks > 1)
+      hipLaunchKernelGGL((k_particle_step_agents<R, N, WAVES, true>), dim3(blocks), dim3(WAVES * 64), 0, stream, p);
+    else
+      hipLaunchKernelGGL((k_particle_step_agents<R, N, WAVES, false>), dim3(blocks), dim3(WAVES * 64), 0, stream, p);
+    CM3_HIP_CHECK(hipGetLastError());
+    return CM3_OK;
+  } else {
+    return fail(CM3_ERR_INVALID, "the lane-per-agent kernel needs n_agents >= 2");
+  }
+}
+
 template <typename R, int N> static int launch_n(const ParticleParams &p, ParticleOp op, hipStream_t stream) {
   if (op == kStep) {
     bool pairs = N >= 3 && (size_t)p.E <= kPairsMaxEnvs;
-    if (p.flags & CM3_FLAG_KERNEL_LANE_PER_ENV) pairs = false;
-    if (p.flags & CM3_FLAG_KERNEL_LANE_PER_PAIR) pairs = true;
+    // many agents: the lane-per-agent mapping wins from ~6k to 128k envs (N = 8, us per launch, pair / agent / env:
+    // 4096: 6.8 / 8.0 / 24;  8192: 10.7 / 8.7 / 24;  16384: 17.7 / 10.7 / 24;  32768: 30 / 15.3 / 25.5;
+    // 65536: 52 / 22.6 / 28.7;  131072: 99 / 37.3 / 39.1;  262144: 192 / 77.7 / 73.7 -- profiles/r01_kernel_sweep.txt)
+    bool agents = N >= 6 && (size_t)p.E >= 6144 && (size_t)p.E <= ((size_t)1 << 17);
+    if (p.flags & CM3_FLAG_KERNEL_LANE_PER_ENV) pairs = agents = false;
+    if (p.flags & CM3_FLAG_KERNEL_LANE_PER_PAIR) { pairs = true; agents = false; }
+    if (p.flags & CM3_FLAG_KERNEL_LANE_PER_AGENT) agents = true;
+    if (agents) {
+      const size_t waves = ((size_t)p.E + AgentGeom<(N >= 2 ? N : 2)>::EPW - 1) / AgentGeom<(N >= 2 ? N : 2)>::EPW;
+      if (waves < 256) return launch_agents<R, N, 1>(p, stream);
+      return launch_agents<R, N, 4>(p, stream);
+    }
     if (pairs) {
       // 4 waves per workgroup (one per SIMD of a CU) measured faster than 1 or 2 from 1024 waves up
       // (tools/probes/step_timeline.hip: 4.38 vs 4.82 us at E=4096, 6.36 vs 7.32 us at E=16384, stamped build);

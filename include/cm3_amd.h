@@ -66,6 +66,7 @@ extern "C" {
 #define CM3_FLAG_KERNEL_LANE_PER_ENV 0x100u  /* particle step: force the one-lane-per-env mapping   */
 #define CM3_FLAG_KERNEL_LANE_PER_PAIR 0x200u /* particle step: force the one-lane-per-agent-pair mapping
                                                 (default: chosen from n_envs; both give identical results) */
+#define CM3_FLAG_KERNEL_LANE_PER_AGENT 0x800u /* particle step: force the one-lane-per-agent mapping (n_agents >= 2) */
 
 int cm3_abi_version(void);
 const char *cm3_last_error(void);

@@ -23,7 +23,7 @@ EDGE = 2e-6
 NAMES = golden_names("particle_")
 
 
-KERNELS = ["env", "pair"]      # both step-kernel mappings must satisfy every parity test
+KERNELS = ["env", "pair", "agent"]      # every step-kernel mapping must satisfy every parity test
 
 
 def _env(cfg, N, E, dtype=torch.float32, prob_random=0.2, max_steps=33, **kw):
@@ -295,13 +295,14 @@ def test_bad_arguments_raise():
 @pytest.mark.parametrize("N,cfg_name", [(2, "particle_stage2_merge.json"), (4, "particle_stage2_cross.json"),
                                         (8, "particle_merge8.json"), (5, "particle_merge8.json")])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
-def test_both_kernel_mappings_agree_bitwise(N, cfg_name, dtype):
+@pytest.mark.parametrize("other", ["pair", "agent"])
+def test_both_kernel_mappings_agree_bitwise(N, cfg_name, dtype, other):
     """Same inputs, same bits: 40 free-running ticks with in-kernel actions and auto-reset (max_steps 7) through
-    the lane-per-env and the lane-per-pair kernels, including terminal capture."""
+    the lane-per-env kernel and the lane-per-pair / lane-per-agent kernels, including terminal capture."""
     cfg = load_cfg(cfg_name)
     E = 1000
     a = _env(cfg, N, E, dtype=dtype, seed=21, auto_reset=True, max_steps=7, kernel="env")
-    b = _env(cfg, N, E, dtype=dtype, seed=21, auto_reset=True, max_steps=7, kernel="pair")
+    b = _env(cfg, N, E, dtype=dtype, seed=21, auto_reset=True, max_steps=7, kernel=other)
     a.enable_terminal_capture()
     b.enable_terminal_capture()
     a.reset()
@@ -313,6 +314,11 @@ def test_both_kernel_mappings_agree_bitwise(N, cfg_name, dtype):
         assert torch.equal(a.last_actions, b.last_actions)
         assert torch.equal(a.collisions, b.collisions) and torch.equal(a.steps, b.steps)
         assert torch.equal(a.goals, b.goals) and torch.equal(a.episode, b.episode)
+        # terminal capture of the envs that finished in this tick
+        d = ra[-1]
+        if bool(d.any()):
+            assert torch.equal(a.terminal_state[d], b.terminal_state[d]), t
+            assert torch.equal(a.terminal_obs_others[d], b.terminal_obs_others[d]), t
     assert torch.equal(a.terminal_state, b.terminal_state)
     assert torch.equal(a.terminal_obs_others, b.terminal_obs_others)
 
@@ -322,7 +328,7 @@ def test_both_kernel_mappings_agree_bitwise(N, cfg_name, dtype):
 def test_f64_free_running_random_configs_all_agent_counts(N, kernel):
     """33 free-running ticks in float64 from random crowded states, random (also out-of-range) actions, for every
     agent count and both kernel mappings: state / obs / rewards / done / collisions against the NumPy oracle."""
-    if N == 1 and kernel == "pair":
+    if N == 1 and kernel in ("pair", "agent"):
         pytest.skip("the pair mapping needs at least two agents")
     rng = np.random.default_rng(100 + N)
     cfg = dict(n_agents=N, agents_x=rng.uniform(-1, 1, N).tolist(), agents_y=rng.uniform(-1, 1, N).tolist(),

@@ -154,7 +154,7 @@ def test_checkers_rollout_matches_oracle_and_16_column_layout():
     assert rows.shape == (4, 16)
 
 
-@pytest.mark.parametrize("kernel", ["env", "pair"])
+@pytest.mark.parametrize("kernel", ["env", "pair", "agent"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 @pytest.mark.parametrize("auto_reset", [False, True])
 def test_fused_rollout_equals_per_tick_rollout(kernel, dtype, auto_reset):

@@ -77,7 +77,7 @@ def test_gpu_particle_momentum_and_idempotent_observe():
     from cm3_amd.particle import VecParticleEnv
     cfg = load_cfg("particle_stage2_antipodal.json")
     E, N = 4096, 4
-    for kernel in ("env", "pair"):
+    for kernel in ("env", "pair", "agent"):
         env = VecParticleEnv(cfg, N, 0.2, 33, E, device="cuda:0", dtype=torch.float64, kernel=kernel)
         rng = np.random.default_rng(0)
         pos = rng.uniform(-0.4, 0.4, (E, N, 2))

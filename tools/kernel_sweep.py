@@ -23,7 +23,7 @@ def main():
             if N == 8 and log2e > 20:
                 continue
             res = {}
-            steppers = {k: ParticleStepper(cfg, N, E, dev, kernel=k) for k in ("env", "pair")}
+            steppers = {k: ParticleStepper(cfg, N, E, dev, kernel=k) for k in ("env", "pair", "agent")}
             for st in steppers.values():
                 st.capture(GRAPH_TICKS)
                 st.run(GRAPH_TICKS * 2)
