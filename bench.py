@@ -469,7 +469,7 @@ def main():
             "agent_steps_per_s": value * N,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "kernel": "k_checkers_step_fast" if kind == "checkers" else "k_particle_step(_pairs)<float,%d>" % N,
+                         "kernel": "k_checkers_step_fast" if kind == "checkers" else "k_particle_step(_pairs|_agents)<float,%d>" % N,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "avg_launch_us": launch_s * 1e6},
         }
