@@ -717,6 +717,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_agents(const Parti
   const bool head = env_ok && gi == 0;   // one lane per env does the per-env stores
   V4 *lds4 = reinterpret_cast<V4 *>(&lds_all[wave][0]);
 
+  CM3_STAMP(0, false);
   // ---- loads (once per launch; the state then lives in registers across the ticks of this launch) -------------
   V4 si = reinterpret_cast<const V4 *>(p.state_in)[(size_t)i * E + ec];
   V2 gl = reinterpret_cast<const V2 *>(p.goals_in)[(size_t)i * E + ec];
@@ -748,6 +749,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_agents(const Parti
     wave_lds_sync();
   };
 
+  CM3_STAMP(1, true);
   const int n_ticks = FUSED ? p.n_ticks : 1;
 #pragma unroll 1
   for (int t = 0; t < n_ticks; ++t) {
@@ -762,6 +764,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_agents(const Parti
       act = actions_t[ec * N + i];
     }
 
+    CM3_STAMP(2, false);
     // ---- action force + contact forces of agent i, other agents in ascending order (core.py:143-155) ------------
     R ux = R(0), uy = R(0);
     if (act == 1) ux = R(-1);
@@ -798,6 +801,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_agents(const Parti
       near_mask &= near_mask - 1u;
     }
 
+    CM3_STAMP(3, false);
     // ---- integrate agent i (core.py:158-169) ---------------------------------------------------------------------
     si.x = si.x * kKeep;
     si.y = si.y * kKeep;
@@ -815,6 +819,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_agents(const Parti
       oj[j].w = __shfl(si.w, base + j, 64);
     }
 
+    CM3_STAMP(4, true);
     // ---- reward / reached / collisions (multi-goal_spread.py:114-143) ----------------------------------------
     R rew;
     {
@@ -851,6 +856,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_agents(const Parti
       tick_ptr(p.done, p.st_done, t)[e] = done ? 1 : 0;
     }
 
+    CM3_STAMP(5, false);
     // ---- same-launch re-initialisation -------------------------------------------------------------------------
     bool was_reset = false;
     if (p.flags & CM3_FLAG_AUTO_RESET) {
@@ -892,6 +898,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_agents(const Parti
       }
     }
 
+    CM3_STAMP(6, false);
     // ---- per-tick stores ------------------------------------------------------------------------------------------
     if (mine) {
       reinterpret_cast<V4 *>(tick_ptr(p.state_out, p.st_state, t))[(size_t)i * E + e] = si;
@@ -901,6 +908,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_agents(const Parti
     store_obs(oj, tick_ptr(p.obs_others, p.st_obs, t));  // observation (multi-goal_spread.py:145-154)
   }
 
+  CM3_STAMP(7, false);
   // ---- live counters, once per launch -------------------------------------------------------------------------------
   if (head) {
     int2 m;
@@ -909,6 +917,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_agents(const Parti
     reinterpret_cast<int2 *>(p.meta_out)[e] = m;
     if (episode != episode_in) p.episode[e] = (int32_t)episode;
   }
+  CM3_STAMP(8, true);
 }
 
 // ---- reset kernel (environment.py:125-149) ------------------------------------------------------------
