@@ -423,14 +423,11 @@ class CheckersRollout(object):
             else:
                 self._enqueue_actor_rollout(policy, epsilon, env._stream())
             return self
-        for t in range(self.T):
-            if policy is None:
-                env._desc.flags = FLAG_GEN_ACTIONS
-            else:
-                prev = self.actions[t - 1] if t > 0 else torch.zeros_like(self.actions[0])
-                a = policy(prev, self.obs_others[t], self.obs_self_t[t], self.obs_self_v[t], self.goals_onehot)
-                self.actions[t].copy_(torch.as_tensor(a, device=env.device).reshape(env.E, env.n))
-                env._desc.flags = 0
+        env._desc.flags = 0
+        for t in range(self.T):                                              # host policy: one call per tick
+            prev = self.actions[t - 1] if t > 0 else torch.zeros_like(self.actions[0])
+            a = policy(prev, self.obs_others[t], self.obs_self_t[t], self.obs_self_v[t], self.goals_onehot)
+            self.actions[t].copy_(torch.as_tensor(a, device=env.device).reshape(env.E, env.n))
             b = self._bufs(t)
             _lib.check(self._lib.cm3_checkers_step(ctypes.byref(env._desc), ctypes.byref(b), env._stream()))
         return self
