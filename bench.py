@@ -473,8 +473,10 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "avg_launch_us": launch_s * 1e6},
         }
-    if rank == 0 and args.workload == "c2" and E == 4096:
-        traffic, rec = pmc_traffic("c2_particle_antipodal_n4_e4096")
+    traffic_tag = {("c2", 4096): "c2_particle_antipodal_n4_e4096", ("c3", 8192): "c3_checkers_stage2_n2_e8192",
+                   ("c5", 8192): "c5_particle_merge8_n8_e8192"}.get((args.workload, E))
+    if rank == 0 and traffic_tag and not args.fused:
+        traffic, rec = pmc_traffic(traffic_tag)
         if traffic is not None:
             out["roofline"]["traffic"] = traffic
             out["roofline"]["traffic_source"] = ("profiles/pmc_traffic.json: %s, %d launches, FETCH_SIZE %.1f KB (x2) + "

@@ -355,18 +355,24 @@ __device__ __forceinline__ void ck_step_env(const CheckersParams &p, size_t e, s
 }
 
 
-// ---- fast path: the reference geometry (3 x 8 band, n_obs 2), 16 lanes per env ----------------------------
+// ---- fast path: the reference geometry (3 x 8 band, n_obs 2), G lanes per env ------------------------------
 // The generic kernel above is latency-bound at the BASELINE batch (8192 envs = 128 waves, each lane filling
-// ~200 bytes one at a time).  Here an env owns 16 consecutive lanes: every lane redundantly runs the (short)
+// ~200 bytes one at a time).  Here an env owns G = 8 consecutive lanes: every lane redundantly runs the (short)
 // sequential state update -- lanes of a wave execute in lockstep, so that costs nothing and needs no shuffle --
-// and then produces a 1/16 share of the env's outputs: one dword of the (4-byte padded) grid record, up to
-// three dwords of the padded obs_self_t record, and one of the small vector outputs.  No LDS; a wave stores
-// 4 whole env records contiguously.
+// and then produces a 1/G share of the env's outputs: dwords g, g + G, ... of the (4-byte padded) grid record and of
+// the padded obs_self_t record, and one of the small vector outputs.  No LDS; a wave stores 64/G whole env records
+// contiguously.
+// lanes per env; measured at C3 (8192 envs, us per tick / fused env-steps/s): 2: 8.3 / 1.3e9, 4: 6.7 / 1.7e9,
+// 8: 5.1 / 2.5e9, 16: 5.7 / 2.4e9, 32: 7.6 / 1.5e9
+#ifndef CM3_CKF_G
+#define CM3_CKF_G 8
+#endif
 template <int N> struct CkFast {
   static constexpr int R = 3, C = 8, O = 2, K = 5, TR = 7, TC = 13;
   static constexpr int GRID_REC = R * (C + 1) * 2;  // 54
   static constexpr int OBST_REC = N * K * K * 3;    // 75 N
-  static constexpr int G = 16;
+  static constexpr int G = CM3_CKF_G;
+  static constexpr int EPW = 64 / G;
 };
 
 // One window / grid cell as packed bytes, branch-free.  (A first version decoded and evaluated every output BYTE with
@@ -438,7 +444,7 @@ __device__ __forceinline__ void ckf_emit(const CheckersParams &p, const CkState<
   const int gd = p.grid_stride >> 2;
   int8_t *grid_t = ck_tick_ptr(p.grid, p.st_grid, t);
   const uint32_t m32 = (uint32_t)s.mask;  // 24 collected bits
-  if (g < gd) reinterpret_cast<uint32_t *>(grid_t + e * (size_t)p.grid_stride)[g] = ckf_grid_dword<N>(m32, g);
+  for (int d = g; d < gd; d += F::G) reinterpret_cast<uint32_t *>(grid_t + e * (size_t)p.grid_stride)[d] = ckf_grid_dword<N>(m32, d);
   // obs_self_t record: dwords g, g+16, ...
   const int od = p.obst_stride >> 2;
   uint32_t *o32 = reinterpret_cast<uint32_t *>(ck_tick_ptr(p.obs_self_t, p.st_obs_self_t, t) + e * (size_t)p.obst_stride);
@@ -487,8 +493,8 @@ __device__ __forceinline__ void ckf_emit(const CheckersParams &p, const CkState<
 
 template <int N, bool FUSED> __global__ void __launch_bounds__(256) k_checkers_step_fast(const CheckersParams p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int g = lane & 15, sub = lane >> 4;
-  const size_t e = ((size_t)blockIdx.x * 4 + wave) * 4 + sub;
+  const int g = lane & (CkFast<N>::G - 1), sub = lane / CkFast<N>::G;
+  const size_t e = ((size_t)blockIdx.x * 4 + wave) * CkFast<N>::EPW + sub;
   const bool env_ok = e < (size_t)p.E;
   const size_t ec = env_ok ? e : (size_t)p.E - 1;
   const bool writer = env_ok && g == 0;
@@ -507,8 +513,8 @@ template <int N, bool FUSED> __global__ void __launch_bounds__(256) k_checkers_s
 
 template <int N> __global__ void __launch_bounds__(256) k_checkers_reset_fast(const CheckersParams p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int g = lane & 15, sub = lane >> 4;
-  const size_t e = ((size_t)blockIdx.x * 4 + wave) * 4 + sub;
+  const int g = lane & (CkFast<N>::G - 1), sub = lane / CkFast<N>::G;
+  const size_t e = ((size_t)blockIdx.x * 4 + wave) * CkFast<N>::EPW + sub;
   const bool env_ok = e < (size_t)p.E;
   const size_t ec = env_ok ? e : (size_t)p.E - 1;
   CkState<N> s;
@@ -649,7 +655,8 @@ static int ck_fill(const cm3_checkers_desc *d, const cm3_checkers_bufs *b, const
 
 template <int N> static int ck_launch(const CheckersParams &p, bool step, hipStream_t stream) {
   if (ck_fast_ok(p)) {
-    const unsigned fblocks = (unsigned)(((size_t)p.E + 15) / 16);  // 4 waves x 4 envs per workgroup
+    constexpr unsigned kEnvsPerBlock = 4 * CkFast<N>::EPW;  // 4 waves x EPW envs per workgroup
+    const unsigned fblocks = (unsigned)(((size_t)p.E + kEnvsPerBlock - 1) / kEnvsPerBlock);
     if (step && p.n_ticks > 1)
       hipLaunchKernelGGL((k_checkers_step_fast<N, true>), dim3(fblocks), dim3(256), 0, stream, p);
     else if (step)
