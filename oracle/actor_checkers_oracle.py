@@ -14,10 +14,13 @@ Restates (float32, like the TF1 graph):
   alg_credit_checkers.Alg.run_actor  /root/reference/alg/alg_credit_checkers.py:229-253 (actions_prev -> one-hot)
 Widths from config_checkers_stage{1,2}.json "nn": A_conv_f 6, A_conv_k [3,3], A_n_h1 256, A_n_h2 256.
 
-PARITY UNPINNED against TensorFlow itself (TF1 is not installable in the build container).  The forward pass is pinned
-to the published semantics of the TF ops; tests/test_oracle_actor_checkers.py cross-checks the convolution and the
-dense chain against an independent PyTorch float32 implementation.  Sampling is distributional, exactly as in
-oracle/actor_oracle.py (one Philox uniform per agent-step, inverse CDF in action order).
+PARITY UNPINNED against TensorFlow itself (TF1 is not installable in the build container).  What IS pinned: the layer
+wiring, flatten / concat order, variable names and shapes -- tests/golden/actor_checkers.npz holds vectors produced by executing
+the reference's OWN function bodies networks.actor_checkers + convnet_1 under a NumPy stand-in for the TF1 calls they make
+(oracle/tf_numpy_shim.py, tests/test_oracle_actor_golden.py); the primitive-op semantics (NHWC "SAME" cross-correlation, dense,
+relu, softmax) rest on their published behaviour, and tests/test_oracle_actor_checkers.py cross-checks them against an
+independent PyTorch float32 implementation.  Sampling is distributional, exactly as in oracle/actor_oracle.py (one Philox
+uniform per agent-step, inverse CDF in action order).
 """
 import numpy as np
 

@@ -9,10 +9,13 @@ Restates (float32, like the TF1 graph):
       probs = (1 - eps) * probs + eps / l_action ; action ~ multinomial(log probs)
   alg_credit.Alg.run_actor           /root/reference/alg/alg_credit.py:249-270   (batch of all agents)
 
-PARITY UNPINNED against TensorFlow itself: TF1 is not installable in the build container (no network), so the
-forward pass is pinned only to the published semantics of tf.layers.dense / tf.nn.relu / tf.nn.softmax, and
-sampling is distributional: tf.multinomial's generator cannot be reproduced, the build draws one uniform per
-agent-step from its Philox stream (oracle/philox.py) and inverts the CDF in action order.
+PARITY UNPINNED against TensorFlow itself: TF1 is not installable in the build container (no network).  What IS pinned
+(tests/test_oracle_actor_golden.py, tests/golden/actor_particle.npz): the layer wiring, concat order, variable names and
+shapes -- the golden vectors come from executing the reference's OWN function body networks.actor_particle under a NumPy
+stand-in for the TF1 calls it makes (oracle/tf_numpy_shim.py); only the semantics of those primitive ops (dense = x @ kernel
++ bias, relu, softmax) rest on their published behaviour.  Sampling is distributional: tf.multinomial's generator cannot be
+reproduced, the build draws one uniform per agent-step from its Philox stream (oracle/philox.py) and inverts the CDF in
+action order.
 """
 import numpy as np
 

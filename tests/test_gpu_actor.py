@@ -182,3 +182,24 @@ def test_fused_policy_rollout_equals_launch_per_tick(N, cfg, auto_reset, precisi
     ea, eb = outs[0][1], outs[1][1]
     assert torch.equal(ea.steps, eb.steps) and torch.equal(ea.collisions, eb.collisions)
     assert torch.equal(ea.episode, eb.episode) and torch.equal(ea.global_state, eb.global_state)
+
+
+@pytest.mark.parametrize("tag,N,stage", [("n4_stage2", 4, 2), ("n1_stage1", 1, 1), ("n8_stage2", 8, 2)])
+def test_device_actor_matches_vectors_from_the_reference_function_body(tag, N, stage):
+    """tests/golden/actor_particle.npz: probabilities obtained by executing the reference's networks.actor_particle under
+    the NumPy TF stand-in (oracle/gen_golden_actor.py).  The rows are laid out as E = rows / N envs for the kernel."""
+    from cm3_amd.actor import ParticleActor
+    from tests.test_oracle_actor_golden import load_cases
+    w, inp, want = load_cases("actor_particle")[tag]
+    rows = want.shape[0]
+    E = rows // N
+    dev = "cuda:0"
+    obs = torch.as_tensor(inp["obs_others"]).reshape(E, N, -1).contiguous().to(dev)
+    state = torch.as_tensor(inp["v_obs"]).reshape(E, N, 4).permute(1, 0, 2).contiguous().to(dev)       # [N][E][4]
+    goals = torch.as_tensor(inp["v_goal"]).reshape(E, N, 2).permute(1, 0, 2).contiguous().to(dev)      # [N][E][2]
+    meta = torch.zeros(E, 2, dtype=torch.int32, device=dev)
+    episode = torch.zeros(E, dtype=torch.int32, device=dev)
+    actions = torch.empty(E, N, dtype=torch.int32, device=dev)
+    probs = torch.empty(E, N, 5, dtype=torch.float32, device=dev)
+    ParticleActor(w, N, stage=stage, device=dev).enqueue(E, obs, state, goals, meta, episode, actions, 0.0, probs)
+    assert np.abs(probs.reshape(rows, 5).cpu().numpy() - want).max() < 2e-5

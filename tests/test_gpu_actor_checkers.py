@@ -260,3 +260,30 @@ def test_bf16_layers_are_close_to_float32(stage):
     assert float(d.max()) > 0                                     # it is a different kernel
     assert (p16.sum(-1) - 1).abs().max() < 1e-5
     assert float((a32 == a16).float().mean()) > 0.97              # same uniforms, nearly the same CDFs
+
+
+@pytest.mark.parametrize("tag,N,stage", [("n2_stage2", 2, 2), ("n1_stage1", 1, 1)])
+def test_device_actor_matches_vectors_from_the_reference_function_body(tag, N, stage):
+    """tests/golden/actor_checkers.npz: probabilities obtained by executing the reference's networks.actor_checkers (and
+    convnet_1) under the NumPy TF stand-in (oracle/gen_golden_actor.py)."""
+    from cm3_amd.actor import CheckersActor
+    from tests.test_oracle_actor_golden import load_cases
+    w, inp, want = load_cases("actor_checkers")[tag]
+    rows = want.shape[0]
+    E = rows // N
+    dev = "cuda:0"
+    stride = (75 * N + 3) // 4 * 4
+    raw = torch.zeros(E, stride, dtype=torch.int8)
+    raw[:, :75 * N] = torch.as_tensor(inp["obs_self_t"]).to(torch.int8).reshape(E, N * 75)
+    raw = raw.to(dev)
+    ov = torch.as_tensor(inp["obs_self_v"]).to(torch.float64).reshape(E, N, 4).contiguous().to(dev)
+    oo = torch.as_tensor(inp["obs_others"]).to(torch.float64).reshape(E, N, -1).contiguous().to(dev)
+    goals = torch.as_tensor(inp["goals"].argmax(1)).to(torch.uint8).reshape(E, N).contiguous().to(dev)
+    prev = torch.as_tensor(inp["a_prev"]).to(torch.int32).reshape(E, N).contiguous().to(dev)
+    steps = torch.zeros(E, dtype=torch.int32, device=dev)
+    episode = torch.zeros(E, dtype=torch.int32, device=dev)
+    actions = torch.empty(E, N, dtype=torch.int32, device=dev)
+    probs = torch.empty(E, N, 5, dtype=torch.float32, device=dev)
+    CheckersActor(w, N, stage=stage, device=dev).enqueue(E, raw, stride, ov, oo, goals, prev, steps, episode, actions,
+                                                         0.0, probs)
+    assert np.abs(probs.reshape(rows, 5).cpu().numpy() - want).max() < 2e-5
