@@ -222,6 +222,38 @@ def measure_read_bandwidth(device, gib=4.0, reps=5):
     return nbytes / (ms * 1e-3) / 1e9
 
 
+def measure_launch_floor(device, read_bytes, write_bytes, blocks, threads=256):
+    """us per launch of (a) the load -> store skeleton with the step launch's traffic and (b) an empty launch of the same
+    shape, each as a 33-node hipGraph replayed like the bench's rollout (cm3_traffic_floor_bench)."""
+    import torch
+    from cm3_amd import _lib
+    lib = _lib.lib()
+    src = torch.zeros(max(read_bytes, 16) // 4, dtype=torch.int32, device=device)
+    dst = torch.zeros(max(write_bytes, 16) // 4, dtype=torch.int32, device=device)
+    res = {}
+    for name, (rb, wb) in (("same_traffic_us", (read_bytes, write_bytes)), ("empty_launch_us", (0, 0))):
+        def enqueue(s, rb=rb, wb=wb):
+            for _ in range(GRAPH_TICKS):
+                _lib.check(lib.cm3_traffic_floor_bench(src.data_ptr(), rb, dst.data_ptr(), wb, blocks, threads, s))
+        graph = _lib.capture_graph(device, enqueue)
+        s = _lib.current_stream_handle(device)
+        for _ in range(5):
+            _lib.check(lib.cm3_graph_launch(graph, s))
+        torch.cuda.synchronize(device)
+        start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 50
+        start.record()
+        for _ in range(reps):
+            _lib.check(lib.cm3_graph_launch(graph, s))
+        stop.record()
+        stop.synchronize()
+        res[name] = start.elapsed_time(stop) * 1e3 / (reps * GRAPH_TICKS)
+        lib.cm3_graph_destroy(graph)
+    res["note"] = ("%d x %d lanes, %d B read then %d B written per launch, no arithmetic; the step kernel's average launch "
+                   "time divided into same_traffic_us is frac_of_floor" % (blocks, threads, read_bytes, write_bytes))
+    return res
+
+
 def cfg_name_of(cfg):
     """Name of the cm3_amd/configs file a loaded particle config came from (for the worker command line)."""
     import cm3_amd
@@ -603,6 +635,18 @@ def main():
         bw = measure_read_bandwidth(device)
         out["roofline"]["measured_read_GBps"] = bw
         out["roofline"]["frac_of_measured_read"] = achieved / bw
+        if kind in ("particle", "checkers") and not args.fused:
+            # What one launch per tick cannot go below at this batch: the same number of 256-lane workgroups reading and
+            # writing the same algorithmic bytes with NO arithmetic (load -> store skeleton), and an empty launch, both
+            # replayed as the same 33-node hipGraph.
+            if kind == "particle":
+                rd, wr = (28 * N + 4) * E, (20 * N + 16 * N * max(N - 1, 1) + 12) * E
+            else:
+                rd, wr = 24 * E, 376 * E
+            rd, wr = (rd + 15) // 16 * 16, (wr + 15) // 16 * 16
+            floor = measure_launch_floor(device, rd, wr, blocks=max(1, min(2048, (E * 16 + 255) // 256)))
+            floor["frac_of_floor"] = floor["same_traffic_us"] / (launch_s * 1e6)
+            out["roofline"]["launch_floor"] = floor
         if not args.no_sweep and kind == "particle":
             sweep = []
             stepper.close()

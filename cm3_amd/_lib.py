@@ -154,6 +154,7 @@ SYMBOLS = {
     "cm3_copy_list": (ctypes.c_int, [c_int32, P(c_void_p), P(c_void_p), P(c_size_t), c_void_p]),
     "cm3_hbm_read_bench": (ctypes.c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
     "cm3_hbm_bench_sink_words": (ctypes.c_int, []),
+    "cm3_traffic_floor_bench": (ctypes.c_int, [c_void_p, c_size_t, c_void_p, c_size_t, c_int32, c_int32, c_void_p]),
     "cm3_graph_begin": (ctypes.c_int, [c_void_p]),
     "cm3_graph_end": (ctypes.c_int, [c_void_p, P(c_void_p)]),
     "cm3_graph_launch": (ctypes.c_int, [c_void_p, c_void_p]),

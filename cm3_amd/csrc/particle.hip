@@ -541,6 +541,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_pairs(const Partic
   const bool lead = slot_ok && k == 0;  // one lane per agent does the per-agent stores
   const bool head = gslot == 0;         // one lane per env does the per-env stores
 
+  CM3_STAMP(0, false);
   // ---- loads (once per launch; the state then lives in registers across the ticks of this launch) -------------
   const V4 *sin4 = reinterpret_cast<const V4 *>(p.state_in);
   V4 si = sin4[(size_t)i * E + ec];
@@ -555,6 +556,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_pairs(const Partic
   const uint64_t genv = (uint64_t)(p.env_id_base + (int64_t)ec);
   const R kDt = R(0.1), kKeep = R(1 - 0.25), kDistMin = R(0.15) + R(0.15);
 
+  CM3_STAMP(1, true);
   // FUSED == false: exactly one tick, the loop and every per-tick pointer offset fold away at compile time
   const int n_ticks = FUSED ? p.n_ticks : 1;
 #pragma unroll 1
@@ -570,6 +572,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_pairs(const Partic
       act = actions_t[ec * N + i];
     }
 
+    CM3_STAMP(2, false);
     // ---- action force + own contact force --------------------------------------------------------------------
     R ux = R(0), uy = R(0);
     if (act == 1) ux = R(-1);
@@ -579,6 +582,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_pairs(const Partic
     R Fx = ux * R(5.0) + R(0.0), Fy = uy * R(5.0) + R(0.0);
     R f_x, f_y;
     contact_force<R>(si.z - sj.z, si.w - sj.w, f_x, f_y);
+    CM3_STAMP(3, false);
 #pragma unroll
     for (int kk = 0; kk < NO; ++kk) {  // contributions of agent i in the reference's order (j ascending)
       const int src = base + i * NO + kk;
@@ -602,6 +606,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_pairs(const Partic
       sj.w = __shfl(si.w, src, 64);
     }
 
+    CM3_STAMP(4, true);
     // ---- reward / reached / collisions (multi-goal_spread.py:114-143) ----------------------------------------
     R rew;
     {
@@ -636,6 +641,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_pairs(const Partic
       tick_ptr(p.done, p.st_done, t)[e] = done ? 1 : 0;
     }
 
+    CM3_STAMP(5, true);
     // ---- same-launch re-initialisation -------------------------------------------------------------------------
     bool was_reset = false;
     if ((p.flags & CM3_FLAG_AUTO_RESET) && done) {
@@ -655,6 +661,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_pairs(const Partic
       was_reset = true;
     }
 
+    CM3_STAMP(6, false);
     // ---- per-tick stores ------------------------------------------------------------------------------------------
     if (env_ok) {
       if (lead) {
@@ -668,6 +675,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_pairs(const Partic
     }
   }
 
+  CM3_STAMP(7, false);
   // ---- live counters, once per launch -------------------------------------------------------------------------------
   if (env_ok && head) {
     int2 m;
@@ -676,6 +684,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_pairs(const Partic
     reinterpret_cast<int2 *>(p.meta_out)[e] = m;
     if (episode != episode_in) p.episode[e] = (int32_t)episode;
   }
+  CM3_STAMP(8, true);
 }
 
 // ---- the step kernel, third mapping: ONE LANE PER AGENT -----------------------------------------------------

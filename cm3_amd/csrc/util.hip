@@ -49,6 +49,23 @@ __global__ void __launch_bounds__(kBenchBlock) k_hbm_read(const uint4 *__restric
   }
 }
 
+
+// Launch-structure floor of a step launch: the same grid reads `n_read` 16-byte vectors (all loads first), then writes
+// `n_write` vectors whose value depends on everything it read -- load -> (no arithmetic) -> store, nothing else.  What a
+// one-launch-per-tick kernel with this traffic cannot go below.
+__global__ void __launch_bounds__(1024) k_traffic_floor(const uint4 *__restrict__ src, size_t n_read, uint4 *__restrict__ dst,
+                                                        size_t n_write) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, total = (size_t)gridDim.x * blockDim.x;
+  uint4 acc = make_uint4(0u, 0u, 0u, 0u);
+  for (size_t i = gid; i < n_read; i += total) {
+    const uint4 v = src[i];
+    acc.x ^= v.x;
+    acc.y ^= v.y;
+    acc.z ^= v.z;
+    acc.w ^= v.w;
+  }
+  for (size_t i = gid; i < n_write; i += total) dst[i] = acc;
+}
 }  // namespace cm3
 
 extern "C" {
@@ -76,6 +93,17 @@ int cm3_device_name(int dev, char *name, int len) {
 }
 
 int cm3_hbm_bench_sink_words(void) { return cm3::kBenchGrid; }
+
+int cm3_traffic_floor_bench(const void *src, size_t read_bytes, void *dst, size_t write_bytes, int32_t blocks,
+                            int32_t threads, void *stream) {
+  CM3_REQUIRE(src && dst, "null buffer");
+  CM3_REQUIRE(read_bytes % 16 == 0 && write_bytes % 16 == 0, "byte counts must be multiples of 16");
+  CM3_REQUIRE(blocks >= 1 && threads >= 64 && threads <= 1024 && threads % 64 == 0, "bad launch shape");
+  hipLaunchKernelGGL(cm3::k_traffic_floor, dim3((unsigned)blocks), dim3((unsigned)threads), 0, (hipStream_t)stream,
+                     (const uint4 *)src, read_bytes / 16, (uint4 *)dst, write_bytes / 16);
+  CM3_HIP_CHECK(hipGetLastError());
+  return CM3_OK;
+}
 
 int cm3_hbm_read_bench(const void *buf, size_t bytes, void *sink, void *stream) {
   CM3_REQUIRE(buf && sink, "null buffer");

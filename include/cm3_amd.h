@@ -378,6 +378,10 @@ int cm3_copy_list(int32_t n, void *const *dst, const void *const *src, const siz
 /* ------------------------------------------------------------------------------------------
  * Measurement and launch plumbing
  * ---------------------------------------------------------------------------------------- */
+/* Launch-structure floor probe: `blocks` x `threads` lanes read read_bytes (16-byte vectors, all loads first), then write
+ * write_bytes whose value depends on what was read -- the load -> store skeleton of a step launch with no arithmetic. */
+int cm3_traffic_floor_bench(const void *src, size_t read_bytes, void *dst, size_t write_bytes, int32_t blocks,
+                            int32_t threads, void *stream);
 /* Streaming 16-byte-per-lane read of `bytes` bytes (multiple of 16); writes one checksum word per
  * workgroup to sink (>= 4*cm3_hbm_bench_sink_words() bytes).  The measured read-bandwidth roofline. */
 int cm3_hbm_read_bench(const void *buf, size_t bytes, void *sink, void *stream);
