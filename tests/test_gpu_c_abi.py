@@ -1,0 +1,26 @@
+"""GPU: a plain C++ program (examples/kat_p1.cpp) that links libcm3_hip.so and uses only the C ABI + the HIP runtime -- no
+Python, no PyTorch -- replays the reference's known-answer vector KAT-P1 in float64."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def test_c_consumer_replays_kat_p1():
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available on this box")
+    import cm3_amd._lib as L
+    L.lib()                                                    # fails loudly if the library is missing
+    exe = os.path.join(ROOT, "examples", "kat_p1")
+    libdir = os.path.join(ROOT, "cm3_amd")
+    subprocess.run([hipcc, "-std=c++17", "-Wno-unused-result", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "examples", "kat_p1.cpp"), "-L", libdir, "-lcm3_hip", "-Wl,-rpath," + libdir,
+                    "-o", exe], check=True, timeout=300)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "KAT-P1 through the C ABI" in out.stdout
