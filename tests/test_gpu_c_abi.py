@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def test_c_consumer_replays_kat_p1():
+def test_c_consumer_replays_kat_p1_and_kat_c1():
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available on this box")
@@ -23,4 +23,4 @@ def test_c_consumer_replays_kat_p1():
                     "-o", exe], check=True, timeout=300)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "KAT-P1 through the C ABI" in out.stdout
+    assert "KAT-P1 through the C ABI" in out.stdout and "KAT-C1 through the C ABI: exact" in out.stdout
