@@ -398,6 +398,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-sweep", action="store_true", help="skip the E-sweep (extra 'sweep' field)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="headline only: skip the fused / policy-rollout / launch-floor extras (clean profiles)")
     ap.add_argument("--fused", action="store_true",
                     help="random-action rollouts with all 33 ticks of an episode in ONE launch "
                          "(CM3_FLAG_FUSED_TICKS); the default keeps one launch per tick")
@@ -514,7 +516,7 @@ def main():
             out["roofline"]["traffic_source"] = ("profiles/pmc_traffic.json: %s, %d launches, FETCH_SIZE %.1f KB (x2) + "
                                                  "WRITE_SIZE %.1f KB" % (rec["kernel"], rec["launches"],
                                                                          rec["FETCH_SIZE_KB"], rec["WRITE_SIZE_KB"]))
-    if world == 1 and rank == 0 and kind in ("particle", "checkers") and not args.fused:
+    if world == 1 and rank == 0 and kind in ("particle", "checkers") and not args.fused and not args.no_extras:
         # Extra (not the headline): the same workload with all 33 ticks of an episode fused into ONE launch
         # (CM3_FLAG_FUSED_TICKS) -- legal for the random-action branch only, where nothing acts between ticks.
         if kind == "particle":
@@ -539,7 +541,7 @@ def main():
             "frac_of_peak": f_bytes / f_launch_s / 1e9 / HBM_PEAK_GBPS}
         fs.close()
         del fs
-    if world == 1 and rank == 0 and kind == "particle" and N in (1, 2, 4, 8) and not args.fused:
+    if world == 1 and rank == 0 and kind == "particle" and N in (1, 2, 4, 8) and not args.fused and not args.no_extras:
         # Extra (not the headline): POLICY-driven collection, the branch the reference takes for 49 950 of its 50 000
         # episodes (train_onpolicy.py:311-313): on-device actor (random float32 weights of the reference's shapes,
         # epsilon 0.1) + env step per tick, (a) alternating launches in one hipGraph, (b) the whole episode in ONE
@@ -577,7 +579,7 @@ def main():
                        "full trajectory storage; the two variants are bit-identical "
                        "(tests/test_gpu_actor.py::test_fused_policy_rollout_equals_launch_per_tick)")
         out["policy_rollout"] = pol
-    if world == 1 and rank == 0 and kind == "checkers" and cfg["n_agents"] in (1, 2) and not args.fused:
+    if world == 1 and rank == 0 and kind == "checkers" and cfg["n_agents"] in (1, 2) and not args.fused and not args.no_extras:
         # Extra (not the headline): POLICY-driven Checkers collection (train_onpolicy.py:309-321): the on-device actor
         # (networks.actor_checkers: conv + dense chain, 153 k MACs per agent row, every layer on the exact-f32 MFMA) and the
         # env step alternate inside one hipGraph; full trajectory storage.  The actor is contraction work: its roofline is
@@ -635,7 +637,7 @@ def main():
         bw = measure_read_bandwidth(device)
         out["roofline"]["measured_read_GBps"] = bw
         out["roofline"]["frac_of_measured_read"] = achieved / bw
-        if kind in ("particle", "checkers") and not args.fused:
+        if kind in ("particle", "checkers") and not args.fused and not args.no_extras:
             # What one launch per tick cannot go below at this batch: the same number of 256-lane workgroups reading and
             # writing the same algorithmic bytes with NO arithmetic (load -> store skeleton), and an empty launch, both
             # replayed as the same 33-node hipGraph.
