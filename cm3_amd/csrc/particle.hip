@@ -509,6 +509,9 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step(const ParticlePara
 // ascending = pair order of core.py:145-147), the post-step positions of j come back by shuffle, and the
 // collision tests / reached flags are reduced with wave ballots.  No LDS: lane (i,k) writes the obs_others
 // vector (i,k), so a wave stores 64/G whole env records contiguously (16 B per lane, unit stride).
+// internal flag bits set by particle_rollout only (never part of the ABI; fill_params rejects unknown public bits)
+constexpr uint32_t kFlagPregenRead = 0x10000u, kFlagPregenWrite = 0x20000u;
+
 template <int N> struct PairGeom {
   static constexpr int NO = N - 1;
   static constexpr int SLOTS = N * NO;
@@ -521,15 +524,29 @@ template <int N> struct PairGeom {
   static constexpr int EPW = 64 / G;  // envs per wave
 };
 
-template <typename R, int N, int WAVES, bool FUSED>
-__global__ void __launch_bounds__(WAVES * 64) k_particle_step_pairs(const ParticleParams p) {
+// SPLIT (ticks of cm3_particle_rollout_* with in-kernel actions, see particle_rollout): the workgroup carries ONE extra
+// wave, the DRAW wave, which draws the actions of the NEXT launch while the physics waves run this tick.  Its lane l
+// serves agent l % N of the workgroup's env l / N: it loads the RNG key (step counter, episode), runs the draw for
+// (episode, step + 1) -- the key the next launch will see unless this tick ends the episode -- and stores one contiguous
+// row of actions into the next tick's slot; the next launch then reads its actions with its other inputs, and the
+// generator's serial ~1.1 k cycles no longer sit between a launch's loads and everything that needs the action.
+// Envs whose episode does end this tick (known to the physics waves only at the end) get their row redrawn for
+// (episode + 1, step 0) by the physics waves.  Two workgroup barriers order the three accesses to an action row, which
+// matters when the trajectory is stepped in place (stride 0: this tick's and the next tick's rows are the same memory):
+// physics read (registers) -> barrier 1 -> draw-wave store (drained) -> barrier 2 -> physics redraw store.  Values and
+// final memory contents are identical to drawing at the head of every launch.
+template <typename R, int N, int WAVES, bool FUSED, bool SPLIT = false>
+__global__ void __launch_bounds__((WAVES + (SPLIT ? 1 : 0)) * 64) k_particle_step_pairs(const ParticleParams p) {
   static_assert(N >= 2, "the pair mapping needs at least two agents");
+  static_assert(!(SPLIT && FUSED), "the draw wave serves exactly one tick");
   using V4 = typename Vec<R>::v4;
   using V2 = typename Vec<R>::v2;
   using PG = PairGeom<N>;
   constexpr int NO = PG::NO, SLOTS = PG::SLOTS, G = PG::G, EPW = PG::EPW;
+  static_assert(!SPLIT || WAVES * EPW * N <= 64, "the draw wave serves every env of the workgroup with one lane per agent");
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave_all = threadIdx.x >> 6;
+  const int wave = wave_all;
   const int gslot = lane & (G - 1), sub = lane / G, base = lane - gslot;
   const size_t E = (size_t)p.E;
   const size_t e = ((size_t)blockIdx.x * WAVES + wave) * EPW + sub;
@@ -541,6 +558,29 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_pairs(const Partic
   const bool lead = slot_ok && k == 0;  // one lane per agent does the per-agent stores
   const bool head = gslot == 0;         // one lane per env does the per-env stores
 
+  const bool pre_rd = SPLIT && (p.flags & kFlagPregenRead), pre_wr = SPLIT && (p.flags & kFlagPregenWrite);
+  if constexpr (SPLIT) {
+    if (wave_all == WAVES) {  // the draw wave (train_onpolicy.py:305-307 for the next launch)
+      const int el = lane / N, ia = lane - el * N;  // env of the workgroup, agent
+      const size_t ed = (size_t)blockIdx.x * (WAVES * EPW) + el;
+      const bool ok = lane < WAVES * EPW * N && ed < E;
+      const size_t edc = ed < E ? ed : E - 1;
+      int a = 0;
+      if (pre_wr) {
+        const int steps_d = p.meta_in[2 * edc];
+        const uint32_t episode_d = (uint32_t)p.episode[edc];
+        const uint64_t genv_d = (uint64_t)(p.env_id_base + (int64_t)edc);
+        const u32x4 w = action_words(p.seed, genv_d, episode_d, (uint32_t)(steps_d + 1), (uint32_t)(ia >> 2));
+        const int q = ia & 3;
+        a = rand5(q == 0 ? w.x : (q == 1 ? w.y : (q == 2 ? w.z : w.w)));
+      }
+      __syncthreads();  // barrier 1: the physics waves hold this tick's actions in registers
+      if (pre_wr && ok) tick_ptr(p.actions, p.st_actions, 1)[ed * N + ia] = a;
+      __builtin_amdgcn_s_waitcnt(0);  // the row is written before the physics waves may redraw parts of it
+      __syncthreads();  // barrier 2
+      return;
+    }
+  }
   CM3_STAMP(0, false);
   // ---- loads (once per launch; the state then lives in registers across the ticks of this launch) -------------
   const V4 *sin4 = reinterpret_cast<const V4 *>(p.state_in);
@@ -562,14 +602,19 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_pairs(const Partic
 #pragma unroll 1
   for (int t = 0; t < n_ticks; ++t) {
     int32_t *actions_t = tick_ptr(p.actions, p.st_actions, t);
-    int act;
-    if (gen) {  // train_onpolicy.py:305-307
-      const u32x4 w = action_words(p.seed, genv, episode, (uint32_t)steps, (uint32_t)(i >> 2));
-      const int q = i & 3;
-      act = rand5(q == 0 ? w.x : (q == 1 ? w.y : (q == 2 ? w.z : w.w)));
-      if (env_ok && lead) actions_t[e * N + i] = act;
+    int act = 0;
+    R f_x, f_y;
+    if (SPLIT && pre_rd) {
+      act = actions_t[ec * N + i];  // drawn by the previous launch (its draw wave, or its physics waves after a reset)
     } else {
-      act = actions_t[ec * N + i];
+      if (gen) {  // train_onpolicy.py:305-307
+        const u32x4 w = action_words(p.seed, genv, episode, (uint32_t)steps, (uint32_t)(i >> 2));
+        const int q = i & 3;
+        act = rand5(q == 0 ? w.x : (q == 1 ? w.y : (q == 2 ? w.z : w.w)));
+        if (env_ok && lead) actions_t[e * N + i] = act;
+      } else {
+        act = actions_t[ec * N + i];
+      }
     }
 
     CM3_STAMP(2, false);
@@ -580,7 +625,6 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_pairs(const Partic
     if (act == 3) uy = R(-1);
     if (act == 4) uy = R(+1);
     R Fx = ux * R(5.0) + R(0.0), Fy = uy * R(5.0) + R(0.0);
-    R f_x, f_y;
     contact_force<R>(si.z - sj.z, si.w - sj.w, f_x, f_y);
     CM3_STAMP(3, false);
 #pragma unroll
@@ -598,6 +642,10 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_pairs(const Partic
     si.z = si.z + si.x * kDt;
     si.w = si.w + si.y * kDt;
     steps += 1;
+    if constexpr (SPLIT) {
+      if (!pre_rd) __builtin_amdgcn_s_waitcnt(0);  // first tick of a rollout: this tick's own action row is written
+      __syncthreads();                             // barrier 1: every physics wave holds its actions in registers
+    }
     {
       const int src = base + j * NO;  // lead lane of agent j
       sj.x = __shfl(si.x, src, 64);
@@ -662,6 +710,15 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_pairs(const Partic
     }
 
     CM3_STAMP(6, false);
+    if constexpr (SPLIT) {
+      __syncthreads();  // barrier 2: the draw wave's row for the next launch is in memory
+      if (pre_wr && was_reset) {  // fresh episode: the next launch sees (episode + 1, step 0)
+        const u32x4 w = action_words(p.seed, genv, episode, 0u, (uint32_t)(i >> 2));
+        const int q = i & 3;
+        const int a = rand5(q == 0 ? w.x : (q == 1 ? w.y : (q == 2 ? w.z : w.w)));
+        if (env_ok && lead) tick_ptr(p.actions, p.st_actions, 1)[e * N + i] = a;
+      }
+    }
     // ---- per-tick stores ------------------------------------------------------------------------------------------
     if (env_ok) {
       if (lead) {
@@ -1076,10 +1133,22 @@ template <typename R, int N, int WAVES> static int launch_pairs(const ParticlePa
   if constexpr (N >= 2) {
     const size_t envs_per_block = (size_t)WAVES * PairGeom<N>::EPW;
     const unsigned blocks = (unsigned)(((size_t)p.E + envs_per_block - 1) / envs_per_block);
-    if (p.n_ticks > 1)
+    constexpr bool kCanSplit = WAVES == 4 && sizeof(R) == 4 && WAVES * PairGeom<N>::EPW * N <= 64;
+    bool split = false;
+    // pays only while the launch is at most one physics wave per SIMD (1024 on the chip): N = 4, us per launch without /
+    // with the draw wave: 4096 envs 3.43 / 3.31; 16384 envs 5.31 / 6.14; N = 8, 4096 envs (4096 waves) 6.7 / 8.7
+    if constexpr (kCanSplit)
+      split = p.n_ticks == 1 && (p.flags & CM3_FLAG_GEN_ACTIONS) && (p.flags & (kFlagPregenRead | kFlagPregenWrite)) &&
+              (size_t)blocks * WAVES <= 1024;
+    if (p.n_ticks > 1) {
       hipLaunchKernelGGL((k_particle_step_pairs<R, N, WAVES, true>), dim3(blocks), dim3(WAVES * 64), 0, stream, p);
-    else
+    } else if (split) {
+      // a tick of cm3_particle_rollout_* with in-kernel actions: the extra wave draws the next launch's actions (SPLIT)
+      if constexpr (kCanSplit)
+        hipLaunchKernelGGL((k_particle_step_pairs<R, N, WAVES, false, true>), dim3(blocks), dim3((WAVES + 1) * 64), 0, stream, p);
+    } else {
       hipLaunchKernelGGL((k_particle_step_pairs<R, N, WAVES, false>), dim3(blocks), dim3(WAVES * 64), 0, stream, p);
+    }
     CM3_HIP_CHECK(hipGetLastError());
     return CM3_OK;
   } else {
@@ -1222,7 +1291,18 @@ static int particle_rollout(const cm3_particle_desc *d, const cm3_particle_traj 
     b.done = (uint8_t *)at(t->done, t->done_stride, k);
     b.term_state = at(t->term_state, t->term_state_stride, k);
     b.term_obs_others = at(t->term_obs_others, t->term_obs_others_stride, k);
-    int rc = particle_call<R>(d, &b, kStep, nullptr, stream);
+    ParticleParams p;
+    int rc = fill_params(d, &b, kStep, nullptr, p);
+    if (rc != CM3_OK) return rc;
+    if ((d->flags & CM3_FLAG_GEN_ACTIONS) && n_ticks > 1) {
+      // Random-action branch: tick k also draws the actions of tick k + 1 (its draw wave, see k_particle_step_pairs) and
+      // tick k + 1 reads them with its other inputs.  Only the pair mapping with 4-wave workgroups in float32 honours the
+      // two bits; every other kernel ignores them and keeps drawing at its head -- same values either way.
+      p.st_actions = t->actions_stride;
+      if (k > 0) p.flags |= kFlagPregenRead;
+      if (k + 1 < n_ticks) p.flags |= kFlagPregenWrite;
+    }
+    rc = launch<R>(p, d->n_agents, kStep, (hipStream_t)stream);
     if (rc != CM3_OK) return rc;
   }
   return CM3_OK;

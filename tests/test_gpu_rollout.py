@@ -228,3 +228,37 @@ def test_checkers_fused_rollout_equals_per_tick(cfg_name):
         assert torch.equal(outs[0][1]._episode, env._episode) and torch.equal(outs[0][1]._goals, env._goals)
         ro.close()
     assert int(a.done.sum()) > 0            # episodes of 9 ticks: several auto-resets inside the 40-tick rollout
+
+
+@pytest.mark.parametrize("E,N,cfg_name", [(4096, 4, "particle_stage2_antipodal.json"), (1000, 4, "particle_stage2_cross.json"),
+                                          (512, 8, "particle_merge8.json")])
+def test_in_place_rollout_with_draw_wave_equals_stepwise(E, N, cfg_name):
+    """cm3_particle_rollout_f32 over ZERO strides (every tick overwrites the live buffers -- how bench.py steps) with
+    in-kernel actions and auto-reset: the launches of a rollout hand the next tick's actions forward (draw wave of the pair
+    mapping, redraw after a reset; same memory row for this tick's and the next tick's actions).  70 ticks = two episode
+    boundaries; must leave exactly the state, counters and last action row of 70 single env.step() launches."""
+    from bench import ParticleStepper
+    from tests.helpers import load_cfg
+    cfg = load_cfg(cfg_name)
+    st = ParticleStepper(cfg, N, E, "cuda:0", seed=77)
+    ref = _penv(E, N, dtype=torch.float32, cfg=cfg_name, seed=77, auto_reset=True)
+    ref.reset()
+    for _ in range(2):
+        st.run(35)                       # eager C rollout loop: 35 launches, flags first / middle / last
+    for _ in range(70):
+        ref.step()
+    torch.cuda.synchronize()
+    a, b = st.env, ref
+    assert torch.equal(a._state[0], b._state[b._cur])
+    assert torch.equal(a._obs_others[0], b._obs_others[b._cur])
+    assert torch.equal(a._goals, b._goals) and torch.equal(a._meta, b._meta) and torch.equal(a._episode, b._episode)
+    assert torch.equal(a._actions[0], b.last_actions)
+    assert int(b._episode.min()) >= 3                # two resets happened
+    st.capture(33)
+    st.run(66)                                      # the same through hipGraph replays
+    for _ in range(66):
+        ref.step()
+    torch.cuda.synchronize()
+    assert torch.equal(a._state[0], b._state[b._cur]) and torch.equal(a._meta, b._meta)
+    assert torch.equal(a._actions[0], b.last_actions)
+    st.close()
