@@ -99,8 +99,8 @@ class ParticleStepper(object):
 
 
 class CheckersStepper(object):
-    """In-place stepping of E Checkers envs (BASELINE configs[2]): one cm3_checkers_step launch per tick,
-    uniform actions drawn in-kernel, auto-reset; replayed as a hipGraph."""
+    """In-place stepping of E Checkers envs (BASELINE configs[2]) through cm3_checkers_rollout: one step launch per
+    tick, uniform actions drawn in-kernel, auto-reset; replayed as a hipGraph."""
 
     def __init__(self, cfg, n_envs, device, seed=12341, env_id_base=0, max_steps=33, fused=False):
         import numpy as np
@@ -117,12 +117,14 @@ class CheckersStepper(object):
         self.device = self.env.device
         self.graph, self.graph_ticks = None, 0
         self.fused = bool(fused)
-        if self.fused:                 # in-place trajectory (zero strides): all ticks of an enqueue() in ONE launch
-            b, t = self.bufs, _lib.CheckersTraj()
-            for name in ("mask", "agents", "steps", "episode", "goals", "actions", "grid", "vec", "obs_others",
-                         "obs_self_t", "obs_self_v", "local_rewards", "reward", "done"):
-                setattr(t, name, getattr(b, name))
-            self.traj = t
+        # in-place trajectory (zero strides = every tick overwrites the same live buffers), stepped through the C rollout
+        # entry: n launches, or ONE launch for all ticks of an enqueue() when fused
+        b, t = self.bufs, _lib.CheckersTraj()
+        for name in ("mask", "agents", "steps", "episode", "goals", "actions", "grid", "vec", "obs_others",
+                     "obs_self_t", "obs_self_v", "local_rewards", "reward", "done"):
+            setattr(t, name, getattr(b, name))
+        self.traj = t
+        if self.fused:
             self.env._desc.flags |= _lib.FLAG_FUSED_TICKS
 
     def stream(self):
@@ -130,12 +132,8 @@ class CheckersStepper(object):
 
     def enqueue(self, n_ticks, stream=None):
         s = self.stream() if stream is None else stream
-        if self.fused:
-            self._lib_mod.check(self.lib.cm3_checkers_rollout(ctypes.byref(self.env._desc), ctypes.byref(self.traj),
-                                                              int(n_ticks), s))
-            return
-        for _ in range(int(n_ticks)):
-            self._lib_mod.check(self.lib.cm3_checkers_step(ctypes.byref(self.env._desc), ctypes.byref(self.bufs), s))
+        self._lib_mod.check(self.lib.cm3_checkers_rollout(ctypes.byref(self.env._desc), ctypes.byref(self.traj),
+                                                          int(n_ticks), s))
 
     capture = ParticleStepper.capture
     run = ParticleStepper.run

@@ -262,3 +262,39 @@ def test_in_place_rollout_with_draw_wave_equals_stepwise(E, N, cfg_name):
     assert torch.equal(a._state[0], b._state[b._cur]) and torch.equal(a._meta, b._meta)
     assert torch.equal(a._actions[0], b.last_actions)
     st.close()
+
+
+@pytest.mark.parametrize("E,stage", [(8192, 2), (1000, 2), (777, 1)])
+def test_checkers_in_place_rollout_with_draw_wave_equals_stepwise(E, stage):
+    """cm3_checkers_rollout over ZERO strides with in-kernel actions and auto-reset (how bench.py steps C3): launches hand
+    the next tick's actions forward (draw wave / redraw after a reset).  70 ticks must leave exactly the compact state,
+    counters, outputs and last action row of 70 single env.step() launches."""
+    from bench import CheckersStepper
+    from cm3_amd.checkers import VecCheckersEnv
+    cfg = load_cfg("checkers_stage%d.json" % stage)
+    n = cfg["n_agents"]
+    goals = np.eye(2) if n > 1 else np.array([[1, 0]])
+    st = CheckersStepper(cfg, E, "cuda:0", seed=99)
+    ref = VecCheckersEnv(cfg["init"], n, 33, E, device="cuda:0", seed=99, auto_reset=True)
+    ref.reset(goals)
+    for _ in range(2):
+        st.run(35)
+    out = None
+    for _ in range(70):
+        out = ref.step()
+    torch.cuda.synchronize()
+    a, b = st.env, ref
+    assert torch.equal(a._mask, b._mask) and torch.equal(a._agents, b._agents)
+    assert torch.equal(a._steps, b._steps) and torch.equal(a._episode, b._episode) and torch.equal(a._goals, b._goals)
+    sa, sb = a._slots[0], b._slots[b._cur]
+    for key in ("actions", "grid_raw", "obs_self_t_raw", "vec", "obs_others", "obs_self_v", "local_rewards", "reward", "done"):
+        assert torch.equal(sa[key], sb[key]), key
+    assert int(b._episode.min()) >= 3
+    st.capture(33)
+    st.run(66)
+    for _ in range(66):
+        ref.step()
+    torch.cuda.synchronize()
+    assert torch.equal(a._mask, b._mask) and torch.equal(a._agents, b._agents) and torch.equal(a._episode, b._episode)
+    assert torch.equal(a._slots[0]["actions"], b._slots[b._cur]["actions"])
+    st.close()
