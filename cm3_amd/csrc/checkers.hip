@@ -324,7 +324,7 @@ __device__ __forceinline__ void ck_tick_env(const CheckersParams &p, int t, size
     const uint64_t want = goal[0] == 0 ? p.green_mask : p.orange_mask;
     done = (s.mask & want) == want;
   } else {
-    done = __popcll(s.mask) == p.max_collectible;
+    done = (int)__popcll(s.mask) == p.max_collectible;
   }
   if (active) {
     double *local_t = ck_tick_ptr(p.local_rewards, p.st_local, t);
