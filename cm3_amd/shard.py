@@ -94,7 +94,6 @@ def normalized_returns(reward, done, valid=None, gamma=0.99, eps=1e-8, group=Non
     Two launches and ONE collective per rollout: cm3_returns_moments_* (discounted returns + this rank's
     float64 moments, deterministic), all_gather_into_tensor of the 3 moments (RCCL), cm3_normalize_* (rank-ordered
     global sums, mean / std, normalisation).  Returns (returns_or_normalised [same shape], (mean, std, count))."""
-    import ctypes
     from . import _lib
     if reward.device.type != "cuda":
         raise _lib.Cm3Error("normalized_returns runs on the GPU; use returns_to_go / normalize_advantages for host tensors")

@@ -4,7 +4,6 @@ import os
 import random
 import sys
 
-import numpy as np
 import pytest
 import torch
 
