@@ -102,6 +102,38 @@ def test_generic_geometry_three_agents():
         assert np.array_equal(done.cpu().numpy(), w[7])
 
 
+@pytest.mark.parametrize("case", range(12))
+def test_generic_geometry_fuzz(case):
+    """Random geometries the reference's constructor accepts (odd rows, even columns, rows x columns <= 64, n_obs 1..3,
+    1..4 agents on distinct start cells; 4-byte padded records on or off) through the generic kernel: 25 ticks of random
+    (also out-of-range) actions, every output bit-exact against the oracle."""
+    rng = np.random.default_rng(1000 + case)
+    R = int(rng.choice([1, 3, 5, 7]))
+    C = int(rng.choice([c for c in (2, 4, 6, 8, 10, 12) if R * c <= 64]))
+    O = int(rng.integers(1, 4))          # n_obs 0 leaves the world without its wall border: the reference indexes out of range
+    N = int(rng.integers(1, min(4, R) + 1))
+    if N == 1 and R < 3:
+        N, R = 1, 3                      # the single-agent start rule puts the agent on row 0 or 2 (checkers.py:271-276)
+        C = min(C, 12)
+    rows = rng.permutation(R)[:N]
+    init = dict(n_rows=R, n_columns=C, n_obs=O, agents_r=[int(r) for r in rows], agents_c=[C] * N)   # start column, distinct rows
+    cfg = dict(n_agents=N, init=init)
+    E = int(rng.integers(1, 300))
+    goal_idx = rng.integers(0, 2, (E, N))
+    orc = VecCheckersOracle(R, C, O, init["agents_r"], init["agents_c"], N, 30, E)
+    want = orc.reset(goal_idx)
+    env = _env(cfg, E, max_steps=30, padded_records=bool(case % 2) and (R, C, O) == (3, 8, 2))
+    out = env.reset(goal_index=torch.as_tensor(goal_idx))
+    _check_obs(out[:4], want)
+    for t in range(25):
+        acts = rng.integers(-1, 7, (E, N))
+        w = orc.step(acts)
+        gs, oo, ot, ov, total, local, done = env.step(torch.as_tensor(acts))
+        _check_obs((gs, oo, ot, ov), w[:5])
+        assert np.array_equal(_f64(total), w[5]) and np.array_equal(_f64(local), w[6])
+        assert np.array_equal(done.cpu().numpy(), w[7])
+
+
 def test_generated_actions_and_auto_reset():
     cfg = load_cfg("checkers_stage2.json")
     E, N, seed = 640, 2, 17
