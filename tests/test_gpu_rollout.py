@@ -243,6 +243,10 @@ def test_in_place_rollout_with_draw_wave_equals_stepwise(E, N, cfg_name):
     st = ParticleStepper(cfg, N, E, "cuda:0", seed=77)
     ref = _penv(E, N, dtype=torch.float32, cfg=cfg_name, seed=77, auto_reset=True)
     ref.reset()
+    # stagger the step counters so that episodes end on different ticks in different envs (and inside one wave)
+    stagger = torch.randint(0, 33, (E,), generator=torch.Generator().manual_seed(5), dtype=torch.int32).to("cuda:0")
+    st.env._meta[:, 0] = stagger
+    ref._meta[:, 0] = stagger
     for _ in range(2):
         st.run(35)                       # eager C rollout loop: 35 launches, flags first / middle / last
     for _ in range(70):
@@ -277,6 +281,10 @@ def test_checkers_in_place_rollout_with_draw_wave_equals_stepwise(E, stage):
     st = CheckersStepper(cfg, E, "cuda:0", seed=99)
     ref = VecCheckersEnv(cfg["init"], n, 33, E, device="cuda:0", seed=99, auto_reset=True)
     ref.reset(goals)
+    # stagger the step counters so that episodes end on different ticks in different envs (and inside one wave)
+    stagger = torch.randint(0, 33, (E,), generator=torch.Generator().manual_seed(6), dtype=torch.int32).to("cuda:0")
+    st.env._steps.copy_(stagger)
+    ref._steps.copy_(stagger)
     for _ in range(2):
         st.run(35)
     out = None
