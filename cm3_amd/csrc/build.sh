@@ -7,7 +7,7 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function"
 mkdir -p "${HERE}/_obj"
 pids=()
-"${HIPCC}" ${FLAGS} -DCM3_PARTICLE_F32 -c "${HERE}/particle.hip" -o "${HERE}/_obj/particle_f32.o" &
+"${HIPCC}" ${FLAGS} -mllvm -amdgpu-kernarg-preload-count=16 -DCM3_PARTICLE_F32 -c "${HERE}/particle.hip" -o "${HERE}/_obj/particle_f32.o" &
 pids+=($!)
 "${HIPCC}" ${FLAGS} -DCM3_PARTICLE_F64 -c "${HERE}/particle.hip" -o "${HERE}/_obj/particle_f64.o" &
 pids+=($!)

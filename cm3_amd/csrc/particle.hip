@@ -536,7 +536,12 @@ template <int N> struct PairGeom {
 // physics read (registers) -> barrier 1 -> draw-wave store (drained) -> barrier 2 -> physics redraw store.  Values and
 // final memory contents are identical to drawing at the head of every launch.
 template <typename R, int N, int WAVES, bool FUSED, bool SPLIT = false>
-__global__ void __launch_bounds__((WAVES + (SPLIT ? 1 : 0)) * 64) k_particle_step_pairs(const ParticleParams p) {
+__global__ void __launch_bounds__((WAVES + (SPLIT ? 1 : 0)) * 64)
+    k_particle_step_pairs(const void *h_state_in, const void *h_goals_in, const int32_t *h_meta_in, const int32_t *h_episode,
+                          const int32_t *h_actions, const int h_E, const uint32_t h_flags, const ParticleParams p) {
+  // The leading arguments repeat the fields of `p` that the first loads need: scalar kernel arguments are preloaded into
+  // SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count), so the addresses of the first loads do not wait for a
+  // kernarg fetch.
   static_assert(N >= 2, "the pair mapping needs at least two agents");
   static_assert(!(SPLIT && FUSED), "the draw wave serves exactly one tick");
   using V4 = typename Vec<R>::v4;
@@ -548,7 +553,7 @@ __global__ void __launch_bounds__((WAVES + (SPLIT ? 1 : 0)) * 64) k_particle_ste
   const int lane = threadIdx.x & 63, wave_all = threadIdx.x >> 6;
   const int wave = wave_all;
   const int gslot = lane & (G - 1), sub = lane / G, base = lane - gslot;
-  const size_t E = (size_t)p.E;
+  const size_t E = (size_t)h_E;
   const size_t e = ((size_t)blockIdx.x * WAVES + wave) * EPW + sub;
   const bool env_ok = e < E;
   const size_t ec = env_ok ? e : E - 1;
@@ -558,7 +563,7 @@ __global__ void __launch_bounds__((WAVES + (SPLIT ? 1 : 0)) * 64) k_particle_ste
   const bool lead = slot_ok && k == 0;  // one lane per agent does the per-agent stores
   const bool head = gslot == 0;         // one lane per env does the per-env stores
 
-  const bool pre_rd = SPLIT && (p.flags & kFlagPregenRead), pre_wr = SPLIT && (p.flags & kFlagPregenWrite);
+  const bool pre_rd = SPLIT && (h_flags & kFlagPregenRead), pre_wr = SPLIT && (h_flags & kFlagPregenWrite);
   if constexpr (SPLIT) {
     if (wave_all == WAVES) {  // the draw wave (train_onpolicy.py:305-307 for the next launch)
       const int el = lane / N, ia = lane - el * N;  // env of the workgroup, agent
@@ -567,8 +572,8 @@ __global__ void __launch_bounds__((WAVES + (SPLIT ? 1 : 0)) * 64) k_particle_ste
       const size_t edc = ed < E ? ed : E - 1;
       int a = 0;
       if (pre_wr) {
-        const int steps_d = p.meta_in[2 * edc];
-        const uint32_t episode_d = (uint32_t)p.episode[edc];
+        const int steps_d = h_meta_in[2 * edc];
+        const uint32_t episode_d = (uint32_t)h_episode[edc];
         const uint64_t genv_d = (uint64_t)(p.env_id_base + (int64_t)edc);
         const u32x4 w = action_words(p.seed, genv_d, episode_d, (uint32_t)(steps_d + 1), (uint32_t)(ia >> 2));
         const int q = ia & 3;
@@ -583,15 +588,15 @@ __global__ void __launch_bounds__((WAVES + (SPLIT ? 1 : 0)) * 64) k_particle_ste
   }
   CM3_STAMP(0, false);
   // ---- loads (once per launch; the state then lives in registers across the ticks of this launch) -------------
-  const V4 *sin4 = reinterpret_cast<const V4 *>(p.state_in);
+  const V4 *sin4 = reinterpret_cast<const V4 *>(h_state_in);
   V4 si = sin4[(size_t)i * E + ec];
   V4 sj = sin4[(size_t)j * E + ec];
-  V2 gl = reinterpret_cast<const V2 *>(p.goals_in)[(size_t)i * E + ec];
-  const int2 meta = reinterpret_cast<const int2 *>(p.meta_in)[ec];
+  V2 gl = reinterpret_cast<const V2 *>(h_goals_in)[(size_t)i * E + ec];
+  const int2 meta = reinterpret_cast<const int2 *>(h_meta_in)[ec];
   int steps = meta.x, collisions = meta.y;
-  const bool gen = (p.flags & CM3_FLAG_GEN_ACTIONS) != 0;
+  const bool gen = (h_flags & CM3_FLAG_GEN_ACTIONS) != 0;
   uint32_t episode = 0;
-  if (gen || (p.flags & CM3_FLAG_AUTO_RESET)) episode = (uint32_t)p.episode[ec];
+  if (gen || (h_flags & CM3_FLAG_AUTO_RESET)) episode = (uint32_t)h_episode[ec];
   const uint32_t episode_in = episode;
   const uint64_t genv = (uint64_t)(p.env_id_base + (int64_t)ec);
   const R kDt = R(0.1), kKeep = R(1 - 0.25), kDistMin = R(0.15) + R(0.15);
@@ -605,7 +610,7 @@ __global__ void __launch_bounds__((WAVES + (SPLIT ? 1 : 0)) * 64) k_particle_ste
     int act = 0;
     R f_x, f_y;
     if (SPLIT && pre_rd) {
-      act = actions_t[ec * N + i];  // drawn by the previous launch (its draw wave, or its physics waves after a reset)
+      act = h_actions[ec * N + i];  // drawn by the previous launch (its draw wave, or its physics waves after a reset)
     } else {
       if (gen) {  // train_onpolicy.py:305-307
         const u32x4 w = action_words(p.seed, genv, episode, (uint32_t)steps, (uint32_t)(i >> 2));
@@ -1141,13 +1146,17 @@ template <typename R, int N, int WAVES> static int launch_pairs(const ParticlePa
       split = p.n_ticks == 1 && (p.flags & CM3_FLAG_GEN_ACTIONS) && (p.flags & (kFlagPregenRead | kFlagPregenWrite)) &&
               (size_t)blocks * WAVES <= 1024;
     if (p.n_ticks > 1) {
-      hipLaunchKernelGGL((k_particle_step_pairs<R, N, WAVES, true>), dim3(blocks), dim3(WAVES * 64), 0, stream, p);
+      hipLaunchKernelGGL((k_particle_step_pairs<R, N, WAVES, true>), dim3(blocks), dim3(WAVES * 64), 0, stream, p.state_in,
+                         p.goals_in, p.meta_in, (const int32_t *)p.episode, (const int32_t *)p.actions, p.E, p.flags, p);
     } else if (split) {
       // a tick of cm3_particle_rollout_* with in-kernel actions: the extra wave draws the next launch's actions (SPLIT)
       if constexpr (kCanSplit)
-        hipLaunchKernelGGL((k_particle_step_pairs<R, N, WAVES, false, true>), dim3(blocks), dim3((WAVES + 1) * 64), 0, stream, p);
+        hipLaunchKernelGGL((k_particle_step_pairs<R, N, WAVES, false, true>), dim3(blocks), dim3((WAVES + 1) * 64), 0, stream,
+                           p.state_in, p.goals_in, p.meta_in, (const int32_t *)p.episode, (const int32_t *)p.actions, p.E,
+                           p.flags, p);
     } else {
-      hipLaunchKernelGGL((k_particle_step_pairs<R, N, WAVES, false>), dim3(blocks), dim3(WAVES * 64), 0, stream, p);
+      hipLaunchKernelGGL((k_particle_step_pairs<R, N, WAVES, false>), dim3(blocks), dim3(WAVES * 64), 0, stream, p.state_in,
+                         p.goals_in, p.meta_in, (const int32_t *)p.episode, (const int32_t *)p.actions, p.E, p.flags, p);
     }
     CM3_HIP_CHECK(hipGetLastError());
     return CM3_OK;
