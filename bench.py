@@ -30,7 +30,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # same guide: v_mfma_f32_16x16x4_f32 / 32x32x2_f32, dense (= the FP32 vector peak)
-GRAPH_TICKS = 33              # one episode per graph replay
+GRAPH_TICKS = 33              # ticks of one rollout (= one episode, max_steps)
+GRAPH_ROLLOUTS = 10           # rollouts captured per hipGraph: a replay costs ~4 us of GPU idle time (33 ticks per replay:
+                              # 3.24 us per tick; 132: 3.11; 330: 3.06)
 
 
 def algorithmic_bytes_per_env_step(n_agents):
@@ -394,6 +396,8 @@ def main():
                     help="c2 (default, the configuration BASELINE.json's metric is quoted on) | c3 | c4 | c5")
     ap.add_argument("--envs-per-gpu", type=int, default=0, help="override the workload's batch size")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--graph-rollouts", type=int, default=GRAPH_ROLLOUTS,
+                    help="33-tick rollouts captured per hipGraph (a remainder of --steps runs as eager launches)")
     ap.add_argument("--no-sweep", action="store_true", help="skip the E-sweep (extra 'sweep' field)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
@@ -455,7 +459,8 @@ def main():
         bytes_per_env_step = CHECKERS_BYTES_PER_ENV_STEP
         dtype_name = "int8/int32 state and grids, f64 normalised outputs (bit-exact)"
     if not args.no_graph:
-        stepper.capture(GRAPH_TICKS)
+        args.graph_rollouts = max(1, min(args.graph_rollouts, steps))
+        stepper.capture(GRAPH_TICKS * (1 if kind == "particle_adv" else args.graph_rollouts))
     stepper.run(max(W, 1))
     torch.cuda.synchronize(device)
 
@@ -494,7 +499,10 @@ def main():
                                    % (wl_desc, E, "one step-kernel launch per tick" if ticks_per_launch == 1 else
                                       "%d ticks fused per launch (random-action branch)" % ticks_per_launch),
                        "envs_per_gpu": E, "n_agents": N, "global_envs": E * world,
-                       "launch": "eager" if args.no_graph else "hipGraph of %d ticks" % GRAPH_TICKS,
+                       "launch": "eager" if args.no_graph else (
+                           "hipGraph of %d ticks" % GRAPH_TICKS if kind == "particle_adv" else
+                           "hipGraph of %d ticks (%d rollouts per replay)" % (GRAPH_TICKS * args.graph_rollouts,
+                                                                              args.graph_rollouts)),
                        "ticks_per_launch": ticks_per_launch,
                        "parallelism": ("env-sharded x%d, one 24-byte moments all-gather (RCCL) per rollout" % world
                                        if kind == "particle_adv" else "env-sharded x%d, no data-path collective" % world)},
