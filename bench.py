@@ -222,9 +222,9 @@ def measure_read_bandwidth(device, gib=4.0, reps=5):
     return nbytes / (ms * 1e-3) / 1e9
 
 
-def measure_launch_floor(device, read_bytes, write_bytes, blocks, threads=256):
+def measure_launch_floor(device, read_bytes, write_bytes, blocks, threads=256, nodes=GRAPH_TICKS):
     """us per launch of (a) the load -> store skeleton with the step launch's traffic and (b) an empty launch of the same
-    shape, each as a 33-node hipGraph replayed like the bench's rollout (cm3_traffic_floor_bench)."""
+    shape, each as a hipGraph of `nodes` launches replayed like the bench's rollout (cm3_traffic_floor_bench)."""
     import torch
     from cm3_amd import _lib
     lib = _lib.lib()
@@ -233,7 +233,7 @@ def measure_launch_floor(device, read_bytes, write_bytes, blocks, threads=256):
     res = {}
     for name, (rb, wb) in (("same_traffic_us", (read_bytes, write_bytes)), ("empty_launch_us", (0, 0))):
         def enqueue(s, rb=rb, wb=wb):
-            for _ in range(GRAPH_TICKS):
+            for _ in range(nodes):
                 _lib.check(lib.cm3_traffic_floor_bench(src.data_ptr(), rb, dst.data_ptr(), wb, blocks, threads, s))
         graph = _lib.capture_graph(device, enqueue)
         s = _lib.current_stream_handle(device)
@@ -241,16 +241,17 @@ def measure_launch_floor(device, read_bytes, write_bytes, blocks, threads=256):
             _lib.check(lib.cm3_graph_launch(graph, s))
         torch.cuda.synchronize(device)
         start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 50
+        reps = max(5, 1650 // nodes)
         start.record()
         for _ in range(reps):
             _lib.check(lib.cm3_graph_launch(graph, s))
         stop.record()
         stop.synchronize()
-        res[name] = start.elapsed_time(stop) * 1e3 / (reps * GRAPH_TICKS)
+        res[name] = start.elapsed_time(stop) * 1e3 / (reps * nodes)
         lib.cm3_graph_destroy(graph)
-    res["note"] = ("%d x %d lanes, %d B read then %d B written per launch, no arithmetic; the step kernel's average launch "
-                   "time divided into same_traffic_us is frac_of_floor" % (blocks, threads, read_bytes, write_bytes))
+    res["note"] = ("%d x %d lanes, %d B read then %d B written per launch, no arithmetic, %d launches per hipGraph replay; "
+                   "the step kernel's average launch time divided into same_traffic_us is frac_of_floor"
+                   % (blocks, threads, read_bytes, write_bytes, nodes))
     return res
 
 
@@ -652,7 +653,8 @@ def main():
             else:
                 rd, wr = 24 * E, 376 * E
             rd, wr = (rd + 15) // 16 * 16, (wr + 15) // 16 * 16
-            floor = measure_launch_floor(device, rd, wr, blocks=max(1, min(2048, (E * 16 + 255) // 256)))
+            floor = measure_launch_floor(device, rd, wr, blocks=max(1, min(2048, (E * 16 + 255) // 256)),
+                                         nodes=GRAPH_TICKS * (1 if args.no_graph else args.graph_rollouts))
             floor["frac_of_floor"] = floor["same_traffic_us"] / (launch_s * 1e6)
             out["roofline"]["launch_floor"] = floor
         if not args.no_sweep and kind == "particle":
