@@ -115,6 +115,14 @@ template <typename R> __device__ __forceinline__ void contact_force(R dx, R dy, 
   }
 }
 
+// the slow path alone, for callers that already hold dist = sqrt(dx^2 + dy^2) and know it is within reach
+template <typename R> __device__ __forceinline__ void contact_force_near(R dx, R dy, R dist, R &f_x, R &f_y) {
+  const R kMargin = R(1e-3), kForce = R(1e+2), kDistMin = R(0.15) + R(0.15);
+  const R pen = logaddexp0<R>(-(dist - kDistMin) / kMargin) * kMargin;
+  f_x = kForce * dx / dist * pen;
+  f_y = kForce * dy / dist * pen;
+}
+
 template <typename R, typename V4> __device__ __forceinline__ V4 sub4(const V4 &a, const V4 &b) {
   V4 r;
   r.x = a.x - b.x;
@@ -846,26 +854,27 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_agents(const Parti
     // Beyond Contact<R>::kSkip the force is exactly (+-)0 and leaves Fx / Fy bit-unchanged (see contact_force), so only
     // the agents within reach are visited, in ascending order; the wave iterates max-over-lanes(#neighbours in reach)
     // times (typically 0-2) instead of running the transcendental chain N-1 times because SOME lane needs it.
-    R dxs[N], dys[N];
+    R dxs[N], dys[N], dists[N];
     unsigned near_mask = 0;
 #pragma unroll
     for (int j = 0; j < N; ++j) {
       dxs[j] = si.z - __shfl(si.z, base + j, 64);
       dys[j] = si.w - __shfl(si.w, base + j, 64);
-      const R dist = Math<R>::sqrt(dxs[j] * dxs[j] + dys[j] * dys[j]);
-      if (j != i && !(dist >= Contact<R>::kSkip)) near_mask |= 1u << j;
+      dists[j] = Math<R>::sqrt(dxs[j] * dxs[j] + dys[j] * dys[j]);
+      if (j != i && !(dists[j] >= Contact<R>::kSkip)) near_mask |= 1u << j;
     }
     while (__any(near_mask != 0u)) {
       const int jn = near_mask ? (__ffs((int)near_mask) - 1) : 0;
-      R dx = dxs[0], dy = dys[0];
+      R dx = dxs[0], dy = dys[0], dist = dists[0];
 #pragma unroll
       for (int j = 1; j < N; ++j) {
         dx = (jn == j) ? dxs[j] : dx;
         dy = (jn == j) ? dys[j] : dy;
+        dist = (jn == j) ? dists[j] : dist;
       }
       if (near_mask) {
         R f_x, f_y;
-        contact_force<R>(dx, dy, f_x, f_y);
+        contact_force_near<R>(dx, dy, dist, f_x, f_y);  // the distance is already known and within reach
         Fx = f_x + Fx;
         Fy = f_y + Fy;
       }
