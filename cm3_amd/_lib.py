@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcm3_hip.so")
 MAX_AGENTS = 8
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 FLAG_AUTO_RESET = 1
 FLAG_GEN_ACTIONS = 2
@@ -33,6 +33,7 @@ c_double, c_size_t = ctypes.c_double, ctypes.c_size_t
 
 class ParticleDesc(ctypes.Structure):
     _fields_ = [("n_envs", c_int32), ("n_agents", c_int32), ("max_steps", c_int32), ("flags", c_uint32),
+                ("env_offset", c_int32), ("env_count", c_int32),
                 ("env_id_base", c_int64), ("seed", c_uint64), ("prob_random", c_double),
                 ("initial_std", c_double),
                 ("agents_x", c_double * MAX_AGENTS), ("agents_y", c_double * MAX_AGENTS),
@@ -42,7 +43,7 @@ class ParticleDesc(ctypes.Structure):
 class ParticleBufs(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in (
         "state_in", "state_out", "goals_in", "goals_out", "meta_in", "meta_out", "episode", "actions",
-        "obs_others", "reward_n", "reward", "done", "term_state", "term_obs_others")]
+        "obs_others", "reward_n", "reward", "done", "term_state", "term_obs_others", "term_collisions")]
 
 
 class ParticleTraj(ctypes.Structure):
@@ -55,7 +56,8 @@ class ParticleTraj(ctypes.Structure):
                 ("done", c_void_p), ("done_stride", c_size_t),
                 ("meta", c_void_p), ("episode", c_void_p),
                 ("term_state", c_void_p), ("term_state_stride", c_size_t),
-                ("term_obs_others", c_void_p), ("term_obs_others_stride", c_size_t)]
+                ("term_obs_others", c_void_p), ("term_obs_others_stride", c_size_t),
+                ("term_collisions", c_void_p), ("term_collisions_stride", c_size_t)]
 
 
 class CheckersDesc(ctypes.Structure):
@@ -69,7 +71,8 @@ class CheckersDesc(ctypes.Structure):
 class CheckersBufs(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in (
         "mask", "agents", "steps", "episode", "goals", "actions", "grid", "vec", "obs_others",
-        "obs_self_t", "obs_self_v", "local_rewards", "reward", "done")]
+        "obs_self_t", "obs_self_v", "local_rewards", "reward", "done",
+        "term_grid", "term_vec", "term_obs_others", "term_obs_self_t", "term_obs_self_v", "goals_next")]
 
 
 class CheckersTraj(ctypes.Structure):
@@ -79,7 +82,13 @@ class CheckersTraj(ctypes.Structure):
                  ("obs_self_t", c_void_p), ("obs_self_t_slot_stride", c_size_t),
                  ("obs_self_v", c_void_p), ("obs_self_v_stride", c_size_t),
                  ("local_rewards", c_void_p), ("local_rewards_stride", c_size_t),
-                 ("reward", c_void_p), ("reward_stride", c_size_t), ("done", c_void_p), ("done_stride", c_size_t)])
+                 ("reward", c_void_p), ("reward_stride", c_size_t), ("done", c_void_p), ("done_stride", c_size_t),
+                 ("term_grid", c_void_p), ("term_grid_slot_stride", c_size_t),
+                 ("term_vec", c_void_p), ("term_vec_stride", c_size_t),
+                 ("term_obs_others", c_void_p), ("term_obs_others_stride", c_size_t),
+                 ("term_obs_self_t", c_void_p), ("term_obs_self_t_slot_stride", c_size_t),
+                 ("term_obs_self_v", c_void_p), ("term_obs_self_v_stride", c_size_t),
+                 ("goals_slots", c_void_p), ("goals_slots_stride", c_size_t)])
 
 
 class ActorParticleDesc(ctypes.Structure):
@@ -94,7 +103,8 @@ class ActorParticleWeights(ctypes.Structure):
 
 
 class ActorParticleBufs(ctypes.Structure):
-    _fields_ = [(n, c_void_p) for n in ("obs_others", "state", "goals", "meta", "episode", "actions", "probs")]
+    _fields_ = [(n, c_void_p) for n in ("obs_others", "state", "goals", "meta", "episode", "actions", "probs",
+                                        "epsilon_dev")]
 
 
 class ActorCheckersDesc(ctypes.Structure):
@@ -111,7 +121,7 @@ class ActorCheckersWeights(ctypes.Structure):
 
 class ActorCheckersBufs(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in ("obs_self_t", "obs_self_v", "obs_others", "goals", "actions_prev", "steps",
-                                        "episode", "actions", "probs")]
+                                        "episode", "actions", "probs", "prev_done", "epsilon_dev")]
 
 
 # every symbol include/cm3_amd.h declares: name -> (restype, argtypes)
@@ -129,6 +139,8 @@ SYMBOLS = {
     "cm3_particle_observe_f64": (ctypes.c_int, [P(ParticleDesc), P(ParticleBufs), c_void_p]),
     "cm3_particle_rollout_f32": (ctypes.c_int, [P(ParticleDesc), P(ParticleTraj), c_int32, c_void_p]),
     "cm3_particle_rollout_f64": (ctypes.c_int, [P(ParticleDesc), P(ParticleTraj), c_int32, c_void_p]),
+    "cm3_particle_rollout_chains_f32": (ctypes.c_int, [P(ParticleDesc), P(ParticleTraj), c_int32, c_int32, P(c_void_p)]),
+    "cm3_particle_rollout_chains_f64": (ctypes.c_int, [P(ParticleDesc), P(ParticleTraj), c_int32, c_int32, P(c_void_p)]),
     "cm3_checkers_step": (ctypes.c_int, [P(CheckersDesc), P(CheckersBufs), c_void_p]),
     "cm3_checkers_rollout": (ctypes.c_int, [P(CheckersDesc), P(CheckersTraj), c_int32, c_void_p]),
     "cm3_checkers_reset": (ctypes.c_int, [P(CheckersDesc), P(CheckersBufs), c_void_p, c_void_p]),
@@ -154,6 +166,9 @@ SYMBOLS = {
     "cm3_copy_list": (ctypes.c_int, [c_int32, P(c_void_p), P(c_void_p), P(c_size_t), c_void_p]),
     "cm3_hbm_read_bench": (ctypes.c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
     "cm3_hbm_bench_sink_words": (ctypes.c_int, []),
+    "cm3_hbm_read_bench_cfg": (ctypes.c_int, [c_void_p, c_size_t, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "cm3_hbm_copy_bench": (ctypes.c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "cm3_hbm_copy_bench_cfg": (ctypes.c_int, [c_void_p, c_void_p, c_size_t, c_int32, c_int32, c_int32, c_void_p]),
     "cm3_traffic_floor_bench": (ctypes.c_int, [c_void_p, c_size_t, c_void_p, c_size_t, c_int32, c_int32, c_void_p]),
     "cm3_graph_begin": (ctypes.c_int, [c_void_p]),
     "cm3_graph_end": (ctypes.c_int, [c_void_p, P(c_void_p)]),

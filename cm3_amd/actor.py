@@ -21,6 +21,16 @@ import torch
 from . import _lib
 from ._lib import Cm3Error
 
+
+def _epsilon_args(epsilon):
+    """(float for the descriptor, device pointer or 0): a float32 device tensor is read by the launch itself, so a
+    captured hipGraph follows the annealed epsilon (train_onpolicy.py:369) without being re-captured."""
+    if isinstance(epsilon, torch.Tensor):
+        if epsilon.dtype != torch.float32 or epsilon.numel() != 1 or epsilon.device.type != "cuda":
+            raise Cm3Error("a device epsilon must be one float32 element on the GPU")
+        return 0.0, epsilon.data_ptr()
+    return float(epsilon), 0
+
 H1_SELF, H1_OTHERS, H2, N_ACTIONS = 64, 128, 64, 5
 _NAMES = {
     "w_self": "actor_branch_self/kernel", "b_self": "actor_branch_self/bias", "w_self_h2": "W_branch_self_h2",
@@ -94,6 +104,7 @@ class ParticleActor(object):
         b = _lib.ActorParticleBufs()
         b.obs_others, b.state, b.goals = _lib.ptr(obs_others), _lib.ptr(state), _lib.ptr(goals)
         b.meta, b.episode, b.actions, b.probs = _lib.ptr(meta), _lib.ptr(episode), _lib.ptr(actions), _lib.ptr(probs)
+        epsilon, b.epsilon_dev = _epsilon_args(epsilon)
         d = self._desc(n_envs, epsilon, self.env_id_base if env_id_base is None else env_id_base)
         s = _lib.current_stream_handle(self.device) if stream is None else stream
         _lib.check(self._lib.cm3_actor_particle_f32(ctypes.byref(d), ctypes.byref(self._wt), ctypes.byref(b), s))
@@ -190,13 +201,16 @@ class CheckersActor(object):
                                                      _lib.current_stream_handle(self.device)))
 
     def enqueue(self, n_envs, obs_self_t_raw, obst_stride, obs_self_v, obs_others, goals, actions_prev, steps, episode,
-                actions, epsilon, probs=None, stream=None, env_id_base=None):
-        """Raw launch on the env's device buffers (obs_self_t_raw: the int8 storage with obst_stride bytes per env)."""
+                actions, epsilon, probs=None, stream=None, env_id_base=None, prev_done=None):
+        """Raw launch on the env's device buffers (obs_self_t_raw: the int8 storage with obst_stride bytes per env).
+        prev_done (uint8 [E], optional): envs that finished an episode on the previous tick see actions_prev = 0."""
         b = _lib.ActorCheckersBufs()
         b.obs_self_t, b.obs_self_v, b.obs_others = _lib.ptr(obs_self_t_raw), _lib.ptr(obs_self_v), _lib.ptr(obs_others)
         b.goals, b.actions_prev, b.steps, b.episode = (_lib.ptr(goals), _lib.ptr(actions_prev), _lib.ptr(steps),
                                                        _lib.ptr(episode))
         b.actions, b.probs = _lib.ptr(actions), _lib.ptr(probs)
+        b.prev_done = _lib.ptr(prev_done)
+        epsilon, b.epsilon_dev = _epsilon_args(epsilon)
         d = self._desc(n_envs, epsilon, self.env_id_base if env_id_base is None else env_id_base, obst_stride)
         s = _lib.current_stream_handle(self.device) if stream is None else stream
         _lib.check(self._lib.cm3_actor_checkers_f32(ctypes.byref(d), ctypes.byref(self._wt), ctypes.byref(b), s))

@@ -66,6 +66,7 @@ class VecCheckersEnv(object):
                 reward=z(E, dt=torch.float64),
                 done=z(E, dt=torch.uint8)))
         self._cur = 0
+        self._term = None
         d = self._desc = _lib.CheckersDesc()
         d.n_envs, d.n_agents, d.n_rows, d.n_columns, d.n_obs = E, N, self.R, self.C, self.O
         d.max_steps = self.max_steps
@@ -97,7 +98,30 @@ class VecCheckersEnv(object):
             setattr(b, k, s[k].data_ptr())
         b.grid = s["grid_raw"].data_ptr()
         b.obs_self_t = s["obs_self_t_raw"].data_ptr()
+        if self._term is not None:
+            t = self._term
+            b.term_grid, b.term_obs_self_t = t["grid_raw"].data_ptr(), t["obs_self_t_raw"].data_ptr()
+            b.term_vec, b.term_obs_others = t["vec"].data_ptr(), t["obs_others"].data_ptr()
+            b.term_obs_self_v = t["obs_self_v"].data_ptr()
         return b
+
+    def enable_terminal_capture(self):
+        """Allocate the term_* arrays so that auto_reset keeps the TRUE post-step observation of an env whose episode
+        ended (the next_* columns of the terminal transition, train_onpolicy.py:336-347); read them with
+        ``terminal_obs()`` where ``done`` is set."""
+        if self._term is None:
+            E, N = self.E, self.n
+            z = lambda *shape, dt: torch.zeros(*shape, dtype=dt, device=self.device)  # noqa: E731
+            grid_raw, obst_raw = z(E, self.grid_stride, dt=torch.int8), z(E, self.obst_stride, dt=torch.int8)
+            self._term = dict(grid_raw=grid_raw, obs_self_t_raw=obst_raw, grid=self.grid_view(grid_raw),
+                              obs_self_t=self.obst_view(obst_raw), vec=z(E, N, 4, dt=torch.int32),
+                              obs_others=z(E, N, self.Lo, dt=torch.float64), obs_self_v=z(E, N, 4, dt=torch.float64))
+
+    def terminal_obs(self):
+        """((grid, vec), obs_others, obs_self_t, obs_self_v) captured by the most recent step() for the envs it
+        re-initialised (rows of other envs are stale)."""
+        t = self._term
+        return None if t is None else ((t["grid"], t["vec"]), t["obs_others"], t["obs_self_t"], t["obs_self_v"])
 
     def _stream(self):
         return _lib.current_stream_handle(self.device)

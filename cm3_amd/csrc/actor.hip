@@ -31,6 +31,7 @@ struct ActorParams {
   const int32_t *meta, *episode;
   int32_t *actions;
   float *probs;
+  const float *eps_dev;  // optional: epsilon read from the device at launch (graph replays follow the annealing)
   const float *w_self, *b_self, *w_self_h2, *w_oth, *b_oth, *w_oth_h2, *b_h2, *w_out, *b_out;  // pack kernel only
   const float *packed;  // kernel-layout weights (PackLayout), written by k_actor_pack
 };
@@ -333,7 +334,7 @@ template <int N, bool BF16> __global__ void __launch_bounds__(256) k_actor_parti
   hr = hr < rows ? hr : rows - 1;
   const size_t he = hr / N;
   const int hi_agent = (int)(hr - he * N);
-  const int head_steps = p.meta[2 * he];
+  const int head_steps = p.meta[2 * he] & 0x7fffffff;  // the sign bit flags a finished env (particle.hip, kFinishedBit)
   const uint32_t head_episode = (uint32_t)p.episode[he];
 
   actor_stage_tables<N, BF16>(lds, p.packed, tid);
@@ -361,7 +362,7 @@ template <int N, bool BF16> __global__ void __launch_bounds__(256) k_actor_parti
   CM3_STAMP(2, false);
   actor_mlp<N, BF16>(lds, b, w, lane, p.stage > 1);
   float pr[kA];
-  actor_head_probs(lds.h2s, lds.wout, w, lane, p.eps, pr);
+  actor_head_probs(lds.h2s, lds.wout, w, lane, p.eps_dev ? *p.eps_dev : p.eps, pr);
   const int act = actor_sample(pr, p.seed, (uint64_t)(p.env_id_base + (int64_t)he), head_episode, head_steps, hi_agent);
   if (head_ok) {
     p.actions[hr] = act;
@@ -467,6 +468,7 @@ extern "C" int cm3_actor_particle_f32(const cm3_actor_particle_desc *d, const cm
   p.E = d->n_envs;
   p.stage = d->stage;
   p.eps = d->epsilon;
+  p.eps_dev = b->epsilon_dev;
   p.bf16 = d->precision == 1 ? 1 : 0;
   p.env_id_base = d->env_id_base;
   p.seed = d->seed;

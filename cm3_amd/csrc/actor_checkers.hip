@@ -69,6 +69,8 @@ struct CkActorParams {
   const double *obs_self_v, *obs_others;
   const uint8_t *goals;
   const int32_t *actions_prev, *steps, *episode;
+  const uint8_t *prev_done;  // optional uint8 [E]: envs whose previous tick ended an episode feed actions_prev = 0
+  const float *eps_dev;      // optional: epsilon read from the device at launch
   int32_t *actions;
   float *probs;
   const float *packed;
@@ -358,7 +360,8 @@ template <bool BF16> __global__ void __launch_bounds__(256) k_ck_actor(const CkA
     float *x = &sX2[tid * kLdX2 + kLin];
 #pragma unroll
     for (int k = 0; k < 4; ++k) x[k] = (float)p.obs_self_v[row * 4 + k];
-    const int ap = p.actions_prev ? p.actions_prev[row] : 0;
+    // a fresh episode starts from actions_prev = zeros (train_onpolicy.py:295)
+    const int ap = (p.actions_prev && !(p.prev_done && p.prev_done[e])) ? p.actions_prev[row] : 0;
 #pragma unroll
     for (int k = 0; k < kA; ++k) x[4 + k] = ap == k ? 1.0f : 0.0f;
     const int gl = p.goals[row];
@@ -506,8 +509,9 @@ template <bool BF16> __global__ void __launch_bounds__(256) k_ck_actor(const CkA
         sum += o[a];
       }
       const float inv = 1.0f / sum;
+      const float eps = p.eps_dev ? *p.eps_dev : p.eps;
 #pragma unroll
-      for (int a = 0; a < kA; ++a) pr[a] = (1.0f - p.eps) * (o[a] * inv) + p.eps / (float)kA;
+      for (int a = 0; a < kA; ++a) pr[a] = (1.0f - eps) * (o[a] * inv) + eps / (float)kA;
       const size_t e = row / N;
       const int i = (int)(row - e * N);
       const int act = actor_sample(pr, p.seed, (uint64_t)(p.env_id_base + (int64_t)e), (uint32_t)p.episode[e], p.steps[e], i);
@@ -593,6 +597,8 @@ extern "C" int cm3_actor_checkers_f32(const cm3_actor_checkers_desc *d, const cm
   p.obs_others = b->obs_others;
   p.goals = b->goals;
   p.actions_prev = b->actions_prev;
+  p.prev_done = b->prev_done;
+  p.eps_dev = b->epsilon_dev;
   p.steps = b->steps;
   p.episode = b->episode;
   p.actions = b->actions;

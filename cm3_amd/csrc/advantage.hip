@@ -109,7 +109,6 @@ __global__ void __launch_bounds__(kAdvBlock) k_returns_moments(const R *__restri
       moments[0] = fs;
       moments[1] = fs2;
       moments[2] = fn;
-      *counter = 0u;  // ready for the next call
     }
   }
 }
@@ -139,10 +138,12 @@ __global__ void __launch_bounds__(kAdvBlock) k_normalize(R *__restrict__ x, cons
     stats[2] = tot2;
   }
   if (!apply) return;
-  const R m = (R)mean, inv = (R)(1.0 / (sd + eps));
+  // the same expression as the host helper cm3_amd.shard.normalize_advantages: (x - (R)mean) / (R)(std + eps), one IEEE
+  // division per element in the working precision -- the two documented paths agree bit for bit
+  const R m = (R)mean, den = (R)(sd + eps);
   for (size_t i = (size_t)blockIdx.x * kAdvBlock + threadIdx.x; i < n_elem; i += (size_t)gridDim.x * kAdvBlock) {
     const bool v = valid ? (valid[i / C] != 0) : true;
-    x[i] = v ? (x[i] - m) * inv : R(0);
+    x[i] = v ? (x[i] - m) / den : R(0);
   }
 }
 
@@ -172,6 +173,8 @@ static int returns_moments(const void *x, const uint8_t *done, const uint8_t *va
   int blocks = (int)((cols + kAdvBlock - 1) / kAdvBlock);
   if (blocks > kAdvMaxBlocks) blocks = kAdvMaxBlocks;
   hipStream_t s = (hipStream_t)stream;
+  // the arrival counter starts every call at zero: a launch that failed or was aborted cannot poison later calls
+  CM3_HIP_CHECK(hipMemsetAsync((char *)scratch + (size_t)kAdvMaxBlocks * 3 * sizeof(double), 0, sizeof(unsigned), s));
   hipLaunchKernelGGL((k_returns_moments<R>), dim3(blocks), dim3(kAdvBlock), 0, s, (const R *)x, done, valid, (R *)out,
                      (double *)scratch, moments, T, E, C, (R)gamma);
   CM3_HIP_CHECK(hipGetLastError());

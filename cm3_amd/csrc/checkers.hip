@@ -44,6 +44,14 @@ struct CheckersParams {
   double *local_rewards;
   double *reward;
   uint8_t *done;
+  // optional: the TRUE post-step observation of envs re-initialised by CM3_FLAG_AUTO_RESET in this launch (the next_* columns
+  // of the terminal transition, stored by the reference before it resets: train_onpolicy.py:336-347)
+  int8_t *term_grid;
+  int32_t *term_vec;
+  double *term_obs_others;
+  int8_t *term_obs_self_t;
+  double *term_obs_self_v;
+  uint8_t *goals_next;  // optional uint8 [E][N]: the goals in effect AFTER this tick (they change only for N == 1 restarts)
   const uint8_t *reset_mask;
   int grid_rec, obst_rec;        // payload bytes per env of grid / obs_self_t
   int grid_stride, obst_stride;  // bytes between consecutive env records (>= payload)
@@ -53,6 +61,16 @@ struct CheckersParams {
   int n_ticks;
   int _pad2;
   size_t st_actions, st_grid, st_vec, st_obs_others, st_obs_self_t, st_obs_self_v, st_local, st_reward, st_done;
+  size_t st_term_grid, st_term_vec, st_term_obs_others, st_term_obs_self_t, st_term_obs_self_v, st_goals_next;
+};
+
+// the five observation arrays one emit writes (the trajectory slot of a tick, or the terminal-capture slot)
+struct CkOut {
+  int8_t *grid;
+  int32_t *vec;
+  double *obs_others;
+  int8_t *obs_self_t;
+  double *obs_self_v;
 };
 
 template <typename T> __device__ __forceinline__ T *ck_tick_ptr(T *base, size_t stride, int t) {
@@ -109,9 +127,42 @@ __device__ __forceinline__ void ck_copy_out(const int8_t *lds, int8_t *dst, int 
 }
 
 template <int N>
+__device__ __forceinline__ void ck_emit_vectors(const CheckersParams &p, const CkState<N> &s, size_t e, const CkOut &out);
+
+// Terminal capture of the generic kernel: one lane writes its env's whole observation straight to global memory (rare:
+// only envs whose episode ended this tick under CM3_FLAG_AUTO_RESET).
+template <int N>
+__device__ __forceinline__ void ck_emit_direct(const CheckersParams &p, const CkState<N> &s, size_t e, const CkOut &out) {
+  int8_t *grow = out.grid + e * (size_t)p.grid_stride;
+  for (int k = 0; k < p.R; ++k)
+    for (int j = 0; j <= p.C; ++j) {
+      int g, o;
+      ck_ch01<N>(p, s, k + p.O, j + p.O, g, o);
+      const int off = (k * (p.C + 1) + j) * 2;
+      grow[off] = (int8_t)g;
+      grow[off + 1] = (int8_t)o;
+    }
+  int8_t *orow = out.obs_self_t + e * (size_t)p.obst_stride;
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    for (int dr = 0; dr < p.K; ++dr)
+      for (int dc = 0; dc < p.K; ++dc) {
+        const int rr = s.r[i] - p.O + dr, cc = s.c[i] - p.O + dc;
+        int g, o;
+        ck_ch01<N>(p, s, rr, cc, g, o);
+        int inv = ck_ch2<N>(p, s, rr, cc);
+        if (dr == p.O && dc == p.O) inv = 0;
+        int8_t *q = orow + ((i * p.K + dr) * p.K + dc) * 3;
+        q[0] = (int8_t)g;
+        q[1] = (int8_t)o;
+        q[2] = (int8_t)inv;
+      }
+  ck_emit_vectors<N>(p, s, e, out);
+}
+
+template <int N>
 __device__ __forceinline__ void ck_emit(const CheckersParams &p, const CkState<N> &s, int8_t *lds, int lane, size_t e0,
                                         size_t e, bool active) {
-  constexpr int NO = N > 1 ? N - 1 : 1;
   long rows_here = (long)p.E - (long)e0;
   rows_here = rows_here < 0 ? 0 : (rows_here > 64 ? 64 : rows_here);
 
@@ -151,7 +202,17 @@ __device__ __forceinline__ void ck_emit(const CheckersParams &p, const CkState<N
     ck_wave_sync();
   }
   if (!active) return;
-  // ---- vec (:79-94), obs_self_v / obs_others (normalize :112-125, :128-154) ----------------------------
+  CkOut o;
+  o.vec = p.vec;
+  o.obs_others = p.obs_others;
+  o.obs_self_v = p.obs_self_v;
+  ck_emit_vectors<N>(p, s, e, o);
+}
+
+// ---- vec (:79-94), obs_self_v / obs_others (normalize :112-125, :128-154) of one env --------------------------
+template <int N>
+__device__ __forceinline__ void ck_emit_vectors(const CheckersParams &p, const CkState<N> &s, size_t e, const CkOut &out) {
+  constexpr int NO = N > 1 ? N - 1 : 1;
   double nr[N], nc[N];
 #pragma unroll
   for (int i = 0; i < N; ++i) {
@@ -166,14 +227,14 @@ __device__ __forceinline__ void ck_emit(const CheckersParams &p, const CkState<N
     v.y = s.c[i];
     v.z = s.ng[i];
     v.w = s.no[i];
-    reinterpret_cast<int4 *>(p.vec)[e * N + i] = v;
+    reinterpret_cast<int4 *>(out.vec)[e * N + i] = v;
     double4 sv;
     sv.x = nr[i];
     sv.y = nc[i];
     sv.z = (double)s.ng[i] / half;
     sv.w = (double)s.no[i] / half;
-    reinterpret_cast<double4 *>(p.obs_self_v)[e * N + i] = sv;
-    double2 *oo = reinterpret_cast<double2 *>(p.obs_others) + (e * N + i) * NO;
+    reinterpret_cast<double4 *>(out.obs_self_v)[e * N + i] = sv;
+    double2 *oo = reinterpret_cast<double2 *>(out.obs_others) + (e * N + i) * NO;
 #pragma unroll
     for (int k = 0; k < NO; ++k) {
       const int j = (N > 1) ? (k < i ? k : k + 1) : 0;
@@ -244,9 +305,11 @@ __device__ __forceinline__ void ck_store_env(const CheckersParams &p, size_t e, 
 }
 
 // One tick of one env (checkers.py:228-262), executed by every lane that maps to env `ec`; `writer` selects the
-// single lane that performs the per-env stores of tick t.  Leaves the post-step (or freshly reset) state in `s`.
+// single lane that performs the per-env stores of tick t.  Leaves the POST-STEP state in `s` and returns whether the
+// episode ended under CM3_FLAG_AUTO_RESET: the caller then captures the terminal observation (term_*) and calls
+// ck_restart_env.
 template <int N>
-__device__ __forceinline__ void ck_tick_env(const CheckersParams &p, int t, size_t e, size_t ec, bool writer, CkState<N> &s,
+__device__ __forceinline__ bool ck_tick_env(const CheckersParams &p, int t, size_t e, size_t ec, bool writer, CkState<N> &s,
                                             CkLive<N> &lv) {
   const bool active = writer;
   int steps = lv.steps;
@@ -333,28 +396,48 @@ __device__ __forceinline__ void ck_tick_env(const CheckersParams &p, int t, size
     ck_tick_ptr(p.reward, p.st_reward, t)[e] = total;
     ck_tick_ptr(p.done, p.st_done, t)[e] = done ? 1 : 0;
   }
-  if ((p.flags & CM3_FLAG_AUTO_RESET) && done) {
-    episode += 1;
-    if (N == 1) {  // train_onpolicy.py:288-291: a fresh random goal per episode
-      goal[0] = (uint8_t)(reset_words(p.seed, genv, episode, 0).x & 1u);
-      if (active) p.goals[e] = goal[0];
-    }
-    ck_init<N>(p, goal, s);
-    steps = 0;
-  }
   lv.steps = steps;
-  lv.episode = episode;
-#pragma unroll
-  for (int i = 0; i < N; ++i) lv.goal[i] = goal[i];
+  return (p.flags & CM3_FLAG_AUTO_RESET) && done;
 }
 
-// plain one-tick step: load, tick 0, store
+// Same-launch re-initialisation of an env whose episode ended (train_onpolicy.py:282 folded into :321).
+template <int N>
+__device__ __forceinline__ void ck_restart_env(const CheckersParams &p, size_t e, size_t ec, bool writer, CkState<N> &s,
+                                               CkLive<N> &lv) {
+  lv.episode += 1;
+  if (N == 1) {  // train_onpolicy.py:288-291: a fresh random goal per episode
+    const uint64_t genv = (uint64_t)(p.env_id_base + (int64_t)ec);
+    lv.goal[0] = (uint8_t)(reset_words(p.seed, genv, lv.episode, 0).x & 1u);
+    if (writer) p.goals[e] = lv.goal[0];
+  }
+  ck_init<N>(p, lv.goal, s);
+  lv.steps = 0;
+}
+
+// plain one-tick step of the generic kernel: load, tick 0, terminal capture + restart, store
 template <int N>
 __device__ __forceinline__ void ck_step_env(const CheckersParams &p, size_t e, size_t ec, bool writer, CkState<N> &s) {
   CkLive<N> lv;
   ck_load_env<N>(p, ec, s, lv);
-  ck_tick_env<N>(p, 0, e, ec, writer, s, lv);
-  if (writer) ck_store_env<N>(p, e, s, lv);
+  if (ck_tick_env<N>(p, 0, e, ec, writer, s, lv)) {
+    if (writer && p.term_grid) {
+      CkOut o;
+      o.grid = p.term_grid;
+      o.vec = p.term_vec;
+      o.obs_others = p.term_obs_others;
+      o.obs_self_t = p.term_obs_self_t;
+      o.obs_self_v = p.term_obs_self_v;
+      ck_emit_direct<N>(p, s, e, o);
+    }
+    ck_restart_env<N>(p, e, ec, writer, s, lv);
+  }
+  if (writer) {
+    ck_store_env<N>(p, e, s, lv);
+    if (p.goals_next) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) p.goals_next[e * N + i] = lv.goal[i];
+    }
+  }
 }
 
 
@@ -437,20 +520,39 @@ template <int N> __device__ __forceinline__ uint32_t ckf_obst_dword(const CkStat
   return (uint32_t)(t >> sh);
 }
 
+// the observation slot written by tick t (slot t + 1 of the trajectory) / the terminal-capture slot of tick t
+__device__ __forceinline__ CkOut ck_out_tick(const CheckersParams &p, int t) {
+  CkOut o;
+  o.grid = ck_tick_ptr(p.grid, p.st_grid, t);
+  o.vec = ck_tick_ptr(p.vec, p.st_vec, t);
+  o.obs_others = ck_tick_ptr(p.obs_others, p.st_obs_others, t);
+  o.obs_self_t = ck_tick_ptr(p.obs_self_t, p.st_obs_self_t, t);
+  o.obs_self_v = ck_tick_ptr(p.obs_self_v, p.st_obs_self_v, t);
+  return o;
+}
+__device__ __forceinline__ CkOut ck_out_term(const CheckersParams &p, int t) {
+  CkOut o;
+  o.grid = ck_tick_ptr(p.term_grid, p.st_term_grid, t);
+  o.vec = ck_tick_ptr(p.term_vec, p.st_term_vec, t);
+  o.obs_others = ck_tick_ptr(p.term_obs_others, p.st_term_obs_others, t);
+  o.obs_self_t = ck_tick_ptr(p.term_obs_self_t, p.st_term_obs_self_t, t);
+  o.obs_self_v = ck_tick_ptr(p.term_obs_self_v, p.st_term_obs_self_v, t);
+  return o;
+}
+
 template <int N>
 __device__ __forceinline__ void ckf_emit(const CheckersParams &p, const CkState<N> &s, int g, size_t e, bool env_ok,
-                                         int t = 0) {
+                                         const CkOut &out) {
   using F = CkFast<N>;
   constexpr int NO = N > 1 ? N - 1 : 1;
   if (!env_ok) return;
   // grid record: dword g
   const int gd = p.grid_stride >> 2;
-  int8_t *grid_t = ck_tick_ptr(p.grid, p.st_grid, t);
   const uint32_t m32 = (uint32_t)s.mask;  // 24 collected bits
-  for (int d = g; d < gd; d += F::G) reinterpret_cast<uint32_t *>(grid_t + e * (size_t)p.grid_stride)[d] = ckf_grid_dword<N>(m32, d);
+  for (int d = g; d < gd; d += F::G) reinterpret_cast<uint32_t *>(out.grid + e * (size_t)p.grid_stride)[d] = ckf_grid_dword<N>(m32, d);
   // obs_self_t record: dwords g, g+16, ...
   const int od = p.obst_stride >> 2;
-  uint32_t *o32 = reinterpret_cast<uint32_t *>(ck_tick_ptr(p.obs_self_t, p.st_obs_self_t, t) + e * (size_t)p.obst_stride);
+  uint32_t *o32 = reinterpret_cast<uint32_t *>(out.obs_self_t + e * (size_t)p.obst_stride);
   for (int d = g; d < od; d += F::G) o32[d] = ckf_obst_dword<N>(s, m32, d);
   // small vector outputs: lane i (< N) writes agent i's rows
   if (g < N) {
@@ -467,15 +569,15 @@ __device__ __forceinline__ void ckf_emit(const CheckersParams &p, const CkState<
     v.y = ci;
     v.z = gi;
     v.w = oi;
-    reinterpret_cast<int4 *>(ck_tick_ptr(p.vec, p.st_vec, t))[e * N + g] = v;
+    reinterpret_cast<int4 *>(out.vec)[e * N + g] = v;
     const double half = (double)(F::R * F::C) / 2.0;
     double4 sv;
     sv.x = ((double)ri - (double)F::TR / 2.0) / (double)F::TR;
     sv.y = ((double)ci - (double)F::TC / 2.0) / (double)F::TC;
     sv.z = (double)gi / half;
     sv.w = (double)oi / half;
-    reinterpret_cast<double4 *>(ck_tick_ptr(p.obs_self_v, p.st_obs_self_v, t))[e * N + g] = sv;
-    double2 *oo = reinterpret_cast<double2 *>(ck_tick_ptr(p.obs_others, p.st_obs_others, t)) + (e * N + g) * NO;
+    reinterpret_cast<double4 *>(out.obs_self_v)[e * N + g] = sv;
+    double2 *oo = reinterpret_cast<double2 *>(out.obs_others) + (e * N + g) * NO;
 #pragma unroll
     for (int k = 0; k < NO; ++k) {
       // k-th other agent of agent g (N == 1: itself)
@@ -541,12 +643,21 @@ __global__ void __launch_bounds__(SPLIT ? 320 : 256) k_checkers_step_fast(const 
   const int n_ticks = FUSED ? p.n_ticks : 1;
 #pragma unroll 1
   for (int t = 0; t < n_ticks; ++t) {
-    ck_tick_env<N>(p, t, e, ec, writer, s, lv);
+    const bool ended = ck_tick_env<N>(p, t, e, ec, writer, s, lv);
     if constexpr (SPLIT) {
       if (!pre_rd) __builtin_amdgcn_s_waitcnt(0);  // first tick of a rollout: this tick's own action row is written
       __syncthreads();                             // barrier 1: the actions of this tick are consumed
     }
-    ckf_emit<N>(p, s, g, e, env_ok, t);
+    if (ended) {  // AUTO_RESET: terminal observation (train_onpolicy.py:336-347), then the fresh episode
+      if (p.term_grid) ckf_emit<N>(p, s, g, e, env_ok, ck_out_term(p, t));
+      ck_restart_env<N>(p, e, ec, writer, s, lv);
+    }
+    ckf_emit<N>(p, s, g, e, env_ok, ck_out_tick(p, t));
+    if (p.goals_next && writer) {
+      uint8_t *gn = ck_tick_ptr(p.goals_next, p.st_goals_next, t);
+#pragma unroll
+      for (int i = 0; i < N; ++i) gn[e * N + i] = lv.goal[i];
+    }
   }
   if constexpr (SPLIT) {
     __syncthreads();  // barrier 2: the draw wave's row for the next launch is in memory
@@ -587,7 +698,7 @@ template <int N> __global__ void __launch_bounds__(256) k_checkers_reset_fast(co
   } else {
     ck_load<N>(p, ec, s);
   }
-  ckf_emit<N>(p, s, g, e, env_ok);
+  ckf_emit<N>(p, s, g, e, env_ok, ck_out_tick(p, 0));
 }
 
 template <int N> __global__ void __launch_bounds__(64) k_checkers_step(const CheckersParams p) {
@@ -704,6 +815,17 @@ static int ck_fill(const cm3_checkers_desc *d, const cm3_checkers_bufs *b, const
   p.local_rewards = b->local_rewards;
   p.reward = b->reward;
   p.done = b->done;
+  {
+    const int have = (b->term_grid != nullptr) + (b->term_vec != nullptr) + (b->term_obs_others != nullptr) +
+                     (b->term_obs_self_t != nullptr) + (b->term_obs_self_v != nullptr);
+    CM3_REQUIRE(have == 0 || have == 5, "terminal capture needs all five term_* arrays (or none)");
+  }
+  p.term_grid = b->term_grid;
+  p.term_vec = b->term_vec;
+  p.term_obs_others = b->term_obs_others;
+  p.term_obs_self_t = b->term_obs_self_t;
+  p.term_obs_self_v = b->term_obs_self_v;
+  p.goals_next = b->goals_next;
   p.reset_mask = mask;
   return CM3_OK;
 }
@@ -778,6 +900,12 @@ static int ck_rollout(const cm3_checkers_desc *d, const cm3_checkers_traj *t, in
     b.local_rewards = (double *)at(t->local_rewards, t->local_rewards_stride, k);
     b.reward = (double *)at(t->reward, t->reward_stride, k);
     b.done = (uint8_t *)at(t->done, t->done_stride, k);
+    b.term_grid = (int8_t *)at(t->term_grid, t->term_grid_slot_stride, k);
+    b.term_vec = (int32_t *)at(t->term_vec, t->term_vec_stride, k);
+    b.term_obs_others = (double *)at(t->term_obs_others, t->term_obs_others_stride, k);
+    b.term_obs_self_t = (int8_t *)at(t->term_obs_self_t, t->term_obs_self_t_slot_stride, k);
+    b.term_obs_self_v = (double *)at(t->term_obs_self_v, t->term_obs_self_v_stride, k);
+    b.goals_next = (uint8_t *)at(t->goals_slots, t->goals_slots_stride, k + 1);
   };
   cm3_checkers_bufs b;
   if (d->flags & CM3_FLAG_FUSED_TICKS) {
@@ -798,6 +926,12 @@ static int ck_rollout(const cm3_checkers_desc *d, const cm3_checkers_traj *t, in
     p.st_local = t->local_rewards_stride;
     p.st_reward = t->reward_stride;
     p.st_done = t->done_stride;
+    p.st_term_grid = t->term_grid_slot_stride;
+    p.st_term_vec = t->term_vec_stride;
+    p.st_term_obs_others = t->term_obs_others_stride;
+    p.st_term_obs_self_t = t->term_obs_self_t_slot_stride;
+    p.st_term_obs_self_v = t->term_obs_self_v_stride;
+    p.st_goals_next = t->goals_slots_stride;
     return ck_dispatch(p, d->n_agents, true, (hipStream_t)stream);
   }
   for (int k = 0; k < n_ticks; ++k) {

@@ -17,14 +17,16 @@
 // the double instantiation differs from NumPy only in the last ulps of exp/log1p.
 #include "common.h"
 #include "philox.h"
+#include "thresholds.h"
 
 namespace cm3 {
 
 struct ParticleParams {
-  int E;
+  int E;          // extent of the env axis of every array (row stride of the [N][E][..] arrays)
   int max_steps;
   uint32_t flags;
   int _pad;
+  int E0, EN;     // this launch covers envs [E0, EN) of the arrays (a sub-batch chain of cm3_particle_rollout_chains_*)
   int64_t env_id_base;
   uint64_t seed;
   double prob_random, initial_std;
@@ -43,13 +45,14 @@ struct ParticleParams {
   uint8_t *done;
   void *term_state;
   void *term_obs_others;
+  int32_t *term_collisions;
   const uint8_t *reset_mask;
   // tick loop inside one launch (CM3_FLAG_FUSED_TICKS): tick t uses <pointer> + t * <stride in bytes> for the
   // per-tick arrays (state_out / goals_out / obs_others / term_* point at slot 1 of their trajectories);
   // n_ticks == 1 with zero strides is the plain one-launch-per-tick step.
   int n_ticks;
   int _pad2;
-  size_t st_state, st_goals, st_obs, st_actions, st_reward_n, st_reward, st_done, st_term_state, st_term_obs;
+  size_t st_state, st_goals, st_obs, st_actions, st_reward_n, st_reward, st_done, st_term_state, st_term_obs, st_term_coll;
 };
 
 template <typename T> __device__ __forceinline__ T *tick_ptr(T *base, size_t stride, int t) {
@@ -94,7 +97,9 @@ template <typename R> __device__ __forceinline__ R logaddexp0(R x) {
 // The reference evaluates this for every agent pair every tick.  Beyond kSkip the soft-plus underflows to
 // exactly 0 in the working precision (float: exp(x) = 0 for x <= -110, i.e. dist >= 0.41; double: x <= -750,
 // dist >= 1.05), pen == 0 and the force is (+-)0, which leaves every accumulator bit-unchanged -- so the
-// transcendental chain is skipped there.  NaN distances take the slow path (NaN propagates as in the reference).
+// transcendental chain is skipped there.  The reach test runs on the SQUARED distance against the exact threshold
+// Thresh<R>::kSkip2 (thresholds.h: sqrt(d2) >= kSkip <=> d2 >= kSkip2), so the square root itself is only taken
+// on the slow path.  NaN distances take the slow path (NaN propagates as in the reference).
 template <typename R> struct Contact;
 template <> struct Contact<float> {
   static constexpr float kSkip = 0.41f;
@@ -103,25 +108,32 @@ template <> struct Contact<double> {
   static constexpr double kSkip = 1.05;
 };
 
-template <typename R> __device__ __forceinline__ void contact_force(R dx, R dy, R &f_x, R &f_y) {
+// the slow path alone, for callers that know d2 = dx^2 + dy^2 is within reach (!(d2 >= kSkip2))
+template <typename R> __device__ __forceinline__ void contact_force_near(R dx, R dy, R d2, R &f_x, R &f_y) {
   const R kMargin = R(1e-3), kForce = R(1e+2), kDistMin = R(0.15) + R(0.15);
-  const R dist = Math<R>::sqrt(dx * dx + dy * dy);
-  f_x = R(0);
-  f_y = R(0);
-  if (!(dist >= Contact<R>::kSkip)) {
-    const R pen = logaddexp0<R>(-(dist - kDistMin) / kMargin) * kMargin;
-    f_x = kForce * dx / dist * pen;
-    f_y = kForce * dy / dist * pen;
-  }
-}
-
-// the slow path alone, for callers that already hold dist = sqrt(dx^2 + dy^2) and know it is within reach
-template <typename R> __device__ __forceinline__ void contact_force_near(R dx, R dy, R dist, R &f_x, R &f_y) {
-  const R kMargin = R(1e-3), kForce = R(1e+2), kDistMin = R(0.15) + R(0.15);
+  const R dist = Math<R>::sqrt(d2);
   const R pen = logaddexp0<R>(-(dist - kDistMin) / kMargin) * kMargin;
   f_x = kForce * dx / dist * pen;
   f_y = kForce * dy / dist * pen;
 }
+
+template <typename R> __device__ __forceinline__ void contact_force(R dx, R dy, R &f_x, R &f_y) {
+  const R d2 = dx * dx + dy * dy;
+  f_x = R(0);
+  f_y = R(0);
+  if (!(d2 >= Thresh<R>::kSkip2)) contact_force_near<R>(dx, dy, d2, f_x, f_y);
+}
+
+// is_collision (multi-goal_spread.py:114-118): sqrt(dx^2 + dy^2) < 0.15 + 0.15, on the squared distance (thresholds.h)
+template <typename R> __device__ __forceinline__ bool is_collision(R dx, R dy) {
+  return dx * dx + dy * dy < Thresh<R>::kColl2;
+}
+
+// Counters of one env as stored in meta[e] = {steps | finished << 31, collisions}.  Without CM3_FLAG_AUTO_RESET an env
+// whose episode has ended is FINISHED: the reference's loop stops calling step() there (train_onpolicy.py:302), so its
+// step and collision counters freeze (scenario.collisions stays the episode's value, read at :356) and `done` stays set
+// until the env is reset; the physics keeps running on it (its transitions are flagged invalid by the collector).
+constexpr int kFinishedBit = (int)0x80000000u;
 
 template <typename R, typename V4> __device__ __forceinline__ V4 sub4(const V4 &a, const V4 &b) {
   V4 r;
@@ -333,10 +345,10 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step(const ParticlePara
   __shared__ __attribute__((aligned(32))) R lds_all[WAVES][G::LDS_REALS];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const size_t e0 = ((size_t)blockIdx.x * WAVES + wave) * 64;
+  const size_t e0 = (size_t)p.E0 + ((size_t)blockIdx.x * WAVES + wave) * 64;
   const size_t e = e0 + lane;
-  const bool active = e < (size_t)p.E;
-  const size_t ec = active ? e : (size_t)p.E - 1;  // clamped index for loads
+  const bool active = e < (size_t)p.EN;
+  const size_t ec = active ? e : (size_t)p.EN - 1;  // clamped index for loads
   const size_t E = (size_t)p.E;
   CM3_STAMP(0, false);
 
@@ -350,14 +362,16 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step(const ParticlePara
 #pragma unroll
   for (int i = 0; i < N; ++i) g[i] = gin2[(size_t)i * E + ec];
   const int2 meta = reinterpret_cast<const int2 *>(p.meta_in)[ec];
-  int steps = meta.x, collisions = meta.y;
+  int steps = meta.x & ~kFinishedBit, collisions = meta.y;
+  bool fin = meta.x < 0;  // finished earlier and not reset since (see kFinishedBit)
+  const bool auto_reset = (p.flags & CM3_FLAG_AUTO_RESET) != 0;
 
   const bool gen = (p.flags & CM3_FLAG_GEN_ACTIONS) != 0;
   uint32_t episode = 0;
   if (gen || (p.flags & CM3_FLAG_AUTO_RESET)) episode = (uint32_t)p.episode[ec];
   const uint32_t episode_in = episode;
   const uint64_t genv = (uint64_t)(p.env_id_base + (int64_t)ec);
-  const R kDistMin = R(0.15) + R(0.15), kDt = R(0.1), kKeep = R(1 - 0.25);
+  const R kDt = R(0.1), kKeep = R(1 - 0.25);
   CM3_STAMP(1, true);
 
   // The state stays in registers across the ticks of this launch (n_ticks == 1: plain one-launch-per-tick step).
@@ -421,7 +435,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step(const ParticlePara
       s[i].z = s[i].z + s[i].x * kDt;
       s[i].w = s[i].w + s[i].y * kDt;
     }
-    steps += 1;  // environment.py:93
+    steps += fin ? 0 : 1;  // environment.py:93
     CM3_STAMP(2, false);
 
     // ---- reward / reached (multi-goal_spread.py:121-143) ----------------------------------------------
@@ -430,24 +444,24 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step(const ParticlePara
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       const R dx = s[i].z - g[i].x, dy = s[i].w - g[i].y;
-      rew[i] = R(0) - Math<R>::sqrt(dx * dx + dy * dy);
-      all_reached = all_reached && (rew[i] >= R(-0.05));
+      const R d2 = dx * dx + dy * dy;
+      rew[i] = R(0) - Math<R>::sqrt(d2);
+      all_reached = all_reached && (d2 < Thresh<R>::kReach2);  // rew[i] >= -0.05 (thresholds.h)
     }
 #pragma unroll
     for (int a = 0; a < N; ++a) {
 #pragma unroll
       for (int b = a + 1; b < N; ++b) {
         // is_collision is symmetric, so the reference's two ordered visits (j,i) and (i,j) collapse into one
-        const R dx = s[b].z - s[a].z, dy = s[b].w - s[a].w;
-        if (Math<R>::sqrt(dx * dx + dy * dy) < kDistMin) {
+        if (is_collision<R>(s[b].z - s[a].z, s[b].w - s[a].w)) {
           rew[a] = rew[a] - R(1);
           rew[b] = rew[b] - R(1);
-          collisions += 2;  // double counts by design (:135-137)
+          collisions += fin ? 0 : 2;  // double counts by design (:135-137)
         }
       }
     }
     const R reward = sum_agents<R, N>(rew);                   // environment.py:107
-    const bool done = (steps == p.max_steps) || all_reached;  // environment.py:118-121
+    const bool done = fin || (steps == p.max_steps) || all_reached;  // environment.py:118-121
 
     CM3_STAMP(3, false);
     if (active) {
@@ -459,10 +473,11 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step(const ParticlePara
 
     // ---- same-launch re-initialisation of finished episodes -------------------------------------------
     bool was_reset = false;
-    if ((p.flags & CM3_FLAG_AUTO_RESET) && done) {
+    if (auto_reset && done) {
       if (active) {
         void *term_state = tick_ptr(p.term_state, p.st_term_state, t);
         void *term_obs = tick_ptr(p.term_obs_others, p.st_term_obs, t);
+        if (p.term_collisions) tick_ptr(p.term_collisions, p.st_term_coll, t)[e] = collisions;
         if (term_state) {
           V4 *t4 = reinterpret_cast<V4 *>(term_state);
 #pragma unroll
@@ -476,6 +491,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step(const ParticlePara
       collisions = 0;
       was_reset = true;
     }
+    fin = done && !auto_reset;
     CM3_STAMP(9, false);
 
     if (active) {
@@ -491,7 +507,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step(const ParticlePara
 
     CM3_STAMP(4, false);
     // ---- observation (multi-goal_spread.py:145-154), env-major rows through the wave's LDS tile --------
-    store_obs_others_staged<R, N>(s, &lds_all[wave][0], lane, e0, p.E,
+    store_obs_others_staged<R, N>(s, &lds_all[wave][0], lane, e0, p.EN,
                                   reinterpret_cast<R *>(tick_ptr(p.obs_others, p.st_obs, t)));
     CM3_STAMP(5, false);
   }
@@ -499,7 +515,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step(const ParticlePara
   // ---- live counters, once per launch ----------------------------------------------------------------------
   if (active) {
     int2 m;
-    m.x = steps;
+    m.x = steps | (fin ? kFinishedBit : 0);
     m.y = collisions;
     reinterpret_cast<int2 *>(p.meta_out)[e] = m;
     if (episode != episode_in) p.episode[e] = (int32_t)episode;
@@ -546,7 +562,8 @@ template <int N> struct PairGeom {
 template <typename R, int N, int WAVES, bool FUSED, bool SPLIT = false>
 __global__ void __launch_bounds__((WAVES + (SPLIT ? 1 : 0)) * 64)
     k_particle_step_pairs(const void *h_state_in, const void *h_goals_in, const int32_t *h_meta_in, const int32_t *h_episode,
-                          const int32_t *h_actions, const int h_E, const uint32_t h_flags, const ParticleParams p) {
+                          const int32_t *h_actions, const int h_E, const uint32_t h_flags, const int h_E0, const int h_EN,
+                          const ParticleParams p) {
   // The leading arguments repeat the fields of `p` that the first loads need: scalar kernel arguments are preloaded into
   // SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count), so the addresses of the first loads do not wait for a
   // kernarg fetch.
@@ -561,10 +578,10 @@ __global__ void __launch_bounds__((WAVES + (SPLIT ? 1 : 0)) * 64)
   const int lane = threadIdx.x & 63, wave_all = threadIdx.x >> 6;
   const int wave = wave_all;
   const int gslot = lane & (G - 1), sub = lane / G, base = lane - gslot;
-  const size_t E = (size_t)h_E;
-  const size_t e = ((size_t)blockIdx.x * WAVES + wave) * EPW + sub;
-  const bool env_ok = e < E;
-  const size_t ec = env_ok ? e : E - 1;
+  const size_t E = (size_t)h_E, EN = (size_t)h_EN;  // array extent (row stride); this launch covers envs [h_E0, h_EN)
+  const size_t e = (size_t)h_E0 + ((size_t)blockIdx.x * WAVES + wave) * EPW + sub;
+  const bool env_ok = e < EN;
+  const size_t ec = env_ok ? e : EN - 1;
   const bool slot_ok = gslot < SLOTS;
   const int gi = slot_ok ? gslot : 0;
   const int i = gi / NO, k = gi - i * NO, j = k < i ? k : k + 1;
@@ -575,15 +592,16 @@ __global__ void __launch_bounds__((WAVES + (SPLIT ? 1 : 0)) * 64)
   if constexpr (SPLIT) {
     if (wave_all == WAVES) {  // the draw wave (train_onpolicy.py:305-307 for the next launch)
       const int el = lane / N, ia = lane - el * N;  // env of the workgroup, agent
-      const size_t ed = (size_t)blockIdx.x * (WAVES * EPW) + el;
-      const bool ok = lane < WAVES * EPW * N && ed < E;
-      const size_t edc = ed < E ? ed : E - 1;
+      const size_t ed = (size_t)h_E0 + (size_t)blockIdx.x * (WAVES * EPW) + el;
+      const bool ok = lane < WAVES * EPW * N && ed < EN;
+      const size_t edc = ed < EN ? ed : EN - 1;
       int a = 0;
       if (pre_wr) {
-        const int steps_d = h_meta_in[2 * edc];
+        const int meta_d = h_meta_in[2 * edc];
+        const int steps_d = (meta_d & ~kFinishedBit) + (meta_d < 0 ? 0 : 1);  // a finished env's counter stays
         const uint32_t episode_d = (uint32_t)h_episode[edc];
         const uint64_t genv_d = (uint64_t)(p.env_id_base + (int64_t)edc);
-        const u32x4 w = action_words(p.seed, genv_d, episode_d, (uint32_t)(steps_d + 1), (uint32_t)(ia >> 2));
+        const u32x4 w = action_words(p.seed, genv_d, episode_d, (uint32_t)steps_d, (uint32_t)(ia >> 2));
         const int q = ia & 3;
         a = rand5(q == 0 ? w.x : (q == 1 ? w.y : (q == 2 ? w.z : w.w)));
       }
@@ -601,13 +619,15 @@ __global__ void __launch_bounds__((WAVES + (SPLIT ? 1 : 0)) * 64)
   V4 sj = sin4[(size_t)j * E + ec];
   V2 gl = reinterpret_cast<const V2 *>(h_goals_in)[(size_t)i * E + ec];
   const int2 meta = reinterpret_cast<const int2 *>(h_meta_in)[ec];
-  int steps = meta.x, collisions = meta.y;
+  int steps = meta.x & ~kFinishedBit, collisions = meta.y;
+  bool fin = meta.x < 0;  // finished earlier and not reset since (see kFinishedBit)
+  const bool auto_reset = (h_flags & CM3_FLAG_AUTO_RESET) != 0;
   const bool gen = (h_flags & CM3_FLAG_GEN_ACTIONS) != 0;
   uint32_t episode = 0;
   if (gen || (h_flags & CM3_FLAG_AUTO_RESET)) episode = (uint32_t)h_episode[ec];
   const uint32_t episode_in = episode;
   const uint64_t genv = (uint64_t)(p.env_id_base + (int64_t)ec);
-  const R kDt = R(0.1), kKeep = R(1 - 0.25), kDistMin = R(0.15) + R(0.15);
+  const R kDt = R(0.1), kKeep = R(1 - 0.25);
 
   CM3_STAMP(1, true);
   // FUSED == false: exactly one tick, the loop and every per-tick pointer offset fold away at compile time
@@ -654,7 +674,7 @@ __global__ void __launch_bounds__((WAVES + (SPLIT ? 1 : 0)) * 64)
     si.y = si.y + (Fy / R(1.0)) * kDt;
     si.z = si.z + si.x * kDt;
     si.w = si.w + si.y * kDt;
-    steps += 1;
+    steps += fin ? 0 : 1;
     if constexpr (SPLIT) {
       if (!pre_rd) __builtin_amdgcn_s_waitcnt(0);  // first tick of a rollout: this tick's own action row is written
       __syncthreads();                             // barrier 1: every physics wave holds its actions in registers
@@ -670,23 +690,21 @@ __global__ void __launch_bounds__((WAVES + (SPLIT ? 1 : 0)) * 64)
     CM3_STAMP(4, true);
     // ---- reward / reached / collisions (multi-goal_spread.py:114-143) ----------------------------------------
     R rew;
+    bool reached;
     {
       const R dx = si.z - gl.x, dy = si.w - gl.y;
-      rew = R(0) - Math<R>::sqrt(dx * dx + dy * dy);
+      const R d2 = dx * dx + dy * dy;
+      rew = R(0) - Math<R>::sqrt(d2);
+      reached = d2 < Thresh<R>::kReach2;  // rew >= -0.05 (thresholds.h)
     }
-    const bool reached = rew >= R(-0.05);
-    bool hit;
-    {
-      const R dx = sj.z - si.z, dy = sj.w - si.w;  // is_collision(a = j, agent = i)
-      hit = slot_ok && (Math<R>::sqrt(dx * dx + dy * dy) < kDistMin);
-    }
+    const bool hit = slot_ok && is_collision<R>(sj.z - si.z, sj.w - si.w);  // is_collision(a = j, agent = i)
     const unsigned long long hits = __ballot(hit);
     const unsigned long long grp = (G == 64) ? hits : ((hits >> base) & ((1ull << (G & 63)) - 1ull));
     const int c_i = __popcll((grp >> (i * NO)) & ((1ull << NO) - 1ull));
 #pragma unroll
     for (int c = 0; c < NO; ++c)
       if (c < c_i) rew = rew - R(1);
-    collisions += __popcll(grp);  // every ordered visit counts (:135-137)
+    collisions += fin ? 0 : __popcll(grp);  // every ordered visit counts (:135-137)
     const unsigned long long rb = __ballot(reached && lead);
     const unsigned long long rgrp = (G == 64) ? rb : ((rb >> base) & ((1ull << (G & 63)) - 1ull));
     const bool all_reached = __popcll(rgrp) == N;
@@ -694,7 +712,7 @@ __global__ void __launch_bounds__((WAVES + (SPLIT ? 1 : 0)) * 64)
 #pragma unroll
     for (int a = 0; a < N; ++a) rews[a] = __shfl(rew, base + a * NO, 64);
     const R reward = sum_agents<R, N>(rews);
-    const bool done = (steps == p.max_steps) || all_reached;
+    const bool done = fin || (steps == p.max_steps) || all_reached;
 
     if (env_ok && lead) reinterpret_cast<R *>(tick_ptr(p.reward_n, p.st_reward_n, t))[e * N + i] = rew;
     if (env_ok && head) {
@@ -705,10 +723,11 @@ __global__ void __launch_bounds__((WAVES + (SPLIT ? 1 : 0)) * 64)
     CM3_STAMP(5, true);
     // ---- same-launch re-initialisation -------------------------------------------------------------------------
     bool was_reset = false;
-    if ((p.flags & CM3_FLAG_AUTO_RESET) && done) {
+    if (auto_reset && done) {
       if (env_ok) {
         void *term_state = tick_ptr(p.term_state, p.st_term_state, t);
         void *term_obs = tick_ptr(p.term_obs_others, p.st_term_obs, t);
+        if (p.term_collisions && head) tick_ptr(p.term_collisions, p.st_term_coll, t)[e] = collisions;
         if (term_state && lead) reinterpret_cast<V4 *>(term_state)[(size_t)i * E + e] = si;
         if (term_obs && slot_ok) reinterpret_cast<V4 *>(term_obs)[e * SLOTS + gslot] = sub4<R, V4>(sj, si);
       }
@@ -721,12 +740,14 @@ __global__ void __launch_bounds__((WAVES + (SPLIT ? 1 : 0)) * 64)
       collisions = 0;
       was_reset = true;
     }
+    const bool newly_fin = done && !auto_reset && !fin;  // this tick ended the episode and nothing restarts it
+    fin = done && !auto_reset;
 
     CM3_STAMP(6, false);
     if constexpr (SPLIT) {
       __syncthreads();  // barrier 2: the draw wave's row for the next launch is in memory
-      if (pre_wr && was_reset) {  // fresh episode: the next launch sees (episode + 1, step 0)
-        const u32x4 w = action_words(p.seed, genv, episode, 0u, (uint32_t)(i >> 2));
+      if (pre_wr && (was_reset || newly_fin)) {  // the next launch sees (episode + 1, step 0) / the frozen step counter
+        const u32x4 w = action_words(p.seed, genv, episode, (uint32_t)steps, (uint32_t)(i >> 2));
         const int q = i & 3;
         const int a = rand5(q == 0 ? w.x : (q == 1 ? w.y : (q == 2 ? w.z : w.w)));
         if (env_ok && lead) tick_ptr(p.actions, p.st_actions, 1)[e * N + i] = a;
@@ -749,7 +770,7 @@ __global__ void __launch_bounds__((WAVES + (SPLIT ? 1 : 0)) * 64)
   // ---- live counters, once per launch -------------------------------------------------------------------------------
   if (env_ok && head) {
     int2 m;
-    m.x = steps;
+    m.x = steps | (fin ? kFinishedBit : 0);
     m.y = collisions;
     reinterpret_cast<int2 *>(p.meta_out)[e] = m;
     if (episode != episode_in) p.episode[e] = (int32_t)episode;
@@ -785,11 +806,11 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_agents(const Parti
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int gi = lane & (G - 1), sub = lane / G, base = lane - gi;
-  const size_t E = (size_t)p.E;
-  const size_t e0 = ((size_t)blockIdx.x * WAVES + wave) * EPW;
+  const size_t E = (size_t)p.E, EN = (size_t)p.EN;  // array extent (row stride); this launch covers envs [E0, EN)
+  const size_t e0 = (size_t)p.E0 + ((size_t)blockIdx.x * WAVES + wave) * EPW;
   const size_t e = e0 + sub;
-  const bool env_ok = e < E;
-  const size_t ec = env_ok ? e : E - 1;
+  const bool env_ok = e < EN;
+  const size_t ec = env_ok ? e : EN - 1;
   const bool agent_ok = gi < N;
   const int i = agent_ok ? gi : 0;
   const bool mine = env_ok && agent_ok;  // this lane owns agent i of env e
@@ -801,16 +822,18 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_agents(const Parti
   V4 si = reinterpret_cast<const V4 *>(p.state_in)[(size_t)i * E + ec];
   V2 gl = reinterpret_cast<const V2 *>(p.goals_in)[(size_t)i * E + ec];
   const int2 meta = reinterpret_cast<const int2 *>(p.meta_in)[ec];
-  int steps = meta.x, collisions = meta.y;
+  int steps = meta.x & ~kFinishedBit, collisions = meta.y;
+  bool fin = meta.x < 0;  // finished earlier and not reset since (see kFinishedBit)
+  const bool auto_reset = (p.flags & CM3_FLAG_AUTO_RESET) != 0;
   const bool gen = (p.flags & CM3_FLAG_GEN_ACTIONS) != 0;
   uint32_t episode = 0;
   if (gen || (p.flags & CM3_FLAG_AUTO_RESET)) episode = (uint32_t)p.episode[ec];
   const uint32_t episode_in = episode;
   const uint64_t genv = (uint64_t)(p.env_id_base + (int64_t)ec);
-  const R kDt = R(0.1), kKeep = R(1 - 0.25), kDistMin = R(0.15) + R(0.15);
+  const R kDt = R(0.1), kKeep = R(1 - 0.25);
 
-  // rows of the wave's obs tile that exist (envs past E are not stored)
-  long envs_here = (long)E - (long)e0;
+  // rows of the wave's obs tile that exist (envs past the launch's range are not stored)
+  long envs_here = (long)EN - (long)e0;
   envs_here = envs_here < 0 ? 0 : (envs_here > EPW ? EPW : envs_here);
   const int nvec = (int)envs_here * VPE;
 
@@ -854,27 +877,28 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_agents(const Parti
     // Beyond Contact<R>::kSkip the force is exactly (+-)0 and leaves Fx / Fy bit-unchanged (see contact_force), so only
     // the agents within reach are visited, in ascending order; the wave iterates max-over-lanes(#neighbours in reach)
     // times (typically 0-2) instead of running the transcendental chain N-1 times because SOME lane needs it.
-    R dxs[N], dys[N], dists[N];
+    // The scan runs on squared distances against the exact threshold (thresholds.h): no square root outside the loop.
+    R dxs[N], dys[N], d2s[N];
     unsigned near_mask = 0;
 #pragma unroll
     for (int j = 0; j < N; ++j) {
       dxs[j] = si.z - __shfl(si.z, base + j, 64);
       dys[j] = si.w - __shfl(si.w, base + j, 64);
-      dists[j] = Math<R>::sqrt(dxs[j] * dxs[j] + dys[j] * dys[j]);
-      if (j != i && !(dists[j] >= Contact<R>::kSkip)) near_mask |= 1u << j;
+      d2s[j] = dxs[j] * dxs[j] + dys[j] * dys[j];
+      if (j != i && !(d2s[j] >= Thresh<R>::kSkip2)) near_mask |= 1u << j;
     }
     while (__any(near_mask != 0u)) {
       const int jn = near_mask ? (__ffs((int)near_mask) - 1) : 0;
-      R dx = dxs[0], dy = dys[0], dist = dists[0];
+      R dx = dxs[0], dy = dys[0], d2 = d2s[0];
 #pragma unroll
       for (int j = 1; j < N; ++j) {
         dx = (jn == j) ? dxs[j] : dx;
         dy = (jn == j) ? dys[j] : dy;
-        dist = (jn == j) ? dists[j] : dist;
+        d2 = (jn == j) ? d2s[j] : d2;
       }
       if (near_mask) {
         R f_x, f_y;
-        contact_force_near<R>(dx, dy, dist, f_x, f_y);  // the distance is already known and within reach
+        contact_force_near<R>(dx, dy, d2, f_x, f_y);  // within reach: the one square root of this neighbour
         Fx = f_x + Fx;
         Fy = f_y + Fy;
       }
@@ -889,7 +913,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_agents(const Parti
     si.y = si.y + (Fy / R(1.0)) * kDt;
     si.z = si.z + si.x * kDt;
     si.w = si.w + si.y * kDt;
-    steps += 1;
+    steps += fin ? 0 : 1;
     V4 oj[N];  // post-step state of every agent of this env
 #pragma unroll
     for (int j = 0; j < N; ++j) {
@@ -902,17 +926,17 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_agents(const Parti
     CM3_STAMP(4, true);
     // ---- reward / reached / collisions (multi-goal_spread.py:114-143) ----------------------------------------
     R rew;
+    bool reached;
     {
       const R dx = si.z - gl.x, dy = si.w - gl.y;
-      rew = R(0) - Math<R>::sqrt(dx * dx + dy * dy);
+      const R d2 = dx * dx + dy * dy;
+      rew = R(0) - Math<R>::sqrt(d2);
+      reached = d2 < Thresh<R>::kReach2;  // rew >= -0.05 (thresholds.h)
     }
-    const bool reached = rew >= R(-0.05);
     int c_i = 0;
 #pragma unroll
-    for (int j = 0; j < N; ++j) {
-      const R dx = oj[j].z - si.z, dy = oj[j].w - si.w;  // is_collision(a = j, agent = i)
-      c_i += (j != i && Math<R>::sqrt(dx * dx + dy * dy) < kDistMin) ? 1 : 0;
-    }
+    for (int j = 0; j < N; ++j)  // is_collision(a = j, agent = i)
+      c_i += (j != i && is_collision<R>(oj[j].z - si.z, oj[j].w - si.w)) ? 1 : 0;
     c_i = agent_ok ? c_i : 0;
 #pragma unroll
     for (int c = 0; c < NO; ++c)
@@ -920,7 +944,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_agents(const Parti
     int c_env = c_i;  // every ordered visit counts (:135-137)
 #pragma unroll
     for (int off = G / 2; off > 0; off >>= 1) c_env += __shfl_xor(c_env, off, 64);
-    collisions += c_env;
+    collisions += fin ? 0 : c_env;
     const unsigned long long rb = __ballot(reached && agent_ok);
     const unsigned long long rgrp = (G == 64) ? rb : ((rb >> base) & ((1ull << (G & 63)) - 1ull));
     const bool all_reached = __popcll(rgrp) == N;
@@ -928,7 +952,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_agents(const Parti
 #pragma unroll
     for (int a = 0; a < N; ++a) rews[a] = __shfl(rew, base + a, 64);
     const R reward = sum_agents<R, N>(rews);
-    const bool done = (steps == p.max_steps) || all_reached;
+    const bool done = fin || (steps == p.max_steps) || all_reached;
 
     if (mine) reinterpret_cast<R *>(tick_ptr(p.reward_n, p.st_reward_n, t))[e * N + i] = rew;
     if (head) {
@@ -939,11 +963,12 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_agents(const Parti
     CM3_STAMP(5, false);
     // ---- same-launch re-initialisation -------------------------------------------------------------------------
     bool was_reset = false;
-    if (p.flags & CM3_FLAG_AUTO_RESET) {
+    if (auto_reset) {
       void *term_state = tick_ptr(p.term_state, p.st_term_state, t);
       void *term_obs = tick_ptr(p.term_obs_others, p.st_term_obs, t);
       if (__any(done)) {  // wave-uniform: the tile store needs every lane
         if (term_state && done && mine) reinterpret_cast<V4 *>(term_state)[(size_t)i * E + e] = si;
+        if (p.term_collisions && done && head) tick_ptr(p.term_collisions, p.st_term_coll, t)[e] = collisions;
         if (term_obs) {
           // terminal observations of the finished envs; rows of unfinished envs in the tile are not written out
           if (agent_ok) {
@@ -978,6 +1003,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_agents(const Parti
       }
     }
 
+    fin = done && !auto_reset;
     CM3_STAMP(6, false);
     // ---- per-tick stores ------------------------------------------------------------------------------------------
     if (mine) {
@@ -992,7 +1018,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_agents(const Parti
   // ---- live counters, once per launch -------------------------------------------------------------------------------
   if (head) {
     int2 m;
-    m.x = steps;
+    m.x = steps | (fin ? kFinishedBit : 0);
     m.y = collisions;
     reinterpret_cast<int2 *>(p.meta_out)[e] = m;
     if (episode != episode_in) p.episode[e] = (int32_t)episode;
@@ -1008,10 +1034,10 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_reset(const ParticlePar
   using G = ObsGeom<R, N>;
   __shared__ __attribute__((aligned(32))) R lds_all[WAVES][G::LDS_REALS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const size_t e0 = ((size_t)blockIdx.x * WAVES + wave) * 64;
+  const size_t e0 = (size_t)p.E0 + ((size_t)blockIdx.x * WAVES + wave) * 64;
   const size_t e = e0 + lane;
-  const bool active = e < (size_t)p.E;
-  const size_t ec = active ? e : (size_t)p.E - 1;
+  const bool active = e < (size_t)p.EN;
+  const size_t ec = active ? e : (size_t)p.EN - 1;
   const size_t E = (size_t)p.E;
   const bool sel = p.reset_mask ? (p.reset_mask[ec] != 0) : true;
   V4 s[N];
@@ -1037,7 +1063,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_reset(const ParticlePar
 #pragma unroll
     for (int i = 0; i < N; ++i) s[i] = sout4[(size_t)i * E + ec];
   }
-  store_obs_others_staged<R, N>(s, &lds_all[wave][0], lane, e0, p.E, reinterpret_cast<R *>(p.obs_others));
+  store_obs_others_staged<R, N>(s, &lds_all[wave][0], lane, e0, p.EN, reinterpret_cast<R *>(p.obs_others));
 }
 
 // ---- observe kernel (multi-goal_spread.py:145-154 after a state injection) -----------------------------
@@ -1047,14 +1073,14 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_observe(const ParticleP
   using G = ObsGeom<R, N>;
   __shared__ __attribute__((aligned(32))) R lds_all[WAVES][G::LDS_REALS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const size_t e0 = ((size_t)blockIdx.x * WAVES + wave) * 64;
+  const size_t e0 = (size_t)p.E0 + ((size_t)blockIdx.x * WAVES + wave) * 64;
   const size_t e = e0 + lane;
-  const size_t ec = e < (size_t)p.E ? e : (size_t)p.E - 1;
+  const size_t ec = e < (size_t)p.EN ? e : (size_t)p.EN - 1;
   V4 s[N];
   const V4 *sin4 = reinterpret_cast<const V4 *>(p.state_in);
 #pragma unroll
   for (int i = 0; i < N; ++i) s[i] = sin4[(size_t)i * p.E + ec];
-  store_obs_others_staged<R, N>(s, &lds_all[wave][0], lane, e0, p.E, reinterpret_cast<R *>(p.obs_others));
+  store_obs_others_staged<R, N>(s, &lds_all[wave][0], lane, e0, p.EN, reinterpret_cast<R *>(p.obs_others));
 }
 
 // ---- host side -------------------------------------------------------------------------------------------
@@ -1088,9 +1114,15 @@ static int fill_params(const cm3_particle_desc *d, const cm3_particle_bufs *b, P
   } else {
     CM3_REQUIRE(b->state_in, "observe: state_in is required");
   }
+  CM3_REQUIRE(d->env_offset >= 0 && d->env_count >= 0 && (int64_t)d->env_offset + d->env_count <= d->n_envs &&
+                  (d->env_count > 0 || d->env_offset == 0),
+              "env_offset / env_count must select a range inside [0, n_envs) (got %d / %d of %d)", d->env_offset,
+              d->env_count, d->n_envs);
   memset(&p, 0, sizeof(p));
   p.n_ticks = 1;
   p.E = d->n_envs;
+  p.E0 = d->env_offset;
+  p.EN = d->env_count > 0 ? d->env_offset + d->env_count : d->n_envs;
   p.max_steps = d->max_steps;
   p.flags = d->flags & ~CM3_FLAG_FUSED_TICKS;
   p.env_id_base = d->env_id_base;
@@ -1117,6 +1149,7 @@ static int fill_params(const cm3_particle_desc *d, const cm3_particle_bufs *b, P
   p.done = b->done;
   p.term_state = b->term_state;
   p.term_obs_others = b->term_obs_others;
+  p.term_collisions = b->term_collisions;
   p.reset_mask = mask;
   return CM3_OK;
 }
@@ -1124,7 +1157,7 @@ static int fill_params(const cm3_particle_desc *d, const cm3_particle_bufs *b, P
 template <typename R, int N, int WAVES>
 static int launch_one(const ParticleParams &p, ParticleOp op, hipStream_t stream) {
   const unsigned per_block = WAVES * 64;
-  const unsigned blocks = (unsigned)(((size_t)p.E + per_block - 1) / per_block);
+  const unsigned blocks = (unsigned)(((size_t)(p.EN - p.E0) + per_block - 1) / per_block);
   switch (op) {
     case kStep:
       if (p.n_ticks > 1)
@@ -1146,26 +1179,28 @@ static int launch_one(const ParticleParams &p, ParticleOp op, hipStream_t stream
 template <typename R, int N, int WAVES> static int launch_pairs(const ParticleParams &p, hipStream_t stream) {
   if constexpr (N >= 2) {
     const size_t envs_per_block = (size_t)WAVES * PairGeom<N>::EPW;
-    const unsigned blocks = (unsigned)(((size_t)p.E + envs_per_block - 1) / envs_per_block);
+    const unsigned blocks = (unsigned)(((size_t)(p.EN - p.E0) + envs_per_block - 1) / envs_per_block);
     constexpr bool kCanSplit = WAVES == 4 && sizeof(R) == 4 && WAVES * PairGeom<N>::EPW * N <= 64;
     bool split = false;
+    // the chip sees every chain of a rollout at once: the occupancy test counts the workgroups of all p.E envs
+    const size_t all_blocks = ((size_t)p.E + envs_per_block - 1) / envs_per_block;
     // pays only while the launch is at most one physics wave per SIMD (1024 on the chip): N = 4, us per launch without /
     // with the draw wave: 4096 envs 3.43 / 3.31; 16384 envs 5.31 / 6.14; N = 8, 4096 envs (4096 waves) 6.7 / 8.7
     if constexpr (kCanSplit)
       split = p.n_ticks == 1 && (p.flags & CM3_FLAG_GEN_ACTIONS) && (p.flags & (kFlagPregenRead | kFlagPregenWrite)) &&
-              (size_t)blocks * WAVES <= 1024;
+              all_blocks * WAVES <= 1024;
     if (p.n_ticks > 1) {
       hipLaunchKernelGGL((k_particle_step_pairs<R, N, WAVES, true>), dim3(blocks), dim3(WAVES * 64), 0, stream, p.state_in,
-                         p.goals_in, p.meta_in, (const int32_t *)p.episode, (const int32_t *)p.actions, p.E, p.flags, p);
+                         p.goals_in, p.meta_in, (const int32_t *)p.episode, (const int32_t *)p.actions, p.E, p.flags, p.E0, p.EN, p);
     } else if (split) {
       // a tick of cm3_particle_rollout_* with in-kernel actions: the extra wave draws the next launch's actions (SPLIT)
       if constexpr (kCanSplit)
         hipLaunchKernelGGL((k_particle_step_pairs<R, N, WAVES, false, true>), dim3(blocks), dim3((WAVES + 1) * 64), 0, stream,
                            p.state_in, p.goals_in, p.meta_in, (const int32_t *)p.episode, (const int32_t *)p.actions, p.E,
-                           p.flags, p);
+                           p.flags, p.E0, p.EN, p);
     } else {
       hipLaunchKernelGGL((k_particle_step_pairs<R, N, WAVES, false>), dim3(blocks), dim3(WAVES * 64), 0, stream, p.state_in,
-                         p.goals_in, p.meta_in, (const int32_t *)p.episode, (const int32_t *)p.actions, p.E, p.flags, p);
+                         p.goals_in, p.meta_in, (const int32_t *)p.episode, (const int32_t *)p.actions, p.E, p.flags, p.E0, p.EN, p);
     }
     CM3_HIP_CHECK(hipGetLastError());
     return CM3_OK;
@@ -1182,7 +1217,7 @@ constexpr size_t kPairsMaxEnvs = (size_t)1 << 14;
 template <typename R, int N, int WAVES> static int launch_agents(const ParticleParams &p, hipStream_t stream) {
   if constexpr (N >= 2) {
     const size_t envs_per_block = (size_t)WAVES * AgentGeom<N>::EPW;
-    const unsigned blocks = (unsigned)(((size_t)p.E + envs_per_block - 1) / envs_per_block);
+    const unsigned blocks = (unsigned)(((size_t)(p.EN - p.E0) + envs_per_block - 1) / envs_per_block);
     if (p.n_ticks > 1)
       hipLaunchKernelGGL((k_particle_step_agents<R, N, WAVES, true>), dim3(blocks), dim3(WAVES * 64), 0, stream, p);
     else
@@ -1277,6 +1312,7 @@ static int particle_rollout(const cm3_particle_desc *d, const cm3_particle_traj 
     b.done = t->done;
     b.term_state = t->term_state;
     b.term_obs_others = t->term_obs_others;
+    b.term_collisions = t->term_collisions;
     ParticleParams p;
     int rc = fill_params(d, &b, kStep, nullptr, p);
     if (rc != CM3_OK) return rc;
@@ -1290,6 +1326,7 @@ static int particle_rollout(const cm3_particle_desc *d, const cm3_particle_traj 
     p.st_done = t->done_stride;
     p.st_term_state = t->term_state_stride;
     p.st_term_obs = t->term_obs_others_stride;
+    p.st_term_coll = t->term_collisions_stride;
     return launch<R>(p, d->n_agents, kStep, (hipStream_t)stream);
   }
   for (int k = 0; k < n_ticks; ++k) {
@@ -1309,6 +1346,7 @@ static int particle_rollout(const cm3_particle_desc *d, const cm3_particle_traj 
     b.done = (uint8_t *)at(t->done, t->done_stride, k);
     b.term_state = at(t->term_state, t->term_state_stride, k);
     b.term_obs_others = at(t->term_obs_others, t->term_obs_others_stride, k);
+    b.term_collisions = (int32_t *)at(t->term_collisions, t->term_collisions_stride, k);
     ParticleParams p;
     int rc = fill_params(d, &b, kStep, nullptr, p);
     if (rc != CM3_OK) return rc;
@@ -1324,6 +1362,53 @@ static int particle_rollout(const cm3_particle_desc *d, const cm3_particle_traj 
     if (rc != CM3_OK) return rc;
   }
   return CM3_OK;
+}
+
+// Independent sub-batch chains (envs never interact): chain c = envs [c * chunk, min((c + 1) * chunk, E)) advances through
+// its n_ticks launches on streams[c]; streams[1..] are forked from / joined back into streams[0] with events, so the call
+// is ordered like one launch sequence on streams[0] -- eagerly, or as parallel branches of the hipGraph being captured on
+// streams[0].  The dependent-launch boundary of one chain (~1.5 us on MI355X) then overlaps the bodies of the others.
+// Every launch is still one tick of its envs; RNG keys are global env ids, so results do not depend on n_chains.
+template <typename R>
+static int particle_rollout_chains(const cm3_particle_desc *d, const cm3_particle_traj *t, int32_t n_ticks, int32_t n_chains,
+                                   void *const *streams) {
+  CM3_REQUIRE(d && t && streams, "null desc/traj/streams");
+  CM3_REQUIRE(n_chains >= 1 && n_chains <= 16, "n_chains must be in 1..16 (got %d)", n_chains);
+  CM3_REQUIRE(d->env_offset == 0 && d->env_count == 0, "chains split the whole batch: env_offset / env_count must be 0");
+  CM3_REQUIRE(d->n_envs > 0, "n_envs must be positive");
+  for (int c = 1; c < n_chains; ++c) CM3_REQUIRE(streams[c] && streams[c] != streams[0], "chains need distinct non-NULL streams");
+  // whole workgroups per chain: every mapping's workgroup covers a divisor of 256 consecutive envs
+  size_t chunk = ((size_t)d->n_envs + n_chains - 1) / n_chains;
+  chunk = (chunk + 255) / 256 * 256;
+  hipStream_t s0 = (hipStream_t)streams[0];
+  hipEvent_t fork = nullptr, join[16] = {nullptr};
+  int used = 0;
+  for (int c = 0; c < n_chains; ++c)
+    if ((size_t)c * chunk < (size_t)d->n_envs) used = c + 1;
+  int rc = CM3_OK;
+  if (used > 1) {
+    CM3_HIP_CHECK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+    CM3_HIP_CHECK(hipEventRecord(fork, s0));
+  }
+  for (int c = 0; c < used && rc == CM3_OK; ++c) {
+    hipStream_t sc = (hipStream_t)streams[c];
+    if (c > 0) CM3_HIP_CHECK(hipStreamWaitEvent(sc, fork, 0));
+    cm3_particle_desc dc = *d;
+    dc.env_offset = (int32_t)((size_t)c * chunk);
+    const size_t end = ((size_t)(c + 1) * chunk < (size_t)d->n_envs) ? (size_t)(c + 1) * chunk : (size_t)d->n_envs;
+    dc.env_count = (int32_t)(end - (size_t)dc.env_offset);
+    rc = particle_rollout<R>(&dc, t, n_ticks, sc);
+    if (c > 0 && rc == CM3_OK) {
+      CM3_HIP_CHECK(hipEventCreateWithFlags(&join[c], hipEventDisableTiming));
+      CM3_HIP_CHECK(hipEventRecord(join[c], sc));
+      CM3_HIP_CHECK(hipStreamWaitEvent(s0, join[c], 0));
+    }
+  }
+  // events may be destroyed once recorded / waited on: the runtime keeps what in-flight work still needs
+  if (fork) (void)hipEventDestroy(fork);
+  for (int c = 1; c < used; ++c)
+    if (join[c]) (void)hipEventDestroy(join[c]);
+  return rc;
 }
 
 }  // namespace cm3
@@ -1350,6 +1435,10 @@ int cm3_particle_observe_f32(const cm3_particle_desc *d, const cm3_particle_bufs
 int cm3_particle_rollout_f32(const cm3_particle_desc *d, const cm3_particle_traj *t, int32_t n, void *s) {
   return cm3::particle_rollout<float>(d, t, n, s);
 }
+int cm3_particle_rollout_chains_f32(const cm3_particle_desc *d, const cm3_particle_traj *t, int32_t n, int32_t n_chains,
+                                    void *const *streams) {
+  return cm3::particle_rollout_chains<float>(d, t, n, n_chains, streams);
+}
 #endif
 #ifdef CM3_PARTICLE_F64
 int cm3_particle_step_f64(const cm3_particle_desc *d, const cm3_particle_bufs *b, void *s) {
@@ -1363,6 +1452,10 @@ int cm3_particle_observe_f64(const cm3_particle_desc *d, const cm3_particle_bufs
 }
 int cm3_particle_rollout_f64(const cm3_particle_desc *d, const cm3_particle_traj *t, int32_t n, void *s) {
   return cm3::particle_rollout<double>(d, t, n, s);
+}
+int cm3_particle_rollout_chains_f64(const cm3_particle_desc *d, const cm3_particle_traj *t, int32_t n, int32_t n_chains,
+                                    void *const *streams) {
+  return cm3::particle_rollout_chains<double>(d, t, n, n_chains, streams);
 }
 #endif
 }

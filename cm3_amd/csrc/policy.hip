@@ -67,7 +67,9 @@ template <int N, bool BF16> __global__ void __launch_bounds__(256) k_policy_roll
   ActorB<N, BF16> b;
   actor_load_b<N, BF16>(q.packed, w, lane, b);
   const int2 meta = reinterpret_cast<const int2 *>(p.meta_in)[e];
-  int steps = meta.x, collisions = meta.y;
+  int steps = meta.x & ~kFinishedBit, collisions = meta.y;
+  bool fin = meta.x < 0;  // finished earlier and not reset since (particle.hip, kFinishedBit)
+  const bool auto_reset = (p.flags & CM3_FLAG_AUTO_RESET) != 0;
   uint32_t episode = (uint32_t)p.episode[e];
   const uint32_t episode_in = episode;
   if (part0) {
@@ -85,7 +87,7 @@ template <int N, bool BF16> __global__ void __launch_bounds__(256) k_policy_roll
   }
   __syncthreads();
 
-  const float kDt = 0.1f, kKeep = 1.0f - 0.25f, kDistMin = 0.15f + 0.15f;
+  const float kDt = 0.1f, kKeep = 1.0f - 0.25f;
 #pragma unroll 1
   for (int t = 0; t < p.n_ticks; ++t) {
     // ---- policy: forward pass, probabilities and the sampled action of row rl (alg_credit.py:113-122) -----------------
@@ -128,24 +130,25 @@ template <int N, bool BF16> __global__ void __launch_bounds__(256) k_policy_roll
     si.y = si.y + (Fy / 1.0f) * kDt;
     si.z = si.z + si.x * kDt;
     si.w = si.w + si.y * kDt;
-    steps += 1;
+    steps += fin ? 0 : 1;
     ns[rl][0] = si.x; ns[rl][1] = si.y; ns[rl][2] = si.z; ns[rl][3] = si.w;
     wave_lds_sync();  // the other agents of this env live in the same wave
 
     // ---- reward / reached / collisions (multi-goal_spread.py:114-143) ----------------------------------------------------------
     float rew;
+    bool reached;
     {
       const float dx = si.z - gl.x, dy = si.w - gl.y;
-      rew = 0.0f - sqrtf(dx * dx + dy * dy);
+      const float d2 = dx * dx + dy * dy;
+      rew = 0.0f - sqrtf(d2);
+      reached = d2 < Thresh<float>::kReach2;  // rew >= -0.05f (thresholds.h)
     }
-    const bool reached = rew >= -0.05f;
     int hits = 0;
 #pragma unroll
     for (int k = 0; k < N - 1; ++k) {
       const int j = k < i ? k : k + 1;
       const int rj = rl - i + j;
-      const float dx = ns[rj][2] - si.z, dy = ns[rj][3] - si.w;  // is_collision(a = j, agent = i)
-      if (sqrtf(dx * dx + dy * dy) < kDistMin) {
+      if (is_collision<float>(ns[rj][2] - si.z, ns[rj][3] - si.w)) {  // is_collision(a = j, agent = i)
         rew = rew - 1.0f;
         hits += 1;
       }
@@ -159,9 +162,9 @@ template <int N, bool BF16> __global__ void __launch_bounds__(256) k_policy_roll
       hit_sum += __shfl(hits, env_lane0 + a, 64);
       all_reached = all_reached && (__shfl((int)reached, env_lane0 + a, 64) != 0);
     }
-    collisions += hit_sum;
+    collisions += fin ? 0 : hit_sum;
     const float reward = sum_agents<float, N>(rews);
-    const bool done = (steps == p.max_steps) || all_reached;
+    const bool done = fin || (steps == p.max_steps) || all_reached;
     if (writer) reinterpret_cast<float *>(tick_ptr(p.reward_n, p.st_reward_n, t))[r] = rew;
     if (head_lane) {
       reinterpret_cast<float *>(tick_ptr(p.reward, p.st_reward, t))[e] = reward;
@@ -170,9 +173,10 @@ template <int N, bool BF16> __global__ void __launch_bounds__(256) k_policy_roll
 
     // ---- same-tick re-initialisation of finished episodes (CM3_FLAG_AUTO_RESET) ------------------------------------------------
     bool was_reset = false;
-    if ((p.flags & CM3_FLAG_AUTO_RESET) && done) {
+    if (auto_reset && done) {
       void *term_state = tick_ptr(p.term_state, p.st_term_state, t);
       void *term_obs = tick_ptr(p.term_obs_others, p.st_term_obs, t);
+      if (head_lane && p.term_collisions) tick_ptr(p.term_collisions, p.st_term_coll, t)[e] = collisions;
       if (writer && term_state) reinterpret_cast<V4 *>(term_state)[(size_t)i * E + e] = si;
       if (writer && term_obs) {
         V4 *o = reinterpret_cast<V4 *>(term_obs) + r * NO;
@@ -195,6 +199,7 @@ template <int N, bool BF16> __global__ void __launch_bounds__(256) k_policy_roll
       ns[rl][0] = si.x; ns[rl][1] = si.y; ns[rl][2] = si.z; ns[rl][3] = si.w;
       wave_lds_sync();
     }
+    fin = done && !auto_reset;
 
     // ---- trajectory stores + the LDS tile of the next tick ---------------------------------------------------------------------
     if (part0) {
@@ -222,7 +227,7 @@ template <int N, bool BF16> __global__ void __launch_bounds__(256) k_policy_roll
 
   if (head_lane) {
     int2 m;
-    m.x = steps;
+    m.x = steps | (fin ? kFinishedBit : 0);
     m.y = collisions;
     reinterpret_cast<int2 *>(p.meta_out)[e] = m;
     if (episode != episode_in) p.episode[e] = (int32_t)episode;
@@ -280,6 +285,8 @@ extern "C" int cm3_policy_rollout_f32(const cm3_particle_desc *d, const cm3_part
   b.done = t->done;
   b.term_state = t->term_state;
   b.term_obs_others = t->term_obs_others;
+  b.term_collisions = t->term_collisions;
+  CM3_REQUIRE(d->env_offset == 0 && d->env_count == 0, "the fused policy rollout covers the whole batch");
   cm3_particle_desc dd = *d;
   dd.flags &= CM3_FLAG_AUTO_RESET;
   PolicyParams q;
@@ -296,6 +303,7 @@ extern "C" int cm3_policy_rollout_f32(const cm3_particle_desc *d, const cm3_part
   q.p.st_done = t->done_stride;
   q.p.st_term_state = t->term_state_stride;
   q.p.st_term_obs = t->term_obs_others_stride;
+  q.p.st_term_coll = t->term_collisions_stride;
   q.obs_in = (const float *)t->obs_others;
   q.packed = (const float *)wt->packed;
   q.probs = probs;

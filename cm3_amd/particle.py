@@ -96,6 +96,7 @@ class VecParticleEnv(object):
         self._obs_others = [z(E, N, L), z(E, N, L)]
         self._term_state = None
         self._term_obs_others = None
+        self._term_collisions = None
         self._cur = 0
         self._desc = _lib.ParticleDesc()
         _fill_desc(self._desc, config_particle, N, prob_random, max_steps, E, seed, env_id_base, 0)
@@ -127,13 +128,16 @@ class VecParticleEnv(object):
         b.done = self._done[dst].data_ptr()
         b.term_state = _lib.ptr(self._term_state)
         b.term_obs_others = _lib.ptr(self._term_obs_others)
+        b.term_collisions = _lib.ptr(self._term_collisions)
         return b
 
     def enable_terminal_capture(self):
-        """Allocate term_state / term_obs_others so AUTO_RESET keeps the true terminal next-state."""
+        """Allocate term_state / term_obs_others / term_collisions so AUTO_RESET keeps the true terminal next-state
+        and the finished episode's collision count (both are overwritten by the re-initialisation otherwise)."""
         if self._term_state is None:
             self._term_state = torch.zeros_like(self._state[0])
             self._term_obs_others = torch.zeros_like(self._obs_others[0])
+            self._term_collisions = torch.zeros(self.E, dtype=torch.int32, device=self.device)
             self._step_bufs.clear()
 
     # ---- reference surface -----------------------------------------------------------------------
@@ -202,12 +206,27 @@ class VecParticleEnv(object):
 
     @property
     def collisions(self):
-        """[E] scenario.collisions (multi-goal_spread.py:93,137; read at train_onpolicy.py:356)."""
+        """[E] scenario.collisions (multi-goal_spread.py:93,137; read at train_onpolicy.py:356).  Without auto_reset the
+        count freezes when the env's episode ends (the reference stops stepping there), so after an episode-synchronous
+        rollout this is every env's per-episode value."""
         return self._meta[:, 1]
 
     @property
     def steps(self):
-        return self._meta[:, 0]
+        """[E] MultiAgentEnv.steps (environment.py:93); frozen once the episode has ended (no auto_reset)."""
+        return self._meta[:, 0] & 0x7FFFFFFF
+
+    @property
+    def finished(self):
+        """bool [E]: the env's episode has ended and it has not been reset since (always False under auto_reset).
+        Stored as the sign bit of the step word (include/cm3_amd.h, meta)."""
+        return self._meta[:, 0] < 0
+
+    @property
+    def terminal_collisions(self):
+        """int32 [E]: scenario.collisions of the episode that ended in the most recent step() for envs re-initialised by
+        auto_reset (needs enable_terminal_capture())."""
+        return self._term_collisions
 
     @property
     def episode(self):

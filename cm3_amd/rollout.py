@@ -45,12 +45,57 @@ CHECKERS_ORDER = ("grid", "vec", "obs_others", "obs_self_t", "obs_self_v", "acti
                   "next_obs_self_v", "done", "goals")
 
 
-def _valid_from_done(done_u8):
+def _valid_from_done(done_u8, finished0=None):
     """valid[t, e] = env e had not finished before tick t (episode-synchronous collection: an env that
-    finishes early stops producing transitions, like the reference's `while not done`)."""
+    finishes early stops producing transitions, like the reference's `while not done`).  finished0 (bool [E]):
+    envs that had already finished when this collection started (collect(reset=False) on an env without
+    auto-reset) produce no valid transition at all."""
     d = done_u8.to(torch.int32)
     finished_before = torch.cumsum(d, dim=0) - d
-    return finished_before == 0
+    valid = finished_before == 0
+    if finished0 is not None:
+        valid = valid & ~finished0.unsqueeze(0)
+    return valid
+
+
+def _copy_pairs(pairs, stream):
+    """(dst, src) tensor pairs: ONE cm3_copy_list launch per 8 regions when every region is 16-byte sized / aligned,
+    torch copies otherwise."""
+    ok = all((d.numel() * d.element_size()) % 16 == 0 and d.data_ptr() % 16 == 0 and s_.data_ptr() % 16 == 0
+             and d.is_contiguous() and s_.is_contiguous() and d.numel() * d.element_size() == s_.numel() * s_.element_size()
+             for d, s_ in pairs)
+    if ok:
+        for k in range(0, len(pairs), 8):
+            _lib.copy_list(pairs[k:k + 8], stream)
+    else:
+        for d, s_ in pairs:
+            d.copy_(s_)
+
+
+class _ActorGraphCache(object):
+    """One captured (actor launch, step launch) x T graph per rollout object.  The key is the policy OBJECT (a strong
+    reference: `id()` of a collected actor can be reused); epsilon is not part of it -- the actor launches read it from
+    a device float that collect() refreshes, so the annealing of train_onpolicy.py:369 never triggers a re-capture."""
+
+    def __init__(self, device):
+        self.device = device
+        self.graph = None
+        self.policy = None
+        self.eps = torch.zeros(1, dtype=torch.float32, device=device)
+
+    def launch(self, lib, policy, epsilon, capture, stream):
+        self.eps.fill_(float(epsilon))          # ordered before the replay on the same stream
+        if self.graph is None or self.policy is not policy:
+            self.destroy(lib)
+            self.graph = _lib.capture_graph(self.device, capture)
+            self.policy = policy
+        _lib.check(lib.cm3_graph_launch(self.graph, stream))
+
+    def destroy(self, lib):
+        if self.graph is not None:
+            torch.cuda.synchronize(self.device)     # a previous replay may still be in flight
+            lib.cm3_graph_destroy(self.graph)
+            self.graph = self.policy = None
 
 
 class ParticleRollout(object):
@@ -62,13 +107,20 @@ class ParticleRollout(object):
         next-state/obs are captured per tick, goals are recorded per slot; every transition is valid.
     """
 
-    def __init__(self, env, n_ticks=None, use_graph=True, fused=False):
+    def __init__(self, env, n_ticks=None, use_graph=True, fused=False, n_chains=1):
         self.env = env
         self.T = int(n_ticks or env.max_steps)
         self.use_graph = bool(use_graph)
         # fused: the random-action branch runs all T ticks in ONE launch (CM3_FLAG_FUSED_TICKS; state in
         # registers, identical results).  Policy-driven collection always launches once per tick.
         self.fused = bool(fused)
+        # n_chains > 1: the random-action branch advances n_chains independent sub-batches of envs on their own
+        # streams (parallel branches of the captured hipGraph): one chain's launch boundary overlaps the others'
+        # kernels.  Identical trajectories (cm3_particle_rollout_chains_*).
+        self.n_chains = int(n_chains)
+        if not (1 <= self.n_chains <= 16):
+            raise Cm3Error("n_chains must be in 1..16")
+        self._chain_streams = [torch.cuda.Stream(device=env.device) for _ in range(self.n_chains - 1)]
         E, N, L, T, dev, dt = env.E, env.n, env.L, self.T, env.device, env.dtype
         z = lambda *s, d=dt: torch.zeros(*s, dtype=d, device=dev)  # noqa: E731
         self.state = z(T + 1, N, E, 4)
@@ -82,10 +134,13 @@ class ParticleRollout(object):
             self.goals = z(T + 1, N, E, 2)
             self.term_state = z(T, N, E, 4)
             self.term_obs_others = z(T, E, N, L)
+            self.term_collisions = z(T, E, d=torch.int32)
         else:
             self.goals = None
-            self.term_state = self.term_obs_others = None
+            self.term_state = self.term_obs_others = self.term_collisions = None
         self._graph = None
+        self._actor_graph = _ActorGraphCache(dev)
+        self._finished0 = None
         self._lib = _lib.lib()
         self.collected = False
 
@@ -119,25 +174,26 @@ class ParticleRollout(object):
             t.term_state_stride = N * E * 4 * es
             t.term_obs_others = self.term_obs_others[t0].data_ptr()
             t.term_obs_others_stride = E * N * L * es
+            t.term_collisions = self.term_collisions[t0].data_ptr()
+            t.term_collisions_stride = E * 4
         return t
 
-    def _enqueue(self, t0, n, flags, stream=None):
+    def _enqueue(self, t0, n, flags, stream=None, chains=False):
         env = self.env
         env._desc.flags = flags
         traj = self._traj(t0)
-        fn = getattr(self._lib, "cm3_particle_rollout_" + env._suffix)
-        _lib.check(fn(ctypes.byref(env._desc), ctypes.byref(traj), int(n),
-                      env._stream() if stream is None else stream))
+        stream = env._stream() if stream is None else stream
+        if chains and self.n_chains > 1:
+            fn = getattr(self._lib, "cm3_particle_rollout_chains_" + env._suffix)
+            streams = (ctypes.c_void_p * self.n_chains)(stream, *[s.cuda_stream for s in self._chain_streams])
+            _lib.check(fn(ctypes.byref(env._desc), ctypes.byref(traj), int(n), self.n_chains, streams))
+        else:
+            fn = getattr(self._lib, "cm3_particle_rollout_" + env._suffix)
+            _lib.check(fn(ctypes.byref(env._desc), ctypes.byref(traj), int(n), stream))
 
     def _copy(self, pairs):
         """(dst, src) tensor pairs: one cm3_copy_list launch when every region is 16-byte sized / aligned."""
-        ok = all((d.numel() * d.element_size()) % 16 == 0 and d.data_ptr() % 16 == 0 and s_.data_ptr() % 16 == 0
-                 and d.is_contiguous() and s_.is_contiguous() for d, s_ in pairs)
-        if ok:
-            _lib.copy_list(pairs, self.env._stream())
-        else:
-            for d, s_ in pairs:
-                d.copy_(s_)
+        _copy_pairs(pairs, self.env._stream())
 
     def _load_slot0(self):
         env = self.env
@@ -163,6 +219,7 @@ class ParticleRollout(object):
             actor.enqueue(env.E, self.obs_others[t], self.state[t], goals, env._meta, env._episode, self.actions[t],
                           epsilon, stream=stream, env_id_base=env.env_id_base)
             self._enqueue(t, 1, base_flags, stream)
+        env._desc.flags = base_flags
 
     def collect(self, policy=None, reset=None, epsilon=0.0):
         """Runs T ticks.  policy None = the reference's random-action branch (train_onpolicy.py:305-307,
@@ -174,18 +231,21 @@ class ParticleRollout(object):
             reset = not self.auto_reset
         if reset:
             env.reset()
+        # envs that are already finished (no auto-reset, collect(reset=False) after their episode ended) stay invalid
+        self._finished0 = None if (self.auto_reset or reset) else env.finished.clone()
         self._load_slot0()
         base = (FLAG_AUTO_RESET if self.auto_reset else 0) | env.kernel_flags
         if policy is None:
             flags = base | FLAG_GEN_ACTIONS
             if self.fused:
-                self._enqueue(0, self.T, flags | _lib.FLAG_FUSED_TICKS)
+                self._enqueue(0, self.T, flags | _lib.FLAG_FUSED_TICKS, chains=True)
             elif self.use_graph:
                 if self._graph is None:
-                    self._graph = _lib.capture_graph(env.device, lambda s: self._enqueue(0, self.T, flags, s))
+                    self._graph = _lib.capture_graph(env.device,
+                                                     lambda s: self._enqueue(0, self.T, flags, s, chains=True))
                 _lib.check(self._lib.cm3_graph_launch(self._graph, env._stream()))
             else:
-                self._enqueue(0, self.T, flags)
+                self._enqueue(0, self.T, flags, chains=True)
         elif hasattr(policy, "enqueue") and hasattr(policy, "act"):      # on-device actor (cm3_amd.actor)
             if env.dtype != torch.float32:
                 raise Cm3Error("the device actor reads float32 env buffers")
@@ -200,14 +260,9 @@ class ParticleRollout(object):
                 _lib.check(self._lib.cm3_policy_rollout_f32(ctypes.byref(env._desc), ctypes.byref(traj), ctypes.byref(ad),
                                                             ctypes.byref(policy._wt), None, 0, self.T, env._stream()))
             elif self.use_graph:
-                key = ("actor", id(policy), float(epsilon))
-                if getattr(self, "_actor_graph_key", None) != key:
-                    if getattr(self, "_actor_graph", None) is not None:
-                        self._lib.cm3_graph_destroy(self._actor_graph)
-                    self._actor_graph = _lib.capture_graph(
-                        env.device, lambda s: self._enqueue_actor_rollout(policy, epsilon, base, s))
-                    self._actor_graph_key = key
-                _lib.check(self._lib.cm3_graph_launch(self._actor_graph, env._stream()))
+                cache = self._actor_graph
+                cache.launch(self._lib, policy, epsilon,
+                             lambda s: self._enqueue_actor_rollout(policy, cache.eps, base, s), env._stream())
             else:
                 self._enqueue_actor_rollout(policy, epsilon, base, env._stream())
         else:
@@ -222,11 +277,10 @@ class ParticleRollout(object):
 
     def close(self):
         if self._graph is not None:
+            torch.cuda.synchronize(self.env.device)
             self._lib.cm3_graph_destroy(self._graph)
             self._graph = None
-        if getattr(self, "_actor_graph", None) is not None:
-            self._lib.cm3_graph_destroy(self._actor_graph)
-            self._actor_graph = None
+        self._actor_graph.destroy(self._lib)
 
     # ---- views --------------------------------------------------------------------------------------------
     @property
@@ -234,7 +288,16 @@ class ParticleRollout(object):
         """bool [T, E]"""
         if self.auto_reset:
             return torch.ones(self.T, self.env.E, dtype=torch.bool, device=self.env.device)
-        return _valid_from_done(self.done)
+        return _valid_from_done(self.done, self._finished0)
+
+    def episode_is_bad(self):
+        """The reference's dual-buffer flag `scenario.collisions != 0` per finished episode (train_onpolicy.py:356).
+        Episode-synchronous mode: bool [E] (the env's collision counter froze when its episode ended; envs that have
+        not finished yet report their running count).  Continuous mode: bool [T, E], meaningful where ``done`` is set
+        -- the count of the episode that ended at that tick (captured before the same-launch reset zeroes it)."""
+        if self.auto_reset:
+            return (self.term_collisions != 0) & self.done.bool()
+        return self.env.collisions != 0
 
     def episode_returns(self):
         """(reward_global [E], reward_local [E,N]) accumulated over each env's episode
@@ -312,13 +375,23 @@ class ParticleRollout(object):
 
 class CheckersRollout(object):
     """T-tick trajectory over a VecCheckersEnv (16-column transitions, train_onpolicy.py:336).
-    Episode-synchronous (the env is reset at the start; transitions after `done` are invalid)."""
+
+    env.auto_reset False: episode-synchronous -- the env is reset at the start of every collect(); transitions of an
+        env after its `done` are flagged invalid (one reference episode per env).
+    env.auto_reset True: continuous -- finished envs restart inside the launch (CM3_FLAG_AUTO_RESET); slot t+1 then
+        holds the FRESH episode's observation, the true terminal next_* of the transition are captured per tick
+        (term_*; the reference stores them before it resets, train_onpolicy.py:336-347), the goals in effect are
+        recorded per slot (they change when a single-agent env restarts, :288-291), and `actions_prev` of the first
+        transition of an episode is zeros (:295).  Every transition is valid; collect() continues where the previous
+        one stopped.
+    """
 
     def __init__(self, env, n_ticks=None, use_graph=True, fused=False):
         self.env = env
         self.T = int(n_ticks or env.max_steps)
         self.use_graph = bool(use_graph)
         self.fused = bool(fused)      # random-action branch in ONE launch (CM3_FLAG_FUSED_TICKS; fast kernel only)
+        self.auto_reset = bool(env.auto_reset)
         self._graph = None
         E, N, T, dev = env.E, env.n, self.T, env.device
         z = lambda *s, d: torch.zeros(*s, dtype=d, device=dev)  # noqa: E731
@@ -333,6 +406,20 @@ class CheckersRollout(object):
         self.local_rewards = z(T, E, N, d=torch.float64)
         self.reward = z(T, E, d=torch.float64)
         self.done = z(T, E, d=torch.uint8)
+        self.prev0 = z(E, N, d=torch.int32)                    # actions_prev of slot 0 (zeros at an episode start)
+        if self.auto_reset:
+            self._term_grid_raw = z(T, E, env.grid_stride, d=torch.int8)
+            self._term_obst_raw = z(T, E, env.obst_stride, d=torch.int8)
+            self.term_grid = env.grid_view(self._term_grid_raw)
+            self.term_obs_self_t = env.obst_view(self._term_obst_raw)
+            self.term_vec = z(T, E, N, 4, d=torch.int32)
+            self.term_obs_others = z(T, E, N, env.Lo, d=torch.float64)
+            self.term_obs_self_v = z(T, E, N, 4, d=torch.float64)
+            self.goal_slots = z(T + 1, E, N, d=torch.uint8)
+        else:
+            self.goal_slots = None
+        self._started = False
+        self._actor_graph = _ActorGraphCache(dev)
         self._lib = _lib.lib()
 
     def _bufs(self, t):
@@ -346,6 +433,11 @@ class CheckersRollout(object):
         b.obs_self_t, b.obs_self_v = self._obst_raw[t + 1].data_ptr(), self.obs_self_v[t + 1].data_ptr()
         b.local_rewards, b.reward, b.done = (self.local_rewards[t].data_ptr(), self.reward[t].data_ptr(),
                                              self.done[t].data_ptr())
+        if self.auto_reset:
+            b.term_grid, b.term_vec = self._term_grid_raw[t].data_ptr(), self.term_vec[t].data_ptr()
+            b.term_obs_others = self.term_obs_others[t].data_ptr()
+            b.term_obs_self_t, b.term_obs_self_v = self._term_obst_raw[t].data_ptr(), self.term_obs_self_v[t].data_ptr()
+            b.goals_next = self.goal_slots[t + 1].data_ptr()
         return b
 
     def _traj(self):
@@ -364,84 +456,139 @@ class CheckersRollout(object):
         t.local_rewards, t.local_rewards_stride = slot(self.local_rewards)
         t.reward, t.reward_stride = slot(self.reward)
         t.done, t.done_stride = slot(self.done)
+        if self.auto_reset:
+            t.term_grid, t.term_grid_slot_stride = slot(self._term_grid_raw)
+            t.term_vec, t.term_vec_stride = slot(self.term_vec)
+            t.term_obs_others, t.term_obs_others_stride = slot(self.term_obs_others)
+            t.term_obs_self_t, t.term_obs_self_t_slot_stride = slot(self._term_obst_raw)
+            t.term_obs_self_v, t.term_obs_self_v_stride = slot(self.term_obs_self_v)
+            t.goals_slots, t.goals_slots_stride = slot(self.goal_slots)
         return t
+
+    def _base_flags(self):
+        return FLAG_AUTO_RESET if self.auto_reset else 0
 
     def _enqueue_random(self, stream, fused):
         env = self.env
-        env._desc.flags = FLAG_GEN_ACTIONS | (_lib.FLAG_FUSED_TICKS if fused else 0)
+        env._desc.flags = self._base_flags() | FLAG_GEN_ACTIONS | (_lib.FLAG_FUSED_TICKS if fused else 0)
         traj = self._traj()
         _lib.check(self._lib.cm3_checkers_rollout(ctypes.byref(env._desc), ctypes.byref(traj), self.T, stream))
         env._desc.flags = 0
 
     def _enqueue_actor_rollout(self, actor, epsilon, stream):
         """T x (actor launch, step launch) on `stream`: the policy reads trajectory slot t (+ actions[t-1] as
-        actions_prev, zeros at t = 0: train_onpolicy.py:295,345) and writes actions[t]; the step kernel consumes them and
-        writes slot t+1 (train_onpolicy.py:309-321 without leaving the device)."""
+        actions_prev -- prev0 at t = 0, zeros where the previous tick ended an episode: train_onpolicy.py:295,345) and
+        writes actions[t]; the step kernel consumes them and writes slot t+1 (train_onpolicy.py:309-321 without leaving
+        the device)."""
         env = self.env
-        env._desc.flags = 0
         for t in range(self.T):
-            actor.enqueue(env.E, self._obst_raw[t], env.obst_stride, self.obs_self_v[t], self.obs_others[t], env._goals,
-                          self.actions[t - 1] if t > 0 else None, env._steps, env._episode, self.actions[t], epsilon,
-                          stream=stream, env_id_base=env._desc.env_id_base)
+            goals = self.goal_slots[t] if self.auto_reset else env._goals
+            actor.enqueue(env.E, self._obst_raw[t], env.obst_stride, self.obs_self_v[t], self.obs_others[t], goals,
+                          self.actions[t - 1] if t > 0 else self.prev0, env._steps, env._episode, self.actions[t], epsilon,
+                          stream=stream, env_id_base=env._desc.env_id_base,
+                          prev_done=self.done[t - 1] if (t > 0 and self.auto_reset) else None)
+            env._desc.flags = self._base_flags()
             b = self._bufs(t)
             _lib.check(self._lib.cm3_checkers_step(ctypes.byref(env._desc), ctypes.byref(b), stream))
+        env._desc.flags = 0
 
-    def collect(self, goals, policy=None, epsilon=0.0):
-        """goals: one-hot [N,2] / [E,N,2] (train_onpolicy.py:287-293).  policy None = uniform random actions
-        drawn in-kernel; a cm3_amd.actor.CheckersActor = the on-device policy (actor and step launches alternate inside
-        one hipGraph); else policy(actions_prev, obs_others, obs_self_t, obs_self_v, goals) -> [E,N] on the host."""
+    def _load_slot0(self):
+        """slot 0 <- the env's current observation (after a reset, or where the previous collect() stopped)."""
         env = self.env
-        (grid, vec), oo, ot, ov, _ = env.reset(goals)
-        self.grid[0].copy_(grid)
-        self.vec[0].copy_(vec)
-        self.obs_others[0].copy_(oo)
-        self.obs_self_t[0].copy_(ot)
-        self.obs_self_v[0].copy_(ov)
+        s = env._slots[env._cur]
+        pairs = [(self._grid_raw[0], s["grid_raw"]), (self._obst_raw[0], s["obs_self_t_raw"]), (self.vec[0], s["vec"]),
+                 (self.obs_others[0], s["obs_others"]), (self.obs_self_v[0], s["obs_self_v"])]
+        if self.goal_slots is not None:
+            pairs.append((self.goal_slots[0], env._goals))
+        _copy_pairs(pairs, env._stream())
+
+    def _store_back(self):
+        """the env's current-observation buffers <- slot T, so that get_obs() / CheckersActor.act(env) / the next
+        collect() see the state the rollout left (the compact live state is advanced in place by the launches)."""
+        env, T = self.env, self.T
+        s = env._slots[env._cur]
+        _copy_pairs([(s["grid_raw"], self._grid_raw[T]), (s["obs_self_t_raw"], self._obst_raw[T]), (s["vec"], self.vec[T]),
+                     (s["obs_others"], self.obs_others[T]), (s["obs_self_v"], self.obs_self_v[T]),
+                     (s["actions"], self.actions[T - 1])], env._stream())
+        # actions_prev of the next collect()'s first transition: the last actions, zeros where that tick ended an episode
+        keep = (self.done[self.T - 1] == 0).unsqueeze(1)
+        self._next_prev0 = torch.where(keep, self.actions[self.T - 1], torch.zeros_like(self.actions[0]))
+
+    def collect(self, goals=None, policy=None, epsilon=0.0, reset=None):
+        """goals: one-hot [N,2] / [E,N,2] (train_onpolicy.py:287-293); needed whenever the env is reset.
+        policy None = uniform random actions drawn in-kernel; a cm3_amd.actor.CheckersActor = the on-device policy (actor
+        and step launches alternate inside one hipGraph); else policy(actions_prev, obs_others, obs_self_t, obs_self_v,
+        goals) -> [E,N] on the host.  reset: None -> always for an episode-synchronous env, only the first time for a
+        continuous (auto-reset) one."""
+        env = self.env
+        if reset is None:
+            reset = (not self.auto_reset) or (not self._started)
+        if reset:
+            if goals is None:
+                raise Cm3Error("collect() resets the env here and needs goals")
+            env.reset(goals)
+            self.prev0.zero_()
+        elif self._started:
+            self.prev0.copy_(self._next_prev0)
+        self._started = True
+        self._load_slot0()
         self.goals_onehot = env.goals.clone()
+        stream = env._stream()
         if policy is None:
             # random-action branch (train_onpolicy.py:305-307): cm3_checkers_rollout -- one fused launch, or T step
             # launches bound to their trajectory slots and replayed as one hipGraph
             if self.fused:
-                self._enqueue_random(env._stream(), True)
+                self._enqueue_random(stream, True)
             elif self.use_graph:
                 if self._graph is None:
                     self._graph = _lib.capture_graph(env.device, lambda st: self._enqueue_random(st, False))
-                _lib.check(self._lib.cm3_graph_launch(self._graph, env._stream()))
+                _lib.check(self._lib.cm3_graph_launch(self._graph, stream))
             else:
-                self._enqueue_random(env._stream(), False)
-            return self
-        if hasattr(policy, "enqueue") and hasattr(policy, "act"):            # on-device actor
+                self._enqueue_random(stream, False)
+        elif hasattr(policy, "enqueue") and hasattr(policy, "act"):            # on-device actor
             if self.use_graph:
-                key = (id(policy), float(epsilon))
-                if getattr(self, "_actor_graph_key", None) != key:
-                    if getattr(self, "_actor_graph", None) is not None:
-                        self._lib.cm3_graph_destroy(self._actor_graph)
-                    self._actor_graph = _lib.capture_graph(
-                        env.device, lambda st: self._enqueue_actor_rollout(policy, epsilon, st))
-                    self._actor_graph_key = key
-                _lib.check(self._lib.cm3_graph_launch(self._actor_graph, env._stream()))
+                cache = self._actor_graph
+                cache.launch(self._lib, policy, epsilon,
+                             lambda st: self._enqueue_actor_rollout(policy, cache.eps, st), stream)
             else:
-                self._enqueue_actor_rollout(policy, epsilon, env._stream())
-            return self
-        env._desc.flags = 0
-        for t in range(self.T):                                              # host policy: one call per tick
-            prev = self.actions[t - 1] if t > 0 else torch.zeros_like(self.actions[0])
-            a = policy(prev, self.obs_others[t], self.obs_self_t[t], self.obs_self_v[t], self.goals_onehot)
-            self.actions[t].copy_(torch.as_tensor(a, device=env.device).reshape(env.E, env.n))
-            b = self._bufs(t)
-            _lib.check(self._lib.cm3_checkers_step(ctypes.byref(env._desc), ctypes.byref(b), env._stream()))
+                self._enqueue_actor_rollout(policy, epsilon, stream)
+        else:
+            for t in range(self.T):                                              # host policy: one call per tick
+                a = policy(self.actions_prev_at(t), self.obs_others[t], self.obs_self_t[t], self.obs_self_v[t],
+                           self.goals_at(t))
+                self.actions[t].copy_(torch.as_tensor(a, device=env.device).reshape(env.E, env.n))
+                env._desc.flags = self._base_flags()
+                b = self._bufs(t)
+                _lib.check(self._lib.cm3_checkers_step(ctypes.byref(env._desc), ctypes.byref(b), stream))
+            env._desc.flags = 0
+        self._store_back()
         return self
+
+    def actions_prev_at(self, t):
+        """int32 [E,N]: the actions_prev fed at tick t (train_onpolicy.py:295,345)."""
+        if t == 0:
+            return self.prev0
+        if not self.auto_reset:
+            return self.actions[t - 1]
+        return torch.where((self.done[t - 1] == 0).unsqueeze(1), self.actions[t - 1], torch.zeros_like(self.actions[0]))
+
+    def goals_at(self, t):
+        """one-hot [E,N,2] goals in effect at tick t."""
+        if self.goal_slots is None:
+            return self.goals_onehot
+        return torch.nn.functional.one_hot(self.goal_slots[t].long(), 2)
 
     def close(self):
         if self._graph is not None:
+            torch.cuda.synchronize(self.env.device)
             self._lib.cm3_graph_destroy(self._graph)
             self._graph = None
-        if getattr(self, "_actor_graph", None) is not None:
-            self._lib.cm3_graph_destroy(self._actor_graph)
-            self._actor_graph = self._actor_graph_key = None
+        self._actor_graph.destroy(self._lib)
 
     @property
     def valid(self):
+        if self.auto_reset:
+            return torch.ones(self.T, self.env.E, dtype=torch.bool, device=self.env.device)
         return _valid_from_done(self.done)
 
     def valid_indices(self):
@@ -452,6 +599,16 @@ class CheckersRollout(object):
              "local_rewards", "next_grid", "next_vec", "next_obs_others", "next_obs_self_t", "next_obs_self_v",
              "done", "goals")
 
+    def _next(self, name, tt, ee):
+        """next_<name> of transitions (tt, ee): slot t+1, or the captured terminal observation where the env restarted
+        in the same launch (continuous mode)."""
+        nxt = getattr(self, name)[tt + 1, ee]
+        if self.auto_reset:
+            term = getattr(self, "term_" + name)[tt, ee]
+            d = self.done[tt, ee].bool().view(-1, *([1] * (nxt.dim() - 1)))
+            nxt = torch.where(d, term, nxt)
+        return nxt
+
     def as_reference_batch(self, tt=None, ee=None, numpy=True):
         """16 columns equal to np.stack(batch[:, k]) of alg_credit_checkers.process_batch
         (alg_credit_checkers.py:427-444); integer-valued columns are cast to the reference's float64."""
@@ -461,17 +618,22 @@ class CheckersRollout(object):
         tt = torch.as_tensor(tt, device=dev, dtype=torch.long)
         ee = torch.as_tensor(ee, device=dev, dtype=torch.long)
         f = lambda x: x.to(torch.float64)  # noqa: E731
-        prev = torch.where((tt > 0).view(-1, 1), self.actions[(tt - 1).clamp(min=0), ee],
-                           torch.zeros_like(self.actions[0, ee]))       # actions_prev starts at zeros (:295)
+        prev = self.actions[(tt - 1).clamp(min=0), ee]
+        if self.auto_reset:                                            # a fresh episode starts from zeros (:295)
+            fresh = self.done[(tt - 1).clamp(min=0), ee].bool().view(-1, 1)
+            prev = torch.where(fresh, torch.zeros_like(prev), prev)
+        prev = torch.where((tt > 0).view(-1, 1), prev, self.prev0[ee])
+        goals = (self.goals_onehot[ee] if self.goal_slots is None
+                 else torch.nn.functional.one_hot(self.goal_slots[tt, ee].long(), 2))
         cols = dict(
             grid=f(self.grid[tt, ee]), vec=f(self.vec[tt, ee]), obs_others=self.obs_others[tt, ee],
             obs_self_t=f(self.obs_self_t[tt, ee]), obs_self_v=self.obs_self_v[tt, ee],
             actions_prev=prev, actions=self.actions[tt, ee], reward=self.reward[tt, ee],
             local_rewards=self.local_rewards[tt, ee],
-            next_grid=f(self.grid[tt + 1, ee]), next_vec=f(self.vec[tt + 1, ee]),
-            next_obs_others=self.obs_others[tt + 1, ee], next_obs_self_t=f(self.obs_self_t[tt + 1, ee]),
-            next_obs_self_v=self.obs_self_v[tt + 1, ee], done=self.done[tt, ee].bool(),
-            goals=self.goals_onehot[ee])
+            next_grid=f(self._next("grid", tt, ee)), next_vec=f(self._next("vec", tt, ee)),
+            next_obs_others=self._next("obs_others", tt, ee), next_obs_self_t=f(self._next("obs_self_t", tt, ee)),
+            next_obs_self_v=self._next("obs_self_v", tt, ee), done=self.done[tt, ee].bool(),
+            goals=goals)
         if numpy:
             cols = {k: v.detach().cpu().numpy() for k, v in cols.items()}
         return cols

@@ -40,14 +40,30 @@ def local_moments(x, valid=None):
                         torch.tensor(float(x64.numel()), dtype=torch.float64, device=x.device)])
 
 
+def gather_moments(m, group=None):
+    """THE collective of the path: this rank's float64 (sum, sum of squares, count) -> float64 [world * 3], the triples
+    of all ranks in rank order (one all_gather_into_tensor of 24 bytes per rank; RCCL over xGMI with backend "nccl").
+    Returns (parts, n_parts); without a process group (or with one rank) it is the identity.  A "gloo" group whose
+    tensors live on the GPU is staged through the host (gloo has no device all-gather)."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return m, 1
+    world = dist.get_world_size(group)
+    m = m.contiguous()
+    if m.device.type == "cuda" and dist.get_backend(group) == "gloo":
+        host = torch.empty(world * 3, dtype=torch.float64)
+        dist.all_gather_into_tensor(host, m.cpu(), group=group)
+        return host.to(m.device), world
+    parts = torch.empty(world * 3, dtype=torch.float64, device=m.device)
+    dist.all_gather_into_tensor(parts, m, group=group)
+    return parts, world
+
+
 def global_moments(x, valid=None, group=None):
     """(mean, std, count) over all ranks.  One all_gather_into_tensor of 3 float64 per rank; the per-rank
     triples are summed in rank order (deterministic, identical on every rank)."""
     m = local_moments(x, valid)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        world = dist.get_world_size(group)
-        gathered = torch.empty(world * 3, dtype=torch.float64, device=m.device)
-        dist.all_gather_into_tensor(gathered, m.contiguous(), group=group)
+    gathered, world = gather_moments(m, group)
+    if world > 1:
         parts = gathered.view(world, 3)
         tot = parts[0].clone()
         for r in range(1, world):
@@ -63,7 +79,9 @@ def global_moments(x, valid=None, group=None):
 def normalize_advantages(adv, valid=None, eps=1e-8, group=None):
     """A_hat = (A - mean) / (std + eps) with batch-wide (all ranks) mean / std; invalid entries -> 0."""
     mean, std, _ = global_moments(adv, valid, group)
-    out = (adv - mean.to(adv.dtype)) / (std.to(adv.dtype) + eps)
+    # one expression for the host helper and cm3_normalize_* (csrc/advantage.hip): the float64 statistics are rounded to
+    # the working precision once, then one IEEE subtraction and one division per element
+    out = (adv - mean.to(adv.dtype)) / (std + eps).to(adv.dtype)
     if valid is not None:
         v = valid
         while v.dim() < out.dim():
@@ -112,11 +130,7 @@ def normalized_returns(reward, done, valid=None, gamma=0.99, eps=1e-8, group=Non
     _lib.check(getattr(lib, "cm3_returns_moments_" + suffix)(
         x.data_ptr(), d8.data_ptr(), _lib.ptr(v8), out.data_ptr(), scratch.data_ptr(), moments.data_ptr(),
         T, E, C, float(gamma), stream))
-    parts, n_parts = moments, 1
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        n_parts = dist.get_world_size(group)
-        parts = torch.empty(n_parts * 3, dtype=torch.float64, device=x.device)
-        dist.all_gather_into_tensor(parts, moments, group=group)
+    parts, n_parts = gather_moments(moments, group)
     # rank-ordered sum of the triples, mean / std and the normalisation itself: one launch
     _lib.check(getattr(lib, "cm3_normalize_" + suffix)(
         out.data_ptr(), _lib.ptr(v8), parts.data_ptr(), n_parts, stats.data_ptr(), out.numel(), C, float(eps),
@@ -128,8 +142,8 @@ _SCRATCH = {}
 
 
 def _scratch(lib, device, stream):
-    """Scratch of cm3_returns_moments_* per (device, stream): zero-filled once, every launch leaves it ready for the next
-    (launches on one stream are ordered, so they can share it)."""
+    """Scratch of cm3_returns_moments_* per (device, stream): launches on one stream are ordered, so they can share it
+    (every call zeroes its arrival counter itself)."""
     key = (device.type, device.index, int(stream or 0))
     if key not in _SCRATCH:
         _SCRATCH[key] = torch.zeros(lib.cm3_returns_scratch_bytes() // 8, dtype=torch.float64, device=device)

@@ -25,7 +25,11 @@
  *                                obs_self (multi-goal_spread.py:154) for env e are the rows
  *                                state[:, e, :].
  *   goals       real [N][E][2]   landmark positions (train_onpolicy.py:283-285)
- *   meta        int32 [E][2]     {steps, collisions}   (environment.py:93; multi-goal_spread.py:93,137)
+ *   meta        int32 [E][2]     {steps | finished << 31, collisions}   (environment.py:93; multi-goal_spread.py:93,137).
+ *                                Without CM3_FLAG_AUTO_RESET an env whose episode ended is FINISHED (sign bit of the step
+ *                                word): the reference stops calling step() there (train_onpolicy.py:302), so its step and
+ *                                collision counters freeze -- `collisions` stays the episode's scenario.collisions, read at
+ *                                train_onpolicy.py:356 -- and `done` stays 1 until the env is reset.
  *   episode     int32 [E]        episodes started so far by env e (RNG key; touched on reset only)
  *   actions     int32 [E][N]     discrete actions 0..4 (environment.py:197-200)
  *   obs_others  real [E][N][L]   L = 4*max(N-1,1)  (multi-goal_spread.py:145-154)
@@ -43,7 +47,7 @@
 extern "C" {
 #endif
 
-#define CM3_ABI_VERSION 2
+#define CM3_ABI_VERSION 3
 #define CM3_MAX_AGENTS 8
 
 #define CM3_OK 0
@@ -82,6 +86,8 @@ typedef struct cm3_particle_desc {
   int32_t n_agents;    /* N, 1..CM3_MAX_AGENTS */
   int32_t max_steps;   /* config.json:61 */
   uint32_t flags;      /* CM3_FLAG_* */
+  int32_t env_offset;  /* launch only envs [env_offset, env_offset + env_count) of the E-extent arrays (a sub-batch; the */
+  int32_t env_count;   /* arrays and RNG keys are untouched by the split).  env_count == 0 (with offset 0) = all E envs */
   int64_t env_id_base; /* global id of local env 0: RNG is keyed by GLOBAL env id, so results do not
                           depend on how envs are sharded over GPUs */
   uint64_t seed;
@@ -106,6 +112,9 @@ typedef struct cm3_particle_bufs {
   uint8_t *done;        /* uint8 [E] out */
   void *term_state;      /* optional real [N][E][4]: written only for envs re-initialised by AUTO_RESET */
   void *term_obs_others; /* optional real [E][N][L]: same */
+  int32_t *term_collisions; /* optional int32 [E]: same -- the finished episode's scenario.collisions (multi-goal_spread.py:137),
+                               which AUTO_RESET zeroes in the same launch; `!= 0` is the reference's is_bad flag of the
+                               dual replay buffer (train_onpolicy.py:356) */
 } cm3_particle_bufs;
 
 /* One tick for E envs in ONE kernel launch: replaces MultiAgentEnv.step (environment.py:81-123) =
@@ -148,12 +157,24 @@ typedef struct cm3_particle_traj {
   int32_t *episode;   /* int32 [E], live */
   void *term_state;      size_t term_state_stride;
   void *term_obs_others; size_t term_obs_others_stride;
+  int32_t *term_collisions; size_t term_collisions_stride; /* optional, n_ticks slots of int32 [E] */
 } cm3_particle_traj;
 
 int cm3_particle_rollout_f32(const cm3_particle_desc *desc, const cm3_particle_traj *traj, int32_t n_ticks,
                              void *stream);
 int cm3_particle_rollout_f64(const cm3_particle_desc *desc, const cm3_particle_traj *traj, int32_t n_ticks,
                              void *stream);
+
+/* The same collection as n_chains INDEPENDENT sub-batch chains (envs never interact, environment.py:81-123 touches one
+ * env): chain c = a contiguous block of envs, its n_ticks step launches go to streams[c].  streams[1..] are forked from
+ * and joined back into streams[0] with events, so the call is ordered like one launch sequence on streams[0] -- eagerly,
+ * or as parallel branches when streams[0] is being captured into a hipGraph (cm3_graph_begin).  The dependent-launch
+ * boundary of one chain then overlaps the kernels of the others.  Every launch is still one tick of its envs; results are
+ * bit-identical for every n_chains (1..16; desc->env_offset / env_count must be 0). */
+int cm3_particle_rollout_chains_f32(const cm3_particle_desc *desc, const cm3_particle_traj *traj, int32_t n_ticks,
+                                    int32_t n_chains, void *const *streams);
+int cm3_particle_rollout_chains_f64(const cm3_particle_desc *desc, const cm3_particle_traj *traj, int32_t n_ticks,
+                                    int32_t n_chains, void *const *streams);
 
 /* ------------------------------------------------------------------------------------------
  * Checkers env (env/checkers.py).  Compact live state, reference-shaped outputs.
@@ -207,11 +228,23 @@ typedef struct cm3_checkers_bufs {
   double *local_rewards;
   double *reward;
   uint8_t *done;
+  /* optional, all five or none: written ONLY for envs re-initialised by CM3_FLAG_AUTO_RESET in this launch -- their TRUE
+     post-step observation, i.e. the next_* columns of the terminal transition, which the reference stores before it resets
+     (train_onpolicy.py:336-347; checkers.py:246-262).  Same layouts / record strides as the five arrays above. */
+  int8_t *term_grid;
+  int32_t *term_vec;
+  double *term_obs_others;
+  int8_t *term_obs_self_t;
+  double *term_obs_self_v;
+  uint8_t *goals_next; /* optional uint8 [E][N]: the goals in effect AFTER this tick -- the goals column of the NEXT
+                          transition (they change only when a single-agent env restarts, train_onpolicy.py:288-291) */
 } cm3_checkers_bufs;
 
 /* Trajectory collection for Checkers (train_onpolicy.py:302-350, 16-column transitions): n_ticks step launches over
  * a time-major trajectory, or ONE launch with CM3_FLAG_FUSED_TICKS (fast kernel only).  Observation arrays have
- * n_ticks+1 slots (slot t = before tick t); per-tick outputs n_ticks slots; strides in BYTES between slots. */
+ * n_ticks+1 slots (slot t = before tick t); per-tick outputs n_ticks slots; strides in BYTES between slots.
+ * With CM3_FLAG_AUTO_RESET (continuous collection) slot t+1 of an env whose episode ended at tick t holds the FRESH
+ * episode's observation (what the policy acts on next) and the terminal next_* go to the term_* slots of tick t. */
 typedef struct cm3_checkers_traj {
   uint64_t *mask; uint32_t *agents; int32_t *steps; int32_t *episode; uint8_t *goals; /* live, in place */
   int32_t *actions;      size_t actions_stride;
@@ -223,6 +256,14 @@ typedef struct cm3_checkers_traj {
   double *local_rewards; size_t local_rewards_stride;
   double *reward;        size_t reward_stride;
   uint8_t *done;         size_t done_stride;
+  /* optional terminal capture (see cm3_checkers_bufs), n_ticks slots each */
+  int8_t *term_grid;        size_t term_grid_slot_stride;
+  int32_t *term_vec;        size_t term_vec_stride;
+  double *term_obs_others;  size_t term_obs_others_stride;
+  int8_t *term_obs_self_t;  size_t term_obs_self_t_slot_stride;
+  double *term_obs_self_v;  size_t term_obs_self_v_stride;
+  uint8_t *goals_slots;     size_t goals_slots_stride; /* optional, n_ticks+1 slots of uint8 [E][N]; slot 0 is the caller's,
+                                                          tick t writes slot t+1 (cm3_checkers_bufs.goals_next) */
 } cm3_checkers_traj;
 
 int cm3_checkers_rollout(const cm3_checkers_desc *desc, const cm3_checkers_traj *traj, int32_t n_ticks, void *stream);
@@ -275,6 +316,8 @@ typedef struct cm3_actor_particle_bufs {
   const int32_t *episode;
   int32_t *actions;
   float *probs; /* optional */
+  const float *epsilon_dev; /* optional device float: read at launch INSTEAD of desc->epsilon, so a captured hipGraph
+                               follows the epsilon annealing of train_onpolicy.py:369 without being re-captured */
 } cm3_actor_particle_bufs;
 
 size_t cm3_actor_particle_packed_bytes(int32_t n_agents);
@@ -344,6 +387,9 @@ typedef struct cm3_actor_checkers_bufs {
   const int32_t *episode;
   int32_t *actions;
   float *probs; /* optional */
+  const uint8_t *prev_done;  /* optional uint8 [E]: envs whose previous tick ended an episode (continuous collection with
+                                CM3_FLAG_AUTO_RESET) feed actions_prev = zeros, as a fresh episode does (train_onpolicy.py:295) */
+  const float *epsilon_dev;  /* optional device float read at launch instead of desc->epsilon (see cm3_actor_particle_bufs) */
 } cm3_actor_checkers_bufs;
 
 size_t cm3_actor_checkers_packed_bytes(void);
@@ -357,11 +403,12 @@ int cm3_actor_checkers_f32(const cm3_actor_checkers_desc *desc, const cm3_actor_
  * Discounted return-to-go over a time-major trajectory, G[t] = x[t] + gamma * (1 - done[t]) * G[t+1], G[T] = 0:
  *   x, out  real [T][E][C]   (C = N for reward_n, 1 for the team reward); out may alias x
  *   done    uint8 [T][E];  valid uint8 [T][E] optional (invalid entries: out = 0, excluded from the moments)
- *   scratch >= cm3_returns_scratch_bytes() bytes, ZERO-FILLED before its first use (the launch leaves it ready for the
- *   next call: the last block to finish folds the per-block partials in block order and resets the ticket counter);
+ *   scratch >= cm3_returns_scratch_bytes() bytes (per-block partials + an arrival counter that every call zeroes with a
+ *   4-byte memset on `stream` before its launch; the last block to arrive folds the partials in block order);
  *   moments double[3] = (sum, sum of squares, count) of this rank's valid returns, computed deterministically.
  *   The host all-gathers the three numbers over the ranks (RCCL); cm3_normalize_* sums the n_parts triples in rank order
- *   and applies x = (x - mean) / (std + eps) with the GLOBAL moments (x real [n_elem], valid indexed by element / C);
+ *   and applies x = (x - (real)mean) / (real)(std + eps) with the GLOBAL moments (x real [n_elem], valid indexed by
+ *   element / C; the same expression as the host helper cm3_amd.shard.normalize_advantages, bit for bit);
  *   stats (optional) receives (mean, std, count); apply = 0 only computes stats.
  * ---------------------------------------------------------------------------------------- */
 size_t cm3_returns_scratch_bytes(void);
@@ -388,6 +435,15 @@ int cm3_traffic_floor_bench(const void *src, size_t read_bytes, void *dst, size_
  * workgroup to sink (>= 4*cm3_hbm_bench_sink_words() bytes).  The measured read-bandwidth roofline. */
 int cm3_hbm_read_bench(const void *buf, size_t bytes, void *sink, void *stream);
 int cm3_hbm_bench_sink_words(void);
+/* The same probe with an explicit configuration (independent 16-byte loads in flight per lane: 1/2/4/8/16; workgroups of
+ * 256 lanes per CU: 1..32; nt != 0: non-temporal loads) -- tools/hbm_probe_sweep.py picks cm3_hbm_read_bench's. */
+int cm3_hbm_read_bench_cfg(const void *buf, size_t bytes, void *sink, int32_t unroll, int32_t wg_per_cu, int32_t nt,
+                           void *stream);
+/* Streaming 16-byte-per-lane copy of `bytes` bytes (the pattern behind the guide's 6.29 TB/s "float4 copy" figure);
+ * the bandwidth is 2 * bytes / time.  unroll 1/2/4/8. */
+int cm3_hbm_copy_bench(void *dst, const void *src, size_t bytes, void *stream);
+int cm3_hbm_copy_bench_cfg(void *dst, const void *src, size_t bytes, int32_t unroll, int32_t wg_per_cu, int32_t nt,
+                           void *stream);
 
 /* hipGraph capture of whatever is enqueued on `stream` between begin and end (launch-bound inner
  * loops: 33 ticks per replay). */

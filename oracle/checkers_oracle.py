@@ -214,6 +214,22 @@ class VecCheckersOracle(object):
         self.steps = np.zeros(self.E, np.int64)
         return self.outputs()
 
+    def reset_envs(self, sel, goal_index=None):
+        """Restart the envs selected by the bool mask `sel` (the outer loop of train_onpolicy.py:281-294 calling
+        Checkers.reset for a fresh episode); goal_index int [E,N] replaces the goals of those envs (N == 1 draws a new
+        one-hot goal per episode, :288-291)."""
+        sel = np.asarray(sel, bool)
+        if goal_index is not None:
+            self.goal = np.where(sel[:, None], np.asarray(goal_index).reshape(self.E, self.N), self.goal)
+        self.mask = np.where(sel, np.uint64(0), self.mask)
+        self.loc[sel, :, 0] = self.start_r
+        self.loc[sel, :, 1] = self.start_c
+        if self.N == 1:
+            self.loc[sel, 0, 0] = (np.where(self.goal[:, 0] == 0, 0, 2) + self.O)[sel]
+        self.count[sel] = 0
+        self.steps = np.where(sel, 0, self.steps)
+        return self.outputs()
+
     # -- dense reconstruction ---------------------------------------------------------------
     def dense_world(self):
         E, TR, TC, O, R, C = self.E, self.TR, self.TC, self.O, self.R, self.C

@@ -32,17 +32,40 @@ def test_header_symbols_all_exported(built):
     assert handle.cm3_abi_version() == built.ABI_VERSION
 
 
-def test_struct_sizes_match_header(built):
+STRUCTS = {"cm3_particle_desc": "ParticleDesc", "cm3_particle_bufs": "ParticleBufs", "cm3_particle_traj": "ParticleTraj",
+           "cm3_checkers_desc": "CheckersDesc", "cm3_checkers_bufs": "CheckersBufs", "cm3_checkers_traj": "CheckersTraj",
+           "cm3_actor_particle_desc": "ActorParticleDesc", "cm3_actor_particle_weights": "ActorParticleWeights",
+           "cm3_actor_particle_bufs": "ActorParticleBufs", "cm3_actor_checkers_desc": "ActorCheckersDesc",
+           "cm3_actor_checkers_weights": "ActorCheckersWeights", "cm3_actor_checkers_bufs": "ActorCheckersBufs"}
+
+
+def test_struct_layouts_match_header(built, tmp_path):
+    """sizeof and every field offset of every struct, as a C compiler sees include/cm3_amd.h, against the ctypes mirror."""
     import ctypes
-    # sizes computed from include/cm3_amd.h by hand: catches accidental field drift
-    assert ctypes.sizeof(built.ParticleDesc) == 4 * 4 + 8 + 8 + 8 + 8 + 4 * 8 * 8
-    assert ctypes.sizeof(built.ParticleBufs) == 14 * 8
-    assert ctypes.sizeof(built.ParticleTraj) == 20 * 8
-    assert ctypes.sizeof(built.CheckersDesc) == 10 * 4 + 8 + 8 + 2 * 8 * 4
-    assert ctypes.sizeof(built.CheckersBufs) == 14 * 8
-    assert ctypes.sizeof(built.ActorParticleDesc) == 10 * 4 + 8 + 8
-    assert ctypes.sizeof(built.ActorParticleWeights) == 10 * 8
-    assert ctypes.sizeof(built.ActorParticleBufs) == 7 * 8
+    import subprocess
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "cm3_amd.h"', 'int main(void) {']
+    for cname, pyname in STRUCTS.items():
+        cls = getattr(built, pyname)
+        lines.append('  printf("%s size %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            lines.append('  printf("%s %s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)])
+    got = {}
+    for line in subprocess.check_output([str(exe)], text=True).splitlines():
+        cname, field, val = line.split()
+        got[(cname, field)] = int(val)
+    for cname, pyname in STRUCTS.items():
+        cls = getattr(built, pyname)
+        assert ctypes.sizeof(cls) == got[(cname, "size")], cname
+        for fname, _ in cls._fields_:
+            assert getattr(cls, fname).offset == got[(cname, fname)], (cname, fname)
+    # every struct the header defines is covered
+    text = open(os.path.join(ROOT, "include", "cm3_amd.h")).read()
+    assert sorted(set(re.findall(r"typedef struct (cm3_[a-z_]+)", text))) == sorted(STRUCTS)
 
 
 def test_invalid_arguments_return_error_codes_without_a_gpu(built):

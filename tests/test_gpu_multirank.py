@@ -1,0 +1,101 @@
+"""GPU: the N > 1 plumbing on a one-GPU box -- bench.py under a launcher (RCCL process group, barrier, all-gather of the
+per-rank times and of the advantage moments), the self-spawning entry, and a genuine world-size-2 execution of the
+product's collective path (both ranks on cuda:0, gloo group)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _env():
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return env
+
+
+def _torchrun(nproc, script_args, timeout=600):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+           "--master-addr", "127.0.0.1", "--master-port", str(_port())] + script_args
+    return subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=timeout)
+
+
+def _json_line(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert lines, stdout[-2000:]
+    return json.loads(lines[-1])
+
+
+@pytest.mark.parametrize("workload", ["c4", "c2"])
+def test_bench_under_torchrun_one_rank(workload):
+    """The driver's N > 1 command shape with N = 1: nccl (= RCCL) init, barriers, the all-gather of the per-rank clocks and
+    (c4) of the advantage moments all execute on the box."""
+    r = _torchrun(1, ["bench.py", "--gpus", "1", "--workload", workload, "--steps", "3", "--warmup", "1", "--no-extras",
+                      "--no-sweep", "--no-cpu-baseline"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = _json_line(r.stdout)
+    assert out["n_gpus"] == 1 and out["scaling"] == "weak" and out["value"] > 1e6
+    assert len(out["per_rank"]) == 1 and out["per_rank"][0]["rank"] == 0
+    assert abs(out["per_rank"][0]["avg_launch_us"] - out["roofline"]["avg_launch_us"]) < 1e-6
+    if workload == "c4":
+        assert "all-gather" in out["config"]["parallelism"]
+    # one clock: value and roofline agree
+    bytes_per_tick = out["roofline"]["algorithmic_bytes_per_launch"] * out["config"]["chains"]
+    assert abs(out["roofline"]["achieved"] * 1e9 / bytes_per_tick * out["config"]["envs_per_gpu"] / out["value"] - 1) < 1e-9
+
+
+def test_bench_self_spawn_with_too_few_gpus_fails_after_spawning():
+    """`python bench.py --gpus N` re-executes itself through torch.distributed.run; with fewer GPUs than ranks the ranks
+    without a device say so (after spawning, not before)."""
+    n = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", str(n), "--steps", "1", "--warmup", "1", "--no-extras",
+                        "--no-sweep", "--no-cpu-baseline"], cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert "needs %d GPUs on this node, only %d visible" % (n, n - 1) in (r.stderr + r.stdout)
+
+
+def test_two_rank_product_path_on_one_gpu(tmp_path):
+    """world size 2: each rank collects its shard of the envs (RNG keyed by global env id), computes its float64 moments on
+    the device, all-gathers the triples and normalises with n_parts = 2.  Both ranks must hold bit-identical statistics,
+    equal to the float64 statistics of the concatenated batch, and the shards must equal the single-process run."""
+    from cm3_amd.shard import normalized_returns, returns_to_go
+    import cm3_amd
+    from cm3_amd.particle import VecParticleEnv
+    from cm3_amd.rollout import ParticleRollout
+    E = 1000 + 24                                   # ragged split: 512 + 512
+    r = _torchrun(2, [os.path.join("tests", "workers", "two_rank_adv_worker.py"), str(tmp_path), str(E)])
+    assert r.returncode == 0, r.stderr[-3000:]
+    parts = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % k)) for k in range(2)]
+    assert parts[0]["mean"] == parts[1]["mean"] and parts[0]["std"] == parts[1]["std"]
+    assert parts[0]["count"] == parts[1]["count"] == float(33 * E * 4)
+    # single process, all envs: the same trajectories (shard invariance) and the same statistics
+    cfg = cm3_amd.load_config("particle_stage2_cross")
+    env = VecParticleEnv(cfg, 4, 0.2, 33, E, device="cuda:0", auto_reset=True, seed=12341)
+    env.reset()
+    ro = ParticleRollout(env, n_ticks=33, use_graph=True).collect(reset=False)
+    whole_r = torch.cat([p["reward_n"] for p in parts], dim=1).cuda()
+    assert torch.equal(whole_r, ro.reward_n)
+    assert torch.equal(torch.cat([p["done"] for p in parts], dim=1).cuda(), ro.done)
+    ret = returns_to_go(ro.reward_n.double(), ro.done, gamma=0.99)
+    assert abs(parts[0]["mean"] - float(ret.mean())) < 1e-5 * abs(float(ret.mean()))        # float32 returns vs float64
+    assert abs(parts[0]["std"] - float(ret.std(unbiased=False))) < 1e-5 * float(ret.std())
+    norm1, (m1, s1, _) = normalized_returns(ro.reward_n, ro.done, None, gamma=0.99)
+    assert abs(float(m1) - parts[0]["mean"]) < 1e-12 * abs(float(m1))      # 1 part vs 2 parts: only the summation tree differs
+    whole_norm = torch.cat([p["norm"] for p in parts], dim=1).cuda()
+    assert torch.allclose(whole_norm, norm1, rtol=1e-6, atol=1e-6)
+    ro.close()

@@ -6,7 +6,8 @@ Tolerances (BASELINE.json north_star): float32 dynamics within 1e-5 PER TICK wit
 float64 state injected before every tick; samples within 2e-6 of the two
 discontinuities (collision radius 0.3, reach radius 0.05) are excluded from reward / done / collision
 comparisons and counted (item 3).  The float64 instantiation free-runs whole episodes and must stay
-within 1e-9 of the reference (only exp/log1p ulps differ).
+within 1e-9 of the reference (only exp/log1p ulps differ); free-running float32 episodes are held to the explicit
+drift bound DRIFT32.
 """
 import numpy as np
 import pytest
@@ -75,12 +76,12 @@ def test_f32_teacher_forced_vs_reference_golden(name, kernel):
         want = g["gs"][:, t]
         assert _maxabs(gs[live] - want[live]) < TOL32, (name, t)
         assert _maxabs(os_[live] - g["obs_self"][live, t]) < TOL32
-        assert _maxabs(oo[live] - g["obs_others"][live, t]) < 2 * TOL32
+        assert _maxabs(oo[live] - g["obs_others"][live, t]) < TOL32
         m_col, m_reach = _margins(want[..., 2:4], g["landmarks"])
         safe = live & (m_col > EDGE) & (m_reach > EDGE)
         skipped += int((live & ~safe).sum())
         assert _maxabs(rew_n[safe] - g["reward_n"][safe, t]) < TOL32
-        assert _maxabs(rew[safe] - g["reward"][safe, t]) < N * TOL32
+        assert _maxabs(rew[safe] - g["reward"][safe, t]) < TOL32
         assert np.array_equal(done[safe], g["done"][safe, t]), (name, t)
         assert np.array_equal(col[safe], g["collisions"][safe, t])
         prev_gs = np.where(live[:, None, None], want, prev_gs)
@@ -110,6 +111,40 @@ def test_f64_free_running_vs_reference_golden(name, kernel):
         assert np.array_equal(done.cpu().numpy()[live], g["done"][live, t])
         assert np.array_equal(env.collisions.cpu().numpy()[live], g["collisions"][live, t])
         assert np.array_equal(env.steps.cpu().numpy()[live], np.full(live.sum(), t + 1))
+
+
+DRIFT32 = 5e-4      # free-running float32 episodes: 10x the drift SURVEY.md section 7.3-2 measured (5.2e-5 with collisions)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("name", NAMES)
+def test_f32_free_running_drift_vs_reference_golden(name, kernel):
+    """Whole episodes in float32 with NO re-injection against the float64 reference trajectory: the contact stiffness
+    (100 / 1e-3) amplifies rounding, so the bar here is an explicit drift bound on the state, DRIFT32, not the per-tick
+    1e-5; rewards / done / collisions are compared where the reference sits further than the bound from a threshold."""
+    g = load_golden(name)
+    m = g["meta"]
+    N, Ep, T = m["n_agents"], len(g["ep_len"]), int(g["ep_len"].max())
+    env = _env(m["config"], N, Ep, prob_random=m["prob_random"], kernel=kernel)
+    gs0 = g["init_gs"]
+    env.set_state(gs0[..., 2:4], gs0[..., 0:2], g["landmarks"])
+    worst, ok_env = 0.0, np.ones(Ep, bool)
+    for t in range(T):
+        live = g["ep_len"] > t
+        acts = np.where(live[:, None], g["actions"][:, t], 0)
+        gs, oo, os_, rew, rew_n, done = env.step(torch.as_tensor(acts))
+        gs, rew_n = _np(gs), _np(rew_n)
+        want = g["gs"][:, t]
+        if not np.isfinite(want[live]).all():         # dist == 0 NaN episodes of a KAT: parity is covered per tick
+            break
+        worst = max(worst, _maxabs(gs[live] - want[live]))
+        m_col, m_reach = _margins(want[..., 2:4], g["landmarks"])
+        ok_env &= ~live | ((m_col > DRIFT32) & (m_reach > DRIFT32))     # once a flip is possible the env's counters may differ
+        safe = live & ok_env
+        assert _maxabs(rew_n[safe] - g["reward_n"][safe, t]) < 2 * DRIFT32, (name, t)     # |d dist| <= sqrt(2) |d pos|
+        assert np.array_equal(done.cpu().numpy()[safe], g["done"][safe, t]), (name, t)
+        assert np.array_equal(env.collisions.cpu().numpy()[safe], g["collisions"][safe, t])
+    assert worst < DRIFT32, (name, worst)
 
 
 def _random_states(rng, E, N, crowd=0.5):
@@ -150,12 +185,12 @@ def test_f32_random_states_vs_oracle(cfg_name, N, E, kernel):
         gs, oo, os_, rew, rew_n, done = env.step(torch.as_tensor(acts))
         gs, oo, rew, rew_n = map(_np, (gs, oo, rew, rew_n))
         assert _maxabs(gs - w_gs) < TOL32
-        assert _maxabs(oo - w_oo) < 2 * TOL32
+        assert _maxabs(oo - w_oo) < TOL32
         m_col, m_reach = orc.pair_margins()
         safe = (m_col > EDGE) & (m_reach > EDGE)
         bad += int((~safe).sum())
         assert _maxabs(rew_n[safe] - w_rn[safe]) < TOL32
-        assert _maxabs(rew[safe] - w_rew[safe]) < N * TOL32
+        assert _maxabs(rew[safe] - w_rew[safe]) < TOL32
         assert np.array_equal(done.cpu().numpy()[safe], w_done[safe])
         assert np.array_equal(env.collisions.cpu().numpy()[safe], orc.collisions[safe])
         assert np.array_equal(env.steps.cpu().numpy(), orc.steps)

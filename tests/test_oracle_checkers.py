@@ -90,3 +90,30 @@ def test_sweep_collects_everything_and_ends_early():
     # episode 3: agent 0 sweeps all 24 cells -> done on tick 24 (index 23)
     assert g["ep_len"][3] == 24 and g["done"][3, 23]
     assert g["vec"][3, 23, 0, 2:].tolist() == [12.0, 12.0]
+
+
+def test_masked_restart_equals_reset():
+    """VecCheckersOracle.reset_envs (the outer loop restarting an episode, train_onpolicy.py:281-294): restarting every env
+    is reset(); restarting some leaves the others untouched."""
+    from oracle.checkers_oracle import VecCheckersOracle
+    rng = np.random.default_rng(3)
+    for N, goals in ((2, np.eye(2)), (1, None)):
+        E = 40
+        a = VecCheckersOracle(3, 8, 2, [0, 2], [8, 8], N, 33, E)
+        b = VecCheckersOracle(3, 8, 2, [0, 2], [8, 8], N, 33, E)
+        g0 = goals if goals is not None else rng.integers(0, 2, (E, 1))
+        a.reset(g0)
+        b.reset(g0)
+        for _ in range(7):
+            acts = rng.integers(0, 5, (E, N))
+            a.step(acts)
+            b.step(acts)
+        sel = rng.random(E) < 0.5
+        new_goal = rng.integers(0, 2, (E, N)) if N == 1 else None
+        out = a.reset_envs(sel, new_goal)
+        assert np.array_equal(a.steps[sel], np.zeros(sel.sum())) and np.array_equal(a.steps[~sel], b.steps[~sel])
+        assert np.array_equal(a.mask[~sel], b.mask[~sel]) and not a.mask[sel].any()
+        fresh = VecCheckersOracle(3, 8, 2, [0, 2], [8, 8], N, 33, E)
+        want = fresh.reset(a.goal)
+        for x, y, z in zip(out, want, b.outputs()):
+            assert np.array_equal(x[sel], y[sel]) and np.array_equal(x[~sel], z[~sel])

@@ -9,7 +9,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from cm3_amd.shard import global_moments, normalize_advantages, returns_to_go, shard_range
+from cm3_amd.shard import (gather_moments, global_moments, local_moments, normalize_advantages, returns_to_go,
+                            shard_range)
 from oracle import philox
 
 
@@ -73,6 +74,14 @@ def _worker(rank, world, port, n_global, out):
         want = (adv - sel.mean()) / (sel.std(unbiased=False) + 1e-8)
         want = torch.where(valid.unsqueeze(-1).expand_as(want), want, torch.zeros_like(want))
         ok = ok and bool(torch.allclose(norm, want, atol=1e-12))
+        # gather_moments is THE collective of the product path (normalized_returns hands its result to cm3_normalize_*
+        # as `parts`, n_parts): rank-ordered triples, identical on every rank
+        mine = local_moments(adv, valid)
+        parts, n_parts = gather_moments(mine)
+        ok = ok and n_parts == world and parts.shape == (3 * world,) and bool(torch.equal(parts[3 * rank:3 * rank + 3], mine))
+        for r in range(world):
+            b, c = shard_range(n_global, r, world)
+            ok = ok and bool(torch.equal(parts[3 * r:3 * r + 3], local_moments(adv_all[:, b:b + c], valid_all[:, b:b + c])))
         # every rank must hold bit-identical statistics
         both = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
         dist.all_gather(both, torch.stack([mean, std]))
