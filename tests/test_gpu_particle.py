@@ -116,6 +116,15 @@ def test_f64_free_running_vs_reference_golden(name, kernel):
 DRIFT32 = 5e-4      # free-running float32 episodes: 10x the drift SURVEY.md section 7.3-2 measured (5.2e-5 with collisions)
 
 
+def _record_drift(name, kernel, worst):
+    """every fixture's measured worst drift, appended to gpurun_out/f32_free_running_drift.txt (the table DESIGN.md quotes)"""
+    import os
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "f32_free_running_drift.txt"), "a") as f:
+        f.write("%-32s %-6s %.3e\n" % (name, kernel, worst))
+
+
 @pytest.mark.parametrize("kernel", KERNELS)
 @pytest.mark.parametrize("name", NAMES)
 def test_f32_free_running_drift_vs_reference_golden(name, kernel):
@@ -144,6 +153,7 @@ def test_f32_free_running_drift_vs_reference_golden(name, kernel):
         assert _maxabs(rew_n[safe] - g["reward_n"][safe, t]) < 2 * DRIFT32, (name, t)     # |d dist| <= sqrt(2) |d pos|
         assert np.array_equal(done.cpu().numpy()[safe], g["done"][safe, t]), (name, t)
         assert np.array_equal(env.collisions.cpu().numpy()[safe], g["collisions"][safe, t])
+    _record_drift(name, kernel, worst)
     assert worst < DRIFT32, (name, worst)
 
 
