@@ -99,3 +99,133 @@ CHECKERS_BATCH_NAMES = ("n_steps", "state_env", "state_agents", "obs_others", "o
                         "done", "goals")
 # process_goals / process_global_state of alg_credit_checkers.py:484-535 are the particle functions above, verbatim
 # in behaviour (l_goal = 2, l_state_one_agent = 4): use process_goals(goals) and process_global_state(state_agents).
+
+
+# ---- every feed_dict of train_step (alg_credit.py:558-800, alg_credit_checkers.py:536-780) -------------------------------
+
+def _rep_n(x, n):
+    """things indexed by n: each time step's block of N rows repeated N times (alg_credit.py:621-623)"""
+    return repeat_indexed_by_n(x, n)
+
+
+def train_step_feeds(cols, run, gamma, epsilon, env="particle", use_Q_credit=True, use_V=True, l_action=5):
+    """The data movement of the reference's train_step on the device: builds, in the reference's order, the feed_dict of
+    every sess.run -- TD targets, the n x n credit repeats (alg_credit.py:614-658) and the n x n x l_action counterfactual
+    tiling (:730-751; Checkers twin alg_credit_checkers.py:590-760) -- from the columns of
+    {Particle,Checkers}Rollout.as_reference_batch(numpy=False).
+
+    ``run(ops, feed)`` plays sess.run: `ops` is a list of the reference's op attribute names (e.g. ["Q_global_op",
+    "Q_global"]), `feed` a dict keyed by the reference's placeholder attribute names; it returns one tensor per op (None
+    for optimiser ops).  Returns the list of (ops, feed) in call order.  Pure gathers / repeats plus the float64 TD
+    arithmetic: bit-identical to the arrays the REAL train_step feeds (tests/golden/trainstep_*.npz, recorded by
+    oracle/gen_golden_trainstep.py from the reference code itself under a recording session)."""
+    checkers = env == "checkers"
+    calls = []
+
+    def call(ops, feed):
+        calls.append((ops, feed))
+        return run(ops, feed)
+
+    if checkers:
+        (n_steps, state_env, state_agents, obs_others, obs_self_t, obs_self_v, actions_prev_1hot, actions_1hot,
+         actions_others_1hot, reward, reward_local, state_env_next, state_agents_next, obs_others_next, obs_self_t_next,
+         obs_self_v_next, done, goals) = process_batch_checkers(cols, l_action)
+        v_global, v_global_next = state_agents, state_agents_next
+    else:
+        (n_steps, v_global, obs_others, v_local, actions_1hot, actions_others_1hot, reward, reward_local, v_global_next,
+         obs_others_next, v_local_next, done, goals) = process_batch(cols, l_action)
+    N = v_global.shape[1]
+    goals_self, _ = process_goals(goals)
+    one, others, _ = process_global_state(v_global)
+    one_next, others_next, _ = process_global_state(v_global_next)
+    f64 = torch.float64
+    not_done = (-(done.to(torch.int64) - 1))                                       # if true, then 0, else 1 (:590)
+
+    def actor_feed(oo, *obs):
+        if checkers:
+            return {"obs_others": oo, "obs_self_t": obs[0], "obs_self_v": obs[1], "actions_prev": obs[2],
+                    "v_goal": goals_self, "epsilon": epsilon}
+        return {"obs_others": oo, "v_obs": obs[0], "v_goal": goals_self, "epsilon": epsilon}
+
+    def with_env(feed, s_env=None, ot=None, ov=None):
+        if checkers:
+            feed["state_env"] = s_env
+            if ot is not None:
+                feed["obs_self_t"], feed["obs_self_v"] = ot, ov
+        return feed
+
+    # ---- Q_n(s, a): target actions a', TD target, optimiser step (alg_credit.py:574-612) ----
+    if checkers:      # run_actor_target(actions_1hot, obs_others_next, ...) (alg_credit_checkers.py:551)
+        acts = call(["action_samples_target"], actor_feed(obs_others_next, obs_self_t_next, obs_self_v_next, actions_1hot))[0]
+    else:
+        acts = call(["action_samples_target"], actor_feed(obs_others_next, v_local_next))[0]
+    a_next, a_others_next = process_actions(acts.reshape(n_steps, N), l_action)
+    q_t = call(["Q_global_target"], with_env({"v_state_one_agent": one_next, "v_goal": goals_self, "action_one": a_next,
+                                              "v_state_other_agents": others_next, "action_others": a_others_next},
+                                             state_env_next if checkers else None,
+                                             obs_self_t_next if checkers else None, obs_self_v_next if checkers else None))[0]
+    td = reward_local.to(f64) + gamma * q_t.reshape(-1) * not_done
+    q_res = call(["Q_global_op", "Q_global"],
+                 with_env({"Q_global_td_target": td, "v_state_one_agent": one, "v_goal": goals_self, "action_one": actions_1hot,
+                           "v_state_other_agents": others, "action_others": actions_others_1hot},
+                          state_env if checkers else None, obs_self_t if checkers else None,
+                          obs_self_v if checkers else None))[1]
+    q_res_rep = q_res.reshape(n_steps, N).repeat_interleave(N, dim=0)               # :612
+
+    rep_m = lambda x: x.repeat_interleave(N, dim=0)                                 # noqa: E731  things indexed by m
+    s_n_rep = s_m_rep = s_others_rep = goals_self_rep = s_env_rep = ot_rep = ov_rep = None
+    if N > 1 and use_Q_credit:      # ---- Q_n(s, a^m) (:616-674) ----
+        goals_self_rep = _rep_n(goals_self, N)
+        feed = {"v_state_one_agent": _rep_n(one_next, N), "v_goal": goals_self_rep, "action_one": rep_m(a_next),
+                "v_state_m": rep_m(one_next), "v_state_other_agents": _rep_n(others_next, N)}
+        if checkers:
+            feed = with_env(feed, rep_m(state_env_next), rep_m(obs_self_t_next), rep_m(obs_self_v_next))
+        qc_t = call(["Q_credit_target"], feed)[0]
+        r_rep = _rep_n(reward_local.reshape(-1, 1), N).reshape(-1)
+        nd_rep = -(_rep_n(done.reshape(-1, 1).to(torch.int64), N).reshape(-1) - 1)
+        td_c = r_rep.to(f64) + gamma * qc_t.reshape(-1) * nd_rep
+        s_n_rep, s_others_rep, s_m_rep = _rep_n(one, N), _rep_n(others, N), rep_m(one)
+        feed = {"Q_credit_td_target": td_c, "v_state_one_agent": s_n_rep, "v_goal": goals_self_rep,
+                "action_one": rep_m(actions_1hot), "v_state_m": s_m_rep, "v_state_other_agents": s_others_rep}
+        if checkers:
+            s_env_rep, ot_rep, ov_rep = rep_m(state_env), rep_m(obs_self_t), rep_m(obs_self_v)
+            feed = with_env(feed, s_env_rep, ot_rep, ov_rep)
+        call(["Q_credit_op"], feed)
+    v_res_rep = None
+    if N > 1 and use_V:             # ---- V_n(s) (:676-699) ----
+        v_t = call(["V_target"], with_env({"v_state_one_agent": one_next, "v_goal": goals_self,
+                                           "v_state_other_agents": others_next}, state_env_next if checkers else None))[0]
+        td_v = reward_local.to(f64) + gamma * v_t.reshape(-1) * not_done
+        v_res = call(["V_op", "V"], with_env({"V_td_target": td_v, "v_state_one_agent": one, "v_goal": goals_self,
+                                              "v_state_other_agents": others}, state_env if checkers else None))[1]
+        v_res_rep = v_res.reshape(n_steps, N).repeat_interleave(N, dim=0)
+
+    # ---- policy: probabilities + counterfactual Q for every action (:704-757) ----
+    pol_obs = (obs_self_t, obs_self_v, actions_prev_1hot) if checkers else (v_local,)
+    rep_a = lambda x: x.repeat_interleave(l_action, dim=0)                          # noqa: E731
+    eye = torch.eye(l_action, dtype=f64, device=one.device)                         # self.actions = np.eye(l_action)
+    if N == 1:                      # stage 1: Q(s, a = every action, g)
+        probs = call(["probs"], actor_feed(obs_others, *pol_obs))[0]
+        feed = {"v_state_one_agent": rep_a(one), "v_goal": rep_a(goals_self), "action_one": eye.repeat(n_steps, 1),
+                "v_state_other_agents": others, "action_others": actions_others_1hot}
+        if checkers:
+            feed = with_env(feed, rep_a(state_env), rep_a(obs_self_t), rep_a(obs_self_v))
+        q_cf = call(["Q_global"], feed)[0].reshape(n_steps, l_action)
+    elif use_Q_credit:
+        probs = call(["probs"], actor_feed(obs_others, *pol_obs))[0].repeat_interleave(N, dim=0)
+        feed = {"v_state_one_agent": rep_a(s_n_rep), "v_goal": rep_a(goals_self_rep),
+                "action_one": eye.repeat(N * N * n_steps, 1), "v_state_m": rep_a(s_m_rep),
+                "v_state_other_agents": rep_a(s_others_rep)}
+        if checkers:
+            feed = with_env(feed, rep_a(s_env_rep), rep_a(ot_rep), rep_a(ov_rep))
+        q_cf = call(["Q_credit"], feed)[0].reshape(n_steps * N * N, l_action)
+    else:
+        probs = torch.zeros(1, l_action, dtype=f64, device=one.device)
+        q_cf = torch.zeros(1, l_action, dtype=f64, device=one.device)
+    feed = actor_feed(obs_others, *pol_obs)
+    feed.update({"action_taken": actions_1hot, "Q_actual": q_res_rep, "probs_evaluated": probs, "Q_cf": q_cf})
+    if N > 1 and use_V:
+        feed["V_evaluated"] = v_res_rep
+    call(["policy_op"], feed)
+    call(["list_update_target_ops"], {})
+    return calls

@@ -97,3 +97,39 @@ def test_checkers_rollout_columns_feed_process_batch():
     assert out[1].shape == (2 * n, 3, 9, 2) and out[4].shape == (2 * n, 5, 5, 3) and out[9].shape == (n,)
     assert out[6].dtype == torch.int64 and out[8].dtype == torch.float64 and out[16].dtype == torch.bool
     assert torch.equal(out[7].argmax(1), cols["actions"].reshape(-1).long())
+
+
+@pytest.mark.parametrize("tag", ["particle_n4", "particle_n1", "checkers_n2", "checkers_n1"])
+def test_train_step_feeds_equal_the_real_train_step(tag):
+    """cm3_amd.batch.train_step_feeds against every feed_dict the REAL reference train_step built (alg_credit.py:558-800 /
+    alg_credit_checkers.py:536-780, incl. the n x n credit repeats and the n x n x l_action counterfactual tiling of
+    :730-751), recorded by oracle/gen_golden_trainstep.py from the reference code under a recording session.  The session's
+    return values are pseudo-random stand-ins for the networks: this pins the data movement and the TD-target arithmetic,
+    not any network."""
+    import json
+    from cm3_amd import batch as BR
+    from tests.helpers import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "trainstep_%s.npz" % tag))
+    meta = json.loads(str(z["index"]))
+    cols = {k[3:]: torch.as_tensor(z[k]) for k in z.files if k.startswith("in_")}
+    it = iter(range(len(meta["calls"])))
+
+    def run(ops, feed):
+        c = next(it)
+        entry = meta["calls"][c]
+        assert ops == entry["ops"], (c, ops, entry["ops"])
+        return [torch.as_tensor(z["c%d_res_%s" % (c, op)]) if op in entry["results"] else None for op in ops]
+
+    calls = BR.train_step_feeds(cols, run, meta["gamma"], meta["epsilon"], env=meta["env"])
+    assert [c[0] for c in calls] == [e["ops"] for e in meta["calls"]]
+    n_arrays = 0
+    for c, ((ops, feed), entry) in enumerate(zip(calls, meta["calls"])):
+        assert sorted(feed) == entry["feed"], (c, ops, sorted(feed), entry["feed"])
+        for k, v in feed.items():
+            want = z["c%d_feed_%s" % (c, k)]
+            got = v.cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+            assert got.shape == want.shape, (c, ops, k, got.shape, want.shape)
+            assert got.dtype == want.dtype, (c, ops, k, got.dtype, want.dtype)      # the reference's own NumPy dtypes
+            assert np.array_equal(got, want), (c, ops, k)
+            n_arrays += 1
+    assert n_arrays >= 30
