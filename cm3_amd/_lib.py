@@ -43,7 +43,7 @@ class ParticleDesc(ctypes.Structure):
 class ParticleBufs(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in (
         "state_in", "state_out", "goals_in", "goals_out", "meta_in", "meta_out", "episode", "actions",
-        "obs_others", "reward_n", "reward", "done", "term_state", "term_obs_others", "term_collisions")]
+        "obs_others", "reward_n", "reward", "done", "term_state", "term_obs_others", "collisions_tick")]
 
 
 class ParticleTraj(ctypes.Structure):
@@ -57,7 +57,7 @@ class ParticleTraj(ctypes.Structure):
                 ("meta", c_void_p), ("episode", c_void_p),
                 ("term_state", c_void_p), ("term_state_stride", c_size_t),
                 ("term_obs_others", c_void_p), ("term_obs_others_stride", c_size_t),
-                ("term_collisions", c_void_p), ("term_collisions_stride", c_size_t)]
+                ("collisions", c_void_p), ("collisions_stride", c_size_t)]
 
 
 class CheckersDesc(ctypes.Structure):

@@ -334,7 +334,7 @@ template <int N, bool BF16> __global__ void __launch_bounds__(256) k_actor_parti
   hr = hr < rows ? hr : rows - 1;
   const size_t he = hr / N;
   const int hi_agent = (int)(hr - he * N);
-  const int head_steps = p.meta[2 * he] & 0x7fffffff;  // the sign bit flags a finished env (particle.hip, kFinishedBit)
+  const int head_steps = p.meta[2 * he];
   const uint32_t head_episode = (uint32_t)p.episode[he];
 
   actor_stage_tables<N, BF16>(lds, p.packed, tid);

@@ -45,14 +45,14 @@ struct ParticleParams {
   uint8_t *done;
   void *term_state;
   void *term_obs_others;
-  int32_t *term_collisions;
+  int32_t *collisions_tick;  // optional int32 [E] per tick: scenario.collisions after this tick (before any same-launch reset)
   const uint8_t *reset_mask;
   // tick loop inside one launch (CM3_FLAG_FUSED_TICKS): tick t uses <pointer> + t * <stride in bytes> for the
   // per-tick arrays (state_out / goals_out / obs_others / term_* point at slot 1 of their trajectories);
   // n_ticks == 1 with zero strides is the plain one-launch-per-tick step.
   int n_ticks;
   int _pad2;
-  size_t st_state, st_goals, st_obs, st_actions, st_reward_n, st_reward, st_done, st_term_state, st_term_obs, st_term_coll;
+  size_t st_state, st_goals, st_obs, st_actions, st_reward_n, st_reward, st_done, st_term_state, st_term_obs, st_coll;
 };
 
 template <typename T> __device__ __forceinline__ T *tick_ptr(T *base, size_t stride, int t) {
@@ -128,12 +128,6 @@ template <typename R> __device__ __forceinline__ void contact_force(R dx, R dy, 
 template <typename R> __device__ __forceinline__ bool is_collision(R dx, R dy) {
   return dx * dx + dy * dy < Thresh<R>::kColl2;
 }
-
-// Counters of one env as stored in meta[e] = {steps | finished << 31, collisions}.  Without CM3_FLAG_AUTO_RESET an env
-// whose episode has ended is FINISHED: the reference's loop stops calling step() there (train_onpolicy.py:302), so its
-// step and collision counters freeze (scenario.collisions stays the episode's value, read at :356) and `done` stays set
-// until the env is reset; the physics keeps running on it (its transitions are flagged invalid by the collector).
-constexpr int kFinishedBit = (int)0x80000000u;
 
 template <typename R, typename V4> __device__ __forceinline__ V4 sub4(const V4 &a, const V4 &b) {
   V4 r;
@@ -362,8 +356,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step(const ParticlePara
 #pragma unroll
   for (int i = 0; i < N; ++i) g[i] = gin2[(size_t)i * E + ec];
   const int2 meta = reinterpret_cast<const int2 *>(p.meta_in)[ec];
-  int steps = meta.x & ~kFinishedBit, collisions = meta.y;
-  bool fin = meta.x < 0;  // finished earlier and not reset since (see kFinishedBit)
+  int steps = meta.x, collisions = meta.y;
   const bool auto_reset = (p.flags & CM3_FLAG_AUTO_RESET) != 0;
 
   const bool gen = (p.flags & CM3_FLAG_GEN_ACTIONS) != 0;
@@ -435,7 +428,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step(const ParticlePara
       s[i].z = s[i].z + s[i].x * kDt;
       s[i].w = s[i].w + s[i].y * kDt;
     }
-    steps += fin ? 0 : 1;  // environment.py:93
+    steps += 1;  // environment.py:93
     CM3_STAMP(2, false);
 
     // ---- reward / reached (multi-goal_spread.py:121-143) ----------------------------------------------
@@ -456,18 +449,19 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step(const ParticlePara
         if (is_collision<R>(s[b].z - s[a].z, s[b].w - s[a].w)) {
           rew[a] = rew[a] - R(1);
           rew[b] = rew[b] - R(1);
-          collisions += fin ? 0 : 2;  // double counts by design (:135-137)
+          collisions += 2;  // double counts by design (:135-137)
         }
       }
     }
     const R reward = sum_agents<R, N>(rew);                   // environment.py:107
-    const bool done = fin || (steps == p.max_steps) || all_reached;  // environment.py:118-121
+    const bool done = (steps == p.max_steps) || all_reached;  // environment.py:118-121
 
     CM3_STAMP(3, false);
     if (active) {
       store_row<R, N>(reinterpret_cast<R *>(tick_ptr(p.reward_n, p.st_reward_n, t)), e, rew);
       reinterpret_cast<R *>(tick_ptr(p.reward, p.st_reward, t))[e] = reward;
       tick_ptr(p.done, p.st_done, t)[e] = done ? 1 : 0;
+      if (p.collisions_tick) tick_ptr(p.collisions_tick, p.st_coll, t)[e] = collisions;
     }
     CM3_STAMP(8, false);
 
@@ -477,7 +471,6 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step(const ParticlePara
       if (active) {
         void *term_state = tick_ptr(p.term_state, p.st_term_state, t);
         void *term_obs = tick_ptr(p.term_obs_others, p.st_term_obs, t);
-        if (p.term_collisions) tick_ptr(p.term_collisions, p.st_term_coll, t)[e] = collisions;
         if (term_state) {
           V4 *t4 = reinterpret_cast<V4 *>(term_state);
 #pragma unroll
@@ -491,7 +484,6 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step(const ParticlePara
       collisions = 0;
       was_reset = true;
     }
-    fin = done && !auto_reset;
     CM3_STAMP(9, false);
 
     if (active) {
@@ -515,7 +507,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step(const ParticlePara
   // ---- live counters, once per launch ----------------------------------------------------------------------
   if (active) {
     int2 m;
-    m.x = steps | (fin ? kFinishedBit : 0);
+    m.x = steps;
     m.y = collisions;
     reinterpret_cast<int2 *>(p.meta_out)[e] = m;
     if (episode != episode_in) p.episode[e] = (int32_t)episode;
@@ -597,8 +589,7 @@ __global__ void __launch_bounds__((WAVES + (SPLIT ? 1 : 0)) * 64)
       const size_t edc = ed < EN ? ed : EN - 1;
       int a = 0;
       if (pre_wr) {
-        const int meta_d = h_meta_in[2 * edc];
-        const int steps_d = (meta_d & ~kFinishedBit) + (meta_d < 0 ? 0 : 1);  // a finished env's counter stays
+        const int steps_d = h_meta_in[2 * edc] + 1;
         const uint32_t episode_d = (uint32_t)h_episode[edc];
         const uint64_t genv_d = (uint64_t)(p.env_id_base + (int64_t)edc);
         const u32x4 w = action_words(p.seed, genv_d, episode_d, (uint32_t)steps_d, (uint32_t)(ia >> 2));
@@ -619,8 +610,7 @@ __global__ void __launch_bounds__((WAVES + (SPLIT ? 1 : 0)) * 64)
   V4 sj = sin4[(size_t)j * E + ec];
   V2 gl = reinterpret_cast<const V2 *>(h_goals_in)[(size_t)i * E + ec];
   const int2 meta = reinterpret_cast<const int2 *>(h_meta_in)[ec];
-  int steps = meta.x & ~kFinishedBit, collisions = meta.y;
-  bool fin = meta.x < 0;  // finished earlier and not reset since (see kFinishedBit)
+  int steps = meta.x, collisions = meta.y;
   const bool auto_reset = (h_flags & CM3_FLAG_AUTO_RESET) != 0;
   const bool gen = (h_flags & CM3_FLAG_GEN_ACTIONS) != 0;
   uint32_t episode = 0;
@@ -674,7 +664,7 @@ __global__ void __launch_bounds__((WAVES + (SPLIT ? 1 : 0)) * 64)
     si.y = si.y + (Fy / R(1.0)) * kDt;
     si.z = si.z + si.x * kDt;
     si.w = si.w + si.y * kDt;
-    steps += fin ? 0 : 1;
+    steps += 1;
     if constexpr (SPLIT) {
       if (!pre_rd) __builtin_amdgcn_s_waitcnt(0);  // first tick of a rollout: this tick's own action row is written
       __syncthreads();                             // barrier 1: every physics wave holds its actions in registers
@@ -704,7 +694,7 @@ __global__ void __launch_bounds__((WAVES + (SPLIT ? 1 : 0)) * 64)
 #pragma unroll
     for (int c = 0; c < NO; ++c)
       if (c < c_i) rew = rew - R(1);
-    collisions += fin ? 0 : __popcll(grp);  // every ordered visit counts (:135-137)
+    collisions += __popcll(grp);  // every ordered visit counts (:135-137)
     const unsigned long long rb = __ballot(reached && lead);
     const unsigned long long rgrp = (G == 64) ? rb : ((rb >> base) & ((1ull << (G & 63)) - 1ull));
     const bool all_reached = __popcll(rgrp) == N;
@@ -712,12 +702,13 @@ __global__ void __launch_bounds__((WAVES + (SPLIT ? 1 : 0)) * 64)
 #pragma unroll
     for (int a = 0; a < N; ++a) rews[a] = __shfl(rew, base + a * NO, 64);
     const R reward = sum_agents<R, N>(rews);
-    const bool done = fin || (steps == p.max_steps) || all_reached;
+    const bool done = (steps == p.max_steps) || all_reached;
 
     if (env_ok && lead) reinterpret_cast<R *>(tick_ptr(p.reward_n, p.st_reward_n, t))[e * N + i] = rew;
     if (env_ok && head) {
       reinterpret_cast<R *>(tick_ptr(p.reward, p.st_reward, t))[e] = reward;
       tick_ptr(p.done, p.st_done, t)[e] = done ? 1 : 0;
+      if (p.collisions_tick) tick_ptr(p.collisions_tick, p.st_coll, t)[e] = collisions;
     }
 
     CM3_STAMP(5, true);
@@ -727,7 +718,6 @@ __global__ void __launch_bounds__((WAVES + (SPLIT ? 1 : 0)) * 64)
       if (env_ok) {
         void *term_state = tick_ptr(p.term_state, p.st_term_state, t);
         void *term_obs = tick_ptr(p.term_obs_others, p.st_term_obs, t);
-        if (p.term_collisions && head) tick_ptr(p.term_collisions, p.st_term_coll, t)[e] = collisions;
         if (term_state && lead) reinterpret_cast<V4 *>(term_state)[(size_t)i * E + e] = si;
         if (term_obs && slot_ok) reinterpret_cast<V4 *>(term_obs)[e * SLOTS + gslot] = sub4<R, V4>(sj, si);
       }
@@ -740,14 +730,12 @@ __global__ void __launch_bounds__((WAVES + (SPLIT ? 1 : 0)) * 64)
       collisions = 0;
       was_reset = true;
     }
-    const bool newly_fin = done && !auto_reset && !fin;  // this tick ended the episode and nothing restarts it
-    fin = done && !auto_reset;
 
     CM3_STAMP(6, false);
     if constexpr (SPLIT) {
       __syncthreads();  // barrier 2: the draw wave's row for the next launch is in memory
-      if (pre_wr && (was_reset || newly_fin)) {  // the next launch sees (episode + 1, step 0) / the frozen step counter
-        const u32x4 w = action_words(p.seed, genv, episode, (uint32_t)steps, (uint32_t)(i >> 2));
+      if (pre_wr && was_reset) {  // fresh episode: the next launch sees (episode + 1, step 0)
+        const u32x4 w = action_words(p.seed, genv, episode, 0u, (uint32_t)(i >> 2));
         const int q = i & 3;
         const int a = rand5(q == 0 ? w.x : (q == 1 ? w.y : (q == 2 ? w.z : w.w)));
         if (env_ok && lead) tick_ptr(p.actions, p.st_actions, 1)[e * N + i] = a;
@@ -770,7 +758,7 @@ __global__ void __launch_bounds__((WAVES + (SPLIT ? 1 : 0)) * 64)
   // ---- live counters, once per launch -------------------------------------------------------------------------------
   if (env_ok && head) {
     int2 m;
-    m.x = steps | (fin ? kFinishedBit : 0);
+    m.x = steps;
     m.y = collisions;
     reinterpret_cast<int2 *>(p.meta_out)[e] = m;
     if (episode != episode_in) p.episode[e] = (int32_t)episode;
@@ -822,8 +810,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_agents(const Parti
   V4 si = reinterpret_cast<const V4 *>(p.state_in)[(size_t)i * E + ec];
   V2 gl = reinterpret_cast<const V2 *>(p.goals_in)[(size_t)i * E + ec];
   const int2 meta = reinterpret_cast<const int2 *>(p.meta_in)[ec];
-  int steps = meta.x & ~kFinishedBit, collisions = meta.y;
-  bool fin = meta.x < 0;  // finished earlier and not reset since (see kFinishedBit)
+  int steps = meta.x, collisions = meta.y;
   const bool auto_reset = (p.flags & CM3_FLAG_AUTO_RESET) != 0;
   const bool gen = (p.flags & CM3_FLAG_GEN_ACTIONS) != 0;
   uint32_t episode = 0;
@@ -913,7 +900,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_agents(const Parti
     si.y = si.y + (Fy / R(1.0)) * kDt;
     si.z = si.z + si.x * kDt;
     si.w = si.w + si.y * kDt;
-    steps += fin ? 0 : 1;
+    steps += 1;
     V4 oj[N];  // post-step state of every agent of this env
 #pragma unroll
     for (int j = 0; j < N; ++j) {
@@ -944,7 +931,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_agents(const Parti
     int c_env = c_i;  // every ordered visit counts (:135-137)
 #pragma unroll
     for (int off = G / 2; off > 0; off >>= 1) c_env += __shfl_xor(c_env, off, 64);
-    collisions += fin ? 0 : c_env;
+    collisions += c_env;
     const unsigned long long rb = __ballot(reached && agent_ok);
     const unsigned long long rgrp = (G == 64) ? rb : ((rb >> base) & ((1ull << (G & 63)) - 1ull));
     const bool all_reached = __popcll(rgrp) == N;
@@ -952,12 +939,13 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_agents(const Parti
 #pragma unroll
     for (int a = 0; a < N; ++a) rews[a] = __shfl(rew, base + a, 64);
     const R reward = sum_agents<R, N>(rews);
-    const bool done = fin || (steps == p.max_steps) || all_reached;
+    const bool done = (steps == p.max_steps) || all_reached;
 
     if (mine) reinterpret_cast<R *>(tick_ptr(p.reward_n, p.st_reward_n, t))[e * N + i] = rew;
     if (head) {
       reinterpret_cast<R *>(tick_ptr(p.reward, p.st_reward, t))[e] = reward;
       tick_ptr(p.done, p.st_done, t)[e] = done ? 1 : 0;
+      if (p.collisions_tick) tick_ptr(p.collisions_tick, p.st_coll, t)[e] = collisions;
     }
 
     CM3_STAMP(5, false);
@@ -968,7 +956,6 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_agents(const Parti
       void *term_obs = tick_ptr(p.term_obs_others, p.st_term_obs, t);
       if (__any(done)) {  // wave-uniform: the tile store needs every lane
         if (term_state && done && mine) reinterpret_cast<V4 *>(term_state)[(size_t)i * E + e] = si;
-        if (p.term_collisions && done && head) tick_ptr(p.term_collisions, p.st_term_coll, t)[e] = collisions;
         if (term_obs) {
           // terminal observations of the finished envs; rows of unfinished envs in the tile are not written out
           if (agent_ok) {
@@ -1003,7 +990,6 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_agents(const Parti
       }
     }
 
-    fin = done && !auto_reset;
     CM3_STAMP(6, false);
     // ---- per-tick stores ------------------------------------------------------------------------------------------
     if (mine) {
@@ -1018,7 +1004,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_agents(const Parti
   // ---- live counters, once per launch -------------------------------------------------------------------------------
   if (head) {
     int2 m;
-    m.x = steps | (fin ? kFinishedBit : 0);
+    m.x = steps;
     m.y = collisions;
     reinterpret_cast<int2 *>(p.meta_out)[e] = m;
     if (episode != episode_in) p.episode[e] = (int32_t)episode;
@@ -1149,7 +1135,7 @@ static int fill_params(const cm3_particle_desc *d, const cm3_particle_bufs *b, P
   p.done = b->done;
   p.term_state = b->term_state;
   p.term_obs_others = b->term_obs_others;
-  p.term_collisions = b->term_collisions;
+  p.collisions_tick = b->collisions_tick;
   p.reset_mask = mask;
   return CM3_OK;
 }
@@ -1312,7 +1298,7 @@ static int particle_rollout(const cm3_particle_desc *d, const cm3_particle_traj 
     b.done = t->done;
     b.term_state = t->term_state;
     b.term_obs_others = t->term_obs_others;
-    b.term_collisions = t->term_collisions;
+    b.collisions_tick = t->collisions;
     ParticleParams p;
     int rc = fill_params(d, &b, kStep, nullptr, p);
     if (rc != CM3_OK) return rc;
@@ -1326,7 +1312,7 @@ static int particle_rollout(const cm3_particle_desc *d, const cm3_particle_traj 
     p.st_done = t->done_stride;
     p.st_term_state = t->term_state_stride;
     p.st_term_obs = t->term_obs_others_stride;
-    p.st_term_coll = t->term_collisions_stride;
+    p.st_coll = t->collisions_stride;
     return launch<R>(p, d->n_agents, kStep, (hipStream_t)stream);
   }
   for (int k = 0; k < n_ticks; ++k) {
@@ -1346,7 +1332,7 @@ static int particle_rollout(const cm3_particle_desc *d, const cm3_particle_traj 
     b.done = (uint8_t *)at(t->done, t->done_stride, k);
     b.term_state = at(t->term_state, t->term_state_stride, k);
     b.term_obs_others = at(t->term_obs_others, t->term_obs_others_stride, k);
-    b.term_collisions = (int32_t *)at(t->term_collisions, t->term_collisions_stride, k);
+    b.collisions_tick = (int32_t *)at(t->collisions, t->collisions_stride, k);
     ParticleParams p;
     int rc = fill_params(d, &b, kStep, nullptr, p);
     if (rc != CM3_OK) return rc;

@@ -67,8 +67,7 @@ template <int N, bool BF16> __global__ void __launch_bounds__(256) k_policy_roll
   ActorB<N, BF16> b;
   actor_load_b<N, BF16>(q.packed, w, lane, b);
   const int2 meta = reinterpret_cast<const int2 *>(p.meta_in)[e];
-  int steps = meta.x & ~kFinishedBit, collisions = meta.y;
-  bool fin = meta.x < 0;  // finished earlier and not reset since (particle.hip, kFinishedBit)
+  int steps = meta.x, collisions = meta.y;
   const bool auto_reset = (p.flags & CM3_FLAG_AUTO_RESET) != 0;
   uint32_t episode = (uint32_t)p.episode[e];
   const uint32_t episode_in = episode;
@@ -130,7 +129,7 @@ template <int N, bool BF16> __global__ void __launch_bounds__(256) k_policy_roll
     si.y = si.y + (Fy / 1.0f) * kDt;
     si.z = si.z + si.x * kDt;
     si.w = si.w + si.y * kDt;
-    steps += fin ? 0 : 1;
+    steps += 1;
     ns[rl][0] = si.x; ns[rl][1] = si.y; ns[rl][2] = si.z; ns[rl][3] = si.w;
     wave_lds_sync();  // the other agents of this env live in the same wave
 
@@ -162,13 +161,14 @@ template <int N, bool BF16> __global__ void __launch_bounds__(256) k_policy_roll
       hit_sum += __shfl(hits, env_lane0 + a, 64);
       all_reached = all_reached && (__shfl((int)reached, env_lane0 + a, 64) != 0);
     }
-    collisions += fin ? 0 : hit_sum;
+    collisions += hit_sum;
     const float reward = sum_agents<float, N>(rews);
-    const bool done = fin || (steps == p.max_steps) || all_reached;
+    const bool done = (steps == p.max_steps) || all_reached;
     if (writer) reinterpret_cast<float *>(tick_ptr(p.reward_n, p.st_reward_n, t))[r] = rew;
     if (head_lane) {
       reinterpret_cast<float *>(tick_ptr(p.reward, p.st_reward, t))[e] = reward;
       tick_ptr(p.done, p.st_done, t)[e] = done ? 1 : 0;
+      if (p.collisions_tick) tick_ptr(p.collisions_tick, p.st_coll, t)[e] = collisions;
     }
 
     // ---- same-tick re-initialisation of finished episodes (CM3_FLAG_AUTO_RESET) ------------------------------------------------
@@ -176,7 +176,6 @@ template <int N, bool BF16> __global__ void __launch_bounds__(256) k_policy_roll
     if (auto_reset && done) {
       void *term_state = tick_ptr(p.term_state, p.st_term_state, t);
       void *term_obs = tick_ptr(p.term_obs_others, p.st_term_obs, t);
-      if (head_lane && p.term_collisions) tick_ptr(p.term_collisions, p.st_term_coll, t)[e] = collisions;
       if (writer && term_state) reinterpret_cast<V4 *>(term_state)[(size_t)i * E + e] = si;
       if (writer && term_obs) {
         V4 *o = reinterpret_cast<V4 *>(term_obs) + r * NO;
@@ -199,7 +198,6 @@ template <int N, bool BF16> __global__ void __launch_bounds__(256) k_policy_roll
       ns[rl][0] = si.x; ns[rl][1] = si.y; ns[rl][2] = si.z; ns[rl][3] = si.w;
       wave_lds_sync();
     }
-    fin = done && !auto_reset;
 
     // ---- trajectory stores + the LDS tile of the next tick ---------------------------------------------------------------------
     if (part0) {
@@ -227,7 +225,7 @@ template <int N, bool BF16> __global__ void __launch_bounds__(256) k_policy_roll
 
   if (head_lane) {
     int2 m;
-    m.x = steps | (fin ? kFinishedBit : 0);
+    m.x = steps;
     m.y = collisions;
     reinterpret_cast<int2 *>(p.meta_out)[e] = m;
     if (episode != episode_in) p.episode[e] = (int32_t)episode;
@@ -285,7 +283,7 @@ extern "C" int cm3_policy_rollout_f32(const cm3_particle_desc *d, const cm3_part
   b.done = t->done;
   b.term_state = t->term_state;
   b.term_obs_others = t->term_obs_others;
-  b.term_collisions = t->term_collisions;
+  b.collisions_tick = t->collisions;
   CM3_REQUIRE(d->env_offset == 0 && d->env_count == 0, "the fused policy rollout covers the whole batch");
   cm3_particle_desc dd = *d;
   dd.flags &= CM3_FLAG_AUTO_RESET;
@@ -303,7 +301,7 @@ extern "C" int cm3_policy_rollout_f32(const cm3_particle_desc *d, const cm3_part
   q.p.st_done = t->done_stride;
   q.p.st_term_state = t->term_state_stride;
   q.p.st_term_obs = t->term_obs_others_stride;
-  q.p.st_term_coll = t->term_collisions_stride;
+  q.p.st_coll = t->collisions_stride;
   q.obs_in = (const float *)t->obs_others;
   q.packed = (const float *)wt->packed;
   q.probs = probs;

@@ -25,7 +25,9 @@ int fail(int code, const char *fmt, ...) {
 // that measured best on MI355X (tools/hbm_probe_sweep.py -> profiles/r02_hbm_probe_sweep.txt); the _cfg entry sweeps.
 constexpr int kBenchBlock = 256;
 constexpr int kBenchMaxGrid = 256 * 32;  // up to 32 workgroups per CU
-constexpr int kBenchUnroll = 8, kBenchWgPerCu = 16, kBenchNt = 1;
+// measured (profiles/r02_hbm_probe_sweep.txt, 3 x 20 repetitions): unroll 1, 8 WG/CU, nt -> 7.06 TB/s; the a-priori guess
+// (8 loads in flight, 16 WG/CU, nt) gave 6.4 TB/s, plain loads 5.6-6.4 TB/s
+constexpr int kBenchUnroll = 1, kBenchWgPerCu = 8, kBenchNt = 1;
 
 typedef uint32_t bench_u4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint4 bench_load(const uint4 *p, bool nt) {
@@ -204,7 +206,7 @@ int cm3_hbm_copy_bench_cfg(void *dst, const void *src, size_t bytes, int32_t unr
 }
 
 int cm3_hbm_copy_bench(void *dst, const void *src, size_t bytes, void *stream) {
-  return cm3_hbm_copy_bench_cfg(dst, src, bytes, 4, 16, 0, stream);
+  return cm3_hbm_copy_bench_cfg(dst, src, bytes, 1, 4, 1, stream);  // best of the sweep: 5.56 TB/s
 }
 
 // ---- hipGraph capture ---------------------------------------------------------------------------------

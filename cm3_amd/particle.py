@@ -96,7 +96,7 @@ class VecParticleEnv(object):
         self._obs_others = [z(E, N, L), z(E, N, L)]
         self._term_state = None
         self._term_obs_others = None
-        self._term_collisions = None
+        self._collisions_tick = None
         self._cur = 0
         self._desc = _lib.ParticleDesc()
         _fill_desc(self._desc, config_particle, N, prob_random, max_steps, E, seed, env_id_base, 0)
@@ -128,16 +128,16 @@ class VecParticleEnv(object):
         b.done = self._done[dst].data_ptr()
         b.term_state = _lib.ptr(self._term_state)
         b.term_obs_others = _lib.ptr(self._term_obs_others)
-        b.term_collisions = _lib.ptr(self._term_collisions)
+        b.collisions_tick = _lib.ptr(self._collisions_tick)
         return b
 
     def enable_terminal_capture(self):
-        """Allocate term_state / term_obs_others / term_collisions so AUTO_RESET keeps the true terminal next-state
-        and the finished episode's collision count (both are overwritten by the re-initialisation otherwise)."""
+        """Allocate term_state / term_obs_others / the per-tick collision count so AUTO_RESET keeps the true terminal
+        next-state and the finished episode's scenario.collisions (both are overwritten by the re-initialisation)."""
         if self._term_state is None:
             self._term_state = torch.zeros_like(self._state[0])
             self._term_obs_others = torch.zeros_like(self._obs_others[0])
-            self._term_collisions = torch.zeros(self.E, dtype=torch.int32, device=self.device)
+            self._collisions_tick = torch.zeros(self.E, dtype=torch.int32, device=self.device)
             self._step_bufs.clear()
 
     # ---- reference surface -----------------------------------------------------------------------
@@ -206,27 +206,21 @@ class VecParticleEnv(object):
 
     @property
     def collisions(self):
-        """[E] scenario.collisions (multi-goal_spread.py:93,137; read at train_onpolicy.py:356).  Without auto_reset the
-        count freezes when the env's episode ends (the reference stops stepping there), so after an episode-synchronous
-        rollout this is every env's per-episode value."""
+        """[E] scenario.collisions (multi-goal_spread.py:93,137; read at train_onpolicy.py:356).  Exactly the reference's
+        counter: it keeps counting if an env is stepped after its episode ended (MultiAgentEnv.step does not look at a
+        previous `done`); the collectors read the per-episode value from the trajectory (ParticleRollout.episode_is_bad)."""
         return self._meta[:, 1]
 
     @property
     def steps(self):
-        """[E] MultiAgentEnv.steps (environment.py:93); frozen once the episode has ended (no auto_reset)."""
-        return self._meta[:, 0] & 0x7FFFFFFF
+        """[E] MultiAgentEnv.steps (environment.py:93)."""
+        return self._meta[:, 0]
 
     @property
-    def finished(self):
-        """bool [E]: the env's episode has ended and it has not been reset since (always False under auto_reset).
-        Stored as the sign bit of the step word (include/cm3_amd.h, meta)."""
-        return self._meta[:, 0] < 0
-
-    @property
-    def terminal_collisions(self):
-        """int32 [E]: scenario.collisions of the episode that ended in the most recent step() for envs re-initialised by
-        auto_reset (needs enable_terminal_capture())."""
-        return self._term_collisions
+    def collisions_after_last_step(self):
+        """int32 [E]: scenario.collisions right after the most recent step(), BEFORE auto_reset zeroed it for the envs
+        whose episode ended there (needs enable_terminal_capture())."""
+        return self._collisions_tick
 
     @property
     def episode(self):

@@ -48,8 +48,8 @@ CHECKERS_ORDER = ("grid", "vec", "obs_others", "obs_self_t", "obs_self_v", "acti
 def _valid_from_done(done_u8, finished0=None):
     """valid[t, e] = env e had not finished before tick t (episode-synchronous collection: an env that
     finishes early stops producing transitions, like the reference's `while not done`).  finished0 (bool [E]):
-    envs that had already finished when this collection started (collect(reset=False) on an env without
-    auto-reset) produce no valid transition at all."""
+    envs whose episode had already ended when this collection started (the collector carries that across
+    collect(reset=False) calls on an env without auto-reset) produce no valid transition at all."""
     d = done_u8.to(torch.int32)
     finished_before = torch.cumsum(d, dim=0) - d
     valid = finished_before == 0
@@ -134,12 +134,16 @@ class ParticleRollout(object):
             self.goals = z(T + 1, N, E, 2)
             self.term_state = z(T, N, E, 4)
             self.term_obs_others = z(T, E, N, L)
-            self.term_collisions = z(T, E, d=torch.int32)
         else:
             self.goals = None
-            self.term_state = self.term_obs_others = self.term_collisions = None
+            self.term_state = self.term_obs_others = None
+        # scenario.collisions after every tick, before any same-launch reset: the per-episode value the reference reads
+        # at train_onpolicy.py:356 sits at the tick that ends the episode
+        self.collisions = z(T, E, d=torch.int32)
         self._graph = None
         self._actor_graph = _ActorGraphCache(dev)
+        # episode-synchronous mode: which envs' episodes have ended since their last reset (carried across collects)
+        self._finished = torch.zeros(E, dtype=torch.bool, device=dev)
         self._finished0 = None
         self._lib = _lib.lib()
         self.collected = False
@@ -174,8 +178,8 @@ class ParticleRollout(object):
             t.term_state_stride = N * E * 4 * es
             t.term_obs_others = self.term_obs_others[t0].data_ptr()
             t.term_obs_others_stride = E * N * L * es
-            t.term_collisions = self.term_collisions[t0].data_ptr()
-            t.term_collisions_stride = E * 4
+        t.collisions = self.collisions[t0].data_ptr()
+        t.collisions_stride = E * 4
         return t
 
     def _enqueue(self, t0, n, flags, stream=None, chains=False):
@@ -231,8 +235,9 @@ class ParticleRollout(object):
             reset = not self.auto_reset
         if reset:
             env.reset()
-        # envs that are already finished (no auto-reset, collect(reset=False) after their episode ended) stay invalid
-        self._finished0 = None if (self.auto_reset or reset) else env.finished.clone()
+            self._finished.zero_()
+        # envs whose episode already ended in an earlier collect (no auto-reset, reset=False) stay invalid
+        self._finished0 = None if self.auto_reset else self._finished.clone()
         self._load_slot0()
         base = (FLAG_AUTO_RESET if self.auto_reset else 0) | env.kernel_flags
         if policy is None:
@@ -272,6 +277,8 @@ class ParticleRollout(object):
                 self.actions[t].copy_(torch.as_tensor(a, device=env.device).reshape(env.E, env.n))
                 self._enqueue(t, 1, base)
         self._store_back()
+        if not self.auto_reset:
+            self._finished |= self.done.bool().any(0)
         self.collected = True
         return self
 
@@ -291,13 +298,19 @@ class ParticleRollout(object):
         return _valid_from_done(self.done, self._finished0)
 
     def episode_is_bad(self):
-        """The reference's dual-buffer flag `scenario.collisions != 0` per finished episode (train_onpolicy.py:356).
-        Episode-synchronous mode: bool [E] (the env's collision counter froze when its episode ended; envs that have
-        not finished yet report their running count).  Continuous mode: bool [T, E], meaningful where ``done`` is set
-        -- the count of the episode that ended at that tick (captured before the same-launch reset zeroes it)."""
+        """The reference's dual-buffer flag `scenario.collisions != 0` per finished episode (train_onpolicy.py:356), read
+        from the per-tick collision counts of the trajectory at the tick that ENDS the episode -- collisions of an env
+        that is stepped on after its `done` (episode-synchronous mode) do not count, as in the reference, whose loop
+        stops there (:302).
+        Episode-synchronous mode: bool [E]; an env still running at the end of this trajectory reports its count so far.
+        Continuous mode: bool [T, E], set only where ``done`` is set (the count of the episode that ended at that tick,
+        captured before the same-launch reset zeroes the live counter)."""
+        d = self.done.bool()
         if self.auto_reset:
-            return (self.term_collisions != 0) & self.done.bool()
-        return self.env.collisions != 0
+            return (self.collisions != 0) & d
+        T = self.T
+        first = torch.where(d.any(0), d.to(torch.uint8).argmax(0), torch.full_like(d[0], T - 1, dtype=torch.long))
+        return self.collisions.gather(0, first.unsqueeze(0)).squeeze(0) != 0
 
     def episode_returns(self):
         """(reward_global [E], reward_local [E,N]) accumulated over each env's episode

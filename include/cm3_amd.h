@@ -25,11 +25,10 @@
  *                                obs_self (multi-goal_spread.py:154) for env e are the rows
  *                                state[:, e, :].
  *   goals       real [N][E][2]   landmark positions (train_onpolicy.py:283-285)
- *   meta        int32 [E][2]     {steps | finished << 31, collisions}   (environment.py:93; multi-goal_spread.py:93,137).
- *                                Without CM3_FLAG_AUTO_RESET an env whose episode ended is FINISHED (sign bit of the step
- *                                word): the reference stops calling step() there (train_onpolicy.py:302), so its step and
- *                                collision counters freeze -- `collisions` stays the episode's scenario.collisions, read at
- *                                train_onpolicy.py:356 -- and `done` stays 1 until the env is reset.
+ *   meta        int32 [E][2]     {steps, collisions}   (environment.py:93; multi-goal_spread.py:93,137).  As in the
+ *                                reference, an env that is stepped after its episode ended keeps counting both
+ *                                (MultiAgentEnv.step never looks at a previous `done`); the COLLECTOR stops using it
+ *                                (train_onpolicy.py:302) -- see cm3_particle_traj.collisions for the per-episode value.
  *   episode     int32 [E]        episodes started so far by env e (RNG key; touched on reset only)
  *   actions     int32 [E][N]     discrete actions 0..4 (environment.py:197-200)
  *   obs_others  real [E][N][L]   L = 4*max(N-1,1)  (multi-goal_spread.py:145-154)
@@ -112,9 +111,11 @@ typedef struct cm3_particle_bufs {
   uint8_t *done;        /* uint8 [E] out */
   void *term_state;      /* optional real [N][E][4]: written only for envs re-initialised by AUTO_RESET */
   void *term_obs_others; /* optional real [E][N][L]: same */
-  int32_t *term_collisions; /* optional int32 [E]: same -- the finished episode's scenario.collisions (multi-goal_spread.py:137),
-                               which AUTO_RESET zeroes in the same launch; `!= 0` is the reference's is_bad flag of the
-                               dual replay buffer (train_onpolicy.py:356) */
+  int32_t *collisions_tick; /* optional int32 [E] out, written for EVERY env: scenario.collisions (multi-goal_spread.py:137)
+                               after this tick and before any same-launch re-initialisation.  At the tick that ends an
+                               episode it is that episode's count, whose `!= 0` is the reference's is_bad flag of the dual
+                               replay buffer (train_onpolicy.py:356): AUTO_RESET zeroes the live counter in the same launch,
+                               and without it the live counter keeps counting if the env is stepped further */
 } cm3_particle_bufs;
 
 /* One tick for E envs in ONE kernel launch: replaces MultiAgentEnv.step (environment.py:81-123) =
@@ -157,7 +158,7 @@ typedef struct cm3_particle_traj {
   int32_t *episode;   /* int32 [E], live */
   void *term_state;      size_t term_state_stride;
   void *term_obs_others; size_t term_obs_others_stride;
-  int32_t *term_collisions; size_t term_collisions_stride; /* optional, n_ticks slots of int32 [E] */
+  int32_t *collisions;  size_t collisions_stride; /* optional, n_ticks slots of int32 [E]: cm3_particle_bufs.collisions_tick */
 } cm3_particle_traj;
 
 int cm3_particle_rollout_f32(const cm3_particle_desc *desc, const cm3_particle_traj *traj, int32_t n_ticks,

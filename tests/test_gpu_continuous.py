@@ -25,7 +25,7 @@ def _penv(E, N=4, dtype=torch.float32, cfg="particle_stage2_antipodal.json", **k
     return VecParticleEnv(c, N, kw.pop("prob_random", 0.2), kw.pop("max_steps", 33), E, device="cuda:0", dtype=dtype, **kw)
 
 
-TRAJ = ("state", "obs_others", "actions", "reward", "reward_n", "done", "goals", "term_collisions")
+TRAJ = ("state", "obs_others", "actions", "reward", "reward_n", "done", "goals", "collisions")
 
 
 @pytest.mark.parametrize("kernel,N,cfg", [("pair", 4, "particle_stage2_cross.json"), ("env", 4, "particle_stage2_cross.json"),
@@ -84,33 +84,37 @@ def _two_agent_cfg(gap):
 
 @pytest.mark.parametrize("kernel", ["env", "pair", "agent"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
-def test_finished_env_freezes_steps_and_collisions(kernel, dtype):
-    """The episode of env A ends at tick 1 (all agents on their landmarks, 0.31 apart: no collision).  The agents are then
-    driven into each other: the physics collides (control env B, same motion, far landmarks, counts them), but A's
-    scenario.collisions stays the EPISODE's 0 and its step counter stays 1 -- the reference stops stepping at `done`
-    (train_onpolicy.py:302) and reads scenario.collisions afterwards (:356)."""
-    E = 130
-    fin = _penv(E, 2, dtype=dtype, cfg=_two_agent_cfg(0.31), prob_random=0.0, kernel=kernel)
+def test_post_done_collisions_do_not_make_an_episode_bad(kernel, dtype):
+    """Env A's episode ends at tick 1 (both agents on their landmarks, 0.31 apart: no collision); the policy then drives
+    the agents into each other.  env.step() is the reference's MultiAgentEnv.step and keeps counting steps and collisions
+    when it is called after `done` (environment.py:93; multi-goal_spread.py:137) -- but the reference's LOOP stops at
+    `done` (train_onpolicy.py:302) and reads scenario.collisions there (:356), so the collector's episode_is_bad() must be
+    False for A.  Control env B (same motion, far landmarks) runs to max_steps and IS bad.  (ADVICE r1, medium.)"""
+    from cm3_amd.rollout import ParticleRollout
+    E, T = 130, 7
     ctl_cfg = _two_agent_cfg(0.31)
     ctl_cfg["landmarks_x"], ctl_cfg["landmarks_y"] = [0.9, -0.9], [0.9, -0.9]
-    ctl = _penv(E, 2, dtype=dtype, cfg=ctl_cfg, prob_random=0.0, kernel=kernel)
-    fin.reset()
-    ctl.reset()
-    stay = torch.zeros(E, 2, dtype=torch.int32, device="cuda:0")
-    push = torch.tensor([[2, 1]], dtype=torch.int32, device="cuda:0").expand(E, 2).contiguous()   # toward each other
-    out = fin.step(stay)
-    ctl.step(stay)
-    assert bool(out[5].all()) and bool(fin.finished.all()) and not bool(ctl.finished.any())
-    assert int(fin.steps.max()) == 1 and int(fin.collisions.max()) == 0
-    for _ in range(6):
-        out = fin.step(push)
-        ctl.step(push)
-        assert bool(out[5].all())                                  # done stays set until the env is reset
-    assert int(ctl.collisions.min()) > 0 and int(ctl.steps.min()) == 7     # the collisions did happen physically
-    assert torch.equal(ctl.global_state, fin.global_state)         # the physics kept running identically
-    assert int(fin.collisions.max()) == 0 and int(fin.steps.max()) == 1 and bool(fin.finished.all())
-    fin.reset()
-    assert not bool(fin.finished.any()) and int(fin.steps.max()) == 0
+    fin = _penv(E, 2, dtype=dtype, cfg=_two_agent_cfg(0.31), prob_random=0.0, kernel=kernel, max_steps=T)
+    ctl = _penv(E, 2, dtype=dtype, cfg=ctl_cfg, prob_random=0.0, kernel=kernel, max_steps=T)
+    tick = {"t": 0}
+
+    def policy(obs_others, obs_self, goals):          # tick 0: stay; afterwards agent 0 right, agent 1 left
+        a = torch.zeros(E, 2, dtype=torch.int32, device="cuda:0")
+        if tick["t"] > 0:
+            a[:, 0], a[:, 1] = 2, 1
+        tick["t"] += 1
+        return a
+    ro_f = ParticleRollout(fin, n_ticks=T, use_graph=False).collect(policy=policy)
+    tick["t"] = 0
+    ro_c = ParticleRollout(ctl, n_ticks=T, use_graph=False).collect(policy=policy)
+    assert bool(ro_f.done[0].all()) and not bool(ro_c.done[:T - 1].any()) and bool(ro_c.done[T - 1].all())
+    assert torch.equal(ro_f.state, ro_c.state)                         # identical physics: the collisions did happen
+    assert int(fin.collisions.min()) > 0 and torch.equal(fin.collisions, ctl.collisions)    # the reference's counter
+    assert int(fin.steps.min()) == T                                   # ... and its step counter keep counting
+    assert torch.equal(ro_f.valid.sum(0), torch.ones(E, dtype=torch.long, device="cuda:0"))  # one valid transition each
+    assert not bool(ro_f.episode_is_bad().any())                       # A: ended clean at tick 1
+    assert bool(ro_c.episode_is_bad().all())                           # B: collided inside its episode
+    assert int(ro_f.collisions[0].max()) == 0 and int(ro_f.collisions[T - 1].min()) > 0
 
 
 def test_episode_synchronous_rollout_is_bad_and_valid_across_collects():
@@ -120,7 +124,7 @@ def test_episode_synchronous_rollout_is_bad_and_valid_across_collects():
     E, N = 256, 2
     env = _penv(E, N, cfg="particle_stage2_merge.json", seed=13, max_steps=12)
     ro = ParticleRollout(env, n_ticks=12, use_graph=False).collect()
-    assert bool(env.finished.all()) and bool(ro.valid.all())
+    assert bool(ro._finished.all()) and bool(ro.valid.all())
     # per-episode collision count from the trajectory itself: every ordered colliding pair costs its agent 1.0 of reward
     # beyond -dist (multi-goal_spread.py:121-138), so reward_n + dist is minus the agent's collision count
     pos = ro.state[1:, :, :, 2:4]                                  # [T, N, E, 2]
@@ -128,7 +132,7 @@ def test_episode_synchronous_rollout_is_bad_and_valid_across_collects():
     hits = (-(ro.reward_n.permute(0, 2, 1) + dist)).round().clamp(min=0).sum((0, 1))
     assert torch.equal(ro.episode_is_bad(), hits > 0)
     assert 0 < int(ro.episode_is_bad().sum()) < E                  # both kinds occur
-    assert torch.equal(env.collisions.to(hits.dtype), hits)
+    assert torch.equal(ro.collisions[-1].to(hits.dtype), hits) and torch.equal(env.collisions, ro.collisions[-1])
     ro.collect(reset=False)                                        # nothing restarted them: all invalid
     assert int(ro.valid.sum()) == 0
     ro.collect(reset=True)
@@ -138,9 +142,9 @@ def test_episode_synchronous_rollout_is_bad_and_valid_across_collects():
 @pytest.mark.parametrize("kernel", ["env", "pair", "agent"])
 @pytest.mark.parametrize("fused", [False, True])
 def test_continuous_rollout_captures_terminal_collisions(kernel, fused):
-    """AUTO_RESET zeroes scenario.collisions in the launch that ends the episode; term_collisions keeps it (the is_bad
-    flag of train_onpolicy.py:356 in continuous mode).  Checked against a second env stepped tick by tick without
-    auto-reset and re-injected at every episode start."""
+    """AUTO_RESET zeroes scenario.collisions in the launch that ends the episode; the trajectory's per-tick `collisions`
+    slot keeps the pre-reset value (the is_bad flag of train_onpolicy.py:356 in continuous mode).  Every tick of every env
+    is checked against a second env stepped tick by tick without auto-reset and re-injected at every episode start."""
     from cm3_amd.rollout import ParticleRollout
     E, N, T, S = 192, 2, 30, 8
     env = _penv(E, N, dtype=torch.float64, cfg="particle_stage2_merge.json", seed=4, auto_reset=True, max_steps=S,
@@ -153,8 +157,8 @@ def test_continuous_rollout_captures_terminal_collisions(kernel, fused):
     for t in range(T):
         _, _, _, _, _, done = ref.step(ro.actions[t])
         assert torch.equal(done, ro.done[t].bool())
+        assert torch.equal(ro.collisions[t], ref.collisions)          # running count, every env, every tick
         if bool(done.any()):
-            assert torch.equal(ro.term_collisions[t][done], ref.collisions[done])
             assert torch.equal(ro.episode_is_bad()[t][done], ref.collisions[done] != 0)
             n_bad += int((ref.collisions[done] != 0).sum())
             assert bool(done.all())                                # every env ends at max_steps here
