@@ -107,7 +107,7 @@ class ParticleRollout(object):
         next-state/obs are captured per tick, goals are recorded per slot; every transition is valid.
     """
 
-    def __init__(self, env, n_ticks=None, use_graph=True, fused=False, n_chains=1):
+    def __init__(self, env, n_ticks=None, use_graph=True, fused=False, n_chains=1, record_collisions=True):
         self.env = env
         self.T = int(n_ticks or env.max_steps)
         self.use_graph = bool(use_graph)
@@ -139,7 +139,8 @@ class ParticleRollout(object):
             self.term_state = self.term_obs_others = None
         # scenario.collisions after every tick, before any same-launch reset: the per-episode value the reference reads
         # at train_onpolicy.py:356 sits at the tick that ends the episode
-        self.collisions = z(T, E, d=torch.int32)
+        # (record_collisions=False drops the slot: episode_is_bad() is then unavailable)
+        self.collisions = z(T, E, d=torch.int32) if record_collisions else None
         self._graph = None
         self._actor_graph = _ActorGraphCache(dev)
         # episode-synchronous mode: which envs' episodes have ended since their last reset (carried across collects)
@@ -178,8 +179,9 @@ class ParticleRollout(object):
             t.term_state_stride = N * E * 4 * es
             t.term_obs_others = self.term_obs_others[t0].data_ptr()
             t.term_obs_others_stride = E * N * L * es
-        t.collisions = self.collisions[t0].data_ptr()
-        t.collisions_stride = E * 4
+        if self.collisions is not None:
+            t.collisions = self.collisions[t0].data_ptr()
+            t.collisions_stride = E * 4
         return t
 
     def _enqueue(self, t0, n, flags, stream=None, chains=False):
@@ -305,6 +307,8 @@ class ParticleRollout(object):
         Episode-synchronous mode: bool [E]; an env still running at the end of this trajectory reports its count so far.
         Continuous mode: bool [T, E], set only where ``done`` is set (the count of the episode that ended at that tick,
         captured before the same-launch reset zeroes the live counter)."""
+        if self.collisions is None:
+            raise Cm3Error("episode_is_bad() needs ParticleRollout(record_collisions=True)")
         d = self.done.bool()
         if self.auto_reset:
             return (self.collisions != 0) & d
