@@ -11,16 +11,18 @@ import torch
 from .rollout import CheckersRollout, ParticleRollout
 
 
-def test_particle(env, actor, n_rounds=1, epsilon=0.0, rollout=None):
+def test_particle(env, actor, n_rounds=1, epsilon=0.0, rollout=None, reset=True):
     """-> (reward_local_avg [N], reward_global_avg, n_episodes) like evaluate.test_particle, over
-    n_rounds x env.n_envs episodes.  `env` must not auto-reset (one episode per env per round)."""
+    n_rounds x env.n_envs episodes.  `env` must not auto-reset (one episode per env per round).  `actor` is the on-device
+    ParticleActor or a host callable policy(obs_others, obs_self, goals) -> [E,N]; reset=False evaluates from the states
+    the env currently holds (state injection: how tests replay the episodes the reference evaluator saw)."""
     if env.auto_reset:
         raise ValueError("evaluation runs one episode per env: build the env with auto_reset=False")
     ro = rollout or ParticleRollout(env, use_graph=True)
     local_total = torch.zeros(env.n, dtype=torch.float64, device=env.device)
     global_total = torch.zeros((), dtype=torch.float64, device=env.device)
     for _ in range(int(n_rounds)):
-        ro.collect(policy=actor, epsilon=epsilon, reset=True)
+        ro.collect(policy=actor, epsilon=epsilon, reset=reset)
         g, l = ro.episode_returns()
         local_total += l.to(torch.float64).sum(0)
         global_total += g.to(torch.float64).sum()
@@ -30,11 +32,12 @@ def test_particle(env, actor, n_rounds=1, epsilon=0.0, rollout=None):
     return (local_total / n).cpu().numpy(), float(global_total / n), int(n)
 
 
-def test_checkers(env, actor, n_rounds=1, epsilon=0.0, rollout=None, generator=None):
+def test_checkers(env, actor, n_rounds=1, epsilon=0.0, rollout=None, generator=None, goals=None):
     """-> (reward_local_avg [N], reward_global_avg, n_episodes, dist_action [N,5]) like evaluate.test_checkers
     (alg/evaluate.py:159-203) over n_rounds x env.n_envs episodes: goals = eye(N), or one random one-hot goal per episode
     when N == 1 (:167-173); actions_prev starts at zeros (:178); dist_action is the normalised action histogram the
-    reference prints (:163,:183-184,:200-201)."""
+    reference prints (:163,:183-184,:200-201).  goals (optional, one-hot [E,N,2]) replaces the draw (tests replay the goals
+    the reference evaluator drew)."""
     if env.auto_reset:
         raise ValueError("evaluation runs one episode per env: build the env with auto_reset=False")
     ro = rollout or CheckersRollout(env, use_graph=True)
@@ -43,12 +46,14 @@ def test_checkers(env, actor, n_rounds=1, epsilon=0.0, rollout=None, generator=N
     global_total = torch.zeros((), dtype=torch.float64, device=dev)
     dist = torch.zeros(N, 5, dtype=torch.float64, device=dev)
     for _ in range(int(n_rounds)):
-        if N == 1:
+        if goals is not None:
+            g_round = torch.as_tensor(goals, device=dev)
+        elif N == 1:
             idx = torch.randint(0, 2, (env.E, 1), device=dev, generator=generator)
-            goals = torch.nn.functional.one_hot(idx, 2)
+            g_round = torch.nn.functional.one_hot(idx, 2)
         else:
-            goals = torch.eye(N, 2, device=dev)
-        ro.collect(goals, policy=actor, epsilon=epsilon)
+            g_round = torch.eye(N, 2, device=dev)
+        ro.collect(g_round, policy=actor, epsilon=epsilon)
         g, l = ro.episode_returns()
         local_total += l.sum(0)
         global_total += g.sum()

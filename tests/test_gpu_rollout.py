@@ -306,3 +306,60 @@ def test_checkers_in_place_rollout_with_draw_wave_equals_stepwise(E, stage):
     assert torch.equal(a._mask, b._mask) and torch.equal(a._agents, b._agents) and torch.equal(a._episode, b._episode)
     assert torch.equal(a._slots[0]["actions"], b._slots[b._cur]["actions"])
     st.close()
+
+
+# ---- batched evaluation against the REAL reference evaluators (alg/evaluate.py) -----------------------------------------
+def _particle_eval_policy(obs_others, obs_self, goals):
+    """the stand-in policy of oracle/gen_golden_evaluate.py (particle_policy), on device tensors"""
+    d = goals - obs_self[..., 2:4]
+    horiz = d[..., 0].abs() > d[..., 1].abs()
+    a = torch.where(horiz, torch.where(d[..., 0] > 0, 2, 1), torch.where(d[..., 1] > 0, 4, 3))
+    fast = (obs_self[..., 0] * obs_self[..., 0] + obs_self[..., 1] * obs_self[..., 1]) > 0.36
+    return torch.where(fast, torch.zeros_like(a), a).to(torch.int32)
+
+
+@pytest.mark.parametrize("tag", ["particle_n4", "particle_n1"])
+def test_batched_evaluation_equals_reference_test_particle(tag):
+    """cm3_amd.evaluate.test_particle == the REAL alg/evaluate.py:test_particle (:87-123), run in the build container on the
+    real reference env with a deterministic stand-in for alg.run_actor (oracle/gen_golden_evaluate.py): same reset states
+    (injected), same policy function, float64 -- per-agent and global return averages to 1e-9.  Pins the evaluator's
+    control flow and accumulation (one episode per env, stop counting at `done`, averages over n_eval), not a network."""
+    import os
+    from cm3_amd import evaluate as EV
+    from tests.helpers import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "evaluate_%s.npz" % tag))
+    N, n_eval = int(z["n_agents"]), int(z["n_eval"])
+    env = _penv(n_eval, N, cfg=str(z["config"]) + ".json", max_steps=int(z["max_steps"]))
+    gs = z["init_gs"]
+    env.set_state(gs[..., 2:4], gs[..., 0:2], z["landmarks"])
+    local, glob, n = EV.test_particle(env, _particle_eval_policy, reset=False)
+    assert n == n_eval
+    assert np.abs(local - z["reward_local_avg"]).max() < 1e-9 * np.abs(z["reward_local_avg"]).max()
+    assert abs(glob - float(z["reward_global_avg"])) < 1e-9 * abs(float(z["reward_global_avg"]))
+
+
+@pytest.mark.parametrize("tag", ["checkers_n2", "checkers_n1"])
+def test_batched_evaluation_equals_reference_test_checkers(tag):
+    """cm3_amd.evaluate.test_checkers == the REAL alg/evaluate.py:test_checkers (:159-203) with the goals it drew and an
+    integer-only stand-in policy that also depends on the episode index (= env index here): exact equality of the averages
+    up to the float64 summation order (1e-12).  The action histogram the reference only prints is not pinned."""
+    import os
+    from cm3_amd import evaluate as EV
+    from cm3_amd.checkers import VecCheckersEnv
+    from tests.helpers import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "evaluate_%s.npz" % tag))
+    N, n_eval = int(z["n_agents"]), int(z["n_eval"])
+    cfg = load_cfg(str(z["config"]) + ".json")
+    env = VecCheckersEnv(cfg["init"], N, int(z["max_steps"]), n_eval, device="cuda:0")
+    episode = torch.arange(n_eval, device="cuda:0").unsqueeze(1)
+    agent = torch.arange(N, device="cuda:0").unsqueeze(0)
+
+    def policy(actions_prev, obs_others, obs_self_t, obs_self_v, goals):
+        t = obs_self_t.to(torch.int64)                                            # [E, N, 5, 5, 3]
+        uncollected = (t[..., 0:2] == -1).flatten(2).sum(2)
+        walls = (t[..., 2] == 1).flatten(2).sum(2)
+        return ((uncollected + 3 * walls + 2 * actions_prev.to(torch.int64) + agent + episode) % 5).to(torch.int32)
+    local, glob, n, dist = EV.test_checkers(env, policy, goals=z["goals"].astype(np.int64))
+    assert n == n_eval and abs(float(dist.sum()) - 1.0) < 1e-12
+    assert np.abs(local - z["reward_local_avg"]).max() < 1e-12
+    assert abs(glob - float(z["reward_global_avg"])) < 1e-12
