@@ -527,6 +527,24 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step(const ParticlePara
 // vector (i,k), so a wave stores 64/G whole env records contiguously (16 B per lane, unit stride).
 // internal flag bits set by particle_rollout only (never part of the ABI; fill_params rejects unknown public bits)
 constexpr uint32_t kFlagPregenRead = 0x10000u, kFlagPregenWrite = 0x20000u;
+// EXPERIMENT (tools/store_policy_ab.py; not part of the ABI): how the pair mapping stores the observation rows, which no later
+// tick reads -- 0 plain, 1 non-temporal, 2 write-through (sc1: the line leaves the XCD's L2), 3 sc0 sc1.
+constexpr uint32_t kFlagObsStoreShift = 20, kFlagObsStoreMask = 3u << kFlagObsStoreShift;
+
+typedef float cm3_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_obs_policy(float4 *p, const float4 &v, uint32_t policy) {
+  const cm3_f4 t = {v.x, v.y, v.z, v.w};
+  if (policy == 1u) {
+    __builtin_nontemporal_store(t, reinterpret_cast<cm3_f4 *>(p));
+  } else if (policy == 2u) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(t) : "memory");
+  } else if (policy == 3u) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(t) : "memory");
+  } else {
+    *p = v;
+  }
+}
+__device__ __forceinline__ void store_obs_policy(double4 *p, const double4 &v, uint32_t) { *p = v; }
 
 template <int N> struct PairGeom {
   static constexpr int NO = N - 1;
@@ -750,7 +768,8 @@ __global__ void __launch_bounds__((WAVES + (SPLIT ? 1 : 0)) * 64)
       }
       // observation (multi-goal_spread.py:145-154): vector (i,k) of env e; lanes of a wave cover whole records
       if (slot_ok)
-        reinterpret_cast<V4 *>(tick_ptr(p.obs_others, p.st_obs, t))[e * SLOTS + gslot] = sub4<R, V4>(sj, si);
+        store_obs_policy(reinterpret_cast<V4 *>(tick_ptr(p.obs_others, p.st_obs, t)) + (e * SLOTS + gslot), sub4<R, V4>(sj, si),
+                         (h_flags & kFlagObsStoreMask) >> kFlagObsStoreShift);
     }
   }
 
@@ -1111,6 +1130,8 @@ static int fill_params(const cm3_particle_desc *d, const cm3_particle_bufs *b, P
   p.EN = d->env_count > 0 ? d->env_offset + d->env_count : d->n_envs;
   p.max_steps = d->max_steps;
   p.flags = d->flags & ~CM3_FLAG_FUSED_TICKS;
+  if (const char *pol = getenv("CM3_EXPERIMENT_OBS_STORE"))   // experiment only (tools/store_policy_ab.py)
+    p.flags |= ((uint32_t)atoi(pol) & 3u) << kFlagObsStoreShift;
   p.env_id_base = d->env_id_base;
   p.seed = d->seed;
   p.prob_random = d->prob_random;
