@@ -138,6 +138,29 @@ template <typename R, typename V4> __device__ __forceinline__ V4 sub4(const V4 &
   return r;
 }
 
+// How the observation rows are stored (no later tick reads them): 0 plain, 1 non-temporal, 2 write-through (sc1: the line
+// leaves the XCD's L2), 3 sc0 sc1.  particle_rollout selects 1 when every tick writes its OWN trajectory slot (stride != 0):
+// measured at C2 (profiles/r02_store_policy_ab.txt) 3.97 -> 3.53 us per tick; for a re-used buffer (stride 0, env.step's
+// double buffer) plain stores stay: nt is neutral to slightly negative there, write-through is worse in both cases.  The env
+// variable CM3_EXPERIMENT_OBS_STORE overrides the choice for tools/store_policy_ab.py.
+constexpr uint32_t kFlagObsStoreShift = 20, kFlagObsStoreMask = 3u << kFlagObsStoreShift;
+constexpr uint32_t kObsStoreNt = 1u << kFlagObsStoreShift;
+// 16-byte store of one observation vector with one of those cache policies
+typedef float cm3_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_obs_policy(float4 *p, const float4 &v, uint32_t policy) {
+  const cm3_f4 t = {v.x, v.y, v.z, v.w};
+  if (policy == 1u) {
+    __builtin_nontemporal_store(t, reinterpret_cast<cm3_f4 *>(p));
+  } else if (policy == 2u) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(t) : "memory");
+  } else if (policy == 3u) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(t) : "memory");
+  } else {
+    *p = v;
+  }
+}
+__device__ __forceinline__ void store_obs_policy(double4 *p, const double4 &v, uint32_t) { *p = v; }
+
 // np.sum(reward_n) as NumPy reduces a contiguous float64 vector (environment.py:107): left to right for
 // n < 8, eight interleaved accumulators folded as a fixed tree for n == 8 (oracle: np_list_sum).
 template <typename R, int N> __device__ __forceinline__ R sum_agents(const R (&v)[N]) {
@@ -221,7 +244,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 // s[i] = (vx, vy, px, py) of agent i.  Row i of obs_others = concat_{j != i, ascending}(s[j] - s[i]).
 template <typename R, int N>
 __device__ __forceinline__ void store_obs_others_staged(const typename Vec<R>::v4 (&s)[N], R *lds, int lane,
-                                                        size_t e0, int E, R *out) {
+                                                        size_t e0, int E, R *out, uint32_t policy = 0u) {
   using V4 = typename Vec<R>::v4;
   using G = ObsGeom<R, N>;
   constexpr int VPR = G::REC / 4;  // vectors per env record
@@ -247,7 +270,7 @@ __device__ __forceinline__ void store_obs_others_staged(const typename Vec<R>::v
     V4 *out4 = reinterpret_cast<V4 *>(out + row0 * G::REC);
     for (int f = lane; f < nvec; f += 64) {
       const int row = f / VPR, q = f - row * VPR;
-      out4[f] = lds4[(row * G::STRIDE) / 4 + q];
+      store_obs_policy(out4 + f, lds4[(row * G::STRIDE) / 4 + q], policy);
     }
     wave_lds_sync();
   }
@@ -500,7 +523,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step(const ParticlePara
     CM3_STAMP(4, false);
     // ---- observation (multi-goal_spread.py:145-154), env-major rows through the wave's LDS tile --------
     store_obs_others_staged<R, N>(s, &lds_all[wave][0], lane, e0, p.EN,
-                                  reinterpret_cast<R *>(tick_ptr(p.obs_others, p.st_obs, t)));
+                                  reinterpret_cast<R *>(tick_ptr(p.obs_others, p.st_obs, t)),
+                                  (p.flags & kFlagObsStoreMask) >> kFlagObsStoreShift);
     CM3_STAMP(5, false);
   }
 
@@ -527,24 +551,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step(const ParticlePara
 // vector (i,k), so a wave stores 64/G whole env records contiguously (16 B per lane, unit stride).
 // internal flag bits set by particle_rollout only (never part of the ABI; fill_params rejects unknown public bits)
 constexpr uint32_t kFlagPregenRead = 0x10000u, kFlagPregenWrite = 0x20000u;
-// EXPERIMENT (tools/store_policy_ab.py; not part of the ABI): how the pair mapping stores the observation rows, which no later
-// tick reads -- 0 plain, 1 non-temporal, 2 write-through (sc1: the line leaves the XCD's L2), 3 sc0 sc1.
-constexpr uint32_t kFlagObsStoreShift = 20, kFlagObsStoreMask = 3u << kFlagObsStoreShift;
 
-typedef float cm3_f4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void store_obs_policy(float4 *p, const float4 &v, uint32_t policy) {
-  const cm3_f4 t = {v.x, v.y, v.z, v.w};
-  if (policy == 1u) {
-    __builtin_nontemporal_store(t, reinterpret_cast<cm3_f4 *>(p));
-  } else if (policy == 2u) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(t) : "memory");
-  } else if (policy == 3u) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(t) : "memory");
-  } else {
-    *p = v;
-  }
-}
-__device__ __forceinline__ void store_obs_policy(double4 *p, const double4 &v, uint32_t) { *p = v; }
+
 
 template <int N> struct PairGeom {
   static constexpr int NO = N - 1;
@@ -853,7 +861,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_agents(const Parti
     }
     wave_lds_sync();
     V4 *out4 = reinterpret_cast<V4 *>(dst) + e0 * VPE;
-    for (int f = lane; f < nvec; f += 64) out4[f] = lds4[f];
+    for (int f = lane; f < nvec; f += 64) store_obs_policy(out4 + f, lds4[f], (p.flags & kFlagObsStoreMask) >> kFlagObsStoreShift);
     wave_lds_sync();
   };
 
@@ -1130,8 +1138,6 @@ static int fill_params(const cm3_particle_desc *d, const cm3_particle_bufs *b, P
   p.EN = d->env_count > 0 ? d->env_offset + d->env_count : d->n_envs;
   p.max_steps = d->max_steps;
   p.flags = d->flags & ~CM3_FLAG_FUSED_TICKS;
-  if (const char *pol = getenv("CM3_EXPERIMENT_OBS_STORE"))   // experiment only (tools/store_policy_ab.py)
-    p.flags |= ((uint32_t)atoi(pol) & 3u) << kFlagObsStoreShift;
   p.env_id_base = d->env_id_base;
   p.seed = d->seed;
   p.prob_random = d->prob_random;
@@ -1289,6 +1295,12 @@ static int particle_call(const cm3_particle_desc *d, const cm3_particle_bufs *b,
   return launch<R>(p, d->n_agents, op, (hipStream_t)stream);
 }
 
+// store flavour of the observation rows for a rollout: non-temporal when every tick has its own slot (see kFlagObsStore*)
+static uint32_t obs_store_policy(size_t obs_stride) {
+  if (const char *pol = getenv("CM3_EXPERIMENT_OBS_STORE")) return ((uint32_t)atoi(pol) & 3u) << kFlagObsStoreShift;
+  return obs_stride != 0 ? kObsStoreNt : 0u;
+}
+
 template <typename R>
 static int particle_rollout(const cm3_particle_desc *d, const cm3_particle_traj *t, int32_t n_ticks, void *stream) {
   CM3_REQUIRE(d && t, "null desc/traj");
@@ -1334,6 +1346,7 @@ static int particle_rollout(const cm3_particle_desc *d, const cm3_particle_traj 
     p.st_term_state = t->term_state_stride;
     p.st_term_obs = t->term_obs_others_stride;
     p.st_coll = t->collisions_stride;
+    p.flags |= obs_store_policy(t->obs_others_stride);
     return launch<R>(p, d->n_agents, kStep, (hipStream_t)stream);
   }
   for (int k = 0; k < n_ticks; ++k) {
@@ -1357,6 +1370,7 @@ static int particle_rollout(const cm3_particle_desc *d, const cm3_particle_traj 
     ParticleParams p;
     int rc = fill_params(d, &b, kStep, nullptr, p);
     if (rc != CM3_OK) return rc;
+    p.flags |= obs_store_policy(t->obs_others_stride);
     if ((d->flags & CM3_FLAG_GEN_ACTIONS) && n_ticks > 1) {
       // Random-action branch: tick k also draws the actions of tick k + 1 (its draw wave, see k_particle_step_pairs) and
       // tick k + 1 reads them with its other inputs.  Only the pair mapping with 4-wave workgroups in float32 honours the
