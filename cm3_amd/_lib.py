@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcm3_hip.so")
+# CM3_AMD_LIB: load another build of the SAME ABI instead (tools/*_ab.py compare two builds on one box)
+LIB_PATH = os.environ.get("CM3_AMD_LIB") or os.path.join(_HERE, "libcm3_hip.so")
 MAX_AGENTS = 8
 ABI_VERSION = 3
 

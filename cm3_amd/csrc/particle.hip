@@ -268,9 +268,16 @@ __device__ __forceinline__ void store_obs_others_staged(const typename Vec<R>::v
     rows_here = rows_here < 0 ? 0 : (rows_here > G::ROWS ? G::ROWS : rows_here);
     const int nvec = (int)rows_here * VPR;
     V4 *out4 = reinterpret_cast<V4 *>(out + row0 * G::REC);
-    for (int f = lane; f < nvec; f += 64) {
-      const int row = f / VPR, q = f - row * VPR;
-      store_obs_policy(out4 + f, lds4[(row * G::STRIDE) / 4 + q], policy);
+    if (policy == 0u) {  // the flavour is launch-uniform: keep the copy-out loops free of it
+      for (int f = lane; f < nvec; f += 64) {
+        const int row = f / VPR, q = f - row * VPR;
+        out4[f] = lds4[(row * G::STRIDE) / 4 + q];
+      }
+    } else {
+      for (int f = lane; f < nvec; f += 64) {
+        const int row = f / VPR, q = f - row * VPR;
+        store_obs_policy(out4 + f, lds4[(row * G::STRIDE) / 4 + q], policy);
+      }
     }
     wave_lds_sync();
   }
@@ -861,7 +868,12 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_agents(const Parti
     }
     wave_lds_sync();
     V4 *out4 = reinterpret_cast<V4 *>(dst) + e0 * VPE;
-    for (int f = lane; f < nvec; f += 64) store_obs_policy(out4 + f, lds4[f], (p.flags & kFlagObsStoreMask) >> kFlagObsStoreShift);
+    const uint32_t policy = (p.flags & kFlagObsStoreMask) >> kFlagObsStoreShift;
+    if (policy == 0u) {  // the flavour is launch-uniform: keep the copy-out loops free of it
+      for (int f = lane; f < nvec; f += 64) out4[f] = lds4[f];
+    } else {
+      for (int f = lane; f < nvec; f += 64) store_obs_policy(out4 + f, lds4[f], policy);
+    }
     wave_lds_sync();
   };
 
@@ -1295,10 +1307,14 @@ static int particle_call(const cm3_particle_desc *d, const cm3_particle_bufs *b,
   return launch<R>(p, d->n_agents, op, (hipStream_t)stream);
 }
 
-// store flavour of the observation rows for a rollout: non-temporal when every tick has its own slot (see kFlagObsStore*)
-static uint32_t obs_store_policy(size_t obs_stride) {
+// Store flavour of the observation rows for a rollout: non-temporal when the rollout's observation slots are a STREAM -- more
+// bytes than the cache hierarchy keeps (half of the 256 MB Infinity Cache) -- and plain when they are small enough to stay
+// cached and be re-read (returns / normalisation / sampling right after a short rollout).  Measured, us per tick plain -> nt
+// (profiles/r02_obs_store_by_workload.txt): C4 26 MB 4.17 -> 4.19-4.22 (plain wins), C2 254 MB 3.96 -> 3.53, C5 2.3 GB
+// 9.37 -> 8.97; any threshold between 26 and 254 MB fits these three points.
+static uint32_t obs_store_policy(size_t obs_stride, int n_ticks) {
   if (const char *pol = getenv("CM3_EXPERIMENT_OBS_STORE")) return ((uint32_t)atoi(pol) & 3u) << kFlagObsStoreShift;
-  return obs_stride != 0 ? kObsStoreNt : 0u;
+  return obs_stride * (size_t)n_ticks >= ((size_t)128 << 20) ? kObsStoreNt : 0u;
 }
 
 template <typename R>
@@ -1346,7 +1362,7 @@ static int particle_rollout(const cm3_particle_desc *d, const cm3_particle_traj 
     p.st_term_state = t->term_state_stride;
     p.st_term_obs = t->term_obs_others_stride;
     p.st_coll = t->collisions_stride;
-    p.flags |= obs_store_policy(t->obs_others_stride);
+    p.flags |= obs_store_policy(t->obs_others_stride, n_ticks);
     return launch<R>(p, d->n_agents, kStep, (hipStream_t)stream);
   }
   for (int k = 0; k < n_ticks; ++k) {
@@ -1370,7 +1386,7 @@ static int particle_rollout(const cm3_particle_desc *d, const cm3_particle_traj 
     ParticleParams p;
     int rc = fill_params(d, &b, kStep, nullptr, p);
     if (rc != CM3_OK) return rc;
-    p.flags |= obs_store_policy(t->obs_others_stride);
+    p.flags |= obs_store_policy(t->obs_others_stride, n_ticks);
     if ((d->flags & CM3_FLAG_GEN_ACTIONS) && n_ticks > 1) {
       // Random-action branch: tick k also draws the actions of tick k + 1 (its draw wave, see k_particle_step_pairs) and
       // tick k + 1 reads them with its other inputs.  Only the pair mapping with 4-wave workgroups in float32 honours the
