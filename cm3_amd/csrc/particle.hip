@@ -138,28 +138,23 @@ template <typename R, typename V4> __device__ __forceinline__ V4 sub4(const V4 &
   return r;
 }
 
-// How the observation rows are stored (no later tick reads them): 0 plain, 1 non-temporal, 2 write-through (sc1: the line
-// leaves the XCD's L2), 3 sc0 sc1.  particle_rollout selects 1 when every tick writes its OWN trajectory slot (stride != 0):
-// measured at C2 (profiles/r02_store_policy_ab.txt) 3.97 -> 3.53 us per tick; for a re-used buffer (stride 0, env.step's
-// double buffer) plain stores stay: nt is neutral to slightly negative there, write-through is worse in both cases.  The env
-// variable CM3_EXPERIMENT_OBS_STORE overrides the choice for tools/store_policy_ab.py.
-constexpr uint32_t kFlagObsStoreShift = 20, kFlagObsStoreMask = 3u << kFlagObsStoreShift;
-constexpr uint32_t kObsStoreNt = 1u << kFlagObsStoreShift;
-// 16-byte store of one observation vector with one of those cache policies
+// How the observation rows are stored (no later tick reads them).  NT = non-temporal: chosen by particle_rollout when the
+// rollout's observation slots are a STREAM (see obs_store_nt); a COMPILE-TIME parameter of the step kernels, so the plain
+// instantiations are byte for byte the code without this feature.  (A first version selected among four flavours at run
+// time: that alone cost 1-3 % on every kernel that carried it -- profiles/r02_base_vs_new_runtime_flavours.txt -- and the
+// write-through flavours it also offered bought nothing, profiles/r02_store_policy_ab.txt.)
+constexpr uint32_t kFlagObsStoreNt = 0x100000u;  // internal launch flag, set by particle_rollout only
+
 typedef float cm3_f4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void store_obs_policy(float4 *p, const float4 &v, uint32_t policy) {
-  const cm3_f4 t = {v.x, v.y, v.z, v.w};
-  if (policy == 1u) {
+template <bool NT> __device__ __forceinline__ void store_obs_vec(float4 *p, const float4 &v) {
+  if constexpr (NT) {
+    const cm3_f4 t = {v.x, v.y, v.z, v.w};
     __builtin_nontemporal_store(t, reinterpret_cast<cm3_f4 *>(p));
-  } else if (policy == 2u) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(t) : "memory");
-  } else if (policy == 3u) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(t) : "memory");
   } else {
     *p = v;
   }
 }
-__device__ __forceinline__ void store_obs_policy(double4 *p, const double4 &v, uint32_t) { *p = v; }
+template <bool NT> __device__ __forceinline__ void store_obs_vec(double4 *p, const double4 &v) { *p = v; }
 
 // np.sum(reward_n) as NumPy reduces a contiguous float64 vector (environment.py:107): left to right for
 // n < 8, eight interleaved accumulators folded as a fixed tree for n == 8 (oracle: np_list_sum).
@@ -242,9 +237,9 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 
 // s[i] = (vx, vy, px, py) of agent i.  Row i of obs_others = concat_{j != i, ascending}(s[j] - s[i]).
-template <typename R, int N>
+template <typename R, int N, bool NT = false>
 __device__ __forceinline__ void store_obs_others_staged(const typename Vec<R>::v4 (&s)[N], R *lds, int lane,
-                                                        size_t e0, int E, R *out, uint32_t policy = 0u) {
+                                                        size_t e0, int E, R *out) {
   using V4 = typename Vec<R>::v4;
   using G = ObsGeom<R, N>;
   constexpr int VPR = G::REC / 4;  // vectors per env record
@@ -268,16 +263,9 @@ __device__ __forceinline__ void store_obs_others_staged(const typename Vec<R>::v
     rows_here = rows_here < 0 ? 0 : (rows_here > G::ROWS ? G::ROWS : rows_here);
     const int nvec = (int)rows_here * VPR;
     V4 *out4 = reinterpret_cast<V4 *>(out + row0 * G::REC);
-    if (policy == 0u) {  // the flavour is launch-uniform: keep the copy-out loops free of it
-      for (int f = lane; f < nvec; f += 64) {
-        const int row = f / VPR, q = f - row * VPR;
-        out4[f] = lds4[(row * G::STRIDE) / 4 + q];
-      }
-    } else {
-      for (int f = lane; f < nvec; f += 64) {
-        const int row = f / VPR, q = f - row * VPR;
-        store_obs_policy(out4 + f, lds4[(row * G::STRIDE) / 4 + q], policy);
-      }
+    for (int f = lane; f < nvec; f += 64) {
+      const int row = f / VPR, q = f - row * VPR;
+      store_obs_vec<NT>(out4 + f, lds4[(row * G::STRIDE) / 4 + q]);
     }
     wave_lds_sync();
   }
@@ -361,7 +349,7 @@ __device__ __forceinline__ void init_episode(const ParticleParams &p, uint64_t g
 }
 
 // ---- the step kernel --------------------------------------------------------------------------------
-template <typename R, int N, int WAVES, bool FUSED>
+template <typename R, int N, int WAVES, bool FUSED, bool NT = false>
 __global__ void __launch_bounds__(WAVES * 64) k_particle_step(const ParticleParams p) {
   using V4 = typename Vec<R>::v4;
   using V2 = typename Vec<R>::v2;
@@ -529,9 +517,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step(const ParticlePara
 
     CM3_STAMP(4, false);
     // ---- observation (multi-goal_spread.py:145-154), env-major rows through the wave's LDS tile --------
-    store_obs_others_staged<R, N>(s, &lds_all[wave][0], lane, e0, p.EN,
-                                  reinterpret_cast<R *>(tick_ptr(p.obs_others, p.st_obs, t)),
-                                  (p.flags & kFlagObsStoreMask) >> kFlagObsStoreShift);
+    store_obs_others_staged<R, N, NT>(s, &lds_all[wave][0], lane, e0, p.EN,
+                                      reinterpret_cast<R *>(tick_ptr(p.obs_others, p.st_obs, t)));
     CM3_STAMP(5, false);
   }
 
@@ -584,7 +571,7 @@ template <int N> struct PairGeom {
 // matters when the trajectory is stepped in place (stride 0: this tick's and the next tick's rows are the same memory):
 // physics read (registers) -> barrier 1 -> draw-wave store (drained) -> barrier 2 -> physics redraw store.  Values and
 // final memory contents are identical to drawing at the head of every launch.
-template <typename R, int N, int WAVES, bool FUSED, bool SPLIT = false>
+template <typename R, int N, int WAVES, bool FUSED, bool SPLIT = false, bool NT = false>
 __global__ void __launch_bounds__((WAVES + (SPLIT ? 1 : 0)) * 64)
     k_particle_step_pairs(const void *h_state_in, const void *h_goals_in, const int32_t *h_meta_in, const int32_t *h_episode,
                           const int32_t *h_actions, const int h_E, const uint32_t h_flags, const int h_E0, const int h_EN,
@@ -783,8 +770,7 @@ __global__ void __launch_bounds__((WAVES + (SPLIT ? 1 : 0)) * 64)
       }
       // observation (multi-goal_spread.py:145-154): vector (i,k) of env e; lanes of a wave cover whole records
       if (slot_ok)
-        store_obs_policy(reinterpret_cast<V4 *>(tick_ptr(p.obs_others, p.st_obs, t)) + (e * SLOTS + gslot), sub4<R, V4>(sj, si),
-                         (h_flags & kFlagObsStoreMask) >> kFlagObsStoreShift);
+        store_obs_vec<NT>(reinterpret_cast<V4 *>(tick_ptr(p.obs_others, p.st_obs, t)) + (e * SLOTS + gslot), sub4<R, V4>(sj, si));
     }
   }
 
@@ -817,7 +803,7 @@ template <int N> struct AgentGeom {
   static constexpr int VPE = N * NO;        // obs vectors per env record
 };
 
-template <typename R, int N, int WAVES, bool FUSED>
+template <typename R, int N, int WAVES, bool FUSED, bool NT = false>
 __global__ void __launch_bounds__(WAVES * 64) k_particle_step_agents(const ParticleParams p) {
   static_assert(N >= 2, "the agent mapping needs at least two agents");
   using V4 = typename Vec<R>::v4;
@@ -868,12 +854,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_agents(const Parti
     }
     wave_lds_sync();
     V4 *out4 = reinterpret_cast<V4 *>(dst) + e0 * VPE;
-    const uint32_t policy = (p.flags & kFlagObsStoreMask) >> kFlagObsStoreShift;
-    if (policy == 0u) {  // the flavour is launch-uniform: keep the copy-out loops free of it
-      for (int f = lane; f < nvec; f += 64) out4[f] = lds4[f];
-    } else {
-      for (int f = lane; f < nvec; f += 64) store_obs_policy(out4 + f, lds4[f], policy);
-    }
+    for (int f = lane; f < nvec; f += 64) store_obs_vec<NT>(out4 + f, lds4[f]);
     wave_lds_sync();
   };
 
@@ -1184,12 +1165,17 @@ static int launch_one(const ParticleParams &p, ParticleOp op, hipStream_t stream
   const unsigned per_block = WAVES * 64;
   const unsigned blocks = (unsigned)(((size_t)(p.EN - p.E0) + per_block - 1) / per_block);
   switch (op) {
-    case kStep:
-      if (p.n_ticks > 1)
-        hipLaunchKernelGGL((k_particle_step<R, N, WAVES, true>), dim3(blocks), dim3(per_block), 0, stream, p);
-      else
-        hipLaunchKernelGGL((k_particle_step<R, N, WAVES, false>), dim3(blocks), dim3(per_block), 0, stream, p);
+    case kStep: {
+      const bool nt = sizeof(R) == 4 && (p.flags & kFlagObsStoreNt);   // streaming-size trajectory (obs_store_nt)
+      if (p.n_ticks > 1) {
+        if (nt) hipLaunchKernelGGL((k_particle_step<R, N, WAVES, true, sizeof(R) == 4>), dim3(blocks), dim3(per_block), 0, stream, p);
+        else hipLaunchKernelGGL((k_particle_step<R, N, WAVES, true>), dim3(blocks), dim3(per_block), 0, stream, p);
+      } else {
+        if (nt) hipLaunchKernelGGL((k_particle_step<R, N, WAVES, false, sizeof(R) == 4>), dim3(blocks), dim3(per_block), 0, stream, p);
+        else hipLaunchKernelGGL((k_particle_step<R, N, WAVES, false>), dim3(blocks), dim3(per_block), 0, stream, p);
+      }
       break;
+    }
     case kReset:
       hipLaunchKernelGGL((k_particle_reset<R, N, WAVES>), dim3(blocks), dim3(per_block), 0, stream, p);
       break;
@@ -1214,19 +1200,26 @@ template <typename R, int N, int WAVES> static int launch_pairs(const ParticlePa
     if constexpr (kCanSplit)
       split = p.n_ticks == 1 && (p.flags & CM3_FLAG_GEN_ACTIONS) && (p.flags & (kFlagPregenRead | kFlagPregenWrite)) &&
               all_blocks * WAVES <= 1024;
+    constexpr bool kF32 = sizeof(R) == 4;
+    const bool nt = kF32 && (p.flags & kFlagObsStoreNt);   // streaming-size trajectory (obs_store_nt)
+#define CM3_LAUNCH_PAIRS(FUSED_, SPLIT_, NT_, THREADS_)                                                                     \
+  hipLaunchKernelGGL((k_particle_step_pairs<R, N, WAVES, FUSED_, SPLIT_, NT_>), dim3(blocks), dim3(THREADS_), 0, stream,    \
+                     p.state_in, p.goals_in, p.meta_in, (const int32_t *)p.episode, (const int32_t *)p.actions, p.E, p.flags, \
+                     p.E0, p.EN, p)
     if (p.n_ticks > 1) {
-      hipLaunchKernelGGL((k_particle_step_pairs<R, N, WAVES, true>), dim3(blocks), dim3(WAVES * 64), 0, stream, p.state_in,
-                         p.goals_in, p.meta_in, (const int32_t *)p.episode, (const int32_t *)p.actions, p.E, p.flags, p.E0, p.EN, p);
+      if (nt) CM3_LAUNCH_PAIRS(true, false, kF32, WAVES * 64);
+      else CM3_LAUNCH_PAIRS(true, false, false, WAVES * 64);
     } else if (split) {
       // a tick of cm3_particle_rollout_* with in-kernel actions: the extra wave draws the next launch's actions (SPLIT)
-      if constexpr (kCanSplit)
-        hipLaunchKernelGGL((k_particle_step_pairs<R, N, WAVES, false, true>), dim3(blocks), dim3((WAVES + 1) * 64), 0, stream,
-                           p.state_in, p.goals_in, p.meta_in, (const int32_t *)p.episode, (const int32_t *)p.actions, p.E,
-                           p.flags, p.E0, p.EN, p);
+      if constexpr (kCanSplit) {
+        if (nt) CM3_LAUNCH_PAIRS(false, true, kF32, (WAVES + 1) * 64);
+        else CM3_LAUNCH_PAIRS(false, true, false, (WAVES + 1) * 64);
+      }
     } else {
-      hipLaunchKernelGGL((k_particle_step_pairs<R, N, WAVES, false>), dim3(blocks), dim3(WAVES * 64), 0, stream, p.state_in,
-                         p.goals_in, p.meta_in, (const int32_t *)p.episode, (const int32_t *)p.actions, p.E, p.flags, p.E0, p.EN, p);
+      if (nt) CM3_LAUNCH_PAIRS(false, false, kF32, WAVES * 64);
+      else CM3_LAUNCH_PAIRS(false, false, false, WAVES * 64);
     }
+#undef CM3_LAUNCH_PAIRS
     CM3_HIP_CHECK(hipGetLastError());
     return CM3_OK;
   } else {
@@ -1243,10 +1236,14 @@ template <typename R, int N, int WAVES> static int launch_agents(const ParticleP
   if constexpr (N >= 2) {
     const size_t envs_per_block = (size_t)WAVES * AgentGeom<N>::EPW;
     const unsigned blocks = (unsigned)(((size_t)(p.EN - p.E0) + envs_per_block - 1) / envs_per_block);
-    if (p.n_ticks > 1)
-      hipLaunchKernelGGL((k_particle_step_agents<R, N, WAVES, true>), dim3(blocks), dim3(WAVES * 64), 0, stream, p);
-    else
-      hipLaunchKernelGGL((k_particle_step_agents<R, N, WAVES, false>), dim3(blocks), dim3(WAVES * 64), 0, stream, p);
+    const bool nt = sizeof(R) == 4 && (p.flags & kFlagObsStoreNt);   // streaming-size trajectory (obs_store_nt)
+    if (p.n_ticks > 1) {
+      if (nt) hipLaunchKernelGGL((k_particle_step_agents<R, N, WAVES, true, sizeof(R) == 4>), dim3(blocks), dim3(WAVES * 64), 0, stream, p);
+      else hipLaunchKernelGGL((k_particle_step_agents<R, N, WAVES, true>), dim3(blocks), dim3(WAVES * 64), 0, stream, p);
+    } else {
+      if (nt) hipLaunchKernelGGL((k_particle_step_agents<R, N, WAVES, false, sizeof(R) == 4>), dim3(blocks), dim3(WAVES * 64), 0, stream, p);
+      else hipLaunchKernelGGL((k_particle_step_agents<R, N, WAVES, false>), dim3(blocks), dim3(WAVES * 64), 0, stream, p);
+    }
     CM3_HIP_CHECK(hipGetLastError());
     return CM3_OK;
   } else {
@@ -1307,14 +1304,11 @@ static int particle_call(const cm3_particle_desc *d, const cm3_particle_bufs *b,
   return launch<R>(p, d->n_agents, op, (hipStream_t)stream);
 }
 
-// Store flavour of the observation rows for a rollout: non-temporal when the rollout's observation slots are a STREAM -- more
-// bytes than the cache hierarchy keeps (half of the 256 MB Infinity Cache) -- and plain when they are small enough to stay
-// cached and be re-read (returns / normalisation / sampling right after a short rollout).  Measured, us per tick plain -> nt
-// (profiles/r02_obs_store_by_workload.txt): C4 26 MB 4.17 -> 4.19-4.22 (plain wins), C2 254 MB 3.96 -> 3.53, C5 2.3 GB
-// 9.37 -> 8.97; any threshold between 26 and 254 MB fits these three points.
-static uint32_t obs_store_policy(size_t obs_stride, int n_ticks) {
-  if (const char *pol = getenv("CM3_EXPERIMENT_OBS_STORE")) return ((uint32_t)atoi(pol) & 3u) << kFlagObsStoreShift;
-  return obs_stride * (size_t)n_ticks >= ((size_t)128 << 20) ? kObsStoreNt : 0u;
+// Non-temporal observation stores for a rollout whose observation slots are a STREAM -- more bytes than the cache hierarchy
+// keeps (half of the 256 MB Infinity Cache) -- and plain ones when they are small enough to stay cached and be re-read (returns
+// / normalisation / sampling right after a short rollout).  float32 only.  Measured support: see DESIGN.md section 0.
+static uint32_t obs_store_nt(size_t obs_stride, int n_ticks) {
+  return obs_stride * (size_t)n_ticks >= ((size_t)128 << 20) ? kFlagObsStoreNt : 0u;
 }
 
 template <typename R>
@@ -1362,7 +1356,7 @@ static int particle_rollout(const cm3_particle_desc *d, const cm3_particle_traj 
     p.st_term_state = t->term_state_stride;
     p.st_term_obs = t->term_obs_others_stride;
     p.st_coll = t->collisions_stride;
-    p.flags |= obs_store_policy(t->obs_others_stride, n_ticks);
+    p.flags |= obs_store_nt(t->obs_others_stride, n_ticks);
     return launch<R>(p, d->n_agents, kStep, (hipStream_t)stream);
   }
   for (int k = 0; k < n_ticks; ++k) {
@@ -1386,7 +1380,7 @@ static int particle_rollout(const cm3_particle_desc *d, const cm3_particle_traj 
     ParticleParams p;
     int rc = fill_params(d, &b, kStep, nullptr, p);
     if (rc != CM3_OK) return rc;
-    p.flags |= obs_store_policy(t->obs_others_stride, n_ticks);
+    p.flags |= obs_store_nt(t->obs_others_stride, n_ticks);
     if ((d->flags & CM3_FLAG_GEN_ACTIONS) && n_ticks > 1) {
       // Random-action branch: tick k also draws the actions of tick k + 1 (its draw wave, see k_particle_step_pairs) and
       // tick k + 1 reads them with its other inputs.  Only the pair mapping with 4-wave workgroups in float32 honours the
