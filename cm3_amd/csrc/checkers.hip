@@ -79,6 +79,7 @@ template <typename T> __device__ __forceinline__ T *ck_tick_ptr(T *base, size_t 
 
 // internal flag bits set by ck_rollout only (never part of the ABI): see k_checkers_step_fast (SPLIT)
 constexpr uint32_t kCkPregenRead = 0x10000u, kCkPregenWrite = 0x20000u;
+constexpr uint32_t kCkObsStoreNt = 0x100000u;  // internal: non-temporal observation stores (set by ck_rollout only)
 
 constexpr int kCkLdsBytes = 40960;  // per-wave staging tile (64 rows x up to 640 bytes)
 
@@ -540,7 +541,40 @@ __device__ __forceinline__ CkOut ck_out_term(const CheckersParams &p, int t) {
   return o;
 }
 
-template <int N>
+// Observation stores of the fast kernel.  NT = non-temporal: chosen by ck_rollout when the rollout's observation slots are a
+// stream (>= 128 MB, like the particle kernels: nothing re-reads them soon); a compile-time parameter, so the plain
+// instantiation is the code without this feature.
+typedef uint32_t ck_u4 __attribute__((ext_vector_type(4)));
+typedef double ck_d2 __attribute__((ext_vector_type(2)));
+template <bool NT> __device__ __forceinline__ void ck_st(uint32_t *p, uint32_t v) {
+  if constexpr (NT) __builtin_nontemporal_store(v, p); else *p = v;
+}
+template <bool NT> __device__ __forceinline__ void ck_st(int4 *p, const int4 &v) {
+  if constexpr (NT) {
+    const ck_u4 t = {(uint32_t)v.x, (uint32_t)v.y, (uint32_t)v.z, (uint32_t)v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<ck_u4 *>(p));
+  } else {
+    *p = v;
+  }
+}
+template <bool NT> __device__ __forceinline__ void ck_st(double2 *p, const double2 &v) {
+  if constexpr (NT) {
+    const ck_d2 t = {v.x, v.y};
+    __builtin_nontemporal_store(t, reinterpret_cast<ck_d2 *>(p));
+  } else {
+    *p = v;
+  }
+}
+template <bool NT> __device__ __forceinline__ void ck_st(double4 *p, const double4 &v) {
+  if constexpr (NT) {
+    ck_st<true>(reinterpret_cast<double2 *>(p), make_double2(v.x, v.y));
+    ck_st<true>(reinterpret_cast<double2 *>(p) + 1, make_double2(v.z, v.w));
+  } else {
+    *p = v;
+  }
+}
+
+template <int N, bool NT = false>
 __device__ __forceinline__ void ckf_emit(const CheckersParams &p, const CkState<N> &s, int g, size_t e, bool env_ok,
                                          const CkOut &out) {
   using F = CkFast<N>;
@@ -549,11 +583,11 @@ __device__ __forceinline__ void ckf_emit(const CheckersParams &p, const CkState<
   // grid record: dword g
   const int gd = p.grid_stride >> 2;
   const uint32_t m32 = (uint32_t)s.mask;  // 24 collected bits
-  for (int d = g; d < gd; d += F::G) reinterpret_cast<uint32_t *>(out.grid + e * (size_t)p.grid_stride)[d] = ckf_grid_dword<N>(m32, d);
+  for (int d = g; d < gd; d += F::G) ck_st<NT>(reinterpret_cast<uint32_t *>(out.grid + e * (size_t)p.grid_stride) + d, ckf_grid_dword<N>(m32, d));
   // obs_self_t record: dwords g, g+16, ...
   const int od = p.obst_stride >> 2;
   uint32_t *o32 = reinterpret_cast<uint32_t *>(out.obs_self_t + e * (size_t)p.obst_stride);
-  for (int d = g; d < od; d += F::G) o32[d] = ckf_obst_dword<N>(s, m32, d);
+  for (int d = g; d < od; d += F::G) ck_st<NT>(o32 + d, ckf_obst_dword<N>(s, m32, d));
   // small vector outputs: lane i (< N) writes agent i's rows
   if (g < N) {
     int ri = s.r[0], ci = s.c[0], gi = s.ng[0], oi = s.no[0];
@@ -569,14 +603,14 @@ __device__ __forceinline__ void ckf_emit(const CheckersParams &p, const CkState<
     v.y = ci;
     v.z = gi;
     v.w = oi;
-    reinterpret_cast<int4 *>(out.vec)[e * N + g] = v;
+    ck_st<NT>(reinterpret_cast<int4 *>(out.vec) + (e * N + g), v);
     const double half = (double)(F::R * F::C) / 2.0;
     double4 sv;
     sv.x = ((double)ri - (double)F::TR / 2.0) / (double)F::TR;
     sv.y = ((double)ci - (double)F::TC / 2.0) / (double)F::TC;
     sv.z = (double)gi / half;
     sv.w = (double)oi / half;
-    reinterpret_cast<double4 *>(out.obs_self_v)[e * N + g] = sv;
+    ck_st<NT>(reinterpret_cast<double4 *>(out.obs_self_v) + (e * N + g), sv);
     double2 *oo = reinterpret_cast<double2 *>(out.obs_others) + (e * N + g) * NO;
 #pragma unroll
     for (int k = 0; k < NO; ++k) {
@@ -591,7 +625,7 @@ __device__ __forceinline__ void ckf_emit(const CheckersParams &p, const CkState<
       double2 t;
       t.x = ((double)rj - (double)F::TR / 2.0) / (double)F::TR;
       t.y = ((double)cj - (double)F::TC / 2.0) / (double)F::TC;
-      oo[k] = t;
+      ck_st<NT>(oo + k, t);
     }
   }
 }
@@ -603,7 +637,7 @@ __device__ __forceinline__ void ckf_emit(const CheckersParams &p, const CkState<
 // their row redrawn for (episode + 1, step 0) by their writer lane.  Two barriers order the accesses to an action row (the
 // same memory for this tick and the next when the trajectory is stepped in place): tick waves have consumed their actions
 // -> barrier 1 -> draw-wave store (drained) -> barrier 2 -> redraw store.
-template <int N, bool FUSED, bool SPLIT = false>
+template <int N, bool FUSED, bool SPLIT = false, bool NT = false>
 __global__ void __launch_bounds__(SPLIT ? 320 : 256) k_checkers_step_fast(const CheckersParams p) {
   static_assert(!(SPLIT && FUSED), "the draw wave serves exactly one tick");
   static_assert(!SPLIT || 4 * CkFast<N>::EPW * N <= 64, "one lane per agent of every env of the workgroup");
@@ -649,10 +683,10 @@ __global__ void __launch_bounds__(SPLIT ? 320 : 256) k_checkers_step_fast(const 
       __syncthreads();                             // barrier 1: the actions of this tick are consumed
     }
     if (ended) {  // AUTO_RESET: terminal observation (train_onpolicy.py:336-347), then the fresh episode
-      if (p.term_grid) ckf_emit<N>(p, s, g, e, env_ok, ck_out_term(p, t));
+      if (p.term_grid) ckf_emit<N, NT>(p, s, g, e, env_ok, ck_out_term(p, t));
       ck_restart_env<N>(p, e, ec, writer, s, lv);
     }
-    ckf_emit<N>(p, s, g, e, env_ok, ck_out_tick(p, t));
+    ckf_emit<N, NT>(p, s, g, e, env_ok, ck_out_tick(p, t));
     if (p.goals_next && writer) {
       uint8_t *gn = ck_tick_ptr(p.goals_next, p.st_goals_next, t);
 #pragma unroll
@@ -834,16 +868,21 @@ template <int N> static int ck_launch(const CheckersParams &p, bool step, hipStr
   if (ck_fast_ok(p)) {
     constexpr unsigned kEnvsPerBlock = 4 * CkFast<N>::EPW;  // 4 waves x EPW envs per workgroup
     const unsigned fblocks = (unsigned)(((size_t)p.E + kEnvsPerBlock - 1) / kEnvsPerBlock);
+    const bool nt = (p.flags & kCkObsStoreNt) != 0;   // streaming-size trajectory (ck_rollout)
     if (step && p.n_ticks > 1) {
-      hipLaunchKernelGGL((k_checkers_step_fast<N, true>), dim3(fblocks), dim3(256), 0, stream, p);
+      if (nt) hipLaunchKernelGGL((k_checkers_step_fast<N, true, false, true>), dim3(fblocks), dim3(256), 0, stream, p);
+      else hipLaunchKernelGGL((k_checkers_step_fast<N, true>), dim3(fblocks), dim3(256), 0, stream, p);
     } else if (step && (p.flags & (kCkPregenRead | kCkPregenWrite))) {
-      if constexpr (4 * CkFast<N>::EPW * N <= 64)
-        hipLaunchKernelGGL((k_checkers_step_fast<N, false, true>), dim3(fblocks), dim3(320), 0, stream, p);
-      else
+      if constexpr (4 * CkFast<N>::EPW * N <= 64) {
+        if (nt) hipLaunchKernelGGL((k_checkers_step_fast<N, false, true, true>), dim3(fblocks), dim3(320), 0, stream, p);
+        else hipLaunchKernelGGL((k_checkers_step_fast<N, false, true>), dim3(fblocks), dim3(320), 0, stream, p);
+      } else {
         return fail(CM3_ERR_INVALID, "internal: draw-wave launch requested for %d agents", N);
-    } else if (step)
-      hipLaunchKernelGGL((k_checkers_step_fast<N, false>), dim3(fblocks), dim3(256), 0, stream, p);
-    else
+      }
+    } else if (step) {
+      if (nt) hipLaunchKernelGGL((k_checkers_step_fast<N, false, false, true>), dim3(fblocks), dim3(256), 0, stream, p);
+      else hipLaunchKernelGGL((k_checkers_step_fast<N, false>), dim3(fblocks), dim3(256), 0, stream, p);
+    } else
       hipLaunchKernelGGL((k_checkers_reset_fast<N>), dim3(fblocks), dim3(256), 0, stream, p);
     CM3_HIP_CHECK(hipGetLastError());
     return CM3_OK;
@@ -907,6 +946,10 @@ static int ck_rollout(const cm3_checkers_desc *d, const cm3_checkers_traj *t, in
     b.term_obs_self_v = (double *)at(t->term_obs_self_v, t->term_obs_self_v_stride, k);
     b.goals_next = (uint8_t *)at(t->goals_slots, t->goals_slots_stride, k + 1);
   };
+  // the rollout's observation slots as a stream (>= 128 MB, beyond what the cache hierarchy keeps): non-temporal stores
+  const size_t obs_bytes = (t->grid_slot_stride + t->vec_stride + t->obs_others_stride + t->obs_self_t_slot_stride +
+                            t->obs_self_v_stride) * (size_t)n_ticks;
+  const uint32_t nt_flag = obs_bytes >= ((size_t)128 << 20) ? kCkObsStoreNt : 0u;
   cm3_checkers_bufs b;
   if (d->flags & CM3_FLAG_FUSED_TICKS) {
     CM3_REQUIRE((d->flags & CM3_FLAG_GEN_ACTIONS) || n_ticks == 1 || t->actions_stride != 0,
@@ -917,6 +960,7 @@ static int ck_rollout(const cm3_checkers_desc *d, const cm3_checkers_traj *t, in
     if (rc != CM3_OK) return rc;
     CM3_REQUIRE(ck_fast_ok(p), "fused Checkers rollouts need the fast kernel (3x8 band, n_obs 2, 4-byte padded records)");
     p.n_ticks = n_ticks;
+    p.flags |= nt_flag;
     p.st_actions = t->actions_stride;
     p.st_grid = t->grid_slot_stride;
     p.st_vec = t->vec_stride;
@@ -939,6 +983,7 @@ static int ck_rollout(const cm3_checkers_desc *d, const cm3_checkers_traj *t, in
     CheckersParams p;
     int rc = ck_fill(d, &b, nullptr, true, p);
     if (rc != CM3_OK) return rc;
+    p.flags |= nt_flag;
     // random-action branch on the multi-lane kernel, at most one wave per SIMD (1024 on the chip) and one draw-wave lane
     // per agent: tick k also draws the actions of tick k + 1 (see k_checkers_step_fast, SPLIT)
     const size_t tick_waves = ((size_t)p.E * CM3_CKF_G + 63) / 64;
