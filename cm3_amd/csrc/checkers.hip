@@ -583,11 +583,19 @@ __device__ __forceinline__ void ckf_emit(const CheckersParams &p, const CkState<
   // grid record: dword g
   const int gd = p.grid_stride >> 2;
   const uint32_t m32 = (uint32_t)s.mask;  // 24 collected bits
-  for (int d = g; d < gd; d += F::G) ck_st<NT>(reinterpret_cast<uint32_t *>(out.grid + e * (size_t)p.grid_stride) + d, ckf_grid_dword<N>(m32, d));
+  if constexpr (NT) {
+    for (int d = g; d < gd; d += F::G) ck_st<true>(reinterpret_cast<uint32_t *>(out.grid + e * (size_t)p.grid_stride) + d, ckf_grid_dword<N>(m32, d));
+  } else {
+    for (int d = g; d < gd; d += F::G) reinterpret_cast<uint32_t *>(out.grid + e * (size_t)p.grid_stride)[d] = ckf_grid_dword<N>(m32, d);
+  }
   // obs_self_t record: dwords g, g+16, ...
   const int od = p.obst_stride >> 2;
   uint32_t *o32 = reinterpret_cast<uint32_t *>(out.obs_self_t + e * (size_t)p.obst_stride);
-  for (int d = g; d < od; d += F::G) ck_st<NT>(o32 + d, ckf_obst_dword<N>(s, m32, d));
+  if constexpr (NT) {
+    for (int d = g; d < od; d += F::G) ck_st<true>(o32 + d, ckf_obst_dword<N>(s, m32, d));
+  } else {
+    for (int d = g; d < od; d += F::G) o32[d] = ckf_obst_dword<N>(s, m32, d);
+  }
   // small vector outputs: lane i (< N) writes agent i's rows
   if (g < N) {
     int ri = s.r[0], ci = s.c[0], gi = s.ng[0], oi = s.no[0];
@@ -603,14 +611,16 @@ __device__ __forceinline__ void ckf_emit(const CheckersParams &p, const CkState<
     v.y = ci;
     v.z = gi;
     v.w = oi;
-    ck_st<NT>(reinterpret_cast<int4 *>(out.vec) + (e * N + g), v);
+    if constexpr (NT) ck_st<true>(reinterpret_cast<int4 *>(out.vec) + (e * N + g), v);
+    else reinterpret_cast<int4 *>(out.vec)[e * N + g] = v;
     const double half = (double)(F::R * F::C) / 2.0;
     double4 sv;
     sv.x = ((double)ri - (double)F::TR / 2.0) / (double)F::TR;
     sv.y = ((double)ci - (double)F::TC / 2.0) / (double)F::TC;
     sv.z = (double)gi / half;
     sv.w = (double)oi / half;
-    ck_st<NT>(reinterpret_cast<double4 *>(out.obs_self_v) + (e * N + g), sv);
+    if constexpr (NT) ck_st<true>(reinterpret_cast<double4 *>(out.obs_self_v) + (e * N + g), sv);
+    else reinterpret_cast<double4 *>(out.obs_self_v)[e * N + g] = sv;
     double2 *oo = reinterpret_cast<double2 *>(out.obs_others) + (e * N + g) * NO;
 #pragma unroll
     for (int k = 0; k < NO; ++k) {
@@ -625,7 +635,8 @@ __device__ __forceinline__ void ckf_emit(const CheckersParams &p, const CkState<
       double2 t;
       t.x = ((double)rj - (double)F::TR / 2.0) / (double)F::TR;
       t.y = ((double)cj - (double)F::TC / 2.0) / (double)F::TC;
-      ck_st<NT>(oo + k, t);
+      if constexpr (NT) ck_st<true>(oo + k, t);
+      else oo[k] = t;
     }
   }
 }
