@@ -741,11 +741,12 @@ def main():
                   "stage-2/W_others_h2": (128, 64), "b": (64,), "actor_out/kernel": (64, 5), "actor_out/bias": (5,)}
         wts = {k: (rng.standard_normal(v) * 0.1).astype(np.float32) for k, v in shapes.items()}
         pol = {}
-        for label, fused in (("launch_per_tick", False), ("one_launch_per_episode", True)):
+        for label, fused, ftick in (("launch_per_tick", False, False), ("fused_launch_per_tick", False, True),
+                                    ("one_launch_per_episode", True, False)):
             penv = VecParticleEnv(cfg, N, 0.2, 33, E, device=device, auto_reset=True)
             penv.reset()
             actor = ParticleActor(wts, N, stage=2, device=device)
-            ro = ParticleRollout(penv, n_ticks=EP_TICKS, use_graph=True, fused=fused)
+            ro = ParticleRollout(penv, n_ticks=EP_TICKS, use_graph=True, fused=fused, fused_policy_tick=ftick)
             for _ in range(3):
                 ro.collect(policy=actor, epsilon=0.1, reset=False)
             torch.cuda.synchronize(device)
@@ -780,7 +781,9 @@ def main():
                                             "frac": tfl / MFMA_F32_PEAK_TFLOPS},
                                "note": "eager launches incl. the host-side allocation of the action tensor"}
         pol["note"] = ("extra, not the headline: actor (networks.actor_particle, float32, exact-f32 MFMA) + step per tick with "
-                       "full trajectory storage; the two variants are bit-identical "
+                       "full trajectory storage.  launch_per_tick = an actor launch then a step launch per tick; "
+                       "fused_launch_per_tick = ONE launch per tick doing both; one_launch_per_episode = all 33 ticks in one "
+                       "launch.  The three variants are bit-identical "
                        "(tests/test_gpu_actor.py::test_fused_policy_rollout_equals_launch_per_tick)")
         out["policy_rollout"] = pol
     if extras and kind == "checkers" and cfg["n_agents"] in (1, 2):

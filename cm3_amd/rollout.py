@@ -81,14 +81,16 @@ class _ActorGraphCache(object):
         self.device = device
         self.graph = None
         self.policy = None
+        self.key = None
         self.eps = torch.zeros(1, dtype=torch.float32, device=device)
 
-    def launch(self, lib, policy, epsilon, capture, stream):
+    def launch(self, lib, policy, epsilon, capture, stream, key=None):
+        """key: anything else the captured launches bake in (the per-tick fused policy kernel takes epsilon by value)."""
         self.eps.fill_(float(epsilon))          # ordered before the replay on the same stream
-        if self.graph is None or self.policy is not policy:
+        if self.graph is None or self.policy is not policy or self.key != key:
             self.destroy(lib)
             self.graph = _lib.capture_graph(self.device, capture)
-            self.policy = policy
+            self.policy, self.key = policy, key
         _lib.check(lib.cm3_graph_launch(self.graph, stream))
 
     def destroy(self, lib):
@@ -107,13 +109,18 @@ class ParticleRollout(object):
         next-state/obs are captured per tick, goals are recorded per slot; every transition is valid.
     """
 
-    def __init__(self, env, n_ticks=None, use_graph=True, fused=False, n_chains=1, record_collisions=True):
+    def __init__(self, env, n_ticks=None, use_graph=True, fused=False, n_chains=1, record_collisions=True,
+                 fused_policy_tick=False):
         self.env = env
         self.T = int(n_ticks or env.max_steps)
         self.use_graph = bool(use_graph)
         # fused: the random-action branch runs all T ticks in ONE launch (CM3_FLAG_FUSED_TICKS; state in
         # registers, identical results).  Policy-driven collection always launches once per tick.
         self.fused = bool(fused)
+        # fused_policy_tick: policy-driven collection with ONE launch per tick -- actor forward pass, sampling and env step of
+        # a tick in one cm3_policy_rollout_f32 launch (n_ticks = 1) instead of an actor launch followed by a step launch;
+        # bit-identical to both other policy modes (n_agents in {1, 2, 4, 8})
+        self.fused_policy_tick = bool(fused_policy_tick)
         # n_chains > 1: the random-action branch advances n_chains independent sub-batches of envs on their own
         # streams (parallel branches of the captured hipGraph): one chain's launch boundary overlaps the others'
         # kernels.  Identical trajectories (cm3_particle_rollout_chains_*).
@@ -227,6 +234,16 @@ class ParticleRollout(object):
             self._enqueue(t, 1, base_flags, stream)
         env._desc.flags = base_flags
 
+    def _enqueue_fused_policy_ticks(self, actor, epsilon, base_flags, stream):
+        """T launches of the fused policy kernel, one tick each (slot t -> slot t+1)."""
+        env = self.env
+        env._desc.flags = base_flags & FLAG_AUTO_RESET
+        ad = actor._desc(env.E, epsilon, env.env_id_base)
+        for t in range(self.T):
+            traj = self._traj(t)
+            _lib.check(self._lib.cm3_policy_rollout_f32(ctypes.byref(env._desc), ctypes.byref(traj), ctypes.byref(ad),
+                                                        ctypes.byref(actor._wt), None, 0, 1, stream))
+
     def collect(self, policy=None, reset=None, epsilon=0.0):
         """Runs T ticks.  policy None = the reference's random-action branch (train_onpolicy.py:305-307,
         drawn in-kernel; the whole rollout is one hipGraph replay); otherwise ``policy(obs_others [E,N,L],
@@ -266,6 +283,15 @@ class ParticleRollout(object):
                 ad = policy._desc(env.E, epsilon, env.env_id_base)
                 _lib.check(self._lib.cm3_policy_rollout_f32(ctypes.byref(env._desc), ctypes.byref(traj), ctypes.byref(ad),
                                                             ctypes.byref(policy._wt), None, 0, self.T, env._stream()))
+            elif self.fused_policy_tick:
+                if policy.seed != env.seed:
+                    raise Cm3Error("fused policy launches need actor.seed == env.seed (one Philox key)")
+                if self.use_graph:      # epsilon is a by-value argument of these launches: part of the graph's key
+                    self._actor_graph.launch(self._lib, policy, epsilon,
+                                             lambda s: self._enqueue_fused_policy_ticks(policy, epsilon, base, s),
+                                             env._stream(), key=("fused_tick", float(epsilon)))
+                else:
+                    self._enqueue_fused_policy_ticks(policy, epsilon, base, env._stream())
             elif self.use_graph:
                 cache = self._actor_graph
                 cache.launch(self._lib, policy, epsilon,

@@ -156,32 +156,37 @@ def test_bf16_second_layer_is_close_to_float32(N, cfg):
 @pytest.mark.parametrize("auto_reset", [False, True])
 @pytest.mark.parametrize("precision", ["f32", "bf16"])
 def test_fused_policy_rollout_equals_launch_per_tick(N, cfg, auto_reset, precision):
-    """csrc/policy.hip (a whole policy-driven episode in one launch) is bit-identical to alternating actor / step
-    launches: trajectories, sampled actions, terminal captures, live counters."""
+    """csrc/policy.hip -- a whole policy-driven episode in one launch, or ONE fused launch per tick (eager and as a
+    captured graph) -- is bit-identical to alternating actor / step launches: trajectories, sampled actions, terminal
+    captures, per-tick collision counts, live counters."""
     from cm3_amd.actor import ParticleActor
     from cm3_amd.rollout import ParticleRollout
     E, T, seed = 333, 40, 13
     stage = 1 if N == 1 else 2
     w = AO.init_weights(np.random.default_rng(N), N, stage=stage)
     outs = []
-    for fused in (False, True):
+    # (fused episode, fused per tick, graph): alternating launches first -- the reference for the other three
+    for fused, ftick, graph in ((False, False, False), (True, False, False), (False, True, False), (False, True, True)):
         env = _env(E, N, cfg, seed=seed, auto_reset=auto_reset, max_steps=9)
         env.reset()
         actor = ParticleActor(w, N, stage=stage, device="cuda:0", seed=seed, precision=precision)
-        ro = ParticleRollout(env, n_ticks=T, use_graph=False, fused=fused).collect(policy=actor, epsilon=0.15, reset=False)
+        ro = ParticleRollout(env, n_ticks=T, use_graph=graph, fused=fused, fused_policy_tick=ftick)
+        ro.collect(policy=actor, epsilon=0.15, reset=False)
         outs.append((ro, env))
-    a, b = outs[0][0], outs[1][0]
-    for name in ("actions", "state", "obs_others", "reward", "reward_n", "done"):
-        assert torch.equal(getattr(a, name), getattr(b, name)), name
-    if auto_reset:
-        assert torch.equal(a.goals, b.goals)
-        d = a.done.bool()
-        assert int(d.sum()) > 0
-        assert torch.equal(a.term_state.permute(0, 2, 1, 3)[d], b.term_state.permute(0, 2, 1, 3)[d])
-        assert torch.equal(a.term_obs_others[d], b.term_obs_others[d])
-    ea, eb = outs[0][1], outs[1][1]
-    assert torch.equal(ea.steps, eb.steps) and torch.equal(ea.collisions, eb.collisions)
-    assert torch.equal(ea.episode, eb.episode) and torch.equal(ea.global_state, eb.global_state)
+    a, ea = outs[0]
+    for b, eb in outs[1:]:
+        for name in ("actions", "state", "obs_others", "reward", "reward_n", "done", "collisions"):
+            assert torch.equal(getattr(a, name), getattr(b, name)), name
+        if auto_reset:
+            assert torch.equal(a.goals, b.goals)
+            d = a.done.bool()
+            assert int(d.sum()) > 0
+            assert torch.equal(a.term_state.permute(0, 2, 1, 3)[d], b.term_state.permute(0, 2, 1, 3)[d])
+            assert torch.equal(a.term_obs_others[d], b.term_obs_others[d])
+        assert torch.equal(ea.steps, eb.steps) and torch.equal(ea.collisions, eb.collisions)
+        assert torch.equal(ea.episode, eb.episode) and torch.equal(ea.global_state, eb.global_state)
+    for ro, _ in outs:
+        ro.close()
 
 
 @pytest.mark.parametrize("tag,N,stage", [("n4_stage2", 4, 2), ("n1_stage1", 1, 1), ("n8_stage2", 8, 2)])
