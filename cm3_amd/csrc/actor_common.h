@@ -13,8 +13,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // action ~ multinomial(probs) (alg_credit.py:120): inverse CDF in action order, one uniform from the Philox stream
 // keyed (seed, global env id, episode, step | agent)
-__device__ __forceinline__ int actor_sample(const float (&pr)[kA], uint64_t seed, uint64_t genv, uint32_t episode,
-                                            int steps, int agent) {
+// the uniform of (seed, global env id, episode, step | agent): depends on nothing the network computes, so a kernel can draw it
+// while its loads are in flight
+__device__ __forceinline__ float actor_uniform(uint64_t seed, uint64_t genv, uint32_t episode, int steps, int agent) {
   u32x4 ctr;
   ctr.x = (uint32_t)genv;
   ctr.y = (uint32_t)(genv >> 32);
@@ -22,7 +23,10 @@ __device__ __forceinline__ int actor_sample(const float (&pr)[kA], uint64_t seed
   ctr.w = kPurposePolicy | ((uint32_t)(agent >> 2) << 24) | ((uint32_t)steps & 0x00FFFFFFu);
   const u32x4 wd = philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
   const int q = agent & 3;
-  const float u = (float)u01(q == 0 ? wd.x : (q == 1 ? wd.y : (q == 2 ? wd.z : wd.w)));
+  return (float)u01(q == 0 ? wd.x : (q == 1 ? wd.y : (q == 2 ? wd.z : wd.w)));
+}
+
+__device__ __forceinline__ int actor_pick(const float (&pr)[kA], float u) {
   int act = kA - 1;
   float cdf = 0.0f;
   bool chosen = false;
@@ -35,6 +39,11 @@ __device__ __forceinline__ int actor_sample(const float (&pr)[kA], uint64_t seed
     }
   }
   return act;
+}
+
+__device__ __forceinline__ int actor_sample(const float (&pr)[kA], uint64_t seed, uint64_t genv, uint32_t episode,
+                                            int steps, int agent) {
+  return actor_pick(pr, actor_uniform(seed, genv, episode, steps, agent));
 }
 
 }  // namespace cm3

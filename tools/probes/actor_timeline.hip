@@ -49,6 +49,19 @@ int main(int argc, char **argv) {
     seg[k] += (double)(h[wv * 16 + k + 1] - h[wv * 16 + k]); cnt[k]++;
   }
   for (int k = 0; k < 7; ++k) printf("   %-32s %9.0f cycles\n", names[k], seg[k] / cnt[k]);
+  // inside segment 0 (non-draining stamps 8, 9, 10), averaged separately over wave 0 of each workgroup and the other waves
+  const char *sub[] = {"entry -> table copy issued+stored", "-> input rows staged (wave 0)", "-> W2 loads issued", "-> all loads landed (drain)"};
+  const int order[] = {0, 8, 9, 10, 1};
+  for (int which = 0; which < 2; ++which) {
+    double a[4] = {0}; int c = 0;
+    for (int wv = 0; wv < waves; ++wv) {
+      if (((wv & 3) == 0) != (which == 0)) continue;
+      for (int k = 0; k < 4; ++k) a[k] += (double)(h[wv * 16 + order[k + 1]] - h[wv * 16 + order[k]]);
+      c++;
+    }
+    printf("   segment 0, %s:\n", which == 0 ? "wave 0 of each workgroup" : "waves 1-3");
+    for (int k = 0; k < 4; ++k) printf("      %-38s %9.0f cycles\n", sub[k], a[k] / c);
+  }
 #endif
   return 0;
 }
