@@ -363,17 +363,18 @@ template <int N, bool BF16> __global__ void __launch_bounds__(256) k_actor_parti
   const uint32_t head_episode = (uint32_t)p.episode[he];
 
 #ifndef CM3_ACTOR_OPT
-#define CM3_ACTOR_OPT 3
+#define CM3_ACTOR_OPT 0
 #endif
   // Everything the workgroup needs from memory is requested here, oldest first = needed first; the W2 slice (phase B) last,
   // so that nothing before phase A waits for it.  Measured per-wave timeline of the first version (tables copied to LDS by a
   // load -> ds_write loop, input rows staged by wave 0 alone, the Philox draw in the head; tools/probes/actor_timeline.hip,
   // 16 384 rows): staging 4.9k cycles of a 21k-cycle latency chain (one workgroup per CU: nothing overlaps it).
-  constexpr int kOpt = CM3_ACTOR_OPT;
+  constexpr int kOpt = CM3_ACTOR_OPT;   // bit 0: first-layer operands from global; bit 1: Philox early; bit 2: all-wave input staging
+  constexpr bool kFirstB = (kOpt & 1) != 0, kPhiloxEarly = (kOpt & 2) != 0, kAllWaves = (kOpt & 4) != 0;
   using PL = PackLayout<N>;
   ActorFirstB<N> fb;
   float u_draw = 0.0f;
-  if constexpr (kOpt >= 1) {
+  if constexpr (kFirstB) {
     // (1) phase-A B operands straight from the packed weights into registers: no table copy on the critical path
     actor_first_b<N, float>(p.packed + PL::kSelf, p.packed + PL::kOth, w, lane, p.stage > 1, fb);
   } else {
@@ -387,7 +388,7 @@ template <int N, bool BF16> __global__ void __launch_bounds__(256) k_actor_parti
   constexpr int NV = 2 + L / 4, NIT = (NV + 3) / 4;
   float4 in_v[NIT];
   const int in_rl = 16 * w + (lane & 15), in_part = lane >> 4;
-  if constexpr (kOpt >= 3) {
+  if constexpr (kAllWaves) {
     const size_t r = row_base + in_rl;
     const size_t rc = r < rows ? r : rows - 1;
     const size_t e = rc / N;
@@ -427,16 +428,16 @@ template <int N, bool BF16> __global__ void __launch_bounds__(256) k_actor_parti
   // the output layer (head only) still goes through LDS: 82 threads copy one 16-byte vector each
   float4 wout_v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   const int wout_t = tid < PL::kOutSize / 4 ? tid : 0;
-  if constexpr (kOpt >= 1) wout_v = reinterpret_cast<const float4 *>(p.packed + PL::kOut)[wout_t];
+  if constexpr (kFirstB) wout_v = reinterpret_cast<const float4 *>(p.packed + PL::kOut)[wout_t];
   CM3_STAMP(9, false);
   ActorB<N, BF16> b;
   actor_load_b<N, BF16>(p.packed, w, lane, b);
   CM3_STAMP(10, false);
-  if constexpr (kOpt >= 2) {
+  if constexpr (kPhiloxEarly) {
     // (2) the sampling uniform depends only on the RNG key: ten Philox rounds in the shadow of the loads above
     u_draw = actor_uniform(p.seed, (uint64_t)(p.env_id_base + (int64_t)he), head_episode, head_steps, hi_agent);
   }
-  if constexpr (kOpt >= 3) {
+  if constexpr (kAllWaves) {
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int v = 4 * it + in_part;
@@ -451,17 +452,17 @@ template <int N, bool BF16> __global__ void __launch_bounds__(256) k_actor_parti
       }
     }
   }
-  if constexpr (kOpt >= 1) {
+  if constexpr (kFirstB) {
     if (tid < PL::kOutSize / 4) reinterpret_cast<float4 *>(lds.tables + PL::kOut)[tid] = wout_v;
   }
   CM3_STAMP(1, true);
   __syncthreads();
   CM3_STAMP(2, false);
-  actor_mlp<N, BF16>(lds, b, w, lane, p.stage > 1, kOpt >= 1 ? &fb : nullptr);
+  actor_mlp<N, BF16>(lds, b, w, lane, p.stage > 1, kFirstB ? &fb : nullptr);
   float pr[kA];
   actor_head_probs(lds.h2s, lds.wout, w, lane, p.eps_dev ? *p.eps_dev : p.eps, pr);
   int act;
-  if constexpr (kOpt >= 2) act = actor_pick(pr, u_draw);
+  if constexpr (kPhiloxEarly) act = actor_pick(pr, u_draw);
   else act = actor_sample(pr, p.seed, (uint64_t)(p.env_id_base + (int64_t)he), head_episode, head_steps, hi_agent);
   if (head_ok) {
     p.actions[hr] = act;
