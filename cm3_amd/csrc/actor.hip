@@ -190,8 +190,7 @@ __device__ __forceinline__ void actor_load_b(const float *packed, int w, int lan
 }
 
 // Phase-A B operands of one lane: unit 16w + col of branch_self and units 32w + 16cq + col of actor_others, k = 4s + hi
-// (B[k = l>>4][j = l&15]).  Read from the unit-major tables -- in LDS (k_policy_rollout stages them once per launch) or
-// straight from the packed weights in global memory (k_actor_particle: 11 dwords per lane, no LDS round trip).
+// (B[k = l>>4][j = l&15]), read from the unit-major first-layer tables in LDS.
 template <int N> struct ActorFirstB {
   static constexpr int L4 = (4 * (N > 1 ? N - 1 : 1)) / 4;
   float bs[2], bias_s;
@@ -216,17 +215,17 @@ __device__ __forceinline__ void actor_first_b(const T *self_tab, const T *oth_ta
   }
 }
 
-// xs tile ready and synchronised on entry (and, without `fb`, the first-layer tables in LDS); h2s ready and synchronised on
-// exit (3 barriers inside).
+// xs tile + tables ready and synchronised on entry; h2s ready and synchronised on exit (3 barriers inside).  The lane's
+// phase-A B operands are read from the LDS tables ONCE, up front (measured -0.9 % per launch against reading them inside each
+// block: 8.80 -> 8.72 us at 16 384 rows, same box).
 template <int N, bool BF16>
 __device__ __forceinline__ void actor_mlp(const ActorLds<N, BF16> &lds, const ActorB<N, BF16> &b, int w, int lane,
-                                          bool stage2, const ActorFirstB<N> *fb = nullptr) {
+                                          bool stage2) {
   using G = ActorGeom<N, BF16>;
   constexpr int L = G::L, KU = G::KU;
   const int col = lane & 15, hi = lane >> 4, c0 = 16 * w;
-  ActorFirstB<N> fl;
-  if (fb == nullptr) actor_first_b<N, float>(&lds.ws_self[0][0], &lds.ws_oth[0][0], w, lane, stage2, fl);
-  const ActorFirstB<N> &f1 = fb ? *fb : fl;
+  ActorFirstB<N> f1;
+  actor_first_b<N, float>(&lds.ws_self[0][0], &lds.ws_oth[0][0], w, lane, stage2, f1);
   // ---- phase A: dense(6 -> 64) units [16w, 16w+16) and dense(L -> 128) units [32w, 32w+32) (networks.py:520-529) ------
   {
     float ax[4][2], ao[4][L / 4];
@@ -362,53 +361,14 @@ template <int N, bool BF16> __global__ void __launch_bounds__(256) k_actor_parti
   const int head_steps = p.meta[2 * he];
   const uint32_t head_episode = (uint32_t)p.episode[he];
 
-#ifndef CM3_ACTOR_OPT
-#define CM3_ACTOR_OPT 0
-#endif
-  // Everything the workgroup needs from memory is requested here, oldest first = needed first; the W2 slice (phase B) last,
-  // so that nothing before phase A waits for it.  Measured per-wave timeline of the first version (tables copied to LDS by a
-  // load -> ds_write loop, input rows staged by wave 0 alone, the Philox draw in the head; tools/probes/actor_timeline.hip,
-  // 16 384 rows): staging 4.9k cycles of a 21k-cycle latency chain (one workgroup per CU: nothing overlaps it).
-  constexpr int kOpt = CM3_ACTOR_OPT;   // bit 0: first-layer operands from global; bit 1: Philox early; bit 2: all-wave input staging
-  constexpr bool kFirstB = (kOpt & 1) != 0, kPhiloxEarly = (kOpt & 2) != 0, kAllWaves = (kOpt & 4) != 0;
-  using PL = PackLayout<N>;
-  ActorFirstB<N> fb;
-  float u_draw = 0.0f;
-  if constexpr (kFirstB) {
-    // (1) phase-A B operands straight from the packed weights into registers: no table copy on the critical path
-    actor_first_b<N, float>(p.packed + PL::kSelf, p.packed + PL::kOth, w, lane, p.stage > 1, fb);
-  } else {
-    actor_stage_tables<N, BF16>(lds, p.packed, tid);
-  }
+  // Kernel entry: tables -> LDS (wide, coalesced copies), wave 0 stages the input rows, the W2 slice is requested last.
+  // Measured and REJECTED in round 2 (tools/probes/actor_timeline.hip, 16 384 rows, same box, three repeats):
+  // first-layer operands straight from global memory into registers instead of the table copy (+9 %: the entry is bound by the
+  // request throughput of 256 workgroups reading the same few KB of L2, and narrow per-lane requests are worse than the wide
+  // copy), the Philox draw before the first barrier (+0.5 %), input rows staged by all four waves (+-0), both (+1.1 %).
+  actor_stage_tables<N, BF16>(lds, p.packed, tid);
   CM3_STAMP(8, false);
-  // (3) every wave stages 16 input rows [v_obs(4) | v_goal(2) | obs_others(L)]: lane l -> row 16w + (l&15); the row's vectors
-  // (state, goals, L/4 observation vectors) are dealt round-robin to the four lane quarters.  All loads are requested into
-  // registers first -- branch-free, through selected addresses -- and written to LDS only after everything else (the W2 slice,
-  // the output layer) has been requested and the Philox draw is done: one memory round trip before phase A, not one per vector.
-  constexpr int NV = 2 + L / 4, NIT = (NV + 3) / 4;
-  float4 in_v[NIT];
-  const int in_rl = 16 * w + (lane & 15), in_part = lane >> 4;
-  if constexpr (kAllWaves) {
-    const size_t r = row_base + in_rl;
-    const size_t rc = r < rows ? r : rows - 1;
-    const size_t e = rc / N;
-    const int i = (int)(rc - e * N);
-    const float *st = p.state + ((size_t)i * p.E + e) * 4;
-    const float *gl = p.goals + ((size_t)i * p.E + e) * 2;   // 8-byte aligned: read as two floats below
-    const float *ob = p.obs_others + rc * L;
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int v = 4 * it + in_part;
-      const int k = v >= 2 && v < NV ? v - 2 : 0;
-      const float *src = v == 0 ? st : ob + 4 * k;            // v == 1 (goals) and v >= NV read a valid dummy vector
-      in_v[it] = *reinterpret_cast<const float4 *>(src);
-      if (v == 1) {
-        const float2 g = *reinterpret_cast<const float2 *>(gl);
-        in_v[it].x = g.x;
-        in_v[it].y = g.y;
-      }
-    }
-  } else if (w == 0) {  // wave 0 stages the 64 input rows [v_obs(4) | v_goal(2) | obs_others(L)] into LDS, one row per lane
+  if (w == 0) {  // wave 0 stages the 64 input rows [v_obs(4) | v_goal(2) | obs_others(L)] into LDS, one row per lane
     const size_t r = row_base + lane;
     const size_t rc = r < rows ? r : rows - 1;
     const size_t e = rc / N;
@@ -425,45 +385,17 @@ template <int N, bool BF16> __global__ void __launch_bounds__(256) k_actor_parti
       lds.xs[lane][6 + 4 * k + 2] = v.z; lds.xs[lane][6 + 4 * k + 3] = v.w;
     }
   }
-  // the output layer (head only) still goes through LDS: 82 threads copy one 16-byte vector each
-  float4 wout_v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  const int wout_t = tid < PL::kOutSize / 4 ? tid : 0;
-  if constexpr (kFirstB) wout_v = reinterpret_cast<const float4 *>(p.packed + PL::kOut)[wout_t];
   CM3_STAMP(9, false);
   ActorB<N, BF16> b;
   actor_load_b<N, BF16>(p.packed, w, lane, b);
   CM3_STAMP(10, false);
-  if constexpr (kPhiloxEarly) {
-    // (2) the sampling uniform depends only on the RNG key: ten Philox rounds in the shadow of the loads above
-    u_draw = actor_uniform(p.seed, (uint64_t)(p.env_id_base + (int64_t)he), head_episode, head_steps, hi_agent);
-  }
-  if constexpr (kAllWaves) {
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int v = 4 * it + in_part;
-      if (v == 0) {
-        lds.xs[in_rl][0] = in_v[it].x; lds.xs[in_rl][1] = in_v[it].y; lds.xs[in_rl][2] = in_v[it].z; lds.xs[in_rl][3] = in_v[it].w;
-      } else if (v == 1) {
-        lds.xs[in_rl][4] = in_v[it].x; lds.xs[in_rl][5] = in_v[it].y;
-      } else if (v < NV) {
-        const int k = v - 2;
-        lds.xs[in_rl][6 + 4 * k + 0] = in_v[it].x; lds.xs[in_rl][6 + 4 * k + 1] = in_v[it].y;
-        lds.xs[in_rl][6 + 4 * k + 2] = in_v[it].z; lds.xs[in_rl][6 + 4 * k + 3] = in_v[it].w;
-      }
-    }
-  }
-  if constexpr (kFirstB) {
-    if (tid < PL::kOutSize / 4) reinterpret_cast<float4 *>(lds.tables + PL::kOut)[tid] = wout_v;
-  }
   CM3_STAMP(1, true);
   __syncthreads();
   CM3_STAMP(2, false);
-  actor_mlp<N, BF16>(lds, b, w, lane, p.stage > 1, kFirstB ? &fb : nullptr);
+  actor_mlp<N, BF16>(lds, b, w, lane, p.stage > 1);
   float pr[kA];
   actor_head_probs(lds.h2s, lds.wout, w, lane, p.eps_dev ? *p.eps_dev : p.eps, pr);
-  int act;
-  if constexpr (kPhiloxEarly) act = actor_pick(pr, u_draw);
-  else act = actor_sample(pr, p.seed, (uint64_t)(p.env_id_base + (int64_t)he), head_episode, head_steps, hi_agent);
+  const int act = actor_sample(pr, p.seed, (uint64_t)(p.env_id_base + (int64_t)he), head_episode, head_steps, hi_agent);
   if (head_ok) {
     p.actions[hr] = act;
     if (p.probs) {
