@@ -1254,10 +1254,19 @@ template <typename R, int N, int WAVES> static int launch_agents(const ParticleP
 template <typename R, int N> static int launch_n(const ParticleParams &p, ParticleOp op, hipStream_t stream) {
   if (op == kStep) {
     bool pairs = N >= 3 && (size_t)p.E <= kPairsMaxEnvs;
-    // many agents: the lane-per-agent mapping wins from ~6k to 128k envs (N = 8, us per launch, pair / agent / env:
-    // 4096: 6.8 / 8.0 / 24;  8192: 10.7 / 8.7 / 24;  16384: 17.7 / 10.7 / 24;  32768: 30 / 15.3 / 25.5;
-    // 65536: 52 / 22.6 / 28.7;  131072: 99 / 37.3 / 39.1;  262144: 192 / 77.7 / 73.7 -- profiles/r01_kernel_sweep.txt)
-    bool agents = N >= 6 && (size_t)p.E >= 6144 && (size_t)p.E <= ((size_t)1 << 17);
+    // Many agents: where the lane-per-agent mapping wins, re-measured in round 2 after the exact squared-distance thresholds
+    // took the square roots out of its neighbour scan (us per tick, in place; profiles/r02_n678_mid_sweep.txt,
+    // r02_n8_mapping_sweep.txt, r02_n567_mapping_sweep.txt; round 1's rule -- N >= 6, 6144..2^17 -- had been tuned on N = 8 only):
+    //   N = 8  pair / agent / env: 4096: 6.2 / 6.7 / 23.8;  6144: 7.9 / 7.0 / 23.7;  65536: 47 / 19.4 / 28.2;  2^18: - / 68.9 / 71.1;
+    //          2^20: - / 286 / 319  -> agent from 6144 up, no upper bound
+    //   N = 7  6144: 7.1 / 6.4 / 18.5;  65536: 41 / 17.9 / 22.6;  2^17..2^20: agent = env within 1 %  -> agent 6144..2^17
+    //   N = 6  8192: 5.7 / 6.0 / 13.2;  16384: 8.8 / 7.5 / 13.5;  65536: 23.6 / 16.3 / 16.7;  2^17: - / 26.6 / 23.5
+    //          -> pair up to 8192, agent from 16384 to 65536 (the crossover between 8192 and 16384 is set at 12288, unmeasured),
+    //             lane-per-env above
+    size_t agents_lo = 6144, agents_hi = (size_t)1 << 17;
+    if (N == 6) { agents_lo = 12288; agents_hi = (size_t)1 << 16; }
+    if (N == 8) agents_hi = ~(size_t)0;
+    bool agents = N >= 6 && (size_t)p.E >= agents_lo && (size_t)p.E <= agents_hi;
     if (p.flags & CM3_FLAG_KERNEL_LANE_PER_ENV) pairs = agents = false;
     if (p.flags & CM3_FLAG_KERNEL_LANE_PER_PAIR) { pairs = true; agents = false; }
     if (p.flags & CM3_FLAG_KERNEL_LANE_PER_AGENT) agents = true;
