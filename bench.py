@@ -527,7 +527,8 @@ def main():
                     help="trajectory (default): every tick writes its slot of a device trajectory (the collection loop); "
                          "in-place: every tick overwrites the same live buffers (stepping only)")
     ap.add_argument("--chains", type=int, default=1,
-                    help="independent sub-batch chains per tick (parallel branches of the hipGraph; 1 = one launch per tick)")
+                    help="independent sub-batch chains per tick (parallel branches of the hipGraph; 1 = one launch per tick). "
+                         "K > 1 measured 1.2-5x SLOWER on MI355X (profiles/r02_chains_diag.txt): kept to reproduce that")
     ap.add_argument("--envs-per-gpu", type=int, default=0, help="override the workload's batch size")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-sweep", action="store_true", help="skip the E-sweep (extra 'sweep' field)")
@@ -855,7 +856,7 @@ def main():
                 rd, wr = 24 * E, 376 * E
             rd, wr = (rd + 15) // 16 * 16, (wr + 15) // 16 * 16
             floor = measure_launch_floor(device, rd, wr, blocks=max(1, min(2048, (E * 16 + 255) // 256)), nodes=PHASE_TICKS)
-            floor["frac_of_floor"] = floor["same_traffic_us"] / (launch_s * 1e6 * stepper_lpt(n_chains))
+            floor["frac_of_floor"] = floor["same_traffic_us"] / (launch_s * 1e6 * max(1, n_chains))   # floor is per whole tick
             out["roofline"]["launch_floor"] = floor
         if not args.no_sweep and kind == "particle":
             if stepper is not None:
@@ -889,11 +890,6 @@ def main():
         dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
     return 0
-
-
-def stepper_lpt(n_chains):
-    """launches per tick of the headline (the launch floor is quoted per tick of the whole batch)."""
-    return float(max(1, n_chains))
 
 
 if __name__ == "__main__":

@@ -3,7 +3,6 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
-#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/cm3_amd.h"

@@ -122,8 +122,9 @@ class ParticleRollout(object):
         # bit-identical to both other policy modes (n_agents in {1, 2, 4, 8})
         self.fused_policy_tick = bool(fused_policy_tick)
         # n_chains > 1: the random-action branch advances n_chains independent sub-batches of envs on their own
-        # streams (parallel branches of the captured hipGraph): one chain's launch boundary overlaps the others'
-        # kernels.  Identical trajectories (cm3_particle_rollout_chains_*).
+        # streams (parallel branches of the captured hipGraph).  Identical trajectories (cm3_particle_rollout_chains_*),
+        # but MEASURED 1.2-5x SLOWER than one chain on MI355X in every form tried (profiles/r02_chains_diag.txt): the
+        # option exists for reproducing that result, not as an optimisation.
         self.n_chains = int(n_chains)
         if not (1 <= self.n_chains <= 16):
             raise Cm3Error("n_chains must be in 1..16")
@@ -232,7 +233,6 @@ class ParticleRollout(object):
             actor.enqueue(env.E, self.obs_others[t], self.state[t], goals, env._meta, env._episode, self.actions[t],
                           epsilon, stream=stream, env_id_base=env.env_id_base)
             self._enqueue(t, 1, base_flags, stream)
-        env._desc.flags = base_flags
 
     def _enqueue_fused_policy_ticks(self, actor, epsilon, base_flags, stream):
         """T launches of the fused policy kernel, one tick each (slot t -> slot t+1)."""

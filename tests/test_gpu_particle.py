@@ -137,8 +137,12 @@ def _record_drift(name, kernel, worst, worst_rew, worst10, n_safe, n_live):
     DESIGN.md quotes; copied to profiles/)"""
     import os
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
-    os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, "f32_free_running_drift.txt"), "a") as f:
+    try:                                                       # scratch output only: never let it fail a test
+        os.makedirs(out, exist_ok=True)
+        f = open(os.path.join(out, "f32_free_running_drift.txt"), "a")
+    except OSError:
+        return
+    with f:
         f.write("%-32s %-6s state_end %.3e  state_t10 %.3e  reward_n(safe) %.3e  compared %d of %d env-ticks\n"
                 % (name, kernel, worst, worst10, worst_rew, n_safe, n_live))
 
