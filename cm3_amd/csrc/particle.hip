@@ -1227,9 +1227,7 @@ template <typename R, int N, int WAVES> static int launch_pairs(const ParticlePa
   }
 }
 
-// Largest batch for which the lane-per-pair mapping is preferred.  Measured on MI355X (tools/kernel_sweep.py,
-// profiles/r01_kernel_sweep.txt): N=4 3.7 vs 6.1 us at E=4096, 5.3 vs 6.5 us at 16384, 8.0 vs 7.4 us at 32768;
-// N=8 6.9 vs 23.9 us at 4096, 17.4 vs 24.2 us at 16384, 29.5 vs 25.4 us at 32768; N=2 is a tie everywhere.
+// Largest batch for which the lane-per-pair mapping is preferred when no per-N entry says otherwise (see launch_n).
 constexpr size_t kPairsMaxEnvs = (size_t)1 << 14;
 
 template <typename R, int N, int WAVES> static int launch_agents(const ParticleParams &p, hipStream_t stream) {
@@ -1253,20 +1251,27 @@ template <typename R, int N, int WAVES> static int launch_agents(const ParticleP
 
 template <typename R, int N> static int launch_n(const ParticleParams &p, ParticleOp op, hipStream_t stream) {
   if (op == kStep) {
-    bool pairs = N >= 3 && (size_t)p.E <= kPairsMaxEnvs;
-    // Many agents: where the lane-per-agent mapping wins, re-measured in round 2 after the exact squared-distance thresholds
-    // took the square roots out of its neighbour scan (us per tick, in place; profiles/r02_n678_mid_sweep.txt,
-    // r02_n8_mapping_sweep.txt, r02_n567_mapping_sweep.txt; round 1's rule -- N >= 6, 6144..2^17 -- had been tuned on N = 8 only):
-    //   N = 8  pair / agent / env: 4096: 6.2 / 6.7 / 23.8;  6144: 7.9 / 7.0 / 23.7;  65536: 47 / 19.4 / 28.2;  2^18: - / 68.9 / 71.1;
-    //          2^20: - / 286 / 319  -> agent from 6144 up, no upper bound
-    //   N = 7  6144: 7.1 / 6.4 / 18.5;  65536: 41 / 17.9 / 22.6;  2^17..2^20: agent = env within 1 %  -> agent 6144..2^17
-    //   N = 6  8192: 5.7 / 6.0 / 13.2;  16384: 8.8 / 7.5 / 13.5;  65536: 23.6 / 16.3 / 16.7;  2^17: - / 26.6 / 23.5
-    //          -> pair up to 8192, agent from 16384 to 65536 (the crossover between 8192 and 16384 is set at 12288, unmeasured),
-    //             lane-per-env above
-    size_t agents_lo = 6144, agents_hi = (size_t)1 << 17;
-    if (N == 6) { agents_lo = 12288; agents_hi = (size_t)1 << 16; }
-    if (N == 8) agents_hi = ~(size_t)0;
-    bool agents = N >= 6 && (size_t)p.E >= agents_lo && (size_t)p.E <= agents_hi;
+    // Which mapping for (N, E): measured on MI355X in round 2, after the exact squared-distance thresholds took the square roots
+    // out of every mapping (in place, us per tick, pair / agent / env; profiles/r02_n2345_mapping_sweep_*.txt, r02_n678_mid_sweep.txt,
+    // r02_n8_mapping_sweep.txt, r02_n567_mapping_sweep.txt).  Round 1's rule (pair for N >= 3 up to 16384 envs, agent for N >= 6 between
+    // 6144 and 2^17) had been tuned on N = 4 and N = 8 only and before that change; it left `auto` up to 41 % behind the best kernel:
+    //   N = 3   24576: 4.43 / 5.15 / 4.97   32768: 5.14 / 5.31 / 5.14   65536: 7.7 / 7.6 / 5.8     -> pair to 32768, then env
+    //   N = 4   16384: 5.06 / 5.13 / 6.65   24576: 6.40 / 6.04 / 7.29   32768: 7.85 / 6.42 / 7.67   65536: 12.6 / 9.1 / 8.4
+    //           -> pair to 16384, agent to 49152, then env
+    //   N = 5    8192: 5.14 / 5.33 / 9.73   16384: 7.64 / 6.42 / 10.0   32768: 12.8 / 9.2 / 11.5    65536: 21 / 14.2 / 12.3
+    //           -> pair to 12288, agent to 49152, then env
+    //   N = 6    8192: 5.7 / 6.0 / 13.2     16384: 8.8 / 7.5 / 13.5     65536: 23.6 / 16.3 / 16.7   2^17: - / 26.6 / 23.5
+    //           -> pair to 12288, agent to 65536, then env
+    //   N = 7    6144: 7.1 / 6.4 / 18.5     65536: 41 / 17.9 / 22.6     2^17 .. 2^20: agent = env within 1 %   -> agent 6144 .. 2^17
+    //   N = 8    4096: 6.2 / 6.7 / 23.8      6144: 7.9 / 7.0 / 23.7     2^18: - / 68.9 / 71.1       2^20: - / 286 / 319
+    //           -> pair below 6144, agent from 6144 up (no upper bound)
+    // Crossovers that fall between two measured sizes (12288, 49152) are interpolated, not measured.
+    constexpr size_t kInf = ~(size_t)0;
+    constexpr size_t kPairMax = N == 3 ? 32768 : kPairsMaxEnvs;
+    constexpr size_t kAgentLo = N == 4 ? 16385 : (N == 5 || N == 6 ? 12288 : (N >= 7 ? 6144 : kInf));
+    constexpr size_t kAgentHi = N == 4 || N == 5 ? 49152 : (N == 6 ? 65536 : (N == 7 ? ((size_t)1 << 17) : (N == 8 ? kInf : 0)));
+    bool pairs = N >= 3 && (size_t)p.E <= kPairMax;
+    bool agents = N >= 4 && (size_t)p.E >= kAgentLo && (size_t)p.E <= kAgentHi;
     if (p.flags & CM3_FLAG_KERNEL_LANE_PER_ENV) pairs = agents = false;
     if (p.flags & CM3_FLAG_KERNEL_LANE_PER_PAIR) { pairs = true; agents = false; }
     if (p.flags & CM3_FLAG_KERNEL_LANE_PER_AGENT) agents = true;
