@@ -449,16 +449,17 @@ __device__ __forceinline__ void ck_step_env(const CheckersParams &p, size_t e, s
 // and then produces a 1/G share of the env's outputs: dwords g, g + G, ... of the (4-byte padded) grid record and of
 // the padded obs_self_t record, and one of the small vector outputs.  No LDS; a wave stores 64/G whole env records
 // contiguously.
-// lanes per env; measured at C3 (8192 envs, us per tick / fused env-steps/s): 2: 8.3 / 1.3e9, 4: 6.7 / 1.7e9,
-// 8: 5.1 / 2.5e9, 16: 5.7 / 2.4e9, 32: 7.6 / 1.5e9
-#ifndef CM3_CKF_G
-#define CM3_CKF_G 8
-#endif
-template <int N> struct CkFast {
+// Lanes per env G.  In-place stepping (re-used buffers), measured at C3 (8192 envs, us per tick / fused env-steps/s) in round 1:
+// 2: 8.3 / 1.3e9, 4: 6.7 / 1.7e9, 8: 5.1 / 2.5e9, 16: 5.7 / 2.4e9, 32: 7.6 / 1.5e9; round 2 (profiles/
+// r02_checkers_lanes_per_env_sweep.txt, three alternating rounds): in place 4: 6.42, 8: 5.05, 16: 5.48 -- but for a streaming-size
+// trajectory (every tick its own slot, non-temporal stores) 4: 7.95, 8: 6.22, 16: 5.87.  So G = 8 everywhere except on the
+// non-temporal path, which uses G = 16 (the round-1 tuning was specific to in-place stepping).
+constexpr int kCkG = 8, kCkGStream = 16;
+template <int N, int G_ = kCkG> struct CkFast {
   static constexpr int R = 3, C = 8, O = 2, K = 5, TR = 7, TC = 13;
   static constexpr int GRID_REC = R * (C + 1) * 2;  // 54
   static constexpr int OBST_REC = N * K * K * 3;    // 75 N
-  static constexpr int G = CM3_CKF_G;
+  static constexpr int G = G_;
   static constexpr int EPW = 64 / G;
 };
 
@@ -574,10 +575,10 @@ template <bool NT> __device__ __forceinline__ void ck_st(double4 *p, const doubl
   }
 }
 
-template <int N, bool NT = false>
+template <int N, bool NT = false, int G = kCkG>
 __device__ __forceinline__ void ckf_emit(const CheckersParams &p, const CkState<N> &s, int g, size_t e, bool env_ok,
                                          const CkOut &out) {
-  using F = CkFast<N>;
+  using F = CkFast<N, G>;
   constexpr int NO = N > 1 ? N - 1 : 1;
   if (!env_ok) return;
   // grid record: dword g
@@ -648,17 +649,18 @@ __device__ __forceinline__ void ckf_emit(const CheckersParams &p, const CkState<
 // their row redrawn for (episode + 1, step 0) by their writer lane.  Two barriers order the accesses to an action row (the
 // same memory for this tick and the next when the trajectory is stepped in place): tick waves have consumed their actions
 // -> barrier 1 -> draw-wave store (drained) -> barrier 2 -> redraw store.
-template <int N, bool FUSED, bool SPLIT = false, bool NT = false>
+template <int N, bool FUSED, bool SPLIT = false, bool NT = false, int G = kCkG>
 __global__ void __launch_bounds__(SPLIT ? 320 : 256) k_checkers_step_fast(const CheckersParams p) {
+  using F = CkFast<N, G>;
   static_assert(!(SPLIT && FUSED), "the draw wave serves exactly one tick");
-  static_assert(!SPLIT || 4 * CkFast<N>::EPW * N <= 64, "one lane per agent of every env of the workgroup");
+  static_assert(!SPLIT || 4 * F::EPW * N <= 64, "one lane per agent of every env of the workgroup");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool pre_rd = SPLIT && (p.flags & kCkPregenRead), pre_wr = SPLIT && (p.flags & kCkPregenWrite);
   if constexpr (SPLIT) {
     if (wave == 4) {  // the draw wave
       const int el = lane / N, ia = lane - el * N;
-      const size_t ed = (size_t)blockIdx.x * (4 * CkFast<N>::EPW) + el;
-      const bool ok = lane < 4 * CkFast<N>::EPW * N && ed < (size_t)p.E;
+      const size_t ed = (size_t)blockIdx.x * (4 * F::EPW) + el;
+      const bool ok = lane < 4 * F::EPW * N && ed < (size_t)p.E;
       const size_t edc = ed < (size_t)p.E ? ed : (size_t)p.E - 1;
       int a = 0;
       if (pre_wr) {
@@ -675,8 +677,8 @@ __global__ void __launch_bounds__(SPLIT ? 320 : 256) k_checkers_step_fast(const 
       return;
     }
   }
-  const int g = lane & (CkFast<N>::G - 1), sub = lane / CkFast<N>::G;
-  const size_t e = ((size_t)blockIdx.x * 4 + wave) * CkFast<N>::EPW + sub;
+  const int g = lane & (F::G - 1), sub = lane / F::G;
+  const size_t e = ((size_t)blockIdx.x * 4 + wave) * F::EPW + sub;
   const bool env_ok = e < (size_t)p.E;
   const size_t ec = env_ok ? e : (size_t)p.E - 1;
   const bool writer = env_ok && g == 0;
@@ -694,10 +696,10 @@ __global__ void __launch_bounds__(SPLIT ? 320 : 256) k_checkers_step_fast(const 
       __syncthreads();                             // barrier 1: the actions of this tick are consumed
     }
     if (ended) {  // AUTO_RESET: terminal observation (train_onpolicy.py:336-347), then the fresh episode
-      if (p.term_grid) ckf_emit<N, NT>(p, s, g, e, env_ok, ck_out_term(p, t));
+      if (p.term_grid) ckf_emit<N, NT, G>(p, s, g, e, env_ok, ck_out_term(p, t));
       ck_restart_env<N>(p, e, ec, writer, s, lv);
     }
-    ckf_emit<N, NT>(p, s, g, e, env_ok, ck_out_tick(p, t));
+    ckf_emit<N, NT, G>(p, s, g, e, env_ok, ck_out_tick(p, t));
     if (p.goals_next && writer) {
       uint8_t *gn = ck_tick_ptr(p.goals_next, p.st_goals_next, t);
 #pragma unroll
@@ -877,21 +879,26 @@ static int ck_fill(const cm3_checkers_desc *d, const cm3_checkers_bufs *b, const
 
 template <int N> static int ck_launch(const CheckersParams &p, bool step, hipStream_t stream) {
   if (ck_fast_ok(p)) {
-    constexpr unsigned kEnvsPerBlock = 4 * CkFast<N>::EPW;  // 4 waves x EPW envs per workgroup
-    const unsigned fblocks = (unsigned)(((size_t)p.E + kEnvsPerBlock - 1) / kEnvsPerBlock);
-    const bool nt = (p.flags & kCkObsStoreNt) != 0;   // streaming-size trajectory (ck_rollout)
+    const bool nt = (p.flags & kCkObsStoreNt) != 0;   // streaming-size trajectory (ck_rollout): non-temporal stores, G = 16
+    const unsigned epb = 4u * (nt ? CkFast<N, kCkGStream>::EPW : CkFast<N>::EPW);  // 4 waves x EPW envs per workgroup
+    const unsigned fblocks = (unsigned)(((size_t)p.E + epb - 1) / epb);
     if (step && p.n_ticks > 1) {
-      if (nt) hipLaunchKernelGGL((k_checkers_step_fast<N, true, false, true>), dim3(fblocks), dim3(256), 0, stream, p);
+      if (nt) hipLaunchKernelGGL((k_checkers_step_fast<N, true, false, true, kCkGStream>), dim3(fblocks), dim3(256), 0, stream, p);
       else hipLaunchKernelGGL((k_checkers_step_fast<N, true>), dim3(fblocks), dim3(256), 0, stream, p);
     } else if (step && (p.flags & (kCkPregenRead | kCkPregenWrite))) {
-      if constexpr (4 * CkFast<N>::EPW * N <= 64) {
-        if (nt) hipLaunchKernelGGL((k_checkers_step_fast<N, false, true, true>), dim3(fblocks), dim3(320), 0, stream, p);
-        else hipLaunchKernelGGL((k_checkers_step_fast<N, false, true>), dim3(fblocks), dim3(320), 0, stream, p);
+      if (nt) {
+        if constexpr (4 * CkFast<N, kCkGStream>::EPW * N <= 64)
+          hipLaunchKernelGGL((k_checkers_step_fast<N, false, true, true, kCkGStream>), dim3(fblocks), dim3(320), 0, stream, p);
+        else
+          return fail(CM3_ERR_INVALID, "internal: draw-wave launch requested for %d agents", N);
       } else {
-        return fail(CM3_ERR_INVALID, "internal: draw-wave launch requested for %d agents", N);
+        if constexpr (4 * CkFast<N>::EPW * N <= 64)
+          hipLaunchKernelGGL((k_checkers_step_fast<N, false, true>), dim3(fblocks), dim3(320), 0, stream, p);
+        else
+          return fail(CM3_ERR_INVALID, "internal: draw-wave launch requested for %d agents", N);
       }
     } else if (step) {
-      if (nt) hipLaunchKernelGGL((k_checkers_step_fast<N, false, false, true>), dim3(fblocks), dim3(256), 0, stream, p);
+      if (nt) hipLaunchKernelGGL((k_checkers_step_fast<N, false, false, true, kCkGStream>), dim3(fblocks), dim3(256), 0, stream, p);
       else hipLaunchKernelGGL((k_checkers_step_fast<N, false>), dim3(fblocks), dim3(256), 0, stream, p);
     } else
       hipLaunchKernelGGL((k_checkers_reset_fast<N>), dim3(fblocks), dim3(256), 0, stream, p);
@@ -997,9 +1004,10 @@ static int ck_rollout(const cm3_checkers_desc *d, const cm3_checkers_traj *t, in
     p.flags |= nt_flag;
     // random-action branch on the multi-lane kernel, at most one wave per SIMD (1024 on the chip) and one draw-wave lane
     // per agent: tick k also draws the actions of tick k + 1 (see k_checkers_step_fast, SPLIT)
-    const size_t tick_waves = ((size_t)p.E * CM3_CKF_G + 63) / 64;
+    const int lanes = nt_flag ? kCkGStream : kCkG;   // lanes per env of the kernel this tick will run
+    const size_t tick_waves = ((size_t)p.E * lanes + 63) / 64;
     if ((d->flags & CM3_FLAG_GEN_ACTIONS) && n_ticks > 1 && ck_fast_ok(p) && tick_waves <= 1024 &&
-        4 * (64 / CM3_CKF_G) * d->n_agents <= 64) {
+        4 * (64 / lanes) * d->n_agents <= 64) {
       p.st_actions = t->actions_stride;
       if (k > 0) p.flags |= kCkPregenRead;
       if (k + 1 < n_ticks) p.flags |= kCkPregenWrite;
