@@ -77,8 +77,7 @@ template <typename T> __device__ __forceinline__ T *ck_tick_ptr(T *base, size_t 
   return reinterpret_cast<T *>(reinterpret_cast<char *>(base) + stride * (size_t)t);
 }
 
-// internal flag bits set by ck_rollout only (never part of the ABI): see k_checkers_step_fast (SPLIT)
-constexpr uint32_t kCkPregenRead = 0x10000u, kCkPregenWrite = 0x20000u;
+// internal flag bits set by ck_rollout only (never part of the ABI)
 constexpr uint32_t kCkObsStoreNt = 0x100000u;  // internal: non-temporal observation stores (set by ck_rollout only)
 
 constexpr int kCkLdsBytes = 40960;  // per-wave staging tile (64 rows x up to 640 bytes)
@@ -321,7 +320,7 @@ __device__ __forceinline__ bool ck_tick_env(const CheckersParams &p, int t, size
   int act[N];
   const uint64_t genv = (uint64_t)(p.env_id_base + (int64_t)ec);
   int32_t *actions_t = ck_tick_ptr(p.actions, p.st_actions, t);
-  if ((p.flags & CM3_FLAG_GEN_ACTIONS) && !(p.flags & kCkPregenRead)) {
+  if (p.flags & CM3_FLAG_GEN_ACTIONS) {
     uint32_t words[4 * ((N + 3) / 4)];
 #pragma unroll
     for (int c = 0; c < (N + 3) / 4; ++c) {
@@ -642,41 +641,13 @@ __device__ __forceinline__ void ckf_emit(const CheckersParams &p, const CkState<
   }
 }
 
-// SPLIT (ticks of cm3_checkers_rollout with in-kernel actions, at most one wave per SIMD; same scheme as the particle pair
-// mapping): a fifth wave draws the actions of the NEXT launch -- key (episode, step + 1), lane l = agent l % N of the
-// workgroup's env l / N, one contiguous row store -- while the four tick waves run; the next launch reads its actions with
-// its other inputs, so the generator's serial chain leaves the head of every launch.  Envs whose episode ends this tick get
-// their row redrawn for (episode + 1, step 0) by their writer lane.  Two barriers order the accesses to an action row (the
-// same memory for this tick and the next when the trajectory is stepped in place): tick waves have consumed their actions
-// -> barrier 1 -> draw-wave store (drained) -> barrier 2 -> redraw store.
-template <int N, bool FUSED, bool SPLIT = false, bool NT = false, int G = kCkG>
-__global__ void __launch_bounds__(SPLIT ? 320 : 256) k_checkers_step_fast(const CheckersParams p) {
+// (Round 1 added a fifth "draw wave" per workgroup that drew the next launch's actions, as in the particle pair mapping: 5.08 ->
+// 4.96 us per tick at C3 then.  Re-measured in round 2 (profiles/r02_draw_wave_on_off.txt) it had become a loss -- stage 2: 4.99 ->
+// 4.88 us, stage 1: 4.19 -> 3.98 us without it -- and was removed together with the particle one.)
+template <int N, bool FUSED, bool NT = false, int G = kCkG>
+__global__ void __launch_bounds__(256) k_checkers_step_fast(const CheckersParams p) {
   using F = CkFast<N, G>;
-  static_assert(!(SPLIT && FUSED), "the draw wave serves exactly one tick");
-  static_assert(!SPLIT || 4 * F::EPW * N <= 64, "one lane per agent of every env of the workgroup");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const bool pre_rd = SPLIT && (p.flags & kCkPregenRead), pre_wr = SPLIT && (p.flags & kCkPregenWrite);
-  if constexpr (SPLIT) {
-    if (wave == 4) {  // the draw wave
-      const int el = lane / N, ia = lane - el * N;
-      const size_t ed = (size_t)blockIdx.x * (4 * F::EPW) + el;
-      const bool ok = lane < 4 * F::EPW * N && ed < (size_t)p.E;
-      const size_t edc = ed < (size_t)p.E ? ed : (size_t)p.E - 1;
-      int a = 0;
-      if (pre_wr) {
-        const uint32_t steps_d = (uint32_t)p.steps[edc], episode_d = (uint32_t)p.episode[edc];
-        const u32x4 w = action_words(p.seed, (uint64_t)(p.env_id_base + (int64_t)edc), episode_d, steps_d + 1u,
-                                     (uint32_t)(ia >> 2));
-        const int q = ia & 3;
-        a = rand5(q == 0 ? w.x : (q == 1 ? w.y : (q == 2 ? w.z : w.w)));
-      }
-      __syncthreads();  // barrier 1
-      if (pre_wr && ok) ck_tick_ptr(p.actions, p.st_actions, 1)[ed * N + ia] = a;
-      __builtin_amdgcn_s_waitcnt(0);
-      __syncthreads();  // barrier 2
-      return;
-    }
-  }
   const int g = lane & (F::G - 1), sub = lane / F::G;
   const size_t e = ((size_t)blockIdx.x * 4 + wave) * F::EPW + sub;
   const bool env_ok = e < (size_t)p.E;
@@ -685,16 +656,11 @@ __global__ void __launch_bounds__(SPLIT ? 320 : 256) k_checkers_step_fast(const 
   CkState<N> s;
   CkLive<N> lv;
   ck_load_env<N>(p, ec, s, lv);
-  const uint32_t episode_before = lv.episode;
   // FUSED == false: exactly one tick; the loop and the per-tick offsets fold away
   const int n_ticks = FUSED ? p.n_ticks : 1;
 #pragma unroll 1
   for (int t = 0; t < n_ticks; ++t) {
     const bool ended = ck_tick_env<N>(p, t, e, ec, writer, s, lv);
-    if constexpr (SPLIT) {
-      if (!pre_rd) __builtin_amdgcn_s_waitcnt(0);  // first tick of a rollout: this tick's own action row is written
-      __syncthreads();                             // barrier 1: the actions of this tick are consumed
-    }
     if (ended) {  // AUTO_RESET: terminal observation (train_onpolicy.py:336-347), then the fresh episode
       if (p.term_grid) ckf_emit<N, NT, G>(p, s, g, e, env_ok, ck_out_term(p, t));
       ck_restart_env<N>(p, e, ec, writer, s, lv);
@@ -704,21 +670,6 @@ __global__ void __launch_bounds__(SPLIT ? 320 : 256) k_checkers_step_fast(const 
       uint8_t *gn = ck_tick_ptr(p.goals_next, p.st_goals_next, t);
 #pragma unroll
       for (int i = 0; i < N; ++i) gn[e * N + i] = lv.goal[i];
-    }
-  }
-  if constexpr (SPLIT) {
-    __syncthreads();  // barrier 2: the draw wave's row for the next launch is in memory
-    if (pre_wr && lv.episode != episode_before && writer) {  // fresh episode: the next launch sees (episode, step 0)
-      const uint64_t genv = (uint64_t)(p.env_id_base + (int64_t)ec);
-      int32_t *next = ck_tick_ptr(p.actions, p.st_actions, 1);
-#pragma unroll
-      for (int c = 0; c < (N + 3) / 4; ++c) {
-        const u32x4 w = action_words(p.seed, genv, lv.episode, 0u, (uint32_t)c);
-        const uint32_t words[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (4 * c + q < N) next[e * N + 4 * c + q] = rand5(words[q]);
-      }
     }
   }
   if (writer) ck_store_env<N>(p, e, s, lv);
@@ -883,22 +834,10 @@ template <int N> static int ck_launch(const CheckersParams &p, bool step, hipStr
     const unsigned epb = 4u * (nt ? CkFast<N, kCkGStream>::EPW : CkFast<N>::EPW);  // 4 waves x EPW envs per workgroup
     const unsigned fblocks = (unsigned)(((size_t)p.E + epb - 1) / epb);
     if (step && p.n_ticks > 1) {
-      if (nt) hipLaunchKernelGGL((k_checkers_step_fast<N, true, false, true, kCkGStream>), dim3(fblocks), dim3(256), 0, stream, p);
+      if (nt) hipLaunchKernelGGL((k_checkers_step_fast<N, true, true, kCkGStream>), dim3(fblocks), dim3(256), 0, stream, p);
       else hipLaunchKernelGGL((k_checkers_step_fast<N, true>), dim3(fblocks), dim3(256), 0, stream, p);
-    } else if (step && (p.flags & (kCkPregenRead | kCkPregenWrite))) {
-      if (nt) {
-        if constexpr (4 * CkFast<N, kCkGStream>::EPW * N <= 64)
-          hipLaunchKernelGGL((k_checkers_step_fast<N, false, true, true, kCkGStream>), dim3(fblocks), dim3(320), 0, stream, p);
-        else
-          return fail(CM3_ERR_INVALID, "internal: draw-wave launch requested for %d agents", N);
-      } else {
-        if constexpr (4 * CkFast<N>::EPW * N <= 64)
-          hipLaunchKernelGGL((k_checkers_step_fast<N, false, true>), dim3(fblocks), dim3(320), 0, stream, p);
-        else
-          return fail(CM3_ERR_INVALID, "internal: draw-wave launch requested for %d agents", N);
-      }
     } else if (step) {
-      if (nt) hipLaunchKernelGGL((k_checkers_step_fast<N, false, false, true, kCkGStream>), dim3(fblocks), dim3(256), 0, stream, p);
+      if (nt) hipLaunchKernelGGL((k_checkers_step_fast<N, false, true, kCkGStream>), dim3(fblocks), dim3(256), 0, stream, p);
       else hipLaunchKernelGGL((k_checkers_step_fast<N, false>), dim3(fblocks), dim3(256), 0, stream, p);
     } else
       hipLaunchKernelGGL((k_checkers_reset_fast<N>), dim3(fblocks), dim3(256), 0, stream, p);
@@ -1002,16 +941,6 @@ static int ck_rollout(const cm3_checkers_desc *d, const cm3_checkers_traj *t, in
     int rc = ck_fill(d, &b, nullptr, true, p);
     if (rc != CM3_OK) return rc;
     p.flags |= nt_flag;
-    // random-action branch on the multi-lane kernel, at most one wave per SIMD (1024 on the chip) and one draw-wave lane
-    // per agent: tick k also draws the actions of tick k + 1 (see k_checkers_step_fast, SPLIT)
-    const int lanes = nt_flag ? kCkGStream : kCkG;   // lanes per env of the kernel this tick will run
-    const size_t tick_waves = ((size_t)p.E * lanes + 63) / 64;
-    if ((d->flags & CM3_FLAG_GEN_ACTIONS) && n_ticks > 1 && ck_fast_ok(p) && tick_waves <= 1024 &&
-        4 * (64 / lanes) * d->n_agents <= 64) {
-      p.st_actions = t->actions_stride;
-      if (k > 0) p.flags |= kCkPregenRead;
-      if (k + 1 < n_ticks) p.flags |= kCkPregenWrite;
-    }
     rc = ck_dispatch(p, d->n_agents, true, (hipStream_t)stream);
     if (rc != CM3_OK) return rc;
   }

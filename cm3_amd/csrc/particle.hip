@@ -543,8 +543,6 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step(const ParticlePara
 // ascending = pair order of core.py:145-147), the post-step positions of j come back by shuffle, and the
 // collision tests / reached flags are reduced with wave ballots.  No LDS: lane (i,k) writes the obs_others
 // vector (i,k), so a wave stores 64/G whole env records contiguously (16 B per lane, unit stride).
-// internal flag bits set by particle_rollout only (never part of the ABI; fill_params rejects unknown public bits)
-constexpr uint32_t kFlagPregenRead = 0x10000u, kFlagPregenWrite = 0x20000u;
 
 
 
@@ -560,19 +558,13 @@ template <int N> struct PairGeom {
   static constexpr int EPW = 64 / G;  // envs per wave
 };
 
-// SPLIT (ticks of cm3_particle_rollout_* with in-kernel actions, see particle_rollout): the workgroup carries ONE extra
-// wave, the DRAW wave, which draws the actions of the NEXT launch while the physics waves run this tick.  Its lane l
-// serves agent l % N of the workgroup's env l / N: it loads the RNG key (step counter, episode), runs the draw for
-// (episode, step + 1) -- the key the next launch will see unless this tick ends the episode -- and stores one contiguous
-// row of actions into the next tick's slot; the next launch then reads its actions with its other inputs, and the
-// generator's serial ~1.1 k cycles no longer sit between a launch's loads and everything that needs the action.
-// Envs whose episode does end this tick (known to the physics waves only at the end) get their row redrawn for
-// (episode + 1, step 0) by the physics waves.  Two workgroup barriers order the three accesses to an action row, which
-// matters when the trajectory is stepped in place (stride 0: this tick's and the next tick's rows are the same memory):
-// physics read (registers) -> barrier 1 -> draw-wave store (drained) -> barrier 2 -> physics redraw store.  Values and
-// final memory contents are identical to drawing at the head of every launch.
-template <typename R, int N, int WAVES, bool FUSED, bool SPLIT = false, bool NT = false>
-__global__ void __launch_bounds__((WAVES + (SPLIT ? 1 : 0)) * 64)
+// (Round 1 gave the workgroup an extra "draw wave" that drew the NEXT launch's actions while the physics waves ran, handing the
+// action row forward between launches: 3.43 -> 3.30 us per tick at C2 then.  Re-measured in round 2 on the same box
+// (profiles/r02_draw_wave_on_off.txt) it had become a loss in every configuration that used it -- in place 0-6 %, trajectory mode
+// 5-10 % -- and was removed: a fifth wave, two workgroup barriers and an extra store + reload of the action row cost more than the
+// Philox chain they hid once the square roots had left the physics chain.)
+template <typename R, int N, int WAVES, bool FUSED, bool NT = false>
+__global__ void __launch_bounds__(WAVES * 64)
     k_particle_step_pairs(const void *h_state_in, const void *h_goals_in, const int32_t *h_meta_in, const int32_t *h_episode,
                           const int32_t *h_actions, const int h_E, const uint32_t h_flags, const int h_E0, const int h_EN,
                           const ParticleParams p) {
@@ -580,12 +572,10 @@ __global__ void __launch_bounds__((WAVES + (SPLIT ? 1 : 0)) * 64)
   // SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count), so the addresses of the first loads do not wait for a
   // kernarg fetch.
   static_assert(N >= 2, "the pair mapping needs at least two agents");
-  static_assert(!(SPLIT && FUSED), "the draw wave serves exactly one tick");
   using V4 = typename Vec<R>::v4;
   using V2 = typename Vec<R>::v2;
   using PG = PairGeom<N>;
   constexpr int NO = PG::NO, SLOTS = PG::SLOTS, G = PG::G, EPW = PG::EPW;
-  static_assert(!SPLIT || WAVES * EPW * N <= 64, "the draw wave serves every env of the workgroup with one lane per agent");
 
   const int lane = threadIdx.x & 63, wave_all = threadIdx.x >> 6;
   const int wave = wave_all;
@@ -600,29 +590,6 @@ __global__ void __launch_bounds__((WAVES + (SPLIT ? 1 : 0)) * 64)
   const bool lead = slot_ok && k == 0;  // one lane per agent does the per-agent stores
   const bool head = gslot == 0;         // one lane per env does the per-env stores
 
-  const bool pre_rd = SPLIT && (h_flags & kFlagPregenRead), pre_wr = SPLIT && (h_flags & kFlagPregenWrite);
-  if constexpr (SPLIT) {
-    if (wave_all == WAVES) {  // the draw wave (train_onpolicy.py:305-307 for the next launch)
-      const int el = lane / N, ia = lane - el * N;  // env of the workgroup, agent
-      const size_t ed = (size_t)h_E0 + (size_t)blockIdx.x * (WAVES * EPW) + el;
-      const bool ok = lane < WAVES * EPW * N && ed < EN;
-      const size_t edc = ed < EN ? ed : EN - 1;
-      int a = 0;
-      if (pre_wr) {
-        const int steps_d = h_meta_in[2 * edc] + 1;
-        const uint32_t episode_d = (uint32_t)h_episode[edc];
-        const uint64_t genv_d = (uint64_t)(p.env_id_base + (int64_t)edc);
-        const u32x4 w = action_words(p.seed, genv_d, episode_d, (uint32_t)steps_d, (uint32_t)(ia >> 2));
-        const int q = ia & 3;
-        a = rand5(q == 0 ? w.x : (q == 1 ? w.y : (q == 2 ? w.z : w.w)));
-      }
-      __syncthreads();  // barrier 1: the physics waves hold this tick's actions in registers
-      if (pre_wr && ok) tick_ptr(p.actions, p.st_actions, 1)[ed * N + ia] = a;
-      __builtin_amdgcn_s_waitcnt(0);  // the row is written before the physics waves may redraw parts of it
-      __syncthreads();  // barrier 2
-      return;
-    }
-  }
   CM3_STAMP(0, false);
   // ---- loads (once per launch; the state then lives in registers across the ticks of this launch) -------------
   const V4 *sin4 = reinterpret_cast<const V4 *>(h_state_in);
@@ -647,17 +614,13 @@ __global__ void __launch_bounds__((WAVES + (SPLIT ? 1 : 0)) * 64)
     int32_t *actions_t = tick_ptr(p.actions, p.st_actions, t);
     int act = 0;
     R f_x, f_y;
-    if (SPLIT && pre_rd) {
-      act = h_actions[ec * N + i];  // drawn by the previous launch (its draw wave, or its physics waves after a reset)
+    if (gen) {  // train_onpolicy.py:305-307
+      const u32x4 w = action_words(p.seed, genv, episode, (uint32_t)steps, (uint32_t)(i >> 2));
+      const int q = i & 3;
+      act = rand5(q == 0 ? w.x : (q == 1 ? w.y : (q == 2 ? w.z : w.w)));
+      if (env_ok && lead) actions_t[e * N + i] = act;
     } else {
-      if (gen) {  // train_onpolicy.py:305-307
-        const u32x4 w = action_words(p.seed, genv, episode, (uint32_t)steps, (uint32_t)(i >> 2));
-        const int q = i & 3;
-        act = rand5(q == 0 ? w.x : (q == 1 ? w.y : (q == 2 ? w.z : w.w)));
-        if (env_ok && lead) actions_t[e * N + i] = act;
-      } else {
-        act = actions_t[ec * N + i];
-      }
+      act = actions_t[ec * N + i];
     }
 
     CM3_STAMP(2, false);
@@ -685,10 +648,6 @@ __global__ void __launch_bounds__((WAVES + (SPLIT ? 1 : 0)) * 64)
     si.z = si.z + si.x * kDt;
     si.w = si.w + si.y * kDt;
     steps += 1;
-    if constexpr (SPLIT) {
-      if (!pre_rd) __builtin_amdgcn_s_waitcnt(0);  // first tick of a rollout: this tick's own action row is written
-      __syncthreads();                             // barrier 1: every physics wave holds its actions in registers
-    }
     {
       const int src = base + j * NO;  // lead lane of agent j
       sj.x = __shfl(si.x, src, 64);
@@ -752,15 +711,6 @@ __global__ void __launch_bounds__((WAVES + (SPLIT ? 1 : 0)) * 64)
     }
 
     CM3_STAMP(6, false);
-    if constexpr (SPLIT) {
-      __syncthreads();  // barrier 2: the draw wave's row for the next launch is in memory
-      if (pre_wr && was_reset) {  // fresh episode: the next launch sees (episode + 1, step 0)
-        const u32x4 w = action_words(p.seed, genv, episode, 0u, (uint32_t)(i >> 2));
-        const int q = i & 3;
-        const int a = rand5(q == 0 ? w.x : (q == 1 ? w.y : (q == 2 ? w.z : w.w)));
-        if (env_ok && lead) tick_ptr(p.actions, p.st_actions, 1)[e * N + i] = a;
-      }
-    }
     // ---- per-tick stores ------------------------------------------------------------------------------------------
     if (env_ok) {
       if (lead) {
@@ -1191,33 +1141,18 @@ template <typename R, int N, int WAVES> static int launch_pairs(const ParticlePa
   if constexpr (N >= 2) {
     const size_t envs_per_block = (size_t)WAVES * PairGeom<N>::EPW;
     const unsigned blocks = (unsigned)(((size_t)(p.EN - p.E0) + envs_per_block - 1) / envs_per_block);
-    constexpr bool kCanSplit = WAVES == 4 && sizeof(R) == 4 && WAVES * PairGeom<N>::EPW * N <= 64;
-    bool split = false;
-    // the chip sees every chain of a rollout at once: the occupancy test counts the workgroups of all p.E envs
-    const size_t all_blocks = ((size_t)p.E + envs_per_block - 1) / envs_per_block;
-    // pays only while the launch is at most one physics wave per SIMD (1024 on the chip): N = 4, us per launch without /
-    // with the draw wave: 4096 envs 3.43 / 3.31; 16384 envs 5.31 / 6.14; N = 8, 4096 envs (4096 waves) 6.7 / 8.7
-    if constexpr (kCanSplit)
-      split = p.n_ticks == 1 && (p.flags & CM3_FLAG_GEN_ACTIONS) && (p.flags & (kFlagPregenRead | kFlagPregenWrite)) &&
-              all_blocks * WAVES <= 1024;
     constexpr bool kF32 = sizeof(R) == 4;
     const bool nt = kF32 && (p.flags & kFlagObsStoreNt);   // streaming-size trajectory (obs_store_nt)
-#define CM3_LAUNCH_PAIRS(FUSED_, SPLIT_, NT_, THREADS_)                                                                     \
-  hipLaunchKernelGGL((k_particle_step_pairs<R, N, WAVES, FUSED_, SPLIT_, NT_>), dim3(blocks), dim3(THREADS_), 0, stream,    \
+#define CM3_LAUNCH_PAIRS(FUSED_, NT_)                                                                                       \
+  hipLaunchKernelGGL((k_particle_step_pairs<R, N, WAVES, FUSED_, NT_>), dim3(blocks), dim3(WAVES * 64), 0, stream,          \
                      p.state_in, p.goals_in, p.meta_in, (const int32_t *)p.episode, (const int32_t *)p.actions, p.E, p.flags, \
                      p.E0, p.EN, p)
     if (p.n_ticks > 1) {
-      if (nt) CM3_LAUNCH_PAIRS(true, false, kF32, WAVES * 64);
-      else CM3_LAUNCH_PAIRS(true, false, false, WAVES * 64);
-    } else if (split) {
-      // a tick of cm3_particle_rollout_* with in-kernel actions: the extra wave draws the next launch's actions (SPLIT)
-      if constexpr (kCanSplit) {
-        if (nt) CM3_LAUNCH_PAIRS(false, true, kF32, (WAVES + 1) * 64);
-        else CM3_LAUNCH_PAIRS(false, true, false, (WAVES + 1) * 64);
-      }
+      if (nt) CM3_LAUNCH_PAIRS(true, kF32);
+      else CM3_LAUNCH_PAIRS(true, false);
     } else {
-      if (nt) CM3_LAUNCH_PAIRS(false, false, kF32, WAVES * 64);
-      else CM3_LAUNCH_PAIRS(false, false, false, WAVES * 64);
+      if (nt) CM3_LAUNCH_PAIRS(false, kF32);
+      else CM3_LAUNCH_PAIRS(false, false);
     }
 #undef CM3_LAUNCH_PAIRS
     CM3_HIP_CHECK(hipGetLastError());
@@ -1395,14 +1330,6 @@ static int particle_rollout(const cm3_particle_desc *d, const cm3_particle_traj 
     int rc = fill_params(d, &b, kStep, nullptr, p);
     if (rc != CM3_OK) return rc;
     p.flags |= obs_store_nt(t->obs_others_stride, n_ticks);
-    if ((d->flags & CM3_FLAG_GEN_ACTIONS) && n_ticks > 1) {
-      // Random-action branch: tick k also draws the actions of tick k + 1 (its draw wave, see k_particle_step_pairs) and
-      // tick k + 1 reads them with its other inputs.  Only the pair mapping with 4-wave workgroups in float32 honours the
-      // two bits; every other kernel ignores them and keeps drawing at its head -- same values either way.
-      p.st_actions = t->actions_stride;
-      if (k > 0) p.flags |= kFlagPregenRead;
-      if (k + 1 < n_ticks) p.flags |= kFlagPregenWrite;
-    }
     rc = launch<R>(p, d->n_agents, kStep, (hipStream_t)stream);
     if (rc != CM3_OK) return rc;
   }

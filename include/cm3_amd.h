@@ -144,8 +144,7 @@ int cm3_particle_observe_f64(const cm3_particle_desc *desc, const cm3_particle_b
  * goals have n_ticks+1 slots (slot t = before tick t, slot t+1 = after); the per-tick outputs have
  * n_ticks slots.  meta/episode are live (in place).  goals_stride == 0 keeps one live goals array.
  * term_* are optional (n_ticks slots).  All strides 0 = every tick overwrites the same live buffers.
- * With CM3_FLAG_GEN_ACTIONS the launch of tick t may already write action slot t+1 (the next launch's draw, made while
- * tick t runs); when the call's launches have completed every slot holds exactly the actions its tick used. */
+ * With CM3_FLAG_GEN_ACTIONS every launch draws its own actions and writes them to its action slot. */
 typedef struct cm3_particle_traj {
   void *state;        size_t state_stride;
   void *goals;        size_t goals_stride;

@@ -60,7 +60,7 @@ def test_chains_equal_single_chain(kernel, N, cfg, mode):
 
 
 def test_chains_in_place_equal_stepwise():
-    """bench.py's in-place stepper with 4 chains == 1 chain (zero strides, draw wave, hipGraph replays)."""
+    """bench.py's in-place stepper with 4 chains == 1 chain (zero strides, hipGraph replays)."""
     from bench import ParticleStepper
     cfg = load_cfg("particle_stage2_antipodal.json")
     a = ParticleStepper(cfg, 4, 4096, "cuda:0", seed=7, n_chains=1)
