@@ -754,7 +754,13 @@ template <int N> struct AgentGeom {
 };
 
 template <typename R, int N, int WAVES, bool FUSED, bool NT = false>
-__global__ void __launch_bounds__(WAVES * 64) k_particle_step_agents(const ParticleParams p) {
+__global__ void __launch_bounds__(WAVES * 64)
+    k_particle_step_agents(const void *h_state_in, const void *h_goals_in, const int32_t *h_meta_in, const int32_t *h_episode,
+                           const int32_t *h_actions, const int h_E, const uint32_t h_flags, const int h_E0, const int h_EN,
+                           const ParticleParams p) {
+  // Leading scalar arguments as in k_particle_step_pairs: they repeat the fields of `p` that the first loads need and are
+  // preloaded into SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count), so the first addresses do not wait for a
+  // kernarg fetch (worth 7.7 % on the pair kernel at C2, profiles/r02_remaining_round1_tunings_rechecked.txt).
   static_assert(N >= 2, "the agent mapping needs at least two agents");
   using V4 = typename Vec<R>::v4;
   using V2 = typename Vec<R>::v2;
@@ -764,8 +770,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_agents(const Parti
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int gi = lane & (G - 1), sub = lane / G, base = lane - gi;
-  const size_t E = (size_t)p.E, EN = (size_t)p.EN;  // array extent (row stride); this launch covers envs [E0, EN)
-  const size_t e0 = (size_t)p.E0 + ((size_t)blockIdx.x * WAVES + wave) * EPW;
+  const size_t E = (size_t)h_E, EN = (size_t)h_EN;  // array extent (row stride); this launch covers envs [E0, EN)
+  const size_t e0 = (size_t)h_E0 + ((size_t)blockIdx.x * WAVES + wave) * EPW;
   const size_t e = e0 + sub;
   const bool env_ok = e < EN;
   const size_t ec = env_ok ? e : EN - 1;
@@ -777,14 +783,14 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step_agents(const Parti
 
   CM3_STAMP(0, false);
   // ---- loads (once per launch; the state then lives in registers across the ticks of this launch) -------------
-  V4 si = reinterpret_cast<const V4 *>(p.state_in)[(size_t)i * E + ec];
-  V2 gl = reinterpret_cast<const V2 *>(p.goals_in)[(size_t)i * E + ec];
-  const int2 meta = reinterpret_cast<const int2 *>(p.meta_in)[ec];
+  V4 si = reinterpret_cast<const V4 *>(h_state_in)[(size_t)i * E + ec];
+  V2 gl = reinterpret_cast<const V2 *>(h_goals_in)[(size_t)i * E + ec];
+  const int2 meta = reinterpret_cast<const int2 *>(h_meta_in)[ec];
   int steps = meta.x, collisions = meta.y;
-  const bool auto_reset = (p.flags & CM3_FLAG_AUTO_RESET) != 0;
-  const bool gen = (p.flags & CM3_FLAG_GEN_ACTIONS) != 0;
+  const bool auto_reset = (h_flags & CM3_FLAG_AUTO_RESET) != 0;
+  const bool gen = (h_flags & CM3_FLAG_GEN_ACTIONS) != 0;
   uint32_t episode = 0;
-  if (gen || (p.flags & CM3_FLAG_AUTO_RESET)) episode = (uint32_t)p.episode[ec];
+  if (gen || (h_flags & CM3_FLAG_AUTO_RESET)) episode = (uint32_t)h_episode[ec];
   const uint32_t episode_in = episode;
   const uint64_t genv = (uint64_t)(p.env_id_base + (int64_t)ec);
   const R kDt = R(0.1), kKeep = R(1 - 0.25);
@@ -1170,13 +1176,18 @@ template <typename R, int N, int WAVES> static int launch_agents(const ParticleP
     const size_t envs_per_block = (size_t)WAVES * AgentGeom<N>::EPW;
     const unsigned blocks = (unsigned)(((size_t)(p.EN - p.E0) + envs_per_block - 1) / envs_per_block);
     const bool nt = sizeof(R) == 4 && (p.flags & kFlagObsStoreNt);   // streaming-size trajectory (obs_store_nt)
+#define CM3_LAUNCH_AGENTS(FUSED_, NT_)                                                                                      \
+  hipLaunchKernelGGL((k_particle_step_agents<R, N, WAVES, FUSED_, NT_>), dim3(blocks), dim3(WAVES * 64), 0, stream,         \
+                     p.state_in, p.goals_in, p.meta_in, (const int32_t *)p.episode, (const int32_t *)p.actions, p.E, p.flags, \
+                     p.E0, p.EN, p)
     if (p.n_ticks > 1) {
-      if (nt) hipLaunchKernelGGL((k_particle_step_agents<R, N, WAVES, true, sizeof(R) == 4>), dim3(blocks), dim3(WAVES * 64), 0, stream, p);
-      else hipLaunchKernelGGL((k_particle_step_agents<R, N, WAVES, true>), dim3(blocks), dim3(WAVES * 64), 0, stream, p);
+      if (nt) CM3_LAUNCH_AGENTS(true, sizeof(R) == 4);
+      else CM3_LAUNCH_AGENTS(true, false);
     } else {
-      if (nt) hipLaunchKernelGGL((k_particle_step_agents<R, N, WAVES, false, sizeof(R) == 4>), dim3(blocks), dim3(WAVES * 64), 0, stream, p);
-      else hipLaunchKernelGGL((k_particle_step_agents<R, N, WAVES, false>), dim3(blocks), dim3(WAVES * 64), 0, stream, p);
+      if (nt) CM3_LAUNCH_AGENTS(false, sizeof(R) == 4);
+      else CM3_LAUNCH_AGENTS(false, false);
     }
+#undef CM3_LAUNCH_AGENTS
     CM3_HIP_CHECK(hipGetLastError());
     return CM3_OK;
   } else {
