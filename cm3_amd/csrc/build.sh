@@ -11,7 +11,9 @@ pids=()
 pids+=($!)
 "${HIPCC}" ${FLAGS} -DCM3_PARTICLE_F64 -c "${HERE}/particle.hip" -o "${HERE}/_obj/particle_f64.o" &
 pids+=($!)
-for f in checkers util advantage actor actor_checkers policy; do
+"${HIPCC}" ${FLAGS} -mllvm -amdgpu-kernarg-preload-count=16 -c "${HERE}/checkers.hip" -o "${HERE}/_obj/checkers.o" &
+pids+=($!)
+for f in util advantage actor actor_checkers policy; do
   "${HIPCC}" ${FLAGS} -c "${HERE}/${f}.hip" -o "${HERE}/_obj/${f}.o" &
   pids+=($!)
 done

@@ -246,7 +246,24 @@ __device__ __forceinline__ void ck_emit_vectors(const CheckersParams &p, const C
   }
 }
 
-template <int N> __device__ __forceinline__ void ck_load(const CheckersParams &p, size_t ec, CkState<N> &s) {
+// the pointers / scalars the first loads of a step launch need; the fast kernel receives them as LEADING scalar kernel arguments
+// (preloaded into SGPRs at wave launch, -mllvm -amdgpu-kernarg-preload-count) so these loads do not wait for a kernarg fetch
+struct CkHead {
+  const uint64_t *mask;
+  const uint32_t *agents;
+  const int32_t *steps;
+  const int32_t *episode;
+  const uint8_t *goals;
+  int E;
+  uint32_t flags;
+};
+__device__ __forceinline__ CkHead ck_head(const CheckersParams &p) {
+  CkHead h;
+  h.mask = p.mask; h.agents = p.agents; h.steps = p.steps; h.episode = p.episode; h.goals = p.goals; h.E = p.E; h.flags = p.flags;
+  return h;
+}
+
+template <int N> __device__ __forceinline__ void ck_load(const CkHead &p, size_t ec, CkState<N> &s) {
   s.mask = p.mask[ec];
 #pragma unroll
   for (int i = 0; i < N; ++i) {
@@ -287,7 +304,7 @@ template <int N> struct CkLive {
 };
 
 template <int N>
-__device__ __forceinline__ void ck_load_env(const CheckersParams &p, size_t ec, CkState<N> &s, CkLive<N> &lv) {
+__device__ __forceinline__ void ck_load_env(const CkHead &p, size_t ec, CkState<N> &s, CkLive<N> &lv) {
   ck_load<N>(p, ec, s);
   lv.steps = p.steps[ec];
 #pragma unroll
@@ -418,7 +435,7 @@ __device__ __forceinline__ void ck_restart_env(const CheckersParams &p, size_t e
 template <int N>
 __device__ __forceinline__ void ck_step_env(const CheckersParams &p, size_t e, size_t ec, bool writer, CkState<N> &s) {
   CkLive<N> lv;
-  ck_load_env<N>(p, ec, s, lv);
+  ck_load_env<N>(ck_head(p), ec, s, lv);
   if (ck_tick_env<N>(p, 0, e, ec, writer, s, lv)) {
     if (writer && p.term_grid) {
       CkOut o;
@@ -645,17 +662,21 @@ __device__ __forceinline__ void ckf_emit(const CheckersParams &p, const CkState<
 // 4.96 us per tick at C3 then.  Re-measured in round 2 (profiles/r02_draw_wave_on_off.txt) it had become a loss -- stage 2: 4.99 ->
 // 4.88 us, stage 1: 4.19 -> 3.98 us without it -- and was removed together with the particle one.)
 template <int N, bool FUSED, bool NT = false, int G = kCkG>
-__global__ void __launch_bounds__(256) k_checkers_step_fast(const CheckersParams p) {
+__global__ void __launch_bounds__(256)
+    k_checkers_step_fast(const uint64_t *h_mask, const uint32_t *h_agents, const int32_t *h_steps, const int32_t *h_episode,
+                         const uint8_t *h_goals, const int h_E, const uint32_t h_flags, const CheckersParams p) {
   using F = CkFast<N, G>;
+  CkHead hd;   // leading, preloaded kernel arguments (see CkHead)
+  hd.mask = h_mask; hd.agents = h_agents; hd.steps = h_steps; hd.episode = h_episode; hd.goals = h_goals; hd.E = h_E; hd.flags = h_flags;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane & (F::G - 1), sub = lane / F::G;
   const size_t e = ((size_t)blockIdx.x * 4 + wave) * F::EPW + sub;
-  const bool env_ok = e < (size_t)p.E;
-  const size_t ec = env_ok ? e : (size_t)p.E - 1;
+  const bool env_ok = e < (size_t)h_E;
+  const size_t ec = env_ok ? e : (size_t)h_E - 1;
   const bool writer = env_ok && g == 0;
   CkState<N> s;
   CkLive<N> lv;
-  ck_load_env<N>(p, ec, s, lv);
+  ck_load_env<N>(hd, ec, s, lv);
   // FUSED == false: exactly one tick; the loop and the per-tick offsets fold away
   const int n_ticks = FUSED ? p.n_ticks : 1;
 #pragma unroll 1
@@ -694,7 +715,7 @@ template <int N> __global__ void __launch_bounds__(256) k_checkers_reset_fast(co
       if (p.episode) p.episode[e] = p.episode[e] + 1;
     }
   } else {
-    ck_load<N>(p, ec, s);
+    ck_load<N>(ck_head(p), ec, s);
   }
   ckf_emit<N>(p, s, g, e, env_ok, ck_out_tick(p, 0));
 }
@@ -732,7 +753,7 @@ template <int N> __global__ void __launch_bounds__(64) k_checkers_reset(const Ch
       if (p.episode) p.episode[e] = p.episode[e] + 1;
     }
   } else {
-    ck_load<N>(p, ec, s);
+    ck_load<N>(ck_head(p), ec, s);
   }
   ck_emit<N>(p, s, lds, lane, e0, e, active);
 }
@@ -833,14 +854,19 @@ template <int N> static int ck_launch(const CheckersParams &p, bool step, hipStr
     const bool nt = (p.flags & kCkObsStoreNt) != 0;   // streaming-size trajectory (ck_rollout): non-temporal stores, G = 16
     const unsigned epb = 4u * (nt ? CkFast<N, kCkGStream>::EPW : CkFast<N>::EPW);  // 4 waves x EPW envs per workgroup
     const unsigned fblocks = (unsigned)(((size_t)p.E + epb - 1) / epb);
+#define CM3_LAUNCH_CKF(...)                                                                                                  \
+  hipLaunchKernelGGL((k_checkers_step_fast<N, __VA_ARGS__>), dim3(fblocks), dim3(256), 0, stream, (const uint64_t *)p.mask,    \
+                     (const uint32_t *)p.agents, (const int32_t *)p.steps, (const int32_t *)p.episode, (const uint8_t *)p.goals, \
+                     p.E, p.flags, p)
     if (step && p.n_ticks > 1) {
-      if (nt) hipLaunchKernelGGL((k_checkers_step_fast<N, true, true, kCkGStream>), dim3(fblocks), dim3(256), 0, stream, p);
-      else hipLaunchKernelGGL((k_checkers_step_fast<N, true>), dim3(fblocks), dim3(256), 0, stream, p);
+      if (nt) CM3_LAUNCH_CKF(true, true, kCkGStream);
+      else CM3_LAUNCH_CKF(true);
     } else if (step) {
-      if (nt) hipLaunchKernelGGL((k_checkers_step_fast<N, false, true, kCkGStream>), dim3(fblocks), dim3(256), 0, stream, p);
-      else hipLaunchKernelGGL((k_checkers_step_fast<N, false>), dim3(fblocks), dim3(256), 0, stream, p);
+      if (nt) CM3_LAUNCH_CKF(false, true, kCkGStream);
+      else CM3_LAUNCH_CKF(false);
     } else
       hipLaunchKernelGGL((k_checkers_reset_fast<N>), dim3(fblocks), dim3(256), 0, stream, p);
+#undef CM3_LAUNCH_CKF
     CM3_HIP_CHECK(hipGetLastError());
     return CM3_OK;
   }
