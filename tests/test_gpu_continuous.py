@@ -1,8 +1,9 @@
 """GPU: round-2 additions of the collection loop (train_onpolicy.py:281-377).
 
 * independent sub-batch chains produce bit-identical trajectories;
-* a finished env (no auto-reset) freezes its step / collision counters -- scenario.collisions is the EPISODE's value when
-  train_onpolicy.py:356 reads it -- and the continuous mode captures the terminal count before the same-launch reset;
+* env.step() keeps the reference's counters (they go on counting if an env is stepped after `done`), and the COLLECTOR reads
+  scenario.collisions of each episode from the per-tick trajectory slot at the tick that ends it (train_onpolicy.py:302, :356);
+  the continuous mode captures that count before the same-launch reset zeroes it;
 * Checkers continuous collection: the terminal transition keeps the true post-step next_* (train_onpolicy.py:336-347),
   goals are recorded per slot, actions_prev restarts at zeros (:295);
 * a captured actor/step graph follows the annealed epsilon (:369) without re-capture;
