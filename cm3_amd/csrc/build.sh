@@ -4,7 +4,8 @@ set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 OUT="${HERE}/../libcm3_hip.so"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function ${CM3_EXTRA_FLAGS:-}"
+OUT="${CM3_OUT:-${OUT}}"
 mkdir -p "${HERE}/_obj"
 pids=()
 "${HIPCC}" ${FLAGS} -mllvm -amdgpu-kernarg-preload-count=16 -DCM3_PARTICLE_F32 -c "${HERE}/particle.hip" -o "${HERE}/_obj/particle_f32.o" &

@@ -58,6 +58,16 @@ struct ParticleParams {
 template <typename T> __device__ __forceinline__ T *tick_ptr(T *base, size_t stride, int t) {
   return reinterpret_cast<T *>(reinterpret_cast<char *>(base) + stride * (size_t)t);
 }
+// Asks for kernel-argument fields NOW: fields first used late in a kernel are otherwise fetched right before that use, and the
+// wave then waits for the scalar load in the middle of its critical path (measured in the pair kernel: three such fetches).
+#define CM3_FETCH_EARLY(...) cm3_fetch_early(__VA_ARGS__)
+template <typename T> __device__ __forceinline__ void cm3_fetch_one(const T &v) { asm volatile("" ::"s"(v)); }
+template <typename... T> __device__ __forceinline__ void cm3_fetch_early(const T &...v) { (cm3_fetch_one(v), ...); }
+
+// element at <uniform base> + <32-bit byte offset>: selects the scalar-base addressing mode of global loads / stores
+template <typename T> __device__ __forceinline__ T *at32(const void *base, uint32_t byte_offset) {
+  return reinterpret_cast<T *>(const_cast<char *>(reinterpret_cast<const char *>(base)) + byte_offset);
+}
 template <> __device__ __forceinline__ void *tick_ptr<void>(void *base, size_t stride, int t) {
   return base ? (void *)(reinterpret_cast<char *>(base) + stride * (size_t)t) : nullptr;
 }
@@ -102,7 +112,14 @@ template <typename R> __device__ __forceinline__ R logaddexp0(R x) {
 // on the slow path.  NaN distances take the slow path (NaN propagates as in the reference).
 template <typename R> struct Contact;
 template <> struct Contact<float> {
-  static constexpr float kSkip = 0.41f;
+#ifndef CM3_F32_LIBM_SOFTPLUS
+  // hardware soft-plus (logaddexp0<float> below): at dist = 0.32f, x = -19.99998 and exp2(x * log2 e) = 2^-28.85; for every
+  // larger dist the term 1 + t rounds to exactly 1 (needs t <= 2^-24: a margin of 4.85 in the exponent against the ~1 ulp of
+  // v_exp_f32), log2(1) = 0, the soft-plus is 0 + 0 and the force +-0
+  static constexpr float kSkip = 0.32f;
+#else
+  static constexpr float kSkip = 0.41f;  // libm: expf(x) = 0 for x <= -110
+#endif
 };
 template <> struct Contact<double> {
   static constexpr double kSkip = 1.05;
@@ -116,6 +133,27 @@ template <typename R> __device__ __forceinline__ void contact_force_near(R dx, R
   f_x = kForce * dx / dist * pen;
   f_y = kForce * dy / dist * pen;
 }
+
+// float32: the soft-plus of the contact chain on the hardware transcendental units (v_exp_f32 / v_log_f32, base 2, ~1 ulp).
+// libm's expf + log1pf were 136 of the ~580 instructions a lane of the C2 kernel executes per tick, and by
+// tools/probes/issue_probe.hip a lone wave pays 4 cycles for every one of them.  What it costs in accuracy:
+//   softplus(x) = max(x, 0) + log(1 + exp(-|x|)); the second term lies in (0, ln 2] and is now computed with an ABSOLUTE
+//   error of ~2e-7 (for t = exp(-|x|) < 6e-8 the sum 1 + t rounds to 1 and the term is dropped: another 6e-8).  That error
+//   reaches the force as 100 * 1e-3 * 3e-7 = 3e-8 and a velocity as 3e-9 per tick -- three orders of magnitude below the
+//   rounding of the float32 distance itself (1 ulp of dist = 3e-8 is amplified by 1/1e-3 in x) and below the 1e-5 bound.
+//   Measured (tools/f32_error_scan.py, 20 x 4096 crowded states per agent count, against the float64 oracle): the worst
+//   errors are IDENTICAL to the libm build's (N = 4: state 1.63e-6, obs_others 2.33e-6; N = 8: 2.97e-6 / 4.30e-6).
+// The reference's own np.logaddexp is libm-dependent in its last ulps, so there never was a bit pattern
+// to match here; sqrt and the three divisions of the chain stay IEEE (replacing them as well measured +30 % error, see
+// profiles/r02_f32_softplus_hw.txt).  x == 0 gives 0 + log2(2) * ln 2 = ln 2; NaN propagates; beyond dist = 0.3166 the force
+// is exactly +-0 (libm: beyond 0.41), which is what kSkip2 relies on only as an upper bound.  The float64 instantiation is
+// unchanged (libm, the 1e-11 parity path).  -DCM3_F32_LIBM_SOFTPLUS builds the libm chain for comparisons.
+#ifndef CM3_F32_LIBM_SOFTPLUS
+template <> __device__ __forceinline__ float logaddexp0<float>(float x) {
+  const float t = __builtin_amdgcn_exp2f(-fabsf(x) * 1.44269504088896340736f);
+  return (x > 0.0f ? x : 0.0f) + __builtin_amdgcn_logf(1.0f + t) * 0.693147180559945309417f;
+}
+#endif
 
 template <typename R> __device__ __forceinline__ void contact_force(R dx, R dy, R &f_x, R &f_y) {
   const R d2 = dx * dx + dy * dy;
@@ -293,9 +331,13 @@ __device__ __forceinline__ bool episode_is_random(const ParticleParams &p, uint6
 
 // Agent i (and its landmark) of the fresh episode.  `i` may be a run-time value: the config arrays are read
 // through a compare-select chain, never through a dynamically indexed private array.
-template <typename R, int N>
+// `presets` (optional): the ax | ay | lx | ly arrays of `p` as they lie in the kernel-argument segment (preset_table below).
+// The kernels whose lanes hold ONE agent (run-time i) read their four values from there with one indexed load each: with
+// the select chains all 4 x CM3_MAX_AGENTS doubles had to sit in SGPRs at once, and the register allocator paid for that
+// on the main path (81 SGPR spill moves per launch in the lane-per-agent kernel at N = 8).
+template <typename R, int N, bool TABLE = false>
 __device__ __forceinline__ void init_agent(const ParticleParams &p, uint64_t genv, uint32_t episode, bool rnd, int i,
-                                           typename Vec<R>::v4 &s, typename Vec<R>::v2 &g) {
+                                           typename Vec<R>::v4 &s, typename Vec<R>::v2 &g, const double *presets = nullptr) {
   const u32x4 a = reset_words(p.seed, genv, episode, 1u + (uint32_t)i);
   double x, y;
   if (rnd) {  // :77-78
@@ -303,10 +345,15 @@ __device__ __forceinline__ void init_agent(const ParticleParams &p, uint64_t gen
     y = 2.0 * u01(a.y) - 1.0;
   } else {  // :80-83
     double cx = 0.0, cy = 0.0;
+    if constexpr (TABLE) {
+      cx = presets[i];
+      cy = presets[CM3_MAX_AGENTS + i];
+    } else {
 #pragma unroll
-    for (int k = 0; k < N; ++k) {
-      cx = (k == i) ? p.ax[k] : cx;
-      cy = (k == i) ? p.ay[k] : cy;
+      for (int k = 0; k < N; ++k) {
+        cx = (k == i) ? p.ax[k] : cx;
+        cy = (k == i) ? p.ay[k] : cy;
+      }
     }
     x = cx;
     y = cy;
@@ -330,10 +377,15 @@ __device__ __forceinline__ void init_agent(const ParticleParams &p, uint64_t gen
     g.y = R(2.0 * u01(l.y) - 1.0);
   } else {  // :91
     double lx = 0.0, ly = 0.0;
+    if constexpr (TABLE) {
+      lx = presets[2 * CM3_MAX_AGENTS + i];
+      ly = presets[3 * CM3_MAX_AGENTS + i];
+    } else {
 #pragma unroll
-    for (int k = 0; k < N; ++k) {
-      lx = (k == i) ? p.lx[k] : lx;
-      ly = (k == i) ? p.ly[k] : ly;
+      for (int k = 0; k < N; ++k) {
+        lx = (k == i) ? p.lx[k] : lx;
+        ly = (k == i) ? p.ly[k] : ly;
+      }
     }
     g.x = R(lx);
     g.y = R(ly);
@@ -346,6 +398,30 @@ __device__ __forceinline__ void init_episode(const ParticleParams &p, uint64_t g
   const bool rnd = episode_is_random(p, genv, episode);
 #pragma unroll
   for (int i = 0; i < N; ++i) init_agent<R, N>(p, genv, episode, rnd, i, s[i], g[i]);
+}
+
+// The explicit arguments of k_particle_step_pairs / k_particle_step_agents as the code object lays them out in the
+// kernel-argument segment (each argument at its natural alignment, in declaration order): gives the offset of `p`.
+struct SharedEnvKernArgs {
+  const void *state_in, *goals_in;
+  const int32_t *meta_in, *episode;
+  int E;
+  uint32_t flags;
+  int E0, EN, max_steps;
+  const int32_t *actions;
+  ParticleParams p;
+};
+static_assert(offsetof(ParticleParams, ay) == offsetof(ParticleParams, ax) + CM3_MAX_AGENTS * sizeof(double) &&
+                  offsetof(ParticleParams, lx) == offsetof(ParticleParams, ax) + 2 * CM3_MAX_AGENTS * sizeof(double) &&
+                  offsetof(ParticleParams, ly) == offsetof(ParticleParams, ax) + 3 * CM3_MAX_AGENTS * sizeof(double),
+              "init_agent reads ax | ay | lx | ly as one table");
+__device__ __forceinline__ const double *preset_table() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const char *args = (const char *)__builtin_amdgcn_kernarg_segment_ptr();  // constant address space -> generic
+  return reinterpret_cast<const double *>(args + offsetof(SharedEnvKernArgs, p) + offsetof(ParticleParams, ax));
+#else
+  return nullptr;  // host pass of the single-source compile: never called
+#endif
 }
 
 // ---- the step kernel --------------------------------------------------------------------------------
@@ -566,11 +642,16 @@ template <int N> struct PairGeom {
 template <typename R, int N, int WAVES, bool FUSED, bool NT = false>
 __global__ void __launch_bounds__(WAVES * 64)
     k_particle_step_pairs(const void *h_state_in, const void *h_goals_in, const int32_t *h_meta_in, const int32_t *h_episode,
-                          const int32_t *h_actions, const int h_E, const uint32_t h_flags, const int h_E0, const int h_EN,
-                          const ParticleParams p) {
+                          const int h_E, const uint32_t h_flags, const int h_E0, const int h_EN, const int h_max_steps,
+                          const int32_t *h_actions, const ParticleParams p) {
   // The leading arguments repeat the fields of `p` that the first loads need: scalar kernel arguments are preloaded into
-  // SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count), so the addresses of the first loads do not wait for a
-  // kernarg fetch.
+  // SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count; the first 14 dwords in practice: everything up to and
+  // including h_max_steps), so the addresses of the first loads do not wait for a kernarg fetch.
+  // Index and address arithmetic is 32-bit: every array of one tick is below 4 GiB (checked by launch_pairs), so an element is
+  // <uniform base pointer> + <32-bit byte offset of the lane>, which the hardware adds itself (global_load/store with a
+  // scalar base).  By tools/probes/issue_probe.hip a lone wave issues one VALU instruction per 4 cycles whatever it is, so at
+  // one wave per SIMD the launch time is the length of the executed path: the 64-bit multiplies, adds and compares of
+  // size_t indexing were ~8 % of it.
   static_assert(N >= 2, "the pair mapping needs at least two agents");
   using V4 = typename Vec<R>::v4;
   using V2 = typename Vec<R>::v2;
@@ -580,10 +661,10 @@ __global__ void __launch_bounds__(WAVES * 64)
   const int lane = threadIdx.x & 63, wave_all = threadIdx.x >> 6;
   const int wave = wave_all;
   const int gslot = lane & (G - 1), sub = lane / G, base = lane - gslot;
-  const size_t E = (size_t)h_E, EN = (size_t)h_EN;  // array extent (row stride); this launch covers envs [h_E0, h_EN)
-  const size_t e = (size_t)h_E0 + ((size_t)blockIdx.x * WAVES + wave) * EPW + sub;
+  const uint32_t E = (uint32_t)h_E, EN = (uint32_t)h_EN;  // array extent (row stride); this launch covers envs [h_E0, h_EN)
+  const uint32_t e = (uint32_t)h_E0 + ((uint32_t)blockIdx.x * WAVES + wave) * EPW + sub;
   const bool env_ok = e < EN;
-  const size_t ec = env_ok ? e : EN - 1;
+  const uint32_t ec = env_ok ? e : EN - 1;
   const bool slot_ok = gslot < SLOTS;
   const int gi = slot_ok ? gslot : 0;
   const int i = gi / NO, k = gi - i * NO, j = k < i ? k : k + 1;
@@ -592,17 +673,19 @@ __global__ void __launch_bounds__(WAVES * 64)
 
   CM3_STAMP(0, false);
   // ---- loads (once per launch; the state then lives in registers across the ticks of this launch) -------------
-  const V4 *sin4 = reinterpret_cast<const V4 *>(h_state_in);
-  V4 si = sin4[(size_t)i * E + ec];
-  V4 sj = sin4[(size_t)j * E + ec];
-  V2 gl = reinterpret_cast<const V2 *>(h_goals_in)[(size_t)i * E + ec];
-  const int2 meta = reinterpret_cast<const int2 *>(h_meta_in)[ec];
+  const uint32_t row_i = (uint32_t)i * E, row_j = (uint32_t)j * E;
+  V4 si = *at32<const V4>(h_state_in, (row_i + ec) * (uint32_t)sizeof(V4));
+  V4 sj = *at32<const V4>(h_state_in, (row_j + ec) * (uint32_t)sizeof(V4));
+  V2 gl = *at32<const V2>(h_goals_in, (row_i + ec) * (uint32_t)sizeof(V2));
+  const int2 meta = *at32<const int2>(h_meta_in, ec * 8u);
   int steps = meta.x, collisions = meta.y;
   const bool auto_reset = (h_flags & CM3_FLAG_AUTO_RESET) != 0;
   const bool gen = (h_flags & CM3_FLAG_GEN_ACTIONS) != 0;
   uint32_t episode = 0;
-  if (gen || (h_flags & CM3_FLAG_AUTO_RESET)) episode = (uint32_t)h_episode[ec];
+  if (gen || (h_flags & CM3_FLAG_AUTO_RESET)) episode = (uint32_t)*at32<const int32_t>(h_episode, ec * 4u);
   const uint32_t episode_in = episode;
+  // (after the vector loads are in flight: the scalar fetches complete in their shadow)
+  CM3_FETCH_EARLY(p.state_out, p.goals_out, p.goals_in, p.collisions_tick, p.reward_n, p.reward, p.done, p.obs_others, p.meta_out);
   const uint64_t genv = (uint64_t)(p.env_id_base + (int64_t)ec);
   const R kDt = R(0.1), kKeep = R(1 - 0.25);
 
@@ -616,11 +699,10 @@ __global__ void __launch_bounds__(WAVES * 64)
     R f_x, f_y;
     if (gen) {  // train_onpolicy.py:305-307
       const u32x4 w = action_words(p.seed, genv, episode, (uint32_t)steps, (uint32_t)(i >> 2));
-      const int q = i & 3;
-      act = rand5(q == 0 ? w.x : (q == 1 ? w.y : (q == 2 ? w.z : w.w)));
-      if (env_ok && lead) actions_t[e * N + i] = act;
+      act = rand5(pick_word(w, i & 3));
+      if (env_ok && lead) *at32<int32_t>(actions_t, (e * N + i) * 4u) = act;
     } else {
-      act = actions_t[ec * N + i];
+      act = *at32<const int32_t>(actions_t, (ec * N + i) * 4u);
     }
 
     CM3_STAMP(2, false);
@@ -681,13 +763,13 @@ __global__ void __launch_bounds__(WAVES * 64)
 #pragma unroll
     for (int a = 0; a < N; ++a) rews[a] = __shfl(rew, base + a * NO, 64);
     const R reward = sum_agents<R, N>(rews);
-    const bool done = (steps == p.max_steps) || all_reached;
+    const bool done = (steps == h_max_steps) || all_reached;
 
-    if (env_ok && lead) reinterpret_cast<R *>(tick_ptr(p.reward_n, p.st_reward_n, t))[e * N + i] = rew;
+    if (env_ok && lead) *at32<R>(tick_ptr(p.reward_n, p.st_reward_n, t), (e * N + i) * (uint32_t)sizeof(R)) = rew;
     if (env_ok && head) {
-      reinterpret_cast<R *>(tick_ptr(p.reward, p.st_reward, t))[e] = reward;
-      tick_ptr(p.done, p.st_done, t)[e] = done ? 1 : 0;
-      if (p.collisions_tick) tick_ptr(p.collisions_tick, p.st_coll, t)[e] = collisions;
+      *at32<R>(tick_ptr(p.reward, p.st_reward, t), e * (uint32_t)sizeof(R)) = reward;
+      *at32<uint8_t>(tick_ptr(p.done, p.st_done, t), e) = done ? 1 : 0;
+      if (p.collisions_tick) *at32<int32_t>(tick_ptr(p.collisions_tick, p.st_coll, t), e * 4u) = collisions;
     }
 
     CM3_STAMP(5, true);
@@ -697,14 +779,14 @@ __global__ void __launch_bounds__(WAVES * 64)
       if (env_ok) {
         void *term_state = tick_ptr(p.term_state, p.st_term_state, t);
         void *term_obs = tick_ptr(p.term_obs_others, p.st_term_obs, t);
-        if (term_state && lead) reinterpret_cast<V4 *>(term_state)[(size_t)i * E + e] = si;
-        if (term_obs && slot_ok) reinterpret_cast<V4 *>(term_obs)[e * SLOTS + gslot] = sub4<R, V4>(sj, si);
+        if (term_state && lead) *at32<V4>(term_state, (row_i + e) * (uint32_t)sizeof(V4)) = si;
+        if (term_obs && slot_ok) *at32<V4>(term_obs, (e * SLOTS + gslot) * (uint32_t)sizeof(V4)) = sub4<R, V4>(sj, si);
       }
       episode += 1;
       const bool rnd = episode_is_random(p, genv, episode);
       V2 gj;
-      init_agent<R, N>(p, genv, episode, rnd, i, si, gl);
-      init_agent<R, N>(p, genv, episode, rnd, j, sj, gj);
+      init_agent<R, N, true>(p, genv, episode, rnd, i, si, gl, preset_table());
+      init_agent<R, N, true>(p, genv, episode, rnd, j, sj, gj, preset_table());
       steps = 0;
       collisions = 0;
       was_reset = true;
@@ -714,13 +796,13 @@ __global__ void __launch_bounds__(WAVES * 64)
     // ---- per-tick stores ------------------------------------------------------------------------------------------
     if (env_ok) {
       if (lead) {
-        reinterpret_cast<V4 *>(tick_ptr(p.state_out, p.st_state, t))[(size_t)i * E + e] = si;
+        *at32<V4>(tick_ptr(p.state_out, p.st_state, t), (row_i + e) * (uint32_t)sizeof(V4)) = si;
         if (p.goals_out != p.goals_in || was_reset)
-          reinterpret_cast<V2 *>(tick_ptr(p.goals_out, p.st_goals, t))[(size_t)i * E + e] = gl;
+          *at32<V2>(tick_ptr(p.goals_out, p.st_goals, t), (row_i + e) * (uint32_t)sizeof(V2)) = gl;
       }
       // observation (multi-goal_spread.py:145-154): vector (i,k) of env e; lanes of a wave cover whole records
       if (slot_ok)
-        store_obs_vec<NT>(reinterpret_cast<V4 *>(tick_ptr(p.obs_others, p.st_obs, t)) + (e * SLOTS + gslot), sub4<R, V4>(sj, si));
+        store_obs_vec<NT>(at32<V4>(tick_ptr(p.obs_others, p.st_obs, t), (e * SLOTS + gslot) * (uint32_t)sizeof(V4)), sub4<R, V4>(sj, si));
     }
   }
 
@@ -730,8 +812,8 @@ __global__ void __launch_bounds__(WAVES * 64)
     int2 m;
     m.x = steps;
     m.y = collisions;
-    reinterpret_cast<int2 *>(p.meta_out)[e] = m;
-    if (episode != episode_in) p.episode[e] = (int32_t)episode;
+    *at32<int2>(p.meta_out, e * 8u) = m;
+    if (episode != episode_in) *at32<int32_t>(p.episode, e * 4u) = (int32_t)episode;
   }
   CM3_STAMP(8, true);
 }
@@ -756,11 +838,12 @@ template <int N> struct AgentGeom {
 template <typename R, int N, int WAVES, bool FUSED, bool NT = false>
 __global__ void __launch_bounds__(WAVES * 64)
     k_particle_step_agents(const void *h_state_in, const void *h_goals_in, const int32_t *h_meta_in, const int32_t *h_episode,
-                           const int32_t *h_actions, const int h_E, const uint32_t h_flags, const int h_E0, const int h_EN,
-                           const ParticleParams p) {
+                           const int h_E, const uint32_t h_flags, const int h_E0, const int h_EN, const int h_max_steps,
+                           const int32_t *h_actions, const ParticleParams p) {
   // Leading scalar arguments as in k_particle_step_pairs: they repeat the fields of `p` that the first loads need and are
   // preloaded into SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count), so the first addresses do not wait for a
-  // kernarg fetch (worth 7.7 % on the pair kernel at C2, profiles/r02_remaining_round1_tunings_rechecked.txt).
+  // kernarg fetch (worth 7.7 % on the pair kernel at C2, profiles/r02_remaining_round1_tunings_rechecked.txt).  32-bit index
+  // and address arithmetic as in the pair kernel (every per-tick array below 4 GiB, checked by launch_agents).
   static_assert(N >= 2, "the agent mapping needs at least two agents");
   using V4 = typename Vec<R>::v4;
   using V2 = typename Vec<R>::v2;
@@ -770,11 +853,11 @@ __global__ void __launch_bounds__(WAVES * 64)
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int gi = lane & (G - 1), sub = lane / G, base = lane - gi;
-  const size_t E = (size_t)h_E, EN = (size_t)h_EN;  // array extent (row stride); this launch covers envs [E0, EN)
-  const size_t e0 = (size_t)h_E0 + ((size_t)blockIdx.x * WAVES + wave) * EPW;
-  const size_t e = e0 + sub;
+  const uint32_t E = (uint32_t)h_E, EN = (uint32_t)h_EN;  // array extent (row stride); this launch covers envs [E0, EN)
+  const uint32_t e0 = (uint32_t)h_E0 + ((uint32_t)blockIdx.x * WAVES + wave) * EPW;
+  const uint32_t e = e0 + sub;
   const bool env_ok = e < EN;
-  const size_t ec = env_ok ? e : EN - 1;
+  const uint32_t ec = env_ok ? e : EN - 1;
   const bool agent_ok = gi < N;
   const int i = agent_ok ? gi : 0;
   const bool mine = env_ok && agent_ok;  // this lane owns agent i of env e
@@ -783,15 +866,18 @@ __global__ void __launch_bounds__(WAVES * 64)
 
   CM3_STAMP(0, false);
   // ---- loads (once per launch; the state then lives in registers across the ticks of this launch) -------------
-  V4 si = reinterpret_cast<const V4 *>(h_state_in)[(size_t)i * E + ec];
-  V2 gl = reinterpret_cast<const V2 *>(h_goals_in)[(size_t)i * E + ec];
-  const int2 meta = reinterpret_cast<const int2 *>(h_meta_in)[ec];
+  const uint32_t row_i = (uint32_t)i * E;
+  V4 si = *at32<const V4>(h_state_in, (row_i + ec) * (uint32_t)sizeof(V4));
+  V2 gl = *at32<const V2>(h_goals_in, (row_i + ec) * (uint32_t)sizeof(V2));
+  const int2 meta = *at32<const int2>(h_meta_in, ec * 8u);
   int steps = meta.x, collisions = meta.y;
   const bool auto_reset = (h_flags & CM3_FLAG_AUTO_RESET) != 0;
   const bool gen = (h_flags & CM3_FLAG_GEN_ACTIONS) != 0;
   uint32_t episode = 0;
-  if (gen || (h_flags & CM3_FLAG_AUTO_RESET)) episode = (uint32_t)h_episode[ec];
+  if (gen || (h_flags & CM3_FLAG_AUTO_RESET)) episode = (uint32_t)*at32<const int32_t>(h_episode, ec * 4u);
   const uint32_t episode_in = episode;
+  // (after the vector loads are in flight: the scalar fetches complete in their shadow)
+  CM3_FETCH_EARLY(p.state_out, p.goals_out, p.goals_in, p.collisions_tick, p.reward_n, p.reward, p.done, p.obs_others, p.meta_out);
   const uint64_t genv = (uint64_t)(p.env_id_base + (int64_t)ec);
   const R kDt = R(0.1), kKeep = R(1 - 0.25);
 
@@ -809,8 +895,7 @@ __global__ void __launch_bounds__(WAVES * 64)
       }
     }
     wave_lds_sync();
-    V4 *out4 = reinterpret_cast<V4 *>(dst) + e0 * VPE;
-    for (int f = lane; f < nvec; f += 64) store_obs_vec<NT>(out4 + f, lds4[f]);
+    for (int f = lane; f < nvec; f += 64) store_obs_vec<NT>(at32<V4>(dst, (e0 * VPE + f) * (uint32_t)sizeof(V4)), lds4[f]);
     wave_lds_sync();
   };
 
@@ -822,11 +907,10 @@ __global__ void __launch_bounds__(WAVES * 64)
     int act;
     if (gen) {  // train_onpolicy.py:305-307
       const u32x4 w = action_words(p.seed, genv, episode, (uint32_t)steps, (uint32_t)(i >> 2));
-      const int q = i & 3;
-      act = rand5(q == 0 ? w.x : (q == 1 ? w.y : (q == 2 ? w.z : w.w)));
-      if (mine) actions_t[e * N + i] = act;
+      act = rand5(pick_word(w, i & 3));
+      if (mine) *at32<int32_t>(actions_t, (e * N + i) * 4u) = act;
     } else {
-      act = actions_t[ec * N + i];
+      act = *at32<const int32_t>(actions_t, (ec * N + i) * 4u);
     }
 
     CM3_STAMP(2, false);
@@ -915,13 +999,13 @@ __global__ void __launch_bounds__(WAVES * 64)
 #pragma unroll
     for (int a = 0; a < N; ++a) rews[a] = __shfl(rew, base + a, 64);
     const R reward = sum_agents<R, N>(rews);
-    const bool done = (steps == p.max_steps) || all_reached;
+    const bool done = (steps == h_max_steps) || all_reached;
 
-    if (mine) reinterpret_cast<R *>(tick_ptr(p.reward_n, p.st_reward_n, t))[e * N + i] = rew;
+    if (mine) *at32<R>(tick_ptr(p.reward_n, p.st_reward_n, t), (e * N + i) * (uint32_t)sizeof(R)) = rew;
     if (head) {
-      reinterpret_cast<R *>(tick_ptr(p.reward, p.st_reward, t))[e] = reward;
-      tick_ptr(p.done, p.st_done, t)[e] = done ? 1 : 0;
-      if (p.collisions_tick) tick_ptr(p.collisions_tick, p.st_coll, t)[e] = collisions;
+      *at32<R>(tick_ptr(p.reward, p.st_reward, t), e * (uint32_t)sizeof(R)) = reward;
+      *at32<uint8_t>(tick_ptr(p.done, p.st_done, t), e) = done ? 1 : 0;
+      if (p.collisions_tick) *at32<int32_t>(tick_ptr(p.collisions_tick, p.st_coll, t), e * 4u) = collisions;
     }
 
     CM3_STAMP(5, false);
@@ -931,7 +1015,7 @@ __global__ void __launch_bounds__(WAVES * 64)
       void *term_state = tick_ptr(p.term_state, p.st_term_state, t);
       void *term_obs = tick_ptr(p.term_obs_others, p.st_term_obs, t);
       if (__any(done)) {  // wave-uniform: the tile store needs every lane
-        if (term_state && done && mine) reinterpret_cast<V4 *>(term_state)[(size_t)i * E + e] = si;
+        if (term_state && done && mine) *at32<V4>(term_state, (row_i + e) * (uint32_t)sizeof(V4)) = si;
         if (term_obs) {
           // terminal observations of the finished envs; rows of unfinished envs in the tile are not written out
           if (agent_ok) {
@@ -940,18 +1024,17 @@ __global__ void __launch_bounds__(WAVES * 64)
               if (j != i) lds4[sub * VPE + i * NO + (j < i ? j : j - 1)] = sub4<R, V4>(oj[j], si);
           }
           wave_lds_sync();
-          V4 *out4 = reinterpret_cast<V4 *>(term_obs) + e0 * VPE;
           const unsigned long long done_bits = __ballot(done);
           for (int f = lane; f < nvec; f += 64) {
             const int row = f / VPE;
-            if ((done_bits >> (row * G)) & 1ull) out4[f] = lds4[f];
+            if ((done_bits >> (row * G)) & 1ull) *at32<V4>(term_obs, (e0 * VPE + f) * (uint32_t)sizeof(V4)) = lds4[f];
           }
           wave_lds_sync();
         }
         if (done) {
           episode += 1;
           const bool rnd = episode_is_random(p, genv, episode);
-          init_agent<R, N>(p, genv, episode, rnd, i, si, gl);
+          init_agent<R, N, true>(p, genv, episode, rnd, i, si, gl, preset_table());
           steps = 0;
           collisions = 0;
           was_reset = true;
@@ -969,9 +1052,9 @@ __global__ void __launch_bounds__(WAVES * 64)
     CM3_STAMP(6, false);
     // ---- per-tick stores ------------------------------------------------------------------------------------------
     if (mine) {
-      reinterpret_cast<V4 *>(tick_ptr(p.state_out, p.st_state, t))[(size_t)i * E + e] = si;
+      *at32<V4>(tick_ptr(p.state_out, p.st_state, t), (row_i + e) * (uint32_t)sizeof(V4)) = si;
       if (p.goals_out != p.goals_in || was_reset)
-        reinterpret_cast<V2 *>(tick_ptr(p.goals_out, p.st_goals, t))[(size_t)i * E + e] = gl;
+        *at32<V2>(tick_ptr(p.goals_out, p.st_goals, t), (row_i + e) * (uint32_t)sizeof(V2)) = gl;
     }
     store_obs(oj, tick_ptr(p.obs_others, p.st_obs, t));  // observation (multi-goal_spread.py:145-154)
   }
@@ -982,8 +1065,8 @@ __global__ void __launch_bounds__(WAVES * 64)
     int2 m;
     m.x = steps;
     m.y = collisions;
-    reinterpret_cast<int2 *>(p.meta_out)[e] = m;
-    if (episode != episode_in) p.episode[e] = (int32_t)episode;
+    *at32<int2>(p.meta_out, e * 8u) = m;
+    if (episode != episode_in) *at32<int32_t>(p.episode, e * 4u) = (int32_t)episode;
   }
   CM3_STAMP(8, true);
 }
@@ -1151,8 +1234,12 @@ template <typename R, int N, int WAVES> static int launch_pairs(const ParticlePa
     const bool nt = kF32 && (p.flags & kFlagObsStoreNt);   // streaming-size trajectory (obs_store_nt)
 #define CM3_LAUNCH_PAIRS(FUSED_, NT_)                                                                                       \
   hipLaunchKernelGGL((k_particle_step_pairs<R, N, WAVES, FUSED_, NT_>), dim3(blocks), dim3(WAVES * 64), 0, stream,          \
-                     p.state_in, p.goals_in, p.meta_in, (const int32_t *)p.episode, (const int32_t *)p.actions, p.E, p.flags, \
-                     p.E0, p.EN, p)
+                     p.state_in, p.goals_in, p.meta_in, (const int32_t *)p.episode, p.E, p.flags, p.E0, p.EN, p.max_steps,        \
+                     (const int32_t *)p.actions, p)
+    // the kernel indexes with 32-bit byte offsets: its largest per-tick array (obs_others) must stay below 4 GiB
+    if ((size_t)p.E * PairGeom<N>::SLOTS * 4 * sizeof(R) >= ((size_t)1 << 32))
+      return fail(CM3_ERR_INVALID, "the lane-per-pair kernel addresses at most 4 GiB per array: %d envs x %d agents is too large "
+                  "(use the default kernel choice)", p.E, N);
     if (p.n_ticks > 1) {
       if (nt) CM3_LAUNCH_PAIRS(true, kF32);
       else CM3_LAUNCH_PAIRS(true, false);
@@ -1178,8 +1265,11 @@ template <typename R, int N, int WAVES> static int launch_agents(const ParticleP
     const bool nt = sizeof(R) == 4 && (p.flags & kFlagObsStoreNt);   // streaming-size trajectory (obs_store_nt)
 #define CM3_LAUNCH_AGENTS(FUSED_, NT_)                                                                                      \
   hipLaunchKernelGGL((k_particle_step_agents<R, N, WAVES, FUSED_, NT_>), dim3(blocks), dim3(WAVES * 64), 0, stream,         \
-                     p.state_in, p.goals_in, p.meta_in, (const int32_t *)p.episode, (const int32_t *)p.actions, p.E, p.flags, \
-                     p.E0, p.EN, p)
+                     p.state_in, p.goals_in, p.meta_in, (const int32_t *)p.episode, p.E, p.flags, p.E0, p.EN, p.max_steps,        \
+                     (const int32_t *)p.actions, p)
+    // 32-bit byte offsets inside the kernel: the largest per-tick array (obs_others) must stay below 4 GiB
+    if ((size_t)p.E * AgentGeom<N>::VPE * 4 * sizeof(R) >= ((size_t)1 << 32))
+      return fail(CM3_ERR_INVALID, "the lane-per-agent kernel addresses at most 4 GiB per array: %d envs x %d agents is too large", p.E, N);
     if (p.n_ticks > 1) {
       if (nt) CM3_LAUNCH_AGENTS(true, sizeof(R) == 4);
       else CM3_LAUNCH_AGENTS(true, false);
@@ -1218,6 +1308,9 @@ template <typename R, int N> static int launch_n(const ParticleParams &p, Partic
     constexpr size_t kAgentHi = N == 4 || N == 5 ? 49152 : (N == 6 ? 65536 : (N == 7 ? ((size_t)1 << 17) : (N == 8 ? kInf : 0)));
     bool pairs = N >= 3 && (size_t)p.E <= kPairMax;
     bool agents = N >= 4 && (size_t)p.E >= kAgentLo && (size_t)p.E <= kAgentHi;
+    // both shared-env mappings index with 32-bit byte offsets (obs_others below 4 GiB per tick); beyond that only a forced choice
+    // reaches them (and is refused by their launchers)
+    if ((size_t)p.E * N * (N - 1) * 4 * sizeof(R) >= ((size_t)1 << 32)) pairs = agents = false;
     if (p.flags & CM3_FLAG_KERNEL_LANE_PER_ENV) pairs = agents = false;
     if (p.flags & CM3_FLAG_KERNEL_LANE_PER_PAIR) { pairs = true; agents = false; }
     if (p.flags & CM3_FLAG_KERNEL_LANE_PER_AGENT) agents = true;

@@ -53,6 +53,14 @@ __host__ __device__ inline double u01(uint32_t r) { return ((double)r + 0.5) * (
 // uniform integer on {0..4}: multiply-shift of one 32-bit word
 __host__ __device__ inline int rand5(uint32_t r) { return (int)mulhi32(r, 5u); }
 
+// word q (0..3) of a block, selected with masks so that all four words stay live: with a q == 0 ? x : ... chain the compiler
+// sinks the last Philox round into divergent per-word branches, which puts taken branches (~40 cycles each for a lone wave) on
+// the critical path of a step launch
+__host__ __device__ inline uint32_t pick_word(const u32x4 &w, int q) {
+  const uint32_t m0 = q == 0 ? ~0u : 0u, m1 = q == 1 ? ~0u : 0u, m2 = q == 2 ? ~0u : 0u, m3 = q == 3 ? ~0u : 0u;
+  return (w.x & m0) | (w.y & m1) | (w.z & m2) | (w.w & m3);
+}
+
 // actions of agents 4c..4c+3 of (env, episode, step) come from call c
 __host__ __device__ inline u32x4 action_words(uint64_t seed, uint64_t env, uint32_t episode, uint32_t step,
                                               uint32_t call) {

@@ -3,7 +3,8 @@
 // The reference compares a distance dist = np.sqrt(np.sum(np.square(delta))) against a constant:
 //   is_collision   dist < 0.15 + 0.15                      (multi-goal_spread.py:114-118)
 //   reached        -dist >= -0.05  <=>  dist <= 0.05       (multi-goal_spread.py:125-129)
-//   (build) the soft contact underflows to exactly +-0 for dist >= kSkip (particle.hip, contact_force)
+//   (build) the soft contact is exactly +-0 for dist >= kSkip (particle.hip, contact_force: 0.32 for the float32 soft-plus on
+//           the hardware transcendental units, 0.41 for float32 libm, 1.05 for float64)
 // IEEE sqrt is correctly rounded and monotone, so for a constant c of the working precision
 //   RN(sqrt(x)) <  c   <=>   x <  T_lt(c)   with T_lt(c) = min{ x : RN(sqrt(x)) >= c }
 //   RN(sqrt(x)) <= c   <=>   x <  T_lt(next_up(c))
@@ -21,8 +22,12 @@ template <typename R> struct Thresh;
 template <> struct Thresh<float> {
   // c = 0.15f + 0.15f = 0x1.333334p-2f (0.3f):  sqrtf(x) < c  <=>  x < kColl2
   static constexpr float kColl2 = 0x1.70a3d8p-4f;   // CM3_THRESH f32 coll 0.3
-  // c = 0.41f (Contact<float>::kSkip):          sqrtf(x) >= c <=>  x >= kSkip2
-  static constexpr float kSkip2 = 0x1.5844dp-3f;    // CM3_THRESH f32 skip 0.41
+  // c = Contact<float>::kSkip:                  sqrtf(x) >= c <=>  x >= kSkip2
+#ifndef CM3_F32_LIBM_SOFTPLUS
+  static constexpr float kSkip2 = 0x1.a36e2cp-4f;   // CM3_THRESH f32 skip 0.32
+#else
+  static constexpr float kSkip2 = 0x1.5844dp-3f;    // CM3_THRESH f32 skip_libm 0.41
+#endif
   // c = 0.05f:                                  sqrtf(x) <= c <=>  x < kReach2
   static constexpr float kReach2 = 0x1.47ae18p-9f;  // CM3_THRESH f32 reach 0.05
 };

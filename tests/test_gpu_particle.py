@@ -194,6 +194,35 @@ def test_f32_free_running_drift_vs_reference_golden(name, kernel):
         assert not failures, (name, failures[:5])
 
 
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_f32_contact_force_is_exactly_zero_from_the_skip_distance(kernel):
+    """The float32 kernels skip the contact chain from dist >= 0.32 (thresholds.h, Contact<float>::kSkip) on the argument that
+    the hardware soft-plus is exactly 0 there.  Checked on the device just BELOW the cut, where the chain still runs: from
+    0.3170 up the computed force must already be exactly +-0 (velocities stay bit-zero), so it is for every larger distance;
+    at 0.31 the force is non-zero (the test does see forces)."""
+    cfg = load_cfg("particle_stage2_merge.json")
+    rng = np.random.default_rng(7)
+    E, N = 4096, 2
+    dist = np.concatenate([np.linspace(0.3170, 0.31999, E // 2), np.linspace(0.32, 0.45, E // 2)])
+    ang = rng.uniform(0, 2 * np.pi, E)
+    centre = rng.uniform(-0.5, 0.5, (E, 2))
+    half = 0.5 * dist[:, None] * np.stack([np.cos(ang), np.sin(ang)], -1)
+    pos = np.stack([centre + half, centre - half], 1).astype(np.float32).astype(np.float64)
+    d32 = np.sqrt(((pos[:, 0].astype(np.float32) - pos[:, 1].astype(np.float32)) ** 2).sum(-1, dtype=np.float32))
+    keep = d32 >= np.float32(0.3168)                       # float32 rounding of the placed positions
+    env = _env(cfg, N, E, kernel=kernel)
+    env.set_state(pos, np.zeros((E, N, 2)), np.full((E, N, 2), 5.0))
+    gs = env.step(torch.zeros(E, N, dtype=torch.int64))[0].cpu().numpy()
+    assert keep.sum() > E * 0.9
+    assert np.all(gs[keep][..., 0:2] == 0.0)               # velocities: exactly zero
+    assert np.array_equal(gs[keep][..., 2:4], pos[keep].astype(np.float32))
+    pos[:, 0] = centre + half * (0.31 / dist[:, None])
+    pos[:, 1] = centre - half * (0.31 / dist[:, None])
+    env.set_state(pos, np.zeros((E, N, 2)), np.full((E, N, 2), 5.0))
+    gs = env.step(torch.zeros(E, N, dtype=torch.int64))[0].cpu().numpy()
+    assert np.all(np.abs(gs[..., 0:2]).max(axis=(1, 2)) > 1e-8)
+
+
 def _random_states(rng, E, N, crowd=0.5):
     """positions in [-1,1]^2 with a fraction of envs squeezed so that contacts are common"""
     pos = rng.uniform(-1, 1, (E, N, 2))

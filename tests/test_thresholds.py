@@ -4,7 +4,10 @@ kernels are EXACT.  Derivation with rational arithmetic, then an exhaustive swee
 rounded square root covers the rest).
 
 Reference expressions: multi-goal_spread.py:114-118 (is_collision: dist < 0.3), :125-129 (reached: -dist >= -0.05);
-the skip distance is the build's exact early-out of core.py:180-196 (cm3_amd/csrc/particle.hip, contact_force)."""
+the skip distance is the build's exact early-out of core.py:180-196 (cm3_amd/csrc/particle.hip, contact_force): beyond it the
+computed force is exactly +-0 -- 0.32 for the float32 soft-plus on the hardware exp2 / log2 units, 0.41 for the float32 libm
+comparison build, 1.05 for float64; that the force IS zero there is the argument in particle.hip plus the GPU parity tests,
+this file pins the equivalence of the squared test with the distance test."""
 import os
 import re
 from fractions import Fraction
@@ -48,9 +51,11 @@ def constants_of(dtype):
     return consts, tag, coll_c, skip_c, reach_c
 
 
-def test_header_has_all_six_constants():
+def test_header_has_all_constants():
+    """three per precision, plus the float32 skip distance of the -DCM3_F32_LIBM_SOFTPLUS comparison build"""
     consts = header_constants()
-    assert sorted(consts) == sorted((t, k) for t in ("f32", "f64") for k in ("coll", "skip", "reach"))
+    assert sorted(consts) == sorted([(t, k) for t in ("f32", "f64") for k in ("coll", "skip", "reach")] + [("f32", "skip_libm")])
+    assert consts[("f32", "skip")][1] == 0.32 and consts[("f32", "skip_libm")][1] == 0.41 and consts[("f64", "skip")][1] == 1.05
 
 
 def test_constants_equal_the_exact_derivation():
@@ -59,6 +64,8 @@ def test_constants_equal_the_exact_derivation():
         assert dtype(consts[(tag, "coll")][0]) == t_lt(coll_c, dtype)
         assert dtype(consts[(tag, "skip")][0]) == t_lt(skip_c, dtype)
         assert dtype(consts[(tag, "reach")][0]) == t_lt(np.nextafter(reach_c, dtype(1)), dtype)
+        if tag == "f32":
+            assert dtype(consts[(tag, "skip_libm")][0]) == t_lt(dtype(consts[(tag, "skip_libm")][1]), dtype)
         # the header's values are exactly representable in the working precision
         for k in ("coll", "skip", "reach"):
             assert float(dtype(consts[(tag, k)][0])) == consts[(tag, k)][0]
@@ -68,6 +75,9 @@ def _check(x, dtype, consts, tag, coll_c, skip_c, reach_c):
     s = np.sqrt(x)
     bad = np.count_nonzero((s < coll_c) != (x < dtype(consts[(tag, "coll")][0])))
     bad += np.count_nonzero((~(s >= skip_c)) != (~(x >= dtype(consts[(tag, "skip")][0]))))
+    if (tag, "skip_libm") in consts:
+        c2, c = consts[(tag, "skip_libm")]
+        bad += np.count_nonzero((~(s >= dtype(c))) != (~(x >= dtype(c2))))
     bad += np.count_nonzero(((dtype(0) - s) >= dtype(-0.05)) != (x < dtype(consts[(tag, "reach")][0])))
     return int(bad)
 
