@@ -325,10 +325,14 @@ __device__ __forceinline__ void ck_store_env(const CheckersParams &p, size_t e, 
 // single lane that performs the per-env stores of tick t.  Leaves the POST-STEP state in `s` and returns whether the
 // episode ended under CM3_FLAG_AUTO_RESET: the caller then captures the terminal observation (term_*) and calls
 // ck_restart_env.
-template <int N>
+// FAST: the reference geometry (3 x 8 band, n_obs 2) as compile-time constants instead of kernel arguments.
+template <int N, bool FAST = false>
 __device__ __forceinline__ bool ck_tick_env(const CheckersParams &p, int t, size_t e, size_t ec, bool writer, CkState<N> &s,
                                             CkLive<N> &lv) {
+  const int gO = FAST ? 2 : p.O, gR = FAST ? 3 : p.R, gC = FAST ? 8 : p.C;
+  const int g_collectible = FAST ? 24 : p.max_collectible;
   const bool active = writer;
+  const int g_max_steps = p.max_steps;
   int steps = lv.steps;
   uint32_t episode = lv.episode;
   uint8_t goal[N];
@@ -350,11 +354,17 @@ __device__ __forceinline__ bool ck_tick_env(const CheckersParams &p, int t, size
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       act[i] = rand5(words[i]);
-      if (active) actions_t[e * N + i] = act[i];
+      if (active) {
+        if constexpr (FAST) *at32<int32_t>(actions_t, ((uint32_t)e * N + i) * 4u) = act[i];
+        else actions_t[e * N + i] = act[i];
+      }
     }
   } else {
 #pragma unroll
-    for (int i = 0; i < N; ++i) act[i] = actions_t[ec * N + i];
+    for (int i = 0; i < N; ++i) {
+      if constexpr (FAST) act[i] = *at32<const int32_t>(actions_t, ((uint32_t)ec * N + i) * 4u);
+      else act[i] = actions_t[ec * N + i];
+    }
   }
 
   // ---- agents act in index order (step :233-237) ---------------------------------------------------------
@@ -368,7 +378,17 @@ __device__ __forceinline__ bool ck_tick_env(const CheckersParams &p, int t, size
       if (a >= 1 && a <= 4) {
         const int tr = s.r[i] + (a == 1 ? -1 : (a == 2 ? 1 : 0));
         const int tc = s.c[i] + (a == 3 ? -1 : (a == 4 ? 1 : 0));
-        if (ck_ch2<N>(p, s, tr, tc) == 0) {
+        bool free_cell;
+        if constexpr (FAST) {
+          const bool wall = tc < 2 || tr < 2 || tr >= 5 || tc >= 11;
+          bool agent = false;
+#pragma unroll
+          for (int j = 0; j < N; ++j) agent = agent || (s.r[j] == tr && s.c[j] == tc);
+          free_cell = !wall && !agent;
+        } else {
+          free_cell = ck_ch2<N>(p, s, tr, tc) == 0;
+        }
+        if (free_cell) {
           s.r[i] = tr;
           s.c[i] = tc;
           moved = true;
@@ -377,9 +397,9 @@ __device__ __forceinline__ bool ck_tick_env(const CheckersParams &p, int t, size
       if (!moved) penalty = -0.1;
     }
     double rew = 0.0;  // get_reward :190-225
-    const int k = s.r[i] - p.O, j = s.c[i] - p.O;
-    if (k >= 0 && k < p.R && j >= 0 && j < p.C) {
-      const uint64_t bit = 1ull << (k * p.C + j);
+    const int k = s.r[i] - gO, j = s.c[i] - gO;
+    if (k >= 0 && k < gR && j >= 0 && j < gC) {
+      const uint64_t bit = 1ull << (k * gC + j);
       if (!(s.mask & bit)) {
         s.mask |= bit;
         const int colour = (k + j) & 1;
@@ -398,20 +418,27 @@ __device__ __forceinline__ bool ck_tick_env(const CheckersParams &p, int t, size
   }
   steps += 1;
   bool done;  // :246-260
-  if (steps == p.max_steps) {
+  if (steps == g_max_steps) {
     done = true;
   } else if (N == 1) {
     const uint64_t want = goal[0] == 0 ? p.green_mask : p.orange_mask;
     done = (s.mask & want) == want;
   } else {
-    done = (int)__popcll(s.mask) == p.max_collectible;
+    done = (int)__popcll(s.mask) == g_collectible;
   }
   if (active) {
     double *local_t = ck_tick_ptr(p.local_rewards, p.st_local, t);
+    if constexpr (FAST) {
 #pragma unroll
-    for (int i = 0; i < N; ++i) local_t[e * N + i] = local[i];
-    ck_tick_ptr(p.reward, p.st_reward, t)[e] = total;
-    ck_tick_ptr(p.done, p.st_done, t)[e] = done ? 1 : 0;
+      for (int i = 0; i < N; ++i) *at32<double>(local_t, ((uint32_t)e * N + i) * 8u) = local[i];
+      *at32<double>(ck_tick_ptr(p.reward, p.st_reward, t), (uint32_t)e * 8u) = total;
+      *at32<uint8_t>(ck_tick_ptr(p.done, p.st_done, t), (uint32_t)e) = done ? 1 : 0;
+    } else {
+#pragma unroll
+      for (int i = 0; i < N; ++i) local_t[e * N + i] = local[i];
+      ck_tick_ptr(p.reward, p.st_reward, t)[e] = total;
+      ck_tick_ptr(p.done, p.st_done, t)[e] = done ? 1 : 0;
+    }
   }
   lv.steps = steps;
   return (p.flags & CM3_FLAG_AUTO_RESET) && done;
@@ -591,69 +618,98 @@ template <bool NT> __device__ __forceinline__ void ck_st(double4 *p, const doubl
   }
 }
 
+template <bool NT> __device__ __forceinline__ void ck_st(double *p, double v) {
+  if constexpr (NT) __builtin_nontemporal_store(v, p); else *p = v;
+}
+
+// Observation of one env, written by its G lanes.  Everything is sized at compile time (the fast kernel's geometry is fixed), so
+// there are no loops with run-time trip counts and no run-time selects of WHAT a lane does beyond its lane index:
+//   grid        dword g of the 14-dword record (two cells each)
+//   obs_self_t  lane q takes window cells 4q .. 4q+3 = bytes 12q .. 12q+11 = three whole dwords (the first version took dwords
+//               g, g + G, ..: two cell evaluations per dword, 6 per lane at N = 2 against 4 here)
+//   vec         lane i < N writes agent i's int4
+//   obs_self_v / obs_others: the 4N + 2N(N-1) normalised doubles of the env, ONE per lane: every one of them is an IEEE
+//               float64 division (normalize, checkers.py:112-125), ~12 double-rate instructions; lanes 0, 1 used to walk six of
+//               them each while the other lanes of the wave waited.  Value v sits at double v of the env's obs_self_v record
+//               (v < 4N) or double v - 4N of its obs_others record, so a wave's lanes store consecutive doubles.
+// Record bytes past the payload rounded up to 4 (caller-chosen strides larger than that) are not written.
 template <int N, bool NT = false, int G = kCkG>
-__device__ __forceinline__ void ckf_emit(const CheckersParams &p, const CkState<N> &s, int g, size_t e, bool env_ok,
+__device__ __forceinline__ void ckf_emit(const CheckersParams &p, const CkState<N> &s, int g, uint32_t e, bool env_ok,
                                          const CkOut &out) {
   using F = CkFast<N, G>;
   constexpr int NO = N > 1 ? N - 1 : 1;
   if (!env_ok) return;
-  // grid record: dword g
-  const int gd = p.grid_stride >> 2;
   const uint32_t m32 = (uint32_t)s.mask;  // 24 collected bits
-  if constexpr (NT) {
-    for (int d = g; d < gd; d += F::G) ck_st<true>(reinterpret_cast<uint32_t *>(out.grid + e * (size_t)p.grid_stride) + d, ckf_grid_dword<N>(m32, d));
-  } else {
-    for (int d = g; d < gd; d += F::G) reinterpret_cast<uint32_t *>(out.grid + e * (size_t)p.grid_stride)[d] = ckf_grid_dword<N>(m32, d);
+  // ---- grid ---------------------------------------------------------------------------------------------------------------
+  constexpr int GD = (F::GRID_REC + 3) / 4;
+  const uint32_t grow = e * (uint32_t)p.grid_stride;
+#pragma unroll
+  for (int d0 = 0; d0 < GD; d0 += G) {
+    const int d = d0 + g;
+    if (d < GD) ck_st<NT>(at32<uint32_t>(out.grid, grow + 4u * d), ckf_grid_dword<N>(m32, d));
   }
-  // obs_self_t record: dwords g, g+16, ...
-  const int od = p.obst_stride >> 2;
-  uint32_t *o32 = reinterpret_cast<uint32_t *>(out.obs_self_t + e * (size_t)p.obst_stride);
-  if constexpr (NT) {
-    for (int d = g; d < od; d += F::G) ck_st<true>(o32 + d, ckf_obst_dword<N>(s, m32, d));
-  } else {
-    for (int d = g; d < od; d += F::G) o32[d] = ckf_obst_dword<N>(s, m32, d);
+  // ---- obs_self_t ---------------------------------------------------------------------------------------------------------
+  constexpr int OD = (F::OBST_REC + 3) / 4, NQ = (OD + 2) / 3;
+  const uint32_t orow = e * (uint32_t)p.obst_stride;
+#pragma unroll
+  for (int q0 = 0; q0 < NQ; q0 += G) {
+    const int q = q0 + g;
+    if (q < NQ) {
+      const uint32_t c0 = ckf_cell3<N>(s, m32, 4 * q), c1 = ckf_cell3<N>(s, m32, 4 * q + 1);
+      const uint32_t c2 = ckf_cell3<N>(s, m32, 4 * q + 2), c3 = ckf_cell3<N>(s, m32, 4 * q + 3);
+      uint32_t *dst = at32<uint32_t>(out.obs_self_t, orow + 12u * q);
+      ck_st<NT>(dst, c0 | (c1 << 24));
+      if (3 * q + 1 < OD) ck_st<NT>(dst + 1, (c1 >> 8) | (c2 << 16));
+      if (3 * q + 2 < OD) ck_st<NT>(dst + 2, (c2 >> 16) | (c3 << 8));
+    }
   }
-  // small vector outputs: lane i (< N) writes agent i's rows
+  // ---- vec ----------------------------------------------------------------------------------------------------------------
   if (g < N) {
-    int ri = s.r[0], ci = s.c[0], gi = s.ng[0], oi = s.no[0];
+    int4 v;
+    v.x = s.r[0]; v.y = s.c[0]; v.z = s.ng[0]; v.w = s.no[0];
 #pragma unroll
     for (int a = 1; a < N; ++a) {
-      ri = (g == a) ? s.r[a] : ri;
-      ci = (g == a) ? s.c[a] : ci;
-      gi = (g == a) ? s.ng[a] : gi;
-      oi = (g == a) ? s.no[a] : oi;
+      v.x = (g == a) ? s.r[a] : v.x;
+      v.y = (g == a) ? s.c[a] : v.y;
+      v.z = (g == a) ? s.ng[a] : v.z;
+      v.w = (g == a) ? s.no[a] : v.w;
     }
-    int4 v;
-    v.x = ri;
-    v.y = ci;
-    v.z = gi;
-    v.w = oi;
-    if constexpr (NT) ck_st<true>(reinterpret_cast<int4 *>(out.vec) + (e * N + g), v);
-    else reinterpret_cast<int4 *>(out.vec)[e * N + g] = v;
-    const double half = (double)(F::R * F::C) / 2.0;
-    double4 sv;
-    sv.x = ((double)ri - (double)F::TR / 2.0) / (double)F::TR;
-    sv.y = ((double)ci - (double)F::TC / 2.0) / (double)F::TC;
-    sv.z = (double)gi / half;
-    sv.w = (double)oi / half;
-    if constexpr (NT) ck_st<true>(reinterpret_cast<double4 *>(out.obs_self_v) + (e * N + g), sv);
-    else reinterpret_cast<double4 *>(out.obs_self_v)[e * N + g] = sv;
-    double2 *oo = reinterpret_cast<double2 *>(out.obs_others) + (e * N + g) * NO;
+    ck_st<NT>(at32<int4>(out.vec, (e * N + g) * 16u), v);
+  }
+  // ---- obs_self_v, obs_others ---------------------------------------------------------------------------------------------
+  constexpr int NSV = 4 * N, NOO = 2 * N * NO, NV = NSV + NOO;
+  const double half = (double)(F::R * F::C) / 2.0;
 #pragma unroll
-    for (int k = 0; k < NO; ++k) {
-      // k-th other agent of agent g (N == 1: itself)
-      int rj = s.r[0], cj = s.c[0];
-      const int j = (N > 1) ? (k < g ? k : k + 1) : 0;
-#pragma unroll
-      for (int a = 1; a < N; ++a) {
-        rj = (j == a) ? s.r[a] : rj;
-        cj = (j == a) ? s.c[a] : cj;
+  for (int v0 = 0; v0 < NV; v0 += G) {
+    const int v = v0 + g;
+    if (v < NV) {
+      const bool others = v >= NSV;
+      const int w = others ? v - NSV : v;
+      // agent whose coordinate / count is normalised, and which of its four numbers
+      int a, comp;
+      if (others) {
+        const int i = w / (2 * NO), k = (w - i * 2 * NO) >> 1;
+        a = (N > 1) ? (k < i ? k : k + 1) : 0;  // k-th other agent of agent i (N == 1: itself)
+        comp = w & 1;
+      } else {
+        a = w >> 2;
+        comp = w & 3;
       }
-      double2 t;
-      t.x = ((double)rj - (double)F::TR / 2.0) / (double)F::TR;
-      t.y = ((double)cj - (double)F::TC / 2.0) / (double)F::TC;
-      if constexpr (NT) ck_st<true>(oo + k, t);
-      else oo[k] = t;
+      int ra = s.r[0], ca = s.c[0], ga = s.ng[0], oa = s.no[0];
+#pragma unroll
+      for (int x = 1; x < N; ++x) {
+        ra = (a == x) ? s.r[x] : ra;
+        ca = (a == x) ? s.c[x] : ca;
+        ga = (a == x) ? s.ng[x] : ga;
+        oa = (a == x) ? s.no[x] : oa;
+      }
+      const int num_i = comp == 0 ? ra : (comp == 1 ? ca : (comp == 2 ? ga : oa));
+      const double off = comp == 0 ? (double)F::TR / 2.0 : (comp == 1 ? (double)F::TC / 2.0 : 0.0);
+      const double den = comp == 0 ? (double)F::TR : (comp == 1 ? (double)F::TC : half);
+      // counts: (double)n / half; coordinates: ((double)r - TR / 2.0) / TR -- x - 0.0 == x exactly, so one expression serves
+      const double val = ((double)num_i - off) / den;
+      if (others) ck_st<NT>(at32<double>(out.obs_others, (e * (uint32_t)NOO + (uint32_t)w) * 8u), val);
+      else ck_st<NT>(at32<double>(out.obs_self_v, (e * (uint32_t)NSV + (uint32_t)w) * 8u), val);
     }
   }
 }
@@ -670,18 +726,24 @@ __global__ void __launch_bounds__(256)
   hd.mask = h_mask; hd.agents = h_agents; hd.steps = h_steps; hd.episode = h_episode; hd.goals = h_goals; hd.E = h_E; hd.flags = h_flags;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane & (F::G - 1), sub = lane / F::G;
-  const size_t e = ((size_t)blockIdx.x * 4 + wave) * F::EPW + sub;
-  const bool env_ok = e < (size_t)h_E;
-  const size_t ec = env_ok ? e : (size_t)h_E - 1;
+  // 32-bit env index and byte offsets (every per-tick array below 4 GiB, checked by ck_launch): addresses are
+  // <uniform base> + <lane offset>, as in the particle kernels
+  const uint32_t e = ((uint32_t)blockIdx.x * 4 + wave) * F::EPW + sub;
+  const bool env_ok = e < (uint32_t)h_E;
+  const uint32_t ec = env_ok ? e : (uint32_t)h_E - 1;
   const bool writer = env_ok && g == 0;
   CkState<N> s;
   CkLive<N> lv;
   ck_load_env<N>(hd, ec, s, lv);
+  // the kernel arguments the tick needs, requested while the state loads are in flight (fetched at their first use they made
+  // the wave wait for a scalar load six times along its critical path)
+  CM3_FETCH_EARLY(p.actions, p.local_rewards, p.reward, p.done, p.grid, p.vec, p.obs_others, p.obs_self_t, p.obs_self_v,
+                  p.goals_next, p.term_grid, p.max_steps, p.grid_stride, p.obst_stride, p.seed, p.env_id_base);
   // FUSED == false: exactly one tick; the loop and the per-tick offsets fold away
   const int n_ticks = FUSED ? p.n_ticks : 1;
 #pragma unroll 1
   for (int t = 0; t < n_ticks; ++t) {
-    const bool ended = ck_tick_env<N>(p, t, e, ec, writer, s, lv);
+    const bool ended = ck_tick_env<N, true>(p, t, e, ec, writer, s, lv);
     if (ended) {  // AUTO_RESET: terminal observation (train_onpolicy.py:336-347), then the fresh episode
       if (p.term_grid) ckf_emit<N, NT, G>(p, s, g, e, env_ok, ck_out_term(p, t));
       ck_restart_env<N>(p, e, ec, writer, s, lv);
@@ -690,7 +752,7 @@ __global__ void __launch_bounds__(256)
     if (p.goals_next && writer) {
       uint8_t *gn = ck_tick_ptr(p.goals_next, p.st_goals_next, t);
 #pragma unroll
-      for (int i = 0; i < N; ++i) gn[e * N + i] = lv.goal[i];
+      for (int i = 0; i < N; ++i) *at32<uint8_t>(gn, e * N + i) = lv.goal[i];
     }
   }
   if (writer) ck_store_env<N>(p, e, s, lv);
@@ -854,6 +916,11 @@ template <int N> static int ck_launch(const CheckersParams &p, bool step, hipStr
     const bool nt = (p.flags & kCkObsStoreNt) != 0;   // streaming-size trajectory (ck_rollout): non-temporal stores, G = 16
     const unsigned epb = 4u * (nt ? CkFast<N, kCkGStream>::EPW : CkFast<N>::EPW);  // 4 waves x EPW envs per workgroup
     const unsigned fblocks = (unsigned)(((size_t)p.E + epb - 1) / epb);
+    if (step) {  // the step kernel indexes with 32-bit byte offsets
+      const size_t widest = (size_t)p.obst_stride > (size_t)N * 32 ? (size_t)p.obst_stride : (size_t)N * 32;
+      if ((size_t)p.E * widest >= ((size_t)1 << 32))
+        return fail(CM3_ERR_INVALID, "the Checkers step kernel addresses at most 4 GiB per array: %d envs x %d agents is too large", p.E, N);
+    }
 #define CM3_LAUNCH_CKF(...)                                                                                                  \
   hipLaunchKernelGGL((k_checkers_step_fast<N, __VA_ARGS__>), dim3(fblocks), dim3(256), 0, stream, (const uint64_t *)p.mask,    \
                      (const uint32_t *)p.agents, (const int32_t *)p.steps, (const int32_t *)p.episode, (const uint8_t *)p.goals, \

@@ -27,6 +27,17 @@ extern __device__ long long *cm3_stamp_buf;
 
 namespace cm3 {
 
+// Asks for kernel-argument fields NOW: fields first used late in a kernel are otherwise fetched right before that use, and the
+// wave then waits for the scalar load in the middle of its critical path (measured in the pair kernel: three such fetches).
+#define CM3_FETCH_EARLY(...) cm3_fetch_early(__VA_ARGS__)
+template <typename T> __device__ __forceinline__ void cm3_fetch_one(const T &v) { asm volatile("" ::"s"(v)); }
+template <typename... T> __device__ __forceinline__ void cm3_fetch_early(const T &...v) { (cm3_fetch_one(v), ...); }
+
+// element at <uniform base> + <32-bit byte offset>: selects the scalar-base addressing mode of global loads / stores
+template <typename T> __device__ __forceinline__ T *at32(const void *base, uint32_t byte_offset) {
+  return reinterpret_cast<T *>(const_cast<char *>(reinterpret_cast<const char *>(base)) + byte_offset);
+}
+
 // ---- error plumbing ------------------------------------------------------------------------
 char *last_error_buf();  // thread-local, 512 bytes
 int fail(int code, const char *fmt, ...);
