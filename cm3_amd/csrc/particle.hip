@@ -405,10 +405,11 @@ static_assert(offsetof(ParticleParams, ay) == offsetof(ParticleParams, ax) + CM3
                   offsetof(ParticleParams, lx) == offsetof(ParticleParams, ax) + 2 * CM3_MAX_AGENTS * sizeof(double) &&
                   offsetof(ParticleParams, ly) == offsetof(ParticleParams, ax) + 3 * CM3_MAX_AGENTS * sizeof(double),
               "init_agent reads ax | ay | lx | ly as one table");
-__device__ __forceinline__ const double *preset_table() {
+// kernel_arg_offset: where the kernel's ParticleParams argument starts in its kernel-argument segment
+__device__ __forceinline__ const double *preset_table(size_t kernel_arg_offset = offsetof(SharedEnvKernArgs, p)) {
 #if defined(__HIP_DEVICE_COMPILE__)
   const char *args = (const char *)__builtin_amdgcn_kernarg_segment_ptr();  // constant address space -> generic
-  return reinterpret_cast<const double *>(args + offsetof(SharedEnvKernArgs, p) + offsetof(ParticleParams, ax));
+  return reinterpret_cast<const double *>(args + kernel_arg_offset + offsetof(ParticleParams, ax));
 #else
   return nullptr;  // host pass of the single-source compile: never called
 #endif
@@ -1293,10 +1294,17 @@ template <typename R, int N> static int launch_n(const ParticleParams &p, Partic
     //           -> pair below 6144, agent from 6144 up (no upper bound)
     // Crossovers that fall between two measured sizes (12288, 49152) are interpolated, not measured.
     constexpr size_t kInf = ~(size_t)0;
-    constexpr size_t kPairMax = N == 3 ? 32768 : kPairsMaxEnvs;
-    constexpr size_t kAgentLo = N == 4 ? 16385 : (N == 5 || N == 6 ? 12288 : (N >= 7 ? 6144 : kInf));
-    constexpr size_t kAgentHi = N == 4 || N == 5 ? 49152 : (N == 6 ? 65536 : (N == 7 ? ((size_t)1 << 17) : (N == 8 ? kInf : 0)));
-    bool pairs = N >= 3 && (size_t)p.E <= kPairMax;
+    // Re-measured after the executed paths of the pair / agent kernels were shortened (hardware soft-plus, 32-bit addressing, no
+    // spills; tools/mapping_sweep.py, profiles/r02_mapping_sweep_after_path_shortening.txt): the table moved a little --
+    //   N = 2: pair wins by 10 % up to 6144 envs (2.31 / - / 2.56 at 2048), level with env above  -> pair to 6144
+    //   N = 3: pair to 24576 (32768: 4.41 / 4.43 / 4.20)
+    //   N = 4: pair to 12288 (3.80 / 3.88 / 4.70), agent to 40960 (16384: 4.41 / 4.06 / 4.85; 49152: 9.0 / 6.40 / 6.30), then env
+    //   N = 5, 6: agent from 8192 (N = 5: 4.31 / 4.23 / 6.41); N = 5 up to 40960, N = 6 up to 65536, then env
+    //   N = 7, 8: agent from 6144 up, no upper bound (N = 7 at 2^20: - / 218 / 231)
+    constexpr size_t kPairMax = N == 2 ? 6144 : (N == 3 ? 24576 : (N == 4 ? 12288 : kPairsMaxEnvs));
+    constexpr size_t kAgentLo = N == 4 ? 12289 : (N == 5 || N == 6 ? 8192 : (N >= 7 ? 6144 : kInf));
+    constexpr size_t kAgentHi = N == 4 || N == 5 ? 40960 : (N == 6 ? 65536 : (N >= 7 ? kInf : 0));
+    bool pairs = N >= 2 && (size_t)p.E <= kPairMax;
     bool agents = N >= 4 && (size_t)p.E >= kAgentLo && (size_t)p.E <= kAgentHi;
     // both shared-env mappings index with 32-bit byte offsets (obs_others below 4 GiB per tick); beyond that only a forced choice
     // reaches them (and is refused by their launchers)

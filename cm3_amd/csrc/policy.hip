@@ -191,7 +191,8 @@ template <int N, bool BF16> __global__ void __launch_bounds__(256) k_policy_roll
       wave_lds_sync();  // every lane of the env has read the terminal states before they are overwritten
       episode += 1;
       const bool rnd = episode_is_random(p, genv, episode);
-      init_agent<float, N>(p, genv, episode, rnd, i, si, gl);
+      static_assert(offsetof(PolicyParams, p) == 0, "preset_table(0): the ParticleParams lead the kernel's only argument");
+      init_agent<float, N, true>(p, genv, episode, rnd, i, si, gl, preset_table(0));
       steps = 0;
       collisions = 0;
       was_reset = true;
