@@ -878,15 +878,36 @@ __global__ void __launch_bounds__(WAVES * 64)
   const int nvec = (int)envs_here * VPE;
 
   // obs rows of this lane (vector k of agent i = s_j - s_i, j the k-th other agent) -> LDS tile -> contiguous rows at dst
-  auto store_obs = [&](const V4 (&oj)[N], void *dst) {
+  // Straight-line code (no branch per vector, no loop with a run-time trip count): the k-th other agent of agent i is k or k + 1,
+  // picked with selects; the tile goes out in ceil(EPW * VPE / 64) unrolled steps, all LDS reads issued before the first wait.
+  // (The first version -- `if (j != i) tile[..] = ..` and `for (f = lane; f < nvec; f += 64)` -- compiled to a branch per
+  // vector and seven read / wait / store / taken-branch rounds at N = 8.)
+  auto fill_tile = [&](const V4 (&oj)[N]) {
     if (agent_ok) {
 #pragma unroll
-      for (int j = 0; j < N; ++j) {
-        if (j != i) lds4[sub * VPE + i * NO + (j < i ? j : j - 1)] = sub4<R, V4>(oj[j], si);
+      for (int k = 0; k < NO; ++k) {
+        const bool below = k < i;  // other agent k (below i) or k + 1
+        V4 o;
+        o.x = below ? oj[k].x : oj[k + 1].x;
+        o.y = below ? oj[k].y : oj[k + 1].y;
+        o.z = below ? oj[k].z : oj[k + 1].z;
+        o.w = below ? oj[k].w : oj[k + 1].w;
+        lds4[sub * VPE + i * NO + k] = sub4<R, V4>(o, si);
       }
     }
     wave_lds_sync();
-    for (int f = lane; f < nvec; f += 64) store_obs_vec<NT>(at32<V4>(dst, (e0 * VPE + f) * (uint32_t)sizeof(V4)), lds4[f]);
+  };
+  auto store_obs = [&](const V4 (&oj)[N], void *dst) {
+    fill_tile(oj);
+    constexpr int STEPS = (EPW * VPE + 63) / 64;
+    V4 row[STEPS];
+#pragma unroll
+    for (int q = 0; q < STEPS; ++q) row[q] = lds4[(q * 64 + lane) < EPW * VPE ? q * 64 + lane : 0];
+#pragma unroll
+    for (int q = 0; q < STEPS; ++q) {
+      const int f = q * 64 + lane;
+      if (f < nvec) store_obs_vec<NT>(at32<V4>(dst, (e0 * VPE + f) * (uint32_t)sizeof(V4)), row[q]);
+    }
     wave_lds_sync();
   };
 
@@ -923,7 +944,7 @@ __global__ void __launch_bounds__(WAVES * 64)
       dxs[j] = si.z - __shfl(si.z, base + j, 64);
       dys[j] = si.w - __shfl(si.w, base + j, 64);
       d2s[j] = dxs[j] * dxs[j] + dys[j] * dys[j];
-      if (j != i && !(d2s[j] >= Thresh<R>::kSkip2)) near_mask |= 1u << j;
+      near_mask |= (unsigned)((j != i) & !(d2s[j] >= Thresh<R>::kSkip2)) << j;  // no branch
     }
     while (__any(near_mask != 0u)) {
       const int jn = near_mask ? (__ffs((int)near_mask) - 1) : 0;
@@ -974,7 +995,7 @@ __global__ void __launch_bounds__(WAVES * 64)
     int c_i = 0;
 #pragma unroll
     for (int j = 0; j < N; ++j)  // is_collision(a = j, agent = i)
-      c_i += (j != i && is_collision<R>(oj[j].z - si.z, oj[j].w - si.w)) ? 1 : 0;
+      c_i += (int)((j != i) & is_collision<R>(oj[j].z - si.z, oj[j].w - si.w));  // no branch
     c_i = agent_ok ? c_i : 0;
 #pragma unroll
     for (int c = 0; c < NO; ++c)
@@ -1009,12 +1030,7 @@ __global__ void __launch_bounds__(WAVES * 64)
         if (term_state && done && mine) *at32<V4>(term_state, (row_i + e) * (uint32_t)sizeof(V4)) = si;
         if (term_obs) {
           // terminal observations of the finished envs; rows of unfinished envs in the tile are not written out
-          if (agent_ok) {
-#pragma unroll
-            for (int j = 0; j < N; ++j)
-              if (j != i) lds4[sub * VPE + i * NO + (j < i ? j : j - 1)] = sub4<R, V4>(oj[j], si);
-          }
-          wave_lds_sync();
+          fill_tile(oj);
           const unsigned long long done_bits = __ballot(done);
           for (int f = lane; f < nvec; f += 64) {
             const int row = f / VPE;
