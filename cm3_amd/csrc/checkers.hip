@@ -497,7 +497,13 @@ __device__ __forceinline__ void ck_step_env(const CheckersParams &p, size_t e, s
 // r02_checkers_lanes_per_env_sweep.txt, three alternating rounds): in place 4: 6.42, 8: 5.05, 16: 5.48 -- but for a streaming-size
 // trajectory (every tick its own slot, non-temporal stores) 4: 7.95, 8: 6.22, 16: 5.87.  So G = 8 everywhere except on the
 // non-temporal path, which uses G = 16 (the round-1 tuning was specific to in-place stepping).
-constexpr int kCkG = 8, kCkGStream = 16;
+#ifndef CM3_CK_G
+#define CM3_CK_G 8
+#endif
+#ifndef CM3_CK_G_STREAM
+#define CM3_CK_G_STREAM 16
+#endif
+constexpr int kCkG = CM3_CK_G, kCkGStream = CM3_CK_G_STREAM;  // (macros: build variants for tools/ab_builds.sh style comparisons)
 template <int N, int G_ = kCkG> struct CkFast {
   static constexpr int R = 3, C = 8, O = 2, K = 5, TR = 7, TC = 13;
   static constexpr int GRID_REC = R * (C + 1) * 2;  // 54

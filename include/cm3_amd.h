@@ -70,6 +70,9 @@ extern "C" {
 #define CM3_FLAG_KERNEL_LANE_PER_PAIR 0x200u /* particle step: force the one-lane-per-agent-pair mapping
                                                 (default: chosen from n_envs; both give identical results) */
 #define CM3_FLAG_KERNEL_LANE_PER_AGENT 0x800u /* particle step: force the one-lane-per-agent mapping (n_agents >= 2) */
+/* The two shared-env mappings index with 32-bit byte offsets: every per-tick array (the largest is obs_others,
+   n_envs * N * (N-1) * 4 reals) must stay below 4 GiB.  The default choice respects that; a FORCED mapping beyond it returns
+   CM3_ERR_INVALID.  (N = 8, float32: 4.79 M envs.) */
 
 int cm3_abi_version(void);
 const char *cm3_last_error(void);
@@ -205,7 +208,10 @@ typedef struct cm3_checkers_desc {
   int32_t grid_stride;       /* bytes between consecutive envs' grid records; 0 = packed (n_rows*(n_columns+1)*2) */
   int32_t obs_self_t_stride; /* bytes between consecutive envs' obs_self_t records; 0 = packed (N*K*K*3).
                                 Records padded to a multiple of 4 bytes (56 / 152 for the reference geometry with
-                                N = 2) enable the multi-lane fast kernel; padding bytes are written as 0 */
+                                N = 2) enable the multi-lane fast kernel, which writes each record up to its payload
+                                rounded up to 4 bytes (the rounding bytes as 0; bytes of a LARGER stride beyond that are
+                                left untouched) and indexes with 32-bit byte offsets: n_envs * obs_self_t_stride (and
+                                n_envs * N * 32) must stay below 4 GiB, else CM3_ERR_INVALID */
   int32_t _pad;
   int64_t env_id_base;
   uint64_t seed;
