@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # CM3_AMD_LIB: load another build of the SAME ABI instead (tools/*_ab.py compare two builds on one box)
 LIB_PATH = os.environ.get("CM3_AMD_LIB") or os.path.join(_HERE, "libcm3_hip.so")
 MAX_AGENTS = 8
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 FLAG_AUTO_RESET = 1
 FLAG_GEN_ACTIONS = 2
@@ -58,7 +58,8 @@ class ParticleTraj(ctypes.Structure):
                 ("meta", c_void_p), ("episode", c_void_p),
                 ("term_state", c_void_p), ("term_state_stride", c_size_t),
                 ("term_obs_others", c_void_p), ("term_obs_others_stride", c_size_t),
-                ("collisions", c_void_p), ("collisions_stride", c_size_t)]
+                ("collisions", c_void_p), ("collisions_stride", c_size_t),
+                ("state_live", c_void_p), ("goals_live", c_void_p)]
 
 
 class CheckersDesc(ctypes.Structure):

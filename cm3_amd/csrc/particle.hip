@@ -46,6 +46,7 @@ struct ParticleParams {
   void *term_state;
   void *term_obs_others;
   int32_t *collisions_tick;  // optional int32 [E] per tick: scenario.collisions after this tick (before any same-launch reset)
+  void *state_copy, *goals_copy;  // optional: the post-step state / goals ALSO go here (cm3_particle_traj.state_live: the slot copy)
   const uint8_t *reset_mask;
   // tick loop inside one launch (CM3_FLAG_FUSED_TICKS): tick t uses <pointer> + t * <stride in bytes> for the
   // per-tick arrays (state_out / goals_out / obs_others / term_* point at slot 1 of their trajectories);
@@ -580,6 +581,12 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step(const ParticlePara
 #pragma unroll
         for (int i = 0; i < N; ++i) gout2[(size_t)i * E + e] = g[i];
       }
+      if (p.state_copy) {  // live-state rollout: the trajectory slot gets a copy (write-only stream)
+#pragma unroll
+        for (int i = 0; i < N; ++i) store_obs_vec<NT>(reinterpret_cast<V4 *>(p.state_copy) + ((size_t)i * E + e), s[i]);
+#pragma unroll
+        for (int i = 0; i < N; ++i) reinterpret_cast<V2 *>(p.goals_copy)[(size_t)i * E + e] = g[i];
+      }
     }
 
     CM3_STAMP(4, false);
@@ -630,7 +637,7 @@ template <int N> struct PairGeom {
 // (profiles/r02_draw_wave_on_off.txt) it had become a loss in every configuration that used it -- in place 0-6 %, trajectory mode
 // 5-10 % -- and was removed: a fifth wave, two workgroup barriers and an extra store + reload of the action row cost more than the
 // Philox chain they hid once the square roots had left the physics chain.)
-template <typename R, int N, int WAVES, bool FUSED, bool NT = false>
+template <typename R, int N, int WAVES, bool FUSED, bool NT = false, bool LIVE = false>
 __global__ void __launch_bounds__(WAVES * 64)
     k_particle_step_pairs(const void *h_state_in, const void *h_goals_in, const int32_t *h_meta_in, const int32_t *h_episode,
                           const int h_E, const uint32_t h_flags, const int h_E0, const int h_EN, const int h_max_steps,
@@ -677,6 +684,7 @@ __global__ void __launch_bounds__(WAVES * 64)
   const uint32_t episode_in = episode;
   // (after the vector loads are in flight: the scalar fetches complete in their shadow)
   CM3_FETCH_EARLY(p.state_out, p.goals_out, p.goals_in, p.collisions_tick, p.reward_n, p.reward, p.done, p.obs_others, p.meta_out);
+  if constexpr (LIVE) CM3_FETCH_EARLY(p.state_copy, p.goals_copy);
   const uint64_t genv = (uint64_t)(p.env_id_base + (int64_t)ec);
   const R kDt = R(0.1), kKeep = R(1 - 0.25);
 
@@ -790,6 +798,10 @@ __global__ void __launch_bounds__(WAVES * 64)
         *at32<V4>(tick_ptr(p.state_out, p.st_state, t), (row_i + e) * (uint32_t)sizeof(V4)) = si;
         if (p.goals_out != p.goals_in || was_reset)
           *at32<V2>(tick_ptr(p.goals_out, p.st_goals, t), (row_i + e) * (uint32_t)sizeof(V2)) = gl;
+        if constexpr (LIVE) {  // live-state rollout (a compile-time variant: the others carry none of it): the slot gets a copy
+          store_obs_vec<NT>(at32<V4>(p.state_copy, (row_i + e) * (uint32_t)sizeof(V4)), si);
+          *at32<V2>(p.goals_copy, (row_i + e) * (uint32_t)sizeof(V2)) = gl;
+        }
       }
       // observation (multi-goal_spread.py:145-154): vector (i,k) of env e; lanes of a wave cover whole records
       if (slot_ok)
@@ -826,7 +838,7 @@ template <int N> struct AgentGeom {
   static constexpr int VPE = N * NO;        // obs vectors per env record
 };
 
-template <typename R, int N, int WAVES, bool FUSED, bool NT = false>
+template <typename R, int N, int WAVES, bool FUSED, bool NT = false, bool LIVE = false>
 __global__ void __launch_bounds__(WAVES * 64)
     k_particle_step_agents(const void *h_state_in, const void *h_goals_in, const int32_t *h_meta_in, const int32_t *h_episode,
                            const int h_E, const uint32_t h_flags, const int h_E0, const int h_EN, const int h_max_steps,
@@ -869,6 +881,7 @@ __global__ void __launch_bounds__(WAVES * 64)
   const uint32_t episode_in = episode;
   // (after the vector loads are in flight: the scalar fetches complete in their shadow)
   CM3_FETCH_EARLY(p.state_out, p.goals_out, p.goals_in, p.collisions_tick, p.reward_n, p.reward, p.done, p.obs_others, p.meta_out);
+  if constexpr (LIVE) CM3_FETCH_EARLY(p.state_copy, p.goals_copy);
   const uint64_t genv = (uint64_t)(p.env_id_base + (int64_t)ec);
   const R kDt = R(0.1), kKeep = R(1 - 0.25);
 
@@ -1062,6 +1075,10 @@ __global__ void __launch_bounds__(WAVES * 64)
       *at32<V4>(tick_ptr(p.state_out, p.st_state, t), (row_i + e) * (uint32_t)sizeof(V4)) = si;
       if (p.goals_out != p.goals_in || was_reset)
         *at32<V2>(tick_ptr(p.goals_out, p.st_goals, t), (row_i + e) * (uint32_t)sizeof(V2)) = gl;
+      if constexpr (LIVE) {  // live-state rollout (a compile-time variant: the others carry none of it): the slot gets a copy
+        store_obs_vec<NT>(at32<V4>(p.state_copy, (row_i + e) * (uint32_t)sizeof(V4)), si);
+        *at32<V2>(p.goals_copy, (row_i + e) * (uint32_t)sizeof(V2)) = gl;
+      }
     }
     store_obs(oj, tick_ptr(p.obs_others, p.st_obs, t));  // observation (multi-goal_spread.py:145-154)
   }
@@ -1202,6 +1219,7 @@ static int fill_params(const cm3_particle_desc *d, const cm3_particle_bufs *b, P
   p.term_state = b->term_state;
   p.term_obs_others = b->term_obs_others;
   p.collisions_tick = b->collisions_tick;
+  p.state_copy = p.goals_copy = nullptr;
   p.reset_mask = mask;
   return CM3_OK;
 }
@@ -1239,17 +1257,21 @@ template <typename R, int N, int WAVES> static int launch_pairs(const ParticlePa
     const unsigned blocks = (unsigned)(((size_t)(p.EN - p.E0) + envs_per_block - 1) / envs_per_block);
     constexpr bool kF32 = sizeof(R) == 4;
     const bool nt = kF32 && (p.flags & kFlagObsStoreNt);   // streaming-size trajectory (obs_store_nt)
-#define CM3_LAUNCH_PAIRS(FUSED_, NT_)                                                                                       \
-  hipLaunchKernelGGL((k_particle_step_pairs<R, N, WAVES, FUSED_, NT_>), dim3(blocks), dim3(WAVES * 64), 0, stream,          \
+#define CM3_LAUNCH_PAIRS(...)                                                                                               \
+  hipLaunchKernelGGL((k_particle_step_pairs<R, N, WAVES, __VA_ARGS__>), dim3(blocks), dim3(WAVES * 64), 0, stream,          \
                      p.state_in, p.goals_in, p.meta_in, (const int32_t *)p.episode, p.E, p.flags, p.E0, p.EN, p.max_steps,        \
                      (const int32_t *)p.actions, p)
     // the kernel indexes with 32-bit byte offsets: its largest per-tick array (obs_others) must stay below 4 GiB
     if ((size_t)p.E * PairGeom<N>::SLOTS * 4 * sizeof(R) >= ((size_t)1 << 32))
       return fail(CM3_ERR_INVALID, "the lane-per-pair kernel addresses at most 4 GiB per array: %d envs x %d agents is too large "
                   "(use the default kernel choice)", p.E, N);
+    const bool live = p.state_copy != nullptr;   // cm3_particle_traj.state_live (per-tick launches only)
     if (p.n_ticks > 1) {
       if (nt) CM3_LAUNCH_PAIRS(true, kF32);
       else CM3_LAUNCH_PAIRS(true, false);
+    } else if (live) {
+      if (nt) CM3_LAUNCH_PAIRS(false, kF32, true);
+      else CM3_LAUNCH_PAIRS(false, false, true);
     } else {
       if (nt) CM3_LAUNCH_PAIRS(false, kF32);
       else CM3_LAUNCH_PAIRS(false, false);
@@ -1270,16 +1292,20 @@ template <typename R, int N, int WAVES> static int launch_agents(const ParticleP
     const size_t envs_per_block = (size_t)WAVES * AgentGeom<N>::EPW;
     const unsigned blocks = (unsigned)(((size_t)(p.EN - p.E0) + envs_per_block - 1) / envs_per_block);
     const bool nt = sizeof(R) == 4 && (p.flags & kFlagObsStoreNt);   // streaming-size trajectory (obs_store_nt)
-#define CM3_LAUNCH_AGENTS(FUSED_, NT_)                                                                                      \
-  hipLaunchKernelGGL((k_particle_step_agents<R, N, WAVES, FUSED_, NT_>), dim3(blocks), dim3(WAVES * 64), 0, stream,         \
+#define CM3_LAUNCH_AGENTS(...)                                                                                              \
+  hipLaunchKernelGGL((k_particle_step_agents<R, N, WAVES, __VA_ARGS__>), dim3(blocks), dim3(WAVES * 64), 0, stream,         \
                      p.state_in, p.goals_in, p.meta_in, (const int32_t *)p.episode, p.E, p.flags, p.E0, p.EN, p.max_steps,        \
                      (const int32_t *)p.actions, p)
     // 32-bit byte offsets inside the kernel: the largest per-tick array (obs_others) must stay below 4 GiB
     if ((size_t)p.E * AgentGeom<N>::VPE * 4 * sizeof(R) >= ((size_t)1 << 32))
       return fail(CM3_ERR_INVALID, "the lane-per-agent kernel addresses at most 4 GiB per array: %d envs x %d agents is too large", p.E, N);
+    const bool live = p.state_copy != nullptr;   // cm3_particle_traj.state_live (per-tick launches only)
     if (p.n_ticks > 1) {
       if (nt) CM3_LAUNCH_AGENTS(true, sizeof(R) == 4);
       else CM3_LAUNCH_AGENTS(true, false);
+    } else if (live) {
+      if (nt) CM3_LAUNCH_AGENTS(false, sizeof(R) == 4, true);
+      else CM3_LAUNCH_AGENTS(false, false, true);
     } else {
       if (nt) CM3_LAUNCH_AGENTS(false, sizeof(R) == 4);
       else CM3_LAUNCH_AGENTS(false, false);
@@ -1384,6 +1410,9 @@ static int particle_rollout(const cm3_particle_desc *d, const cm3_particle_traj 
   CM3_REQUIRE(n_ticks >= 1, "n_ticks must be >= 1");
   CM3_REQUIRE(t->state && t->goals && t->obs_others && t->actions && t->reward_n && t->reward && t->done && t->meta,
               "rollout: trajectory base pointers are required");
+  CM3_REQUIRE((t->state_live == nullptr) == (t->goals_live == nullptr), "rollout: state_live and goals_live go together");
+  CM3_REQUIRE(!t->state_live || (t->state_stride != 0 && t->goals_stride != 0),
+              "rollout: live buffers are for slot trajectories (state_stride / goals_stride must be non-zero)");
   auto at = [](void *base, size_t stride, int k) -> void * {
     return base ? (void *)((char *)base + stride * (size_t)k) : nullptr;
   };
@@ -1429,10 +1458,11 @@ static int particle_rollout(const cm3_particle_desc *d, const cm3_particle_traj 
   for (int k = 0; k < n_ticks; ++k) {
     cm3_particle_bufs b;
     memset(&b, 0, sizeof(b));
-    b.state_in = at(t->state, t->state_stride, k);
-    b.state_out = at(t->state, t->state_stride, k + 1);
-    b.goals_in = at(t->goals, t->goals_stride, k);
-    b.goals_out = at(t->goals, t->goals_stride, k + 1);
+    const bool live = t->state_live != nullptr;
+    b.state_in = live ? t->state_live : at(t->state, t->state_stride, k);
+    b.state_out = live ? t->state_live : at(t->state, t->state_stride, k + 1);
+    b.goals_in = live ? t->goals_live : at(t->goals, t->goals_stride, k);
+    b.goals_out = live ? t->goals_live : at(t->goals, t->goals_stride, k + 1);
     b.meta_in = t->meta;
     b.meta_out = t->meta;
     b.episode = t->episode;
@@ -1448,6 +1478,10 @@ static int particle_rollout(const cm3_particle_desc *d, const cm3_particle_traj 
     int rc = fill_params(d, &b, kStep, nullptr, p);
     if (rc != CM3_OK) return rc;
     p.flags |= obs_store_nt(t->obs_others_stride, n_ticks);
+    if (live) {
+      p.state_copy = at(t->state, t->state_stride, k + 1);
+      p.goals_copy = at(t->goals, t->goals_stride, k + 1);
+    }
     rc = launch<R>(p, d->n_agents, kStep, (hipStream_t)stream);
     if (rc != CM3_OK) return rc;
   }

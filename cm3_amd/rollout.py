@@ -110,7 +110,7 @@ class ParticleRollout(object):
     """
 
     def __init__(self, env, n_ticks=None, use_graph=True, fused=False, n_chains=1, record_collisions=True,
-                 fused_policy_tick=False):
+                 fused_policy_tick=False, live_state=None):
         self.env = env
         self.T = int(n_ticks or env.max_steps)
         self.use_graph = bool(use_graph)
@@ -125,6 +125,9 @@ class ParticleRollout(object):
         # streams (parallel branches of the captured hipGraph).  Identical trajectories (cm3_particle_rollout_chains_*),
         # but MEASURED 1.2-5x SLOWER than one chain on MI355X in every form tried (profiles/r02_chains_diag.txt): the
         # option exists for reproducing that result, not as an optimisation.
+        # live_state: None = by size (see collect); True / False force stepping in place on the env's buffers with slot copies /
+        # chaining the ticks through the slots.  Identical trajectories either way (tests/test_gpu_rollout.py).
+        self.live_state = live_state
         self.n_chains = int(n_chains)
         if not (1 <= self.n_chains <= 16):
             raise Cm3Error("n_chains must be in 1..16")
@@ -151,6 +154,7 @@ class ParticleRollout(object):
         self.collisions = z(T, E, d=torch.int32) if record_collisions else None
         self._graph = None
         self._actor_graph = _ActorGraphCache(dev)
+        self._live, self._live_cur = False, env._cur
         # episode-synchronous mode: which envs' episodes have ended since their last reset (carried across collects)
         self._finished = torch.zeros(E, dtype=torch.bool, device=dev)
         self._finished0 = None
@@ -158,10 +162,16 @@ class ParticleRollout(object):
         self.collected = False
 
     # ---- plumbing ------------------------------------------------------------------------------------
-    def _traj(self, t0=0):
+    def _traj(self, t0=0, live=False):
+        """live: per-tick launches step IN PLACE on the env's own state / goals buffers and write every tick's state / goals
+        to its slot as a copy (cm3_particle_traj.state_live): a tick then loads lines its predecessor read and overwrote
+        instead of a fresh slot that was only ever written -- 0.19 us of 2.83 per tick at C2 (tools/trajectory_gap.py)."""
         env, es = self.env, self.state.element_size()
         E, N, L = env.E, env.n, env.L
         t = _lib.ParticleTraj()
+        if live:
+            t.state_live = env._state[env._cur].data_ptr()
+            t.goals_live = env._goals.data_ptr()
         t.state = self.state[t0].data_ptr()
         t.state_stride = N * E * 4 * es
         if self.goals is not None:
@@ -192,10 +202,10 @@ class ParticleRollout(object):
             t.collisions_stride = E * 4
         return t
 
-    def _enqueue(self, t0, n, flags, stream=None, chains=False):
+    def _enqueue(self, t0, n, flags, stream=None, chains=False, live=False):
         env = self.env
         env._desc.flags = flags
-        traj = self._traj(t0)
+        traj = self._traj(t0, live)
         stream = env._stream() if stream is None else stream
         if chains and self.n_chains > 1:
             fn = getattr(self._lib, "cm3_particle_rollout_chains_" + env._suffix)
@@ -216,11 +226,13 @@ class ParticleRollout(object):
             pairs.append((self.goals[0], env._goals))
         self._copy(pairs)
 
-    def _store_back(self):
+    def _store_back(self, live=False):
         env = self.env
-        pairs = [(env._state[env._cur], self.state[self.T]), (env._obs_others[env._cur], self.obs_others[self.T])]
-        if self.goals is not None:
-            pairs.append((env._goals, self.goals[self.T]))
+        pairs = [(env._obs_others[env._cur], self.obs_others[self.T])]
+        if not live:    # (live: the env's state / goals buffers ARE the final state)
+            pairs.append((env._state[env._cur], self.state[self.T]))
+            if self.goals is not None:
+                pairs.append((env._goals, self.goals[self.T]))
         self._copy(pairs)
 
     # ---- collection ------------------------------------------------------------------------------------
@@ -228,11 +240,12 @@ class ParticleRollout(object):
         """T x (actor launch, step launch) on `stream`: the policy reads slot t, writes actions[t]; the step kernel
         consumes them and writes slot t+1 (train_onpolicy.py:311-323 without leaving the device)."""
         env = self.env
+        live = self._live
         for t in range(self.T):
             goals = self.goals[t] if self.goals is not None else env._goals
             actor.enqueue(env.E, self.obs_others[t], self.state[t], goals, env._meta, env._episode, self.actions[t],
                           epsilon, stream=stream, env_id_base=env.env_id_base)
-            self._enqueue(t, 1, base_flags, stream)
+            self._enqueue(t, 1, base_flags, stream, live=live)
 
     def _enqueue_fused_policy_ticks(self, actor, epsilon, base_flags, stream):
         """T launches of the fused policy kernel, one tick each (slot t -> slot t+1)."""
@@ -259,6 +272,23 @@ class ParticleRollout(object):
         self._finished0 = None if self.auto_reset else self._finished.clone()
         self._load_slot0()
         base = (FLAG_AUTO_RESET if self.auto_reset else 0) | env.kernel_flags
+        # per-tick step launches of a slot trajectory step in place on the env's live buffers (see _traj); the launches that
+        # keep the state in registers (fused) or read the slots themselves (fused policy kernels) do not
+        # -- and only while a tick's state is small: the slot copy is extra write traffic, the gain is load latency.  Measured
+        # (tools/trajectory_gap.py, profiles/r02_trajectory_gap_live_state.txt): below ~1 MiB of state per tick live wins by
+        # 4-14 % (C2: 2.87 -> 2.74 us), from there on chaining the ticks through the slots is as fast or faster (C5: 5.53 vs 5.74)
+        # ... and only for a streaming-size trajectory (the library's criterion for non-temporal observation stores: >= 128 MB of
+        # observation slots): a small trajectory that is collected over and over (C4: 26 MB) stays cache-resident, its slots are
+        # not "fresh", and the copies only cost (3.63 -> 3.70 us per tick at C4)
+        es = self.state.element_size()
+        small = env.n * env.E * 4 * es < (1 << 20) and env.E * env.n * env.L * es * self.T >= (128 << 20)
+        if self.live_state is not None:
+            small = bool(self.live_state)
+        live = self._live = (self.goals is not None and small and not self.fused
+                             and not (self.fused_policy_tick and policy is not None))
+        if live and self._live_cur != env._cur:    # captured graphs hold the live buffer's address
+            self._drop_graphs()
+            self._live_cur = env._cur
         if policy is None:
             flags = base | FLAG_GEN_ACTIONS
             if self.fused:
@@ -266,10 +296,10 @@ class ParticleRollout(object):
             elif self.use_graph:
                 if self._graph is None:
                     self._graph = _lib.capture_graph(env.device,
-                                                     lambda s: self._enqueue(0, self.T, flags, s, chains=True))
+                                                     lambda s: self._enqueue(0, self.T, flags, s, chains=True, live=live))
                 _lib.check(self._lib.cm3_graph_launch(self._graph, env._stream()))
             else:
-                self._enqueue(0, self.T, flags, chains=True)
+                self._enqueue(0, self.T, flags, chains=True, live=live)
         elif hasattr(policy, "enqueue") and hasattr(policy, "act"):      # on-device actor (cm3_amd.actor)
             if env.dtype != torch.float32:
                 raise Cm3Error("the device actor reads float32 env buffers")
@@ -303,19 +333,22 @@ class ParticleRollout(object):
                 goals = (self.goals[t] if self.goals is not None else env._goals).permute(1, 0, 2)
                 a = policy(self.obs_others[t], self.state[t].permute(1, 0, 2), goals)
                 self.actions[t].copy_(torch.as_tensor(a, device=env.device).reshape(env.E, env.n))
-                self._enqueue(t, 1, base)
-        self._store_back()
+                self._enqueue(t, 1, base, live=live)
+        self._store_back(live)
         if not self.auto_reset:
             self._finished |= self.done.bool().any(0)
         self.collected = True
         return self
 
-    def close(self):
+    def _drop_graphs(self):
         if self._graph is not None:
             torch.cuda.synchronize(self.env.device)
             self._lib.cm3_graph_destroy(self._graph)
             self._graph = None
         self._actor_graph.destroy(self._lib)
+
+    def close(self):
+        self._drop_graphs()
 
     # ---- views --------------------------------------------------------------------------------------------
     @property

@@ -364,3 +364,37 @@ def test_batched_evaluation_equals_reference_test_checkers(tag):
     assert n == n_eval and abs(float(dist.sum()) - 1.0) < 1e-12
     assert np.abs(local - z["reward_local_avg"]).max() < 1e-12
     assert abs(glob - float(z["reward_global_avg"])) < 1e-12
+
+
+@pytest.mark.parametrize("kernel,N,E", [("env", 4, 1000), ("pair", 4, 1000), ("agent", 4, 1000), ("agent", 8, 520), ("pair", 2, 333)])
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_live_state_rollout_equals_slot_chained_rollout(kernel, N, E, use_graph):
+    """cm3_particle_traj.state_live (ABI 4): stepping in place on the env's own state / goals buffers with a copy into every slot
+    gives the trajectory, the terminal captures and the final env state of chaining the ticks through the slots, bit for bit --
+    over episode ends (max_steps 7), for every mapping, two collects in a row."""
+    from cm3_amd.particle import VecParticleEnv
+    from cm3_amd.rollout import ParticleRollout
+    cfg = load_cfg("particle_merge8.json")
+    envs, ros = [], []
+    for live in (True, False):
+        env = VecParticleEnv(cfg, N, 0.2, 7, E, device="cuda:0", dtype=torch.float32, seed=5, auto_reset=True, kernel=kernel)
+        env.reset()
+        envs.append(env)
+        ros.append(ParticleRollout(env, n_ticks=20, use_graph=use_graph, live_state=live))
+    for rep in range(2):
+        a, b = (ro.collect(reset=False) for ro in ros)
+        assert a._live and not b._live
+        for name in ("state", "goals", "obs_others", "actions", "reward", "reward_n", "done", "term_state", "term_obs_others",
+                     "collisions"):
+            x, y = getattr(a, name), getattr(b, name)
+            if name in ("term_state", "term_obs_others"):      # defined where an episode ended
+                d = a.done.bool()
+                x = x.permute(0, 2, 1, 3)[d] if name == "term_state" else x[d]
+                y = y.permute(0, 2, 1, 3)[d] if name == "term_state" else y[d]
+            assert torch.equal(x, y), (name, rep)
+        assert bool(a.done.any())
+        for attr in ("global_state", "goals", "steps", "collisions", "episode"):
+            assert torch.equal(getattr(envs[0], attr), getattr(envs[1], attr)), (attr, rep)
+        assert torch.equal(envs[0].get_obs()[1], envs[1].get_obs()[1])
+    for ro in ros:
+        ro.close()
