@@ -184,6 +184,12 @@ template <bool NT> __device__ __forceinline__ void store_obs_vec(float4 *p, cons
   }
 }
 template <bool NT> __device__ __forceinline__ void store_obs_vec(double4 *p, const double4 &v) { *p = v; }
+// The per-agent 4-byte outputs (actions, reward_n) of the lane-per-agent mapping: a wave writes 256 contiguous bytes = whole
+// lines of them per instruction, so on the non-temporal path they take the hint too (C5 trajectory 5.56 -> 5.48 us per tick, same
+// box; the per-ENV outputs are partial lines per instruction and lose with it: profiles/r02_small_outputs_nt_store.txt)
+template <bool NT, typename T> __device__ __forceinline__ void store_small(T *p, T v) {
+  if constexpr (NT && sizeof(T) == 4) __builtin_nontemporal_store(v, p); else *p = v;
+}
 
 // np.sum(reward_n) as NumPy reduces a contiguous float64 vector (environment.py:107): left to right for
 // n < 8, eight interleaved accumulators folded as a fixed tree for n == 8 (oracle: np_list_sum).
@@ -933,7 +939,7 @@ __global__ void __launch_bounds__(WAVES * 64)
     if (gen) {  // train_onpolicy.py:305-307
       const u32x4 w = action_words(p.seed, genv, episode, (uint32_t)steps, (uint32_t)(i >> 2));
       act = rand5(pick_word(w, i & 3));
-      if (mine) *at32<int32_t>(actions_t, (e * N + i) * 4u) = act;
+      if (mine) store_small<NT>(at32<int32_t>(actions_t, (e * N + i) * 4u), act);
     } else {
       act = *at32<const int32_t>(actions_t, (ec * N + i) * 4u);
     }
@@ -1026,7 +1032,7 @@ __global__ void __launch_bounds__(WAVES * 64)
     const R reward = sum_agents<R, N>(rews);
     const bool done = (steps == h_max_steps) || all_reached;
 
-    if (mine) *at32<R>(tick_ptr(p.reward_n, p.st_reward_n, t), (e * N + i) * (uint32_t)sizeof(R)) = rew;
+    if (mine) store_small<NT>(at32<R>(tick_ptr(p.reward_n, p.st_reward_n, t), (e * N + i) * (uint32_t)sizeof(R)), rew);
     if (head) {
       *at32<R>(tick_ptr(p.reward, p.st_reward, t), e * (uint32_t)sizeof(R)) = reward;
       *at32<uint8_t>(tick_ptr(p.done, p.st_done, t), e) = done ? 1 : 0;
