@@ -645,6 +645,7 @@ def main():
                                       if fused_ticks == 1 else "%d ticks fused per launch (random-action branch)" % fused_ticks),
                        "envs_per_gpu": E, "n_agents": N, "global_envs": E * world, "mode": mode, "chains": n_chains,
                        "launch": launch_desc, "ticks_per_launch": fused_ticks,
+                       "live_state": bool(getattr(getattr(stepper, "ro", None), "_live", False)),
                        "step_definition": ("one 33-tick rollout + advantage normalisation" if kind == "particle_adv" else
                                            "one collection phase = %d episodes x %d ticks (train_onpolicy.py:359-377)"
                                            % (PHASE_EPISODES, EP_TICKS)),
