@@ -26,7 +26,7 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     lib = _lib.lib()
-    env = VecCheckersEnv(cfg["init"], cfg["n_agents"], 33, 8192, device=dev, seed=1, auto_reset=True)
+    env = VecCheckersEnv(cfg["init"], cfg["n_agents"], int(os.environ.get("MAX_STEPS", "33")), 8192, device=dev, seed=1, auto_reset=True)
     env.reset(np.eye(2))
     ro = CheckersRollout(env, n_ticks=T)
     full = ro._traj()
