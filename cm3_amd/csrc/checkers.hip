@@ -366,6 +366,7 @@ __device__ __forceinline__ bool ck_tick_env(const CheckersParams &p, int t, size
       else act[i] = actions_t[ec * N + i];
     }
   }
+  CM3_STAMP(2, false);
 
   // ---- agents act in index order (step :233-237) ---------------------------------------------------------
   double local[N];
@@ -417,6 +418,7 @@ __device__ __forceinline__ bool ck_tick_env(const CheckersParams &p, int t, size
     total = ((local[0] + local[1]) + (local[2] + local[3])) + ((local[4] + local[5]) + (local[6] + local[7]));
   }
   steps += 1;
+  CM3_STAMP(3, false);
   bool done;  // :246-260
   if (steps == g_max_steps) {
     done = true;
@@ -654,6 +656,7 @@ __device__ __forceinline__ void ckf_emit(const CheckersParams &p, const CkState<
     const int d = d0 + g;
     if (d < GD) ck_st<NT>(at32<uint32_t>(out.grid, grow + 4u * d), ckf_grid_dword<N>(m32, d));
   }
+  CM3_STAMP(5, false);
   // ---- obs_self_t ---------------------------------------------------------------------------------------------------------
   constexpr int OD = (F::OBST_REC + 3) / 4, NQ = (OD + 2) / 3;
   const uint32_t orow = e * (uint32_t)p.obst_stride;
@@ -669,6 +672,7 @@ __device__ __forceinline__ void ckf_emit(const CheckersParams &p, const CkState<
       if (3 * q + 2 < OD) ck_st<NT>(dst + 2, (c2 >> 16) | (c3 << 8));
     }
   }
+  CM3_STAMP(6, false);
   // ---- vec ----------------------------------------------------------------------------------------------------------------
   if (g < N) {
     int4 v;
@@ -682,6 +686,7 @@ __device__ __forceinline__ void ckf_emit(const CheckersParams &p, const CkState<
     }
     ck_st<NT>(at32<int4>(out.vec, (e * N + g) * 16u), v);
   }
+  CM3_STAMP(7, false);
   // ---- obs_self_v, obs_others ---------------------------------------------------------------------------------------------
   constexpr int NSV = 4 * N, NOO = 2 * N * NO, NV = NSV + NOO;
   const double half = (double)(F::R * F::C) / 2.0;
@@ -740,21 +745,25 @@ __global__ void __launch_bounds__(256)
   const bool writer = env_ok && g == 0;
   CkState<N> s;
   CkLive<N> lv;
+  CM3_STAMP(0, false);
   ck_load_env<N>(hd, ec, s, lv);
   // the kernel arguments the tick needs, requested while the state loads are in flight (fetched at their first use they made
   // the wave wait for a scalar load six times along its critical path)
   CM3_FETCH_EARLY(p.actions, p.local_rewards, p.reward, p.done, p.grid, p.vec, p.obs_others, p.obs_self_t, p.obs_self_v,
                   p.goals_next, p.term_grid, p.max_steps, p.grid_stride, p.obst_stride, p.seed, p.env_id_base);
+  CM3_STAMP(1, true);
   // FUSED == false: exactly one tick; the loop and the per-tick offsets fold away
   const int n_ticks = FUSED ? p.n_ticks : 1;
 #pragma unroll 1
   for (int t = 0; t < n_ticks; ++t) {
     const bool ended = ck_tick_env<N, true>(p, t, e, ec, writer, s, lv);
+    CM3_STAMP(4, false);
     if (ended) {  // AUTO_RESET: terminal observation (train_onpolicy.py:336-347), then the fresh episode
       if (p.term_grid) ckf_emit<N, NT, G>(p, s, g, e, env_ok, ck_out_term(p, t));
       ck_restart_env<N>(p, e, ec, writer, s, lv);
     }
     ckf_emit<N, NT, G>(p, s, g, e, env_ok, ck_out_tick(p, t));
+    CM3_STAMP(8, false);
     if (p.goals_next && writer) {
       uint8_t *gn = ck_tick_ptr(p.goals_next, p.st_goals_next, t);
 #pragma unroll
@@ -762,6 +771,7 @@ __global__ void __launch_bounds__(256)
     }
   }
   if (writer) ck_store_env<N>(p, e, s, lv);
+  CM3_STAMP(9, true);
 }
 
 template <int N> __global__ void __launch_bounds__(256) k_checkers_reset_fast(const CheckersParams p) {
