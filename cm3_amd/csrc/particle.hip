@@ -263,6 +263,15 @@ template <typename R, int N> struct ObsGeom {
   static constexpr int LDS_REALS = ROWS * STRIDE;
 };
 
+// Cross-lane moves inside a 16-lane DPP row: no LDS round trip (a waited-for ds_bpermute is ~66 clocks, a DPP move ~11).
+//   kDppXor1 / kDppXor2: lane ^ 1 / lane ^ 2 inside each quad; kDppHalfMirror: lane i <-> 7 - i inside each 8 lanes;
+//   kDppBcast + n: lane n of the row to every lane of the row (gfx90a+).
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppBcast = 0x150;
+template <int CTRL> __device__ __forceinline__ float dpp_f32(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL> __device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+
 __device__ __forceinline__ void wave_lds_sync() {
   // LDS operations of one wave execute in issue order; this only stops the compiler from moving
   // LDS accesses across the write -> read hand-off inside the wave.
@@ -774,8 +783,15 @@ __global__ void __launch_bounds__(WAVES * 64)
     const unsigned long long rgrp = (G == 64) ? rb : ((rb >> base) & ((1ull << (G & 63)) - 1ull));
     const bool all_reached = __popcll(rgrp) == N;
     R rews[N];
+    if constexpr (N == 4 && sizeof(R) == 4) {  // G == 16: an env is one DPP row, agent a's lead lane is lane 3a of it
+      rews[0] = dpp_f32<kDppBcast + 0>(rew);
+      rews[1] = dpp_f32<kDppBcast + 3>(rew);
+      rews[2] = dpp_f32<kDppBcast + 6>(rew);
+      rews[3] = dpp_f32<kDppBcast + 9>(rew);
+    } else {
 #pragma unroll
-    for (int a = 0; a < N; ++a) rews[a] = __shfl(rew, base + a * NO, 64);
+      for (int a = 0; a < N; ++a) rews[a] = __shfl(rew, base + a * NO, 64);
+    }
     const R reward = sum_agents<R, N>(rews);
     const bool done = (steps == h_max_steps) || all_reached;
 
@@ -1029,16 +1045,35 @@ __global__ void __launch_bounds__(WAVES * 64)
     for (int c = 0; c < NO; ++c)
       if (c < c_i) rew = rew - R(1);
     int c_env = c_i;  // every ordered visit counts (:135-137)
+    if constexpr (G == 8) {
+      c_env += dpp_i32<kDppXor1>(c_env);
+      c_env += dpp_i32<kDppXor2>(c_env);
+      c_env += dpp_i32<kDppHalfMirror>(c_env);  // the quads are uniform by now: lane 7 - i holds the other quad's sum
+    } else if constexpr (G == 4) {
+      c_env += dpp_i32<kDppXor1>(c_env);
+      c_env += dpp_i32<kDppXor2>(c_env);
+    } else {
 #pragma unroll
-    for (int off = G / 2; off > 0; off >>= 1) c_env += __shfl_xor(c_env, off, 64);
+      for (int off = G / 2; off > 0; off >>= 1) c_env += __shfl_xor(c_env, off, 64);
+    }
     collisions += c_env;
     const unsigned long long rb = __ballot(reached && agent_ok);
     const unsigned long long rgrp = (G == 64) ? rb : ((rb >> base) & ((1ull << (G & 63)) - 1ull));
     const bool all_reached = __popcll(rgrp) == N;
-    R rews[N];
+    R reward;
+    if constexpr (N == 8 && sizeof(R) == 4) {
+      // NumPy's pairwise tree for 8 values (sum_agents): ((v0+v1)+(v2+v3)) + ((v4+v5)+(v6+v7)), as three DPP adds -- IEEE addition
+      // commutes, so every lane of the env ends with exactly that value
+      R tsum = rew + dpp_f32<kDppXor1>(rew);
+      tsum = tsum + dpp_f32<kDppXor2>(tsum);
+      const R other = dpp_f32<kDppHalfMirror>(tsum);
+      reward = gi < 4 ? tsum + other : other + tsum;
+    } else {
+      R rews[N];
 #pragma unroll
-    for (int a = 0; a < N; ++a) rews[a] = __shfl(rew, base + a, 64);
-    const R reward = sum_agents<R, N>(rews);
+      for (int a = 0; a < N; ++a) rews[a] = __shfl(rew, base + a, 64);
+      reward = sum_agents<R, N>(rews);
+    }
     const bool done = (steps == h_max_steps) || all_reached;
 
     if (mine) store_small<NT>(at32<R>(tick_ptr(p.reward_n, p.st_reward_n, t), (e * N + i) * (uint32_t)sizeof(R)), rew);
