@@ -647,12 +647,15 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step(const ParticlePara
 template <int N> struct PairGeom {
   static constexpr int NO = N - 1;
   static constexpr int SLOTS = N * NO;
+  // lanes per agent: its N-1 pair lanes, padded to a power of two where that keeps the group size (N = 3, 4, 5) -- an agent is then
+  // a pair / a quad of lanes and its forces come together with DPP quad permutes instead of an LDS shuffle round trip
+  static constexpr int LA = (N >= 3 && N <= 5) ? (N == 3 ? 2 : 4) : NO;
   static constexpr int pow2ceil(int v) {
     int r = 1;
     while (r < v) r <<= 1;
     return r;
   }
-  static constexpr int G = pow2ceil(SLOTS);
+  static constexpr int G = pow2ceil(N * LA);
   static constexpr int EPW = 64 / G;  // envs per wave
 };
 
@@ -678,7 +681,8 @@ __global__ void __launch_bounds__(WAVES * 64)
   using V4 = typename Vec<R>::v4;
   using V2 = typename Vec<R>::v2;
   using PG = PairGeom<N>;
-  constexpr int NO = PG::NO, SLOTS = PG::SLOTS, G = PG::G, EPW = PG::EPW;
+  constexpr int NO = PG::NO, SLOTS = PG::SLOTS, G = PG::G, EPW = PG::EPW, LA = PG::LA;
+  static_assert(PairGeom<N>::pow2ceil(SLOTS) == G, "the padded lane layout must not change the group size");
 
   const int lane = threadIdx.x & 63, wave_all = threadIdx.x >> 6;
   const int wave = wave_all;
@@ -687,9 +691,11 @@ __global__ void __launch_bounds__(WAVES * 64)
   const uint32_t e = (uint32_t)h_E0 + ((uint32_t)blockIdx.x * WAVES + wave) * EPW + sub;
   const bool env_ok = e < EN;
   const uint32_t ec = env_ok ? e : EN - 1;
-  const bool slot_ok = gslot < SLOTS;
-  const int gi = slot_ok ? gslot : 0;
-  const int i = gi / NO, k = gi - i * NO, j = k < i ? k : k + 1;
+  // lane gslot of the group = pair lane k of agent i: gslot = i * LA + k, k < N - 1 (LA == N - 1 unless padded, see PairGeom)
+  const int i_raw = gslot / LA, k_raw = gslot - i_raw * LA;
+  const bool slot_ok = i_raw < N && k_raw < NO;
+  const int i = slot_ok ? i_raw : 0, k = slot_ok ? k_raw : 0, j = k < i ? k : k + 1;
+  const int vslot = i * NO + k;  // index of this lane's obs_others vector inside the env record
   const bool lead = slot_ok && k == 0;  // one lane per agent does the per-agent stores
   const bool head = gslot == 0;         // one lane per env does the per-env stores
 
@@ -738,11 +744,29 @@ __global__ void __launch_bounds__(WAVES * 64)
     R Fx = ux * R(5.0) + R(0.0), Fy = uy * R(5.0) + R(0.0);
     contact_force<R>(si.z - sj.z, si.w - sj.w, f_x, f_y);
     CM3_STAMP(3, false);
+    if constexpr (sizeof(R) == 4 && LA == 4 && NO >= 3) {  // the agent's lanes are a quad
+      Fx = dpp_f32<0x00>(f_x) + Fx;  // quad_perm:[0,0,0,0]
+      Fy = dpp_f32<0x00>(f_y) + Fy;
+      Fx = dpp_f32<0x55>(f_x) + Fx;  // [1,1,1,1]
+      Fy = dpp_f32<0x55>(f_y) + Fy;
+      Fx = dpp_f32<0xAA>(f_x) + Fx;  // [2,2,2,2]
+      Fy = dpp_f32<0xAA>(f_y) + Fy;
+      if constexpr (NO == 4) {
+        Fx = dpp_f32<0xFF>(f_x) + Fx;  // [3,3,3,3]
+        Fy = dpp_f32<0xFF>(f_y) + Fy;
+      }
+    } else if constexpr (sizeof(R) == 4 && LA == 2) {  // N = 3: two agents per quad
+      Fx = dpp_f32<0xA0>(f_x) + Fx;  // quad_perm:[0,0,2,2]
+      Fy = dpp_f32<0xA0>(f_y) + Fy;
+      Fx = dpp_f32<0xF5>(f_x) + Fx;  // [1,1,3,3]
+      Fy = dpp_f32<0xF5>(f_y) + Fy;
+    } else {
 #pragma unroll
-    for (int kk = 0; kk < NO; ++kk) {  // contributions of agent i in the reference's order (j ascending)
-      const int src = base + i * NO + kk;
-      Fx = __shfl(f_x, src, 64) + Fx;
-      Fy = __shfl(f_y, src, 64) + Fy;
+      for (int kk = 0; kk < NO; ++kk) {  // contributions of agent i in the reference's order (j ascending)
+        const int src = base + i * LA + kk;
+        Fx = __shfl(f_x, src, 64) + Fx;
+        Fy = __shfl(f_y, src, 64) + Fy;
+      }
     }
 
     // ---- integrate agent i (every lane of agent i computes the same values) ---------------------------------
@@ -754,7 +778,7 @@ __global__ void __launch_bounds__(WAVES * 64)
     si.w = si.w + si.y * kDt;
     steps += 1;
     {
-      const int src = base + j * NO;  // lead lane of agent j
+      const int src = base + j * LA;  // lead lane of agent j
       sj.x = __shfl(si.x, src, 64);
       sj.y = __shfl(si.y, src, 64);
       sj.z = __shfl(si.z, src, 64);
@@ -774,7 +798,7 @@ __global__ void __launch_bounds__(WAVES * 64)
     const bool hit = slot_ok && is_collision<R>(sj.z - si.z, sj.w - si.w);  // is_collision(a = j, agent = i)
     const unsigned long long hits = __ballot(hit);
     const unsigned long long grp = (G == 64) ? hits : ((hits >> base) & ((1ull << (G & 63)) - 1ull));
-    const int c_i = __popcll((grp >> (i * NO)) & ((1ull << NO) - 1ull));
+    const int c_i = __popcll((grp >> (i * LA)) & ((1ull << NO) - 1ull));
 #pragma unroll
     for (int c = 0; c < NO; ++c)
       if (c < c_i) rew = rew - R(1);
@@ -784,13 +808,13 @@ __global__ void __launch_bounds__(WAVES * 64)
     const bool all_reached = __popcll(rgrp) == N;
     R rews[N];
     if constexpr (N == 4 && sizeof(R) == 4) {  // G == 16: an env is one DPP row, agent a's lead lane is lane 3a of it
-      rews[0] = dpp_f32<kDppBcast + 0>(rew);
-      rews[1] = dpp_f32<kDppBcast + 3>(rew);
-      rews[2] = dpp_f32<kDppBcast + 6>(rew);
-      rews[3] = dpp_f32<kDppBcast + 9>(rew);
+      rews[0] = dpp_f32<kDppBcast + 0 * LA>(rew);
+      rews[1] = dpp_f32<kDppBcast + 1 * LA>(rew);
+      rews[2] = dpp_f32<kDppBcast + 2 * LA>(rew);
+      rews[3] = dpp_f32<kDppBcast + 3 * LA>(rew);
     } else {
 #pragma unroll
-      for (int a = 0; a < N; ++a) rews[a] = __shfl(rew, base + a * NO, 64);
+      for (int a = 0; a < N; ++a) rews[a] = __shfl(rew, base + a * LA, 64);
     }
     const R reward = sum_agents<R, N>(rews);
     const bool done = (steps == h_max_steps) || all_reached;
@@ -810,7 +834,7 @@ __global__ void __launch_bounds__(WAVES * 64)
         void *term_state = tick_ptr(p.term_state, p.st_term_state, t);
         void *term_obs = tick_ptr(p.term_obs_others, p.st_term_obs, t);
         if (term_state && lead) *at32<V4>(term_state, (row_i + e) * (uint32_t)sizeof(V4)) = si;
-        if (term_obs && slot_ok) *at32<V4>(term_obs, (e * SLOTS + gslot) * (uint32_t)sizeof(V4)) = sub4<R, V4>(sj, si);
+        if (term_obs && slot_ok) *at32<V4>(term_obs, (e * SLOTS + vslot) * (uint32_t)sizeof(V4)) = sub4<R, V4>(sj, si);
       }
       episode += 1;
       const bool rnd = episode_is_random(p, genv, episode);
@@ -836,7 +860,7 @@ __global__ void __launch_bounds__(WAVES * 64)
       }
       // observation (multi-goal_spread.py:145-154): vector (i,k) of env e; lanes of a wave cover whole records
       if (slot_ok)
-        store_obs_vec<NT>(at32<V4>(tick_ptr(p.obs_others, p.st_obs, t), (e * SLOTS + gslot) * (uint32_t)sizeof(V4)), sub4<R, V4>(sj, si));
+        store_obs_vec<NT>(at32<V4>(tick_ptr(p.obs_others, p.st_obs, t), (e * SLOTS + vslot) * (uint32_t)sizeof(V4)), sub4<R, V4>(sj, si));
     }
   }
 
