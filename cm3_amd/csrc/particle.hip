@@ -755,6 +755,9 @@ __global__ void __launch_bounds__(WAVES * 64)
         Fx = dpp_f32<0xFF>(f_x) + Fx;  // [3,3,3,3]
         Fy = dpp_f32<0xFF>(f_y) + Fy;
       }
+    } else if constexpr (N == 2) {  // one pair lane per agent: its only contribution is its own
+      Fx = f_x + Fx;
+      Fy = f_y + Fy;
     } else if constexpr (sizeof(R) == 4 && LA == 2) {  // N = 3: two agents per quad
       Fx = dpp_f32<0xA0>(f_x) + Fx;  // quad_perm:[0,0,2,2]
       Fy = dpp_f32<0xA0>(f_y) + Fy;
@@ -777,7 +780,12 @@ __global__ void __launch_bounds__(WAVES * 64)
     si.z = si.z + si.x * kDt;
     si.w = si.w + si.y * kDt;
     steps += 1;
-    {
+    if constexpr (N == 2 && sizeof(R) == 4) {  // the other agent is the neighbouring lane
+      sj.x = dpp_f32<kDppXor1>(si.x);
+      sj.y = dpp_f32<kDppXor1>(si.y);
+      sj.z = dpp_f32<kDppXor1>(si.z);
+      sj.w = dpp_f32<kDppXor1>(si.w);
+    } else {
       const int src = base + j * LA;  // lead lane of agent j
       sj.x = __shfl(si.x, src, 64);
       sj.y = __shfl(si.y, src, 64);
@@ -807,7 +815,10 @@ __global__ void __launch_bounds__(WAVES * 64)
     const unsigned long long rgrp = (G == 64) ? rb : ((rb >> base) & ((1ull << (G & 63)) - 1ull));
     const bool all_reached = __popcll(rgrp) == N;
     R rews[N];
-    if constexpr (N == 4 && sizeof(R) == 4) {  // G == 16: an env is one DPP row, agent a's lead lane is lane 3a of it
+    if constexpr (N == 2 && sizeof(R) == 4) {  // G == 2: agents 0 / 1 are the even / odd lane of each pair
+      rews[0] = dpp_f32<0xA0>(rew);  // quad_perm:[0,0,2,2]
+      rews[1] = dpp_f32<0xF5>(rew);  // [1,1,3,3]
+    } else if constexpr (N == 4 && sizeof(R) == 4) {  // G == 16: an env is one DPP row, agent a's lead lane is lane a * LA of it
       rews[0] = dpp_f32<kDppBcast + 0 * LA>(rew);
       rews[1] = dpp_f32<kDppBcast + 1 * LA>(rew);
       rews[2] = dpp_f32<kDppBcast + 2 * LA>(rew);
