@@ -400,9 +400,17 @@ __device__ __forceinline__ bool ck_tick_env(const CheckersParams &p, int t, size
     double rew = 0.0;  // get_reward :190-225
     const int k = s.r[i] - gO, j = s.c[i] - gO;
     if (k >= 0 && k < gR && j >= 0 && j < gC) {
-      const uint64_t bit = 1ull << (k * gC + j);
-      if (!(s.mask & bit)) {
-        s.mask |= bit;
+      bool fresh;
+      if constexpr (FAST) {  // 24 reward cells: the collected mask fits 32 bits
+        const uint32_t bit = 1u << (k * gC + j), m = (uint32_t)s.mask;
+        fresh = !(m & bit);
+        if (fresh) s.mask = (uint64_t)(m | bit);
+      } else {
+        const uint64_t bit = 1ull << (k * gC + j);
+        fresh = !(s.mask & bit);
+        if (fresh) s.mask |= bit;
+      }
+      if (fresh) {
         const int colour = (k + j) & 1;
         if (colour == 0) s.ng[i] += 1; else s.no[i] += 1;
         rew = (colour == (int)goal[i]) ? 1.0 : -0.5;
@@ -426,7 +434,7 @@ __device__ __forceinline__ bool ck_tick_env(const CheckersParams &p, int t, size
     const uint64_t want = goal[0] == 0 ? p.green_mask : p.orange_mask;
     done = (s.mask & want) == want;
   } else {
-    done = (int)__popcll(s.mask) == g_collectible;
+    done = (FAST ? (int)__popc((uint32_t)s.mask) : (int)__popcll(s.mask)) == g_collectible;
   }
   if (active) {
     double *local_t = ck_tick_ptr(p.local_rewards, p.st_local, t);
