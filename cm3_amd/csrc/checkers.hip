@@ -383,8 +383,9 @@ __device__ __forceinline__ bool ck_tick_env(const CheckersParams &p, int t, size
         if constexpr (FAST) {
           const bool wall = tc < 2 || tr < 2 || tr >= 5 || tc >= 11;
           bool agent = false;
+          const int trc = tr | (tc << 8);
 #pragma unroll
-          for (int j = 0; j < N; ++j) agent = agent || (s.r[j] == tr && s.c[j] == tc);
+          for (int j = 0; j < N; ++j) agent = agent | ((s.r[j] | (s.c[j] << 8)) == trc);
           free_cell = !wall && !agent;
         } else {
           free_cell = ck_ch2<N>(p, s, tr, tc) == 0;
@@ -554,8 +555,9 @@ template <int N> __device__ __forceinline__ uint32_t ckf_cell3(const CkState<N> 
   // channel 2: walls +1 (2-wide border and right of the start column), agents -1, own cell 0 (:43-51, :105-107)
   const bool wall = (unsigned)kk >= (unsigned)F::R || (unsigned)jj >= (unsigned)(F::C + 1);
   bool agent = false;
+  const int rc = rr | (cc << 8);  // one compare per agent on the packed (row, column)
 #pragma unroll
-  for (int a = 0; a < N; ++a) agent = agent || (s.r[a] == rr && s.c[a] == cc);
+  for (int a = 0; a < N; ++a) agent = agent | ((s.r[a] | (s.c[a] << 8)) == rc);
   const uint32_t v2 = (cell == KK / 2) ? 0u : (wall ? 0x01u : (agent ? 0xffu : 0u));
   return cg < N * KK ? (v01 | (v2 << 16)) : 0u;
 }
