@@ -507,12 +507,14 @@ __device__ __forceinline__ void ck_step_env(const CheckersParams &p, size_t e, s
 // 2: 8.3 / 1.3e9, 4: 6.7 / 1.7e9, 8: 5.1 / 2.5e9, 16: 5.7 / 2.4e9, 32: 7.6 / 1.5e9; round 2 (profiles/
 // r02_checkers_lanes_per_env_sweep.txt, three alternating rounds): in place 4: 6.42, 8: 5.05, 16: 5.48 -- but for a streaming-size
 // trajectory (every tick its own slot, non-temporal stores) 4: 7.95, 8: 6.22, 16: 5.87.  So G = 8 everywhere except on the
-// non-temporal path, which uses G = 16 (the round-1 tuning was specific to in-place stepping).
+// non-temporal path, which used G = 16 (the round-1 tuning was specific to in-place stepping) -- until the emit was re-cut along
+// lane lines at the end of round 2: since then 8 lanes win there too (streaming trajectory 8: 4.22, 16: 4.30; in place 8: 3.87,
+// 16: 4.16, 32: 5.4), so both paths use 8.
 #ifndef CM3_CK_G
 #define CM3_CK_G 8
 #endif
 #ifndef CM3_CK_G_STREAM
-#define CM3_CK_G_STREAM 16
+#define CM3_CK_G_STREAM 8   // (16 until the emit was re-cut along lane lines; re-measured after that: 8 lanes 4.22 us, 16 lanes 4.30)
 #endif
 constexpr int kCkG = CM3_CK_G, kCkGStream = CM3_CK_G_STREAM;  // (macros: build variants for tools/ab_builds.sh style comparisons)
 template <int N, int G_ = kCkG> struct CkFast {
