@@ -1403,6 +1403,12 @@ template <typename R, int N, int WAVES> static int launch_agents(const ParticleP
   }
 }
 
+#ifndef CM3_PAIR_WAVES
+#define CM3_PAIR_WAVES 4   // waves per workgroup of the shared-env mappings at >= 256 waves (macros: build variants for comparisons)
+#endif
+#ifndef CM3_AGENT_WAVES
+#define CM3_AGENT_WAVES 4
+#endif
 template <typename R, int N> static int launch_n(const ParticleParams &p, ParticleOp op, hipStream_t stream) {
   if (op == kStep) {
     // Which mapping for (N, E): measured on MI355X in round 2, after the exact squared-distance thresholds took the square roots
@@ -1442,7 +1448,7 @@ template <typename R, int N> static int launch_n(const ParticleParams &p, Partic
     if (agents) {
       const size_t waves = ((size_t)p.E + AgentGeom<(N >= 2 ? N : 2)>::EPW - 1) / AgentGeom<(N >= 2 ? N : 2)>::EPW;
       if (waves < 256) return launch_agents<R, N, 1>(p, stream);
-      return launch_agents<R, N, 4>(p, stream);
+      return launch_agents<R, N, CM3_AGENT_WAVES>(p, stream);
     }
     if (pairs) {
       // 4 waves per workgroup (one per SIMD of a CU) measured faster than 1 or 2 from 1024 waves up
@@ -1450,7 +1456,7 @@ template <typename R, int N> static int launch_n(const ParticleParams &p, Partic
       // below 256 waves single-wave workgroups spread the work over more CUs.
       const size_t waves = ((size_t)p.E + PairGeom<(N >= 2 ? N : 2)>::EPW - 1) / PairGeom<(N >= 2 ? N : 2)>::EPW;
       if (waves < 256) return launch_pairs<R, N, 1>(p, stream);
-      return launch_pairs<R, N, 4>(p, stream);
+      return launch_pairs<R, N, CM3_PAIR_WAVES>(p, stream);
     }
   }
   // lane-per-env.  Small batches: one wave per workgroup; large: 4 waves per workgroup (one per SIMD).
