@@ -12,13 +12,18 @@ pids=()
 pids+=($!)
 "${HIPCC}" ${FLAGS} -DCM3_PARTICLE_F64 -c "${HERE}/particle.hip" -o "${HERE}/_obj/particle_f64.o" &
 pids+=($!)
-"${HIPCC}" ${FLAGS} -mllvm -amdgpu-kernarg-preload-count=16 -c "${HERE}/checkers.hip" -o "${HERE}/_obj/checkers.o" &
+# the two shared-env float32 step kernels once more, scheduled for instruction-level parallelism (see the head of particle.hip)
+"${HIPCC}" ${FLAGS} -mllvm -amdgpu-kernarg-preload-count=16 -mllvm -amdgpu-sched-strategy=max-ilp -DCM3_PARTICLE_F32 -DCM3_PARTICLE_ILP_TU \
+  -c "${HERE}/particle.hip" -o "${HERE}/_obj/particle_f32_ilp.o" &
+pids+=($!)
+# Checkers: max-ILP scheduling throughout (C3 4.26 -> 4.16 us per tick; 2^16 .. 2^20 envs within 1 %)
+"${HIPCC}" ${FLAGS} -mllvm -amdgpu-kernarg-preload-count=16 -mllvm -amdgpu-sched-strategy=max-ilp -c "${HERE}/checkers.hip" -o "${HERE}/_obj/checkers.o" &
 pids+=($!)
 for f in util advantage actor actor_checkers policy; do
   "${HIPCC}" ${FLAGS} -c "${HERE}/${f}.hip" -o "${HERE}/_obj/${f}.o" &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait "$p"; done
-"${HIPCC}" --offload-arch=gfx950 -shared -fPIC -o "${OUT}" "${HERE}/_obj/particle_f32.o" "${HERE}/_obj/particle_f64.o" \
+"${HIPCC}" --offload-arch=gfx950 -shared -fPIC -o "${OUT}" "${HERE}/_obj/particle_f32.o" "${HERE}/_obj/particle_f32_ilp.o" "${HERE}/_obj/particle_f64.o" \
   "${HERE}/_obj/checkers.o" "${HERE}/_obj/util.o" "${HERE}/_obj/advantage.o" "${HERE}/_obj/actor.o" "${HERE}/_obj/actor_checkers.o" "${HERE}/_obj/policy.o"
 echo "built ${OUT}"

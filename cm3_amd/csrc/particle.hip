@@ -19,7 +19,24 @@
 #include "philox.h"
 #include "thresholds.h"
 
+// This file is compiled a THIRD time for float32 (build.sh: -DCM3_PARTICLE_ILP_TU with -mllvm -amdgpu-sched-strategy=max-ilp): only the
+// two shared-env step kernels and their launchers, tagged with TU = 1 so that they are distinct symbols.  The max-ILP scheduling
+// strategy shortens the executed path of these kernels where a SIMD holds one or two waves (C2 2.61 -> 2.55 us per tick, fused
+// rollout +8 %) and costs occupancy where it holds many (N = 8 at 2^20 envs: 5.4 -> 5.0 TB/s), so the default build of a kernel is
+// kept for launches of more than kIlpMaxWaves waves (profiles/r02_sched_strategy_max_ilp.txt).
+#ifdef CM3_PARTICLE_ILP_TU
+#define CM3_PARTICLE_TU 1
+#else
+#define CM3_PARTICLE_TU 0
+#endif
+
 namespace cm3 {
+
+struct ParticleParams;
+// launchers of the max-ILP translation unit (float32 only): waves = 1 or 4 per workgroup; n_agents 2..8
+int particle_ilp_launch_pairs_f32(const ParticleParams &p, int n_agents, int waves_per_wg, hipStream_t stream);
+int particle_ilp_launch_agents_f32(const ParticleParams &p, int n_agents, int waves_per_wg, hipStream_t stream);
+[[maybe_unused]] constexpr size_t kIlpMaxWaves = 16384;
 
 struct ParticleParams {
   int E;          // extent of the env axis of every array (row stride of the [N][E][..] arrays)
@@ -664,7 +681,7 @@ template <int N> struct PairGeom {
 // (profiles/r02_draw_wave_on_off.txt) it had become a loss in every configuration that used it -- in place 0-6 %, trajectory mode
 // 5-10 % -- and was removed: a fifth wave, two workgroup barriers and an extra store + reload of the action row cost more than the
 // Philox chain they hid once the square roots had left the physics chain.)
-template <typename R, int N, int WAVES, bool FUSED, bool NT = false, bool LIVE = false>
+template <typename R, int N, int WAVES, bool FUSED, bool NT = false, bool LIVE = false, int TU = CM3_PARTICLE_TU>
 __global__ void __launch_bounds__(WAVES * 64)
     k_particle_step_pairs(const void *h_state_in, const void *h_goals_in, const int32_t *h_meta_in, const int32_t *h_episode,
                           const int h_E, const uint32_t h_flags, const int h_E0, const int h_EN, const int h_max_steps,
@@ -904,7 +921,7 @@ template <int N> struct AgentGeom {
   static constexpr int VPE = N * NO;        // obs vectors per env record
 };
 
-template <typename R, int N, int WAVES, bool FUSED, bool NT = false, bool LIVE = false>
+template <typename R, int N, int WAVES, bool FUSED, bool NT = false, bool LIVE = false, int TU = CM3_PARTICLE_TU>
 __global__ void __launch_bounds__(WAVES * 64)
     k_particle_step_agents(const void *h_state_in, const void *h_goals_in, const int32_t *h_meta_in, const int32_t *h_episode,
                            const int h_E, const uint32_t h_flags, const int h_E0, const int h_EN, const int h_max_steps,
@@ -1447,6 +1464,10 @@ template <typename R, int N> static int launch_n(const ParticleParams &p, Partic
     if (p.flags & CM3_FLAG_KERNEL_LANE_PER_AGENT) agents = true;
     if (agents) {
       const size_t waves = ((size_t)p.E + AgentGeom<(N >= 2 ? N : 2)>::EPW - 1) / AgentGeom<(N >= 2 ? N : 2)>::EPW;
+#ifndef CM3_PARTICLE_ILP_TU
+      if constexpr (sizeof(R) == 4 && N >= 2 && CM3_AGENT_WAVES == 4)
+        if (waves <= kIlpMaxWaves) return particle_ilp_launch_agents_f32(p, N, waves < 256 ? 1 : 4, stream);
+#endif
       if (waves < 256) return launch_agents<R, N, 1>(p, stream);
       return launch_agents<R, N, CM3_AGENT_WAVES>(p, stream);
     }
@@ -1455,6 +1476,10 @@ template <typename R, int N> static int launch_n(const ParticleParams &p, Partic
       // (tools/probes/step_timeline.hip: 4.38 vs 4.82 us at E=4096, 6.36 vs 7.32 us at E=16384, stamped build);
       // below 256 waves single-wave workgroups spread the work over more CUs.
       const size_t waves = ((size_t)p.E + PairGeom<(N >= 2 ? N : 2)>::EPW - 1) / PairGeom<(N >= 2 ? N : 2)>::EPW;
+#ifndef CM3_PARTICLE_ILP_TU
+      if constexpr (sizeof(R) == 4 && N >= 2 && CM3_PAIR_WAVES == 4)
+        if (waves <= kIlpMaxWaves) return particle_ilp_launch_pairs_f32(p, N, waves < 256 ? 1 : 4, stream);
+#endif
       if (waves < 256) return launch_pairs<R, N, 1>(p, stream);
       return launch_pairs<R, N, CM3_PAIR_WAVES>(p, stream);
     }
@@ -1627,6 +1652,42 @@ static int particle_rollout_chains(const cm3_particle_desc *d, const cm3_particl
 }
 
 }  // namespace cm3
+
+#ifdef CM3_PARTICLE_ILP_TU
+namespace cm3 {
+template <int N> static int ilp_pairs_n(const ParticleParams &p, int w, hipStream_t s) {
+  return w == 1 ? launch_pairs<float, N, 1>(p, s) : launch_pairs<float, N, 4>(p, s);
+}
+template <int N> static int ilp_agents_n(const ParticleParams &p, int w, hipStream_t s) {
+  return w == 1 ? launch_agents<float, N, 1>(p, s) : launch_agents<float, N, 4>(p, s);
+}
+int particle_ilp_launch_pairs_f32(const ParticleParams &p, int n_agents, int w, hipStream_t s) {
+  switch (n_agents) {
+    case 2: return ilp_pairs_n<2>(p, w, s);
+    case 3: return ilp_pairs_n<3>(p, w, s);
+    case 4: return ilp_pairs_n<4>(p, w, s);
+    case 5: return ilp_pairs_n<5>(p, w, s);
+    case 6: return ilp_pairs_n<6>(p, w, s);
+    case 7: return ilp_pairs_n<7>(p, w, s);
+    case 8: return ilp_pairs_n<8>(p, w, s);
+  }
+  return fail(CM3_ERR_INVALID, "n_agents %d unsupported", n_agents);
+}
+int particle_ilp_launch_agents_f32(const ParticleParams &p, int n_agents, int w, hipStream_t s) {
+  switch (n_agents) {
+    case 2: return ilp_agents_n<2>(p, w, s);
+    case 3: return ilp_agents_n<3>(p, w, s);
+    case 4: return ilp_agents_n<4>(p, w, s);
+    case 5: return ilp_agents_n<5>(p, w, s);
+    case 6: return ilp_agents_n<6>(p, w, s);
+    case 7: return ilp_agents_n<7>(p, w, s);
+    case 8: return ilp_agents_n<8>(p, w, s);
+  }
+  return fail(CM3_ERR_INVALID, "n_agents %d unsupported", n_agents);
+}
+}  // namespace cm3
+#define CM3_NO_ENTRY_POINTS 1
+#endif
 
 // The library compiles this file twice (build.sh): -DCM3_PARTICLE_F32 and -DCM3_PARTICLE_F64 each instantiate one
 // real type, which halves the wall-clock of the build.  Without either macro both are instantiated.
