@@ -13,11 +13,11 @@ pids+=($!)
 "${HIPCC}" ${FLAGS} -DCM3_PARTICLE_F64 -c "${HERE}/particle.hip" -o "${HERE}/_obj/particle_f64.o" &
 pids+=($!)
 # the two shared-env float32 step kernels once more, scheduled for instruction-level parallelism (see the head of particle.hip)
-"${HIPCC}" ${FLAGS} -mllvm -amdgpu-kernarg-preload-count=16 -mllvm -amdgpu-sched-strategy=max-ilp ${CM3_HOT_FLAGS:-} -DCM3_PARTICLE_F32 -DCM3_PARTICLE_ILP_TU \
+"${HIPCC}" ${FLAGS} -mllvm -amdgpu-kernarg-preload-count=16 -mllvm -amdgpu-sched-strategy=${CM3_HOT_SCHED:-max-ilp} ${CM3_HOT_FLAGS:-} -DCM3_PARTICLE_F32 -DCM3_PARTICLE_ILP_TU \
   -c "${HERE}/particle.hip" -o "${HERE}/_obj/particle_f32_ilp.o" &
 pids+=($!)
 # Checkers: max-ILP scheduling throughout (C3 4.26 -> 4.16 us per tick; 2^16 .. 2^20 envs within 1 %)
-"${HIPCC}" ${FLAGS} -mllvm -amdgpu-kernarg-preload-count=16 -mllvm -amdgpu-sched-strategy=max-ilp ${CM3_HOT_FLAGS:-} -c "${HERE}/checkers.hip" -o "${HERE}/_obj/checkers.o" &
+"${HIPCC}" ${FLAGS} -mllvm -amdgpu-kernarg-preload-count=16 -mllvm -amdgpu-sched-strategy=${CM3_HOT_SCHED:-max-ilp} ${CM3_HOT_FLAGS:-} -c "${HERE}/checkers.hip" -o "${HERE}/_obj/checkers.o" &
 pids+=($!)
 for f in util advantage actor actor_checkers policy; do
   "${HIPCC}" ${FLAGS} -c "${HERE}/${f}.hip" -o "${HERE}/_obj/${f}.o" &
