@@ -1451,8 +1451,11 @@ template <typename R, int N> static int launch_n(const ParticleParams &p, Partic
     //   N = 4: pair to 12288 (3.80 / 3.88 / 4.70), agent to 40960 (16384: 4.41 / 4.06 / 4.85; 49152: 9.0 / 6.40 / 6.30), then env
     //   N = 5, 6: agent from 8192 (N = 5: 4.31 / 4.23 / 6.41); N = 5 up to 40960, N = 6 up to 65536, then env
     //   N = 7, 8: agent from 6144 up, no upper bound (N = 7 at 2^20: - / 218 / 231)
-    constexpr size_t kPairMax = N == 2 ? 6144 : (N == 3 ? 24576 : (N == 4 ? 12288 : kPairsMaxEnvs));
-    constexpr size_t kAgentLo = N == 4 ? 12289 : (N == 5 || N == 6 ? 8192 : (N >= 7 ? 6144 : kInf));
+    // ... and once more on the final build (max-ILP pair / agent kernels; profiles/r02_mapping_sweep_final_build.txt):
+    //   N = 2: pair up to 32768 envs (16384: 2.57 / - / 2.68; 32768: 2.89 / - / 3.01); N = 6: agent from 6144 (4.27 / 4.11);
+    //   N = 7, 8: agent from 4096 (N = 8: 5.12 / 4.57, N = 7: 4.73 / 4.34; at 2048 pair: 3.83 / 4.29)
+    constexpr size_t kPairMax = N == 2 ? 32768 : (N == 3 ? 24576 : (N == 4 ? 12288 : kPairsMaxEnvs));
+    constexpr size_t kAgentLo = N == 4 ? 12289 : (N == 5 ? 8192 : (N == 6 ? 6144 : (N >= 7 ? 4096 : kInf)));
     constexpr size_t kAgentHi = N == 4 || N == 5 ? 40960 : (N == 6 ? 65536 : (N >= 7 ? kInf : 0));
     bool pairs = N >= 2 && (size_t)p.E <= kPairMax;
     bool agents = N >= 4 && (size_t)p.E >= kAgentLo && (size_t)p.E <= kAgentHi;
