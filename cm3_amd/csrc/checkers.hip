@@ -62,6 +62,7 @@ struct CheckersParams {
   int _pad2;
   size_t st_actions, st_grid, st_vec, st_obs_others, st_obs_self_t, st_obs_self_v, st_local, st_reward, st_done;
   size_t st_term_grid, st_term_vec, st_term_obs_others, st_term_obs_self_t, st_term_obs_self_v, st_goals_next;
+  CM3_SPAN_FIELD  // (span build only, common.h)
 };
 
 // the five observation arrays one emit writes (the trajectory slot of a tick, or the terminal-capture slot)
@@ -745,6 +746,7 @@ __global__ void __launch_bounds__(256)
     k_checkers_step_fast(const uint64_t *h_mask, const uint32_t *h_agents, const int32_t *h_steps, const int32_t *h_episode,
                          const uint8_t *h_goals, const int h_E, const uint32_t h_flags, const CheckersParams p) {
   using F = CkFast<N, G>;
+  CM3_SPAN_IN();
   CkHead hd;   // leading, preloaded kernel arguments (see CkHead)
   hd.mask = h_mask; hd.agents = h_agents; hd.steps = h_steps; hd.episode = h_episode; hd.goals = h_goals; hd.E = h_E; hd.flags = h_flags;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -784,6 +786,7 @@ __global__ void __launch_bounds__(256)
   }
   if (writer) ck_store_env<N>(p, e, s, lv);
   CM3_STAMP(9, true);
+  CM3_SPAN_OUT(p.span);
 }
 
 template <int N> __global__ void __launch_bounds__(256) k_checkers_reset_fast(const CheckersParams p) {
@@ -936,6 +939,7 @@ static int ck_fill(const cm3_checkers_desc *d, const cm3_checkers_bufs *b, const
   p.term_obs_self_v = b->term_obs_self_v;
   p.goals_next = b->goals_next;
   p.reset_mask = mask;
+  if (step) CM3_SPAN_SET(p);
   return CM3_OK;
 }
 

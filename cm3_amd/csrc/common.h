@@ -25,6 +25,38 @@ extern __device__ long long *cm3_stamp_buf;
   } while (0)
 #endif
 
+// Kernel-span instrumentation (build variant -DCM3_SPAN_STAMPS -> libcm3_hip_span.so; never defined in the product build):
+// exactly TWO time stamps per wave -- the first instruction of the wave and, after its last store has been acknowledged, its
+// last -- each the constant 100 MHz s_memrealtime counter plus the shader clock (s_memtime).  Lane 0 of every wave writes the
+// four values to record <wave index in the launch> of the launch's slot (cm3_span_config / cm3::span_next_slot, util.hip);
+// tools/kernel_span.py reduces them per launch to first-wave-in / last-wave-out (span) and start-to-start.  The entry stamps
+// stay in SGPRs until the exit store, so nothing waits for them on the way in.
+#ifdef CM3_SPAN_STAMPS
+namespace cm3 { long long *span_next_slot(); }
+#define CM3_SPAN_FIELD long long *span;
+#define CM3_SPAN_IN()                                                         \
+  const unsigned long long _span_rt0 = __builtin_amdgcn_s_memrealtime();     \
+  const unsigned long long _span_ck0 = __builtin_amdgcn_s_memtime();         \
+  __builtin_amdgcn_sched_barrier(0)
+#define CM3_SPAN_OUT(slot)                                                                                  \
+  do {                                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    __builtin_amdgcn_s_waitcnt(0);                                                                          \
+    const unsigned long long _rt1 = __builtin_amdgcn_s_memrealtime(), _ck1 = __builtin_amdgcn_s_memtime();  \
+    if ((slot) && (threadIdx.x & 63) == 0) {                                                                \
+      unsigned long long *_r = reinterpret_cast<unsigned long long *>(slot) +                               \
+                               ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 4;            \
+      _r[0] = _span_rt0; _r[1] = _span_ck0; _r[2] = _rt1; _r[3] = _ck1;                                      \
+    }                                                                                                       \
+  } while (0)
+#define CM3_SPAN_SET(p) (p).span = ::cm3::span_next_slot()
+#else
+#define CM3_SPAN_FIELD
+#define CM3_SPAN_IN() do { } while (0)
+#define CM3_SPAN_OUT(slot) do { } while (0)
+#define CM3_SPAN_SET(p) do { } while (0)
+#endif
+
 namespace cm3 {
 
 // Asks for kernel-argument fields NOW: fields first used late in a kernel are otherwise fetched right before that use, and the

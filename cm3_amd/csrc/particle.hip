@@ -33,7 +33,7 @@
 namespace cm3 {
 
 struct ParticleParams;
-// launchers of the max-ILP translation unit (float32 only): waves = 1 or 4 per workgroup; n_agents 2..8
+// launchers of the max-ILP translation unit (float32 only): waves = 1 or CM3_PAIR_WAVES / CM3_AGENT_WAVES per workgroup; n_agents 2..8
 int particle_ilp_launch_pairs_f32(const ParticleParams &p, int n_agents, int waves_per_wg, hipStream_t stream);
 int particle_ilp_launch_agents_f32(const ParticleParams &p, int n_agents, int waves_per_wg, hipStream_t stream);
 [[maybe_unused]] constexpr size_t kIlpMaxWaves = 16384;
@@ -71,6 +71,7 @@ struct ParticleParams {
   int n_ticks;
   int _pad2;
   size_t st_state, st_goals, st_obs, st_actions, st_reward_n, st_reward, st_done, st_term_state, st_term_obs, st_coll;
+  CM3_SPAN_FIELD  // (span build only, common.h: where this launch's per-wave time stamps go)
 };
 
 template <typename T> __device__ __forceinline__ T *tick_ptr(T *base, size_t stride, int t) {
@@ -462,6 +463,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step(const ParticlePara
   using G = ObsGeom<R, N>;
   __shared__ __attribute__((aligned(32))) R lds_all[WAVES][G::LDS_REALS];
 
+  CM3_SPAN_IN();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const size_t e0 = (size_t)p.E0 + ((size_t)blockIdx.x * WAVES + wave) * 64;
   const size_t e = e0 + lane;
@@ -646,6 +648,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step(const ParticlePara
     if (episode != episode_in) p.episode[e] = (int32_t)episode;
   }
   CM3_STAMP(6, true);
+  CM3_SPAN_OUT(p.span);
 }
 
 // ---- the step kernel, second mapping: ONE LANE PER ORDERED AGENT PAIR -------------------------------------
@@ -700,6 +703,7 @@ __global__ void __launch_bounds__(WAVES * 64)
   using PG = PairGeom<N>;
   constexpr int NO = PG::NO, SLOTS = PG::SLOTS, G = PG::G, EPW = PG::EPW, LA = PG::LA;
   static_assert(PairGeom<N>::pow2ceil(SLOTS) == G, "the padded lane layout must not change the group size");
+  CM3_SPAN_IN();
 
   const int lane = threadIdx.x & 63, wave_all = threadIdx.x >> 6;
   const int wave = wave_all;
@@ -902,6 +906,7 @@ __global__ void __launch_bounds__(WAVES * 64)
     if (episode != episode_in) *at32<int32_t>(p.episode, e * 4u) = (int32_t)episode;
   }
   CM3_STAMP(8, true);
+  CM3_SPAN_OUT(p.span);
 }
 
 // ---- the step kernel, third mapping: ONE LANE PER AGENT -----------------------------------------------------
@@ -936,6 +941,7 @@ __global__ void __launch_bounds__(WAVES * 64)
   using AG = AgentGeom<N>;
   constexpr int NO = AG::NO, G = AG::G, EPW = AG::EPW, VPE = AG::VPE;
   __shared__ __attribute__((aligned(32))) R lds_all[WAVES][EPW * VPE * 4];
+  CM3_SPAN_IN();
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int gi = lane & (G - 1), sub = lane / G, base = lane - gi;
@@ -1195,6 +1201,7 @@ __global__ void __launch_bounds__(WAVES * 64)
     if (episode != episode_in) *at32<int32_t>(p.episode, e * 4u) = (int32_t)episode;
   }
   CM3_STAMP(8, true);
+  CM3_SPAN_OUT(p.span);
 }
 
 // ---- reset kernel (environment.py:125-149) ------------------------------------------------------------
@@ -1323,6 +1330,7 @@ static int fill_params(const cm3_particle_desc *d, const cm3_particle_bufs *b, P
   p.collisions_tick = b->collisions_tick;
   p.state_copy = p.goals_copy = nullptr;
   p.reset_mask = mask;
+  if (op == kStep) CM3_SPAN_SET(p);
   return CM3_OK;
 }
 
@@ -1468,8 +1476,8 @@ template <typename R, int N> static int launch_n(const ParticleParams &p, Partic
     if (agents) {
       const size_t waves = ((size_t)p.E + AgentGeom<(N >= 2 ? N : 2)>::EPW - 1) / AgentGeom<(N >= 2 ? N : 2)>::EPW;
 #ifndef CM3_PARTICLE_ILP_TU
-      if constexpr (sizeof(R) == 4 && N >= 2 && CM3_AGENT_WAVES == 4)
-        if (waves <= kIlpMaxWaves) return particle_ilp_launch_agents_f32(p, N, waves < 256 ? 1 : 4, stream);
+      if constexpr (sizeof(R) == 4 && N >= 2)
+        if (waves <= kIlpMaxWaves) return particle_ilp_launch_agents_f32(p, N, waves < 256 ? 1 : CM3_AGENT_WAVES, stream);
 #endif
       if (waves < 256) return launch_agents<R, N, 1>(p, stream);
       return launch_agents<R, N, CM3_AGENT_WAVES>(p, stream);
@@ -1480,8 +1488,8 @@ template <typename R, int N> static int launch_n(const ParticleParams &p, Partic
       // below 256 waves single-wave workgroups spread the work over more CUs.
       const size_t waves = ((size_t)p.E + PairGeom<(N >= 2 ? N : 2)>::EPW - 1) / PairGeom<(N >= 2 ? N : 2)>::EPW;
 #ifndef CM3_PARTICLE_ILP_TU
-      if constexpr (sizeof(R) == 4 && N >= 2 && CM3_PAIR_WAVES == 4)
-        if (waves <= kIlpMaxWaves) return particle_ilp_launch_pairs_f32(p, N, waves < 256 ? 1 : 4, stream);
+      if constexpr (sizeof(R) == 4 && N >= 2)
+        if (waves <= kIlpMaxWaves) return particle_ilp_launch_pairs_f32(p, N, waves < 256 ? 1 : CM3_PAIR_WAVES, stream);
 #endif
       if (waves < 256) return launch_pairs<R, N, 1>(p, stream);
       return launch_pairs<R, N, CM3_PAIR_WAVES>(p, stream);
@@ -1659,10 +1667,10 @@ static int particle_rollout_chains(const cm3_particle_desc *d, const cm3_particl
 #ifdef CM3_PARTICLE_ILP_TU
 namespace cm3 {
 template <int N> static int ilp_pairs_n(const ParticleParams &p, int w, hipStream_t s) {
-  return w == 1 ? launch_pairs<float, N, 1>(p, s) : launch_pairs<float, N, 4>(p, s);
+  return w == 1 ? launch_pairs<float, N, 1>(p, s) : launch_pairs<float, N, CM3_PAIR_WAVES>(p, s);
 }
 template <int N> static int ilp_agents_n(const ParticleParams &p, int w, hipStream_t s) {
-  return w == 1 ? launch_agents<float, N, 1>(p, s) : launch_agents<float, N, 4>(p, s);
+  return w == 1 ? launch_agents<float, N, 1>(p, s) : launch_agents<float, N, CM3_AGENT_WAVES>(p, s);
 }
 int particle_ilp_launch_pairs_f32(const ParticleParams &p, int n_agents, int w, hipStream_t s) {
   switch (n_agents) {

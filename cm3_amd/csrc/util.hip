@@ -18,6 +18,19 @@ int fail(int code, const char *fmt, ...) {
   return code;
 }
 
+#ifdef CM3_SPAN_STAMPS
+// Kernel-span stamps (common.h): launches take consecutive slots of a caller-provided device buffer, in enqueue order (a
+// captured graph node keeps the slot it was given at capture time, so a replay overwrites the same slots).
+static long long *g_span_base = nullptr;
+static int64_t g_span_slots = 0, g_span_slot_bytes = 0, g_span_next = 0;
+long long *span_next_slot() {
+  if (!g_span_base || g_span_slots <= 0) return nullptr;
+  long long *r = reinterpret_cast<long long *>(reinterpret_cast<char *>(g_span_base) + (g_span_next % g_span_slots) * g_span_slot_bytes);
+  ++g_span_next;
+  return r;
+}
+#endif
+
 // ---- streaming read / copy probes: the measured roofline denominator ---------------
 // Grid-stride 16-byte loads, U independent loads in flight per lane per iteration (all issued before the XOR fold
 // consumes them); NT selects non-temporal loads (the stream is read once: no reason to keep it in L2 / MALL).  One
@@ -109,8 +122,16 @@ template <int U> static void launch_copy(bool nt, int grid, hipStream_t s, uint4
 // Launch-structure floor of a step launch: the same grid reads `n_read` 16-byte vectors (all loads first), then writes
 // `n_write` vectors whose value depends on everything it read -- load -> (no arithmetic) -> store, nothing else.  What a
 // one-launch-per-tick kernel with this traffic cannot go below.
+#ifdef CM3_SPAN_STAMPS
+#define CM3_FLOOR_SPAN_PARAM , long long *span
+#define CM3_FLOOR_SPAN_ARG , ::cm3::span_next_slot()
+#else
+#define CM3_FLOOR_SPAN_PARAM
+#define CM3_FLOOR_SPAN_ARG
+#endif
 __global__ void __launch_bounds__(1024) k_traffic_floor(const uint4 *__restrict__ src, size_t n_read, uint4 *__restrict__ dst,
-                                                        size_t n_write) {
+                                                        size_t n_write CM3_FLOOR_SPAN_PARAM) {
+  CM3_SPAN_IN();
   const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, total = (size_t)gridDim.x * blockDim.x;
   uint4 acc = make_uint4(0u, 0u, 0u, 0u);
   for (size_t i = gid; i < n_read; i += total) {
@@ -121,6 +142,7 @@ __global__ void __launch_bounds__(1024) k_traffic_floor(const uint4 *__restrict_
     acc.w ^= v.w;
   }
   for (size_t i = gid; i < n_write; i += total) dst[i] = acc;
+  CM3_SPAN_OUT(span);
 }
 }  // namespace cm3
 
@@ -148,6 +170,19 @@ int cm3_device_name(int dev, char *name, int len) {
   return CM3_OK;
 }
 
+#ifdef CM3_SPAN_STAMPS
+// (span build only; not part of the product ABI)  buf: n_slots x slot_bytes device bytes, slot_bytes >= 32 x waves per launch;
+// NULL switches the stamps off.  Resets the slot counter.  Returns the number of slots handed out before the call.
+int64_t cm3_span_config(void *buf, int64_t n_slots, int64_t slot_bytes) {
+  const int64_t used = cm3::g_span_next;
+  cm3::g_span_base = (long long *)buf;
+  cm3::g_span_slots = n_slots;
+  cm3::g_span_slot_bytes = slot_bytes;
+  cm3::g_span_next = 0;
+  return used;
+}
+#endif
+
 int cm3_hbm_bench_sink_words(void) { return cm3::kBenchMaxGrid; }
 
 int cm3_traffic_floor_bench(const void *src, size_t read_bytes, void *dst, size_t write_bytes, int32_t blocks,
@@ -156,7 +191,7 @@ int cm3_traffic_floor_bench(const void *src, size_t read_bytes, void *dst, size_
   CM3_REQUIRE(read_bytes % 16 == 0 && write_bytes % 16 == 0, "byte counts must be multiples of 16");
   CM3_REQUIRE(blocks >= 1 && threads >= 64 && threads <= 1024 && threads % 64 == 0, "bad launch shape");
   hipLaunchKernelGGL(cm3::k_traffic_floor, dim3((unsigned)blocks), dim3((unsigned)threads), 0, (hipStream_t)stream,
-                     (const uint4 *)src, read_bytes / 16, (uint4 *)dst, write_bytes / 16);
+                     (const uint4 *)src, read_bytes / 16, (uint4 *)dst, write_bytes / 16 CM3_FLOOR_SPAN_ARG);
   CM3_HIP_CHECK(hipGetLastError());
   return CM3_OK;
 }
