@@ -738,6 +738,221 @@ __device__ __forceinline__ void ckf_emit(const CheckersParams &p, const CkState<
   }
 }
 
+// ---- table-driven observation emit of the step kernel (round 3) ------------------------------------------------------------
+// The emit above evaluates every window cell from scratch (~45 instructions per cell) and needs ~185 lane-geometry instructions
+// (which cell, which agent, which row) that the compiler placed AFTER the tick: at one wave per SIMD every one of them is ~4.5
+// cycles of the launch.  What those instructions compute does not depend on the state:
+//   * the STATIC content of an expanded board cell (rr, cc) -- wall byte, colour channel, which bit of the collected mask it
+//     shows -- is a constant of the geometry: one dword per cell of the 7 x 16 padded board (CkBoardTab::board);
+//   * the twelve-or-so normalised float64 values of an env are (r - 3.5) / 7, (c - 6.5) / 13 or n / 12 with r in 0..6, c in
+//     0..12, n in 0..12: 33 possible doubles (CkBoardTab::norm; constexpr IEEE divisions = the device's IEEE divisions);
+//   * which cells / grid dword / value a LANE produces is a function of its lane index: per-N plan tables (CkPlanTab<N>).
+// All three are compile-time constants in device memory.  A wave copies the 720-byte board / norm table into a private LDS region
+// and loads its lanes' plan entries while the state loads are in flight (nothing of it waits on the critical path); after the
+// tick a window cell is  e = board[agent base + plan offset];  cell = e ^ (e & 0xfefe & -collected(e >> 24)) | agent byte
+// (~13 instructions), four cells become three dwords with three byte permutes, a normalised value is one LDS read.
+// Bit-exact by construction (same values), checked by the same tests as the emit above (which the reset kernel keeps using).
+struct CkBoardTab {
+  uint32_t board[7 * 16];  // entry of board cell (rr, cc) at [rr * 16 + cc]: ch0 | ch1 << 8 | ch2 << 16 | bit index << 24
+  double norm[34];         // [0..6] row, [7..19] column, [20..32] count
+  constexpr CkBoardTab() : board{}, norm{} {
+    for (int rr = 0; rr < 7; ++rr)
+      for (int cc = 0; cc < 16; ++cc) {
+        const int kk = rr - 2, jj = cc - 2;
+        const bool band_row = kk >= 0 && kk < 3;
+        const bool inband = band_row && jj >= 0 && jj < 8, valid = band_row && jj >= 0 && jj < 9;
+        uint32_t e = 0;
+        if (inband) e |= 0xffu << (8 * ((kk + jj) & 1));  // -1: still there (the collected bit flips it to +1)
+        if (!valid) e |= 1u << 16;                        // wall
+        e |= (uint32_t)(inband ? kk * 8 + jj : 31) << 24;  // bit 31 of the 24-bit mask is never set
+        board[rr * 16 + cc] = e;
+      }
+    for (int r = 0; r < 7; ++r) norm[r] = ((double)r - 7.0 / 2.0) / 7.0;
+    for (int c = 0; c < 13; ++c) norm[7 + c] = ((double)c - 13.0 / 2.0) / 13.0;
+    for (int n = 0; n < 13; ++n) norm[20 + n] = ((double)n - 0.0) / (24.0 / 2.0);
+  }
+};
+static_assert(sizeof(CkBoardTab) == 720, "the kernel stages 45 x 16 bytes");
+__device__ const CkBoardTab kCkBoardTab = CkBoardTab();
+
+template <int N> struct CkPlanTab {
+  static constexpr int NO = N > 1 ? N - 1 : 1;
+  static constexpr int KK = 25, OD = (75 * N + 3) / 4, NQ = (OD + 2) / 3, NCELL = 4 * NQ;
+  static constexpr int NSV = 4 * N, NOO = 2 * N * NO, NV = NSV + NOO, GD = 14;
+  uint32_t cell[NCELL][4];  // window cell cg: {board byte offset from the agent's cell, packed (row, column) offset, agent byte mask, agent | invalid << 31}
+  uint32_t grid[16][4];     // grid dword d: {static dword, bit index of cell 2d, of cell 2d + 1, 0}
+  uint32_t val[NV][4];      // value v: {norm index of number 0, agent, bit offset of the number in the agent word, byte offset | others << 31}
+  constexpr CkPlanTab() : cell{}, grid{}, val{} {
+    for (int cg = 0; cg < NCELL; ++cg) {
+      const bool ok = cg < KK * N;
+      const int i = ok ? cg / KK : 0, c = ok ? cg - KK * i : 12;
+      const int dr = c / 5 - 2, dc = c % 5 - 2;
+      cell[cg][0] = (uint32_t)((dr * 16 + dc) * 4);
+      cell[cg][1] = (uint32_t)(dr + dc * 256);
+      cell[cg][2] = (ok && c != 12) ? 0xff0000u : 0u;  // the agent's own (centre) cell is valid (checkers.py:105-107)
+      cell[cg][3] = (uint32_t)i | (ok ? 0u : 0x80000000u);
+    }
+    for (int d = 0; d < 16; ++d) {
+      uint32_t w = 0, b[2] = {31, 31};
+      for (int h = 0; h < 2; ++h) {
+        const int cl = 2 * d + h;
+        if (cl < 27) {
+          const int k = cl / 9, j = cl - 9 * k;
+          if (j < 8) {
+            w |= 0xffu << (16 * h + 8 * ((k + j) & 1));
+            b[h] = (uint32_t)(k * 8 + j);
+          }
+        }
+      }
+      grid[d][0] = w;
+      grid[d][1] = b[0];
+      grid[d][2] = b[1];
+    }
+    for (int v = 0; v < NV; ++v) {
+      const bool others = v >= NSV;
+      const int w = others ? v - NSV : v;
+      int a = 0, comp = 0;
+      if (others) {
+        const int i = w / (2 * NO), k = (w - i * 2 * NO) >> 1;
+        a = (N > 1) ? (k < i ? k : k + 1) : 0;
+        comp = w & 1;
+      } else {
+        a = w >> 2;
+        comp = w & 3;
+      }
+      val[v][0] = comp == 0 ? 0u : (comp == 1 ? 7u : 20u);
+      val[v][1] = (uint32_t)a;
+      val[v][2] = (uint32_t)(8 * comp);
+      val[v][3] = (uint32_t)(w * 8) | (others ? 0x80000000u : 0u);
+    }
+  }
+};
+template <int N> __device__ const CkPlanTab<N> kCkPlanTab = CkPlanTab<N>();
+
+// what a lane produces (registers; loaded once per launch while the state loads are in flight)
+template <int N, int G> struct CkLanePlan {
+  using T = CkPlanTab<N>;
+  static constexpr int NSLOT = (T::NQ + G - 1) / G, NGRID = (T::GD + G - 1) / G, NVAL = (T::NV + G - 1) / G;
+  uint4 cell[NSLOT][4];
+  uint4 grid[NGRID];
+  uint4 val[NVAL];
+};
+
+template <int N, int G> __device__ __forceinline__ void ckf_plan_load(int g, CkLanePlan<N, G> &pl) {
+  using T = CkPlanTab<N>;
+  using P = CkLanePlan<N, G>;
+  const CkPlanTab<N> *tab = &kCkPlanTab<N>;
+#pragma unroll
+  for (int it = 0; it < P::NSLOT; ++it) {
+    const int q = it * G + g, qc = q < T::NQ ? q : T::NQ - 1;
+#pragma unroll
+    for (int x = 0; x < 4; ++x) pl.cell[it][x] = *reinterpret_cast<const uint4 *>(&tab->cell[4 * qc + x][0]);
+  }
+#pragma unroll
+  for (int it = 0; it < P::NGRID; ++it) pl.grid[it] = *reinterpret_cast<const uint4 *>(&tab->grid[(it * G + g) & 15][0]);
+#pragma unroll
+  for (int it = 0; it < P::NVAL; ++it) {
+    const int v = it * G + g;
+    pl.val[it] = *reinterpret_cast<const uint4 *>(&tab->val[v < T::NV ? v : T::NV - 1][0]);
+  }
+}
+
+// the wave's private copy of kCkBoardTab in LDS (45 x 16 bytes), written by lanes 0..44
+__device__ __forceinline__ void ckf_stage_board(uint4 *lds_tab, int lane) {
+  const uint4 *src = reinterpret_cast<const uint4 *>(&kCkBoardTab);
+  const uint4 t = src[lane < 45 ? lane : 44];
+  if (lane < 45) lds_tab[lane] = t;
+}
+
+template <int N, bool NT = false, int G = kCkG>
+__device__ __forceinline__ void ckf_emit_tab(const CheckersParams &p, const CkState<N> &s, const CkLanePlan<N, G> &pl,
+                                             const uint4 *lds_tab, int g, uint32_t e, bool env_ok, const CkOut &out) {
+  using T = CkPlanTab<N>;
+  using P = CkLanePlan<N, G>;
+  if (!env_ok) return;
+  const char *tab = reinterpret_cast<const char *>(lds_tab);
+  const uint32_t m32 = (uint32_t)s.mask;  // 24 collected bits
+  uint32_t rc[N], base[N], word[N];
+#pragma unroll
+  for (int a = 0; a < N; ++a) {
+    rc[a] = (uint32_t)s.r[a] | ((uint32_t)s.c[a] << 8);
+    base[a] = (uint32_t)s.r[a] * 64u + (uint32_t)s.c[a] * 4u;
+    word[a] = rc[a] | ((uint32_t)s.ng[a] << 16) | ((uint32_t)s.no[a] << 24);
+  }
+  // ---- obs_self_t: lane q takes window cells 4q .. 4q + 3 = three whole dwords ------------------------------------------------
+  const uint32_t orow = e * (uint32_t)p.obst_stride;
+#pragma unroll
+  for (int it = 0; it < P::NSLOT; ++it) {
+    const int q = it * G + g;
+    uint32_t c[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      const uint4 pc = pl.cell[it][x];
+      const uint32_t ia = pc.w & 0xffu;
+      uint32_t b = base[0], r0 = rc[0];
+#pragma unroll
+      for (int a = 1; a < N; ++a) {
+        b = (ia == (uint32_t)a) ? base[a] : b;
+        r0 = (ia == (uint32_t)a) ? rc[a] : r0;
+      }
+      const uint32_t ent = *reinterpret_cast<const uint32_t *>(tab + (b + pc.x));
+      const uint32_t rcx = r0 + pc.y;
+      bool agent = false;
+#pragma unroll
+      for (int a = 0; a < N; ++a) agent = agent | (rc[a] == rcx);
+      const uint32_t got = (uint32_t)__builtin_amdgcn_sbfe((int)m32, ent >> 24, 1);  // 0 / ~0: the cell's collected bit
+      uint32_t v = (ent ^ (ent & got & 0xfefeu)) | (agent ? pc.z : 0u);
+      if ((it + 1) * G * 4 > T::KK * N) v = ((int)pc.w < 0) ? 0u : v;  // (compile time: only the slots that can hold padding cells)
+      c[x] = v;
+    }
+    if (q < T::NQ) {
+      // bytes: c0[0..2] c1[0..2] c2[0..2] c3[0..2] -> three dwords (v_perm_b32: selector byte k picks byte k of {hi, lo})
+      const uint32_t d0 = __builtin_amdgcn_perm(c[1], c[0], 0x04020100u);
+      const uint32_t d1 = __builtin_amdgcn_perm(c[2], c[1], 0x05040201u);
+      const uint32_t d2 = __builtin_amdgcn_perm(c[3], c[2], 0x06050402u);
+      uint32_t *dst = at32<uint32_t>(out.obs_self_t, orow + 12u * q);
+      ck_st<NT>(dst, d0);
+      if (3 * q + 1 < T::OD) ck_st<NT>(dst + 1, d1);
+      if (3 * q + 2 < T::OD) ck_st<NT>(dst + 2, d2);
+    }
+  }
+  // ---- grid: dword d = cells 2d, 2d + 1 of get_valid_grid (checkers.py:66-76) --------------------------------------------------
+  const uint32_t grow = e * (uint32_t)p.grid_stride;
+#pragma unroll
+  for (int it = 0; it < P::NGRID; ++it) {
+    const int d = it * G + g;
+    const uint4 pg = pl.grid[it];
+    const uint32_t g0 = (uint32_t)__builtin_amdgcn_sbfe((int)m32, pg.y, 1), g1 = (uint32_t)__builtin_amdgcn_sbfe((int)m32, pg.z, 1);
+    const uint32_t w = pg.x ^ (pg.x & g0 & 0x0000fefeu) ^ (pg.x & g1 & 0xfefe0000u);
+    if (d < T::GD) ck_st<NT>(at32<uint32_t>(out.grid, grow + 4u * d), w);
+  }
+  // ---- vec ------------------------------------------------------------------------------------------------------------------
+  if (g < N) {
+    uint32_t wa = word[0];
+#pragma unroll
+    for (int a = 1; a < N; ++a) wa = (g == a) ? word[a] : wa;
+    int4 v;
+    v.x = (int)(wa & 0xffu); v.y = (int)((wa >> 8) & 0xffu); v.z = (int)((wa >> 16) & 0xffu); v.w = (int)(wa >> 24);
+    ck_st<NT>(at32<int4>(out.vec, (e * N + g) * 16u), v);
+  }
+  // ---- obs_self_v, obs_others: one table read per value ---------------------------------------------------------------------
+#pragma unroll
+  for (int it = 0; it < P::NVAL; ++it) {
+    const int v = it * G + g;
+    const uint4 pv = pl.val[it];
+    uint32_t wa = word[0];
+#pragma unroll
+    for (int a = 1; a < N; ++a) wa = (pv.y == (uint32_t)a) ? word[a] : wa;
+    const uint32_t num = (wa >> pv.z) & 0xffu;
+    const double val = *reinterpret_cast<const double *>(tab + 448u + 8u * (pv.x + num));
+    if (v < T::NV) {
+      const uint32_t off = pv.w & 0x7fffffffu;
+      if ((int)pv.w < 0) ck_st<NT>(at32<double>(out.obs_others, e * (uint32_t)(T::NOO * 8) + off), val);
+      else ck_st<NT>(at32<double>(out.obs_self_v, e * (uint32_t)(T::NSV * 8) + off), val);
+    }
+  }
+}
+
 // (Round 1 added a fifth "draw wave" per workgroup that drew the next launch's actions, as in the particle pair mapping: 5.08 ->
 // 4.96 us per tick at C3 then.  Re-measured in round 2 (profiles/r02_draw_wave_on_off.txt) it had become a loss -- stage 2: 4.99 ->
 // 4.88 us, stage 1: 4.19 -> 3.98 us without it -- and was removed together with the particle one.)
@@ -759,8 +974,15 @@ __global__ void __launch_bounds__(256)
   const bool writer = env_ok && g == 0;
   CkState<N> s;
   CkLive<N> lv;
+  __shared__ __attribute__((aligned(16))) uint4 lds_tab_all[4][45];
+  uint4 *lds_tab = &lds_tab_all[wave][0];
   CM3_STAMP(0, false);
   ck_load_env<N>(hd, ec, s, lv);
+  // while those loads are in flight: the wave's copy of the board / norm table and this lane's plan (see ckf_emit_tab)
+  ckf_stage_board(lds_tab, lane);
+  CkLanePlan<N, G> pl;
+  ckf_plan_load<N, G>(g, pl);
+  ck_wave_sync();
   // the kernel arguments the tick needs, requested while the state loads are in flight (fetched at their first use they made
   // the wave wait for a scalar load six times along its critical path)
   CM3_FETCH_EARLY(p.actions, p.local_rewards, p.reward, p.done, p.grid, p.vec, p.obs_others, p.obs_self_t, p.obs_self_v,
@@ -773,10 +995,10 @@ __global__ void __launch_bounds__(256)
     const bool ended = ck_tick_env<N, true>(p, t, e, ec, writer, s, lv);
     CM3_STAMP(4, false);
     if (ended) {  // AUTO_RESET: terminal observation (train_onpolicy.py:336-347), then the fresh episode
-      if (p.term_grid) ckf_emit<N, NT, G>(p, s, g, e, env_ok, ck_out_term(p, t));
+      if (p.term_grid) ckf_emit_tab<N, NT, G>(p, s, pl, lds_tab, g, e, env_ok, ck_out_term(p, t));
       ck_restart_env<N>(p, e, ec, writer, s, lv);
     }
-    ckf_emit<N, NT, G>(p, s, g, e, env_ok, ck_out_tick(p, t));
+    ckf_emit_tab<N, NT, G>(p, s, pl, lds_tab, g, e, env_ok, ck_out_tick(p, t));
     CM3_STAMP(8, false);
     if (p.goals_next && writer) {
       uint8_t *gn = ck_tick_ptr(p.goals_next, p.st_goals_next, t);

@@ -191,22 +191,37 @@ template <typename R, typename V4> __device__ __forceinline__ V4 sub4(const V4 &
 // time: that alone cost 1-3 % on every kernel that carried it -- profiles/r02_base_vs_new_runtime_flavours.txt -- and the
 // write-through flavours it also offered bought nothing, profiles/r02_store_policy_ab.txt.)
 constexpr uint32_t kFlagObsStoreNt = 0x100000u;  // internal launch flag, set by particle_rollout only
+constexpr size_t kWtMinObsBytes = (size_t)3 << 20;  // observation bytes per launch from which the rows are written through (kSpWt)
 
 typedef float cm3_f4 __attribute__((ext_vector_type(4)));
-template <bool NT> __device__ __forceinline__ void store_obs_vec(float4 *p, const float4 &v) {
-  if constexpr (NT) {
+// Store policy of the observation rows, a COMPILE-TIME parameter of the step kernels (kSpPlain kernels are byte for byte the code
+// without this feature):
+//   kSpPlain  ordinary stores
+//   kSpNt     non-temporal hint: the rollout's observation slots are a STREAM (>= 128 MB, obs_store_nt); C2 trajectory 3.97 -> 3.53 us
+//   kSpWt     write-through + non-temporal ("sc1 nt"): round 3, for launches that write >= kWtMinObsBytes of observation rows.  A
+//             kernel boundary writes back every line the launch left dirty in the XCD L2s (the gap between two launches grows from
+//             1.2 us to 2.1 us behind C5's 10.6 MB: profiles/r03_kernel_span_first_record.txt); written through, the rows leave
+//             during the launch instead.  Measured (profiles/r03_obs_store_write_through.txt, same box, in place): N = 8 at 8192
+//             envs 5.01 -> 4.48 us, 16 384 envs 6.97 -> 5.87; N = 4 at 65 536 envs 6.33 -> 5.76, 262 144 envs 17.9 -> 15.9, 2^22
+//             envs 337 -> 305; and a LOSS where a launch writes little (C2: 0.8 MB, 2.55 -> 2.93 us) or in 4-byte pieces (Checkers).
+constexpr int kSpPlain = 0, kSpNt = 1, kSpWt = 2;
+template <int SP> __device__ __forceinline__ void store_obs_vec(float4 *p, const float4 &v) {
+  if constexpr (SP == kSpWt) {
+    const cm3_f4 t = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
+  } else if constexpr (SP == kSpNt) {
     const cm3_f4 t = {v.x, v.y, v.z, v.w};
     __builtin_nontemporal_store(t, reinterpret_cast<cm3_f4 *>(p));
   } else {
     *p = v;
   }
 }
-template <bool NT> __device__ __forceinline__ void store_obs_vec(double4 *p, const double4 &v) { *p = v; }
+template <int SP> __device__ __forceinline__ void store_obs_vec(double4 *p, const double4 &v) { *p = v; }
 // The per-agent 4-byte outputs (actions, reward_n) of the lane-per-agent mapping: a wave writes 256 contiguous bytes = whole
 // lines of them per instruction, so on the non-temporal path they take the hint too (C5 trajectory 5.56 -> 5.48 us per tick, same
 // box; the per-ENV outputs are partial lines per instruction and lose with it: profiles/r02_small_outputs_nt_store.txt)
-template <bool NT, typename T> __device__ __forceinline__ void store_small(T *p, T v) {
-  if constexpr (NT && sizeof(T) == 4) __builtin_nontemporal_store(v, p); else *p = v;
+template <int SP, typename T> __device__ __forceinline__ void store_small(T *p, T v) {
+  if constexpr (SP == kSpNt && sizeof(T) == 4) __builtin_nontemporal_store(v, p); else *p = v;
 }
 
 // np.sum(reward_n) as NumPy reduces a contiguous float64 vector (environment.py:107): left to right for
@@ -299,7 +314,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 
 // s[i] = (vx, vy, px, py) of agent i.  Row i of obs_others = concat_{j != i, ascending}(s[j] - s[i]).
-template <typename R, int N, bool NT = false>
+template <typename R, int N, int SP = kSpPlain>
 __device__ __forceinline__ void store_obs_others_staged(const typename Vec<R>::v4 (&s)[N], R *lds, int lane,
                                                         size_t e0, int E, R *out) {
   using V4 = typename Vec<R>::v4;
@@ -327,7 +342,7 @@ __device__ __forceinline__ void store_obs_others_staged(const typename Vec<R>::v
     V4 *out4 = reinterpret_cast<V4 *>(out + row0 * G::REC);
     for (int f = lane; f < nvec; f += 64) {
       const int row = f / VPR, q = f - row * VPR;
-      store_obs_vec<NT>(out4 + f, lds4[(row * G::STRIDE) / 4 + q]);
+      store_obs_vec<SP>(out4 + f, lds4[(row * G::STRIDE) / 4 + q]);
     }
     wave_lds_sync();
   }
@@ -456,7 +471,7 @@ __device__ __forceinline__ const double *preset_table(size_t kernel_arg_offset =
 }
 
 // ---- the step kernel --------------------------------------------------------------------------------
-template <typename R, int N, int WAVES, bool FUSED, bool NT = false>
+template <typename R, int N, int WAVES, bool FUSED, int SP = kSpPlain>
 __global__ void __launch_bounds__(WAVES * 64) k_particle_step(const ParticleParams p) {
   using V4 = typename Vec<R>::v4;
   using V2 = typename Vec<R>::v2;
@@ -626,7 +641,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step(const ParticlePara
       }
       if (p.state_copy) {  // live-state rollout: the trajectory slot gets a copy (write-only stream)
 #pragma unroll
-        for (int i = 0; i < N; ++i) store_obs_vec<NT>(reinterpret_cast<V4 *>(p.state_copy) + ((size_t)i * E + e), s[i]);
+        for (int i = 0; i < N; ++i) store_obs_vec<SP>(reinterpret_cast<V4 *>(p.state_copy) + ((size_t)i * E + e), s[i]);
 #pragma unroll
         for (int i = 0; i < N; ++i) reinterpret_cast<V2 *>(p.goals_copy)[(size_t)i * E + e] = g[i];
       }
@@ -634,7 +649,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step(const ParticlePara
 
     CM3_STAMP(4, false);
     // ---- observation (multi-goal_spread.py:145-154), env-major rows through the wave's LDS tile --------
-    store_obs_others_staged<R, N, NT>(s, &lds_all[wave][0], lane, e0, p.EN,
+    store_obs_others_staged<R, N, SP>(s, &lds_all[wave][0], lane, e0, p.EN,
                                       reinterpret_cast<R *>(tick_ptr(p.obs_others, p.st_obs, t)));
     CM3_STAMP(5, false);
   }
@@ -684,7 +699,7 @@ template <int N> struct PairGeom {
 // (profiles/r02_draw_wave_on_off.txt) it had become a loss in every configuration that used it -- in place 0-6 %, trajectory mode
 // 5-10 % -- and was removed: a fifth wave, two workgroup barriers and an extra store + reload of the action row cost more than the
 // Philox chain they hid once the square roots had left the physics chain.)
-template <typename R, int N, int WAVES, bool FUSED, bool NT = false, bool LIVE = false, int TU = CM3_PARTICLE_TU>
+template <typename R, int N, int WAVES, bool FUSED, int SP = kSpPlain, bool LIVE = false, int TU = CM3_PARTICLE_TU>
 __global__ void __launch_bounds__(WAVES * 64)
     k_particle_step_pairs(const void *h_state_in, const void *h_goals_in, const int32_t *h_meta_in, const int32_t *h_episode,
                           const int h_E, const uint32_t h_flags, const int h_E0, const int h_EN, const int h_max_steps,
@@ -886,13 +901,13 @@ __global__ void __launch_bounds__(WAVES * 64)
         if (p.goals_out != p.goals_in || was_reset)
           *at32<V2>(tick_ptr(p.goals_out, p.st_goals, t), (row_i + e) * (uint32_t)sizeof(V2)) = gl;
         if constexpr (LIVE) {  // live-state rollout (a compile-time variant: the others carry none of it): the slot gets a copy
-          store_obs_vec<NT>(at32<V4>(p.state_copy, (row_i + e) * (uint32_t)sizeof(V4)), si);
+          store_obs_vec<SP>(at32<V4>(p.state_copy, (row_i + e) * (uint32_t)sizeof(V4)), si);
           *at32<V2>(p.goals_copy, (row_i + e) * (uint32_t)sizeof(V2)) = gl;
         }
       }
       // observation (multi-goal_spread.py:145-154): vector (i,k) of env e; lanes of a wave cover whole records
       if (slot_ok)
-        store_obs_vec<NT>(at32<V4>(tick_ptr(p.obs_others, p.st_obs, t), (e * SLOTS + vslot) * (uint32_t)sizeof(V4)), sub4<R, V4>(sj, si));
+        store_obs_vec<SP>(at32<V4>(tick_ptr(p.obs_others, p.st_obs, t), (e * SLOTS + vslot) * (uint32_t)sizeof(V4)), sub4<R, V4>(sj, si));
     }
   }
 
@@ -926,7 +941,7 @@ template <int N> struct AgentGeom {
   static constexpr int VPE = N * NO;        // obs vectors per env record
 };
 
-template <typename R, int N, int WAVES, bool FUSED, bool NT = false, bool LIVE = false, int TU = CM3_PARTICLE_TU>
+template <typename R, int N, int WAVES, bool FUSED, int SP = kSpPlain, bool LIVE = false, int TU = CM3_PARTICLE_TU>
 __global__ void __launch_bounds__(WAVES * 64)
     k_particle_step_agents(const void *h_state_in, const void *h_goals_in, const int32_t *h_meta_in, const int32_t *h_episode,
                            const int h_E, const uint32_t h_flags, const int h_E0, const int h_EN, const int h_max_steps,
@@ -1008,7 +1023,7 @@ __global__ void __launch_bounds__(WAVES * 64)
 #pragma unroll
     for (int q = 0; q < STEPS; ++q) {
       const int f = q * 64 + lane;
-      if (f < nvec) store_obs_vec<NT>(at32<V4>(dst, (e0 * VPE + f) * (uint32_t)sizeof(V4)), row[q]);
+      if (f < nvec) store_obs_vec<SP>(at32<V4>(dst, (e0 * VPE + f) * (uint32_t)sizeof(V4)), row[q]);
     }
     wave_lds_sync();
   };
@@ -1022,7 +1037,7 @@ __global__ void __launch_bounds__(WAVES * 64)
     if (gen) {  // train_onpolicy.py:305-307
       const u32x4 w = action_words(p.seed, genv, episode, (uint32_t)steps, (uint32_t)(i >> 2));
       act = rand5(pick_word(w, i & 3));
-      if (mine) store_small<NT>(at32<int32_t>(actions_t, (e * N + i) * 4u), act);
+      if (mine) store_small<SP>(at32<int32_t>(actions_t, (e * N + i) * 4u), act);
     } else {
       act = *at32<const int32_t>(actions_t, (ec * N + i) * 4u);
     }
@@ -1134,7 +1149,7 @@ __global__ void __launch_bounds__(WAVES * 64)
     }
     const bool done = (steps == h_max_steps) || all_reached;
 
-    if (mine) store_small<NT>(at32<R>(tick_ptr(p.reward_n, p.st_reward_n, t), (e * N + i) * (uint32_t)sizeof(R)), rew);
+    if (mine) store_small<SP>(at32<R>(tick_ptr(p.reward_n, p.st_reward_n, t), (e * N + i) * (uint32_t)sizeof(R)), rew);
     if (head) {
       *at32<R>(tick_ptr(p.reward, p.st_reward, t), e * (uint32_t)sizeof(R)) = reward;
       *at32<uint8_t>(tick_ptr(p.done, p.st_done, t), e) = done ? 1 : 0;
@@ -1184,7 +1199,7 @@ __global__ void __launch_bounds__(WAVES * 64)
       if (p.goals_out != p.goals_in || was_reset)
         *at32<V2>(tick_ptr(p.goals_out, p.st_goals, t), (row_i + e) * (uint32_t)sizeof(V2)) = gl;
       if constexpr (LIVE) {  // live-state rollout (a compile-time variant: the others carry none of it): the slot gets a copy
-        store_obs_vec<NT>(at32<V4>(p.state_copy, (row_i + e) * (uint32_t)sizeof(V4)), si);
+        store_obs_vec<SP>(at32<V4>(p.state_copy, (row_i + e) * (uint32_t)sizeof(V4)), si);
         *at32<V2>(p.goals_copy, (row_i + e) * (uint32_t)sizeof(V2)) = gl;
       }
     }
@@ -1340,12 +1355,16 @@ static int launch_one(const ParticleParams &p, ParticleOp op, hipStream_t stream
   const unsigned blocks = (unsigned)(((size_t)(p.EN - p.E0) + per_block - 1) / per_block);
   switch (op) {
     case kStep: {
+      constexpr int kNt = sizeof(R) == 4 ? kSpNt : kSpPlain, kWt = sizeof(R) == 4 ? kSpWt : kSpPlain;
       const bool nt = sizeof(R) == 4 && (p.flags & kFlagObsStoreNt);   // streaming-size trajectory (obs_store_nt)
+      // a launch that writes >= kWtMinObsBytes of observation rows writes them through (kSpWt; per-tick launches only)
+      const bool wt = sizeof(R) == 4 && (size_t)(p.EN - p.E0) * ObsGeom<R, N>::REC * sizeof(R) >= kWtMinObsBytes && !p.state_copy;
       if (p.n_ticks > 1) {
-        if (nt) hipLaunchKernelGGL((k_particle_step<R, N, WAVES, true, sizeof(R) == 4>), dim3(blocks), dim3(per_block), 0, stream, p);
+        if (nt) hipLaunchKernelGGL((k_particle_step<R, N, WAVES, true, kNt>), dim3(blocks), dim3(per_block), 0, stream, p);
         else hipLaunchKernelGGL((k_particle_step<R, N, WAVES, true>), dim3(blocks), dim3(per_block), 0, stream, p);
       } else {
-        if (nt) hipLaunchKernelGGL((k_particle_step<R, N, WAVES, false, sizeof(R) == 4>), dim3(blocks), dim3(per_block), 0, stream, p);
+        if (wt) hipLaunchKernelGGL((k_particle_step<R, N, WAVES, false, kWt>), dim3(blocks), dim3(per_block), 0, stream, p);
+        else if (nt) hipLaunchKernelGGL((k_particle_step<R, N, WAVES, false, kNt>), dim3(blocks), dim3(per_block), 0, stream, p);
         else hipLaunchKernelGGL((k_particle_step<R, N, WAVES, false>), dim3(blocks), dim3(per_block), 0, stream, p);
       }
       break;
@@ -1365,8 +1384,8 @@ template <typename R, int N, int WAVES> static int launch_pairs(const ParticlePa
   if constexpr (N >= 2) {
     const size_t envs_per_block = (size_t)WAVES * PairGeom<N>::EPW;
     const unsigned blocks = (unsigned)(((size_t)(p.EN - p.E0) + envs_per_block - 1) / envs_per_block);
-    constexpr bool kF32 = sizeof(R) == 4;
-    const bool nt = kF32 && (p.flags & kFlagObsStoreNt);   // streaming-size trajectory (obs_store_nt)
+    constexpr int kF32 = sizeof(R) == 4 ? kSpNt : kSpPlain;
+    const bool nt = sizeof(R) == 4 && (p.flags & kFlagObsStoreNt);   // streaming-size trajectory (obs_store_nt)
 #define CM3_LAUNCH_PAIRS(...)                                                                                               \
   hipLaunchKernelGGL((k_particle_step_pairs<R, N, WAVES, __VA_ARGS__>), dim3(blocks), dim3(WAVES * 64), 0, stream,          \
                      p.state_in, p.goals_in, p.meta_in, (const int32_t *)p.episode, p.E, p.flags, p.E0, p.EN, p.max_steps,        \
@@ -1378,13 +1397,13 @@ template <typename R, int N, int WAVES> static int launch_pairs(const ParticlePa
     const bool live = p.state_copy != nullptr;   // cm3_particle_traj.state_live (per-tick launches only)
     if (p.n_ticks > 1) {
       if (nt) CM3_LAUNCH_PAIRS(true, kF32);
-      else CM3_LAUNCH_PAIRS(true, false);
+      else CM3_LAUNCH_PAIRS(true, kSpPlain);
     } else if (live) {
       if (nt) CM3_LAUNCH_PAIRS(false, kF32, true);
-      else CM3_LAUNCH_PAIRS(false, false, true);
+      else CM3_LAUNCH_PAIRS(false, kSpPlain, true);
     } else {
       if (nt) CM3_LAUNCH_PAIRS(false, kF32);
-      else CM3_LAUNCH_PAIRS(false, false);
+      else CM3_LAUNCH_PAIRS(false, kSpPlain);
     }
 #undef CM3_LAUNCH_PAIRS
     CM3_HIP_CHECK(hipGetLastError());
@@ -1410,15 +1429,19 @@ template <typename R, int N, int WAVES> static int launch_agents(const ParticleP
     if ((size_t)p.E * AgentGeom<N>::VPE * 4 * sizeof(R) >= ((size_t)1 << 32))
       return fail(CM3_ERR_INVALID, "the lane-per-agent kernel addresses at most 4 GiB per array: %d envs x %d agents is too large", p.E, N);
     const bool live = p.state_copy != nullptr;   // cm3_particle_traj.state_live (per-tick launches only)
+    constexpr int kNt = sizeof(R) == 4 ? kSpNt : kSpPlain, kWt = sizeof(R) == 4 ? kSpWt : kSpPlain;
+    // a launch that writes >= kWtMinObsBytes of observation rows writes them through (kSpWt; per-tick launches, no slot copies)
+    const bool wt = sizeof(R) == 4 && (size_t)(p.EN - p.E0) * AgentGeom<N>::VPE * 4 * sizeof(R) >= kWtMinObsBytes;
     if (p.n_ticks > 1) {
-      if (nt) CM3_LAUNCH_AGENTS(true, sizeof(R) == 4);
-      else CM3_LAUNCH_AGENTS(true, false);
+      if (nt) CM3_LAUNCH_AGENTS(true, kNt);
+      else CM3_LAUNCH_AGENTS(true, kSpPlain);
     } else if (live) {
-      if (nt) CM3_LAUNCH_AGENTS(false, sizeof(R) == 4, true);
-      else CM3_LAUNCH_AGENTS(false, false, true);
+      if (nt) CM3_LAUNCH_AGENTS(false, kNt, true);
+      else CM3_LAUNCH_AGENTS(false, kSpPlain, true);
     } else {
-      if (nt) CM3_LAUNCH_AGENTS(false, sizeof(R) == 4);
-      else CM3_LAUNCH_AGENTS(false, false);
+      if (wt) CM3_LAUNCH_AGENTS(false, kWt);
+      else if (nt) CM3_LAUNCH_AGENTS(false, kNt);
+      else CM3_LAUNCH_AGENTS(false, kSpPlain);
     }
 #undef CM3_LAUNCH_AGENTS
     CM3_HIP_CHECK(hipGetLastError());
