@@ -779,89 +779,109 @@ template <int N> struct CkPlanTab {
   static constexpr int NO = N > 1 ? N - 1 : 1;
   static constexpr int KK = 25, OD = (75 * N + 3) / 4, NQ = (OD + 2) / 3, NCELL = 4 * NQ;
   static constexpr int NSV = 4 * N, NOO = 2 * N * NO, NV = NSV + NOO, GD = 14;
-  uint32_t cell[NCELL][4];  // window cell cg: {board byte offset from the agent's cell, packed (row, column) offset, agent byte mask, agent | invalid << 31}
-  uint32_t grid[16][4];     // grid dword d: {static dword, bit index of cell 2d, of cell 2d + 1, 0}
-  uint32_t val[NV][4];      // value v: {norm index of number 0, agent, bit offset of the number in the agent word, byte offset | others << 31}
-  constexpr CkPlanTab() : cell{}, grid{}, val{} {
+  static constexpr int NGV = (GD > NV ? GD : NV);
+  // window cell cg, two dwords: { board byte offset from the agent's cell (low 16 bits, signed) | packed (row, column) offset << 16,
+  //                              agent | agent byte mask (0xff0000 or 0) | invalid << 31 }
+  uint32_t cell[NCELL][2];
+  // lane slot j = grid dword j AND normalised value j: { grid static dword, bit index of grid cell 2j | of cell 2j + 1 << 8,
+  //   norm index of number 0 | agent << 8 | bit offset of the number in the agent word << 16, byte offset | others << 31 }
+  uint32_t gv[NGV + 1][4];
+  constexpr CkPlanTab() : cell{}, gv{} {
     for (int cg = 0; cg < NCELL; ++cg) {
       const bool ok = cg < KK * N;
       const int i = ok ? cg / KK : 0, c = ok ? cg - KK * i : 12;
       const int dr = c / 5 - 2, dc = c % 5 - 2;
-      cell[cg][0] = (uint32_t)((dr * 16 + dc) * 4);
-      cell[cg][1] = (uint32_t)(dr + dc * 256);
-      cell[cg][2] = (ok && c != 12) ? 0xff0000u : 0u;  // the agent's own (centre) cell is valid (checkers.py:105-107)
-      cell[cg][3] = (uint32_t)i | (ok ? 0u : 0x80000000u);
+      cell[cg][0] = ((uint32_t)((dr * 16 + dc) * 4) & 0xffffu) | ((uint32_t)(dr + dc * 256) << 16);
+      cell[cg][1] = (uint32_t)i | ((ok && c != 12) ? 0xff0000u : 0u) | (ok ? 0u : 0x80000000u);  // own (centre) cell: valid (checkers.py:105-107)
     }
-    for (int d = 0; d < 16; ++d) {
+    for (int j = 0; j <= NGV; ++j) {
       uint32_t w = 0, b[2] = {31, 31};
       for (int h = 0; h < 2; ++h) {
-        const int cl = 2 * d + h;
-        if (cl < 27) {
-          const int k = cl / 9, j = cl - 9 * k;
-          if (j < 8) {
-            w |= 0xffu << (16 * h + 8 * ((k + j) & 1));
-            b[h] = (uint32_t)(k * 8 + j);
+        const int cl = 2 * j + h;
+        if (j < GD && cl < 27) {
+          const int k = cl / 9, jj = cl - 9 * k;
+          if (jj < 8) {
+            w |= 0xffu << (16 * h + 8 * ((k + jj) & 1));
+            b[h] = (uint32_t)(k * 8 + jj);
           }
         }
       }
-      grid[d][0] = w;
-      grid[d][1] = b[0];
-      grid[d][2] = b[1];
-    }
-    for (int v = 0; v < NV; ++v) {
+      gv[j][0] = w;
+      gv[j][1] = b[0] | (b[1] << 8);
+      const int v = j < NV ? j : NV - 1;
       const bool others = v >= NSV;
-      const int w = others ? v - NSV : v;
+      const int wv = others ? v - NSV : v;
       int a = 0, comp = 0;
       if (others) {
-        const int i = w / (2 * NO), k = (w - i * 2 * NO) >> 1;
+        const int i = wv / (2 * NO), k = (wv - i * 2 * NO) >> 1;
         a = (N > 1) ? (k < i ? k : k + 1) : 0;
-        comp = w & 1;
+        comp = wv & 1;
       } else {
-        a = w >> 2;
-        comp = w & 3;
+        a = wv >> 2;
+        comp = wv & 3;
       }
-      val[v][0] = comp == 0 ? 0u : (comp == 1 ? 7u : 20u);
-      val[v][1] = (uint32_t)a;
-      val[v][2] = (uint32_t)(8 * comp);
-      val[v][3] = (uint32_t)(w * 8) | (others ? 0x80000000u : 0u);
+      gv[j][2] = (comp == 0 ? 0u : (comp == 1 ? 7u : 20u)) | ((uint32_t)a << 8) | ((uint32_t)(8 * comp) << 16);
+      gv[j][3] = (uint32_t)(wv * 8) | (others ? 0x80000000u : 0u);
     }
   }
 };
 template <int N> __device__ const CkPlanTab<N> kCkPlanTab = CkPlanTab<N>();
 
-// what a lane produces (registers; loaded once per launch while the state loads are in flight)
+// What a lane produces (registers; loaded once per launch while the state loads are in flight and decoded there).  Every wave of a
+// launch reads these tables through its CU's 64 B / clock vector cache, so they are kept small: 7 sixteen-byte loads per lane at
+// N = 2 (a first version with one dword per field took 13 -- 14 KB per wave -- and the wave ended up waiting for them).
 template <int N, int G> struct CkLanePlan {
   using T = CkPlanTab<N>;
-  static constexpr int NSLOT = (T::NQ + G - 1) / G, NGRID = (T::GD + G - 1) / G, NVAL = (T::NV + G - 1) / G;
-  uint4 cell[NSLOT][4];
-  uint4 grid[NGRID];
-  uint4 val[NVAL];
+  static constexpr int NSLOT = (T::NQ + G - 1) / G, NGV = (T::NGV + G - 1) / G;
+  uint32_t boff[NSLOT][4], rcd[NSLOT][4], amask[NSLOT][4], agent[NSLOT][4];
+  bool invalid[NSLOT][4];
+  uint32_t gstatic[NGV], gb0[NGV], gb1[NGV];
+  uint32_t vidx[NGV], vagent[NGV], vshift[NGV], voff[NGV];
 };
 
-template <int N, int G> __device__ __forceinline__ void ckf_plan_load(int g, CkLanePlan<N, G> &pl) {
+// the wave's private copy of kCkBoardTab in LDS (45 x 16 bytes, written by lanes 0..44) and the lane's plan: ALL loads are
+// requested before the first of them is waited for (the LDS write placed right behind its load made the wave wait for the table
+// before it had even requested its plan: a second memory round trip on the critical path)
+template <int N, int G> __device__ __forceinline__ void ckf_plan_load(int g, int lane, uint4 *lds_tab, CkLanePlan<N, G> &pl) {
   using T = CkPlanTab<N>;
   using P = CkLanePlan<N, G>;
   const CkPlanTab<N> *tab = &kCkPlanTab<N>;
+  const uint4 board_vec = reinterpret_cast<const uint4 *>(&kCkBoardTab)[lane < 45 ? lane : 44];
+  uint4 c01[P::NSLOT], c23[P::NSLOT], gv[P::NGV];
 #pragma unroll
   for (int it = 0; it < P::NSLOT; ++it) {
     const int q = it * G + g, qc = q < T::NQ ? q : T::NQ - 1;
-#pragma unroll
-    for (int x = 0; x < 4; ++x) pl.cell[it][x] = *reinterpret_cast<const uint4 *>(&tab->cell[4 * qc + x][0]);
+    c01[it] = *reinterpret_cast<const uint4 *>(&tab->cell[4 * qc][0]);
+    c23[it] = *reinterpret_cast<const uint4 *>(&tab->cell[4 * qc + 2][0]);
   }
 #pragma unroll
-  for (int it = 0; it < P::NGRID; ++it) pl.grid[it] = *reinterpret_cast<const uint4 *>(&tab->grid[(it * G + g) & 15][0]);
-#pragma unroll
-  for (int it = 0; it < P::NVAL; ++it) {
-    const int v = it * G + g;
-    pl.val[it] = *reinterpret_cast<const uint4 *>(&tab->val[v < T::NV ? v : T::NV - 1][0]);
+  for (int it = 0; it < P::NGV; ++it) {
+    const int j = it * G + g;
+    gv[it] = *reinterpret_cast<const uint4 *>(&tab->gv[j < T::NGV ? j : T::NGV][0]);
   }
-}
-
-// the wave's private copy of kCkBoardTab in LDS (45 x 16 bytes), written by lanes 0..44
-__device__ __forceinline__ void ckf_stage_board(uint4 *lds_tab, int lane) {
-  const uint4 *src = reinterpret_cast<const uint4 *>(&kCkBoardTab);
-  const uint4 t = src[lane < 45 ? lane : 44];
-  if (lane < 45) lds_tab[lane] = t;
+  if (lane < 45) lds_tab[lane] = board_vec;
+#pragma unroll
+  for (int it = 0; it < P::NSLOT; ++it) {
+    const uint32_t w0[4] = {c01[it].x, c01[it].z, c23[it].x, c23[it].z}, w1[4] = {c01[it].y, c01[it].w, c23[it].y, c23[it].w};
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      pl.boff[it][x] = (uint32_t)__builtin_amdgcn_sbfe((int)w0[x], 0, 16);
+      pl.rcd[it][x] = (uint32_t)((int)w0[x] >> 16);
+      pl.amask[it][x] = w1[x] & 0xff0000u;
+      pl.agent[it][x] = w1[x] & 0xffu;
+      pl.invalid[it][x] = (int)w1[x] < 0;
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < P::NGV; ++it) {
+    pl.gstatic[it] = gv[it].x;
+    pl.gb0[it] = gv[it].y & 0xffu;
+    pl.gb1[it] = gv[it].y >> 8;
+    pl.vidx[it] = gv[it].z & 0xffu;
+    pl.vagent[it] = (gv[it].z >> 8) & 0xffu;
+    pl.vshift[it] = gv[it].z >> 16;
+    pl.voff[it] = gv[it].w;
+  }
 }
 
 template <int N, bool NT = false, int G = kCkG>
@@ -870,6 +890,9 @@ __device__ __forceinline__ void ckf_emit_tab(const CheckersParams &p, const CkSt
   using T = CkPlanTab<N>;
   using P = CkLanePlan<N, G>;
   if (!env_ok) return;
+#if defined(CM3_CK_ABLATE) && CM3_CK_ABLATE == 2  // (measurement builds only: the tick without any observation emit)
+  return;
+#endif
   const char *tab = reinterpret_cast<const char *>(lds_tab);
   const uint32_t m32 = (uint32_t)s.mask;  // 24 collected bits
   uint32_t rc[N], base[N], word[N];
@@ -881,28 +904,30 @@ __device__ __forceinline__ void ckf_emit_tab(const CheckersParams &p, const CkSt
   }
   // ---- obs_self_t: lane q takes window cells 4q .. 4q + 3 = three whole dwords ------------------------------------------------
   const uint32_t orow = e * (uint32_t)p.obst_stride;
+#if defined(CM3_CK_ABLATE) && CM3_CK_ABLATE == 1  // (measurement builds only: no obs_self_t)
+  if (false)
+#endif
 #pragma unroll
   for (int it = 0; it < P::NSLOT; ++it) {
     const int q = it * G + g;
     uint32_t c[4];
 #pragma unroll
     for (int x = 0; x < 4; ++x) {
-      const uint4 pc = pl.cell[it][x];
-      const uint32_t ia = pc.w & 0xffu;
+      const uint32_t ia = pl.agent[it][x];
       uint32_t b = base[0], r0 = rc[0];
 #pragma unroll
       for (int a = 1; a < N; ++a) {
         b = (ia == (uint32_t)a) ? base[a] : b;
         r0 = (ia == (uint32_t)a) ? rc[a] : r0;
       }
-      const uint32_t ent = *reinterpret_cast<const uint32_t *>(tab + (b + pc.x));
-      const uint32_t rcx = r0 + pc.y;
+      const uint32_t ent = *reinterpret_cast<const uint32_t *>(tab + (b + pl.boff[it][x]));
+      const uint32_t rcx = r0 + pl.rcd[it][x];
       bool agent = false;
 #pragma unroll
       for (int a = 0; a < N; ++a) agent = agent | (rc[a] == rcx);
       const uint32_t got = (uint32_t)__builtin_amdgcn_sbfe((int)m32, ent >> 24, 1);  // 0 / ~0: the cell's collected bit
-      uint32_t v = (ent ^ (ent & got & 0xfefeu)) | (agent ? pc.z : 0u);
-      if ((it + 1) * G * 4 > T::KK * N) v = ((int)pc.w < 0) ? 0u : v;  // (compile time: only the slots that can hold padding cells)
+      uint32_t v = (ent ^ (ent & got & 0xfefeu)) | (agent ? pl.amask[it][x] : 0u);
+      if ((it + 1) * G * 4 > T::KK * N) v = pl.invalid[it][x] ? 0u : v;  // (compile time: only the slots that can hold padding cells)
       c[x] = v;
     }
     if (q < T::NQ) {
@@ -919,12 +944,14 @@ __device__ __forceinline__ void ckf_emit_tab(const CheckersParams &p, const CkSt
   // ---- grid: dword d = cells 2d, 2d + 1 of get_valid_grid (checkers.py:66-76) --------------------------------------------------
   const uint32_t grow = e * (uint32_t)p.grid_stride;
 #pragma unroll
-  for (int it = 0; it < P::NGRID; ++it) {
+  for (int it = 0; it < P::NGV; ++it) {
     const int d = it * G + g;
-    const uint4 pg = pl.grid[it];
-    const uint32_t g0 = (uint32_t)__builtin_amdgcn_sbfe((int)m32, pg.y, 1), g1 = (uint32_t)__builtin_amdgcn_sbfe((int)m32, pg.z, 1);
-    const uint32_t w = pg.x ^ (pg.x & g0 & 0x0000fefeu) ^ (pg.x & g1 & 0xfefe0000u);
-    if (d < T::GD) ck_st<NT>(at32<uint32_t>(out.grid, grow + 4u * d), w);
+    if (it * G < T::GD) {  // (compile time)
+      const uint32_t gs = pl.gstatic[it];
+      const uint32_t g0 = (uint32_t)__builtin_amdgcn_sbfe((int)m32, pl.gb0[it], 1), g1 = (uint32_t)__builtin_amdgcn_sbfe((int)m32, pl.gb1[it], 1);
+      const uint32_t w = gs ^ (gs & g0 & 0x0000fefeu) ^ (gs & g1 & 0xfefe0000u);
+      if (d < T::GD) ck_st<NT>(at32<uint32_t>(out.grid, grow + 4u * d), w);
+    }
   }
   // ---- vec ------------------------------------------------------------------------------------------------------------------
   if (g < N) {
@@ -937,18 +964,19 @@ __device__ __forceinline__ void ckf_emit_tab(const CheckersParams &p, const CkSt
   }
   // ---- obs_self_v, obs_others: one table read per value ---------------------------------------------------------------------
 #pragma unroll
-  for (int it = 0; it < P::NVAL; ++it) {
+  for (int it = 0; it < P::NGV; ++it) {
     const int v = it * G + g;
-    const uint4 pv = pl.val[it];
-    uint32_t wa = word[0];
+    if (it * G < T::NV) {  // (compile time)
+      uint32_t wa = word[0];
 #pragma unroll
-    for (int a = 1; a < N; ++a) wa = (pv.y == (uint32_t)a) ? word[a] : wa;
-    const uint32_t num = (wa >> pv.z) & 0xffu;
-    const double val = *reinterpret_cast<const double *>(tab + 448u + 8u * (pv.x + num));
-    if (v < T::NV) {
-      const uint32_t off = pv.w & 0x7fffffffu;
-      if ((int)pv.w < 0) ck_st<NT>(at32<double>(out.obs_others, e * (uint32_t)(T::NOO * 8) + off), val);
-      else ck_st<NT>(at32<double>(out.obs_self_v, e * (uint32_t)(T::NSV * 8) + off), val);
+      for (int a = 1; a < N; ++a) wa = (pl.vagent[it] == (uint32_t)a) ? word[a] : wa;
+      const uint32_t num = (wa >> pl.vshift[it]) & 0xffu;
+      const double val = *reinterpret_cast<const double *>(tab + 448u + 8u * (pl.vidx[it] + num));
+      if (v < T::NV) {
+        const uint32_t off = pl.voff[it] & 0x7fffffffu;
+        if ((int)pl.voff[it] < 0) ck_st<NT>(at32<double>(out.obs_others, e * (uint32_t)(T::NOO * 8) + off), val);
+        else ck_st<NT>(at32<double>(out.obs_self_v, e * (uint32_t)(T::NSV * 8) + off), val);
+      }
     }
   }
 }
@@ -979,9 +1007,8 @@ __global__ void __launch_bounds__(256)
   CM3_STAMP(0, false);
   ck_load_env<N>(hd, ec, s, lv);
   // while those loads are in flight: the wave's copy of the board / norm table and this lane's plan (see ckf_emit_tab)
-  ckf_stage_board(lds_tab, lane);
   CkLanePlan<N, G> pl;
-  ckf_plan_load<N, G>(g, pl);
+  ckf_plan_load<N, G>(g, lane, lds_tab, pl);
   ck_wave_sync();
   // the kernel arguments the tick needs, requested while the state loads are in flight (fetched at their first use they made
   // the wave wait for a scalar load six times along its critical path)
