@@ -329,7 +329,11 @@ __device__ __forceinline__ void ck_store_env(const CheckersParams &p, size_t e, 
 // FAST: the reference geometry (3 x 8 band, n_obs 2) as compile-time constants instead of kernel arguments.
 template <int N, bool FAST = false>
 __device__ __forceinline__ bool ck_tick_env(const CheckersParams &p, int t, size_t e, size_t ec, bool writer, CkState<N> &s,
-                                            CkLive<N> &lv) {
+                                            CkLive<N> &lv, const char *fast_tab = nullptr
+#ifdef CM3_SPAN_MARKS
+                                            , unsigned long long *_span_mk = nullptr
+#endif
+                                            ) {
   const int gO = FAST ? 2 : p.O, gR = FAST ? 3 : p.R, gC = FAST ? 8 : p.C;
   const int g_collectible = FAST ? 24 : p.max_collectible;
   const bool active = writer;
@@ -368,9 +372,49 @@ __device__ __forceinline__ bool ck_tick_env(const CheckersParams &p, int t, size
     }
   }
   CM3_STAMP(2, false);
+  CM3_SPAN_MARK(3, false);  // actions drawn
 
   // ---- agents act in index order (step :233-237) ---------------------------------------------------------
   double local[N];
+  if constexpr (FAST) {
+    // Straight-line version for the reference geometry (round 3).  The if / else form below compiles to ~10 exec-mask regions per
+    // agent; by the marked two-stamp build the draw + act phase took 1935 of the wave's 4700 cycles for ~235 instructions.  Same
+    // semantics, every decision a select:
+    //   move (agent_act :157-187): target = cell + delta(action) (delta 0 for "stay" AND for an out-of-range action); a move happens iff
+    //   the target is inside the band and no agent stands on it -- the agent's own cell is occupied by itself, so delta 0 never moves;
+    //   penalty -0.1 iff action != 0 and no move.  reward (get_reward :190-225) as below.  local = penalty + reward comes from a
+    //   six-entry table of those very float64 sums (kCkBoardTab.norm[34..39], in the wave's LDS copy).
+    uint32_t m = (uint32_t)s.mask;
+    uint32_t rcp[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) rcp[j] = (uint32_t)s.r[j] | ((uint32_t)s.c[j] << 8);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const uint32_t a = (uint32_t)act[i];
+      const uint32_t sh = (a < 7u ? a : 7u) * 8u;
+      const int dr = __builtin_amdgcn_sbfe((int)(uint32_t)(0x0000000001ff00ull >> sh), 0, 8);   // action 1: -1, 2: +1
+      const int dc = __builtin_amdgcn_sbfe((int)(uint32_t)(0x00000001ff000000ull >> sh), 0, 8);   // action 3: -1, 4: +1
+      const int tr = s.r[i] + dr, tc = s.c[i] + dc;
+      const uint32_t trc = (uint32_t)tr | ((uint32_t)tc << 8);
+      bool blocked = ((unsigned)(tr - 2) >= 3u) | ((unsigned)(tc - 2) >= 9u);
+#pragma unroll
+      for (int j = 0; j < N; ++j) blocked = blocked | (rcp[j] == trc);
+      s.r[i] = blocked ? s.r[i] : tr;
+      s.c[i] = blocked ? s.c[i] : tc;
+      rcp[i] = blocked ? rcp[i] : trc;
+      const uint32_t pen = (uint32_t)((a != 0u) & blocked);
+      const int k = s.r[i] - 2, j = s.c[i] - 2;
+      const uint32_t bit = 1u << ((k * 8 + j) & 31);
+      const bool fresh = ((unsigned)k < 3u) & ((unsigned)j < 8u) & ((m & bit) == 0u);
+      m |= fresh ? bit : 0u;
+      const uint32_t colour = (uint32_t)(k + j) & 1u;
+      s.ng[i] += (int)(fresh & (colour == 0u));
+      s.no[i] += (int)(fresh & (colour != 0u));
+      const uint32_t kind = fresh ? (colour == (uint32_t)goal[i] ? 1u : 2u) : 0u;
+      local[i] = *reinterpret_cast<const double *>(fast_tab + 448u + 8u * (34u + 3u * pen + kind));
+    }
+    s.mask = (uint64_t)m;
+  } else {
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     const int a = act[i];
@@ -420,6 +464,7 @@ __device__ __forceinline__ bool ck_tick_env(const CheckersParams &p, int t, size
     }
     local[i] = penalty + rew;
   }
+  }
   double total = local[0];  // np.sum(local_rewards) :243 (left to right for n < 8)
   if constexpr (N < 8) {
 #pragma unroll
@@ -429,6 +474,7 @@ __device__ __forceinline__ bool ck_tick_env(const CheckersParams &p, int t, size
   }
   steps += 1;
   CM3_STAMP(3, false);
+  CM3_SPAN_MARK(4, false);  // agents have acted
   bool done;  // :246-260
   if (steps == g_max_steps) {
     done = true;
@@ -747,14 +793,14 @@ __device__ __forceinline__ void ckf_emit(const CheckersParams &p, const CkState<
 //   * the twelve-or-so normalised float64 values of an env are (r - 3.5) / 7, (c - 6.5) / 13 or n / 12 with r in 0..6, c in
 //     0..12, n in 0..12: 33 possible doubles (CkBoardTab::norm; constexpr IEEE divisions = the device's IEEE divisions);
 //   * which cells / grid dword / value a LANE produces is a function of its lane index: per-N plan tables (CkPlanTab<N>).
-// All three are compile-time constants in device memory.  A wave copies the 720-byte board / norm table into a private LDS region
+// All three are compile-time constants in device memory.  A wave copies the 768-byte board / norm table into a private LDS region
 // and loads its lanes' plan entries while the state loads are in flight (nothing of it waits on the critical path); after the
 // tick a window cell is  e = board[agent base + plan offset];  cell = e ^ (e & 0xfefe & -collected(e >> 24)) | agent byte
 // (~13 instructions), four cells become three dwords with three byte permutes, a normalised value is one LDS read.
 // Bit-exact by construction (same values), checked by the same tests as the emit above (which the reset kernel keeps using).
 struct CkBoardTab {
   uint32_t board[7 * 16];  // entry of board cell (rr, cc) at [rr * 16 + cc]: ch0 | ch1 << 8 | ch2 << 16 | bit index << 24
-  double norm[34];         // [0..6] row, [7..19] column, [20..32] count
+  double norm[40];         // [0..6] row, [7..19] column, [20..32] count; [34..39] local reward = penalty + reward (ck_tick_env)
   constexpr CkBoardTab() : board{}, norm{} {
     for (int rr = 0; rr < 7; ++rr)
       for (int cc = 0; cc < 16; ++cc) {
@@ -770,9 +816,12 @@ struct CkBoardTab {
     for (int r = 0; r < 7; ++r) norm[r] = ((double)r - 7.0 / 2.0) / 7.0;
     for (int c = 0; c < 13; ++c) norm[7 + c] = ((double)c - 13.0 / 2.0) / 13.0;
     for (int n = 0; n < 13; ++n) norm[20 + n] = ((double)n - 0.0) / (24.0 / 2.0);
+    const double penalty[2] = {0.0, -0.1}, reward[3] = {0.0, 1.0, -0.5};  // checkers.py:186, :213-222 (matching / other colour)
+    for (int pp = 0; pp < 2; ++pp)
+      for (int kk = 0; kk < 3; ++kk) norm[34 + 3 * pp + kk] = penalty[pp] + reward[kk];
   }
 };
-static_assert(sizeof(CkBoardTab) == 720, "the kernel stages 45 x 16 bytes");
+static_assert(sizeof(CkBoardTab) == 768, "the kernel stages 48 x 16 bytes");
 __device__ const CkBoardTab kCkBoardTab = CkBoardTab();
 
 template <int N> struct CkPlanTab {
@@ -839,14 +888,14 @@ template <int N, int G> struct CkLanePlan {
   uint32_t vidx[NGV], vagent[NGV], vshift[NGV], voff[NGV];
 };
 
-// the wave's private copy of kCkBoardTab in LDS (45 x 16 bytes, written by lanes 0..44) and the lane's plan: ALL loads are
+// the wave's private copy of kCkBoardTab in LDS (48 x 16 bytes, written by lanes 0..47) and the lane's plan: ALL loads are
 // requested before the first of them is waited for (the LDS write placed right behind its load made the wave wait for the table
 // before it had even requested its plan: a second memory round trip on the critical path)
 template <int N, int G> __device__ __forceinline__ void ckf_plan_load(int g, int lane, uint4 *lds_tab, CkLanePlan<N, G> &pl) {
   using T = CkPlanTab<N>;
   using P = CkLanePlan<N, G>;
   const CkPlanTab<N> *tab = &kCkPlanTab<N>;
-  const uint4 board_vec = reinterpret_cast<const uint4 *>(&kCkBoardTab)[lane < 45 ? lane : 44];
+  const uint4 board_vec = reinterpret_cast<const uint4 *>(&kCkBoardTab)[lane < 48 ? lane : 47];
   uint4 c01[P::NSLOT], c23[P::NSLOT], gv[P::NGV];
 #pragma unroll
   for (int it = 0; it < P::NSLOT; ++it) {
@@ -859,7 +908,7 @@ template <int N, int G> __device__ __forceinline__ void ckf_plan_load(int g, int
     const int j = it * G + g;
     gv[it] = *reinterpret_cast<const uint4 *>(&tab->gv[j < T::NGV ? j : T::NGV][0]);
   }
-  if (lane < 45) lds_tab[lane] = board_vec;
+  if (lane < 48) lds_tab[lane] = board_vec;
 #pragma unroll
   for (int it = 0; it < P::NSLOT; ++it) {
     const uint32_t w0[4] = {c01[it].x, c01[it].z, c23[it].x, c23[it].z}, w1[4] = {c01[it].y, c01[it].w, c23[it].y, c23[it].w};
@@ -890,9 +939,6 @@ __device__ __forceinline__ void ckf_emit_tab(const CheckersParams &p, const CkSt
   using T = CkPlanTab<N>;
   using P = CkLanePlan<N, G>;
   if (!env_ok) return;
-#if defined(CM3_CK_ABLATE) && CM3_CK_ABLATE == 2  // (measurement builds only: the tick without any observation emit)
-  return;
-#endif
   const char *tab = reinterpret_cast<const char *>(lds_tab);
   const uint32_t m32 = (uint32_t)s.mask;  // 24 collected bits
   uint32_t rc[N], base[N], word[N];
@@ -902,31 +948,55 @@ __device__ __forceinline__ void ckf_emit_tab(const CheckersParams &p, const CkSt
     base[a] = (uint32_t)s.r[a] * 64u + (uint32_t)s.c[a] * 4u;
     word[a] = rc[a] | ((uint32_t)s.ng[a] << 16) | ((uint32_t)s.no[a] << 24);
   }
+  // ---- every table read of this lane first (cell entries, normalised values), ONE wait, then arithmetic and stores: a waited-for
+  //      LDS read is ~100+ cycles for a lone wave, and reads issued behind exec-masked store blocks each got their own wait ---------
+  uint32_t ent[P::NSLOT][4], rcx[P::NSLOT][4];
+#pragma unroll
+  for (int it = 0; it < P::NSLOT; ++it) {
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      const uint32_t ia = pl.agent[it][x];
+      uint32_t bb = base[0], r0 = rc[0];
+#pragma unroll
+      for (int a = 1; a < N; ++a) {
+        bb = (ia == (uint32_t)a) ? base[a] : bb;
+        r0 = (ia == (uint32_t)a) ? rc[a] : r0;
+      }
+      ent[it][x] = *reinterpret_cast<const uint32_t *>(tab + (bb + pl.boff[it][x]));
+      rcx[it][x] = r0 + pl.rcd[it][x];
+    }
+  }
+  double nval[P::NGV];
+#pragma unroll
+  for (int it = 0; it < P::NGV; ++it) {
+    nval[it] = 0.0;
+    if (it * G < T::NV) {  // (compile time)
+      uint32_t wa = word[0];
+#pragma unroll
+      for (int a = 1; a < N; ++a) wa = (pl.vagent[it] == (uint32_t)a) ? word[a] : wa;
+      const uint32_t num = (wa >> pl.vshift[it]) & 0xffu;
+      nval[it] = *reinterpret_cast<const double *>(tab + 448u + 8u * (pl.vidx[it] + num));
+    }
+  }
+  // (the compiler otherwise sinks the reads of the later slots into the exec-masked blocks that consume them)
+#pragma unroll
+  for (int it = 0; it < P::NSLOT; ++it)
+#pragma unroll
+    for (int x = 0; x < 4; ++x) asm volatile("" : "+v"(ent[it][x]));
   // ---- obs_self_t: lane q takes window cells 4q .. 4q + 3 = three whole dwords ------------------------------------------------
   const uint32_t orow = e * (uint32_t)p.obst_stride;
-#if defined(CM3_CK_ABLATE) && CM3_CK_ABLATE == 1  // (measurement builds only: no obs_self_t)
-  if (false)
-#endif
 #pragma unroll
   for (int it = 0; it < P::NSLOT; ++it) {
     const int q = it * G + g;
     uint32_t c[4];
 #pragma unroll
     for (int x = 0; x < 4; ++x) {
-      const uint32_t ia = pl.agent[it][x];
-      uint32_t b = base[0], r0 = rc[0];
-#pragma unroll
-      for (int a = 1; a < N; ++a) {
-        b = (ia == (uint32_t)a) ? base[a] : b;
-        r0 = (ia == (uint32_t)a) ? rc[a] : r0;
-      }
-      const uint32_t ent = *reinterpret_cast<const uint32_t *>(tab + (b + pl.boff[it][x]));
-      const uint32_t rcx = r0 + pl.rcd[it][x];
       bool agent = false;
 #pragma unroll
-      for (int a = 0; a < N; ++a) agent = agent | (rc[a] == rcx);
-      const uint32_t got = (uint32_t)__builtin_amdgcn_sbfe((int)m32, ent >> 24, 1);  // 0 / ~0: the cell's collected bit
-      uint32_t v = (ent ^ (ent & got & 0xfefeu)) | (agent ? pl.amask[it][x] : 0u);
+      for (int a = 0; a < N; ++a) agent = agent | (rc[a] == rcx[it][x]);
+      const uint32_t en = ent[it][x];
+      const uint32_t got = (uint32_t)__builtin_amdgcn_sbfe((int)m32, en >> 24, 1);  // 0 / ~0: the cell's collected bit
+      uint32_t v = (en ^ (en & got & 0xfefeu)) | (agent ? pl.amask[it][x] : 0u);
       if ((it + 1) * G * 4 > T::KK * N) v = pl.invalid[it][x] ? 0u : v;  // (compile time: only the slots that can hold padding cells)
       c[x] = v;
     }
@@ -962,20 +1032,15 @@ __device__ __forceinline__ void ckf_emit_tab(const CheckersParams &p, const CkSt
     v.x = (int)(wa & 0xffu); v.y = (int)((wa >> 8) & 0xffu); v.z = (int)((wa >> 16) & 0xffu); v.w = (int)(wa >> 24);
     ck_st<NT>(at32<int4>(out.vec, (e * N + g) * 16u), v);
   }
-  // ---- obs_self_v, obs_others: one table read per value ---------------------------------------------------------------------
+  // ---- obs_self_v, obs_others ------------------------------------------------------------------------------------------------
 #pragma unroll
   for (int it = 0; it < P::NGV; ++it) {
     const int v = it * G + g;
     if (it * G < T::NV) {  // (compile time)
-      uint32_t wa = word[0];
-#pragma unroll
-      for (int a = 1; a < N; ++a) wa = (pl.vagent[it] == (uint32_t)a) ? word[a] : wa;
-      const uint32_t num = (wa >> pl.vshift[it]) & 0xffu;
-      const double val = *reinterpret_cast<const double *>(tab + 448u + 8u * (pl.vidx[it] + num));
       if (v < T::NV) {
         const uint32_t off = pl.voff[it] & 0x7fffffffu;
-        if ((int)pl.voff[it] < 0) ck_st<NT>(at32<double>(out.obs_others, e * (uint32_t)(T::NOO * 8) + off), val);
-        else ck_st<NT>(at32<double>(out.obs_self_v, e * (uint32_t)(T::NSV * 8) + off), val);
+        if ((int)pl.voff[it] < 0) ck_st<NT>(at32<double>(out.obs_others, e * (uint32_t)(T::NOO * 8) + off), nval[it]);
+        else ck_st<NT>(at32<double>(out.obs_self_v, e * (uint32_t)(T::NSV * 8) + off), nval[it]);
       }
     }
   }
@@ -1002,7 +1067,7 @@ __global__ void __launch_bounds__(256)
   const bool writer = env_ok && g == 0;
   CkState<N> s;
   CkLive<N> lv;
-  __shared__ __attribute__((aligned(16))) uint4 lds_tab_all[4][45];
+  __shared__ __attribute__((aligned(16))) uint4 lds_tab_all[4][48];
   uint4 *lds_tab = &lds_tab_all[wave][0];
   CM3_STAMP(0, false);
   ck_load_env<N>(hd, ec, s, lv);
@@ -1010,6 +1075,7 @@ __global__ void __launch_bounds__(256)
   CkLanePlan<N, G> pl;
   ckf_plan_load<N, G>(g, lane, lds_tab, pl);
   ck_wave_sync();
+  CM3_SPAN_MARK(0, true);   // loads back
   // the kernel arguments the tick needs, requested while the state loads are in flight (fetched at their first use they made
   // the wave wait for a scalar load six times along its critical path)
   CM3_FETCH_EARLY(p.actions, p.local_rewards, p.reward, p.done, p.grid, p.vec, p.obs_others, p.obs_self_t, p.obs_self_v,
@@ -1019,14 +1085,20 @@ __global__ void __launch_bounds__(256)
   const int n_ticks = FUSED ? p.n_ticks : 1;
 #pragma unroll 1
   for (int t = 0; t < n_ticks; ++t) {
-    const bool ended = ck_tick_env<N, true>(p, t, e, ec, writer, s, lv);
+    const bool ended = ck_tick_env<N, true>(p, t, e, ec, writer, s, lv, reinterpret_cast<const char *>(lds_tab)
+#ifdef CM3_SPAN_MARKS
+                                                , _span_mk
+#endif
+                                                );
     CM3_STAMP(4, false);
+    CM3_SPAN_MARK(1, false);  // draw + agents act done
     if (ended) {  // AUTO_RESET: terminal observation (train_onpolicy.py:336-347), then the fresh episode
       if (p.term_grid) ckf_emit_tab<N, NT, G>(p, s, pl, lds_tab, g, e, env_ok, ck_out_term(p, t));
       ck_restart_env<N>(p, e, ec, writer, s, lv);
     }
     ckf_emit_tab<N, NT, G>(p, s, pl, lds_tab, g, e, env_ok, ck_out_tick(p, t));
     CM3_STAMP(8, false);
+    CM3_SPAN_MARK(2, false);  // observation stores issued
     if (p.goals_next && writer) {
       uint8_t *gn = ck_tick_ptr(p.goals_next, p.st_goals_next, t);
 #pragma unroll

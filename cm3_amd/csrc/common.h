@@ -28,7 +28,7 @@ extern __device__ long long *cm3_stamp_buf;
 // Kernel-span instrumentation (build variant -DCM3_SPAN_STAMPS -> libcm3_hip_span.so; never defined in the product build):
 // exactly TWO time stamps per wave -- the first instruction of the wave and, after its last store has been acknowledged, its
 // last -- each the constant 100 MHz s_memrealtime counter plus the shader clock (s_memtime).  Lane 0 of every wave writes the
-// four values to record <wave index in the launch> of the launch's slot (cm3_span_config / cm3::span_next_slot, util.hip);
+// four values to record <wave index in the launch> (128 bytes each) of the launch's slot (cm3_span_config / cm3::span_next_slot, util.hip);
 // tools/kernel_span.py reduces them per launch to first-wave-in / last-wave-out (span) and start-to-start.  The entry stamps
 // stay in SGPRs until the exit store, so nothing waits for them on the way in.
 #ifdef CM3_SPAN_STAMPS
@@ -37,7 +37,22 @@ namespace cm3 { long long *span_next_slot(); }
 #define CM3_SPAN_IN()                                                         \
   const unsigned long long _span_rt0 = __builtin_amdgcn_s_memrealtime();     \
   const unsigned long long _span_ck0 = __builtin_amdgcn_s_memtime();         \
+  unsigned long long _span_mk[8] = {0, 0, 0, 0, 0, 0, 0, 0};                 \
   __builtin_amdgcn_sched_barrier(0)
+// optional intermediate shader-clock marks (at most 8; -DCM3_SPAN_MARKS builds only: they pin the instruction schedule around them
+// and so lengthen the kernel a little -- the two-stamp record is taken WITHOUT them).  drain: first wait for every outstanding
+// memory operation (only where the code waits for all of them anyway, e.g. right behind the initial loads).
+#ifdef CM3_SPAN_MARKS
+#define CM3_SPAN_MARK(k, drain)                          \
+  do {                                                   \
+    __builtin_amdgcn_sched_barrier(0);                   \
+    if (drain) __builtin_amdgcn_s_waitcnt(0);            \
+    _span_mk[k] = __builtin_amdgcn_s_memtime();          \
+    __builtin_amdgcn_sched_barrier(0);                   \
+  } while (0)
+#else
+#define CM3_SPAN_MARK(k, drain) do { } while (0)
+#endif
 #define CM3_SPAN_OUT(slot)                                                                                  \
   do {                                                                                                      \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
@@ -45,14 +60,16 @@ namespace cm3 { long long *span_next_slot(); }
     const unsigned long long _rt1 = __builtin_amdgcn_s_memrealtime(), _ck1 = __builtin_amdgcn_s_memtime();  \
     if ((slot) && (threadIdx.x & 63) == 0) {                                                                \
       unsigned long long *_r = reinterpret_cast<unsigned long long *>(slot) +                               \
-                               ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 4;            \
+                               ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16;           \
       _r[0] = _span_rt0; _r[1] = _span_ck0; _r[2] = _rt1; _r[3] = _ck1;                                      \
+      for (int _k = 0; _k < 8; ++_k) _r[4 + _k] = _span_mk[_k];                                             \
     }                                                                                                       \
   } while (0)
 #define CM3_SPAN_SET(p) (p).span = ::cm3::span_next_slot()
 #else
 #define CM3_SPAN_FIELD
 #define CM3_SPAN_IN() do { } while (0)
+#define CM3_SPAN_MARK(k, drain) do { } while (0)
 #define CM3_SPAN_OUT(slot) do { } while (0)
 #define CM3_SPAN_SET(p) do { } while (0)
 #endif

@@ -755,6 +755,7 @@ __global__ void __launch_bounds__(WAVES * 64)
   const R kDt = R(0.1), kKeep = R(1 - 0.25);
 
   CM3_STAMP(1, true);
+  CM3_SPAN_MARK(0, true);   // loads back
   // FUSED == false: exactly one tick, the loop and every per-tick pointer offset fold away at compile time
   const int n_ticks = FUSED ? p.n_ticks : 1;
 #pragma unroll 1
@@ -771,6 +772,7 @@ __global__ void __launch_bounds__(WAVES * 64)
     }
 
     CM3_STAMP(2, false);
+    CM3_SPAN_MARK(1, false);  // action drawn
     // ---- action force + own contact force --------------------------------------------------------------------
     R ux = R(0), uy = R(0);
     if (act == 1) ux = R(-1);
@@ -830,6 +832,7 @@ __global__ void __launch_bounds__(WAVES * 64)
     }
 
     CM3_STAMP(4, true);
+    CM3_SPAN_MARK(2, false);  // forces, integration, post-step positions exchanged
     // ---- reward / reached / collisions (multi-goal_spread.py:114-143) ----------------------------------------
     R rew;
     bool reached;
@@ -874,6 +877,7 @@ __global__ void __launch_bounds__(WAVES * 64)
     }
 
     CM3_STAMP(5, true);
+    CM3_SPAN_MARK(3, false);  // rewards / done stored
     // ---- same-launch re-initialisation -------------------------------------------------------------------------
     bool was_reset = false;
     if (auto_reset && done) {
@@ -911,6 +915,7 @@ __global__ void __launch_bounds__(WAVES * 64)
     }
   }
 
+  CM3_SPAN_MARK(4, false);  // state + observation stores issued
   CM3_STAMP(7, false);
   // ---- live counters, once per launch -------------------------------------------------------------------------------
   if (env_ok && head) {

@@ -171,7 +171,7 @@ int cm3_device_name(int dev, char *name, int len) {
 }
 
 #ifdef CM3_SPAN_STAMPS
-// (span build only; not part of the product ABI)  buf: n_slots x slot_bytes device bytes, slot_bytes >= 32 x waves per launch;
+// (span build only; not part of the product ABI)  buf: n_slots x slot_bytes device bytes, slot_bytes >= 128 x waves per launch;
 // NULL switches the stamps off.  Resets the slot counter.  Returns the number of slots handed out before the call.
 int64_t cm3_span_config(void *buf, int64_t n_slots, int64_t slot_bytes) {
   const int64_t used = cm3::g_span_next;

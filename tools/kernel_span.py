@@ -32,7 +32,8 @@ import cm3_amd  # noqa: E402
 from cm3_amd import _lib  # noqa: E402
 
 RT_NS = 10.0          # one s_memrealtime tick (100 MHz)
-MAX_WAVES = 4096      # per launch, upper bound of the record area
+MAX_WAVES = 2048      # per launch, upper bound of the record area
+REC = 16               # 64-bit words per wave record: rt_in, ck_in, rt_out, ck_out, 8 optional marks (ck), pad
 
 
 def span_config(buf, n_slots):
@@ -43,7 +44,7 @@ def span_config(buf, n_slots):
         raise SystemExit("this library has no span stamps: build with -DCM3_SPAN_STAMPS and select it with CM3_AMD_LIB")
     fn.restype = ctypes.c_int64
     fn.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64]
-    return fn(buf.data_ptr() if buf is not None else None, n_slots, MAX_WAVES * 32)
+    return fn(buf.data_ptr() if buf is not None else None, n_slots, MAX_WAVES * REC * 8)
 
 
 def reduce_slots(rec):
@@ -56,7 +57,11 @@ def reduce_slots(rec):
     start, last_in, end = rt_in.min(1), np.where(used, rec[:, :, 0], 0).max(1), rt_out.max(1)
     life_rt = np.where(used, rec[:, :, 2] - rec[:, :, 0], 0).sum(1) / np.maximum(waves, 1)
     life_ck = np.where(used, rec[:, :, 3] - rec[:, :, 1], 0).sum(1) / np.maximum(waves, 1)
-    return dict(waves=waves, start=start, end=end, span=end - start, skew_in=last_in - start, life_rt=life_rt, life_ck=life_ck)
+    marks = []
+    for k in range(8):     # optional -DCM3_SPAN_MARKS marks: mean over waves and launches of (mark - wave in), shader cycles
+        m = used & (rec[:, :, 4 + k] != 0)
+        marks.append(float((rec[:, :, 4 + k] - rec[:, :, 1])[m].mean()) if m.any() else None)
+    return dict(marks=marks, waves=waves, start=start, end=end, span=end - start, skew_in=last_in - start, life_rt=life_rt, life_ck=life_ck)
 
 
 def stats(x, scale=1.0):
@@ -78,8 +83,12 @@ def report(name, desc, r, ev_us_per_launch, n_launches, out):
              "   | shader cycles: mean %.0f  (= %.2f GHz)" % (r["life_ck"].mean(), r["life_ck"].mean() / max(r["life_rt"].mean() * RT_NS, 1e-9)),
              "   sum of start-to-start over the replay: %.3f us per launch; HIP events around the same replays: %.3f us per launch "
              "(ratio %.4f)" % (s2s.mean() * us, ev_us_per_launch, s2s.mean() * us / ev_us_per_launch)]
+    if any(m is not None for m in r["marks"]):
+        lines.append("   marks (shader cycles after the wave's first instruction, mean): " +
+                     "  ".join("m%d %.0f" % (k, m) for k, m in enumerate(r["marks"]) if m is not None) +
+                     "  | out %.0f" % r["life_ck"].mean())
     print("\n".join(lines))
-    out[name] = dict(desc=desc, launches=n_launches, waves=int(np.median(r["waves"])),
+    out[name] = dict(marks_cycles=r["marks"], desc=desc, launches=n_launches, waves=int(np.median(r["waves"])),
                      span_us_mean=float(r["span"].mean() * us), span_us_median=float(np.median(r["span"]) * us),
                      span_us_min=float(r["span"].min() * us),
                      start_to_start_us_mean=float(s2s.mean() * us), start_to_start_us_median=float(np.median(s2s) * us),
@@ -90,7 +99,7 @@ def report(name, desc, r, ev_us_per_launch, n_launches, out):
 
 def run_stepper(name, make, n_launches, steps, warm, desc, out):
     dev = torch.device("cuda", 0)
-    buf = torch.zeros(n_launches * MAX_WAVES * 4, dtype=torch.int64, device=dev)
+    buf = torch.zeros(n_launches * MAX_WAVES * REC, dtype=torch.int64, device=dev)
     span_config(buf, n_launches)          # the next n_launches step launches (= the graph capture) take slots 0..n-1
     st = make()
     st.run(warm * n_launches)
@@ -98,7 +107,7 @@ def run_stepper(name, make, n_launches, steps, warm, desc, out):
     ms = bench.timed_ticks(st, steps * n_launches)
     torch.cuda.synchronize(dev)
     used = span_config(None, 0)
-    rec = buf.cpu().numpy().reshape(n_launches, MAX_WAVES, 4)
+    rec = buf.cpu().numpy().reshape(n_launches, MAX_WAVES, REC)
     st.close()
     if used != n_launches:
         print("   (note: %d slots were handed out, expected %d)" % (used, n_launches))
