@@ -765,8 +765,7 @@ __global__ void __launch_bounds__(WAVES * 64)
     R f_x, f_y;
     if (gen) {  // train_onpolicy.py:305-307
       const u32x4 w = action_words(p.seed, genv, episode, (uint32_t)steps, (uint32_t)(i >> 2));
-      act = rand5(pick_word(w, i & 3));
-      if (env_ok && lead) *at32<int32_t>(actions_t, (e * N + i) * 4u) = act;
+      act = rand5(pick_word(w, i & 3));  // (stored with the other per-agent outputs at the end of the tick)
     } else {
       act = *at32<const int32_t>(actions_t, (ec * N + i) * 4u);
     }
@@ -869,12 +868,7 @@ __global__ void __launch_bounds__(WAVES * 64)
     const R reward = sum_agents<R, N>(rews);
     const bool done = (steps == h_max_steps) || all_reached;
 
-    if (env_ok && lead) *at32<R>(tick_ptr(p.reward_n, p.st_reward_n, t), (e * N + i) * (uint32_t)sizeof(R)) = rew;
-    if (env_ok && head) {
-      *at32<R>(tick_ptr(p.reward, p.st_reward, t), e * (uint32_t)sizeof(R)) = reward;
-      *at32<uint8_t>(tick_ptr(p.done, p.st_done, t), e) = done ? 1 : 0;
-      if (p.collisions_tick) *at32<int32_t>(tick_ptr(p.collisions_tick, p.st_coll, t), e * 4u) = collisions;
-    }
+    const int collisions_tick = collisions;  // scenario.collisions after this tick, before any same-launch reset
 
     CM3_STAMP(5, true);
     CM3_SPAN_MARK(3, false);  // rewards / done stored
@@ -899,8 +893,13 @@ __global__ void __launch_bounds__(WAVES * 64)
 
     CM3_STAMP(6, false);
     // ---- per-tick stores ------------------------------------------------------------------------------------------
+    // Stores grouped by predicate -- per agent, per pair, per env: an exec-masked region (s_and_saveexec ... s_or exec) costs a lone
+    // wave about twice its instruction count (tools/probes/salu_valu_probe.hip), and the first version had one region per output,
+    // eight per tick.  (Storing from ALL lanes instead -- duplicates writing the same value -- was measured too: +8 % at C2.)
     if (env_ok) {
       if (lead) {
+        if (gen) *at32<int32_t>(actions_t, (e * N + i) * 4u) = act;
+        *at32<R>(tick_ptr(p.reward_n, p.st_reward_n, t), (e * N + i) * (uint32_t)sizeof(R)) = rew;
         *at32<V4>(tick_ptr(p.state_out, p.st_state, t), (row_i + e) * (uint32_t)sizeof(V4)) = si;
         if (p.goals_out != p.goals_in || was_reset)
           *at32<V2>(tick_ptr(p.goals_out, p.st_goals, t), (row_i + e) * (uint32_t)sizeof(V2)) = gl;
@@ -912,18 +911,32 @@ __global__ void __launch_bounds__(WAVES * 64)
       // observation (multi-goal_spread.py:145-154): vector (i,k) of env e; lanes of a wave cover whole records
       if (slot_ok)
         store_obs_vec<SP>(at32<V4>(tick_ptr(p.obs_others, p.st_obs, t), (e * SLOTS + vslot) * (uint32_t)sizeof(V4)), sub4<R, V4>(sj, si));
+      if (head) {
+        *at32<R>(tick_ptr(p.reward, p.st_reward, t), e * (uint32_t)sizeof(R)) = reward;
+        *at32<uint8_t>(tick_ptr(p.done, p.st_done, t), e) = done ? 1 : 0;
+        if (p.collisions_tick) *at32<int32_t>(tick_ptr(p.collisions_tick, p.st_coll, t), e * 4u) = collisions_tick;
+        if constexpr (!FUSED) {  // the live counters, once per launch
+          int2 m;
+          m.x = steps;
+          m.y = collisions;
+          *at32<int2>(p.meta_out, e * 8u) = m;
+          if (episode != episode_in) *at32<int32_t>(p.episode, e * 4u) = (int32_t)episode;
+        }
+      }
     }
   }
 
   CM3_SPAN_MARK(4, false);  // state + observation stores issued
   CM3_STAMP(7, false);
   // ---- live counters, once per launch -------------------------------------------------------------------------------
-  if (env_ok && head) {
-    int2 m;
-    m.x = steps;
-    m.y = collisions;
-    *at32<int2>(p.meta_out, e * 8u) = m;
-    if (episode != episode_in) *at32<int32_t>(p.episode, e * 4u) = (int32_t)episode;
+  if constexpr (FUSED) {
+    if (env_ok && head) {
+      int2 m;
+      m.x = steps;
+      m.y = collisions;
+      *at32<int2>(p.meta_out, e * 8u) = m;
+      if (episode != episode_in) *at32<int32_t>(p.episode, e * 4u) = (int32_t)episode;
+    }
   }
   CM3_STAMP(8, true);
   CM3_SPAN_OUT(p.span);
