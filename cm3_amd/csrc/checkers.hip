@@ -1266,11 +1266,16 @@ static int ck_fill(const cm3_checkers_desc *d, const cm3_checkers_bufs *b, const
 
 template <int N> static int ck_launch(const CheckersParams &p, bool step, hipStream_t stream) {
   if (ck_fast_ok(p)) {
-    const bool nt = (p.flags & kCkObsStoreNt) != 0;   // streaming-size trajectory (ck_rollout): non-temporal stores, G = 16
+    const bool nt = (p.flags & kCkObsStoreNt) != 0;   // streaming-size trajectory (ck_rollout): non-temporal stores, kCkGStream lanes per env
     const unsigned epb = 4u * (nt ? CkFast<N, kCkGStream>::EPW : CkFast<N>::EPW);  // 4 waves x EPW envs per workgroup
     const unsigned fblocks = (unsigned)(((size_t)p.E + epb - 1) / epb);
-    if (step) {  // the step kernel indexes with 32-bit byte offsets
-      const size_t widest = (size_t)p.obst_stride > (size_t)N * 32 ? (size_t)p.obst_stride : (size_t)N * 32;
+    if (step) {  // the step kernel indexes with 32-bit byte offsets: the widest per-env record of any per-tick array bounds E
+      // obs_self_t (stride), grid (stride), obs_self_v 32 N, obs_others 16 N max(N-1, 1), vec 16 N, local_rewards 8 N
+      size_t widest = (size_t)p.obst_stride;
+      const size_t others = (size_t)16 * N * (N > 1 ? N - 1 : 1);
+      if ((size_t)p.grid_stride > widest) widest = (size_t)p.grid_stride;
+      if ((size_t)N * 32 > widest) widest = (size_t)N * 32;
+      if (others > widest) widest = others;
       if ((size_t)p.E * widest >= ((size_t)1 << 32))
         return fail(CM3_ERR_INVALID, "the Checkers step kernel addresses at most 4 GiB per array: %d envs x %d agents is too large", p.E, N);
     }

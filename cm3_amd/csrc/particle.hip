@@ -1677,24 +1677,44 @@ static int particle_rollout_chains(const cm3_particle_desc *d, const cm3_particl
   int used = 0;
   for (int c = 0; c < n_chains; ++c)
     if ((size_t)c * chunk < (size_t)d->n_envs) used = c + 1;
+  // The first error is remembered and the fork / join epilogue ALWAYS runs for every side stream that was forked: returning from
+  // inside the loop leaked the events and, during hipGraph capture, left side streams un-joined (the capture on streams[0] was
+  // then invalid and had to be aborted by the caller).
   int rc = CM3_OK;
+  auto note = [&rc](hipError_t e, const char *what) {
+    if (e != hipSuccess && rc == CM3_OK) rc = fail(CM3_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
+  };
   if (used > 1) {
-    CM3_HIP_CHECK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
-    CM3_HIP_CHECK(hipEventRecord(fork, s0));
+    note(hipEventCreateWithFlags(&fork, hipEventDisableTiming), "hipEventCreateWithFlags");
+    if (fork) note(hipEventRecord(fork, s0), "hipEventRecord(fork)");
   }
-  for (int c = 0; c < used && rc == CM3_OK; ++c) {
+  bool forked[16] = {false};
+  for (int c = 0; c < used; ++c) {
     hipStream_t sc = (hipStream_t)streams[c];
-    if (c > 0) CM3_HIP_CHECK(hipStreamWaitEvent(sc, fork, 0));
-    cm3_particle_desc dc = *d;
-    dc.env_offset = (int32_t)((size_t)c * chunk);
-    const size_t end = ((size_t)(c + 1) * chunk < (size_t)d->n_envs) ? (size_t)(c + 1) * chunk : (size_t)d->n_envs;
-    dc.env_count = (int32_t)(end - (size_t)dc.env_offset);
-    rc = particle_rollout<R>(&dc, t, n_ticks, sc);
-    if (c > 0 && rc == CM3_OK) {
-      CM3_HIP_CHECK(hipEventCreateWithFlags(&join[c], hipEventDisableTiming));
-      CM3_HIP_CHECK(hipEventRecord(join[c], sc));
-      CM3_HIP_CHECK(hipStreamWaitEvent(s0, join[c], 0));
+    if (c > 0) {
+      if (rc != CM3_OK || !fork) break;          // nothing further is forked after an error
+      const hipError_t e = hipStreamWaitEvent(sc, fork, 0);
+      note(e, "hipStreamWaitEvent(fork)");
+      if (e != hipSuccess) break;
+      forked[c] = true;
     }
+    if (rc == CM3_OK) {
+      cm3_particle_desc dc = *d;
+      dc.env_offset = (int32_t)((size_t)c * chunk);
+      const size_t end = ((size_t)(c + 1) * chunk < (size_t)d->n_envs) ? (size_t)(c + 1) * chunk : (size_t)d->n_envs;
+      dc.env_count = (int32_t)(end - (size_t)dc.env_offset);
+      const int r = particle_rollout<R>(&dc, t, n_ticks, sc);
+      if (r != CM3_OK && rc == CM3_OK) rc = r;
+    }
+  }
+  for (int c = 1; c < used; ++c) {              // join every forked side stream back into streams[0], error or not
+    if (!forked[c]) continue;
+    hipStream_t sc = (hipStream_t)streams[c];
+    hipError_t e = hipEventCreateWithFlags(&join[c], hipEventDisableTiming);
+    note(e, "hipEventCreateWithFlags");
+    if (e != hipSuccess) continue;
+    note(hipEventRecord(join[c], sc), "hipEventRecord(join)");
+    note(hipStreamWaitEvent(s0, join[c], 0), "hipStreamWaitEvent(join)");
   }
   // events may be destroyed once recorded / waited on: the runtime keeps what in-flight work still needs
   if (fork) (void)hipEventDestroy(fork);

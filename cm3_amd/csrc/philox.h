@@ -32,8 +32,8 @@ __host__ __device__ inline u32x4 philox4x32_10(u32x4 ctr, uint32_t k0, uint32_t 
     const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
     const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
     u32x4 n;
-#if defined(__HIP_DEVICE_COMPILE__)
-    // one three-input xor (v_bitop3_b32, truth table 0x96) instead of two v_xor: 20 VALU instructions fewer per draw
+#if defined(__HIP_DEVICE_COMPILE__) && defined(__gfx950__) && __has_builtin(__builtin_amdgcn_bitop3_b32)
+    // one three-input xor (v_bitop3_b32, truth table 0x96; gfx950 only) instead of two v_xor: 20 VALU instructions fewer per draw
     n.x = __builtin_amdgcn_bitop3_b32(hi1, ctr.y, k0, 0x96);
     n.z = __builtin_amdgcn_bitop3_b32(hi0, ctr.w, k1, 0x96);
 #else

@@ -18,6 +18,7 @@ All arithmetic happens in libcm3_hip.so (cm3_amd/csrc/particle.hip) on tensors o
 this module only allocates, binds pointers and shapes views.  No CPU fallback exists.
 """
 import ctypes
+import weakref
 
 import torch
 
@@ -98,6 +99,7 @@ class VecParticleEnv(object):
         self._term_obs_others = None
         self._collisions_tick = None
         self._cur = 0
+        self._rollouts = weakref.WeakSet()       # collectors to tell about resets / state injections (_notify_reset)
         self._desc = _lib.ParticleDesc()
         _fill_desc(self._desc, config_particle, N, prob_random, max_steps, E, seed, env_id_base, 0)
         self._lib = _lib.lib()
@@ -154,7 +156,14 @@ class VecParticleEnv(object):
         _lib.check(self._fn("reset")(ctypes.byref(self._desc), ctypes.byref(b), _lib.ptr(m), self._stream()))
         done = torch.zeros(self.E, dtype=torch.bool, device=self.device)   # np.any(done_n) is False after reset
         gs = self.global_state
+        self._notify_reset(m)
         return gs, self._obs_others[cur], gs, done
+
+    def _notify_reset(self, mask=None):
+        """A ParticleRollout carries which envs' episodes have already ended across collect(reset=False) calls; an env that
+        is re-seeded OUTSIDE the collector (reset(), set_state()) starts a fresh episode and must not stay flagged."""
+        for ro in list(self._rollouts):
+            ro.mark_reset(mask)
 
     def step(self, actions=None):
         """environment.py:81-123.  ``actions`` int [E, N]; None draws uniform actions in-kernel
@@ -257,6 +266,7 @@ class VecParticleEnv(object):
         self._meta[:, 1] = 0 if collisions is None else torch.as_tensor(collisions, device=self.device).to(torch.int32)
         if episode is not None:
             self._episode.copy_(torch.as_tensor(episode, device=self.device).to(torch.int32))
+        self._notify_reset(None)
         b = self._bufs(cur, cur)
         _lib.check(self._fn("observe")(ctypes.byref(self._desc), ctypes.byref(b), self._stream()))
         return self.global_state, self._obs_others[cur]

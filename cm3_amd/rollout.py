@@ -160,6 +160,18 @@ class ParticleRollout(object):
         self._finished0 = None
         self._lib = _lib.lib()
         self.collected = False
+        if hasattr(env, "_rollouts"):
+            env._rollouts.add(self)          # env.reset() / env.set_state() outside the collector clear `_finished` (mark_reset)
+
+    def mark_reset(self, mask=None):
+        """Envs (bool / uint8 [E] mask; None = all) were re-seeded outside this collector -- env.reset(mask), env.set_state():
+        their next episode is fresh, so transitions collected with reset=False are valid again.  VecParticleEnv calls this
+        itself; call it by hand only for an env object that does not."""
+        if mask is None:
+            self._finished.zero_()
+        else:
+            m = torch.as_tensor(mask, device=self.env.device).bool().reshape(-1)
+            self._finished &= ~m
 
     # ---- plumbing ------------------------------------------------------------------------------------
     def _traj(self, t0=0, live=False):

@@ -219,8 +219,10 @@ typedef struct cm3_checkers_desc {
                                 Records padded to a multiple of 4 bytes (56 / 152 for the reference geometry with
                                 N = 2) enable the multi-lane fast kernel, which writes each record up to its payload
                                 rounded up to 4 bytes (the rounding bytes as 0; bytes of a LARGER stride beyond that are
-                                left untouched) and indexes with 32-bit byte offsets: n_envs * obs_self_t_stride (and
-                                n_envs * N * 32) must stay below 4 GiB, else CM3_ERR_INVALID */
+                                left untouched) and indexes with 32-bit byte offsets: n_envs times the widest per-env record
+                                of any per-tick array -- max(obs_self_t_stride, grid_stride, 32 N, 16 N max(N-1, 1)) bytes
+                                (obs_others is the widest from N = 6 on: 896 B at N = 8) -- must stay below 4 GiB, else
+                                CM3_ERR_INVALID */
   int32_t _pad;
   int64_t env_id_base;
   uint64_t seed;

@@ -103,3 +103,26 @@ def test_product_never_imports_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+def test_checkers_step_refuses_batches_beyond_its_32_bit_offsets(built):
+    """The fast Checkers step kernel addresses with 32-bit byte offsets; the launcher must refuse a batch whose WIDEST per-env
+    record (obs_others from N = 6 on: 16 N (N - 1) bytes, wider than the 75 N-byte window record) would wrap them -- before any
+    HIP call, so this runs without a GPU.  (the guard used to look at the window record only.)"""
+    import ctypes
+    handle = built.lib()
+    d = built.CheckersDesc()
+    b = built.CheckersBufs()
+    fake = 0x10000                       # non-NULL placeholders: never dereferenced on this path
+    for name, _ in b._fields_:
+        setattr(b, name, fake)
+    N = 8
+    d.n_agents, d.n_rows, d.n_columns, d.n_obs, d.max_steps = N, 3, 8, 2, 33
+    d.grid_stride, d.obs_self_t_stride = 56, 600
+    for k in range(N):
+        d.agents_r[k], d.agents_c[k] = k % 3, 8 - k // 3      # distinct start cells inside the band
+    widest = 16 * N * (N - 1)                                   # 896 B > 600 B
+    d.n_envs = (1 << 32) // widest + 1
+    assert d.n_envs * 600 < (1 << 32)                           # the window record alone would have passed
+    assert handle.cm3_checkers_step(ctypes.byref(d), ctypes.byref(b), None) == -1
+    assert b"4 GiB" in handle.cm3_last_error()

@@ -339,3 +339,33 @@ def test_normalize_with_eight_rank_moments(dtype):
     whole = torch.cat([s[v] for s, v in zip(shards, valids)]).double()
     assert abs(float(mean) - float(whole.mean())) < 1e-9 * (1 + abs(float(whole.mean())))
     assert abs(float(std) - float(whole.std(unbiased=False))) < 1e-7 * float(whole.std())
+
+
+def test_external_reset_clears_the_finished_flags_of_a_reused_rollout():
+    """a reused ParticleRollout on an env WITHOUT auto-reset carries `_finished` across collect(reset=False)
+    calls; re-seeding the env outside the collector (env.reset(), env.reset(mask), env.set_state()) must clear it, or
+    every later transition stays invalid and episode_returns() is all zero."""
+    from cm3_amd.rollout import ParticleRollout
+    E, T = 256, 9
+    env = _penv(E, seed=41, auto_reset=False, max_steps=T)
+    env.reset()
+    ro = ParticleRollout(env, n_ticks=T, use_graph=False)
+    ro.collect(reset=False)
+    assert bool(ro.valid.all()) and bool(ro._finished.all())          # every episode ended at max_steps
+    ro.collect(reset=False)
+    assert not bool(ro.valid.any())                                    # stepped on past `done`: nothing valid
+    env.reset()                                                        # external re-seed of every env
+    ro.collect(reset=False)
+    assert bool(ro.valid.all())
+    half = torch.zeros(E, dtype=torch.bool, device=env.device)
+    half[: E // 2] = True
+    env.reset(half)                                                    # ... of a subset
+    ro.collect(reset=False)
+    v = ro.valid
+    assert bool(v[:, : E // 2].all()) and not bool(v[:, E // 2:].any())
+    st = env.get_state()
+    env.set_state(st["pos"], st["vel"], st["landmarks"])               # state injection restarts the step counters
+    ro.collect(reset=False)
+    assert bool(ro.valid.all())
+    g, _ = ro.episode_returns()
+    assert float(g.abs().min()) > 0.0
