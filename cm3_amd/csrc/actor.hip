@@ -24,7 +24,7 @@ constexpr int kH1S = 64, kH1O = 128, kH2 = 64;
 struct ActorParams {
   int E, stage;
   float eps;
-  int bf16;  // second layer on the bf16 matrix cores (f32 accumulate); 0 = exact f32 MFMA
+  int bf16;  // precision of the second layer: kPrecF32 / kPrecBf16 / kPrecF16x3 (see ActorGeom)
   int64_t env_id_base;
   uint64_t seed;
   const float *obs_others, *state, *goals;
@@ -50,7 +50,8 @@ template <int N> struct PackLayout {
   static constexpr int kBh2 = kTables;                   // [64]
   static constexpr int kW2f = kBh2 + kH2;                // [4 waves][64 lanes][48 k-steps] f32 B operands
   static constexpr int kW2b = kW2f + 4 * 64 * (KU / 4);  // [4][64][6][8] bf16 B operands (stored in float slots)
-  static constexpr int kTotal = kW2b + 4 * 64 * (KU / 4) / 2;
+  static constexpr int kW2x = kW2b + 4 * 64 * (KU / 4) / 2;  // [4][64][6][hi | lo][8] split-float16 B operands (kPrecF16x3)
+  static constexpr int kTotal = kW2x + 4 * 64 * (KU / 4);
 };
 
 template <int N> __global__ void __launch_bounds__(256) k_actor_pack(const ActorParams p, float *out) {
@@ -73,7 +74,7 @@ template <int N> __global__ void __launch_bounds__(256) k_actor_pack(const Actor
       const int u = t - PL::kW2f, s = u % (PL::KU / 4), lane = (u / (PL::KU / 4)) & 63, w = u / (PL::KU / 4) / 64;
       const int k = 4 * s + (lane >> 4), j = 16 * w + (lane & 15);  // B[k = l>>4][j = l&15] of k-step s
       v = k < kH1S ? p.w_self_h2[k * kH2 + j] : (stage2 ? p.w_oth_h2[(k - kH1S) * kH2 + j] : 0.0f);
-    } else {
+    } else if (t < PL::kW2x) {
       // two bf16 per float slot: element index eidx = 2 (t - kW2b) + {0,1} in [w][lane][s(6)][q(8)]
       __bf16 pair[2];
       for (int h = 0; h < 2; ++h) {
@@ -83,6 +84,20 @@ template <int N> __global__ void __launch_bounds__(256) k_actor_pack(const Actor
         const int k = 32 * s + 8 * (lane >> 4) + q, j = 16 * w + (lane & 15);
         const float wv = k < kH1S ? p.w_self_h2[k * kH2 + j] : (stage2 ? p.w_oth_h2[(k - kH1S) * kH2 + j] : 0.0f);
         pair[h] = (__bf16)wv;
+      }
+      __builtin_memcpy(&v, pair, 4);
+    } else {
+      // split float16 (kPrecF16x3): eidx = 2 (t - kW2x) + {0,1} in [w][lane][s(6)][part(2: hi, lo)][q(8)];
+      // hi = f16(w), lo = f16(w - hi): hi + lo carries 22 of the weight's 24 significand bits
+      _Float16 pair[2];
+      for (int h = 0; h < 2; ++h) {
+        const int eidx = 2 * (t - PL::kW2x) + h;
+        const int q = eidx & 7, part = (eidx >> 3) & 1, s = (eidx >> 4) % (PL::KU / 32), lane = ((eidx >> 4) / (PL::KU / 32)) & 63;
+        const int w = (eidx >> 4) / (PL::KU / 32) / 64;
+        const int k = 32 * s + 8 * (lane >> 4) + q, j = 16 * w + (lane & 15);
+        const float wv = k < kH1S ? p.w_self_h2[k * kH2 + j] : (stage2 ? p.w_oth_h2[(k - kH1S) * kH2 + j] : 0.0f);
+        const _Float16 hi = (_Float16)wv;
+        pair[h] = part == 0 ? hi : (_Float16)(wv - (float)hi);
       }
       __builtin_memcpy(&v, pair, 4);
     }
@@ -112,26 +127,43 @@ template <int N> __global__ void __launch_bounds__(256) k_actor_pack(const Actor
 //   History: weights streamed through SGPRs into VALU FMAs: 23 us per tick at 4096 envs x 4 agents; first layer
 //   evaluated directly in the A-operand layout in all four waves: 2750 VALU instructions per wave, 14.5 us (PMC runs in
 //   profiles/); this structure: 9.5 us.
-template <int N, bool BF16> struct ActorGeom {
+// precision of the 192 -> 64 second layer (cm3_actor_particle_desc.precision)
+//   kPrecF32     exact float32 MFMA (v_mfma_f32_16x16x4_f32: a k-ordered fmaf chain), 192 MFMAs of 32 cycles per wave
+//   kPrecBf16    activations and weights rounded to bf16, f32 accumulate: 24 MFMAs; probabilities move by ~1e-2 -- not a parity path
+//   kPrecF16x3   (round 3) SPLIT float16: x = hi + lo with hi = f16(x), lo = f16(x - hi), for activations and weights alike, and
+//                x w ~ hi hi + hi lo + lo hi on v_mfma_f32_16x16x32_f16 (products exact, f32 accumulate): 72 MFMAs of ~8 cycles.
+//                float16 keeps 11 significand bits, so hi + lo keeps 22 of float32's 24; what is dropped is lo lo and the second
+//                residuals, ~3 x 2^-22 relative per product.  Measured against the float64 oracle with deliberately large
+//                weights (tests/test_gpu_actor.py) the probabilities stay inside the 2e-5 the float32 path is held to.
+//                (The same split in bf16 -- 16 bits per factor -- was tried first: 3.7e-5 .. 1.1e-4, outside the bound;
+//                profiles/r03_actor_split_precision.txt.)  Range: float16 overflows at 65504; a first-layer activation beyond
+//                that (weights ~3 orders of magnitude above anything a trained policy holds) saturates instead of matching.
+constexpr int kPrecF32 = 0, kPrecBf16 = 1, kPrecF16x3 = 2;
+
+template <int N, int PREC> struct ActorGeom {
+  static constexpr bool BF16 = PREC != kPrecF32;     // activations stored as bf16 (one plane, or hi + lo planes)
+  static constexpr int PLANES = PREC == kPrecF16x3 ? 2 : 1;
   static constexpr int L = 4 * (N > 1 ? N - 1 : 1);
   static constexpr int SW = 8;            // ws_self row: 6 weights, bias, pad
   static constexpr int OW = L + 4;        // ws_oth row: L weights, bias, pad (multiple of 4 floats)
   static constexpr int KU = kH1S + kH1O;  // 192 first-layer units = K of the second layer
   static constexpr int HB = KU + 8;       // bf16 row: 200 halfwords = 400 B (16-byte aligned rows)
   static constexpr int XW = 6 + L + 1;    // input tile row: [v_obs(4) | v_goal(2) | obs_others(L)], odd stride
-  static constexpr int kH1Floats = BF16 ? (64 * HB) / 2 : 64 * (KU + 1);
+  static constexpr int kH1Floats = BF16 ? PLANES * (64 * HB) / 2 : 64 * (KU + 1);
   static_assert(64 * (kH2 + 1) <= kH1Floats, "h2 must fit into the h1 storage");
 };
 
 // Views into the workgroup's LDS (declared by the kernel with CM3_ACTOR_LDS).  h2 reuses the h1 storage once every wave
 // is done reading h1, which keeps the workgroup at 66 KB (f32) / 42 KB (bf16) so that two workgroups fit a CU.
-template <int N, bool BF16> struct ActorLds {
-  using G = ActorGeom<N, BF16>;
+template <int N, int PREC> struct ActorLds {
+  using G = ActorGeom<N, PREC>;
   float (*ws_self)[G::SW];
   float (*ws_oth)[G::OW];
   const float *wout;
   float (*h1s)[G::KU + 1];
-  __bf16 (*h1b)[G::HB];
+  __bf16 (*h1b)[G::HB];     // kPrecBf16: bf16 activations
+  _Float16 (*h1h)[G::HB];   // kPrecF16x3: the hi plane ...
+  _Float16 (*h1l)[G::HB];   // ... and the lo plane
   float (*h2s)[kH2 + 1];
   float (*xs)[G::XW];
   float *tables;
@@ -148,30 +180,42 @@ template <int N, bool BF16> struct ActorLds {
   name.wout = &name##_tables[PackLayout<N_>::kOut];                                                            \
   name.h1s = reinterpret_cast<float (*)[ActorGeom<N_, BF16_>::KU + 1]>(name##_h1raw);                          \
   name.h1b = reinterpret_cast<__bf16 (*)[ActorGeom<N_, BF16_>::HB]>(name##_h1raw);                             \
+  name.h1h = reinterpret_cast<_Float16 (*)[ActorGeom<N_, BF16_>::HB]>(name##_h1raw);                           \
+  name.h1l = reinterpret_cast<_Float16 (*)[ActorGeom<N_, BF16_>::HB]>(name##_h1raw) + 64;                      \
   name.h2s = reinterpret_cast<float (*)[kH2 + 1]>(name##_h1raw);                                               \
   name.xs = name##_xs
 
 // first-layer tables + output layer -> LDS: straight 16-byte copies of the packed prefix
-template <int N, bool BF16>
-__device__ __forceinline__ void actor_stage_tables(const ActorLds<N, BF16> &lds, const float *packed, int tid) {
+template <int N, int PREC>
+__device__ __forceinline__ void actor_stage_tables(const ActorLds<N, PREC> &lds, const float *packed, int tid) {
   const float4 *src = reinterpret_cast<const float4 *>(packed);
   float4 *dst = reinterpret_cast<float4 *>(lds.tables);
   for (int t = tid; t < PackLayout<N>::kTables / 4; t += 256) dst[t] = src[t];
 }
 
 // B operands of this wave's 16 columns of W2 = [W_branch_self_h2 ; W_others_h2] and their bias, kept in VGPRs
-template <int N, bool BF16> struct ActorB {
-  using G = ActorGeom<N, BF16>;
-  float bw[BF16 ? 1 : G::KU / 4];
-  bf16x8 bwb[BF16 ? G::KU / 32 : 1];
+template <int N, int PREC> struct ActorB {
+  using G = ActorGeom<N, PREC>;
+  float bw[PREC == kPrecF32 ? G::KU / 4 : 1];
+  bf16x8 bwb[PREC == kPrecBf16 ? G::KU / 32 : 1];       // kPrecBf16: bf16 weights
+  f16x8 bwh[PREC == kPrecF16x3 ? G::KU / 32 : 1];       // kPrecF16x3: the hi parts ...
+  f16x8 bwl[PREC == kPrecF16x3 ? G::KU / 32 : 1];       // ... and the lo parts
   float bias_h2;
 };
 
-template <int N, bool BF16>
-__device__ __forceinline__ void actor_load_b(const float *packed, int w, int lane, ActorB<N, BF16> &b) {
-  using G = ActorGeom<N, BF16>;
+template <int N, int PREC>
+__device__ __forceinline__ void actor_load_b(const float *packed, int w, int lane, ActorB<N, PREC> &b) {
+  using G = ActorGeom<N, PREC>;
   using PL = PackLayout<N>;
-  if constexpr (BF16) {
+  if constexpr (PREC == kPrecF16x3) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(packed + PL::kW2x) + (size_t)(w * 64 + lane) * (G::KU / 16);
+#pragma unroll
+    for (int s = 0; s < G::KU / 32; ++s) {
+      const uint4 hi = src[2 * s], lo = src[2 * s + 1];
+      __builtin_memcpy(&b.bwh[s], &hi, 16);
+      __builtin_memcpy(&b.bwl[s], &lo, 16);
+    }
+  } else if constexpr (PREC == kPrecBf16) {
     const uint4 *src = reinterpret_cast<const uint4 *>(packed + PL::kW2b) + (size_t)(w * 64 + lane) * (G::KU / 32);
 #pragma unroll
     for (int s = 0; s < G::KU / 32; ++s) {
@@ -218,10 +262,11 @@ __device__ __forceinline__ void actor_first_b(const T *self_tab, const T *oth_ta
 // xs tile + tables ready and synchronised on entry; h2s ready and synchronised on exit (3 barriers inside).  The lane's
 // phase-A B operands are read from the LDS tables ONCE, up front (measured -0.9 % per launch against reading them inside each
 // block: 8.80 -> 8.72 us at 16 384 rows, same box).
-template <int N, bool BF16>
-__device__ __forceinline__ void actor_mlp(const ActorLds<N, BF16> &lds, const ActorB<N, BF16> &b, int w, int lane,
+template <int N, int PREC>
+__device__ __forceinline__ void actor_mlp(const ActorLds<N, PREC> &lds, const ActorB<N, PREC> &b, int w, int lane,
                                           bool stage2) {
-  using G = ActorGeom<N, BF16>;
+  using G = ActorGeom<N, PREC>;
+  constexpr bool BF16 = G::BF16;
   constexpr int L = G::L, KU = G::KU;
   const int col = lane & 15, hi = lane >> 4, c0 = 16 * w;
   ActorFirstB<N> f1;
@@ -247,7 +292,11 @@ __device__ __forceinline__ void actor_mlp(const ActorLds<N, BF16> &lds, const Ac
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
           const float h = fmaxf(c[reg] + bias, 0.0f);
-          if constexpr (BF16) lds.h1b[16 * t + 4 * hi + reg][unit] = (__bf16)h;
+          if constexpr (PREC == kPrecF16x3) {
+            const _Float16 hh = (_Float16)h;
+            lds.h1h[16 * t + 4 * hi + reg][unit] = hh;
+            lds.h1l[16 * t + 4 * hi + reg][unit] = (_Float16)(h - (float)hh);
+          } else if constexpr (BF16) lds.h1b[16 * t + 4 * hi + reg][unit] = (__bf16)h;
           else lds.h1s[16 * t + 4 * hi + reg][unit] = h;
         }
       }
@@ -264,7 +313,11 @@ __device__ __forceinline__ void actor_mlp(const ActorLds<N, BF16> &lds, const Ac
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
           const float h = fmaxf(c[reg] + bias, 0.0f);  // stage 1: exactly 0, the others branch is absent
-          if constexpr (BF16) lds.h1b[16 * t + 4 * hi + reg][kH1S + unit] = (__bf16)h;
+          if constexpr (PREC == kPrecF16x3) {
+            const _Float16 hh = (_Float16)h;
+            lds.h1h[16 * t + 4 * hi + reg][kH1S + unit] = hh;
+            lds.h1l[16 * t + 4 * hi + reg][kH1S + unit] = (_Float16)(h - (float)hh);
+          } else if constexpr (BF16) lds.h1b[16 * t + 4 * hi + reg][kH1S + unit] = (__bf16)h;
           else lds.h1s[16 * t + 4 * hi + reg][kH1S + unit] = h;
         }
       }
@@ -277,7 +330,19 @@ __device__ __forceinline__ void actor_mlp(const ActorLds<N, BF16> &lds, const Ac
   f32x4 acc[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-  if constexpr (BF16) {
+  if constexpr (PREC == kPrecF16x3) {
+#pragma unroll
+    for (int s = 0; s < KU / 32; ++s) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {  // the two small terms first, then hi x hi
+        const f16x8 ah = *reinterpret_cast<const f16x8 *>(&lds.h1h[16 * t + col][32 * s + 8 * hi]);
+        const f16x8 al = *reinterpret_cast<const f16x8 *>(&lds.h1l[16 * t + col][32 * s + 8 * hi]);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, b.bwh[s], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, b.bwl[s], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, b.bwh[s], acc[t], 0, 0, 0);
+      }
+    }
+  } else if constexpr (BF16) {
 #pragma unroll
     for (int s = 0; s < KU / 32; ++s) {
 #pragma unroll
@@ -342,10 +407,10 @@ __device__ __forceinline__ void actor_head_probs(const float (*h2s)[kH2 + 1], co
   for (int a = 0; a < kA; ++a) pr[a] = (1.0f - eps) * (o[a] * inv) + eps / (float)kA;
 }
 
-template <int N, bool BF16> __global__ void __launch_bounds__(256) k_actor_particle(const ActorParams p) {
-  using G = ActorGeom<N, BF16>;
+template <int N, int PREC> __global__ void __launch_bounds__(256) k_actor_particle(const ActorParams p) {
+  using G = ActorGeom<N, PREC>;
   constexpr int L = G::L;
-  CM3_ACTOR_LDS(N, BF16, lds);
+  CM3_ACTOR_LDS(N, PREC, lds);
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const size_t rows = (size_t)p.E * N;
@@ -366,7 +431,7 @@ template <int N, bool BF16> __global__ void __launch_bounds__(256) k_actor_parti
   // first-layer operands straight from global memory into registers instead of the table copy (+9 %: the entry is bound by the
   // request throughput of 256 workgroups reading the same few KB of L2, and narrow per-lane requests are worse than the wide
   // copy), the Philox draw before the first barrier (+0.5 %), input rows staged by all four waves (+-0), both (+1.1 %).
-  actor_stage_tables<N, BF16>(lds, p.packed, tid);
+  actor_stage_tables<N, PREC>(lds, p.packed, tid);
   CM3_STAMP(8, false);
   if (w == 0) {  // wave 0 stages the 64 input rows [v_obs(4) | v_goal(2) | obs_others(L)] into LDS, one row per lane
     const size_t r = row_base + lane;
@@ -386,13 +451,13 @@ template <int N, bool BF16> __global__ void __launch_bounds__(256) k_actor_parti
     }
   }
   CM3_STAMP(9, false);
-  ActorB<N, BF16> b;
-  actor_load_b<N, BF16>(p.packed, w, lane, b);
+  ActorB<N, PREC> b;
+  actor_load_b<N, PREC>(p.packed, w, lane, b);
   CM3_STAMP(10, false);
   CM3_STAMP(1, true);
   __syncthreads();
   CM3_STAMP(2, false);
-  actor_mlp<N, BF16>(lds, b, w, lane, p.stage > 1);
+  actor_mlp<N, PREC>(lds, b, w, lane, p.stage > 1);
   float pr[kA];
   actor_head_probs(lds.h2s, lds.wout, w, lane, p.eps_dev ? *p.eps_dev : p.eps, pr);
   const int act = actor_sample(pr, p.seed, (uint64_t)(p.env_id_base + (int64_t)he), head_episode, head_steps, hi_agent);
@@ -409,10 +474,12 @@ template <int N, bool BF16> __global__ void __launch_bounds__(256) k_actor_parti
 template <int N> static int actor_launch(const ActorParams &p, hipStream_t s) {
   const size_t rows = (size_t)p.E * N;
   const unsigned blocks = (unsigned)((rows + 63) / 64);
-  if (p.bf16)
-    hipLaunchKernelGGL((k_actor_particle<N, true>), dim3(blocks), dim3(256), 0, s, p);
+  if (p.bf16 == kPrecF16x3)
+    hipLaunchKernelGGL((k_actor_particle<N, kPrecF16x3>), dim3(blocks), dim3(256), 0, s, p);
+  else if (p.bf16 == kPrecBf16)
+    hipLaunchKernelGGL((k_actor_particle<N, kPrecBf16>), dim3(blocks), dim3(256), 0, s, p);
   else
-    hipLaunchKernelGGL((k_actor_particle<N, false>), dim3(blocks), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((k_actor_particle<N, kPrecF32>), dim3(blocks), dim3(256), 0, s, p);
   CM3_HIP_CHECK(hipGetLastError());
   return CM3_OK;
 }
@@ -492,7 +559,7 @@ extern "C" int cm3_actor_particle_f32(const cm3_actor_particle_desc *d, const cm
               "supported actor widths are 64/128/64/5 (config.json nn block); got %d/%d/%d/%d", d->n_h1_self,
               d->n_h1_others, d->n_h2, d->n_actions);
   CM3_REQUIRE(d->epsilon >= 0.0f && d->epsilon <= 1.0f, "epsilon must be in [0,1]");
-  CM3_REQUIRE(d->precision == 0 || d->precision == 1, "precision must be 0 (float32) or 1 (bf16 second layer)");
+  CM3_REQUIRE(d->precision >= 0 && d->precision <= 2, "precision must be 0 (float32), 1 (bf16 second layer) or 2 (split float16)");
   CM3_REQUIRE(wt->packed, "weights->packed is NULL: run cm3_actor_particle_pack once per weight update");
   CM3_REQUIRE(b->obs_others && b->state && b->goals && b->meta && b->episode && b->actions, "missing buffers");
   ActorParams p;
@@ -501,7 +568,7 @@ extern "C" int cm3_actor_particle_f32(const cm3_actor_particle_desc *d, const cm
   p.stage = d->stage;
   p.eps = d->epsilon;
   p.eps_dev = b->epsilon_dev;
-  p.bf16 = d->precision == 1 ? 1 : 0;
+  p.bf16 = d->precision;
   p.env_id_base = d->env_id_base;
   p.seed = d->seed;
   p.obs_others = (const float *)b->obs_others;

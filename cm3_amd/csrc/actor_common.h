@@ -10,6 +10,7 @@ constexpr uint32_t kPurposePolicy = 0x40000000u;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // action ~ multinomial(probs) (alg_credit.py:120): inverse CDF in action order, one uniform from the Philox stream
 // keyed (seed, global env id, episode, step | agent)

@@ -35,7 +35,7 @@ struct PolicyParams {
   int stage;
 };
 
-template <int N, bool BF16> __global__ void __launch_bounds__(256) k_policy_rollout(const PolicyParams q) {
+template <int N, int BF16> __global__ void __launch_bounds__(256) k_policy_rollout(const PolicyParams q) {
   using G = ActorGeom<N, BF16>;
   using V4 = float4;
   using V2 = float2;
@@ -233,13 +233,15 @@ template <int N, bool BF16> __global__ void __launch_bounds__(256) k_policy_roll
   }
 }
 
-template <int N> static int policy_launch(const PolicyParams &q, bool bf16, hipStream_t s) {
+template <int N> static int policy_launch(const PolicyParams &q, int prec, hipStream_t s) {
   const size_t rows = (size_t)q.p.E * N;
   const unsigned blocks = (unsigned)((rows + 63) / 64);
-  if (bf16)
-    hipLaunchKernelGGL((k_policy_rollout<N, true>), dim3(blocks), dim3(256), 0, s, q);
+  if (prec == kPrecF16x3)
+    hipLaunchKernelGGL((k_policy_rollout<N, kPrecF16x3>), dim3(blocks), dim3(256), 0, s, q);
+  else if (prec == kPrecBf16)
+    hipLaunchKernelGGL((k_policy_rollout<N, kPrecBf16>), dim3(blocks), dim3(256), 0, s, q);
   else
-    hipLaunchKernelGGL((k_policy_rollout<N, false>), dim3(blocks), dim3(256), 0, s, q);
+    hipLaunchKernelGGL((k_policy_rollout<N, kPrecF32>), dim3(blocks), dim3(256), 0, s, q);
   CM3_HIP_CHECK(hipGetLastError());
   return CM3_OK;
 }
@@ -310,7 +312,8 @@ extern "C" int cm3_policy_rollout_f32(const cm3_particle_desc *d, const cm3_part
   q.eps = ad->epsilon;
   q.stage = ad->stage;
   hipStream_t s = (hipStream_t)stream;
-  const bool bf16 = ad->precision == 1;
+  CM3_REQUIRE(ad->precision >= 0 && ad->precision <= 2, "precision must be 0, 1 or 2");
+  const int bf16 = ad->precision;
   switch (d->n_agents) {
     case 1: return policy_launch<1>(q, bf16, s);
     case 2: return policy_launch<2>(q, bf16, s);

@@ -311,9 +311,12 @@ typedef struct cm3_actor_particle_desc {
   int32_t stage;       /* 1: self branch only; 2: + others branch */
   int32_t n_h1_self, n_h1_others, n_h2, n_actions; /* 64, 128, 64, 5 */
   float epsilon;
-  int32_t precision;   /* 0: float32 throughout (parity path; exact-f32 MFMA).  1: second layer on the bf16 matrix
-                          cores with float32 accumulation (activations and W2 rounded to bf16; probabilities move by
-                          up to ~1e-2) */
+  int32_t precision;   /* 0: float32 throughout (exact-f32 MFMA: a k-ordered fmaf chain).  1: second layer on the bf16
+                          matrix cores with float32 accumulation (activations and W2 rounded to bf16; probabilities move
+                          by up to ~1e-2).  2: SPLIT float16 -- activations and W2 as hi + lo float16 pairs, three f16 MFMA
+                          passes (hi hi + hi lo + lo hi), float32 accumulation (22 of 24 significand bits per factor):
+                          probabilities within the 2e-5 of the float64 oracle that precision 0 is held to, ~5x fewer
+                          matrix-core cycles; first-layer activations must stay below 65504 */
   int32_t _pad;
   int64_t env_id_base;
   uint64_t seed;

@@ -18,7 +18,10 @@ def _env(E, N, cfg, max_steps=33, **kw):
 @pytest.mark.parametrize("N,cfg,stage", [(4, "particle_stage2_antipodal.json", 2), (2, "particle_stage2_merge.json", 2),
                                          (1, "particle_stage1.json", 1), (8, "particle_merge8.json", 2)])
 @pytest.mark.parametrize("eps", [0.0, 0.3])
-def test_actor_probs_and_samples_match_oracle(N, cfg, stage, eps):
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_actor_probs_and_samples_match_oracle(N, cfg, stage, eps, precision):
+    """precision "f16x3" (split float16: hi hi + hi lo + lo hi on the f16 matrix cores) is held to the SAME bound as the
+    exact float32 path: 2e-5 on every probability, identical actions off CDF boundaries."""
     from cm3_amd.actor import ParticleActor
     E, seed = 1000, 77
     rng = np.random.default_rng(N * 10 + stage)
@@ -27,7 +30,7 @@ def test_actor_probs_and_samples_match_oracle(N, cfg, stage, eps):
     env.reset()
     for _ in range(3):
         env.step()
-    actor = ParticleActor(w, N, stage=stage, device="cuda:0", seed=seed)
+    actor = ParticleActor(w, N, stage=stage, device="cuda:0", seed=seed, precision=precision)
     actions, probs = actor.act(env, eps, return_probs=True)
     gs, oo = env.get_obs()
     rows = E * N
@@ -154,7 +157,7 @@ def test_bf16_second_layer_is_close_to_float32(N, cfg):
 @pytest.mark.parametrize("N,cfg", [(4, "particle_stage2_cross.json"), (2, "particle_stage2_merge.json"),
                                     (8, "particle_merge8.json"), (1, "particle_stage1.json")])
 @pytest.mark.parametrize("auto_reset", [False, True])
-@pytest.mark.parametrize("precision", ["f32", "bf16"])
+@pytest.mark.parametrize("precision", ["f32", "bf16", "f16x3"])
 def test_fused_policy_rollout_equals_launch_per_tick(N, cfg, auto_reset, precision):
     """csrc/policy.hip -- a whole policy-driven episode in one launch, or ONE fused launch per tick (eager and as a
     captured graph) -- is bit-identical to alternating actor / step launches: trajectories, sampled actions, terminal
@@ -189,8 +192,9 @@ def test_fused_policy_rollout_equals_launch_per_tick(N, cfg, auto_reset, precisi
         ro.close()
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
 @pytest.mark.parametrize("tag,N,stage", [("n4_stage2", 4, 2), ("n1_stage1", 1, 1), ("n8_stage2", 8, 2)])
-def test_device_actor_matches_vectors_from_the_reference_function_body(tag, N, stage):
+def test_device_actor_matches_vectors_from_the_reference_function_body(tag, N, stage, precision):
     """tests/golden/actor_particle.npz: probabilities obtained by executing the reference's networks.actor_particle under
     the NumPy TF stand-in (oracle/gen_golden_actor.py).  The rows are laid out as E = rows / N envs for the kernel."""
     from cm3_amd.actor import ParticleActor
@@ -206,5 +210,6 @@ def test_device_actor_matches_vectors_from_the_reference_function_body(tag, N, s
     episode = torch.zeros(E, dtype=torch.int32, device=dev)
     actions = torch.empty(E, N, dtype=torch.int32, device=dev)
     probs = torch.empty(E, N, 5, dtype=torch.float32, device=dev)
-    ParticleActor(w, N, stage=stage, device=dev).enqueue(E, obs, state, goals, meta, episode, actions, 0.0, probs)
+    ParticleActor(w, N, stage=stage, device=dev, precision=precision).enqueue(E, obs, state, goals, meta, episode, actions,
+                                                                             0.0, probs)
     assert np.abs(probs.reshape(rows, 5).cpu().numpy() - want).max() < 2e-5
