@@ -86,7 +86,7 @@ class ParticleStepper(GraphStepper):
     trajectory is stored).  Used for the E-sweep and as the labelled `in_place` extra."""
 
     def __init__(self, cfg, n_agents, n_envs, device, seed=12341, env_id_base=0, max_steps=33, prob_random=0.2,
-                 kernel="auto", fused=False, n_chains=1):
+                 kernel="auto", fused=False, n_chains=1, tensor_actions=False):
         import torch
         from cm3_amd import _lib
         from cm3_amd.particle import VecParticleEnv
@@ -96,6 +96,9 @@ class ParticleStepper(GraphStepper):
         self.env.reset()
         e = self.env
         e._desc.flags = _lib.FLAG_AUTO_RESET | _lib.FLAG_GEN_ACTIONS | e.kernel_flags
+        if tensor_actions:      # the policy-provided-actions branch (train_onpolicy.py:311-313): the step launch READS its actions
+            e._desc.flags &= ~_lib.FLAG_GEN_ACTIONS
+            e._actions[0].random_(0, 5)
         self.fused = bool(fused)
         if self.fused:       # all ticks of an enqueue() in ONE launch (state in registers)
             e._desc.flags |= _lib.FLAG_FUSED_TICKS
@@ -234,16 +237,19 @@ class RolloutAdvStepper(object):
         self.device = self.env.device
         self.last = None
         self.launches_per_tick = int(n_chains)
+        self.collective_s, self.rollouts = 0.0, 0     # host time inside the all-gather call, summed over rollouts
 
     def capture(self, n_ticks):
         pass
 
     def run(self, n_ticks):
-        from cm3_amd.shard import normalized_returns
         assert n_ticks % EP_TICKS == 0, "c4 runs whole 33-tick rollouts"
         for _ in range(n_ticks // EP_TICKS):
-            self.ro.collect(reset=False)
-            self.last = normalized_returns(self.ro.reward_n, self.ro.done, None, gamma=0.99)
+            # one rank: slot copies + 33 step launches + returns / moments + normalise = ONE hipGraph replay; several ranks:
+            # the graph ends at the moments, the 24-byte all-gather (RCCL) and the normalise launch follow
+            *self.last, t_coll = self.ro.collect_normalized(gamma=0.99, time_collective=True)
+            self.collective_s += t_coll
+            self.rollouts += 1
 
     def close(self):
         self.ro.close()
@@ -465,6 +471,17 @@ def pmc_traffic(tag):
     return rec["hbm_bytes_per_launch"], rec
 
 
+def span_record(tag):
+    """The undisturbed kernel-duration record of this workload (profiles/r03_kernel_span.json, written by tools/kernel_span.py
+    from the two-stamp build on an UNPROFILED 330-launch hipGraph): per-launch span (first wave in -> last wave out) and
+    start-to-start; None if absent.  rocprofv3's kernel-trace average is not used for this: it exceeds the unprofiled time per
+    launch (the profiler stretches every dispatch of a launch-bound graph)."""
+    path = os.path.join(ROOT, "profiles", "r03_kernel_span.json")
+    if not os.path.exists(path):
+        return None
+    return json.load(open(path)).get(tag)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -479,7 +496,31 @@ def self_spawn(n_gpus):
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")          # one launch thread per rank; the host side is a hipGraph replay loop
     return subprocess.call(cmd, env=env)
+
+
+def pin_rank_to_gpu_numa_node(device_index):
+    """Best effort: bind this rank's host threads to the CPUs of the NUMA node its GPU hangs off (the launch thread then
+    writes AQL packets / kernel arguments from local memory).  Returns a short description for the JSON line; never raises."""
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(device_index)
+        bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read().strip())
+        if node < 0:
+            return "%s: no NUMA affinity reported" % bdf
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return "%s: NUMA node %d has no allowed CPU" % (bdf, node)
+        os.sched_setaffinity(0, cpus)
+        return "%s: NUMA node %d, %d CPUs" % (bdf, node, len(cpus))
+    except Exception as exc:
+        return "not pinned (%s)" % type(exc).__name__
 
 
 def build_headline(args, kind, cfg, N, E, device, rank, n_chains):
@@ -564,6 +605,7 @@ def main():
         graft.build()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    pinned = pin_rank_to_gpu_numa_node(local_rank) if under_launcher else "single process: not pinned"
     # everything (launches, graph replays, HIP events) goes on one explicit non-default stream
     bench_stream = torch.cuda.Stream(device=device)
     torch.cuda.set_stream(bench_stream)
@@ -594,6 +636,8 @@ def main():
             dist.barrier(device_ids=[local_rank])
 
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if kind == "particle_adv":
+        stepper.collective_s, stepper.rollouts = 0.0, 0
     barrier()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
@@ -661,8 +705,17 @@ def main():
                          "clock": "wall clock of the timed region (max over ranks) for value, avg_launch_us and achieved alike; "
                                   "avg_launch_us_hip_events = HIP events on the launch stream around the same region"},
             "per_rank": [{"rank": r, "wall_s": w_, "avg_launch_us": w_ / launches * 1e6,
-                          "avg_launch_us_hip_events": e_ / launches * 1e6} for r, (w_, e_) in enumerate(per_rank)],
+                          "avg_launch_us_hip_events": e_ / launches * 1e6, "env_id_base": r * E, "envs": E}
+                         for r, (w_, e_) in enumerate(per_rank)],
+            "rank0_host_affinity": pinned,
         }
+        if kind == "particle_adv":
+            out["collective"] = {
+                "what": "all_gather_into_tensor of 3 float64 per rank (advantage moments), once per rollout",
+                "host_us_per_rollout_rank0": stepper.collective_s / max(stepper.rollouts, 1) * 1e6,
+                "share_of_step_rank0": stepper.collective_s / max(wall, 1e-12),
+                "note": ("one rank: the collective is the identity and the whole rollout + normalisation is ONE hipGraph replay"
+                         if world == 1 else "host time of the all-gather call (enqueue + any wait it implies), rank 0")}
     traffic_tag = {("c2", 4096, "trajectory"): "c2_trajectory_n4_e4096", ("c2", 4096, "in-place"): "c2_particle_antipodal_n4_e4096",
                    ("c3", 8192, "in-place"): "c3_checkers_stage2_n2_e8192", ("c3", 8192, "trajectory"): "c3_trajectory_n2_e8192",
                    ("c5", 8192, "in-place"): "c5_particle_merge8_n8_e8192",
@@ -674,6 +727,16 @@ def main():
             out["roofline"]["traffic_source"] = ("profiles/pmc_traffic.json: %s, %d launches, FETCH_SIZE %.1f KB (x2) + "
                                                  "WRITE_SIZE %.1f KB" % (rec["kernel"], rec["launches"],
                                                                          rec["FETCH_SIZE_KB"], rec["WRITE_SIZE_KB"]))
+    if rank == 0 and not args.fused and n_chains == 1:
+        rec = span_record("%s_%s" % (args.workload, mode.replace("-", "_")))
+        if rec and E == default_e:
+            out["roofline"]["kernel_span"] = {
+                "span_us": rec["span_us_mean"], "start_to_start_us": rec["start_to_start_us_mean"], "gap_us": rec["gap_us_mean"],
+                "achieved_GBps_over_span": bytes_per_launch / (rec["span_us_mean"] * 1e-6) / 1e9,
+                "frac_of_peak_over_span": bytes_per_launch / (rec["span_us_mean"] * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                "source": "profiles/r03_kernel_span.json (tools/kernel_span.py, two-stamp build, unprofiled 330-launch hipGraph): "
+                          "span = first wave in -> last wave out; start-to-start includes the dependent-launch boundary and is "
+                          "what roofline.avg_launch_us of THIS run measures live"}
     extras = world == 1 and rank == 0 and not args.no_extras and not args.fused
     if extras and kind in ("particle", "checkers"):
         stepper.close()
@@ -743,50 +806,77 @@ def main():
                   "stage-2/W_others_h2": (128, 64), "b": (64,), "actor_out/kernel": (64, 5), "actor_out/bias": (5,)}
         wts = {k: (rng.standard_normal(v) * 0.1).astype(np.float32) for k, v in shapes.items()}
         pol = {}
-        for label, fused, ftick in (("launch_per_tick", False, False), ("fused_launch_per_tick", False, True),
-                                    ("one_launch_per_episode", True, False)):
+        macs = 6 * 64 + Lo * 128 + 64 * 64 + 128 * 64 + 64 * 5
+        for prec in ("f32", "f16x3"):
+            sub = {}
+            for label, kw in (("launch_per_tick", dict(policy_mode="tick")),
+                              ("fused_launch_per_tick", dict(policy_mode="tick", fused_policy_tick=True)),
+                              ("one_launch_per_episode", dict())):          # the default of collect(policy=...): policy_mode="auto"
+                if prec != "f32" and label == "fused_launch_per_tick":
+                    continue
+                penv = VecParticleEnv(cfg, N, 0.2, 33, E, device=device, auto_reset=True)
+                penv.reset()
+                actor = ParticleActor(wts, N, stage=2, device=device, precision=prec)
+                ro = ParticleRollout(penv, n_ticks=EP_TICKS, use_graph=True, **kw)
+                for _ in range(3):
+                    ro.collect(policy=actor, epsilon=0.1, reset=False)
+                torch.cuda.synchronize(device)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                reps = 20
+                e0.record()
+                for _ in range(reps):
+                    ro.collect(policy=actor, epsilon=0.1, reset=False)
+                e1.record()
+                e1.synchronize()
+                us = e0.elapsed_time(e1) * 1e3 / (reps * EP_TICKS)
+                tfl = 2.0 * macs * E * N / (us * 1e-6) / 1e12
+                sub[label] = {"us_per_tick": us, "env_steps_per_s": E / us * 1e6,
+                              "network_TFLOPs": tfl, "frac_of_f32_mfma_peak": tfl / MFMA_F32_PEAK_TFLOPS}
+                ro.close()
+            # the actor kernel alone (hipGraph of 100 launches: start-to-start, no host allocation inside)
             penv = VecParticleEnv(cfg, N, 0.2, 33, E, device=device, auto_reset=True)
             penv.reset()
-            actor = ParticleActor(wts, N, stage=2, device=device)
-            ro = ParticleRollout(penv, n_ticks=EP_TICKS, use_graph=True, fused=fused, fused_policy_tick=ftick)
+            actor = ParticleActor(wts, N, stage=2, device=device, precision=prec)
+            acts = torch.empty(E, N, dtype=torch.int32, device=device)
+            from cm3_amd import _lib as _l
+
+            def enq(s_, actor=actor, penv=penv, acts=acts):
+                for _ in range(100):
+                    actor.enqueue(E, penv._obs_others[penv._cur], penv._state[penv._cur], penv._goals, penv._meta, penv._episode,
+                                  acts, 0.1, stream=s_, env_id_base=0)
+            g = _l.capture_graph(device, enq)
+            sh = _l.current_stream_handle(device)
             for _ in range(3):
-                ro.collect(policy=actor, epsilon=0.1, reset=False)
+                _l.check(_l.lib().cm3_graph_launch(g, sh))
             torch.cuda.synchronize(device)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            reps = 20
             e0.record()
-            for _ in range(reps):
-                ro.collect(policy=actor, epsilon=0.1, reset=False)
+            for _ in range(10):
+                _l.check(_l.lib().cm3_graph_launch(g, sh))
             e1.record()
             e1.synchronize()
-            us = e0.elapsed_time(e1) * 1e3 / (reps * EP_TICKS)
-            pol[label] = {"us_per_tick": us, "env_steps_per_s": E / us * 1e6}
-            ro.close()
-        # the actor kernel alone against the f32 matrix-core peak (FLOPs of the network itself)
-        penv = VecParticleEnv(cfg, N, 0.2, 33, E, device=device, auto_reset=True)
-        penv.reset()
-        actor = ParticleActor(wts, N, stage=2, device=device)
-        for _ in range(3):
-            actor.act(penv, 0.1)
-        torch.cuda.synchronize(device)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(50):
-            actor.act(penv, 0.1)
-        e1.record()
-        e1.synchronize()
-        a_us = e0.elapsed_time(e1) * 1e3 / 50
-        macs = 6 * 64 + Lo * 128 + 64 * 64 + 128 * 64 + 64 * 5
-        tfl = 2.0 * macs * E * N / (a_us * 1e-6) / 1e12
-        pol["actor_kernel"] = {"kernel": "k_actor_particle", "avg_launch_us": a_us, "rows": E * N, "macs_per_row": macs,
-                               "roofline": {"bound": "mfma", "achieved": tfl, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                            "frac": tfl / MFMA_F32_PEAK_TFLOPS},
-                               "note": "eager launches incl. the host-side allocation of the action tensor"}
-        pol["note"] = ("extra, not the headline: actor (networks.actor_particle, float32, exact-f32 MFMA) + step per tick with "
-                       "full trajectory storage.  launch_per_tick = an actor launch then a step launch per tick; "
-                       "fused_launch_per_tick = ONE launch per tick doing both; one_launch_per_episode = all 33 ticks in one "
-                       "launch.  The three variants are bit-identical "
-                       "(tests/test_gpu_actor.py::test_fused_policy_rollout_equals_launch_per_tick)")
+            a_us = e0.elapsed_time(e1) * 1e3 / 1000
+            torch.cuda.synchronize(device)
+            _l.lib().cm3_graph_destroy(g)
+            tfl = 2.0 * macs * E * N / (a_us * 1e-6) / 1e12
+            sub["actor_kernel"] = {"kernel": "k_actor_particle<%d, %s>" % (N, prec), "avg_launch_us": a_us, "rows": E * N,
+                                   "macs_per_row": macs,
+                                   "roofline": {"bound": "mfma", "achieved": tfl, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                                "frac": tfl / MFMA_F32_PEAK_TFLOPS},
+                                   "note": "start-to-start inside a hipGraph of 100 launches; FLOPs of the network itself against "
+                                           "the float32 matrix-core peak (f16x3 runs its second layer as three float16 passes)"}
+            pol[prec] = sub
+        best = pol["f16x3"]["one_launch_per_episode"]
+        pol["headline"] = {"what": "policy-driven collection (train_onpolicy.py:311-313), the default of "
+                                   "ParticleRollout.collect(policy=actor): one launch per episode, actor precision f16x3",
+                           "us_per_tick": best["us_per_tick"], "env_steps_per_s": best["env_steps_per_s"],
+                           "roofline": {"bound": "mfma", "achieved": best["network_TFLOPs"], "peak": MFMA_F32_PEAK_TFLOPS,
+                                        "unit": "TFLOP/s", "frac": best["frac_of_f32_mfma_peak"]}}
+        pol["note"] = ("second headline: actor (networks.actor_particle; second layer exact float32 MFMA (f32) or split float16 "
+                       "(f16x3, same 2e-5 parity bound)) + env step per tick with full trajectory storage.  launch_per_tick = an "
+                       "actor launch then a step launch per tick; fused_launch_per_tick = ONE launch per tick doing both; "
+                       "one_launch_per_episode = all 33 ticks in one launch (the default).  The modes are bit-identical per "
+                       "precision (tests/test_gpu_actor.py::test_fused_policy_rollout_equals_launch_per_tick)")
         out["policy_rollout"] = pol
     if extras and kind == "checkers" and cfg["n_agents"] in (1, 2):
         # POLICY-driven Checkers collection (train_onpolicy.py:309-321): the on-device actor (networks.actor_checkers:
@@ -865,26 +955,53 @@ def main():
                 del stepper
                 stepper = None
             sweep = []
+            L3 = 256 << 20
+
+            def point(Es, variant, st, n_ticks, ws_bytes, note):
+                """two timed passes, the second reported: the first measurements after a change of batch size run ~5 % slow
+                whichever kernel they are (profiles/r02_auto_vs_best_all.txt, order check)"""
+                st.run(n_ticks)
+                torch.cuda.synchronize(device)
+                timed_ticks(st, n_ticks)
+                ms = timed_ticks(st, n_ticks)
+                per = ms * 1e-3 / n_ticks
+                gbps = bytes_per_env_step * Es / per / 1e9
+                sweep.append({"envs": Es, "variant": variant, "env_steps_per_s": Es / per, "avg_launch_us": per * 1e6,
+                              "achieved_GBps": gbps, "frac_of_peak": gbps / HBM_PEAK_GBPS,
+                              "frac_of_measured_read": gbps / bw_read, "working_set_bytes": int(ws_bytes),
+                              "cache_resident": bool(ws_bytes < L3), "mode": note})
+                st.close()
+                torch.cuda.empty_cache()
+
+            per_tick = lambda Es: bytes_per_env_step * Es          # noqa: E731  bytes one tick touches (in place: re-used buffers)
             for log2e in (14, 16, 18, 20, 22):
                 Es = 1 << log2e
                 st = ParticleStepper(cfg, N, Es, device, kernel=args.kernel, fused=args.fused)
                 st.capture(EP_TICKS)
-                st.run(EP_TICKS)
-                torch.cuda.synchronize(device)
-                n = EP_TICKS * (10 if log2e <= 18 else 3)
-                # two timed passes, the second reported: the first measurements after a change of batch size run ~5 % slow
-                # whichever kernel they are (profiles/r02_auto_vs_best_all.txt, order check)
-                timed_ticks(st, n)
-                ms = timed_ticks(st, n)
-                per = ms * 1e-3 / n
-                gbps = bytes_per_env_step * Es / per / 1e9
-                sweep.append({"envs": Es, "env_steps_per_s": Es / per, "avg_launch_us": per * 1e6,
-                              "achieved_GBps": gbps, "frac_of_peak": gbps / HBM_PEAK_GBPS,
-                              "frac_of_measured_read": gbps / bw_read,
-                              "mode": "in-place, hipGraph of 33 ticks, second of two timed passes"})
-                st.close()
-                del st
-                torch.cuda.empty_cache()
+                point(Es, "in-place", st, EP_TICKS * (10 if log2e <= 18 else 3), per_tick(Es),
+                      "in place (re-used buffers), hipGraph of 33 ticks, in-kernel actions; second of two timed passes")
+            if not args.fused:
+                # SURVEY.md section 8(d) "Extra sweep": the same kernels (a) streaming into a trajectory (every tick its own
+                # slot: nothing is re-used, non-temporal / write-through stores), (b) reading policy-provided actions instead of
+                # drawing them, (c) launched eagerly instead of as a hipGraph
+                for log2e in (12, 16, 18, 20):
+                    Es = 1 << log2e
+                    T = EP_TICKS
+                    st = TrajectoryStepper(cfg, N, Es, device, kernel=args.kernel, phase_ticks=T)
+                    slots = (T + 1) * Es * (16 * N + 8 * N + 16 * N * max(N - 1, 1)) + T * Es * (8 * N + 9) + \
+                        T * Es * (16 * N + 16 * N * max(N - 1, 1) + 4)
+                    point(Es, "trajectory", st, T * (10 if log2e <= 16 else 3), slots,
+                          "trajectory mode: slots t -> t+1 of a [34, E, ...] device trajectory incl. terminal capture, one hipGraph "
+                          "replay per 33-tick collect")
+                for log2e in (12, 16, 20):
+                    Es = 1 << log2e
+                    st = ParticleStepper(cfg, N, Es, device, kernel=args.kernel, tensor_actions=True)
+                    st.capture(EP_TICKS)
+                    point(Es, "in-place, tensor actions", st, EP_TICKS * (10 if log2e <= 16 else 3), per_tick(Es),
+                          "in place, hipGraph of 33 ticks, actions READ from a device tensor (the policy-provided branch)")
+                    st = ParticleStepper(cfg, N, Es, device, kernel=args.kernel)
+                    point(Es, "in-place, eager launches", st, EP_TICKS * (10 if log2e <= 16 else 3), per_tick(Es),
+                          "in place, in-kernel actions, 33 eager launches per enqueue (no hipGraph)")
             out["sweep"] = sweep
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_checkers(cfg) if kind == "checkers" else cpu_baseline(cfg, N)

@@ -149,7 +149,8 @@ template <int N, int PREC> struct ActorGeom {
   static constexpr int KU = kH1S + kH1O;  // 192 first-layer units = K of the second layer
   static constexpr int HB = KU + 8;       // bf16 row: 200 halfwords = 400 B (16-byte aligned rows)
   static constexpr int XW = 6 + L + 1;    // input tile row: [v_obs(4) | v_goal(2) | obs_others(L)], odd stride
-  static constexpr int kH1Floats = BF16 ? PLANES * (64 * HB) / 2 : 64 * (KU + 1);
+  static constexpr int HS = KU + 2;        // f32 row: 194 floats (8-byte aligned rows; reads of 16 rows x 2 k hit 32 distinct banks)
+  static constexpr int kH1Floats = BF16 ? PLANES * (64 * HB) / 2 : 64 * HS;
   static_assert(64 * (kH2 + 1) <= kH1Floats, "h2 must fit into the h1 storage");
 };
 
@@ -160,12 +161,13 @@ template <int N, int PREC> struct ActorLds {
   float (*ws_self)[G::SW];
   float (*ws_oth)[G::OW];
   const float *wout;
-  float (*h1s)[G::KU + 1];
+  float (*h1s)[G::HS];
   __bf16 (*h1b)[G::HB];     // kPrecBf16: bf16 activations
   _Float16 (*h1h)[G::HB];   // kPrecF16x3: the hi plane ...
   _Float16 (*h1l)[G::HB];   // ... and the lo plane
   float (*h2s)[kH2 + 1];
   float (*xs)[G::XW];
+  float (*lg)[8];          // logits of the 64 rows (head: C tile -> row per lane)
   float *tables;
 };
 
@@ -173,12 +175,14 @@ template <int N, int PREC> struct ActorLds {
   __shared__ __attribute__((aligned(16))) float name##_tables[PackLayout<N_>::kTables];                        \
   __shared__ __attribute__((aligned(16))) float name##_h1raw[ActorGeom<N_, BF16_>::kH1Floats];                 \
   __shared__ float name##_xs[64][ActorGeom<N_, BF16_>::XW];                                                    \
+  __shared__ float name##_lg[64][8];                                                                           \
   ActorLds<N_, BF16_> name;                                                                                    \
+  name.lg = name##_lg;                                                                                         \
   name.tables = name##_tables;                                                                                 \
   name.ws_self = reinterpret_cast<float (*)[ActorGeom<N_, BF16_>::SW]>(&name##_tables[PackLayout<N_>::kSelf]); \
   name.ws_oth = reinterpret_cast<float (*)[ActorGeom<N_, BF16_>::OW]>(&name##_tables[PackLayout<N_>::kOth]);   \
   name.wout = &name##_tables[PackLayout<N_>::kOut];                                                            \
-  name.h1s = reinterpret_cast<float (*)[ActorGeom<N_, BF16_>::KU + 1]>(name##_h1raw);                          \
+  name.h1s = reinterpret_cast<float (*)[ActorGeom<N_, BF16_>::HS]>(name##_h1raw);                              \
   name.h1b = reinterpret_cast<__bf16 (*)[ActorGeom<N_, BF16_>::HB]>(name##_h1raw);                             \
   name.h1h = reinterpret_cast<_Float16 (*)[ActorGeom<N_, BF16_>::HB]>(name##_h1raw);                           \
   name.h1l = reinterpret_cast<_Float16 (*)[ActorGeom<N_, BF16_>::HB]>(name##_h1raw) + 64;                      \
@@ -237,8 +241,8 @@ __device__ __forceinline__ void actor_load_b(const float *packed, int w, int lan
 // (B[k = l>>4][j = l&15]), read from the unit-major first-layer tables in LDS.
 template <int N> struct ActorFirstB {
   static constexpr int L4 = (4 * (N > 1 ? N - 1 : 1)) / 4;
-  float bs[2], bias_s;
-  float bo[2][L4], bias_o[2];
+  float bs[2], bias_s[4];       // bias of units 16w + 4 (l>>4) + reg: the TRANSPOSED C tile holds four units of one row per lane
+  float bo[2][L4], bias_o[2][4];
 };
 
 template <int N, typename T>
@@ -249,13 +253,15 @@ __device__ __forceinline__ void actor_first_b(const T *self_tab, const T *oth_ta
   const int unit = 16 * w + col;
 #pragma unroll
   for (int s = 0; s < 2; ++s) f.bs[s] = (4 * s + hi < 6) ? self_tab[unit * PL::SW + 4 * s + hi] : 0.0f;
-  f.bias_s = self_tab[unit * PL::SW + 6];
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) f.bias_s[reg] = self_tab[(16 * w + 4 * hi + reg) * PL::SW + 6];
 #pragma unroll
   for (int cq = 0; cq < 2; ++cq) {
     const int uo = 32 * w + 16 * cq + col;
 #pragma unroll
     for (int s = 0; s < ActorFirstB<N>::L4; ++s) f.bo[cq][s] = stage2 ? oth_tab[uo * PL::OW + 4 * s + hi] : 0.0f;
-    f.bias_o[cq] = stage2 ? oth_tab[uo * PL::OW + PL::L] : 0.0f;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) f.bias_o[cq][reg] = stage2 ? oth_tab[(32 * w + 16 * cq + 4 * hi + reg) * PL::OW + PL::L] : 0.0f;
   }
 }
 
@@ -281,45 +287,55 @@ __device__ __forceinline__ void actor_mlp(const ActorLds<N, PREC> &lds, const Ac
 #pragma unroll
       for (int s = 0; s < L / 4; ++s) ao[t][s] = lds.xs[16 * t + col][6 + 4 * s + hi];
     }
-    {  // branch_self
-      const int unit = 16 * w + col;
-      const float bias = f1.bias_s;
+    // TRANSPOSED tiles (round 3): C[i = unit][j = row] = sum_k W1[k][unit] x[row][k] -- the weight operand goes in as A, the input
+    // tile as B (the per-lane registers are the same ones as for C[row][unit]; same products in the same k order, so the values are
+    // bit-identical).  A lane then holds FOUR CONSECUTIVE UNITS of ONE row (row 16t + (l&15), units u0 + 4 (l>>4) + reg): one
+    // ds_write_b64 per four float16 values (two for hi + lo), two per four float32 values -- 24 LDS stores per wave instead of 96 / 48.
+    auto put4 = [&](int row, int unit0, const float (&h)[4]) {
+      if constexpr (PREC == kPrecF16x3) {
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        h4 vh, vl;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          vh[r] = (_Float16)h[r];
+          vl[r] = (_Float16)(h[r] - (float)vh[r]);
+        }
+        *reinterpret_cast<h4 *>(&lds.h1h[row][unit0]) = vh;
+        *reinterpret_cast<h4 *>(&lds.h1l[row][unit0]) = vl;
+      } else if constexpr (BF16) {
+        typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+        b4 vb;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vb[r] = (__bf16)h[r];
+        *reinterpret_cast<b4 *>(&lds.h1b[row][unit0]) = vb;
+      } else {
+        *reinterpret_cast<float2 *>(&lds.h1s[row][unit0]) = make_float2(h[0], h[1]);
+        *reinterpret_cast<float2 *>(&lds.h1s[row][unit0 + 2]) = make_float2(h[2], h[3]);
+      }
+    };
+    {  // branch_self: units 16w .. 16w + 15
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         f32x4 c = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int s = 0; s < 2; ++s) c = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[t][s], f1.bs[s], c, 0, 0, 0);
+        for (int s = 0; s < 2; ++s) c = __builtin_amdgcn_mfma_f32_16x16x4f32(f1.bs[s], ax[t][s], c, 0, 0, 0);
+        float h[4];
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const float h = fmaxf(c[reg] + bias, 0.0f);
-          if constexpr (PREC == kPrecF16x3) {
-            const _Float16 hh = (_Float16)h;
-            lds.h1h[16 * t + 4 * hi + reg][unit] = hh;
-            lds.h1l[16 * t + 4 * hi + reg][unit] = (_Float16)(h - (float)hh);
-          } else if constexpr (BF16) lds.h1b[16 * t + 4 * hi + reg][unit] = (__bf16)h;
-          else lds.h1s[16 * t + 4 * hi + reg][unit] = h;
-        }
+        for (int reg = 0; reg < 4; ++reg) h[reg] = fmaxf(c[reg] + f1.bias_s[reg], 0.0f);
+        put4(16 * t + col, 16 * w + 4 * hi, h);
       }
     }
 #pragma unroll
-    for (int cq = 0; cq < 2; ++cq) {  // actor_others: two 16-unit column tiles
-      const int unit = 32 * w + 16 * cq + col;
-      const float bias = f1.bias_o[cq];
+    for (int cq = 0; cq < 2; ++cq) {  // actor_others: two 16-unit tiles, units 32w + 16cq .. + 15
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         f32x4 c = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int s = 0; s < L / 4; ++s) c = __builtin_amdgcn_mfma_f32_16x16x4f32(ao[t][s], f1.bo[cq][s], c, 0, 0, 0);
+        for (int s = 0; s < L / 4; ++s) c = __builtin_amdgcn_mfma_f32_16x16x4f32(f1.bo[cq][s], ao[t][s], c, 0, 0, 0);
+        float h[4];
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const float h = fmaxf(c[reg] + bias, 0.0f);  // stage 1: exactly 0, the others branch is absent
-          if constexpr (PREC == kPrecF16x3) {
-            const _Float16 hh = (_Float16)h;
-            lds.h1h[16 * t + 4 * hi + reg][kH1S + unit] = hh;
-            lds.h1l[16 * t + 4 * hi + reg][kH1S + unit] = (_Float16)(h - (float)hh);
-          } else if constexpr (BF16) lds.h1b[16 * t + 4 * hi + reg][kH1S + unit] = (__bf16)h;
-          else lds.h1s[16 * t + 4 * hi + reg][kH1S + unit] = h;
-        }
+        for (int reg = 0; reg < 4; ++reg) h[reg] = fmaxf(c[reg] + f1.bias_o[cq][reg], 0.0f);  // stage 1: exactly 0, no others branch
+        put4(16 * t + col, kH1S + 32 * w + 16 * cq + 4 * hi, h);
       }
     }
   }
@@ -370,36 +386,55 @@ __device__ __forceinline__ void actor_mlp(const ActorLds<N, PREC> &lds, const Ac
   CM3_STAMP(6, false);
 }
 
-// Final layer, all four waves: wave w finishes rows [16w, 16w+16).  Lane l takes row 16w + (l&15) and a quarter of the
-// 64 second-layer units (part = l>>4): 16 x 5 FMAs, then the four partial logit vectors are summed across the parts
-// with two xor-shuffles (same order in every lane, so all four copies are identical).  actor_out + softmax
-// (networks.py:536-537), epsilon mix (alg_credit.py:119): returns the mixed probabilities of row 16w + (l&15).
-__device__ __forceinline__ void actor_head_probs(const float (*h2s)[kH2 + 1], const float *wout, int w, int lane,
-                                                 float eps, float (&pr)[kA]) {
-  const int rl = 16 * w + (lane & 15), part = lane >> 4;
+// Final layer, all four waves: wave w finishes rows [16w, 16w+16) on the matrix cores (round 3) -- one 16 x 16 tile, K = 64:
+//   A[i = l&15][k = l>>4] = h2[16w + (l&15)][4s + (l>>4)]   one ds_read_b32 per k-step
+//   B[k = l>>4][j = l&15] = w_out[4s + (l>>4)][j] for j < 5, else 0   (16 VGPRs per lane, ActorHeadB, loaded once per launch)
+// 16 v_mfma_f32_16x16x4_f32 = a k-ordered fmaf chain per logit (exact float32, like the other layers), + bias.  The C tile
+// (col = action, row = 4 (l>>4) + reg) goes through a 2 KB LDS tile so that lane l continues with ALL five logits of row
+// 16w + (l&15): softmax (networks.py:536-537), epsilon mix (alg_credit.py:119).  (The first version gave every lane a quarter of
+// the 64 units: 80 broadcast LDS reads of w_out + 16 of h2 + 80 FMAs + 10 shuffles per lane -- 3.5k of the wave's ~14k cycles per
+// tick; profiles/r03_actor_*.)
+__device__ __forceinline__ void wave_sync_lds() {
+  // LDS operations of one wave execute in issue order; this only keeps the compiler from moving them across the hand-off
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+struct ActorHeadB {
+  float wo[kH2 / 4];
+  float bias;
+};
+__device__ __forceinline__ void actor_head_load(const float *wout, int lane, ActorHeadB &hb) {
+  const int j = lane & 15, hi = lane >> 4;
+#pragma unroll
+  for (int s = 0; s < kH2 / 4; ++s) hb.wo[s] = j < kA ? wout[(4 * s + hi) * kA + j] : 0.0f;
+  hb.bias = j < kA ? wout[kH2 * kA + j] : 0.0f;
+}
+
+__device__ __forceinline__ void actor_head_probs(const float (*h2s)[kH2 + 1], const ActorHeadB &hb, float (*lg)[8], int w,
+                                                 int lane, float eps, float (&pr)[kA]) {
+  const int col = lane & 15, hi = lane >> 4;
+  f32x4 acc = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int s = 0; s < kH2 / 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(h2s[16 * w + col][4 * s + hi], hb.wo[s], acc, 0, 0, 0);
+  if (col < kA) {
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) lg[16 * w + 4 * hi + reg][col] = acc[reg] + hb.bias;
+  }
+  wave_sync_lds();
   float o[kA];
 #pragma unroll
-  for (int a = 0; a < kA; ++a) o[a] = 0.0f;
-#pragma unroll
-  for (int kk = 0; kk < kH2 / 4; ++kk) {
-    const int k = 16 * part + kk;
-    const float hk = h2s[rl][k];
-#pragma unroll
-    for (int a = 0; a < kA; ++a) o[a] = fmaf(hk, wout[k * kA + a], o[a]);
-  }
-#pragma unroll
-  for (int a = 0; a < kA; ++a) {
-    o[a] += __shfl_xor(o[a], 16, 64);
-    o[a] += __shfl_xor(o[a], 32, 64);
-    o[a] += wout[kH2 * kA + a];  // bias
-  }
+  for (int a = 0; a < kA; ++a) o[a] = lg[16 * w + col][a];
   float m = o[0];
 #pragma unroll
   for (int a = 1; a < kA; ++a) m = fmaxf(m, o[a]);
   float sum = 0.0f;
 #pragma unroll
   for (int a = 0; a < kA; ++a) {
-    o[a] = expf(o[a] - m);
+    // exp on the hardware unit (v_exp_f32, base 2, ~1 ulp): the argument is <= 0, the result in (0, 1], and a relative 1e-7 on
+    // a probability is two orders of magnitude inside the 2e-5 the head is held to (libm's expf was ~12 instructions x 5 on the
+    // path of the 16 head lanes of every wave)
+    o[a] = __builtin_amdgcn_exp2f((o[a] - m) * 1.44269504088896340736f);
     sum += o[a];
   }
   const float inv = 1.0f / sum;
@@ -457,10 +492,14 @@ template <int N, int PREC> __global__ void __launch_bounds__(256) k_actor_partic
   CM3_STAMP(1, true);
   __syncthreads();
   CM3_STAMP(2, false);
+  ActorHeadB hb;
+  actor_head_load(lds.wout, lane, hb);      // (the tables are in LDS: synchronised above)
   actor_mlp<N, PREC>(lds, b, w, lane, p.stage > 1);
   float pr[kA];
-  actor_head_probs(lds.h2s, lds.wout, w, lane, p.eps_dev ? *p.eps_dev : p.eps, pr);
-  const int act = actor_sample(pr, p.seed, (uint64_t)(p.env_id_base + (int64_t)he), head_episode, head_steps, hi_agent);
+  // the uniform first: its Philox rounds are VALU work that can issue between the head's dependent MFMAs
+  const float u = actor_uniform(p.seed, (uint64_t)(p.env_id_base + (int64_t)he), head_episode, head_steps, hi_agent);
+  actor_head_probs(lds.h2s, hb, lds.lg, w, lane, p.eps_dev ? *p.eps_dev : p.eps, pr);
+  const int act = actor_pick(pr, u);
   if (head_ok) {
     p.actions[hr] = act;
     if (p.probs) {

@@ -85,6 +85,8 @@ template <int N, int BF16> __global__ void __launch_bounds__(256) k_policy_rollo
     }
   }
   __syncthreads();
+  ActorHeadB hb;
+  actor_head_load(lds.wout, lane, hb);      // output-layer operands of this lane, once per launch
 
   const float kDt = 0.1f, kKeep = 1.0f - 0.25f;
 #pragma unroll 1
@@ -92,8 +94,9 @@ template <int N, int BF16> __global__ void __launch_bounds__(256) k_policy_rollo
     // ---- policy: forward pass, probabilities and the sampled action of row rl (alg_credit.py:113-122) -----------------
     actor_mlp<N, BF16>(lds, b, w, lane, q.stage > 1);
     float pr[kA];
-    actor_head_probs(lds.h2s, lds.wout, w, lane, q.eps, pr);
-    const int act = actor_sample(pr, p.seed, genv, episode, steps, i);
+    const float u = actor_uniform(p.seed, genv, episode, steps, i);  // (Philox: VALU work between the head's dependent MFMAs)
+    actor_head_probs(lds.h2s, hb, lds.lg, w, lane, q.eps, pr);
+    const int act = actor_pick(pr, u);
     if (writer) {
       tick_ptr(p.actions, p.st_actions, t)[r] = act;
       if (q.probs) {

@@ -110,7 +110,7 @@ class ParticleRollout(object):
     """
 
     def __init__(self, env, n_ticks=None, use_graph=True, fused=False, n_chains=1, record_collisions=True,
-                 fused_policy_tick=False, live_state=None):
+                 fused_policy_tick=False, live_state=None, policy_mode="auto"):
         self.env = env
         self.T = int(n_ticks or env.max_steps)
         self.use_graph = bool(use_graph)
@@ -121,6 +121,15 @@ class ParticleRollout(object):
         # a tick in one cm3_policy_rollout_f32 launch (n_ticks = 1) instead of an actor launch followed by a step launch;
         # bit-identical to both other policy modes (n_agents in {1, 2, 4, 8})
         self.fused_policy_tick = bool(fused_policy_tick)
+        # policy_mode: how collect(policy=<device actor>) launches (all three are bit-identical, tests/test_gpu_actor.py):
+        #   "episode"  the whole policy-driven episode in ONE launch (csrc/policy.hip) -- the fastest (C2: 5.6 vs 10.6 us per tick);
+        #   "tick"     an actor launch and a step launch per tick inside one hipGraph;
+        #   "auto"     (default, round 3) "episode" whenever the fused kernel applies -- n_agents in {1, 2, 4, 8}, float32 env,
+        #              actor.seed == env.seed (one Philox key), one chain -- else "tick".  fused=True / fused_policy_tick=True
+        #              still force their modes.
+        if policy_mode not in ("auto", "episode", "tick"):
+            raise Cm3Error("policy_mode must be 'auto', 'episode' or 'tick'")
+        self.policy_mode = policy_mode
         # n_chains > 1: the random-action branch advances n_chains independent sub-batches of envs on their own
         # streams (parallel branches of the captured hipGraph).  Identical trajectories (cm3_particle_rollout_chains_*),
         # but MEASURED 1.2-5x SLOWER than one chain on MI355X in every form tried (profiles/r02_chains_diag.txt): the
@@ -296,7 +305,11 @@ class ParticleRollout(object):
         small = env.n * env.E * 4 * es < (1 << 20) and env.E * env.n * env.L * es * self.T >= (128 << 20)
         if self.live_state is not None:
             small = bool(self.live_state)
-        live = self._live = (self.goals is not None and small and not self.fused
+        dev_policy = policy is not None and hasattr(policy, "enqueue") and hasattr(policy, "act")
+        policy_episode = dev_policy and (self.fused or (self.policy_mode in ("auto", "episode") and env.n in (1, 2, 4, 8)
+                                                        and getattr(policy, "seed", None) == env.seed and self.n_chains == 1
+                                                        and not self.fused_policy_tick))
+        live = self._live = (self.goals is not None and small and not self.fused and not policy_episode
                              and not (self.fused_policy_tick and policy is not None))
         if live and self._live_cur != env._cur:    # captured graphs hold the live buffer's address
             self._drop_graphs()
@@ -315,7 +328,12 @@ class ParticleRollout(object):
         elif hasattr(policy, "enqueue") and hasattr(policy, "act"):      # on-device actor (cm3_amd.actor)
             if env.dtype != torch.float32:
                 raise Cm3Error("the device actor reads float32 env buffers")
-            if self.fused:
+            episode_ok = (env.n in (1, 2, 4, 8) and getattr(policy, "seed", None) == env.seed and self.n_chains == 1
+                          and not self.fused_policy_tick)
+            if self.policy_mode == "episode" and not episode_ok and not self.fused:
+                raise Cm3Error("policy_mode='episode' needs n_agents in {1, 2, 4, 8} and actor.seed == env.seed")
+            whole_episode = self.fused or (self.policy_mode in ("auto", "episode") and episode_ok)
+            if whole_episode:
                 # the whole policy-driven episode in ONE launch (csrc/policy.hip): weights, observation tile and env
                 # state stay in LDS / registers for all T ticks; bit-identical to alternating actor / step launches
                 if policy.seed != env.seed:
@@ -352,7 +370,73 @@ class ParticleRollout(object):
         self.collected = True
         return self
 
+    def collect_normalized(self, gamma=0.99, eps=1e-8, normalize=True, group=None, time_collective=False):
+        """Random-action collection (continuous mode) FOLLOWED by the advantage-normalisation step over reward_n -- BASELINE
+        configs[3]: discounted returns + this rank's float64 moments, ONE 24-byte all-gather over the ranks, normalisation
+        with the global statistics (cm3_amd.shard).  With one rank the collective is the identity and the whole step --
+        slot copy in, T step launches, slot copy out, returns + moments, normalise -- is ONE hipGraph replay; with several
+        ranks the graph ends at the moments, the all-gather and the normalise launch follow eagerly (RCCL / gloo).
+        Returns (normalised returns [T,E,N], (mean, std, count) device scalars); with time_collective=True also the seconds
+        the host spent in the all-gather call (0.0 for one rank)."""
+        import time
+        from .shard import ReturnsNormalizer, gather_moments
+        import torch.distributed as dist
+        env = self.env
+        if not self.auto_reset or self.fused or self.n_chains != 1:
+            raise Cm3Error("collect_normalized runs the continuous, one-launch-per-tick random-action collection")
+        world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        key = (float(gamma), float(eps), bool(normalize), world > 1)
+        if getattr(self, "_norm_key", None) != key:
+            self._drop_norm_graph()
+            self._norm = ReturnsNormalizer(self.reward_n, self.done, gamma, eps, normalize)
+            self._norm_key = key
+        self._finished0 = None
+        es = self.state.element_size()
+        small = env.n * env.E * 4 * es < (1 << 20) and env.E * env.n * env.L * es * self.T >= (128 << 20)
+        live = self._live = bool(small if self.live_state is None else self.live_state)
+        if live and self._live_cur != env._cur:
+            self._drop_graphs()
+            self._live_cur = env._cur
+        flags = FLAG_AUTO_RESET | env.kernel_flags | FLAG_GEN_ACTIONS
+
+        def enqueue(s):
+            pairs = [(self.state[0], env._state[env._cur]), (self.obs_others[0], env._obs_others[env._cur]),
+                     (self.goals[0], env._goals)]
+            _copy_pairs(pairs, s)
+            self._enqueue(0, self.T, flags, s, live=live)
+            back = [(env._obs_others[env._cur], self.obs_others[self.T])]
+            if not live:
+                back += [(env._state[env._cur], self.state[self.T]), (env._goals, self.goals[self.T])]
+            _copy_pairs(back, s)
+            self._norm.enqueue_moments(s)
+            if world == 1:
+                self._norm.enqueue_normalize(s)
+
+        stream = env._stream()
+        if self.use_graph:
+            if getattr(self, "_norm_graph", None) is None:
+                self._norm_graph = _lib.capture_graph(env.device, enqueue)
+            _lib.check(self._lib.cm3_graph_launch(self._norm_graph, stream))
+        else:
+            enqueue(stream)
+        t_coll = 0.0
+        if world > 1:
+            t0 = time.perf_counter()
+            parts, n_parts = gather_moments(self._norm.moments, group)
+            t_coll = time.perf_counter() - t0
+            self._norm.enqueue_normalize(stream, parts, n_parts)
+        self.collected = True
+        res = (self._norm.out, (self._norm.stats[0], self._norm.stats[1], self._norm.stats[2]))
+        return res + (t_coll,) if time_collective else res
+
+    def _drop_norm_graph(self):
+        if getattr(self, "_norm_graph", None) is not None:
+            torch.cuda.synchronize(self.env.device)
+            self._lib.cm3_graph_destroy(self._norm_graph)
+        self._norm_graph = None
+
     def _drop_graphs(self):
+        self._drop_norm_graph()
         if self._graph is not None:
             torch.cuda.synchronize(self.env.device)
             self._lib.cm3_graph_destroy(self._graph)

@@ -138,6 +138,40 @@ def normalized_returns(reward, done, valid=None, gamma=0.99, eps=1e-8, group=Non
     return out, (stats[0], stats[1], stats[2])
 
 
+class ReturnsNormalizer(object):
+    """normalized_returns() with PERSISTENT buffers and separately enqueueable halves, so that a collector can capture
+    `collect -> returns + moments -> (all-gather) -> normalise` into hipGraphs (ParticleRollout.collect_normalized):
+        enqueue_moments(stream)            cm3_returns_moments_*  -> self.out (returns), self.moments (this rank's triple)
+        enqueue_normalize(stream, parts)   cm3_normalize_* over `parts` (self.moments itself when there is one rank)
+    reward [T,E] or [T,E,C] float32/float64 and done uint8 [T,E] are the trajectory's own tensors (read in place)."""
+
+    def __init__(self, reward, done, gamma=0.99, eps=1e-8, normalize=True):
+        from . import _lib
+        if reward.device.type != "cuda" or not reward.is_contiguous() or done.dtype != torch.uint8 or not done.is_contiguous():
+            raise _lib.Cm3Error("ReturnsNormalizer needs contiguous device tensors (reward float, done uint8)")
+        self._lib_mod, self.lib = _lib, _lib.lib()
+        self.reward, self.done = reward, done
+        self.T, self.E = int(reward.shape[0]), int(reward.shape[1])
+        self.C = 1 if reward.dim() == 2 else int(reward.shape[2])
+        self.suffix = {torch.float32: "f32", torch.float64: "f64"}[reward.dtype]
+        self.gamma, self.eps, self.apply = float(gamma), float(eps), 1 if normalize else 0
+        self.out = torch.empty_like(reward)
+        self.buf = torch.zeros(6, dtype=torch.float64, device=reward.device)
+        self.moments, self.stats = self.buf[0:3], self.buf[3:6]
+        self.scratch = torch.zeros(self.lib.cm3_returns_scratch_bytes() // 8, dtype=torch.float64, device=reward.device)
+
+    def enqueue_moments(self, stream):
+        self._lib_mod.check(getattr(self.lib, "cm3_returns_moments_" + self.suffix)(
+            self.reward.data_ptr(), self.done.data_ptr(), 0, self.out.data_ptr(), self.scratch.data_ptr(),
+            self.moments.data_ptr(), self.T, self.E, self.C, self.gamma, stream))
+
+    def enqueue_normalize(self, stream, parts=None, n_parts=1):
+        parts = self.moments if parts is None else parts
+        self._lib_mod.check(getattr(self.lib, "cm3_normalize_" + self.suffix)(
+            self.out.data_ptr(), 0, parts.data_ptr(), int(n_parts), self.stats.data_ptr(), self.out.numel(), self.C,
+            self.eps, self.apply, stream))
+
+
 _SCRATCH = {}
 
 

@@ -423,8 +423,9 @@ int cm3_actor_checkers_f32(const cm3_actor_checkers_desc *desc, const cm3_actor_
  * Discounted return-to-go over a time-major trajectory, G[t] = x[t] + gamma * (1 - done[t]) * G[t+1], G[T] = 0:
  *   x, out  real [T][E][C]   (C = N for reward_n, 1 for the team reward); out may alias x
  *   done    uint8 [T][E];  valid uint8 [T][E] optional (invalid entries: out = 0, excluded from the moments)
- *   scratch >= cm3_returns_scratch_bytes() bytes (per-block partials + an arrival counter that every call zeroes with a
- *   4-byte memset on `stream` before its launch; the last block to arrive folds the partials in block order);
+ *   scratch >= cm3_returns_scratch_bytes() bytes, ZERO-INITIALISED ONCE by the caller (per-block partials + an arrival
+ *   counter; the last block to arrive folds the partials in block order and resets the counter for the next call on the
+ *   same stream -- no memset launch per call);
  *   moments double[3] = (sum, sum of squares, count) of this rank's valid returns, computed deterministically.
  *   The host all-gathers the three numbers over the ranks (RCCL); cm3_normalize_* sums the n_parts triples in rank order
  *   and applies x = (x - (real)mean) / (real)(std + eps) with the GLOBAL moments (x real [n_elem], valid indexed by

@@ -50,16 +50,17 @@ def test_actor_probs_and_samples_match_oracle(N, cfg, stage, eps, precision):
     assert np.abs(freq - want.mean(0)).max() < 0.05
 
 
-def test_policy_rollout_on_device_equals_host_driven_policy():
-    """ParticleRollout.collect(policy=actor): alternate actor/step launches in one hipGraph == calling the actor and
-    the env from the host tick by tick."""
+@pytest.mark.parametrize("policy_mode", ["auto", "tick"])
+def test_policy_rollout_on_device_equals_host_driven_policy(policy_mode):
+    """ParticleRollout.collect(policy=actor) -- "auto": the whole episode in one launch (the default since round 3); "tick":
+    alternate actor / step launches in one hipGraph -- == calling the actor and the env from the host tick by tick."""
     from cm3_amd.actor import ParticleActor
     from cm3_amd.rollout import ParticleRollout
     N, E, seed = 4, 512, 5
     w = AO.init_weights(np.random.default_rng(3), N)
     actor = ParticleActor(w, N, device="cuda:0", seed=seed)
     env_a = _env(E, N, "particle_stage2_cross.json", seed=seed)
-    ro = ParticleRollout(env_a, use_graph=True).collect(policy=actor, epsilon=0.2)
+    ro = ParticleRollout(env_a, use_graph=True, policy_mode=policy_mode).collect(policy=actor, epsilon=0.2)
     ro.collect(policy=actor, epsilon=0.2)                       # second replay = a fresh episode
     env_b = _env(E, N, "particle_stage2_cross.json", seed=seed)
     env_b.reset()
@@ -173,7 +174,7 @@ def test_fused_policy_rollout_equals_launch_per_tick(N, cfg, auto_reset, precisi
         env = _env(E, N, cfg, seed=seed, auto_reset=auto_reset, max_steps=9)
         env.reset()
         actor = ParticleActor(w, N, stage=stage, device="cuda:0", seed=seed, precision=precision)
-        ro = ParticleRollout(env, n_ticks=T, use_graph=graph, fused=fused, fused_policy_tick=ftick)
+        ro = ParticleRollout(env, n_ticks=T, use_graph=graph, fused=fused, fused_policy_tick=ftick, policy_mode="tick")
         ro.collect(policy=actor, epsilon=0.15, reset=False)
         outs.append((ro, env))
     a, ea = outs[0]

@@ -282,7 +282,7 @@ def test_actor_graph_follows_annealed_epsilon_without_recapture():
         env = _penv(E, N, seed=12341, auto_reset=True, max_steps=7)
         env.reset()
         actor = _particle_actor(N)
-        ro = ParticleRollout(env, n_ticks=T, use_graph=graph)
+        ro = ParticleRollout(env, n_ticks=T, use_graph=graph, policy_mode="tick")      # the captured actor / step graph
         handles, acts = [], []
         for eps in (0.5, 0.3, 0.05):
             ro.collect(policy=actor, epsilon=eps, reset=False)

@@ -41,7 +41,7 @@ def _json_line(stdout):
     return json.loads(lines[-1])
 
 
-@pytest.mark.parametrize("workload", ["c4", "c2"])
+@pytest.mark.parametrize("workload", ["c4", "c2", "c5", "c3"])
 def test_bench_under_torchrun_one_rank(workload):
     """The driver's N > 1 command shape with N = 1: nccl (= RCCL) init, barriers, the all-gather of the per-rank clocks and
     (c4) of the advantage moments all execute on the box."""
@@ -99,3 +99,77 @@ def test_two_rank_product_path_on_one_gpu(tmp_path):
     whole_norm = torch.cat([p["norm"] for p in parts], dim=1).cuda()
     assert torch.allclose(whole_norm, norm1, rtol=1e-6, atol=1e-6)
     ro.close()
+
+
+@pytest.mark.parametrize("workload", ["c5", "c3", "c2"])
+def test_shards_reproduce_the_single_process_trajectory(workload):
+    """What `bench.py --gpus G` relies on for every workload: rank r steps envs [r E, (r + 1) E) with env_id_base = r E, and
+    because every random stream is keyed by the GLOBAL env id the G shards together are, bit for bit, the trajectory of one
+    process stepping G E envs (here G = 2 shards on one GPU against the whole batch; in-kernel actions, auto-reset)."""
+    import numpy as np
+    import cm3_amd
+    from cm3_amd.rollout import CheckersRollout, ParticleRollout
+    T, E = 40, 1024 + 64
+    halves = [(0, 512 + 64), (512 + 64, 512)]
+    if workload == "c3":
+        from cm3_amd.checkers import VecCheckersEnv
+        cfg = cm3_amd.load_config("checkers_stage2")
+        goals = np.eye(2)
+        def run(base, n):
+            env = VecCheckersEnv(cfg["init"], 2, 9, n, device="cuda:0", auto_reset=True, env_id_base=base, seed=12341)
+            ro = CheckersRollout(env, n_ticks=T, use_graph=True).collect(goals)
+            out = {k: getattr(ro, k).clone() for k in ("actions", "reward", "local_rewards", "done", "vec", "obs_self_v", "obs_others")}
+            out["grid"], out["obs_self_t"] = ro.grid.clone(), ro.obs_self_t.clone()
+            ro.close()
+            return out
+        env_axis = {k: 1 for k in ("actions", "reward", "local_rewards", "done", "vec", "obs_self_v", "obs_others", "grid", "obs_self_t")}
+    else:
+        from cm3_amd.particle import VecParticleEnv
+        name, N = ("particle_merge8", 8) if workload == "c5" else ("particle_stage2_antipodal", 4)
+        cfg = cm3_amd.load_config(name)
+        def run(base, n):
+            env = VecParticleEnv(cfg, N, 0.2, 9, n, device="cuda:0", auto_reset=True, env_id_base=base, seed=12341)
+            env.reset()
+            ro = ParticleRollout(env, n_ticks=T, use_graph=True).collect(reset=False)
+            out = {k: getattr(ro, k).clone() for k in ("actions", "reward", "reward_n", "done", "obs_others", "collisions", "state", "goals",
+                                                       "term_state", "term_obs_others")}
+            ro.close()
+            return out
+        env_axis = dict(actions=1, reward=1, reward_n=1, done=1, obs_others=1, collisions=1, state=2, goals=2, term_state=2,
+                        term_obs_others=1)
+    whole = run(0, E)
+    parts = [run(b, n) for b, n in halves]
+    for k, ax in env_axis.items():
+        assert torch.equal(torch.cat([p[k] for p in parts], dim=ax), whole[k]), k
+    assert int(whole["done"].sum()) >= 3 * E
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_collect_normalized_is_collect_followed_by_normalized_returns(use_graph):
+    """ParticleRollout.collect_normalized -- slot copies, T step launches, returns + moments, normalise captured as ONE hipGraph
+    (world size 1: the all-gather is the identity) -- equals collect() followed by cm3_amd.shard.normalized_returns, bit for
+    bit, rollout after rollout (graph replays)."""
+    import cm3_amd
+    from cm3_amd.particle import VecParticleEnv
+    from cm3_amd.rollout import ParticleRollout
+    from cm3_amd.shard import normalized_returns
+    cfg = cm3_amd.load_config("particle_stage2_cross")
+    E, T = 777, 33
+    envs = [VecParticleEnv(cfg, 4, 0.2, 33, E, device="cuda:0", auto_reset=True, seed=12341) for _ in range(2)]
+    for e in envs:
+        e.reset()
+    a, b = (ParticleRollout(e, n_ticks=T, use_graph=use_graph) for e in envs)
+    for _ in range(3):
+        a.collect(reset=False)
+        want, (m, s, n) = normalized_returns(a.reward_n, a.done, None, gamma=0.99)
+        got, (m2, s2, n2), t_coll = b.collect_normalized(gamma=0.99, time_collective=True)
+        assert t_coll == 0.0
+        for name in ("state", "obs_others", "actions", "reward_n", "done", "goals", "term_state"):
+            assert torch.equal(getattr(a, name), getattr(b, name)), name
+        assert torch.equal(want, got)
+        assert float(m) == float(m2) and float(s) == float(s2) and float(n) == float(n2) == float(T * E * 4)
+        assert torch.equal(envs[0].global_state, envs[1].global_state)
+    raw, _ = b.collect_normalized(gamma=0.99, normalize=False)          # a different key re-captures
+    assert float(raw.abs().max()) > 1.0
+    a.close()
+    b.close()
