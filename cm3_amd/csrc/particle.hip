@@ -1047,6 +1047,7 @@ __global__ void __launch_bounds__(WAVES * 64)
   };
 
   CM3_STAMP(1, true);
+  CM3_SPAN_MARK(0, true);   // loads back
   const int n_ticks = FUSED ? p.n_ticks : 1;
 #pragma unroll 1
   for (int t = 0; t < n_ticks; ++t) {
@@ -1061,6 +1062,7 @@ __global__ void __launch_bounds__(WAVES * 64)
     }
 
     CM3_STAMP(2, false);
+    CM3_SPAN_MARK(1, false);  // action drawn
     // ---- action force + contact forces of agent i, other agents in ascending order (core.py:143-155) ------------
     R ux = R(0), uy = R(0);
     if (act == 1) ux = R(-1);
@@ -1100,6 +1102,7 @@ __global__ void __launch_bounds__(WAVES * 64)
     }
 
     CM3_STAMP(3, false);
+    CM3_SPAN_MARK(2, false);  // neighbour scan + contact forces
     // ---- integrate agent i (core.py:158-169) ---------------------------------------------------------------------
     si.x = si.x * kKeep;
     si.y = si.y * kKeep;
@@ -1118,6 +1121,7 @@ __global__ void __launch_bounds__(WAVES * 64)
     }
 
     CM3_STAMP(4, true);
+    CM3_SPAN_MARK(3, false);  // integrated, post-step states exchanged
     // ---- reward / reached / collisions (multi-goal_spread.py:114-143) ----------------------------------------
     R rew;
     bool reached;
@@ -1175,6 +1179,7 @@ __global__ void __launch_bounds__(WAVES * 64)
     }
 
     CM3_STAMP(5, false);
+    CM3_SPAN_MARK(4, false);  // rewards / done stored
     // ---- same-launch re-initialisation -------------------------------------------------------------------------
     bool was_reset = false;
     if (auto_reset) {
@@ -1211,6 +1216,7 @@ __global__ void __launch_bounds__(WAVES * 64)
     }
 
     CM3_STAMP(6, false);
+    CM3_SPAN_MARK(5, false);  // reset handled
     // ---- per-tick stores ------------------------------------------------------------------------------------------
     if (mine) {
       *at32<V4>(tick_ptr(p.state_out, p.st_state, t), (row_i + e) * (uint32_t)sizeof(V4)) = si;
@@ -1224,6 +1230,7 @@ __global__ void __launch_bounds__(WAVES * 64)
     store_obs(oj, tick_ptr(p.obs_others, p.st_obs, t));  // observation (multi-goal_spread.py:145-154)
   }
 
+  CM3_SPAN_MARK(6, false);  // state + observation stores issued
   CM3_STAMP(7, false);
   // ---- live counters, once per launch -------------------------------------------------------------------------------
   if (head) {
@@ -1454,7 +1461,8 @@ template <typename R, int N, int WAVES> static int launch_agents(const ParticleP
       if (nt) CM3_LAUNCH_AGENTS(true, kNt);
       else CM3_LAUNCH_AGENTS(true, kSpPlain);
     } else if (live) {
-      if (nt) CM3_LAUNCH_AGENTS(false, kNt, true);
+      if (wt) CM3_LAUNCH_AGENTS(false, kWt, true);
+      else if (nt) CM3_LAUNCH_AGENTS(false, kNt, true);
       else CM3_LAUNCH_AGENTS(false, kSpPlain, true);
     } else {
       if (wt) CM3_LAUNCH_AGENTS(false, kWt);

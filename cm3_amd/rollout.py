@@ -297,12 +297,15 @@ class ParticleRollout(object):
         # keep the state in registers (fused) or read the slots themselves (fused policy kernels) do not
         # -- and only while a tick's state is small: the slot copy is extra write traffic, the gain is load latency.  Measured
         # (tools/trajectory_gap.py, profiles/r02_trajectory_gap_live_state.txt): below ~1 MiB of state per tick live wins by
-        # 4-14 % (C2: 2.87 -> 2.74 us), from there on chaining the ticks through the slots is as fast or faster (C5: 5.53 vs 5.74)
+        # 4-14 % (C2: 2.87 -> 2.74 us), from there on chaining the ticks through the slots is as fast or faster (C5: 5.53 vs 5.74).
+        # Round 3 (write-through slot copies; profiles/r03_live_state_crossover.txt): live now also wins AT 1 MiB -- C5 5.20 -> 5.06,
+        # N = 4 at 16 384 envs 3.86 -> 3.70 -- ties at 2-4 MiB and loses from 16 MiB on, so the bound is inclusive.  (Marked two-stamp
+        # build at C5: a tick that loads slot t waits 2311 cycles for its state, one that steps in place 1121.)
         # ... and only for a streaming-size trajectory (the library's criterion for non-temporal observation stores: >= 128 MB of
         # observation slots): a small trajectory that is collected over and over (C4: 26 MB) stays cache-resident, its slots are
         # not "fresh", and the copies only cost (3.63 -> 3.70 us per tick at C4)
         es = self.state.element_size()
-        small = env.n * env.E * 4 * es < (1 << 20) and env.E * env.n * env.L * es * self.T >= (128 << 20)
+        small = env.n * env.E * 4 * es <= (1 << 20) and env.E * env.n * env.L * es * self.T >= (128 << 20)
         if self.live_state is not None:
             small = bool(self.live_state)
         dev_policy = policy is not None and hasattr(policy, "enqueue") and hasattr(policy, "act")
@@ -392,7 +395,7 @@ class ParticleRollout(object):
             self._norm_key = key
         self._finished0 = None
         es = self.state.element_size()
-        small = env.n * env.E * 4 * es < (1 << 20) and env.E * env.n * env.L * es * self.T >= (128 << 20)
+        small = env.n * env.E * 4 * es <= (1 << 20) and env.E * env.n * env.L * es * self.T >= (128 << 20)
         live = self._live = bool(small if self.live_state is None else self.live_state)
         if live and self._live_cur != env._cur:
             self._drop_graphs()
