@@ -191,7 +191,11 @@ template <typename R, typename V4> __device__ __forceinline__ V4 sub4(const V4 &
 // time: that alone cost 1-3 % on every kernel that carried it -- profiles/r02_base_vs_new_runtime_flavours.txt -- and the
 // write-through flavours it also offered bought nothing, profiles/r02_store_policy_ab.txt.)
 constexpr uint32_t kFlagObsStoreNt = 0x100000u;  // internal launch flag, set by particle_rollout only
-constexpr size_t kWtMinObsBytes = (size_t)3 << 20;  // observation bytes per launch from which the rows are written through (kSpWt)
+constexpr size_t kWtMinObsBytes = (size_t)3 << 20;
+#ifndef CM3_AGENTS2_MAX_ENVS
+#define CM3_AGENTS2_MAX_ENVS 8192    // (macro: build variant for the crossover measurement)
+#endif
+constexpr size_t kAgents2MaxEnvs = CM3_AGENTS2_MAX_ENVS;  // N = 8: two lanes per agent up to this many envs per launch  // observation bytes per launch from which the rows are written through (kSpWt)
 
 typedef float cm3_f4 __attribute__((ext_vector_type(4)));
 // Store policy of the observation rows, a COMPILE-TIME parameter of the step kernels (kSpPlain kernels are byte for byte the code
@@ -1244,6 +1248,261 @@ __global__ void __launch_bounds__(WAVES * 64)
   CM3_SPAN_OUT(p.span);
 }
 
+// ---- lane-per-agent mapping with TWO LANES PER AGENT (N = 8, float32, per-tick launches; round 3) --------------------------------
+// At C5 the one-lane-per-agent kernel above runs one wave per SIMD for ~7500 cycles, most of them in work that is proportional to
+// the number of OTHER agents a lane walks: the neighbour scan + contact forces (1770 cycles), the exchange of the post-step states
+// (530), the collision tests (1000 with the reward) and the observation tile (1300).  Here an env owns 16 lanes = one DPP row; lane
+// (i, h) = agent i, half h handles the other agents j in [4h, 4h + 4): half the scan, half the contact passes, half the state
+// exchange, half of the agent's observation row -- and twice the waves, i.e. two per SIMD, where a lone wave leaves three of four
+// issue slots empty (tools/probes/issue_probe.hip).  What both lanes of an agent do redundantly (action draw, integration, reward
+// distance, reset) is lockstep work.  Bit-identical to the other mappings:
+//   * contact forces are summed in the reference's order (other agents ascending, core.py:145-155) by two chained passes -- every
+//     lane adds its four contributions (exactly +0 for agents beyond reach or itself, which leaves a sum bit-unchanged: a partial
+//     sum is never -0) to a start value; pass 1 starts from the action force, pass 2 from the EVEN lane's pass-1 result (DPP), so
+//     the odd lane ends with f7 + (f6 + (f5 + (f4 + (f3 + (f2 + (f1 + (f0 + F_action))))))) and hands it back to the even lane;
+//   * collision counts add up over the pair, the env's count and NumPy's 8-value pairwise reward tree are DPP row reductions.
+template <int WAVES, int SP = kSpPlain, bool LIVE = false, int TU = CM3_PARTICLE_TU>
+__global__ void __launch_bounds__(WAVES * 64)
+    k_particle_step_agents2(const void *h_state_in, const void *h_goals_in, const int32_t *h_meta_in, const int32_t *h_episode,
+                            const int h_E, const uint32_t h_flags, const int h_E0, const int h_EN, const int h_max_steps,
+                            const int32_t *h_actions, const ParticleParams p) {
+  using R = float;
+  using V4 = float4;
+  using V2 = float2;
+  constexpr int N = 8, NO = 7, G = 16, EPW = 4, VPE = N * NO, NH = 4;  // NH: other agents per half
+  __shared__ __attribute__((aligned(32))) R lds_all[WAVES][EPW * VPE * 4];
+  CM3_SPAN_IN();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int gi = lane & (G - 1), sub = lane / G, base = lane - gi;
+  const int i = gi >> 1, h = gi & 1;
+  const uint32_t E = (uint32_t)h_E, EN = (uint32_t)h_EN;
+  const uint32_t e0 = (uint32_t)h_E0 + ((uint32_t)blockIdx.x * WAVES + wave) * EPW;
+  const uint32_t e = e0 + sub;
+  const bool env_ok = e < EN;
+  const uint32_t ec = env_ok ? e : EN - 1;
+  const bool mine = env_ok && h == 0;    // the even lane of an agent's pair does the per-agent stores
+  const bool head = env_ok && gi == 0;   // one lane per env does the per-env stores
+  V4 *lds4 = reinterpret_cast<V4 *>(&lds_all[wave][0]);
+
+  const uint32_t row_i = (uint32_t)i * E;
+  V4 si = *at32<const V4>(h_state_in, (row_i + ec) * (uint32_t)sizeof(V4));
+  V2 gl = *at32<const V2>(h_goals_in, (row_i + ec) * (uint32_t)sizeof(V2));
+  const int2 meta = *at32<const int2>(h_meta_in, ec * 8u);
+  int steps = meta.x, collisions = meta.y;
+  const bool auto_reset = (h_flags & CM3_FLAG_AUTO_RESET) != 0;
+  const bool gen = (h_flags & CM3_FLAG_GEN_ACTIONS) != 0;
+  uint32_t episode = 0;
+  if (gen || (h_flags & CM3_FLAG_AUTO_RESET)) episode = (uint32_t)*at32<const int32_t>(h_episode, ec * 4u);
+  const uint32_t episode_in = episode;
+  CM3_FETCH_EARLY(p.state_out, p.goals_out, p.goals_in, p.collisions_tick, p.reward_n, p.reward, p.done, p.obs_others, p.meta_out);
+  if constexpr (LIVE) CM3_FETCH_EARLY(p.state_copy, p.goals_copy);
+  const uint64_t genv = (uint64_t)(p.env_id_base + (int64_t)ec);
+  const R kDt = R(0.1), kKeep = R(1 - 0.25);
+  long envs_here = (long)EN - (long)e0;
+  envs_here = envs_here < 0 ? 0 : (envs_here > EPW ? EPW : envs_here);
+  const int nvec = (int)envs_here * VPE;
+  const int src0 = base + 8 * h;  // lane of agent 4h (its even lane); agent 4h + q sits two lanes further per q
+
+  // this half's share of agent i's observation row -> the wave's tile.  The slot of agent i itself (when it falls into this half)
+  // repeats the next one: the same value written twice to the same place, no predicate.
+  auto fill_tile = [&](const V4 (&oj)[NH]) {
+#pragma unroll
+    for (int q = 0; q < NH; ++q) {
+      const int j = 4 * h + q;
+      const bool self = j == i;
+      const int jj = self ? 4 * h + ((q + 1) & 3) : j;
+      V4 o;
+      o.x = self ? oj[(q + 1) & 3].x : oj[q].x;
+      o.y = self ? oj[(q + 1) & 3].y : oj[q].y;
+      o.z = self ? oj[(q + 1) & 3].z : oj[q].z;
+      o.w = self ? oj[(q + 1) & 3].w : oj[q].w;
+      const int k = jj < i ? jj : jj - 1;
+      lds4[sub * VPE + i * NO + k] = sub4<R, V4>(o, si);
+    }
+    wave_lds_sync();
+  };
+  auto gather = [&](V4 (&oj)[NH]) {  // post-step (or fresh) state of this half's four other agents
+#pragma unroll
+    for (int q = 0; q < NH; ++q) {
+      oj[q].x = __shfl(si.x, src0 + 2 * q, 64);
+      oj[q].y = __shfl(si.y, src0 + 2 * q, 64);
+      oj[q].z = __shfl(si.z, src0 + 2 * q, 64);
+      oj[q].w = __shfl(si.w, src0 + 2 * q, 64);
+    }
+  };
+  CM3_SPAN_MARK(0, true);   // loads back
+
+  int32_t *actions_t = p.actions;
+  int act;
+  if (gen) {  // train_onpolicy.py:305-307
+    const u32x4 w = action_words(p.seed, genv, episode, (uint32_t)steps, (uint32_t)(i >> 2));
+    act = rand5(pick_word(w, i & 3));
+    if (mine) store_small<SP>(at32<int32_t>(actions_t, (e * N + i) * 4u), act);
+  } else {
+    act = *at32<const int32_t>(actions_t, (ec * N + i) * 4u);
+  }
+  CM3_SPAN_MARK(1, false);  // action drawn
+  R ux = R(0), uy = R(0);
+  if (act == 1) ux = R(-1);
+  if (act == 2) ux = R(+1);
+  if (act == 3) uy = R(-1);
+  if (act == 4) uy = R(+1);
+  const R Fax = ux * R(5.0) + R(0.0), Fay = uy * R(5.0) + R(0.0);
+  // ---- this half's neighbours within reach (exact test on the squared distance, thresholds.h) and their contact forces ------------
+  R dxs[NH], dys[NH], d2s[NH], fx[NH], fy[NH];
+  unsigned near_mask = 0;
+#pragma unroll
+  for (int q = 0; q < NH; ++q) {
+    dxs[q] = si.z - __shfl(si.z, src0 + 2 * q, 64);
+    dys[q] = si.w - __shfl(si.w, src0 + 2 * q, 64);
+    d2s[q] = dxs[q] * dxs[q] + dys[q] * dys[q];
+    near_mask |= (unsigned)((4 * h + q != i) & !(d2s[q] >= Thresh<R>::kSkip2)) << q;
+    fx[q] = R(0);
+    fy[q] = R(0);
+  }
+  while (__any(near_mask != 0u)) {
+    const int qn = near_mask ? (__ffs((int)near_mask) - 1) : 0;
+    R dx = dxs[0], dy = dys[0], d2 = d2s[0];
+#pragma unroll
+    for (int q = 1; q < NH; ++q) {
+      dx = (qn == q) ? dxs[q] : dx;
+      dy = (qn == q) ? dys[q] : dy;
+      d2 = (qn == q) ? d2s[q] : d2;
+    }
+    if (near_mask) {
+      R f_x, f_y;
+      contact_force_near<R>(dx, dy, d2, f_x, f_y);
+#pragma unroll
+      for (int q = 0; q < NH; ++q) {
+        fx[q] = (qn == q) ? f_x : fx[q];
+        fy[q] = (qn == q) ? f_y : fy[q];
+      }
+    }
+    near_mask &= near_mask - 1u;
+  }
+  // two chained passes in the reference's order (see the head of the kernel)
+  R Px = Fax, Py = Fay;
+#pragma unroll
+  for (int q = 0; q < NH; ++q) {
+    Px = fx[q] + Px;
+    Py = fy[q] + Py;
+  }
+  Px = dpp_f32<0xA0>(Px);  // quad_perm:[0,0,2,2]: the even lane's sum over agents 0..3
+  Py = dpp_f32<0xA0>(Py);
+#pragma unroll
+  for (int q = 0; q < NH; ++q) {
+    Px = fx[q] + Px;
+    Py = fy[q] + Py;
+  }
+  const R Fx = h ? Px : dpp_f32<0xF5>(Px);  // quad_perm:[1,1,3,3]: the odd lane holds the complete sum
+  const R Fy = h ? Py : dpp_f32<0xF5>(Py);
+  CM3_SPAN_MARK(2, false);  // neighbour scan + contact forces
+  // ---- integrate agent i (core.py:158-169) ---------------------------------------------------------------------------------------
+  si.x = si.x * kKeep;
+  si.y = si.y * kKeep;
+  si.x = si.x + (Fx / R(1.0)) * kDt;
+  si.y = si.y + (Fy / R(1.0)) * kDt;
+  si.z = si.z + si.x * kDt;
+  si.w = si.w + si.y * kDt;
+  steps += 1;
+  V4 oj[NH];
+  gather(oj);
+  CM3_SPAN_MARK(3, false);  // integrated, post-step states exchanged
+  // ---- reward / reached / collisions (multi-goal_spread.py:114-143) -----------------------------------------------------------------
+  R rew;
+  bool reached;
+  {
+    const R dx = si.z - gl.x, dy = si.w - gl.y;
+    const R d2 = dx * dx + dy * dy;
+    rew = R(0) - Math<R>::sqrt(d2);
+    reached = d2 < Thresh<R>::kReach2;
+  }
+  int c_half = 0;
+#pragma unroll
+  for (int q = 0; q < NH; ++q) c_half += (int)((4 * h + q != i) & is_collision<R>(oj[q].z - si.z, oj[q].w - si.w));
+  const int c_i = c_half + dpp_i32<kDppXor1>(c_half);
+#pragma unroll
+  for (int c = 0; c < NO; ++c)
+    if (c < c_i) rew = rew - R(1);
+  int c_env = c_half;  // every ordered visit counts (:135-137): the sum over the env's 16 lanes
+  c_env += dpp_i32<kDppXor1>(c_env);
+  c_env += dpp_i32<kDppXor2>(c_env);
+  c_env += dpp_i32<kDppHalfMirror>(c_env);
+  c_env += dpp_i32<0x140>(c_env);  // row_mirror: lane i <-> 15 - i (the two halves of the row are uniform by now)
+  collisions += c_env;
+  const unsigned long long rb = __ballot(reached && h == 0);
+  const bool all_reached = __popcll((rb >> base) & 0xffffull) == N;
+  // NumPy's pairwise tree for 8 values: ((v0+v1)+(v2+v3)) + ((v4+v5)+(v6+v7)); agents i, i^1 are two lanes apart
+  R tsum = rew + dpp_f32<kDppXor2>(rew);
+  tsum = tsum + dpp_f32<kDppHalfMirror>(tsum);
+  const R other = dpp_f32<0x140>(tsum);
+  const R reward = gi < 8 ? tsum + other : other + tsum;
+  const bool done = (steps == h_max_steps) || all_reached;
+  if (mine) store_small<SP>(at32<R>(p.reward_n, (e * N + i) * (uint32_t)sizeof(R)), rew);
+  if (head) {
+    *at32<R>(p.reward, e * (uint32_t)sizeof(R)) = reward;
+    *at32<uint8_t>(p.done, e) = done ? 1 : 0;
+    if (p.collisions_tick) *at32<int32_t>(p.collisions_tick, e * 4u) = collisions;
+  }
+  CM3_SPAN_MARK(4, false);  // rewards / done stored
+  // ---- same-launch re-initialisation ---------------------------------------------------------------------------------------------
+  bool was_reset = false;
+  if (auto_reset) {
+    if (__any(done)) {  // wave-uniform: the tile store needs every lane
+      if (p.term_state && done && mine) *at32<V4>(p.term_state, (row_i + e) * (uint32_t)sizeof(V4)) = si;
+      if (p.term_obs_others) {
+        fill_tile(oj);
+        const unsigned long long done_bits = __ballot(done);
+        for (int f = lane; f < nvec; f += 64) {
+          const int row = f / VPE;
+          if ((done_bits >> (row * G)) & 1ull) *at32<V4>(p.term_obs_others, (e0 * VPE + f) * (uint32_t)sizeof(V4)) = lds4[f];
+        }
+        wave_lds_sync();
+      }
+      if (done) {
+        episode += 1;
+        const bool rnd = episode_is_random(p, genv, episode);
+        init_agent<R, N, true>(p, genv, episode, rnd, i, si, gl, preset_table());
+        steps = 0;
+        collisions = 0;
+        was_reset = true;
+      }
+      gather(oj);  // fresh episodes: the observation is that of the reset state
+    }
+  }
+  CM3_SPAN_MARK(5, false);  // reset handled
+  // ---- per-tick stores ---------------------------------------------------------------------------------------------------------------
+  if (mine) {
+    *at32<V4>(p.state_out, (row_i + e) * (uint32_t)sizeof(V4)) = si;
+    if (p.goals_out != p.goals_in || was_reset) *at32<V2>(p.goals_out, (row_i + e) * (uint32_t)sizeof(V2)) = gl;
+    if constexpr (LIVE) {
+      store_obs_vec<SP>(at32<V4>(p.state_copy, (row_i + e) * (uint32_t)sizeof(V4)), si);
+      *at32<V2>(p.goals_copy, (row_i + e) * (uint32_t)sizeof(V2)) = gl;
+    }
+  }
+  {  // observation (multi-goal_spread.py:145-154): the tile goes out as contiguous 16-byte-per-lane rows
+    fill_tile(oj);
+    constexpr int STEPS = (EPW * VPE + 63) / 64;
+    V4 row[STEPS];
+#pragma unroll
+    for (int q = 0; q < STEPS; ++q) row[q] = lds4[(q * 64 + lane) < EPW * VPE ? q * 64 + lane : 0];
+#pragma unroll
+    for (int q = 0; q < STEPS; ++q) {
+      const int f = q * 64 + lane;
+      if (f < nvec) store_obs_vec<SP>(at32<V4>(p.obs_others, (e0 * VPE + f) * (uint32_t)sizeof(V4)), row[q]);
+    }
+  }
+  CM3_SPAN_MARK(6, false);  // state + observation stores issued
+  if (head) {
+    int2 m;
+    m.x = steps;
+    m.y = collisions;
+    *at32<int2>(p.meta_out, e * 8u) = m;
+    if (episode != episode_in) *at32<int32_t>(p.episode, e * 4u) = (int32_t)episode;
+  }
+  CM3_SPAN_OUT(p.span);
+}
+
 // ---- reset kernel (environment.py:125-149) ------------------------------------------------------------
 template <typename R, int N, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) k_particle_reset(const ParticleParams p) {
@@ -1457,6 +1716,28 @@ template <typename R, int N, int WAVES> static int launch_agents(const ParticleP
     constexpr int kNt = sizeof(R) == 4 ? kSpNt : kSpPlain, kWt = sizeof(R) == 4 ? kSpWt : kSpPlain;
     // a launch that writes >= kWtMinObsBytes of observation rows writes them through (kSpWt; per-tick launches, no slot copies)
     const bool wt = sizeof(R) == 4 && (size_t)(p.EN - p.E0) * AgentGeom<N>::VPE * 4 * sizeof(R) >= kWtMinObsBytes;
+    if constexpr (N == 8 && sizeof(R) == 4) {
+      // two lanes per agent (k_particle_step_agents2) while the batch leaves SIMDs with one wave: per-tick launches up to kAgents2MaxEnvs
+      if (p.n_ticks == 1 && (size_t)(p.EN - p.E0) <= kAgents2MaxEnvs) {
+        const unsigned blocks2 = (unsigned)(((size_t)(p.EN - p.E0) + (size_t)WAVES * 4 - 1) / ((size_t)WAVES * 4));
+#define CM3_LAUNCH_AGENTS2(...)                                                                                             \
+  hipLaunchKernelGGL((k_particle_step_agents2<WAVES, __VA_ARGS__>), dim3(blocks2), dim3(WAVES * 64), 0, stream, p.state_in,  \
+                     p.goals_in, p.meta_in, (const int32_t *)p.episode, p.E, p.flags, p.E0, p.EN, p.max_steps,               \
+                     (const int32_t *)p.actions, p)
+        if (live) {
+          if (wt) CM3_LAUNCH_AGENTS2(kWt, true);
+          else if (nt) CM3_LAUNCH_AGENTS2(kNt, true);
+          else CM3_LAUNCH_AGENTS2(kSpPlain, true);
+        } else {
+          if (wt) CM3_LAUNCH_AGENTS2(kWt);
+          else if (nt) CM3_LAUNCH_AGENTS2(kNt);
+          else CM3_LAUNCH_AGENTS2(kSpPlain);
+        }
+#undef CM3_LAUNCH_AGENTS2
+        CM3_HIP_CHECK(hipGetLastError());
+        return CM3_OK;
+      }
+    }
     if (p.n_ticks > 1) {
       if (nt) CM3_LAUNCH_AGENTS(true, kNt);
       else CM3_LAUNCH_AGENTS(true, kSpPlain);
