@@ -43,6 +43,7 @@ namespace cm3 { long long *span_next_slot(); }
 // and so lengthen the kernel a little -- the two-stamp record is taken WITHOUT them).  drain: first wait for every outstanding
 // memory operation (only where the code waits for all of them anyway, e.g. right behind the initial loads).
 #ifdef CM3_SPAN_MARKS
+#define CM3_SPAN_STORE_MARKS(r) for (int _k = 0; _k < 8; ++_k) (r)[4 + _k] = _span_mk[_k]
 #define CM3_SPAN_MARK(k, drain)                          \
   do {                                                   \
     __builtin_amdgcn_sched_barrier(0);                   \
@@ -51,6 +52,7 @@ namespace cm3 { long long *span_next_slot(); }
     __builtin_amdgcn_sched_barrier(0);                   \
   } while (0)
 #else
+#define CM3_SPAN_STORE_MARKS(r) (void)_span_mk   /* the two-stamp record stores two 16-byte vectors per wave and nothing else */
 #define CM3_SPAN_MARK(k, drain) do { } while (0)
 #endif
 #define CM3_SPAN_OUT(slot)                                                                                  \
@@ -62,7 +64,7 @@ namespace cm3 { long long *span_next_slot(); }
       unsigned long long *_r = reinterpret_cast<unsigned long long *>(slot) +                               \
                                ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16;           \
       _r[0] = _span_rt0; _r[1] = _span_ck0; _r[2] = _rt1; _r[3] = _ck1;                                      \
-      for (int _k = 0; _k < 8; ++_k) _r[4 + _k] = _span_mk[_k];                                             \
+      CM3_SPAN_STORE_MARKS(_r);                                                                             \
     }                                                                                                       \
   } while (0)
 #define CM3_SPAN_SET(p) (p).span = ::cm3::span_next_slot()

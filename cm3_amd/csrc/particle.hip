@@ -195,7 +195,7 @@ constexpr size_t kWtMinObsBytes = (size_t)3 << 20;
 #ifndef CM3_AGENTS2_MAX_ENVS
 #define CM3_AGENTS2_MAX_ENVS 8192    // (macro: build variant for the crossover measurement)
 #endif
-constexpr size_t kAgents2MaxEnvs = CM3_AGENTS2_MAX_ENVS;  // N = 8: two lanes per agent up to this many envs per launch  // observation bytes per launch from which the rows are written through (kSpWt)
+constexpr size_t kAgents2MaxEnvs = CM3_AGENTS2_MAX_ENVS;  // N = 8: two lanes per agent up to this many envs per launch
 
 typedef float cm3_f4 __attribute__((ext_vector_type(4)));
 // Store policy of the observation rows, a COMPILE-TIME parameter of the step kernels (kSpPlain kernels are byte for byte the code
