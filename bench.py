@@ -812,8 +812,6 @@ def main():
             for label, kw in (("launch_per_tick", dict(policy_mode="tick")),
                               ("fused_launch_per_tick", dict(policy_mode="tick", fused_policy_tick=True)),
                               ("one_launch_per_episode", dict())):          # the default of collect(policy=...): policy_mode="auto"
-                if prec != "f32" and label == "fused_launch_per_tick":
-                    continue
                 penv = VecParticleEnv(cfg, N, 0.2, 33, E, device=device, auto_reset=True)
                 penv.reset()
                 actor = ParticleActor(wts, N, stage=2, device=device, precision=prec)
