@@ -42,7 +42,7 @@ template <int N, int BF16> __global__ void __launch_bounds__(256) k_policy_rollo
   constexpr int L = G::L, NO = N > 1 ? N - 1 : 1;
   const ParticleParams &p = q.p;
   CM3_ACTOR_LDS(N, BF16, lds);
-  __shared__ float ns[64][4];  // post-step (vx, vy, px, py) of every row, exchanged inside a wave
+  __shared__ __attribute__((aligned(16))) float4 ns[64];  // post-step (vx, vy, px, py) of every row, exchanged inside a wave
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const size_t E = (size_t)p.E;
@@ -133,8 +133,14 @@ template <int N, int BF16> __global__ void __launch_bounds__(256) k_policy_rollo
     si.z = si.z + si.x * kDt;
     si.w = si.w + si.y * kDt;
     steps += 1;
-    ns[rl][0] = si.x; ns[rl][1] = si.y; ns[rl][2] = si.z; ns[rl][3] = si.w;
+    ns[rl] = si;      // (one 16-byte LDS store; the other agents' rows come back as 16-byte reads, once, for collisions AND observation)
     wave_lds_sync();  // the other agents of this env live in the same wave
+    V4 oth[NO];
+#pragma unroll
+    for (int k = 0; k < NO; ++k) {
+      const int j = (N > 1) ? (k < i ? k : k + 1) : 0;
+      oth[k] = ns[rl - i + j];
+    }
 
     // ---- reward / reached / collisions (multi-goal_spread.py:114-143) ----------------------------------------------------------
     float rew;
@@ -148,9 +154,7 @@ template <int N, int BF16> __global__ void __launch_bounds__(256) k_policy_rollo
     int hits = 0;
 #pragma unroll
     for (int k = 0; k < N - 1; ++k) {
-      const int j = k < i ? k : k + 1;
-      const int rj = rl - i + j;
-      if (is_collision<float>(ns[rj][2] - si.z, ns[rj][3] - si.w)) {  // is_collision(a = j, agent = i)
+      if (is_collision<float>(oth[k].z - si.z, oth[k].w - si.w)) {  // is_collision(a = j, agent = i)
         rew = rew - 1.0f;
         hits += 1;
       }
@@ -158,11 +162,24 @@ template <int N, int BF16> __global__ void __launch_bounds__(256) k_policy_rollo
     float rews[N];
     int hit_sum = 0;
     bool all_reached = true;
+    if constexpr (N == 4) {  // the env's four agents are one DPP quad: broadcasts and sums without the LDS crossbar
+      rews[0] = dpp_f32<0x00>(rew);
+      rews[1] = dpp_f32<0x55>(rew);
+      rews[2] = dpp_f32<0xAA>(rew);
+      rews[3] = dpp_f32<0xFF>(rew);
+      hit_sum = hits + dpp_i32<kDppXor1>(hits);
+      hit_sum += dpp_i32<kDppXor2>(hit_sum);
+      int r4 = (int)reached;
+      r4 &= dpp_i32<kDppXor1>(r4);
+      r4 &= dpp_i32<kDppXor2>(r4);
+      all_reached = r4 != 0;
+    } else {
 #pragma unroll
-    for (int a = 0; a < N; ++a) {  // per-env reductions over the N part-0 lanes of this env
-      rews[a] = __shfl(rew, env_lane0 + a, 64);
-      hit_sum += __shfl(hits, env_lane0 + a, 64);
-      all_reached = all_reached && (__shfl((int)reached, env_lane0 + a, 64) != 0);
+      for (int a = 0; a < N; ++a) {  // per-env reductions over the N part-0 lanes of this env
+        rews[a] = __shfl(rew, env_lane0 + a, 64);
+        hit_sum += __shfl(hits, env_lane0 + a, 64);
+        all_reached = all_reached && (__shfl((int)reached, env_lane0 + a, 64) != 0);
+      }
     }
     collisions += hit_sum;
     const float reward = sum_agents<float, N>(rews);
@@ -185,10 +202,8 @@ template <int N, int BF16> __global__ void __launch_bounds__(256) k_policy_rollo
 #pragma unroll
         for (int k = 0; k < NO; ++k) {
           const int j = (N > 1) ? (k < i ? k : k + 1) : 0;
-          const int rj = rl - i + j;
-          V4 d;
-          d.x = ns[rj][0] - si.x; d.y = ns[rj][1] - si.y; d.z = ns[rj][2] - si.z; d.w = ns[rj][3] - si.w;
-          o[k] = d;
+          (void)j;
+          o[k] = sub4<float, V4>(oth[k], si);
         }
       }
       wave_lds_sync();  // every lane of the env has read the terminal states before they are overwritten
@@ -199,8 +214,15 @@ template <int N, int BF16> __global__ void __launch_bounds__(256) k_policy_rollo
       steps = 0;
       collisions = 0;
       was_reset = true;
-      ns[rl][0] = si.x; ns[rl][1] = si.y; ns[rl][2] = si.z; ns[rl][3] = si.w;
+      ns[rl] = si;
       wave_lds_sync();
+    }
+    if (auto_reset && __any(done)) {  // fresh episodes in this wave: the observation is that of the reset states
+#pragma unroll
+      for (int k = 0; k < NO; ++k) {
+        const int j = (N > 1) ? (k < i ? k : k + 1) : 0;
+        oth[k] = ns[rl - i + j];
+      }
     }
 
     // ---- trajectory stores + the LDS tile of the next tick ---------------------------------------------------------------------
@@ -214,9 +236,8 @@ template <int N, int BF16> __global__ void __launch_bounds__(256) k_policy_rollo
 #pragma unroll
       for (int k = 0; k < NO; ++k) {  // observation (multi-goal_spread.py:145-154)
         const int j = (N > 1) ? (k < i ? k : k + 1) : 0;
-        const int rj = rl - i + j;
-        V4 d;
-        d.x = ns[rj][0] - si.x; d.y = ns[rj][1] - si.y; d.z = ns[rj][2] - si.z; d.w = ns[rj][3] - si.w;
+        (void)j;
+        const V4 d = sub4<float, V4>(oth[k], si);
         if (row_ok) o[k] = d;
         lds.xs[rl][6 + 4 * k + 0] = d.x; lds.xs[rl][6 + 4 * k + 1] = d.y;
         lds.xs[rl][6 + 4 * k + 2] = d.z; lds.xs[rl][6 + 4 * k + 3] = d.w;
