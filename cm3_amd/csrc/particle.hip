@@ -1394,8 +1394,11 @@ __global__ void __launch_bounds__(WAVES * 64)
     Px = fx[q] + Px;
     Py = fy[q] + Py;
   }
-  const R Fx = h ? Px : dpp_f32<0xF5>(Px);  // quad_perm:[1,1,3,3]: the odd lane holds the complete sum
-  const R Fy = h ? Py : dpp_f32<0xF5>(Py);
+  // quad_perm:[1,1,3,3]: the odd lane holds the complete sum.  The moves run with ALL lanes enabled, before the select: a DPP
+  // move inside the h == 0 branch would read lanes that are switched off there (and get 0)
+  const R Qx = dpp_f32<0xF5>(Px), Qy = dpp_f32<0xF5>(Py);
+  const R Fx = h ? Px : Qx;
+  const R Fy = h ? Py : Qy;
   CM3_SPAN_MARK(2, false);  // neighbour scan + contact forces
   // ---- integrate agent i (core.py:158-169) ---------------------------------------------------------------------------------------
   si.x = si.x * kKeep;
