@@ -305,26 +305,6 @@ template <int N> struct CkLive {
 };
 
 template <int N>
-__device__ __forceinline__ void ck_load_env_fast(const CkHead &p, uint32_t ec, CkState<N> &s, CkLive<N> &lv) {
-  // the fast kernel's loads: <uniform base> + <32-bit byte offset> (every array below 4 GiB, checked by ck_launch)
-  s.mask = *at32<const uint64_t>(p.mask, ec * 8u);
-#pragma unroll
-  for (int i = 0; i < N; ++i) {
-    const uint32_t w = *at32<const uint32_t>(p.agents, ((uint32_t)i * (uint32_t)p.E + ec) * 4u);
-    s.r[i] = (int)(w & 0xff);
-    s.c[i] = (int)((w >> 8) & 0xff);
-    s.ng[i] = (int)((w >> 16) & 0xff);
-    s.no[i] = (int)((w >> 24) & 0xff);
-  }
-  lv.steps = *at32<const int32_t>(p.steps, ec * 4u);
-#pragma unroll
-  for (int i = 0; i < N; ++i) lv.goal[i] = *at32<const uint8_t>(p.goals, ec * N + i);
-  lv.episode = 0;
-  if (p.flags & (CM3_FLAG_GEN_ACTIONS | CM3_FLAG_AUTO_RESET)) lv.episode = (uint32_t)*at32<const int32_t>(p.episode, ec * 4u);
-  lv.episode_in = lv.episode;
-}
-
-template <int N>
 __device__ __forceinline__ void ck_load_env(const CkHead &p, size_t ec, CkState<N> &s, CkLive<N> &lv) {
   ck_load<N>(p, ec, s);
   lv.steps = p.steps[ec];
@@ -377,16 +357,11 @@ __device__ __forceinline__ bool ck_tick_env(const CheckersParams &p, int t, size
       words[4 * c + 3] = w.w;
     }
 #pragma unroll
-    for (int i = 0; i < N; ++i) act[i] = rand5(words[i]);
-    if (active) {  // (one predicated region for the whole row)
-      if constexpr (FAST && N == 2) {
-        *at32<int2>(actions_t, (uint32_t)e * 8u) = make_int2(act[0], act[1]);
-      } else {
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-          if constexpr (FAST) *at32<int32_t>(actions_t, ((uint32_t)e * N + i) * 4u) = act[i];
-          else actions_t[e * N + i] = act[i];
-        }
+    for (int i = 0; i < N; ++i) {
+      act[i] = rand5(words[i]);
+      if (active) {
+        if constexpr (FAST) *at32<int32_t>(actions_t, ((uint32_t)e * N + i) * 4u) = act[i];
+        else actions_t[e * N + i] = act[i];
       }
     }
   } else {
@@ -539,18 +514,6 @@ __device__ __forceinline__ void ck_restart_env(const CheckersParams &p, size_t e
   }
   ck_init<N>(p, lv.goal, s);
   lv.steps = 0;
-}
-
-template <int N>
-__device__ __forceinline__ void ck_store_env_fast(const CheckersParams &p, uint32_t e, const CkState<N> &s, const CkLive<N> &lv) {
-  // (scalar-base addressing like the loads)
-  *at32<uint64_t>(p.mask, e * 8u) = s.mask;
-#pragma unroll
-  for (int i = 0; i < N; ++i)
-    *at32<uint32_t>(p.agents, ((uint32_t)i * (uint32_t)p.E + e) * 4u) =
-        (uint32_t)s.r[i] | ((uint32_t)s.c[i] << 8) | ((uint32_t)s.ng[i] << 16) | ((uint32_t)s.no[i] << 24);
-  *at32<int32_t>(p.steps, e * 4u) = lv.steps;
-  if (lv.episode != lv.episode_in) *at32<int32_t>(p.episode, e * 4u) = (int32_t)lv.episode;
 }
 
 // plain one-tick step of the generic kernel: load, tick 0, terminal capture + restart, store
@@ -724,45 +687,6 @@ template <bool NT> __device__ __forceinline__ void ck_st(double4 *p, const doubl
 
 template <bool NT> __device__ __forceinline__ void ck_st(double *p, double v) {
   if constexpr (NT) __builtin_nontemporal_store(v, p); else *p = v;
-}
-
-// Stores of the table emit: <uniform base> + <32-bit byte offset>.  The non-temporal builtin takes a generic pointer and costs a
-// 64-bit VGPR address add per store; here the hint rides on the scalar-base form (the base is a kernel argument + tick offset:
-// wave-uniform), written in assembly because no builtin carries both.  (x3 / x4 stores end with s_nop 1: the data registers must
-// not be overwritten before the store has read them.)
-template <bool NT> __device__ __forceinline__ void ck_sto(void *base, uint32_t off, uint32_t v) {
-  if constexpr (NT) asm volatile("global_store_dword %0, %1, %2 nt" ::"v"(off), "v"(v), "s"(base) : "memory");
-  else *at32<uint32_t>(base, off) = v;
-}
-template <bool NT> __device__ __forceinline__ void ck_sto(void *base, uint32_t off, uint32_t a, uint32_t b) {
-  if constexpr (NT) {
-    const uint64_t t = (uint64_t)a | ((uint64_t)b << 32);
-    asm volatile("global_store_dwordx2 %0, %1, %2 nt" ::"v"(off), "v"(t), "s"(base) : "memory");
-  } else {
-    *at32<uint2>(base, off) = make_uint2(a, b);
-  }
-}
-template <bool NT> __device__ __forceinline__ void ck_sto(void *base, uint32_t off, uint32_t a, uint32_t b, uint32_t c) {
-  if constexpr (NT) {
-    typedef uint32_t u3 __attribute__((ext_vector_type(3)));
-    const u3 t = {a, b, c};
-    asm volatile("global_store_dwordx3 %0, %1, %2 nt\n\ts_nop 1" ::"v"(off), "v"(t), "s"(base) : "memory");
-  } else {
-    uint32_t *d = at32<uint32_t>(base, off);
-    d[0] = a; d[1] = b; d[2] = c;
-  }
-}
-template <bool NT> __device__ __forceinline__ void ck_sto(void *base, uint32_t off, const int4 &v) {
-  if constexpr (NT) {
-    const ck_u4 t = {(uint32_t)v.x, (uint32_t)v.y, (uint32_t)v.z, (uint32_t)v.w};
-    asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(off), "v"(t), "s"(base) : "memory");
-  } else {
-    *at32<int4>(base, off) = v;
-  }
-}
-template <bool NT> __device__ __forceinline__ void ck_sto(void *base, uint32_t off, double v) {
-  if constexpr (NT) asm volatile("global_store_dwordx2 %0, %1, %2 nt" ::"v"(off), "v"(v), "s"(base) : "memory");
-  else *at32<double>(base, off) = v;
 }
 
 // Observation of one env, written by its G lanes.  Everything is sized at compile time (the fast kernel's geometry is fixed), so
@@ -1081,10 +1005,10 @@ __device__ __forceinline__ void ckf_emit_tab(const CheckersParams &p, const CkSt
       const uint32_t d0 = __builtin_amdgcn_perm(c[1], c[0], 0x04020100u);
       const uint32_t d1 = __builtin_amdgcn_perm(c[2], c[1], 0x05040201u);
       const uint32_t d2 = __builtin_amdgcn_perm(c[3], c[2], 0x06050402u);
-      // (whole 12-byte pieces except in the last slot of a record, whose tail is one or two dwords)
-      if (3 * q + 2 < T::OD) ck_sto<NT>(out.obs_self_t, orow + 12u * q, d0, d1, d2);
-      else if (3 * q + 1 < T::OD) ck_sto<NT>(out.obs_self_t, orow + 12u * q, d0, d1);
-      else ck_sto<NT>(out.obs_self_t, orow + 12u * q, d0);
+      uint32_t *dst = at32<uint32_t>(out.obs_self_t, orow + 12u * q);
+      ck_st<NT>(dst, d0);
+      if (3 * q + 1 < T::OD) ck_st<NT>(dst + 1, d1);
+      if (3 * q + 2 < T::OD) ck_st<NT>(dst + 2, d2);
     }
   }
   // ---- grid: dword d = cells 2d, 2d + 1 of get_valid_grid (checkers.py:66-76) --------------------------------------------------
@@ -1096,7 +1020,7 @@ __device__ __forceinline__ void ckf_emit_tab(const CheckersParams &p, const CkSt
       const uint32_t gs = pl.gstatic[it];
       const uint32_t g0 = (uint32_t)__builtin_amdgcn_sbfe((int)m32, pl.gb0[it], 1), g1 = (uint32_t)__builtin_amdgcn_sbfe((int)m32, pl.gb1[it], 1);
       const uint32_t w = gs ^ (gs & g0 & 0x0000fefeu) ^ (gs & g1 & 0xfefe0000u);
-      if (d < T::GD) ck_sto<NT>(out.grid, grow + 4u * d, w);
+      if (d < T::GD) ck_st<NT>(at32<uint32_t>(out.grid, grow + 4u * d), w);
     }
   }
   // ---- vec ------------------------------------------------------------------------------------------------------------------
@@ -1106,7 +1030,7 @@ __device__ __forceinline__ void ckf_emit_tab(const CheckersParams &p, const CkSt
     for (int a = 1; a < N; ++a) wa = (g == a) ? word[a] : wa;
     int4 v;
     v.x = (int)(wa & 0xffu); v.y = (int)((wa >> 8) & 0xffu); v.z = (int)((wa >> 16) & 0xffu); v.w = (int)(wa >> 24);
-    ck_sto<NT>(out.vec, (e * N + g) * 16u, v);
+    ck_st<NT>(at32<int4>(out.vec, (e * N + g) * 16u), v);
   }
   // ---- obs_self_v, obs_others ------------------------------------------------------------------------------------------------
 #pragma unroll
@@ -1115,8 +1039,8 @@ __device__ __forceinline__ void ckf_emit_tab(const CheckersParams &p, const CkSt
     if (it * G < T::NV) {  // (compile time)
       if (v < T::NV) {
         const uint32_t off = pl.voff[it] & 0x7fffffffu;
-        if ((int)pl.voff[it] < 0) ck_sto<NT>(out.obs_others, e * (uint32_t)(T::NOO * 8) + off, nval[it]);
-        else ck_sto<NT>(out.obs_self_v, e * (uint32_t)(T::NSV * 8) + off, nval[it]);
+        if ((int)pl.voff[it] < 0) ck_st<NT>(at32<double>(out.obs_others, e * (uint32_t)(T::NOO * 8) + off), nval[it]);
+        else ck_st<NT>(at32<double>(out.obs_self_v, e * (uint32_t)(T::NSV * 8) + off), nval[it]);
       }
     }
   }
@@ -1146,7 +1070,7 @@ __global__ void __launch_bounds__(256)
   __shared__ __attribute__((aligned(16))) uint4 lds_tab_all[4][48];
   uint4 *lds_tab = &lds_tab_all[wave][0];
   CM3_STAMP(0, false);
-  ck_load_env_fast<N>(hd, ec, s, lv);
+  ck_load_env<N>(hd, ec, s, lv);
   // while those loads are in flight: the wave's copy of the board / norm table and this lane's plan (see ckf_emit_tab)
   CkLanePlan<N, G> pl;
   ckf_plan_load<N, G>(g, lane, lds_tab, pl);
@@ -1181,7 +1105,7 @@ __global__ void __launch_bounds__(256)
       for (int i = 0; i < N; ++i) *at32<uint8_t>(gn, e * N + i) = lv.goal[i];
     }
   }
-  if (writer) ck_store_env_fast<N>(p, e, s, lv);
+  if (writer) ck_store_env<N>(p, e, s, lv);
   CM3_STAMP(9, true);
   CM3_SPAN_OUT(p.span);
 }

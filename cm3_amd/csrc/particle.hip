@@ -193,7 +193,7 @@ template <typename R, typename V4> __device__ __forceinline__ V4 sub4(const V4 &
 constexpr uint32_t kFlagObsStoreNt = 0x100000u;  // internal launch flag, set by particle_rollout only
 constexpr size_t kWtMinObsBytes = (size_t)3 << 20;
 #ifndef CM3_AGENTS2_MAX_ENVS
-#define CM3_AGENTS2_MAX_ENVS 8192    // (macro: build variant for the crossover measurement)
+#define CM3_AGENTS2_MAX_ENVS 32768   // measured crossover, profiles/r03_two_lanes_per_agent.txt (macro: build variant for that measurement)
 #endif
 constexpr size_t kAgents2MaxEnvs = CM3_AGENTS2_MAX_ENVS;  // N = 8: two lanes per agent up to this many envs per launch
 
@@ -1720,7 +1720,7 @@ template <typename R, int N, int WAVES> static int launch_agents(const ParticleP
     // a launch that writes >= kWtMinObsBytes of observation rows writes them through (kSpWt; per-tick launches, no slot copies)
     const bool wt = sizeof(R) == 4 && (size_t)(p.EN - p.E0) * AgentGeom<N>::VPE * 4 * sizeof(R) >= kWtMinObsBytes;
     if constexpr (N == 8 && sizeof(R) == 4) {
-      // two lanes per agent (k_particle_step_agents2) while the batch leaves SIMDs with one wave: per-tick launches up to kAgents2MaxEnvs
+      // two lanes per agent (k_particle_step_agents2) while a SIMD holds few waves: per-tick launches up to kAgents2MaxEnvs
       if (p.n_ticks == 1 && (size_t)(p.EN - p.E0) <= kAgents2MaxEnvs) {
         const unsigned blocks2 = (unsigned)(((size_t)(p.EN - p.E0) + (size_t)WAVES * 4 - 1) / ((size_t)WAVES * 4));
 #define CM3_LAUNCH_AGENTS2(...)                                                                                             \
@@ -1796,7 +1796,9 @@ template <typename R, int N> static int launch_n(const ParticleParams &p, Partic
     //   N = 2: pair up to 32768 envs (16384: 2.57 / - / 2.68; 32768: 2.89 / - / 3.01); N = 6: agent from 6144 (4.27 / 4.11);
     //   N = 7, 8: agent from 4096 (N = 8: 5.12 / 4.57, N = 7: 4.73 / 4.34; at 2048 pair: 3.83 / 4.29)
     constexpr size_t kPairMax = N == 2 ? 32768 : (N == 3 ? 24576 : (N == 4 ? 12288 : kPairsMaxEnvs));
-    constexpr size_t kAgentLo = N == 4 ? 12289 : (N == 5 ? 8192 : (N == 6 ? 6144 : (N >= 7 ? 4096 : kInf)));
+    // round 3, N = 8 with two lanes per agent (k_particle_step_agents2; profiles/r03_two_lanes_per_agent.txt): agent from 2048
+    // (in place 3.50 vs pair 3.54; 3072: 3.66 vs 4.04; 1024: 3.40 vs 3.02 -> pair)
+    constexpr size_t kAgentLo = N == 4 ? 12289 : (N == 5 ? 8192 : (N == 6 ? 6144 : (N == 7 ? 4096 : (N == 8 ? 2048 : kInf))));
     constexpr size_t kAgentHi = N == 4 || N == 5 ? 40960 : (N == 6 ? 65536 : (N >= 7 ? kInf : 0));
     bool pairs = N >= 2 && (size_t)p.E <= kPairMax;
     bool agents = N >= 4 && (size_t)p.E >= kAgentLo && (size_t)p.E <= kAgentHi;
