@@ -1799,7 +1799,12 @@ template <typename R, int N> static int launch_n(const ParticleParams &p, Partic
     // round 3, N = 8 with two lanes per agent (k_particle_step_agents2; profiles/r03_two_lanes_per_agent.txt): agent from 2048
     // (in place 3.50 vs pair 3.54; 3072: 3.66 vs 4.04; 1024: 3.40 vs 3.02 -> pair)
     constexpr size_t kAgentLo = N == 4 ? 12289 : (N == 5 ? 8192 : (N == 6 ? 6144 : (N == 7 ? 4096 : (N == 8 ? 2048 : kInf))));
-    constexpr size_t kAgentHi = N == 4 || N == 5 ? 40960 : (N == 6 ? 65536 : (N >= 7 ? kInf : 0));
+    // round 3, large batches after the write-through observation stores (profiles/r03_mapping_sweep_large.txt; env / agent):
+    //   N = 6: 2^17 17.7 / 17.4, 2^19 66.3 / 62.3, 2^20 125.5 / 121.9, 2^21 290 / 326   -> agent up to 1.5 M envs (was 65536)
+    //   N = 7: 2^19 89 / 80, 2^20 164-170 / 153-217 (the agent mapping is bimodal there: it depends on where the allocator
+    //          put the buffers), 2^21 392-412 / 437-466                                -> agent up to 768 K envs (was unbounded)
+    //   N = 8: 2^19 110.5 / 99.9, 2^20 222-233 / 278-281 (6.1 vs 4.9 TB/s), 2^21 489-556 / 477-505 -> agent up to 768 K envs
+    constexpr size_t kAgentHi = N == 4 || N == 5 ? 40960 : (N == 6 ? 1572864 : (N >= 7 ? 786432 : 0));
     bool pairs = N >= 2 && (size_t)p.E <= kPairMax;
     bool agents = N >= 4 && (size_t)p.E >= kAgentLo && (size_t)p.E <= kAgentHi;
     // both shared-env mappings index with 32-bit byte offsets (obs_others below 4 GiB per tick); beyond that only a forced choice
