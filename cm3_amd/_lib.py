@@ -62,6 +62,11 @@ class ParticleTraj(ctypes.Structure):
                 ("state_live", c_void_p), ("goals_live", c_void_p)]
 
 
+class CopyShift(ctypes.Structure):
+    _fields_ = [("n", c_int32), ("_pad", c_int32), ("first_dst", c_void_p * 4), ("mid", c_void_p * 4),
+                ("last_src", c_void_p * 4), ("bytes", c_size_t * 4)]
+
+
 class CheckersDesc(ctypes.Structure):
     _fields_ = [("n_envs", c_int32), ("n_agents", c_int32), ("n_rows", c_int32), ("n_columns", c_int32),
                 ("n_obs", c_int32), ("max_steps", c_int32), ("flags", c_uint32), ("grid_stride", c_int32),
@@ -165,6 +170,10 @@ SYMBOLS = {
                                          c_int32, c_void_p]),
     "cm3_normalize_f64": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_size_t, c_int32, c_double,
                                          c_int32, c_void_p]),
+    "cm3_returns_normalize_f32": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                 c_int32, c_int32, c_int32, c_double, c_double, c_int32, c_void_p, c_void_p]),
+    "cm3_returns_normalize_f64": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                 c_int32, c_int32, c_int32, c_double, c_double, c_int32, c_void_p, c_void_p]),
     "cm3_copy_list": (ctypes.c_int, [c_int32, P(c_void_p), P(c_void_p), P(c_size_t), c_void_p]),
     "cm3_hbm_read_bench": (ctypes.c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
     "cm3_hbm_bench_sink_words": (ctypes.c_int, []),

@@ -58,12 +58,16 @@ def _valid_from_done(done_u8, finished0=None):
     return valid
 
 
+def _pairs_aligned(pairs):
+    return all((d.numel() * d.element_size()) % 16 == 0 and d.data_ptr() % 16 == 0 and s_.data_ptr() % 16 == 0
+               and d.is_contiguous() and s_.is_contiguous() and d.numel() * d.element_size() == s_.numel() * s_.element_size()
+               for d, s_ in pairs)
+
+
 def _copy_pairs(pairs, stream):
     """(dst, src) tensor pairs: ONE cm3_copy_list launch per 8 regions when every region is 16-byte sized / aligned,
-    torch copies otherwise."""
-    ok = all((d.numel() * d.element_size()) % 16 == 0 and d.data_ptr() % 16 == 0 and s_.data_ptr() % 16 == 0
-             and d.is_contiguous() and s_.is_contiguous() and d.numel() * d.element_size() == s_.numel() * s_.element_size()
-             for d, s_ in pairs)
+    torch copies (on torch's current stream) otherwise."""
+    ok = _pairs_aligned(pairs)
     if ok:
         for k in range(0, len(pairs), 8):
             _lib.copy_list(pairs[k:k + 8], stream)
@@ -236,6 +240,32 @@ class ParticleRollout(object):
             fn = getattr(self._lib, "cm3_particle_rollout_" + env._suffix)
             _lib.check(fn(ctypes.byref(env._desc), ctypes.byref(traj), int(n), stream))
 
+    def _enqueue_tick0_from_env(self, flags, stream):
+        """Tick 0 as a plain step launch that READS the env's own state / goals buffers (not slot 0) and writes slot 1 and the
+        per-tick slots 0: the copy that records slot 0 then no longer stands between the caller and the first step launch
+        (collect_normalized runs it on a parallel branch of its graph).  Values are those of `_enqueue(0, 1, ...)`."""
+        env = self.env
+        b = _lib.ParticleBufs()
+        b.state_in = env._state[env._cur].data_ptr()
+        b.state_out = self.state[1].data_ptr()
+        b.goals_in = env._goals.data_ptr()
+        b.goals_out = self.goals[1].data_ptr() if self.goals is not None else env._goals.data_ptr()
+        b.meta_in = b.meta_out = env._meta.data_ptr()
+        b.episode = env._episode.data_ptr()
+        b.actions = self.actions[0].data_ptr()
+        b.obs_others = self.obs_others[1].data_ptr()
+        b.reward_n = self.reward_n[0].data_ptr()
+        b.reward = self.reward[0].data_ptr()
+        b.done = self.done[0].data_ptr()
+        if self.term_state is not None:
+            b.term_state = self.term_state[0].data_ptr()
+            b.term_obs_others = self.term_obs_others[0].data_ptr()
+        if self.collisions is not None:
+            b.collisions_tick = self.collisions[0].data_ptr()
+        env._desc.flags = flags
+        fn = getattr(self._lib, "cm3_particle_step_" + env._suffix)
+        _lib.check(fn(ctypes.byref(env._desc), ctypes.byref(b), stream))
+
     def _copy(self, pairs):
         """(dst, src) tensor pairs: one cm3_copy_list launch when every region is 16-byte sized / aligned."""
         _copy_pairs(pairs, self.env._stream())
@@ -405,11 +435,22 @@ class ParticleRollout(object):
         def enqueue(s):
             pairs = [(self.state[0], env._state[env._cur]), (self.obs_others[0], env._obs_others[env._cur]),
                      (self.goals[0], env._goals)]
-            _copy_pairs(pairs, s)
-            self._enqueue(0, self.T, flags, s, live=live)
             back = [(env._obs_others[env._cur], self.obs_others[self.T])]
             if not live:
                 back += [(env._state[env._cur], self.state[self.T]), (env._goals, self.goals[self.T])]
+            if self.use_graph and not live and world == 1 and _pairs_aligned(pairs + back):
+                # one rank, one graph: tick 0 reads the env's buffers directly (not slot 0), and the launch that computes the
+                # returns and their partial moments also records slot 0 from the env's buffers and then leaves slot T in them --
+                # the chain of dependent launches is T step launches + 2, not T + 4
+                self._enqueue_tick0_from_env(flags, s)
+                if self.T > 1:
+                    self._enqueue(1, self.T - 1, flags, s, live=False)
+                self._norm.enqueue_fused(s, [(self.state[0], env._state[env._cur], self.state[self.T]),
+                                             (self.obs_others[0], env._obs_others[env._cur], self.obs_others[self.T]),
+                                             (self.goals[0], env._goals, self.goals[self.T])])
+                return
+            _copy_pairs(pairs, s)
+            self._enqueue(0, self.T, flags, s, live=live)
             _copy_pairs(back, s)
             self._norm.enqueue_moments(s)
             if world == 1:

@@ -165,6 +165,23 @@ class ReturnsNormalizer(object):
             self.reward.data_ptr(), self.done.data_ptr(), 0, self.out.data_ptr(), self.scratch.data_ptr(),
             self.moments.data_ptr(), self.T, self.E, self.C, self.gamma, stream))
 
+    def enqueue_fused(self, stream, shift=None):
+        """enqueue_moments + enqueue_normalize on this rank's own moments (cm3_returns_normalize_*: two launches, the first of them
+        in one memory round trip for T <= 40), bit for bit; shift: optional list of up to 4 (first_dst, mid, last_src) tensor
+        triples -- first_dst <- mid, then mid <- last_src, done by the first launch (include/cm3_amd.h cm3_copy_shift)."""
+        cs = None
+        if shift:
+            cs = self._lib_mod.CopyShift()
+            cs.n = len(shift)
+            for r, (a, m, c) in enumerate(shift):
+                cs.first_dst[r], cs.mid[r], cs.last_src[r] = a.data_ptr(), m.data_ptr(), c.data_ptr()
+                cs.bytes[r] = m.numel() * m.element_size()
+        import ctypes
+        self._lib_mod.check(getattr(self.lib, "cm3_returns_normalize_" + self.suffix)(
+            self.reward.data_ptr(), self.done.data_ptr(), 0, self.out.data_ptr(), self.scratch.data_ptr(),
+            self.moments.data_ptr(), self.stats.data_ptr(), self.T, self.E, self.C, self.gamma, self.eps, self.apply,
+            ctypes.byref(cs) if cs is not None else None, stream))
+
     def enqueue_normalize(self, stream, parts=None, n_parts=1):
         parts = self.moments if parts is None else parts
         self._lib_mod.check(getattr(self.lib, "cm3_normalize_" + self.suffix)(

@@ -424,8 +424,8 @@ int cm3_actor_checkers_f32(const cm3_actor_checkers_desc *desc, const cm3_actor_
  *   x, out  real [T][E][C]   (C = N for reward_n, 1 for the team reward); out may alias x
  *   done    uint8 [T][E];  valid uint8 [T][E] optional (invalid entries: out = 0, excluded from the moments)
  *   scratch >= cm3_returns_scratch_bytes() bytes, ZERO-INITIALISED ONCE by the caller (per-block partials + an arrival
- *   counter; the last block to arrive folds the partials in block order and resets the counter for the next call on the
- *   same stream -- no memset launch per call);
+ *   counter; the last block to arrive folds the partials in block order and resets the counter for the
+ *   next call on the same stream -- no memset launch per call);
  *   moments double[3] = (sum, sum of squares, count) of this rank's valid returns, computed deterministically.
  *   The host all-gathers the three numbers over the ranks (RCCL); cm3_normalize_* sums the n_parts triples in rank order
  *   and applies x = (x - (real)mean) / (real)(std + eps) with the GLOBAL moments (x real [n_elem], valid indexed by
@@ -441,6 +441,29 @@ int cm3_normalize_f32(void *x, const uint8_t *valid, const double *parts, int32_
                       int32_t C, double eps, int32_t apply, void *stream);
 int cm3_normalize_f64(void *x, const uint8_t *valid, const double *parts, int32_t n_parts, double *stats, size_t n_elem,
                       int32_t C, double eps, int32_t apply, void *stream);
+/* ONE rank's whole advantage step (the all-gather is the identity) as TWO launches: cm3_returns_moments_* + cm3_normalize_* with
+ * n_parts = 1 on its own moments, bit for bit.  Launch A computes the returns and per-block partial moments (short trajectories,
+ * T <= 40: the whole column in one memory round trip), launch B folds the partials in block order in every block -- the fold of
+ * cm3_returns_moments_*, so `moments` receives the same bits -- and normalises; no atomics, no arrival counter.
+ * `shift` (optional) adds the slot bookkeeping of the rollout whose rewards these are to launch A, element by element:
+ * first_dst[r] <- mid[r], then mid[r] <- last_src[r] (r < n <= 4; 16-byte aligned pointers and sizes).  With mid = the env's live
+ * buffers, first_dst = slot 0 and last_src = slot T of a trajectory whose first tick READ the live buffers, this records the
+ * initial state into slot 0 and leaves the final state in the live buffers (train_onpolicy.py:340-343 "state = next_state" across
+ * rollouts) without launches of its own: a 33-tick rollout is a chain of dependent launches of ~2.6 us each, and its tail was four. */
+typedef struct cm3_copy_shift {
+  int32_t n;
+  int32_t _pad;
+  void *first_dst[4];
+  void *mid[4];
+  const void *last_src[4];
+  size_t bytes[4];
+} cm3_copy_shift;
+int cm3_returns_normalize_f32(const void *x, const uint8_t *done, const uint8_t *valid, void *out, void *scratch,
+                              double *moments, double *stats, int32_t T, int32_t E, int32_t C, double gamma, double eps,
+                              int32_t apply, const cm3_copy_shift *shift, void *stream);
+int cm3_returns_normalize_f64(const void *x, const uint8_t *done, const uint8_t *valid, void *out, void *scratch,
+                              double *moments, double *stats, int32_t T, int32_t E, int32_t C, double gamma, double eps,
+                              int32_t apply, const cm3_copy_shift *shift, void *stream);
 /* Up to 8 device-to-device copies (16-byte aligned pointers and sizes) in ONE launch: trajectory slot <-> live env buffers
  * of the collection loop (train_onpolicy.py:340-343 "state = next_state" across rollouts). */
 int cm3_copy_list(int32_t n, void *const *dst, const void *const *src, const size_t *bytes, void *stream);

@@ -208,6 +208,50 @@ def test_returns_moments_and_normalisation_kernels(dtype, C):
     assert torch.equal(again, norm) and float(mean_b) == float(mean) and float(std_b) == float(std)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("E,C", [(1000, 4), (4096, 4), (70000, 8), (333, 1)])
+def test_single_rank_advantage_step_equals_moments_then_normalize(dtype, E, C):
+    """cm3_returns_normalize_* (returns + per-block partials [+ the slot bookkeeping cm3_copy_shift], then fold + normalisation in
+    every block) against cm3_returns_moments_* + cm3_normalize_*, bit for bit, call after call; 70000 x 8 columns = more columns
+    than lanes in the grid (the generic walk), the others take the one-round-trip kernel (T <= 40)."""
+    import ctypes
+    from cm3_amd import _lib
+    from cm3_amd.shard import ReturnsNormalizer
+    T = 33
+    g = torch.Generator(device="cuda").manual_seed(E + C)
+    x = torch.randn((T, E, C) if C > 1 else (T, E), generator=g, device="cuda", dtype=dtype) * 3 - 1
+    done = (torch.rand(T, E, generator=g, device="cuda") < 0.05).to(torch.uint8)
+    valid = (torch.rand(T, E, generator=g, device="cuda") > 0.1).to(torch.uint8)
+    lib = _lib.lib()
+    sfx = "f32" if dtype == torch.float32 else "f64"
+    s = _lib.current_stream_handle(x.device)
+    for v8 in (None, valid):
+        for apply in (1, 0):
+            two, one = ReturnsNormalizer(x, done, 0.97, 1e-8, bool(apply)), ReturnsNormalizer(x, done, 0.97, 1e-8, bool(apply))
+            # slot bookkeeping: a <- m, m <- c
+            m0 = torch.randn(4096, generator=g, device="cuda")
+            c0 = torch.randn(4096, generator=g, device="cuda")
+            a, m, c = torch.zeros_like(m0), m0.clone(), c0.clone()
+            cs = _lib.CopyShift()
+            cs.n = 1
+            cs.first_dst[0], cs.mid[0], cs.last_src[0], cs.bytes[0] = a.data_ptr(), m.data_ptr(), c.data_ptr(), m.numel() * 4
+            for rep in range(3):
+                _lib.check(getattr(lib, "cm3_returns_moments_" + sfx)(
+                    x.data_ptr(), done.data_ptr(), _lib.ptr(v8), two.out.data_ptr(), two.scratch.data_ptr(), two.moments.data_ptr(),
+                    T, E, C, 0.97, s))
+                _lib.check(getattr(lib, "cm3_normalize_" + sfx)(
+                    two.out.data_ptr(), _lib.ptr(v8), two.moments.data_ptr(), 1, two.stats.data_ptr(), two.out.numel(), C, 1e-8,
+                    apply, s))
+                _lib.check(getattr(lib, "cm3_returns_normalize_" + sfx)(
+                    x.data_ptr(), done.data_ptr(), _lib.ptr(v8), one.out.data_ptr(), one.scratch.data_ptr(), one.moments.data_ptr(),
+                    one.stats.data_ptr(), T, E, C, 0.97, 1e-8, apply, ctypes.byref(cs) if rep == 0 else None, s))
+                torch.cuda.synchronize()
+                assert torch.equal(one.out, two.out), (rep, apply)
+                assert torch.equal(one.buf, two.buf)
+            assert torch.equal(a, m0) and torch.equal(m, c0) and torch.equal(c, c0)
+    assert float(one.stats[2]) > 0
+
+
 @pytest.mark.parametrize("cfg_name", ["checkers_stage2.json", "checkers_stage1.json"])
 def test_checkers_fused_rollout_equals_per_tick(cfg_name):
     from cm3_amd.checkers import VecCheckersEnv
