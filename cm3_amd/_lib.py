@@ -135,6 +135,7 @@ class ActorCheckersBufs(ctypes.Structure):
 P = ctypes.POINTER
 SYMBOLS = {
     "cm3_abi_version": (ctypes.c_int, []),
+    "cm3_source_id": (ctypes.c_char_p, []),
     "cm3_last_error": (ctypes.c_char_p, []),
     "cm3_device_count": (ctypes.c_int, []),
     "cm3_device_name": (ctypes.c_int, [ctypes.c_int, ctypes.c_char_p, ctypes.c_int]),
@@ -220,8 +221,32 @@ def lib():
         fn.argtypes = args
     if handle.cm3_abi_version() != ABI_VERSION:
         raise Cm3Error("ABI version mismatch: library %d, binding %d" % (handle.cm3_abi_version(), ABI_VERSION))
+    # a library built from other sources than the ones next to this file is refused (a test run against a stale build proves
+    # nothing); CM3_AMD_LIB = an explicitly chosen build (same-box A/B comparisons, the two-stamp build) is taken as it is
+    if "CM3_AMD_LIB" not in os.environ and os.environ.get("CM3_AMD_ALLOW_STALE") != "1":
+        built, have = handle.cm3_source_id().decode(), source_id()
+        if have is not None and built != have:
+            raise Cm3Error("%s was built from other sources (library %s, sources %s): rebuild with cm3_amd/csrc/build.sh "
+                           "or `python -c 'import __graft_entry__ as g; g.build()'`" % (LIB_PATH, built, have))
     _lib = handle
     return _lib
+
+
+def source_id():
+    """What csrc/build.sh bakes into the library as cm3_source_id(): the first 16 hex digits of the SHA-256 over csrc/*.hip and
+    csrc/*.h (byte order of the names) followed by include/cm3_amd.h.  None when the sources are not there (a wheel without them)."""
+    import hashlib
+    here = os.path.dirname(os.path.abspath(__file__))
+    csrc = os.path.join(here, "csrc")
+    header = os.path.join(os.path.dirname(here), "include", "cm3_amd.h")
+    if not os.path.isdir(csrc) or not os.path.exists(header):
+        return None
+    names = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h")))
+    h = hashlib.sha256()
+    for f in names + [header]:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def check(rc):

@@ -7,6 +7,9 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function ${CM3_EXTRA_FLAGS:-}"
 OUT="${CM3_OUT:-${OUT}}"
 mkdir -p "${HERE}/_obj"
+# identity of the sources this library is built from (cm3_source_id(); cm3_amd/_lib.py refuses a library whose id differs from
+# the sources next to it: a test run against a stale build proves nothing)
+SRC_ID="$(cat $(ls "${HERE}"/*.hip "${HERE}"/*.h | LC_ALL=C sort) "${HERE}/../../include/cm3_amd.h" | sha256sum | cut -c1-16)"
 pids=()
 "${HIPCC}" ${FLAGS} -mllvm -amdgpu-kernarg-preload-count=16 -DCM3_PARTICLE_F32 -c "${HERE}/particle.hip" -o "${HERE}/_obj/particle_f32.o" &
 pids+=($!)
@@ -20,7 +23,7 @@ pids+=($!)
 "${HIPCC}" ${FLAGS} -mllvm -amdgpu-kernarg-preload-count=16 -mllvm -amdgpu-sched-strategy=${CM3_HOT_SCHED:-max-ilp} ${CM3_HOT_FLAGS:-} -c "${HERE}/checkers.hip" -o "${HERE}/_obj/checkers.o" &
 pids+=($!)
 for f in util advantage actor actor_checkers policy; do
-  "${HIPCC}" ${FLAGS} -c "${HERE}/${f}.hip" -o "${HERE}/_obj/${f}.o" &
+  "${HIPCC}" ${FLAGS} -DCM3_SOURCE_ID="\"${SRC_ID}\"" -c "${HERE}/${f}.hip" -o "${HERE}/_obj/${f}.o" &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait "$p"; done

@@ -150,6 +150,11 @@ extern "C" {
 
 int cm3_abi_version(void) { return CM3_ABI_VERSION; }
 
+#ifndef CM3_SOURCE_ID
+#define CM3_SOURCE_ID "unknown"
+#endif
+const char *cm3_source_id(void) { return CM3_SOURCE_ID; }
+
 const char *cm3_last_error(void) { return cm3::last_error_buf(); }
 
 int cm3_device_count(void) {

@@ -438,7 +438,7 @@ class ParticleRollout(object):
             back = [(env._obs_others[env._cur], self.obs_others[self.T])]
             if not live:
                 back += [(env._state[env._cur], self.state[self.T]), (env._goals, self.goals[self.T])]
-            if self.use_graph and not live and world == 1 and _pairs_aligned(pairs + back):
+            if not live and world == 1 and _pairs_aligned(pairs + back):
                 # one rank, one graph: tick 0 reads the env's buffers directly (not slot 0), and the launch that computes the
                 # returns and their partial moments also records slot 0 from the env's buffers and then leaves slot T in them --
                 # the chain of dependent launches is T step launches + 2, not T + 4

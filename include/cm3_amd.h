@@ -75,6 +75,9 @@ extern "C" {
    CM3_ERR_INVALID.  (N = 8, float32: 4.79 M envs.) */
 
 int cm3_abi_version(void);
+/* First 16 hex digits of the SHA-256 over the library's sources (csrc/*.hip, csrc/*.h in byte order of their names, then this
+ * header), baked in by csrc/build.sh.  The Python binding compares it with the sources next to it and refuses a stale build. */
+const char *cm3_source_id(void);
 const char *cm3_last_error(void);
 /* Number of visible HIP devices (0 when none); fills name (<= len bytes) of device `dev` if name != NULL. */
 int cm3_device_count(void);

@@ -127,3 +127,18 @@ def test_checkers_step_refuses_batches_beyond_its_32_bit_offsets(built):
     assert d.n_envs * 600 < (1 << 32)                           # the window record alone would have passed
     assert handle.cm3_checkers_step(ctypes.byref(d), ctypes.byref(b), None) == -1
     assert b"4 GiB" in handle.cm3_last_error()
+
+
+def test_library_carries_the_identity_of_its_sources(built):
+    """cm3_source_id() = the hash csrc/build.sh computed over the sources = the hash the binding computes over the files next to
+    it; the binding refuses a library built from other sources (a green test run against a stale build proves nothing)."""
+    import subprocess
+    import sys
+    handle = built.lib()
+    assert handle.cm3_source_id().decode() == built.source_id() and len(built.source_id()) == 16
+    code = ("import cm3_amd._lib as l\n"
+            "l.source_id = lambda: '0' * 16\n"
+            "try:\n    l.lib()\nexcept l.Cm3Error as e:\n    print('REFUSED' if 'other sources' in str(e) else e)\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT,
+                         env={k: v for k, v in os.environ.items() if k not in ("CM3_AMD_LIB", "CM3_AMD_ALLOW_STALE")})
+    assert "REFUSED" in out.stdout, out.stdout + out.stderr
