@@ -154,11 +154,12 @@ class CheckersActor(object):
     """
 
     def __init__(self, weights, n_agents, stage=2, device="cuda:0", seed=12341, env_id_base=0, precision="f32"):
-        """precision "f32" (default, the parity path) or "bf16" (the two 256x256 layers on the bf16 matrix cores, float32
-        accumulation: 2.4x faster, probabilities within ~1e-2 of the float32 ones)."""
+        """precision of the two 256x256 layers (86 % of the network's FLOPs): "f32" (default: exact-f32 MFMA), "f16x3" (split
+        float16: activations and weights as float16 hi + lo, three float16 MFMAs per product with float32 accumulation -- held to
+        the same 2e-5 parity bound as "f32"), or "bf16" (not a parity path: probabilities within ~1e-2 of the float32 ones)."""
         self.device = _lib.require_gpu(device)
-        if precision not in ("f32", "bf16"):
-            raise Cm3Error("precision must be 'f32' or 'bf16'")
+        if precision not in PRECISIONS:
+            raise Cm3Error("precision must be one of %s" % sorted(PRECISIONS))
         self.precision = precision
         self.n = int(n_agents)
         self.stage = int(stage)

@@ -75,8 +75,8 @@ extern "C" {
    CM3_ERR_INVALID.  (N = 8, float32: 4.79 M envs.) */
 
 int cm3_abi_version(void);
-/* First 16 hex digits of the SHA-256 over the library's sources (csrc/*.hip, csrc/*.h in byte order of their names, then this
- * header), baked in by csrc/build.sh.  The Python binding compares it with the sources next to it and refuses a stale build. */
+/* First 16 hex digits of the SHA-256 over the library's sources (the .hip and .h files of csrc/ in byte order of their names,
+ * then this header), baked in by csrc/build.sh.  The Python binding compares it with the sources next to it and refuses a stale build. */
 const char *cm3_source_id(void);
 const char *cm3_last_error(void);
 /* Number of visible HIP devices (0 when none); fills name (<= len bytes) of device `dev` if name != NULL. */
@@ -387,7 +387,9 @@ typedef struct cm3_actor_checkers_desc {
   float epsilon;
   int32_t precision;         /* 0: float32 throughout (parity path).  1: the two 256x256 layers on the bf16 matrix cores with
                                 float32 accumulation (first-layer activations and those weights rounded to bf16; probabilities
-                                move by up to ~1e-2) */
+                                move by up to ~1e-2).  2: the same two layers in split float16 -- activations and weights as
+                                float16 hi + lo, hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16, float32 accumulation: a
+                                parity path (held to the 2e-5 of precision 0) at a third of the bf16 layers' MFMA rate */
   int32_t obs_self_t_stride; /* bytes between env records of obs_self_t (cm3_checkers_desc.obs_self_t_stride) */
   int64_t env_id_base;
   uint64_t seed;

@@ -31,10 +31,12 @@ def _oracle_probs(w, env, prev, eps):
         env.goals.reshape(rows, 2).cpu().numpy()), eps)
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
 @pytest.mark.parametrize("stage", [1, 2])
 @pytest.mark.parametrize("eps", [0.0, 0.3])
 @pytest.mark.parametrize("E", [1000, 33])
-def test_actor_probs_and_samples_match_oracle(stage, eps, E):
+def test_actor_probs_and_samples_match_oracle(stage, eps, E, precision):
+    """precision "f16x3" (the two 256x256 layers as three float16 MFMAs over hi + lo splits) is held to the float32 bound."""
     from cm3_amd.actor import CheckersActor
     seed = 91
     rng = np.random.default_rng(stage * 7 + E)
@@ -43,7 +45,7 @@ def test_actor_probs_and_samples_match_oracle(stage, eps, E):
     env.reset(_goals(rng, E, N))
     for _ in range(5):
         env.step()                       # in-kernel uniform actions: agents spread out, pick cells up
-    actor = CheckersActor(w, N, stage=stage, device="cuda:0", seed=seed)
+    actor = CheckersActor(w, N, stage=stage, device="cuda:0", seed=seed, precision=precision)
     prev = rng.integers(0, 5, (E, N))
     actions, probs = actor.act(env, eps, actions_prev=prev, return_probs=True)
     rows = E * N
@@ -287,3 +289,31 @@ def test_device_actor_matches_vectors_from_the_reference_function_body(tag, N, s
     CheckersActor(w, N, stage=stage, device=dev).enqueue(E, raw, stride, ov, oo, goals, prev, steps, episode, actions,
                                                          0.0, probs)
     assert np.abs(probs.reshape(rows, 5).cpu().numpy() - want).max() < 2e-5
+
+
+@pytest.mark.parametrize("stage", [1, 2])
+def test_split_float16_layers_stay_in_the_float32_error_class(stage):
+    """precision="f16x3" against the float64-accumulated oracle next to precision="f32": worst error of the same order (the
+    parity bound 2e-5 holds for both), a different kernel, and the same sampled actions off CDF boundaries."""
+    from cm3_amd.actor import CheckersActor
+    rng = np.random.default_rng(33)
+    E = 2000
+    env, N = _env(E, stage, seed=8)
+    env.reset(_goals(rng, E, N))
+    for _ in range(5):
+        env.step()
+    w = AO.init_weights(rng, N, stage=stage)
+    prev = rng.integers(0, 5, (E, N))
+    want = _oracle_probs(w, env, prev, 0.0)
+    out = {}
+    for prec in ("f32", "f16x3"):
+        a, p = CheckersActor(w, N, stage=stage, device="cuda:0", seed=8, precision=prec).act(env, 0.0, actions_prev=prev,
+                                                                                            return_probs=True)
+        out[prec] = (a.reshape(-1).cpu().numpy(), p.reshape(E * N, 5).cpu().numpy())
+    e32, e16 = np.abs(out["f32"][1] - want).max(), np.abs(out["f16x3"][1] - want).max()
+    print("worst |p - oracle|: f32 %.2e, f16x3 %.2e" % (e32, e16))
+    assert e32 < 2e-5 and e16 < 2e-5
+    assert np.abs(out["f32"][1] - out["f16x3"][1]).max() > 0          # it is a different kernel
+    u = AO.policy_uniforms(8, np.arange(E), env._episode.cpu().numpy(), env.steps.cpu().numpy(), N).reshape(E * N)
+    safe = np.abs(np.cumsum(want, axis=1) - u[:, None]).min(axis=1) > 1e-4
+    assert np.array_equal(out["f32"][0][safe], out["f16x3"][0][safe])
