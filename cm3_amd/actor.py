@@ -32,7 +32,7 @@ def _epsilon_args(epsilon):
     return float(epsilon), 0
 
 H1_SELF, H1_OTHERS, H2, N_ACTIONS = 64, 128, 64, 5
-PRECISIONS = {"f32": 0, "bf16": 1, "f16x3": 2}       # cm3_actor_particle_desc.precision
+PRECISIONS = {"f32": 0, "bf16": 1, "f16x3": 2, "f16x3all": 3}       # cm3_actor_particle_desc.precision
 _NAMES = {
     "w_self": "actor_branch_self/kernel", "b_self": "actor_branch_self/bias", "w_self_h2": "W_branch_self_h2",
     "w_others": "stage-2/actor_others/kernel", "b_others": "stage-2/actor_others/bias",

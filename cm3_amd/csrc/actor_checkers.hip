@@ -62,7 +62,21 @@ constexpr int kPH2Sh = kPH2Ob + kH1 * kH2 / 2;
 constexpr int kPH2Sl = kPH2Sh + kH1 * kH2 / 2;
 constexpr int kPH2Oh = kPH2Sl + kH1 * kH2 / 2;
 constexpr int kPH2Ol = kPH2Oh + kH1 * kH2 / 2;
-constexpr int kPTotal = kPH2Ol + kH1 * kH2 / 2;
+// ... and of the five small matrices for precision = 3 (every layer in split float16): K padded to a multiple of 32
+constexpr int kKConvX = 96, kKSelfX = 64, kKOthX = 32;
+constexpr int kXConvH = kPH2Ol + kH1 * kH2 / 2;
+constexpr int kXConvL = kXConvH + kKConvX * kNConv / 2;
+constexpr int kXLinH = kXConvL + kKConvX * kNConv / 2;
+constexpr int kXLinL = kXLinH + kKLin * kNLin / 2;
+constexpr int kXSelfH = kXLinL + kKLin * kNLin / 2;
+constexpr int kXSelfL = kXSelfH + kKSelfX * kH1 / 2;
+constexpr int kXOthH = kXSelfL + kKSelfX * kH1 / 2;
+constexpr int kXOthL = kXOthH + kKOthX * kH1 / 2;
+constexpr int kXOutH = kXOthL + kKOthX * kH1 / 2;
+constexpr int kXOutL = kXOutH + kH2 * 16 / 2;
+constexpr int kPTotal = kXOutL + kH2 * 16 / 2;
+// float16 LDS planes of precision = 3: row strides in halfwords, K + 8 (= 4 x odd words: conflict-free 16-byte A reads)
+constexpr int kLhX0 = kKConvX + 8, kLhC1 = kNConv + 8, kLhX2 = kKSelfX + 8, kLhXO = kKOthX + 8;
 constexpr int kLdHb = kH1 + 8;  // bf16 / f16 activation row: 264 halfwords = 528 B (= 4 mod 64 words, 16-byte aligned rows)
 }  // namespace ck_actor
 
@@ -102,6 +116,37 @@ __global__ void __launch_bounds__(256) k_ck_actor_pack(const CkActorParams p, fl
   using namespace ck_actor;
   const bool stage2 = p.stage > 1;
   for (int t = blockIdx.x * 256 + threadIdx.x; t < kPTotal; t += gridDim.x * 256) {
+    if (t >= kXConvH) {  // float16 hi / lo of the small matrices: [col tile][k-step][lane][8], k = 32 st + 8 (l >> 4) + q
+      int base, KS, layer;
+      if (t < kXLinH) { base = kXConvH; KS = kKConvX / 32; layer = 0; }
+      else if (t < kXSelfH) { base = kXLinH; KS = kKLin / 32; layer = 1; }
+      else if (t < kXOthH) { base = kXSelfH; KS = kKSelfX / 32; layer = 2; }
+      else if (t < kXOutH) { base = kXOthH; KS = kKOthX / 32; layer = 3; }
+      else { base = kXOutH; KS = kH2 / 32; layer = 6; }
+      const int ncols = layer == 0 ? kNConv : (layer == 1 ? kNLin : (layer == 6 ? 16 : kH1));
+      const int half = KS * 32 * ncols / 2;            // floats per plane
+      const bool low = (t - base) >= half;
+      _Float16 pair[2];
+      for (int h = 0; h < 2; ++h) {
+        const int eidx = 2 * (t - base - (low ? half : 0)) + h;
+        const int q = eidx & 7, lane = (eidx >> 3) & 63, rest = eidx >> 9, st = rest % KS, ct = rest / KS;
+        const int k = 32 * st + 8 * (lane >> 4) + q, n = 16 * ct + (lane & 15);
+        float wv;
+        switch (layer) {
+          case 0: wv = ck_conv_toeplitz(p, k, n); break;
+          case 1: wv = k < 25 * kConvF ? p.lin_w[k * kLin + n] : 0.0f; break;
+          case 2: wv = k < kCat ? p.self_w[k * kH1 + n] : 0.0f; break;
+          case 3: wv = (stage2 && k < p.Lo) ? p.oth_w[k * kH1 + n] : 0.0f; break;
+          default: wv = n < kA ? p.out_w[k * kA + n] : 0.0f; break;
+        }
+        const _Float16 hi = (_Float16)wv;
+        pair[h] = low ? (_Float16)(wv - (float)hi) : hi;
+      }
+      float v;
+      __builtin_memcpy(&v, pair, 4);
+      out[t] = v;
+      continue;
+    }
     if (t >= kPH2Sh) {  // float16 hi / lo B operands of v_mfma_f32_16x16x32_f16, the layout of the bf16 copies below
       const int sec = (t - kPH2Sh) / (kH1 * kH2 / 2);   // 0: self hi, 1: self lo, 2: others hi, 3: others lo
       const bool oth = sec >= 2, low = (sec & 1) != 0;
@@ -403,6 +448,41 @@ __device__ __forceinline__ void gemm_tiles_f16x3(const _Float16 *Ah, const _Floa
   }
 }
 
+// softmax (networks.py:576), epsilon mix (alg_credit_checkers.py:112), sampling (:113): lane l < 16 takes row 16w + l
+__device__ __forceinline__ void ck_actor_head(const CkActorParams &p, const float (*sLG)[8], int w, int lane, size_t row_base,
+                                              size_t rows) {
+  const int N = p.N;
+  if (lane < 16) {
+    const size_t row = row_base + 16 * w + lane;
+    if (row < rows) {
+      float o[kA], pr[kA];
+#pragma unroll
+      for (int a = 0; a < kA; ++a) o[a] = sLG[16 * w + lane][a];
+      float m = o[0];
+#pragma unroll
+      for (int a = 1; a < kA; ++a) m = fmaxf(m, o[a]);
+      float sum = 0.0f;
+#pragma unroll
+      for (int a = 0; a < kA; ++a) {
+        o[a] = expf(o[a] - m);
+        sum += o[a];
+      }
+      const float inv = 1.0f / sum;
+      const float eps = p.eps_dev ? *p.eps_dev : p.eps;
+#pragma unroll
+      for (int a = 0; a < kA; ++a) pr[a] = (1.0f - eps) * (o[a] * inv) + eps / (float)kA;
+      const size_t e = row / N;
+      const int i = (int)(row - e * N);
+      const int act = actor_sample(pr, p.seed, (uint64_t)(p.env_id_base + (int64_t)e), (uint32_t)p.episode[e], p.steps[e], i);
+      p.actions[row] = act;
+      if (p.probs) {
+#pragma unroll
+        for (int a = 0; a < kA; ++a) p.probs[row * kA + a] = pr[a];
+      }
+    }
+  }
+}
+
 // PREC: 0 = float32 throughout, 1 = bf16 256 x 256 layers (not a parity path), 2 = split-float16 256 x 256 layers
 template <int PREC> __global__ void __launch_bounds__(256) k_ck_actor(const CkActorParams p) {
   constexpr bool BF16 = PREC == 1, F16X3 = PREC == 2;
@@ -611,37 +691,230 @@ template <int PREC> __global__ void __launch_bounds__(256) k_ck_actor(const CkAc
   }
   __builtin_amdgcn_s_waitcnt(0);
   __builtin_amdgcn_wave_barrier();
-  // softmax (networks.py:576), epsilon mix (alg_credit_checkers.py:112), sampling (:113): lane l < 16 takes row 16w + l
-  if (lane < 16) {
-    const size_t row = row_base + 16 * w + lane;
-    if (row < rows) {
-      float o[kA], pr[kA];
+  ck_actor_head(p, sLG, w, lane, row_base, rows);
+  CM3_STAMP(12, true);
+}
+
+// ---- precision = 3: EVERY layer in split float16 ------------------------------------------------------------------------------
+// The five small layers are 14 % of the MACs but, on the exact-f32 MFMA, most of the matrix-core time that is left once the two
+// 256 x 256 layers run in float16.  Same tile loop for every layer: A from float16 hi / lo LDS planes, B from the packed hi / lo
+// tiles, three MFMAs per (row tile, column tile, k-step of 32) -- two where the activations are exact in float16 (the window
+// bytes are -1 / 0 / 1: no lo plane).
+template <int CT, int KS>
+__device__ __forceinline__ void load_bx(const float *Bh, const float *Bl, int ct0, int lane, uint4 (&b0)[2][CT]) {
 #pragma unroll
-      for (int a = 0; a < kA; ++a) o[a] = sLG[16 * w + lane][a];
-      float m = o[0];
+  for (int c = 0; c < CT; ++c) {
+    b0[0][c] = (reinterpret_cast<const uint4 *>(Bh) + ((size_t)(ct0 + c) * KS) * 64 + lane)[0];
+    b0[1][c] = (reinterpret_cast<const uint4 *>(Bl) + ((size_t)(ct0 + c) * KS) * 64 + lane)[0];
+  }
+}
+
+template <int RT, int CT, int KS, bool ALO>
+__device__ __forceinline__ void gemm_x3(const _Float16 *Ah, const _Float16 *Al, int lda, int rt0, const float *Bh, const float *Bl,
+                                        int ct0, int lane, const uint4 (&b0)[2][CT], f32x4 (&acc)[RT][CT]) {
+  const int col = lane & 15, hi = lane >> 4;
+  const uint4 *bsrc[2][CT];
 #pragma unroll
-      for (int a = 1; a < kA; ++a) m = fmaxf(m, o[a]);
-      float sum = 0.0f;
+  for (int c = 0; c < CT; ++c) {
+    bsrc[0][c] = reinterpret_cast<const uint4 *>(Bh) + ((size_t)(ct0 + c) * KS) * 64 + lane;
+    bsrc[1][c] = reinterpret_cast<const uint4 *>(Bl) + ((size_t)(ct0 + c) * KS) * 64 + lane;
+  }
+  uint4 bcur[2][CT], bnext[2][CT];
 #pragma unroll
-      for (int a = 0; a < kA; ++a) {
-        o[a] = expf(o[a] - m);
-        sum += o[a];
+  for (int c = 0; c < CT; ++c) {
+    bcur[0][c] = b0[0][c];
+    bcur[1][c] = b0[1][c];
+  }
+#pragma unroll
+  for (int st = 0; st < KS; ++st) {
+    if (st + 1 < KS) {
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        bnext[0][c] = bsrc[0][c][(st + 1) * 64];
+        bnext[1][c] = bsrc[1][c][(st + 1) * 64];
       }
-      const float inv = 1.0f / sum;
-      const float eps = p.eps_dev ? *p.eps_dev : p.eps;
+    }
+    f16x8 ah[RT], al[RT];
 #pragma unroll
-      for (int a = 0; a < kA; ++a) pr[a] = (1.0f - eps) * (o[a] * inv) + eps / (float)kA;
-      const size_t e = row / N;
-      const int i = (int)(row - e * N);
-      const int act = actor_sample(pr, p.seed, (uint64_t)(p.env_id_base + (int64_t)e), (uint32_t)p.episode[e], p.steps[e], i);
-      p.actions[row] = act;
-      if (p.probs) {
+    for (int t = 0; t < RT; ++t) {
+      ah[t] = *reinterpret_cast<const f16x8 *>(Ah + (16 * (rt0 + t) + col) * lda + 32 * st + 8 * hi);
+      if constexpr (ALO) al[t] = *reinterpret_cast<const f16x8 *>(Al + (16 * (rt0 + t) + col) * lda + 32 * st + 8 * hi);
+    }
 #pragma unroll
-        for (int a = 0; a < kA; ++a) p.probs[row * kA + a] = pr[a];
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        f16x8 bh, bl;
+        __builtin_memcpy(&bh, &bcur[0][c], 16);
+        __builtin_memcpy(&bl, &bcur[1][c], 16);
+        if constexpr (ALO) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh, acc[t][c], 0, 0, 0);
+        acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl, acc[t][c], 0, 0, 0);
+        acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh, acc[t][c], 0, 0, 0);
+      }
+    if (st + 1 < KS) {
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        bcur[0][c] = bnext[0][c];
+        bcur[1][c] = bnext[1][c];
       }
     }
   }
-  CM3_STAMP(12, true);
+}
+
+__device__ __forceinline__ void put_split(_Float16 *h, _Float16 *l, int at, float v) {
+  const _Float16 vh = (_Float16)v;
+  h[at] = vh;
+  l[at] = (_Float16)(v - (float)vh);
+}
+
+__global__ void __launch_bounds__(256) k_ck_actor_x3(const CkActorParams p) {
+  using namespace ck_actor;
+  // H planes [64][264] hi | lo (first-layer activations, then h2); before that the same storage holds X0 (hi only) and C1 hi | lo
+  __shared__ __attribute__((aligned(16))) _Float16 sH[2 * 64 * kLdHb];
+  __shared__ __attribute__((aligned(16))) _Float16 sX2[2 * 64 * kLhX2];
+  __shared__ __attribute__((aligned(16))) _Float16 sXO[2 * 64 * kLhXO];
+  __shared__ float sLG[64][8];
+  _Float16 *sHh = sH, *sHl = sH + 64 * kLdHb;
+  _Float16 *sX0 = sH, *sC1h = sH + 64 * kLhX0, *sC1l = sC1h + 64 * kLhC1;
+  _Float16 *sX2h = sX2, *sX2l = sX2 + 64 * kLhX2, *sXOh = sXO, *sXOl = sXO + 64 * kLhXO;
+  static_assert(64 * kLhX0 + 2 * 64 * kLhC1 <= 2 * 64 * kLdHb, "X0 and the C1 planes must fit into the H storage");
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int N = p.N;
+  const size_t rows = (size_t)p.E * N;
+  const size_t row_base = (size_t)blockIdx.x * 64;
+  const float *pk = p.packed;
+
+  uint4 b_conv[2][5];
+  load_bx<5, kKConvX / 32>(pk + kXConvH, pk + kXConvL, 5 * (w >> 1), lane, b_conv);
+  // ---- stage the inputs (see k_ck_actor) -------------------------------------------------------------------------------------------
+  if ((p.obst_stride & 3) == 0 && (64 % N) == 0) {
+    const int epw = 64 / N, dpe = p.obst_stride >> 2, rec = N * kObs;
+    const size_t e0 = row_base / N;
+    for (int d = tid; d < epw * dpe; d += 256) {
+      const int el = d / dpe, dd = d - el * dpe;
+      size_t e = e0 + el;
+      e = e < (size_t)p.E ? e : (size_t)p.E - 1;
+      const uint32_t v = reinterpret_cast<const uint32_t *>(p.obs_self_t + e * (size_t)p.obst_stride)[dd];
+#pragma unroll
+      for (int sb = 0; sb < 4; ++sb) {
+        const int bb = 4 * dd + sb;
+        if (bb < rec) {
+          const int i = bb / kObs, k = bb - i * kObs;
+          sX0[(el * N + i) * kLhX0 + k] = (_Float16)(float)(int8_t)(v >> (8 * sb));
+        }
+      }
+    }
+    for (int idx = tid; idx < 64 * (kKConvX - kObs); idx += 256) {
+      const int r = idx / (kKConvX - kObs), k = kObs + idx - r * (kKConvX - kObs);
+      sX0[r * kLhX0 + k] = (_Float16)0.0f;
+    }
+  } else {
+    for (int idx = tid; idx < 64 * kKConvX; idx += 256) {
+      const int r = idx / kKConvX, k = idx - r * kKConvX;
+      size_t row = row_base + r;
+      row = row < rows ? row : rows - 1;
+      const size_t e = row / N;
+      const int i = (int)(row - e * N);
+      sX0[r * kLhX0 + k] = k < kObs ? (_Float16)(float)p.obs_self_t[e * (size_t)p.obst_stride + (size_t)i * kObs + k] : (_Float16)0.0f;
+    }
+  }
+  if (tid < 64) {  // concat tail: v_obs_self (4), a_prev one-hot (5), v_goal one-hot (2); pad; v_obs_others (natural order)
+    size_t row = row_base + tid;
+    row = row < rows ? row : rows - 1;
+    const size_t e = row / N;
+    const int at0 = tid * kLhX2 + kLin;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) put_split(sX2h, sX2l, at0 + k, (float)p.obs_self_v[row * 4 + k]);
+    const int ap = (p.actions_prev && !(p.prev_done && p.prev_done[e])) ? p.actions_prev[row] : 0;
+#pragma unroll
+    for (int k = 0; k < kA; ++k) put_split(sX2h, sX2l, at0 + 4 + k, ap == k ? 1.0f : 0.0f);
+    const int gl = p.goals[row];
+    put_split(sX2h, sX2l, at0 + 9, gl == 0 ? 1.0f : 0.0f);
+    put_split(sX2h, sX2l, at0 + 10, gl == 0 ? 0.0f : 1.0f);
+#pragma unroll
+    for (int k = kCat - kLin; k < kKSelfX - kLin; ++k) put_split(sX2h, sX2l, at0 + k, 0.0f);
+    for (int k = 0; k < kKOthX; ++k)
+      put_split(sXOh, sXOl, tid * kLhXO + k, k < p.Lo ? (float)p.obs_others[row * p.Lo + k] : 0.0f);
+  }
+  __syncthreads();
+
+  uint4 b_lin[2][1], b_self[2][4], b_h2[2][4], b_oth[2][4], b_out[2][1];
+  // ---- conv (Toeplitz): X0 [64][96] -> C1 [64][160], relu ------------------------------------------------------------------------
+  {
+    f32x4 acc[2][5];
+    float bias[5];
+    load_bias<5>(pk + kPConvB, 5 * (w >> 1), lane, bias);
+    zero_tiles(acc);
+    gemm_x3<2, 5, kKConvX / 32, false>(sX0, sX0, kLhX0, 2 * (w & 1), pk + kXConvH, pk + kXConvL, 5 * (w >> 1), lane, b_conv, acc);
+    load_bx<1, kKLin / 32>(pk + kXLinH, pk + kXLinL, w >> 1, lane, b_lin);
+    store_relu_f16x2<2, 5>(sC1h, sC1l, kLhC1, 2 * (w & 1), 5 * (w >> 1), bias, lane, acc);
+  }
+  __syncthreads();
+  // ---- conv_linear: C1 [64][160] -> X2[:, 0:32], relu ---------------------------------------------------------------------------
+  {
+    f32x4 acc[2][1];
+    float bias[1];
+    load_bias<1>(pk + kPLinB, w >> 1, lane, bias);
+    zero_tiles(acc);
+    gemm_x3<2, 1, kKLin / 32, true>(sC1h, sC1l, kLhC1, 2 * (w & 1), pk + kXLinH, pk + kXLinL, w >> 1, lane, b_lin, acc);
+    load_bx<4, kKSelfX / 32>(pk + kXSelfH, pk + kXSelfL, 4 * w, lane, b_self);
+    store_relu_f16x2<2, 1>(sX2h, sX2l, kLhX2, 2 * (w & 1), w >> 1, bias, lane, acc);
+  }
+  __syncthreads();
+  // ---- branch_self: X2 [64][64] -> H [64][256], relu; wave w owns columns [64w, 64w + 64) from here on -----------------------------
+  {
+    f32x4 acc[4][4];
+    float bias[4];
+    load_bias<4>(pk + kPSelfB, 4 * w, lane, bias);
+    zero_tiles(acc);
+    gemm_x3<4, 4, kKSelfX / 32, true>(sX2h, sX2l, kLhX2, 0, pk + kXSelfH, pk + kXSelfL, 4 * w, lane, b_self, acc);
+    load_bx<4, 8>(pk + kPH2Sh, pk + kPH2Sl, 4 * w, lane, b_h2);
+    store_relu_f16x2<4, 4>(sHh, sHl, kLdHb, 0, 4 * w, bias, lane, acc);
+  }
+  __syncthreads();
+  // ---- h2 = relu(branch_self W_self_h2 + branch_others W_others_h2 + b) ------------------------------------------------------------
+  f32x4 acc2[4][4];
+  zero_tiles(acc2);
+  gemm_x3<4, 4, 8, true>(sHh, sHl, kLdHb, 0, pk + kPH2Sh, pk + kPH2Sl, 4 * w, lane, b_h2, acc2);
+  const bool stage2 = p.stage > 1;
+  float bias_oth[4], bias_h2[4];
+  load_bias<4>(pk + kPOthB, 4 * w, lane, bias_oth);
+  load_bias<4>(pk + kPH2B, 4 * w, lane, bias_h2);
+  if (stage2) load_bx<4, 1>(pk + kXOthH, pk + kXOthL, 4 * w, lane, b_oth);
+  else load_bx<1, 8>(pk + kXOutH, pk + kXOutL, 0, lane, b_out);
+  __syncthreads();  // every wave is done reading branch_self
+  if (stage2) {
+    {
+      f32x4 acc[4][4];
+      zero_tiles(acc);
+      gemm_x3<4, 4, 1, true>(sXOh, sXOl, kLhXO, 0, pk + kXOthH, pk + kXOthL, 4 * w, lane, b_oth, acc);
+      load_bx<4, 8>(pk + kPH2Oh, pk + kPH2Ol, 4 * w, lane, b_h2);
+      store_relu_f16x2<4, 4>(sHh, sHl, kLdHb, 0, 4 * w, bias_oth, lane, acc);
+    }
+    __syncthreads();
+    gemm_x3<4, 4, 8, true>(sHh, sHl, kLdHb, 0, pk + kPH2Oh, pk + kPH2Ol, 4 * w, lane, b_h2, acc2);
+    load_bx<1, 8>(pk + kXOutH, pk + kXOutL, 0, lane, b_out);
+    __syncthreads();
+  }
+  store_relu_f16x2<4, 4>(sHh, sHl, kLdHb, 0, 4 * w, bias_h2, lane, acc2);
+  __syncthreads();
+  // ---- actor_out: wave w finishes rows [16w, 16w + 16) -----------------------------------------------------------------------------
+  {
+    f32x4 acc[1][1];
+    zero_tiles(acc);
+    gemm_x3<1, 1, 8, true>(sHh, sHl, kLdHb, w, pk + kXOutH, pk + kXOutL, 0, lane, b_out, acc);
+    const int col = lane & 15, hi = lane >> 4;
+    if (col < 8) {
+      const float b = pk[kPOutB + col];
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) sLG[16 * w + 4 * hi + reg][col] = acc[0][0][reg] + b;
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_wave_barrier();
+  ck_actor_head(p, sLG, w, lane, row_base, rows);
 }
 
 static int ck_actor_check(const cm3_actor_checkers_desc *d) {
@@ -695,7 +968,7 @@ extern "C" int cm3_actor_checkers_f32(const cm3_actor_checkers_desc *d, const cm
   CM3_REQUIRE(wt && b, "null weights/bufs");
   CM3_REQUIRE(d->n_envs > 0, "n_envs must be positive");
   CM3_REQUIRE(d->epsilon >= 0.0f && d->epsilon <= 1.0f, "epsilon must be in [0,1]");
-  CM3_REQUIRE(d->precision >= 0 && d->precision <= 2, "precision must be 0 (float32), 1 (bf16 256x256 layers) or 2 (split float16)");
+  CM3_REQUIRE(d->precision >= 0 && d->precision <= 3, "precision must be 0 (float32), 1 (bf16 256x256 layers), 2 or 3 (split float16)");
   CM3_REQUIRE(wt->packed, "weights->packed is NULL: run cm3_actor_checkers_pack once per weight update");
   CM3_REQUIRE(b->obs_self_t && b->obs_self_v && b->obs_others && b->goals && b->steps && b->episode && b->actions,
               "missing buffers");
@@ -727,6 +1000,7 @@ extern "C" int cm3_actor_checkers_f32(const cm3_actor_checkers_desc *d, const cm
   const dim3 grid((unsigned)((rows + 63) / 64));
   if (d->precision == 1) hipLaunchKernelGGL(k_ck_actor<1>, grid, dim3(256), 0, (hipStream_t)stream, p);
   else if (d->precision == 2) hipLaunchKernelGGL(k_ck_actor<2>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  else if (d->precision == 3) hipLaunchKernelGGL(k_ck_actor_x3, grid, dim3(256), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(k_ck_actor<0>, grid, dim3(256), 0, (hipStream_t)stream, p);
   CM3_HIP_CHECK(hipGetLastError());
   return CM3_OK;

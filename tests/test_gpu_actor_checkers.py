@@ -31,7 +31,7 @@ def _oracle_probs(w, env, prev, eps):
         env.goals.reshape(rows, 2).cpu().numpy()), eps)
 
 
-@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "f16x3all"])
 @pytest.mark.parametrize("stage", [1, 2])
 @pytest.mark.parametrize("eps", [0.0, 0.3])
 @pytest.mark.parametrize("E", [1000, 33])
@@ -306,13 +306,15 @@ def test_split_float16_layers_stay_in_the_float32_error_class(stage):
     prev = rng.integers(0, 5, (E, N))
     want = _oracle_probs(w, env, prev, 0.0)
     out = {}
-    for prec in ("f32", "f16x3"):
+    for prec in ("f32", "f16x3", "f16x3all"):
         a, p = CheckersActor(w, N, stage=stage, device="cuda:0", seed=8, precision=prec).act(env, 0.0, actions_prev=prev,
                                                                                             return_probs=True)
         out[prec] = (a.reshape(-1).cpu().numpy(), p.reshape(E * N, 5).cpu().numpy())
     e32, e16 = np.abs(out["f32"][1] - want).max(), np.abs(out["f16x3"][1] - want).max()
-    print("worst |p - oracle|: f32 %.2e, f16x3 %.2e" % (e32, e16))
-    assert e32 < 2e-5 and e16 < 2e-5
+    e16a = np.abs(out["f16x3all"][1] - want).max()
+    print("worst |p - oracle|: f32 %.2e, f16x3 %.2e, f16x3all %.2e" % (e32, e16, e16a))
+    assert e32 < 2e-5 and e16 < 2e-5 and e16a < 2e-5
+    assert np.array_equal(out["f32"][0][np.abs(np.cumsum(want, axis=1) - AO.policy_uniforms(8, np.arange(E), env._episode.cpu().numpy(), env.steps.cpu().numpy(), N).reshape(E * N)[:, None]).min(axis=1) > 1e-4], out["f16x3all"][0][np.abs(np.cumsum(want, axis=1) - AO.policy_uniforms(8, np.arange(E), env._episode.cpu().numpy(), env.steps.cpu().numpy(), N).reshape(E * N)[:, None]).min(axis=1) > 1e-4])
     assert np.abs(out["f32"][1] - out["f16x3"][1]).max() > 0          # it is a different kernel
     u = AO.policy_uniforms(8, np.arange(E), env._episode.cpu().numpy(), env.steps.cpu().numpy(), N).reshape(E * N)
     safe = np.abs(np.cumsum(want, axis=1) - u[:, None]).min(axis=1) > 1e-4
