@@ -32,7 +32,7 @@ def _epsilon_args(epsilon):
     return float(epsilon), 0
 
 H1_SELF, H1_OTHERS, H2, N_ACTIONS = 64, 128, 64, 5
-PRECISIONS = {"f32": 0, "bf16": 1, "f16x3": 2, "f16x3all": 3}       # cm3_actor_particle_desc.precision
+PRECISIONS = {"f32": 0, "bf16": 1, "f16x3": 2}       # cm3_actor_particle_desc.precision
 _NAMES = {
     "w_self": "actor_branch_self/kernel", "b_self": "actor_branch_self/bias", "w_self_h2": "W_branch_self_h2",
     "w_others": "stage-2/actor_others/kernel", "b_others": "stage-2/actor_others/bias",
@@ -154,9 +154,10 @@ class CheckersActor(object):
     """
 
     def __init__(self, weights, n_agents, stage=2, device="cuda:0", seed=12341, env_id_base=0, precision="f32"):
-        """precision of the two 256x256 layers (86 % of the network's FLOPs): "f32" (default: exact-f32 MFMA), "f16x3" (split
-        float16: activations and weights as float16 hi + lo, three float16 MFMAs per product with float32 accumulation -- held to
-        the same 2e-5 parity bound as "f32"), or "bf16" (not a parity path: probabilities within ~1e-2 of the float32 ones)."""
+        """precision: "f32" (default: every layer on the exact-f32 MFMA), "f16x3" (every layer in split float16: activations and
+        weights as float16 hi + lo, three float16 MFMAs per product with float32 accumulation -- held to the same 2e-5 parity
+        bound as "f32", half its time per launch), or "bf16" (the two 256x256 layers rounded to bf16; not a parity path:
+        probabilities within ~1e-2 of the float32 ones)."""
         self.device = _lib.require_gpu(device)
         if precision not in PRECISIONS:
             raise Cm3Error("precision must be one of %s" % sorted(PRECISIONS))

@@ -20,7 +20,7 @@
 //   conv      : the 3x3 SAME convolution as a [80 x 160] Toeplitz matrix (zeros for out-of-window taps and padding)
 //   precision = 1 (opt-in, not the parity path): the first-layer activations are stored as bf16 and the two 256 x 256
 //               matrices run on v_mfma_f32_16x16x32_bf16 (f32 accumulation, 16x the f32 MFMA rate); everything else stays f32.
-//   precision = 2 (split float16, a parity path): the same two layers as hi * hi + hi * lo + lo * hi on
+//   precision = 2 (split float16, a parity path; k_ck_actor_x3): EVERY layer as hi * hi + hi * lo + lo * hi on
 //               v_mfma_f32_16x16x32_f16 with activations and weights split into float16 hi + lo (22 significand bits per factor).
 //   wave tiles: conv 2 row x 5 col tiles, conv_linear 2 x 1, branch_self / branch_others / h2: 4 x 4 (all 64 rows x 64
 //               columns per wave, 64 accumulator VGPRs), actor_out: wave w finishes rows [16w, 16w+16).
@@ -62,7 +62,7 @@ constexpr int kPH2Sh = kPH2Ob + kH1 * kH2 / 2;
 constexpr int kPH2Sl = kPH2Sh + kH1 * kH2 / 2;
 constexpr int kPH2Oh = kPH2Sl + kH1 * kH2 / 2;
 constexpr int kPH2Ol = kPH2Oh + kH1 * kH2 / 2;
-// ... and of the five small matrices for precision = 3 (every layer in split float16): K padded to a multiple of 32
+// ... and of the five small matrices (precision = 2 runs every layer in split float16): K padded to a multiple of 32
 constexpr int kKConvX = 96, kKSelfX = 64, kKOthX = 32;
 constexpr int kXConvH = kPH2Ol + kH1 * kH2 / 2;
 constexpr int kXConvL = kXConvH + kKConvX * kNConv / 2;
@@ -75,7 +75,7 @@ constexpr int kXOthL = kXOthH + kKOthX * kH1 / 2;
 constexpr int kXOutH = kXOthL + kKOthX * kH1 / 2;
 constexpr int kXOutL = kXOutH + kH2 * 16 / 2;
 constexpr int kPTotal = kXOutL + kH2 * 16 / 2;
-// float16 LDS planes of precision = 3: row strides in halfwords, K + 8 (= 4 x odd words: conflict-free 16-byte A reads)
+// float16 LDS planes of precision = 2: row strides in halfwords, K + 8 (= 4 x odd words: conflict-free 16-byte A reads)
 constexpr int kLhX0 = kKConvX + 8, kLhC1 = kNConv + 8, kLhX2 = kKSelfX + 8, kLhXO = kKOthX + 8;
 constexpr int kLdHb = kH1 + 8;  // bf16 / f16 activation row: 264 halfwords = 528 B (= 4 mod 64 words, 16-byte aligned rows)
 }  // namespace ck_actor
@@ -366,7 +366,7 @@ __device__ __forceinline__ void gemm_tiles_bf16(const __bf16 *A, int lda, const 
   }
 }
 
-// ---- precision = 2: the same two layers as three float16 MFMAs per step -- (a_lo, b_hi) + (a_hi, b_lo) + (a_hi, b_hi), float32
+// ---- precision = 2 (split float16): three float16 MFMAs per product -- (a_lo, b_hi) + (a_hi, b_lo) + (a_hi, b_hi), float32
 // accumulation.  Activations and weights are split x = hi + lo with hi = (float16)x, lo = (float16)(x - hi): 22 of float32's 24
 // significand bits per factor, the error class of the exact-f32 path (tests hold the same 2e-5) at 16/3 of its MFMA rate.
 template <int RT, int CT>
@@ -385,66 +385,6 @@ __device__ __forceinline__ void store_relu_f16x2(_Float16 *Oh, _Float16 *Ol, int
         Oh[at] = vh;
         Ol[at] = (_Float16)(v - (float)vh);
       }
-  }
-}
-
-template <int CT> __device__ __forceinline__ void load_b0_f16x2(const float *Bh, const float *Bl, int ct0, int lane, uint4 (&b0)[2][CT]) {
-#pragma unroll
-  for (int c = 0; c < CT; ++c) {
-    b0[0][c] = (reinterpret_cast<const uint4 *>(Bh) + ((size_t)(ct0 + c) * 8) * 64 + lane)[0];
-    b0[1][c] = (reinterpret_cast<const uint4 *>(Bl) + ((size_t)(ct0 + c) * 8) * 64 + lane)[0];
-  }
-}
-
-template <int CT>
-__device__ __forceinline__ void gemm_tiles_f16x3(const _Float16 *Ah, const _Float16 *Al, int lda, const float *Bh, const float *Bl,
-                                                 int ct0, int lane, const uint4 (&b0)[2][CT], f32x4 (&acc)[4][CT]) {
-  const int col = lane & 15, hi = lane >> 4;
-  const uint4 *bsrc[2][CT];
-#pragma unroll
-  for (int c = 0; c < CT; ++c) {
-    bsrc[0][c] = reinterpret_cast<const uint4 *>(Bh) + ((size_t)(ct0 + c) * 8) * 64 + lane;
-    bsrc[1][c] = reinterpret_cast<const uint4 *>(Bl) + ((size_t)(ct0 + c) * 8) * 64 + lane;
-  }
-  uint4 bcur[2][CT], bnext[2][CT];
-#pragma unroll
-  for (int c = 0; c < CT; ++c) {
-    bcur[0][c] = b0[0][c];
-    bcur[1][c] = b0[1][c];
-  }
-#pragma unroll
-  for (int st = 0; st < 8; ++st) {
-    if (st + 1 < 8) {
-#pragma unroll
-      for (int c = 0; c < CT; ++c) {
-        bnext[0][c] = bsrc[0][c][(st + 1) * 64];
-        bnext[1][c] = bsrc[1][c][(st + 1) * 64];
-      }
-    }
-    f16x8 ah[4], al[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      ah[t] = *reinterpret_cast<const f16x8 *>(Ah + (16 * t + col) * lda + 32 * st + 8 * hi);
-      al[t] = *reinterpret_cast<const f16x8 *>(Al + (16 * t + col) * lda + 32 * st + 8 * hi);
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int c = 0; c < CT; ++c) {
-        f16x8 bh, bl;
-        __builtin_memcpy(&bh, &bcur[0][c], 16);
-        __builtin_memcpy(&bl, &bcur[1][c], 16);
-        acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh, acc[t][c], 0, 0, 0);
-        acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl, acc[t][c], 0, 0, 0);
-        acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh, acc[t][c], 0, 0, 0);
-      }
-    if (st + 1 < 8) {
-#pragma unroll
-      for (int c = 0; c < CT; ++c) {
-        bcur[0][c] = bnext[0][c];
-        bcur[1][c] = bnext[1][c];
-      }
-    }
   }
 }
 
@@ -483,19 +423,16 @@ __device__ __forceinline__ void ck_actor_head(const CkActorParams &p, const floa
   }
 }
 
-// PREC: 0 = float32 throughout, 1 = bf16 256 x 256 layers (not a parity path), 2 = split-float16 256 x 256 layers
-template <int PREC> __global__ void __launch_bounds__(256) k_ck_actor(const CkActorParams p) {
-  constexpr bool BF16 = PREC == 1, F16X3 = PREC == 2;
+// BF16: the two 256 x 256 layers on the bf16 matrix cores (precision = 1, not a parity path); otherwise float32 throughout
+template <bool BF16> __global__ void __launch_bounds__(256) k_ck_actor(const CkActorParams p) {
   using namespace ck_actor;
   // H: [64][260] first-layer activations / h2; before that it holds X0 [64][84] and C1 [64][164]
-  __shared__ __attribute__((aligned(16))) float sH[64 * (kLdH + 4)];  // (+4: room for two [64][264] float16 planes)
+  __shared__ __attribute__((aligned(16))) float sH[64 * kLdH];
   __shared__ __attribute__((aligned(16))) float sX2[64 * kLdX2];
   __shared__ __attribute__((aligned(16))) float sXO[64 * kLdXO];
   __shared__ float sLG[64][8];
   float *sX0 = sH, *sC1 = sH + 64 * kLdX0;
   __bf16 *sHb = reinterpret_cast<__bf16 *>(sH);  // BF16: first-layer activations [64][264] bf16
-  _Float16 *sHh = reinterpret_cast<_Float16 *>(sH), *sHl = sHh + 64 * kLdHb;  // F16X3: their float16 hi and lo planes
-  static_assert(2 * 64 * kLdHb * 2 <= 64 * (kLdH + 4) * 4, "two float16 planes must fit into the H storage");
   static_assert(64 * kLdX0 + 64 * kLdC1 <= 64 * kLdH, "X0 and C1 must fit into the H storage");
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -575,7 +512,7 @@ template <int PREC> __global__ void __launch_bounds__(256) k_ck_actor(const CkAc
 
   // ---- conv (Toeplitz) : X0 [64][80] -> C1 [64][160], relu -----------------------------------------------------------------
   float4 b_lin[1], b_self[4], b_h2[4], b_oth[4], b_out[1];
-  uint4 b_h2b[4], b_h2x[2][4];
+  uint4 b_h2b[4];
   {
     f32x4 acc[2][5];
     float bias[5];
@@ -609,9 +546,6 @@ template <int PREC> __global__ void __launch_bounds__(256) k_ck_actor(const CkAc
     if constexpr (BF16) {
       load_b0_bf16<4>(pk + kPH2Sb, 4 * w, lane, b_h2b);
       store_relu_bf16<4, 4>(sHb, kLdHb, 0, 4 * w, bias, lane, acc);
-    } else if constexpr (F16X3) {
-      load_b0_f16x2<4>(pk + kPH2Sh, pk + kPH2Sl, 4 * w, lane, b_h2x);
-      store_relu_f16x2<4, 4>(sHh, sHl, kLdHb, 0, 4 * w, bias, lane, acc);
     } else {
       load_b0<4, kH1 / 16>(pk + kPH2S, 4 * w, lane, b_h2);
       store_relu<4, 4>(sH, kLdH, 0, 4 * w, bias, lane, acc);
@@ -623,7 +557,6 @@ template <int PREC> __global__ void __launch_bounds__(256) k_ck_actor(const CkAc
   f32x4 acc2[4][4];
   zero_tiles(acc2);
   if constexpr (BF16) gemm_tiles_bf16<4>(sHb, kLdHb, pk + kPH2Sb, 4 * w, lane, b_h2b, acc2);
-  else if constexpr (F16X3) gemm_tiles_f16x3<4>(sHh, sHl, kLdHb, pk + kPH2Sh, pk + kPH2Sl, 4 * w, lane, b_h2x, acc2);
   else gemm_tiles<4, 4, kH1 / 16>(sH, kLdH, 0, pk + kPH2S, 4 * w, lane, b_h2, acc2);
   const bool stage2 = p.stage > 1;
   float bias_oth[4], bias_h2[4];
@@ -656,9 +589,6 @@ template <int PREC> __global__ void __launch_bounds__(256) k_ck_actor(const CkAc
       if constexpr (BF16) {
         load_b0_bf16<4>(pk + kPH2Ob, 4 * w, lane, b_h2b);
         store_relu_bf16<4, 4>(sHb, kLdHb, 0, 4 * w, bias_oth, lane, acc);
-      } else if constexpr (F16X3) {
-        load_b0_f16x2<4>(pk + kPH2Oh, pk + kPH2Ol, 4 * w, lane, b_h2x);
-        store_relu_f16x2<4, 4>(sHh, sHl, kLdHb, 0, 4 * w, bias_oth, lane, acc);
       } else {
         load_b0<4, kH1 / 16>(pk + kPH2O, 4 * w, lane, b_h2);
         store_relu<4, 4>(sH, kLdH, 0, 4 * w, bias_oth, lane, acc);
@@ -667,7 +597,6 @@ template <int PREC> __global__ void __launch_bounds__(256) k_ck_actor(const CkAc
     __syncthreads();
     CM3_STAMP(8, false);
     if constexpr (BF16) gemm_tiles_bf16<4>(sHb, kLdHb, pk + kPH2Ob, 4 * w, lane, b_h2b, acc2);
-    else if constexpr (F16X3) gemm_tiles_f16x3<4>(sHh, sHl, kLdHb, pk + kPH2Oh, pk + kPH2Ol, 4 * w, lane, b_h2x, acc2);
     else gemm_tiles<4, 4, kH1 / 16>(sH, kLdH, 0, pk + kPH2O, 4 * w, lane, b_h2, acc2);
     load_b0<1, kH2 / 16>(pk + kPOut, 0, lane, b_out);
     CM3_STAMP(9, true);
@@ -695,9 +624,9 @@ template <int PREC> __global__ void __launch_bounds__(256) k_ck_actor(const CkAc
   CM3_STAMP(12, true);
 }
 
-// ---- precision = 3: EVERY layer in split float16 ------------------------------------------------------------------------------
+// ---- the precision = 2 kernel: EVERY layer in split float16 ---------------------------------------------------------------------
 // The five small layers are 14 % of the MACs but, on the exact-f32 MFMA, most of the matrix-core time that is left once the two
-// 256 x 256 layers run in float16.  Same tile loop for every layer: A from float16 hi / lo LDS planes, B from the packed hi / lo
+// 256 x 256 layers run in float16 (measured: 256 x 256 layers only 30.4 us per launch at 16 384 rows, all layers 26.5 us).  Same tile loop for every layer: A from float16 hi / lo LDS planes, B from the packed hi / lo
 // tiles, three MFMAs per (row tile, column tile, k-step of 32) -- two where the activations are exact in float16 (the window
 // bytes are -1 / 0 / 1: no lo plane).
 template <int CT, int KS>
@@ -968,7 +897,7 @@ extern "C" int cm3_actor_checkers_f32(const cm3_actor_checkers_desc *d, const cm
   CM3_REQUIRE(wt && b, "null weights/bufs");
   CM3_REQUIRE(d->n_envs > 0, "n_envs must be positive");
   CM3_REQUIRE(d->epsilon >= 0.0f && d->epsilon <= 1.0f, "epsilon must be in [0,1]");
-  CM3_REQUIRE(d->precision >= 0 && d->precision <= 3, "precision must be 0 (float32), 1 (bf16 256x256 layers), 2 or 3 (split float16)");
+  CM3_REQUIRE(d->precision >= 0 && d->precision <= 2, "precision must be 0 (float32), 1 (bf16 256x256 layers) or 2 (split float16)");
   CM3_REQUIRE(wt->packed, "weights->packed is NULL: run cm3_actor_checkers_pack once per weight update");
   CM3_REQUIRE(b->obs_self_t && b->obs_self_v && b->obs_others && b->goals && b->steps && b->episode && b->actions,
               "missing buffers");
@@ -998,10 +927,9 @@ extern "C" int cm3_actor_checkers_f32(const cm3_actor_checkers_desc *d, const cm
   p.packed = (const float *)wt->packed;
   const size_t rows = (size_t)p.E * p.N;
   const dim3 grid((unsigned)((rows + 63) / 64));
-  if (d->precision == 1) hipLaunchKernelGGL(k_ck_actor<1>, grid, dim3(256), 0, (hipStream_t)stream, p);
-  else if (d->precision == 2) hipLaunchKernelGGL(k_ck_actor<2>, grid, dim3(256), 0, (hipStream_t)stream, p);
-  else if (d->precision == 3) hipLaunchKernelGGL(k_ck_actor_x3, grid, dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(k_ck_actor<0>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  if (d->precision == 1) hipLaunchKernelGGL(k_ck_actor<true>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  else if (d->precision == 2) hipLaunchKernelGGL(k_ck_actor_x3, grid, dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(k_ck_actor<false>, grid, dim3(256), 0, (hipStream_t)stream, p);
   CM3_HIP_CHECK(hipGetLastError());
   return CM3_OK;
 }

@@ -387,9 +387,9 @@ typedef struct cm3_actor_checkers_desc {
   float epsilon;
   int32_t precision;         /* 0: float32 throughout (parity path).  1: the two 256x256 layers on the bf16 matrix cores with
                                 float32 accumulation (first-layer activations and those weights rounded to bf16; probabilities
-                                move by up to ~1e-2).  2: the same two layers in split float16 -- activations and weights as
-                                float16 hi + lo, hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16, float32 accumulation: a
-                                parity path (held to the 2e-5 of precision 0) at a third of the bf16 layers' MFMA rate */
+                                move by up to ~1e-2).  2: EVERY layer in split float16 -- activations and weights as float16
+                                hi + lo, hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16, float32 accumulation: a parity
+                                path (held to the 2e-5 of precision 0) in about half the time of precision 0 */
   int32_t obs_self_t_stride; /* bytes between env records of obs_self_t (cm3_checkers_desc.obs_self_t_stride) */
   int64_t env_id_base;
   uint64_t seed;

@@ -34,7 +34,7 @@ def main():
     torch.cuda.set_stream(torch.cuda.Stream(device=dev))
     cfg = cm3_amd.load_config("checkers_stage2")
     N = 2
-    for prec, E in [(pr, e) for pr in ("f32", "f16x3", "f16x3all", "bf16") for e in (8192, 65536)]:
+    for prec, E in [(pr, e) for pr in ("f32", "f16x3", "bf16") for e in (8192, 65536)]:
         actor = CheckersActor(random_weights(np.random.default_rng(0), N), N, device=dev, precision=prec)
         env = VecCheckersEnv(cfg["init"], N, 33, E, device=dev)
         env.reset(np.eye(2))
