@@ -349,14 +349,20 @@ __device__ __forceinline__ void actor_mlp(const ActorLds<N, PREC> &lds, const Ac
   if constexpr (PREC == kPrecF16x3) {
 #pragma unroll
     for (int s = 0; s < KU / 32; ++s) {
+      // the two small terms first, then hi x hi -- each product over all four row tiles before the next, so that two MFMAs on the
+      // same accumulator are four issues apart (back to back they wait for each other: measured on the Checkers actor)
+      f16x8 ah[4], al[4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {  // the two small terms first, then hi x hi
-        const f16x8 ah = *reinterpret_cast<const f16x8 *>(&lds.h1h[16 * t + col][32 * s + 8 * hi]);
-        const f16x8 al = *reinterpret_cast<const f16x8 *>(&lds.h1l[16 * t + col][32 * s + 8 * hi]);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, b.bwh[s], acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, b.bwl[s], acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, b.bwh[s], acc[t], 0, 0, 0);
+      for (int t = 0; t < 4; ++t) {
+        ah[t] = *reinterpret_cast<const f16x8 *>(&lds.h1h[16 * t + col][32 * s + 8 * hi]);
+        al[t] = *reinterpret_cast<const f16x8 *>(&lds.h1l[16 * t + col][32 * s + 8 * hi]);
       }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], b.bwh[s], acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], b.bwl[s], acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], b.bwh[s], acc[t], 0, 0, 0);
     }
   } else if constexpr (BF16) {
 #pragma unroll

@@ -369,25 +369,6 @@ __device__ __forceinline__ void gemm_tiles_bf16(const __bf16 *A, int lda, const 
 // ---- precision = 2 (split float16): three float16 MFMAs per product -- (a_lo, b_hi) + (a_hi, b_lo) + (a_hi, b_hi), float32
 // accumulation.  Activations and weights are split x = hi + lo with hi = (float16)x, lo = (float16)(x - hi): 22 of float32's 24
 // significand bits per factor, the error class of the exact-f32 path (tests hold the same 2e-5) at 16/3 of its MFMA rate.
-template <int RT, int CT>
-__device__ __forceinline__ void store_relu_f16x2(_Float16 *Oh, _Float16 *Ol, int ldo, int rt0, int ct0, const float (&bias)[CT],
-                                                 int lane, const f32x4 (&acc)[RT][CT]) {
-  const int col = lane & 15, hi = lane >> 4;
-#pragma unroll
-  for (int c = 0; c < CT; ++c) {
-#pragma unroll
-    for (int t = 0; t < RT; ++t)
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const float v = fmaxf(acc[t][c][reg] + bias[c], 0.0f);
-        const _Float16 vh = (_Float16)v;
-        const int at = (16 * (rt0 + t) + 4 * hi + reg) * ldo + 16 * (ct0 + c) + col;
-        Oh[at] = vh;
-        Ol[at] = (_Float16)(v - (float)vh);
-      }
-  }
-}
-
 // softmax (networks.py:576), epsilon mix (alg_credit_checkers.py:112), sampling (:113): lane l < 16 takes row 16w + l
 __device__ __forceinline__ void ck_actor_head(const CkActorParams &p, const float (*sLG)[8], int w, int lane, size_t row_base,
                                               size_t rows) {
@@ -626,7 +607,8 @@ template <bool BF16> __global__ void __launch_bounds__(256) k_ck_actor(const CkA
 
 // ---- the precision = 2 kernel: EVERY layer in split float16 ---------------------------------------------------------------------
 // The five small layers are 14 % of the MACs but, on the exact-f32 MFMA, most of the matrix-core time that is left once the two
-// 256 x 256 layers run in float16 (measured: 256 x 256 layers only 30.4 us per launch at 16 384 rows, all layers 26.5 us).  Same tile loop for every layer: A from float16 hi / lo LDS planes, B from the packed hi / lo
+// 256 x 256 layers run in float16 (measured, 16 384 rows: 256 x 256 layers only 30.4 us per launch, all layers 27.1, this kernel
+// 23.3; every step in profiles/r03_checkers_actor_split_precision.txt).  Same tile loop for every layer: A from float16 hi / lo LDS planes, B from the packed hi / lo
 // tiles, three MFMAs per (row tile, column tile, k-step of 32) -- two where the activations are exact in float16 (the window
 // bytes are -1 / 0 / 1: no lo plane).
 template <int CT, int KS>
@@ -638,6 +620,10 @@ __device__ __forceinline__ void load_bx(const float *Bh, const float *Bl, int ct
   }
 }
 
+// TRANSPOSED tiles: the weights are the A operand and the activations the B operand, so a lane ends with FOUR CONSECUTIVE UNITS
+// (4 (l >> 4) + reg of column tile c) of ONE agent row (16 (rt0 + t) + (l & 15)) -- contiguous in the next layer's row-major
+// plane: one 8-byte LDS store per plane and tile instead of four 2-byte stores (the epilogues were a quarter of this kernel).
+// Both operand fragments are "8 consecutive k of index l & 15" in the same registers as before; only their roles swap.
 template <int RT, int CT, int KS, bool ALO>
 __device__ __forceinline__ void gemm_x3(const _Float16 *Ah, const _Float16 *Al, int lda, int rt0, const float *Bh, const float *Bl,
                                         int ct0, int lane, const uint4 (&b0)[2][CT], f32x4 (&acc)[RT][CT]) {
@@ -648,19 +634,25 @@ __device__ __forceinline__ void gemm_x3(const _Float16 *Ah, const _Float16 *Al, 
     bsrc[0][c] = reinterpret_cast<const uint4 *>(Bh) + ((size_t)(ct0 + c) * KS) * 64 + lane;
     bsrc[1][c] = reinterpret_cast<const uint4 *>(Bl) + ((size_t)(ct0 + c) * KS) * 64 + lane;
   }
-  uint4 bcur[2][CT], bnext[2][CT];
+  // weights of k-step st + 2 are requested before the MFMAs of step st issue (a ring of three: one step of MFMAs, 768 cycles for
+  // the 4 x 4 tiles, is shorter than the L2 round trip of a lone workgroup)
+  uint4 bq[3][2][CT];
 #pragma unroll
   for (int c = 0; c < CT; ++c) {
-    bcur[0][c] = b0[0][c];
-    bcur[1][c] = b0[1][c];
+    bq[0][0][c] = b0[0][c];
+    bq[0][1][c] = b0[1][c];
+    if (KS > 1) {
+      bq[1][0][c] = bsrc[0][c][64];
+      bq[1][1][c] = bsrc[1][c][64];
+    }
   }
 #pragma unroll
   for (int st = 0; st < KS; ++st) {
-    if (st + 1 < KS) {
+    if (st + 2 < KS) {
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
-        bnext[0][c] = bsrc[0][c][(st + 1) * 64];
-        bnext[1][c] = bsrc[1][c][(st + 1) * 64];
+        bq[(st + 2) % 3][0][c] = bsrc[0][c][(st + 2) * 64];
+        bq[(st + 2) % 3][1][c] = bsrc[1][c][(st + 2) * 64];
       }
     }
     f16x8 ah[RT], al[RT];
@@ -669,23 +661,58 @@ __device__ __forceinline__ void gemm_x3(const _Float16 *Ah, const _Float16 *Al, 
       ah[t] = *reinterpret_cast<const f16x8 *>(Ah + (16 * (rt0 + t) + col) * lda + 32 * st + 8 * hi);
       if constexpr (ALO) al[t] = *reinterpret_cast<const f16x8 *>(Al + (16 * (rt0 + t) + col) * lda + 32 * st + 8 * hi);
     }
+    // the three products one after the other over ALL tiles: RT x CT independent accumulators between two MFMAs on the same one
+    f16x8 wh[CT], wl[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      __builtin_memcpy(&wh[c], &bq[st % 3][0][c], 16);
+      __builtin_memcpy(&wl[c], &bq[st % 3][1][c], 16);
+    }
+    if constexpr (ALO) {
+#pragma unroll
+      for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[c], al[t], acc[t][c], 0, 0, 0);
+    }
 #pragma unroll
     for (int t = 0; t < RT; ++t)
 #pragma unroll
-      for (int c = 0; c < CT; ++c) {
-        f16x8 bh, bl;
-        __builtin_memcpy(&bh, &bcur[0][c], 16);
-        __builtin_memcpy(&bl, &bcur[1][c], 16);
-        if constexpr (ALO) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh, acc[t][c], 0, 0, 0);
-        acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl, acc[t][c], 0, 0, 0);
-        acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh, acc[t][c], 0, 0, 0);
-      }
-    if (st + 1 < KS) {
+      for (int c = 0; c < CT; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[c], ah[t], acc[t][c], 0, 0, 0);
 #pragma unroll
-      for (int c = 0; c < CT; ++c) {
-        bcur[0][c] = bnext[0][c];
-        bcur[1][c] = bnext[1][c];
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+      for (int c = 0; c < CT; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[c], ah[t], acc[t][c], 0, 0, 0);
+  }
+}
+
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// this lane's four bias values per column tile (units 16 (ct0 + c) + 4 (l >> 4) + reg)
+template <int CT> __device__ __forceinline__ void load_bias4(const float *bias, int ct0, int lane, float4 (&b)[CT]) {
+#pragma unroll
+  for (int c = 0; c < CT; ++c) b[c] = *reinterpret_cast<const float4 *>(bias + 16 * (ct0 + c) + 4 * (lane >> 4));
+}
+
+// O[agent row][unit] = relu(acc + bias[unit]) as float16 hi / lo planes, transposed tiles (see gemm_x3)
+template <int RT, int CT>
+__device__ __forceinline__ void store_relu_x3(_Float16 *Oh, _Float16 *Ol, int ldo, int rt0, int ct0, const float4 (&bias)[CT], int lane,
+                                              const f32x4 (&acc)[RT][CT]) {
+  const int col = lane & 15, hi = lane >> 4;
+#pragma unroll
+  for (int c = 0; c < CT; ++c) {
+    const float bs[4] = {bias[c].x, bias[c].y, bias[c].z, bias[c].w};
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      f16x4 vh, vl;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const float v = fmaxf(acc[t][c][reg] + bs[reg], 0.0f);
+        vh[reg] = (_Float16)v;
+        vl[reg] = (_Float16)(v - (float)vh[reg]);
       }
+      const int at = (16 * (rt0 + t) + col) * ldo + 16 * (ct0 + c) + 4 * hi;
+      *reinterpret_cast<f16x4 *>(Oh + at) = vh;
+      *reinterpret_cast<f16x4 *>(Ol + at) = vl;
     }
   }
 }
@@ -714,30 +741,94 @@ __global__ void __launch_bounds__(256) k_ck_actor_x3(const CkActorParams p) {
   const size_t rows = (size_t)p.E * N;
   const size_t row_base = (size_t)blockIdx.x * 64;
   const float *pk = p.packed;
+  CM3_STAMP(0, false);
 
   uint4 b_conv[2][5];
   load_bx<5, kKConvX / 32>(pk + kXConvH, pk + kXConvL, 5 * (w >> 1), lane, b_conv);
-  // ---- stage the inputs (see k_ck_actor) -------------------------------------------------------------------------------------------
-  if ((p.obst_stride & 3) == 0 && (64 % N) == 0) {
-    const int epw = 64 / N, dpe = p.obst_stride >> 2, rec = N * kObs;
-    const size_t e0 = row_base / N;
-    for (int d = tid; d < epw * dpe; d += 256) {
-      const int el = d / dpe, dd = d - el * dpe;
-      size_t e = e0 + el;
-      e = e < (size_t)p.E ? e : (size_t)p.E - 1;
-      const uint32_t v = reinterpret_cast<const uint32_t *>(p.obs_self_t + e * (size_t)p.obst_stride)[dd];
+  // ---- stage the inputs: every global load is issued first, the zero fills run while they are in flight, then the scatter ----------
+  // (a lone workgroup per CU hides nothing: staged one dependent load after the other this phase was a fifth of the launch)
+  // fast path: N a power of two <= 64 (the 64 rows are whole envs), dword-aligned env records, and 4 N lanes per env cover a
+  // record in kWin dwords each (true for records padded to a dword: 75 N bytes <= 80 N); anything else takes the byte path.
+  // Lane li of env el loads dwords li, li + 4 N, ...: shifts only (a runtime division is ~40 instructions on this hardware).
+  constexpr int kWin = 5;
+  const int dpe = p.obst_stride >> 2, rec = N * kObs;
+  const int lsh = 2 + (__ffs(N) - 1), lpe = 4 * N;   // lanes per env = 256 / (64 / N)
+  const bool dwords = (N & (N - 1)) == 0 && N <= 64 && (p.obst_stride & 3) == 0 && dpe <= kWin * lpe;
+  const int wel = tid >> lsh, wli = tid & (lpe - 1);
+  uint32_t wv[kWin];
+  if (dwords) {
+    size_t e = row_base / N + wel;
+    e = e < (size_t)p.E ? e : (size_t)p.E - 1;
+    const uint32_t *recp = reinterpret_cast<const uint32_t *>(p.obs_self_t + e * (size_t)p.obst_stride);
+#pragma unroll
+    for (int q = 0; q < kWin; ++q) {
+      const int dd = wli + lpe * q;
+      wv[q] = recp[dd < dpe ? dd : 0];
+    }
+  }
+  // the concat tail and v_obs_others, four lanes per agent row: v_obs_self | a_prev + goal one-hots | pad | v_obs_others
+  const int trow = tid >> 2, part = tid & 3;
+  size_t row_t = row_base + trow;
+  row_t = row_t < rows ? row_t : rows - 1;
+  double tv[4] = {0.0, 0.0, 0.0, 0.0};
+  int ap = 0, gl = 0;
+  if (part == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) tv[k] = p.obs_self_v[row_t * 4 + k];
+  } else if (part == 1) {
+    // a fresh episode starts from actions_prev = zeros (train_onpolicy.py:295)
+    const size_t e = row_t / N;
+    ap = (p.actions_prev && !(p.prev_done && p.prev_done[e])) ? p.actions_prev[row_t] : 0;
+    gl = p.goals[row_t];
+  }
+  // zero fills: the k padding of X0, the tail of X2 (units 32 .. 63: values follow below, same wave, program order), the XO rows
+  if (dwords) {
+    for (int idx = tid; idx < 64 * (kKConvX - kObs); idx += 256) {
+      const int r = idx / (kKConvX - kObs), k = kObs + idx - r * (kKConvX - kObs);
+      sX0[r * kLhX0 + k] = (_Float16)0.0f;
+    }
+  }
+  {
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    if (part == 2) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        *reinterpret_cast<uint4 *>(sX2h + trow * kLhX2 + kLin + 8 * q) = z;
+        *reinterpret_cast<uint4 *>(sX2l + trow * kLhX2 + kLin + 8 * q) = z;
+      }
+    } else if (part == 3) {
+#pragma unroll
+      for (int q = 0; q < kKOthX / 8; ++q) {
+        *reinterpret_cast<uint4 *>(sXOh + trow * kLhXO + 8 * q) = z;
+        *reinterpret_cast<uint4 *>(sXOl + trow * kLhXO + 8 * q) = z;
+      }
+    }
+  }
+  const int at0 = trow * kLhX2 + kLin;
+  if (part == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) put_split(sX2h, sX2l, at0 + k, (float)tv[k]);
+  } else if (part == 1) {
+#pragma unroll
+    for (int k = 0; k < kA; ++k) sX2h[at0 + 4 + k] = ap == k ? (_Float16)1.0f : (_Float16)0.0f;
+    sX2h[at0 + 9] = gl == 0 ? (_Float16)1.0f : (_Float16)0.0f;
+    sX2h[at0 + 10] = gl == 0 ? (_Float16)0.0f : (_Float16)1.0f;
+  } else if (part == 3) {
+    for (int k = 0; k < p.Lo; ++k) put_split(sXOh, sXOl, trow * kLhXO + k, (float)p.obs_others[row_t * p.Lo + k]);
+  }
+  if (dwords) {
+    // window bytes -> float16 (values in {-1, 0, 1}): each dword's four bytes go to their (row, k) slots
+#pragma unroll
+    for (int q = 0; q < kWin; ++q) {
+      const int dd = wli + lpe * q;
 #pragma unroll
       for (int sb = 0; sb < 4; ++sb) {
         const int bb = 4 * dd + sb;
         if (bb < rec) {
           const int i = bb / kObs, k = bb - i * kObs;
-          sX0[(el * N + i) * kLhX0 + k] = (_Float16)(float)(int8_t)(v >> (8 * sb));
+          sX0[(wel * N + i) * kLhX0 + k] = (_Float16)(float)(int8_t)(wv[q] >> (8 * sb));
         }
       }
-    }
-    for (int idx = tid; idx < 64 * (kKConvX - kObs); idx += 256) {
-      const int r = idx / (kKConvX - kObs), k = kObs + idx - r * (kKConvX - kObs);
-      sX0[r * kLhX0 + k] = (_Float16)0.0f;
     }
   } else {
     for (int idx = tid; idx < 64 * kKConvX; idx += 256) {
@@ -749,101 +840,94 @@ __global__ void __launch_bounds__(256) k_ck_actor_x3(const CkActorParams p) {
       sX0[r * kLhX0 + k] = k < kObs ? (_Float16)(float)p.obs_self_t[e * (size_t)p.obst_stride + (size_t)i * kObs + k] : (_Float16)0.0f;
     }
   }
-  if (tid < 64) {  // concat tail: v_obs_self (4), a_prev one-hot (5), v_goal one-hot (2); pad; v_obs_others (natural order)
-    size_t row = row_base + tid;
-    row = row < rows ? row : rows - 1;
-    const size_t e = row / N;
-    const int at0 = tid * kLhX2 + kLin;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) put_split(sX2h, sX2l, at0 + k, (float)p.obs_self_v[row * 4 + k]);
-    const int ap = (p.actions_prev && !(p.prev_done && p.prev_done[e])) ? p.actions_prev[row] : 0;
-#pragma unroll
-    for (int k = 0; k < kA; ++k) put_split(sX2h, sX2l, at0 + 4 + k, ap == k ? 1.0f : 0.0f);
-    const int gl = p.goals[row];
-    put_split(sX2h, sX2l, at0 + 9, gl == 0 ? 1.0f : 0.0f);
-    put_split(sX2h, sX2l, at0 + 10, gl == 0 ? 0.0f : 1.0f);
-#pragma unroll
-    for (int k = kCat - kLin; k < kKSelfX - kLin; ++k) put_split(sX2h, sX2l, at0 + k, 0.0f);
-    for (int k = 0; k < kKOthX; ++k)
-      put_split(sXOh, sXOl, tid * kLhXO + k, k < p.Lo ? (float)p.obs_others[row * p.Lo + k] : 0.0f);
-  }
+  CM3_STAMP(1, true);
   __syncthreads();
+  CM3_STAMP(2, false);
 
   uint4 b_lin[2][1], b_self[2][4], b_h2[2][4], b_oth[2][4], b_out[2][1];
   // ---- conv (Toeplitz): X0 [64][96] -> C1 [64][160], relu ------------------------------------------------------------------------
   {
     f32x4 acc[2][5];
-    float bias[5];
-    load_bias<5>(pk + kPConvB, 5 * (w >> 1), lane, bias);
+    float4 bias[5];
+    load_bias4<5>(pk + kPConvB, 5 * (w >> 1), lane, bias);
     zero_tiles(acc);
     gemm_x3<2, 5, kKConvX / 32, false>(sX0, sX0, kLhX0, 2 * (w & 1), pk + kXConvH, pk + kXConvL, 5 * (w >> 1), lane, b_conv, acc);
     load_bx<1, kKLin / 32>(pk + kXLinH, pk + kXLinL, w >> 1, lane, b_lin);
-    store_relu_f16x2<2, 5>(sC1h, sC1l, kLhC1, 2 * (w & 1), 5 * (w >> 1), bias, lane, acc);
+    store_relu_x3<2, 5>(sC1h, sC1l, kLhC1, 2 * (w & 1), 5 * (w >> 1), bias, lane, acc);
   }
   __syncthreads();
+  CM3_STAMP(3, false);
   // ---- conv_linear: C1 [64][160] -> X2[:, 0:32], relu ---------------------------------------------------------------------------
   {
     f32x4 acc[2][1];
-    float bias[1];
-    load_bias<1>(pk + kPLinB, w >> 1, lane, bias);
+    float4 bias[1];
+    load_bias4<1>(pk + kPLinB, w >> 1, lane, bias);
     zero_tiles(acc);
     gemm_x3<2, 1, kKLin / 32, true>(sC1h, sC1l, kLhC1, 2 * (w & 1), pk + kXLinH, pk + kXLinL, w >> 1, lane, b_lin, acc);
     load_bx<4, kKSelfX / 32>(pk + kXSelfH, pk + kXSelfL, 4 * w, lane, b_self);
-    store_relu_f16x2<2, 1>(sX2h, sX2l, kLhX2, 2 * (w & 1), w >> 1, bias, lane, acc);
+    store_relu_x3<2, 1>(sX2h, sX2l, kLhX2, 2 * (w & 1), w >> 1, bias, lane, acc);
   }
   __syncthreads();
-  // ---- branch_self: X2 [64][64] -> H [64][256], relu; wave w owns columns [64w, 64w + 64) from here on -----------------------------
+  CM3_STAMP(4, false);
+  // ---- branch_self: X2 [64][64] -> H [64][256], relu; wave w owns units [64w, 64w + 64) from here on -------------------------------
   {
     f32x4 acc[4][4];
-    float bias[4];
-    load_bias<4>(pk + kPSelfB, 4 * w, lane, bias);
+    float4 bias[4];
+    load_bias4<4>(pk + kPSelfB, 4 * w, lane, bias);
     zero_tiles(acc);
     gemm_x3<4, 4, kKSelfX / 32, true>(sX2h, sX2l, kLhX2, 0, pk + kXSelfH, pk + kXSelfL, 4 * w, lane, b_self, acc);
     load_bx<4, 8>(pk + kPH2Sh, pk + kPH2Sl, 4 * w, lane, b_h2);
-    store_relu_f16x2<4, 4>(sHh, sHl, kLdHb, 0, 4 * w, bias, lane, acc);
+    store_relu_x3<4, 4>(sHh, sHl, kLdHb, 0, 4 * w, bias, lane, acc);
   }
   __syncthreads();
+  CM3_STAMP(5, false);
   // ---- h2 = relu(branch_self W_self_h2 + branch_others W_others_h2 + b) ------------------------------------------------------------
   f32x4 acc2[4][4];
   zero_tiles(acc2);
   gemm_x3<4, 4, 8, true>(sHh, sHl, kLdHb, 0, pk + kPH2Sh, pk + kPH2Sl, 4 * w, lane, b_h2, acc2);
   const bool stage2 = p.stage > 1;
-  float bias_oth[4], bias_h2[4];
-  load_bias<4>(pk + kPOthB, 4 * w, lane, bias_oth);
-  load_bias<4>(pk + kPH2B, 4 * w, lane, bias_h2);
+  float4 bias_oth[4], bias_h2[4];
+  load_bias4<4>(pk + kPOthB, 4 * w, lane, bias_oth);
+  load_bias4<4>(pk + kPH2B, 4 * w, lane, bias_h2);
   if (stage2) load_bx<4, 1>(pk + kXOthH, pk + kXOthL, 4 * w, lane, b_oth);
   else load_bx<1, 8>(pk + kXOutH, pk + kXOutL, 0, lane, b_out);
+  CM3_STAMP(6, true);
   __syncthreads();  // every wave is done reading branch_self
+  CM3_STAMP(7, false);
   if (stage2) {
     {
       f32x4 acc[4][4];
       zero_tiles(acc);
       gemm_x3<4, 4, 1, true>(sXOh, sXOl, kLhXO, 0, pk + kXOthH, pk + kXOthL, 4 * w, lane, b_oth, acc);
       load_bx<4, 8>(pk + kPH2Oh, pk + kPH2Ol, 4 * w, lane, b_h2);
-      store_relu_f16x2<4, 4>(sHh, sHl, kLdHb, 0, 4 * w, bias_oth, lane, acc);
+      store_relu_x3<4, 4>(sHh, sHl, kLdHb, 0, 4 * w, bias_oth, lane, acc);
     }
     __syncthreads();
+    CM3_STAMP(8, false);
     gemm_x3<4, 4, 8, true>(sHh, sHl, kLdHb, 0, pk + kPH2Oh, pk + kPH2Ol, 4 * w, lane, b_h2, acc2);
     load_bx<1, 8>(pk + kXOutH, pk + kXOutL, 0, lane, b_out);
+    CM3_STAMP(9, true);
     __syncthreads();
   }
-  store_relu_f16x2<4, 4>(sHh, sHl, kLdHb, 0, 4 * w, bias_h2, lane, acc2);
+  CM3_STAMP(10, false);
+  store_relu_x3<4, 4>(sHh, sHl, kLdHb, 0, 4 * w, bias_h2, lane, acc2);
   __syncthreads();
-  // ---- actor_out: wave w finishes rows [16w, 16w + 16) -----------------------------------------------------------------------------
+  CM3_STAMP(11, false);
+  // ---- actor_out: wave w finishes agent rows [16w, 16w + 16); transposed tile: lane (row l & 15) holds logits 4 (l >> 4) + reg ----------
   {
     f32x4 acc[1][1];
     zero_tiles(acc);
     gemm_x3<1, 1, 8, true>(sHh, sHl, kLdHb, w, pk + kXOutH, pk + kXOutL, 0, lane, b_out, acc);
     const int col = lane & 15, hi = lane >> 4;
-    if (col < 8) {
-      const float b = pk[kPOutB + col];
+    if (hi < 2) {
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) sLG[16 * w + 4 * hi + reg][col] = acc[0][0][reg] + b;
+      for (int reg = 0; reg < 4; ++reg) sLG[16 * w + col][4 * hi + reg] = acc[0][0][reg] + pk[kPOutB + 4 * hi + reg];
     }
   }
   __builtin_amdgcn_s_waitcnt(0);
   __builtin_amdgcn_wave_barrier();
   ck_actor_head(p, sLG, w, lane, row_base, rows);
+  CM3_STAMP(12, true);
 }
 
 static int ck_actor_check(const cm3_actor_checkers_desc *d) {

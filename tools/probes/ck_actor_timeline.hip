@@ -6,7 +6,7 @@ __device__ long long *cm3_stamp_buf;
 #include "../../cm3_amd/csrc/util.hip"
 #include <vector>
 int main(int argc, char **argv) {
-  const int E = argc > 1 ? atoi(argv[1]) : 8192, N = 2, Lo = 2;
+  const int E = argc > 1 ? atoi(argv[1]) : 8192, N = 2, Lo = 2, prec = argc > 2 ? atoi(argv[2]) : 0;   // prec: 0 f32, 1 bf16, 2 f16x3
   int8_t *obst; double *obsv, *obso; uint8_t *goals; int32_t *steps, *episode, *actions; float *w; long long *stamps;
   hipMalloc((void **)&obst, (size_t)E * 152); hipMalloc((void **)&obsv, (size_t)E * N * 32); hipMalloc((void **)&obso, (size_t)E * N * Lo * 8);
   hipMalloc((void **)&goals, (size_t)E * N); hipMalloc((void **)&steps, (size_t)E * 4); hipMalloc((void **)&episode, (size_t)E * 4);
@@ -22,7 +22,7 @@ int main(int argc, char **argv) {
 #endif
   cm3_actor_checkers_desc d; memset(&d, 0, sizeof(d));
   d.n_envs = E; d.n_agents = N; d.stage = 2; d.n_obs = 2; d.conv_f = 6; d.n_conv_linear = 32; d.n_h1 = 256; d.n_h2 = 256; d.n_actions = 5;
-  d.epsilon = 0.1f; d.obs_self_t_stride = 152;
+  d.epsilon = 0.1f; d.obs_self_t_stride = 152; d.precision = prec;
   cm3_actor_checkers_weights wt; float *q = w;
   wt.conv_w = q; q += 162; wt.conv_b = q; q += 6; wt.lin_w = q; q += 4800; wt.lin_b = q; q += 32; wt.self_w = q; q += 43 * 256; wt.self_b = q; q += 256;
   wt.w_self_h2 = q; q += 65536; wt.others_w = q; q += Lo * 256; wt.others_b = q; q += 256; wt.w_others_h2 = q; q += 65536; wt.b_h2 = q; q += 256;
@@ -40,7 +40,7 @@ int main(int argc, char **argv) {
   for (int t = 0; t < 100; ++t) cm3_actor_checkers_f32(&d, &wt, &b, s);
   hipEventRecord(e1, s); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
-  printf("E=%d: %.3f us per actor launch (back-to-back eager)\n", E, ms * 1e3 / 100);
+  printf("E=%d precision=%d: %.3f us per actor launch (back-to-back eager)\n", E, prec, ms * 1e3 / 100);
 #ifdef CM3_STAMPS
   std::vector<long long> h((size_t)waves * 16);
   hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost);
