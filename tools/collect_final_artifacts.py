@@ -3,7 +3,7 @@
 
     python tools/collect_final_artifacts.py            # after gpurun -- 'bash tools/round3_final.sh'
 
-bench lines -> profiles/r03_bench_c{2..5}.json, the two-stamp record -> profiles/r03_kernel_span_c{2,3,5}.txt (+ .json),
+bench lines -> profiles/r03_bench_c{2..5}.json, the two-stamp record -> profiles/r03_kernel_span_c{2,3,4,5}.txt (+ .json),
 PMC summaries -> profiles/r03_pmc_*.txt + profiles/pmc_traffic.json, the rocprofv3 kernel-trace summary ->
 profiles/r03_bench_c2_kernel_stats.txt, the test / smoke tails -> profiles/r03_pytest_gpu_summary.txt.
 """
@@ -48,7 +48,7 @@ def main():
             blocks[cur] = []
         if cur and not l.startswith("{") and not l.startswith("#"):
             blocks[cur].append(l)
-    for wl in ("c2", "c3", "c5"):
+    for wl in ("c2", "c3", "c4", "c5"):
         d = bench[wl]
         inpl = d.get("launch_modes", {}).get("in_place_chains1", {}).get("us_per_tick")
         out = [HEAD.rstrip("\n")] + tool_head

@@ -8,7 +8,7 @@ python -c "import __graft_entry__ as g; g.build()" > "$O/build.log" 2>&1
 timeout 2400 python -m pytest tests -m gpu -q > "$O/pytest_gpu.log" 2>&1; echo "suite rc=$?"; grep -E "^FAILED|^ERROR" "$O/pytest_gpu.log" | head; tail -1 "$O/pytest_gpu.log"
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$O/smoke.log" 2>&1; echo "smoke rc=$?"; tail -1 "$O/smoke.log"
 # undisturbed kernel durations (two stamps per wave, unprofiled graph replays)
-CM3_AMD_LIB=$R/cm3_amd/libcm3_hip_span.so timeout 900 python tools/kernel_span.py c2 c3 c5 floor --json > "$O/kernel_span.txt" 2> "$O/kernel_span.err"; echo "span rc=$?"
+CM3_AMD_LIB=$R/cm3_amd/libcm3_hip_span.so timeout 900 python tools/kernel_span.py c2 c3 c4 c5 floor --json > "$O/kernel_span.txt" 2> "$O/kernel_span.err"; echo "span rc=$?"
 grep "^{" "$O/kernel_span.txt" | tail -1 > "$O/kernel_span.json"; cp "$O/kernel_span.json" "$R/profiles/r03_kernel_span.json"
 timeout 1200 python bench.py > "$O/bench_c2.json" 2> "$O/bench_c2.err"; echo "bench c2 rc=$?"
 for wl in c3 c4 c5; do timeout 900 python bench.py --workload $wl --no-sweep > "$O/bench_$wl.json" 2> "$O/bench_$wl.err"; echo "bench $wl rc=$?"; done
