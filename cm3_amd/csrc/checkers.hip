@@ -1061,7 +1061,7 @@ __global__ void __launch_bounds__(256)
   const int g = lane & (F::G - 1), sub = lane / F::G;
   // 32-bit env index and byte offsets (every per-tick array below 4 GiB, checked by ck_launch): addresses are
   // <uniform base> + <lane offset>, as in the particle kernels
-  const uint32_t e = ((uint32_t)blockIdx.x * 4 + wave) * F::EPW + sub;
+  const uint32_t e = (cm3_xcd_block(h_flags) * 4 + wave) * F::EPW + sub;
   const bool env_ok = e < (uint32_t)h_E;
   const uint32_t ec = env_ok ? e : (uint32_t)h_E - 1;
   const bool writer = env_ok && g == 0;
@@ -1268,7 +1268,9 @@ template <int N> static int ck_launch(const CheckersParams &p, bool step, hipStr
   if (ck_fast_ok(p)) {
     const bool nt = (p.flags & kCkObsStoreNt) != 0;   // streaming-size trajectory (ck_rollout): non-temporal stores, kCkGStream lanes per env
     const unsigned epb = 4u * (nt ? CkFast<N, kCkGStream>::EPW : CkFast<N>::EPW);  // 4 waves x EPW envs per workgroup
-    const unsigned fblocks = (unsigned)(((size_t)p.E + epb - 1) / epb);
+    const unsigned raw_blocks = (unsigned)(((size_t)p.E + epb - 1) / epb);
+    const unsigned fblocks = cm3_xcd_grid(raw_blocks);         // XCD-aware block order (common.h)
+    const uint32_t xf = cm3_xcd_flags(raw_blocks);
     if (step) {  // the step kernel indexes with 32-bit byte offsets: the widest per-env record of any per-tick array bounds E
       // obs_self_t (stride), grid (stride), obs_self_v 32 N, obs_others 16 N max(N-1, 1), vec 16 N, local_rewards 8 N
       size_t widest = (size_t)p.obst_stride;
@@ -1282,7 +1284,7 @@ template <int N> static int ck_launch(const CheckersParams &p, bool step, hipStr
 #define CM3_LAUNCH_CKF(...)                                                                                                  \
   hipLaunchKernelGGL((k_checkers_step_fast<N, __VA_ARGS__>), dim3(fblocks), dim3(256), 0, stream, (const uint64_t *)p.mask,    \
                      (const uint32_t *)p.agents, (const int32_t *)p.steps, (const int32_t *)p.episode, (const uint8_t *)p.goals, \
-                     p.E, p.flags, p)
+                     p.E, p.flags | xf, p)
     if (step && p.n_ticks > 1) {
       if (nt) CM3_LAUNCH_CKF(true, true, kCkGStream);
       else CM3_LAUNCH_CKF(true);

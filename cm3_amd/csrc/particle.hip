@@ -728,7 +728,7 @@ __global__ void __launch_bounds__(WAVES * 64)
   const int wave = wave_all;
   const int gslot = lane & (G - 1), sub = lane / G, base = lane - gslot;
   const uint32_t E = (uint32_t)h_E, EN = (uint32_t)h_EN;  // array extent (row stride); this launch covers envs [h_E0, h_EN)
-  const uint32_t e = (uint32_t)h_E0 + ((uint32_t)blockIdx.x * WAVES + wave) * EPW + sub;
+  const uint32_t e = (uint32_t)h_E0 + (cm3_xcd_block(h_flags) * WAVES + wave) * EPW + sub;
   const bool env_ok = e < EN;
   const uint32_t ec = env_ok ? e : EN - 1;
   // lane gslot of the group = pair lane k of agent i: gslot = i * LA + k, k < N - 1 (LA == N - 1 unless padded, see PairGeom)
@@ -983,7 +983,7 @@ __global__ void __launch_bounds__(WAVES * 64)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int gi = lane & (G - 1), sub = lane / G, base = lane - gi;
   const uint32_t E = (uint32_t)h_E, EN = (uint32_t)h_EN;  // array extent (row stride); this launch covers envs [E0, EN)
-  const uint32_t e0 = (uint32_t)h_E0 + ((uint32_t)blockIdx.x * WAVES + wave) * EPW;
+  const uint32_t e0 = (uint32_t)h_E0 + (cm3_xcd_block(h_flags) * WAVES + wave) * EPW;
   const uint32_t e = e0 + sub;
   const bool env_ok = e < EN;
   const uint32_t ec = env_ok ? e : EN - 1;
@@ -1276,7 +1276,7 @@ __global__ void __launch_bounds__(WAVES * 64)
   const int gi = lane & (G - 1), sub = lane / G, base = lane - gi;
   const int i = gi >> 1, h = gi & 1;
   const uint32_t E = (uint32_t)h_E, EN = (uint32_t)h_EN;
-  const uint32_t e0 = (uint32_t)h_E0 + ((uint32_t)blockIdx.x * WAVES + wave) * EPW;
+  const uint32_t e0 = (uint32_t)h_E0 + (cm3_xcd_block(h_flags) * WAVES + wave) * EPW;
   const uint32_t e = e0 + sub;
   const bool env_ok = e < EN;
   const uint32_t ec = env_ok ? e : EN - 1;
@@ -1670,12 +1670,14 @@ static int launch_one(const ParticleParams &p, ParticleOp op, hipStream_t stream
 template <typename R, int N, int WAVES> static int launch_pairs(const ParticleParams &p, hipStream_t stream) {
   if constexpr (N >= 2) {
     const size_t envs_per_block = (size_t)WAVES * PairGeom<N>::EPW;
-    const unsigned blocks = (unsigned)(((size_t)(p.EN - p.E0) + envs_per_block - 1) / envs_per_block);
+    const unsigned raw_blocks = (unsigned)(((size_t)(p.EN - p.E0) + envs_per_block - 1) / envs_per_block);
+    const unsigned blocks = cm3_xcd_grid(raw_blocks);          // XCD-aware block order (common.h)
+    const uint32_t xf = cm3_xcd_flags(raw_blocks);
     constexpr int kF32 = sizeof(R) == 4 ? kSpNt : kSpPlain;
     const bool nt = sizeof(R) == 4 && (p.flags & kFlagObsStoreNt);   // streaming-size trajectory (obs_store_nt)
 #define CM3_LAUNCH_PAIRS(...)                                                                                               \
   hipLaunchKernelGGL((k_particle_step_pairs<R, N, WAVES, __VA_ARGS__>), dim3(blocks), dim3(WAVES * 64), 0, stream,          \
-                     p.state_in, p.goals_in, p.meta_in, (const int32_t *)p.episode, p.E, p.flags, p.E0, p.EN, p.max_steps,        \
+                     p.state_in, p.goals_in, p.meta_in, (const int32_t *)p.episode, p.E, p.flags | xf, p.E0, p.EN, p.max_steps,   \
                      (const int32_t *)p.actions, p)
     // the kernel indexes with 32-bit byte offsets: its largest per-tick array (obs_others) must stay below 4 GiB
     if ((size_t)p.E * PairGeom<N>::SLOTS * 4 * sizeof(R) >= ((size_t)1 << 32))
@@ -1706,11 +1708,13 @@ constexpr size_t kPairsMaxEnvs = (size_t)1 << 14;
 template <typename R, int N, int WAVES> static int launch_agents(const ParticleParams &p, hipStream_t stream) {
   if constexpr (N >= 2) {
     const size_t envs_per_block = (size_t)WAVES * AgentGeom<N>::EPW;
-    const unsigned blocks = (unsigned)(((size_t)(p.EN - p.E0) + envs_per_block - 1) / envs_per_block);
+    const unsigned raw_blocks = (unsigned)(((size_t)(p.EN - p.E0) + envs_per_block - 1) / envs_per_block);
+    const unsigned blocks = cm3_xcd_grid(raw_blocks);          // XCD-aware block order (common.h)
+    const uint32_t xf = cm3_xcd_flags(raw_blocks);
     const bool nt = sizeof(R) == 4 && (p.flags & kFlagObsStoreNt);   // streaming-size trajectory (obs_store_nt)
 #define CM3_LAUNCH_AGENTS(...)                                                                                              \
   hipLaunchKernelGGL((k_particle_step_agents<R, N, WAVES, __VA_ARGS__>), dim3(blocks), dim3(WAVES * 64), 0, stream,         \
-                     p.state_in, p.goals_in, p.meta_in, (const int32_t *)p.episode, p.E, p.flags, p.E0, p.EN, p.max_steps,        \
+                     p.state_in, p.goals_in, p.meta_in, (const int32_t *)p.episode, p.E, p.flags | xf, p.E0, p.EN, p.max_steps,   \
                      (const int32_t *)p.actions, p)
     // 32-bit byte offsets inside the kernel: the largest per-tick array (obs_others) must stay below 4 GiB
     if ((size_t)p.E * AgentGeom<N>::VPE * 4 * sizeof(R) >= ((size_t)1 << 32))
@@ -1722,10 +1726,12 @@ template <typename R, int N, int WAVES> static int launch_agents(const ParticleP
     if constexpr (N == 8 && sizeof(R) == 4) {
       // two lanes per agent (k_particle_step_agents2) while a SIMD holds few waves: per-tick launches up to kAgents2MaxEnvs
       if (p.n_ticks == 1 && (size_t)(p.EN - p.E0) <= kAgents2MaxEnvs) {
-        const unsigned blocks2 = (unsigned)(((size_t)(p.EN - p.E0) + (size_t)WAVES * 4 - 1) / ((size_t)WAVES * 4));
+        const unsigned raw2 = (unsigned)(((size_t)(p.EN - p.E0) + (size_t)WAVES * 4 - 1) / ((size_t)WAVES * 4));
+        const unsigned blocks2 = cm3_xcd_grid(raw2);
+        const uint32_t xf2 = cm3_xcd_flags(raw2);
 #define CM3_LAUNCH_AGENTS2(...)                                                                                             \
   hipLaunchKernelGGL((k_particle_step_agents2<WAVES, __VA_ARGS__>), dim3(blocks2), dim3(WAVES * 64), 0, stream, p.state_in,  \
-                     p.goals_in, p.meta_in, (const int32_t *)p.episode, p.E, p.flags, p.E0, p.EN, p.max_steps,               \
+                     p.goals_in, p.meta_in, (const int32_t *)p.episode, p.E, p.flags | xf2, p.E0, p.EN, p.max_steps,         \
                      (const int32_t *)p.actions, p)
         if (live) {
           if (wt) CM3_LAUNCH_AGENTS2(kWt, true);
