@@ -30,34 +30,38 @@ extern __device__ long long *cm3_stamp_buf;
 // envs per line, reward / collisions / episode: 32, meta: 16) are written in pieces by workgroups on eight different XCDs, each of
 // which keeps, and at the end of the launch writes back, its own partial copy.  Here the workgroups that are dispatched together
 // (a tile of 8 G consecutive block ids; G = 32: one per CU) cover 8 G CONSECUTIVE env blocks, and XCD x takes G consecutive ones
-// of them: logical block = tile base + (b % 8) G + (b / 8) % G.  log2 G travels in four bits of the kernels' leading `flags`
+// of them: logical block = tile base + (b % 8) G + (b / 8) % G.  The mode travels in the top byte of the kernels' leading `flags`
 // argument (a preloaded SGPR: reading gridDim instead put a scalar load in front of the first global loads and lost what the order
-// gains); launches of fewer than kXcdMinBlocks workgroups keep the plain order (G = 1).  Launchers round the grid up with
+// gains); launches of fewer than CM3_XCD_MIN_BLOCKS workgroups keep the plain order.  Launchers round the grid up with
 // cm3_xcd_grid(); a logical block beyond the batch finds no env of its own (the kernels clamp and store nothing).
 // Measured (profiles/r03_xcd_block_order.txt): C5 4.83 -> 4.41 us per tick, C3 3.64 -> 3.56, C2 2.54 -> 2.49.
-constexpr uint32_t kFlagXcdShift = 24, kFlagXcdMask = 0xFu << kFlagXcdShift;   // internal launch flag bits: log2 G
-#ifndef CM3_XCD_LOG2_GROUP
-#define CM3_XCD_LOG2_GROUP 5u     // (macros: build variants for the comparison)
-#endif
+// Launches of up to 256 workgroups (all in flight together) simply give XCD x the x-th eighth: logical block = (b % 8) G + b / 8 with
+// G = ceil(blocks / 8) -- every XCD gets work whatever the count (a 256-tile with 128 or 192 blocks would leave XCDs idle: measured
+// +11 .. 18 % on such launches).  The mode travels in the top byte of `flags`: 0 plain order, 1 .. 32 = G of an eighths launch,
+// kXcdTiles = tiles of 256.
+constexpr uint32_t kFlagXcdShift = 24, kXcdTiles = 63u;   // internal launch flag bits
 #ifndef CM3_XCD_MIN_BLOCKS
-#define CM3_XCD_MIN_BLOCKS 128u
+#define CM3_XCD_MIN_BLOCKS 64u    // (macro: build variant for the comparison)
 #endif
 __device__ __forceinline__ uint32_t cm3_xcd_block(uint32_t flags) {
-  const uint32_t b = blockIdx.x, lg = (flags & kFlagXcdMask) >> kFlagXcdShift, G = 1u << lg;
-  return (b & ~(8u * G - 1u)) | ((b & 7u) << lg) | ((b >> 3) & (G - 1u));
+  const uint32_t b = blockIdx.x, v = flags >> kFlagXcdShift;
+  const uint32_t tiled = (b & ~255u) | ((b & 7u) << 5) | ((b >> 3) & 31u);
+  const uint32_t eighth = (b & 7u) * v + (b >> 3);
+  return v == 0u ? b : (v == kXcdTiles ? tiled : eighth);
 }
-// host: the flag bits and the rounded grid for a launch of `blocks` workgroups
+// host: the flag bits and the grid for a launch of `blocks` workgroups
 static inline uint32_t cm3_xcd_flags(unsigned blocks) {
 #ifdef CM3_NO_XCD_ORDER
   (void)blocks;
   return 0u;
 #else
-  return blocks >= CM3_XCD_MIN_BLOCKS ? (CM3_XCD_LOG2_GROUP << kFlagXcdShift) : 0u;
+  if (blocks < CM3_XCD_MIN_BLOCKS) return 0u;
+  return (blocks <= 256u ? (blocks + 7u) / 8u : kXcdTiles) << kFlagXcdShift;
 #endif
 }
 static inline unsigned cm3_xcd_grid(unsigned blocks) {
-  const unsigned tile = 8u << ((cm3_xcd_flags(blocks) & kFlagXcdMask) >> kFlagXcdShift);
-  return (blocks + tile - 1u) / tile * tile;
+  const uint32_t v = cm3_xcd_flags(blocks) >> kFlagXcdShift;
+  return v == 0u ? blocks : (v == kXcdTiles ? (blocks + 255u) / 256u * 256u : 8u * v);
 }
 
 // Kernel-span instrumentation (build variant -DCM3_SPAN_STAMPS -> libcm3_hip_span.so; never defined in the product build):

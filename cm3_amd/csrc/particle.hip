@@ -1802,9 +1802,11 @@ template <typename R, int N> static int launch_n(const ParticleParams &p, Partic
     //   N = 2: pair up to 32768 envs (16384: 2.57 / - / 2.68; 32768: 2.89 / - / 3.01); N = 6: agent from 6144 (4.27 / 4.11);
     //   N = 7, 8: agent from 4096 (N = 8: 5.12 / 4.57, N = 7: 4.73 / 4.34; at 2048 pair: 3.83 / 4.29)
     constexpr size_t kPairMax = N == 2 ? 32768 : (N == 3 ? 24576 : (N == 4 ? 12288 : kPairsMaxEnvs));
-    // round 3, N = 8 with two lanes per agent (k_particle_step_agents2; profiles/r03_two_lanes_per_agent.txt): agent from 2048
-    // (in place 3.50 vs pair 3.54; 3072: 3.66 vs 4.04; 1024: 3.40 vs 3.02 -> pair)
-    constexpr size_t kAgentLo = N == 4 ? 12289 : (N == 5 ? 8192 : (N == 6 ? 6144 : (N == 7 ? 4096 : (N == 8 ? 2048 : kInf))));
+    // round 3: N = 8 with two lanes per agent (k_particle_step_agents2; profiles/r03_two_lanes_per_agent.txt) moved its crossover
+    // to 2048 envs; the XCD-aware block order (common.h) then sped the pair mapping up most at exactly these sizes
+    // (profiles/r03_xcd_block_order.txt; pair / agent, in place): N = 8: 2048 3.42 / 3.74, 4096 4.47 / 3.84 -> agent from 4096;
+    // N = 7: 4096 4.12 / 4.31, 6144 5.03 / 4.29 -> agent from 6144; N = 6: 6144 3.86 / 4.14, 8192 4.37 / 4.11 -> agent from 8192
+    constexpr size_t kAgentLo = N == 4 ? 12289 : (N == 5 ? 8192 : (N == 6 ? 8192 : (N == 7 ? 6144 : (N == 8 ? 4096 : kInf))));
     // round 3, large batches after the write-through observation stores (profiles/r03_mapping_sweep_large.txt; env / agent):
     //   N = 6: 2^17 17.7 / 17.4, 2^19 66.3 / 62.3, 2^20 125.5 / 121.9, 2^21 290 / 326   -> agent up to 1.5 M envs (was 65536)
     //   N = 7: 2^19 89 / 80, 2^20 164-170 / 153-217 (the agent mapping is bimodal there: it depends on where the allocator
