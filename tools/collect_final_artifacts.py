@@ -20,8 +20,10 @@ HEAD = """# Round 3 FINAL build: undisturbed kernel-duration record (tools/kerne
 # csrc/build.sh with -DCM3_SPAN_STAMPS, csrc/common.h): every wave stamps s_memrealtime (100 MHz) + s_memtime at its first
 # instruction and after its last store has been acknowledged; bench.py's own 330-launch hipGraph, NOT profiled; stamps of the
 # last of 20 timed replays.  span = first wave in -> last wave out; start-to-start = consecutive first-wave-in; gap = the
-# dependent-launch boundary.  The stamp store itself (one more 128-byte store per wave before the wave ends) adds ~0.1-0.15 us
-# to start-to-start / gap in THIS build; the product's time per launch is bench.py's us_per_tick of the same box, quoted below.
+# dependent-launch boundary.  The stamp store itself (one more 32-byte store per wave into its own 128-byte record, after the
+# wave's last store has been acknowledged) lengthens the BOUNDARY in this build -- by 0.1-0.2 us at 1024 waves per launch, by
+# ~0.6 us in the C5 trajectory launches (2048 waves); the spans are not affected.  The product's time per launch is bench.py's
+# us_per_tick of the same box, quoted below: read span from this record, and gap as (product time per launch - span).
 """
 
 
