@@ -1806,7 +1806,8 @@ template <typename R, int N> static int launch_n(const ParticleParams &p, Partic
     // to 2048 envs; the XCD-aware block order (common.h) then sped the pair mapping up most at exactly these sizes
     // (profiles/r03_xcd_block_order.txt; pair / agent, in place): N = 8: 2048 3.42 / 3.74, 4096 4.47 / 3.84 -> agent from 4096;
     // N = 7: 4096 4.12 / 4.31, 6144 5.03 / 4.29 -> agent from 6144; N = 6: 6144 3.86 / 4.14, 8192 4.37 / 4.11 -> agent from 8192
-    constexpr size_t kAgentLo = N == 4 ? 12289 : (N == 5 ? 8192 : (N == 6 ? 8192 : (N == 7 ? 6144 : (N == 8 ? 4096 : kInf))));
+    // N = 5: 8192 3.86 / 4.02, 12288 4.74 / 4.42 -> agent from 10240 (profiles/r03_mapping_sweep_xcd.txt)
+    constexpr size_t kAgentLo = N == 4 ? 12289 : (N == 5 ? 10240 : (N == 6 ? 8192 : (N == 7 ? 6144 : (N == 8 ? 4096 : kInf))));
     // round 3, large batches after the write-through observation stores (profiles/r03_mapping_sweep_large.txt; env / agent):
     //   N = 6: 2^17 17.7 / 17.4, 2^19 66.3 / 62.3, 2^20 125.5 / 121.9, 2^21 290 / 326   -> agent up to 1.5 M envs (was 65536)
     //   N = 7: 2^19 89 / 80, 2^20 164-170 / 153-217 (the agent mapping is bimodal there: it depends on where the allocator
