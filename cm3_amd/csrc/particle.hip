@@ -196,6 +196,7 @@ constexpr size_t kWtMinObsBytes = (size_t)3 << 20;
 #define CM3_AGENTS2_MAX_ENVS 32768   // measured crossover, profiles/r03_two_lanes_per_agent.txt (macro: build variant for that measurement)
 #endif
 constexpr size_t kAgents2MaxEnvs = CM3_AGENTS2_MAX_ENVS;  // N = 8: two lanes per agent up to this many envs per launch
+constexpr size_t kAgents2EarlyMaxEnvs = 16384;            // ... with its write-through stores ahead of the reward work up to here
 
 typedef float cm3_f4 __attribute__((ext_vector_type(4)));
 // Store policy of the observation rows, a COMPILE-TIME parameter of the step kernels (kSpPlain kernels are byte for byte the code
@@ -1124,6 +1125,19 @@ __global__ void __launch_bounds__(WAVES * 64)
       oj[j].w = __shfl(si.w, base + j, 64);
     }
 
+    // state / goals stores of this tick (issued last: moving the write-through stores of this kernel ahead of the reward work, as
+    // the two-lanes kernel does for small batches, LOST 2-6 % at the batch sizes this kernel serves: profiles/r03_early_wt_stores.txt)
+    auto emit_state = [&](bool fresh_goals) {
+      if (mine) {
+        *at32<V4>(tick_ptr(p.state_out, p.st_state, t), (row_i + e) * (uint32_t)sizeof(V4)) = si;
+        if (p.goals_out != p.goals_in || fresh_goals)
+          *at32<V2>(tick_ptr(p.goals_out, p.st_goals, t), (row_i + e) * (uint32_t)sizeof(V2)) = gl;
+        if constexpr (LIVE) {  // live-state rollout (a compile-time variant: the others carry none of it): the slot gets a copy
+          store_obs_vec<SP>(at32<V4>(p.state_copy, (row_i + e) * (uint32_t)sizeof(V4)), si);
+          *at32<V2>(p.goals_copy, (row_i + e) * (uint32_t)sizeof(V2)) = gl;
+        }
+      }
+    };
     CM3_STAMP(4, true);
     CM3_SPAN_MARK(3, false);  // integrated, post-step states exchanged
     // ---- reward / reached / collisions (multi-goal_spread.py:114-143) ----------------------------------------
@@ -1222,15 +1236,7 @@ __global__ void __launch_bounds__(WAVES * 64)
     CM3_STAMP(6, false);
     CM3_SPAN_MARK(5, false);  // reset handled
     // ---- per-tick stores ------------------------------------------------------------------------------------------
-    if (mine) {
-      *at32<V4>(tick_ptr(p.state_out, p.st_state, t), (row_i + e) * (uint32_t)sizeof(V4)) = si;
-      if (p.goals_out != p.goals_in || was_reset)
-        *at32<V2>(tick_ptr(p.goals_out, p.st_goals, t), (row_i + e) * (uint32_t)sizeof(V2)) = gl;
-      if constexpr (LIVE) {  // live-state rollout (a compile-time variant: the others carry none of it): the slot gets a copy
-        store_obs_vec<SP>(at32<V4>(p.state_copy, (row_i + e) * (uint32_t)sizeof(V4)), si);
-        *at32<V2>(p.goals_copy, (row_i + e) * (uint32_t)sizeof(V2)) = gl;
-      }
-    }
+    emit_state(was_reset);
     store_obs(oj, tick_ptr(p.obs_others, p.st_obs, t));  // observation (multi-goal_spread.py:145-154)
   }
 
@@ -1261,7 +1267,7 @@ __global__ void __launch_bounds__(WAVES * 64)
 //     sum is never -0) to a start value; pass 1 starts from the action force, pass 2 from the EVEN lane's pass-1 result (DPP), so
 //     the odd lane ends with f7 + (f6 + (f5 + (f4 + (f3 + (f2 + (f1 + (f0 + F_action))))))) and hands it back to the even lane;
 //   * collision counts add up over the pair, the env's count and NumPy's 8-value pairwise reward tree are DPP row reductions.
-template <int WAVES, int SP = kSpPlain, bool LIVE = false, int TU = CM3_PARTICLE_TU>
+template <int WAVES, int SP = kSpPlain, bool LIVE = false, bool EARLY = false, int TU = CM3_PARTICLE_TU>
 __global__ void __launch_bounds__(WAVES * 64)
     k_particle_step_agents2(const void *h_state_in, const void *h_goals_in, const int32_t *h_meta_in, const int32_t *h_episode,
                             const int h_E, const uint32_t h_flags, const int h_E0, const int h_EN, const int h_max_steps,
@@ -1410,7 +1416,40 @@ __global__ void __launch_bounds__(WAVES * 64)
   steps += 1;
   V4 oj[NH];
   gather(oj);
-  CM3_SPAN_MARK(3, false);  // integrated, post-step states exchanged
+  // observation (multi-goal_spread.py:145-154): the tile goes out as contiguous 16-byte-per-lane rows.  EARLY (write-through
+  // launches of up to kAgents2EarlyMaxEnvs envs): NOW, before the rewards are worked out -- write-through stores are acknowledged
+  // only by memory (~800 cycles) and the wave cannot end before they are; issued here their round trip overlaps the ~1000 cycles
+  // of reward / reset work, issued last the wave sat waiting for it (marked build: 839 cycles from 'stores issued' to 'drained').
+  // Envs that reset in this tick get their rows written once more below, with the observation of the reset state (same lanes, same
+  // addresses, program order).  With more waves per SIMD the wait is hidden anyway and the early stores only get in the way
+  // (32768 envs: +2 %), hence the bound (profiles/r03_early_wt_stores.txt).
+  auto emit_obs = [&](const V4 (&o)[NH]) {
+    fill_tile(o);
+    constexpr int STEPS = (EPW * VPE + 63) / 64;
+    V4 row[STEPS];
+#pragma unroll
+    for (int q = 0; q < STEPS; ++q) row[q] = lds4[(q * 64 + lane) < EPW * VPE ? q * 64 + lane : 0];
+#pragma unroll
+    for (int q = 0; q < STEPS; ++q) {
+      const int f = q * 64 + lane;
+      if (f < nvec) store_obs_vec<SP>(at32<V4>(p.obs_others, (e0 * VPE + f) * (uint32_t)sizeof(V4)), row[q]);
+    }
+    wave_lds_sync();   // the tile may be refilled (terminal capture, a second emit)
+  };
+  if constexpr (EARLY) emit_obs(oj);
+  // ... and the agent's state / goals (the slot copy of a live rollout is a write-through store as well), for the same reason
+  auto emit_state = [&](bool fresh_goals) {
+    if (mine) {
+      *at32<V4>(p.state_out, (row_i + e) * (uint32_t)sizeof(V4)) = si;
+      if (p.goals_out != p.goals_in || fresh_goals) *at32<V2>(p.goals_out, (row_i + e) * (uint32_t)sizeof(V2)) = gl;
+      if constexpr (LIVE) {
+        store_obs_vec<SP>(at32<V4>(p.state_copy, (row_i + e) * (uint32_t)sizeof(V4)), si);
+        *at32<V2>(p.goals_copy, (row_i + e) * (uint32_t)sizeof(V2)) = gl;
+      }
+    }
+  };
+  if constexpr (EARLY) emit_state(false);
+  CM3_SPAN_MARK(3, false);  // integrated, post-step states exchanged (EARLY: state + observation stores issued)
   // ---- reward / reached / collisions (multi-goal_spread.py:114-143) -----------------------------------------------------------------
   R rew;
   bool reached;
@@ -1471,31 +1510,18 @@ __global__ void __launch_bounds__(WAVES * 64)
         was_reset = true;
       }
       gather(oj);  // fresh episodes: the observation is that of the reset state
+      if constexpr (EARLY) {
+        emit_obs(oj);
+        if (was_reset) emit_state(true);
+      }
     }
   }
   CM3_SPAN_MARK(5, false);  // reset handled
-  // ---- per-tick stores ---------------------------------------------------------------------------------------------------------------
-  if (mine) {
-    *at32<V4>(p.state_out, (row_i + e) * (uint32_t)sizeof(V4)) = si;
-    if (p.goals_out != p.goals_in || was_reset) *at32<V2>(p.goals_out, (row_i + e) * (uint32_t)sizeof(V2)) = gl;
-    if constexpr (LIVE) {
-      store_obs_vec<SP>(at32<V4>(p.state_copy, (row_i + e) * (uint32_t)sizeof(V4)), si);
-      *at32<V2>(p.goals_copy, (row_i + e) * (uint32_t)sizeof(V2)) = gl;
-    }
+  if constexpr (!EARLY) {  // the usual place: last
+    emit_state(was_reset);
+    emit_obs(oj);
   }
-  {  // observation (multi-goal_spread.py:145-154): the tile goes out as contiguous 16-byte-per-lane rows
-    fill_tile(oj);
-    constexpr int STEPS = (EPW * VPE + 63) / 64;
-    V4 row[STEPS];
-#pragma unroll
-    for (int q = 0; q < STEPS; ++q) row[q] = lds4[(q * 64 + lane) < EPW * VPE ? q * 64 + lane : 0];
-#pragma unroll
-    for (int q = 0; q < STEPS; ++q) {
-      const int f = q * 64 + lane;
-      if (f < nvec) store_obs_vec<SP>(at32<V4>(p.obs_others, (e0 * VPE + f) * (uint32_t)sizeof(V4)), row[q]);
-    }
-  }
-  CM3_SPAN_MARK(6, false);  // state + observation stores issued
+  CM3_SPAN_MARK(6, false);  // (the state and the observation went out right after the step, see emit_obs / emit_state)
   if (head) {
     int2 m;
     m.x = steps;
@@ -1733,12 +1759,15 @@ template <typename R, int N, int WAVES> static int launch_agents(const ParticleP
   hipLaunchKernelGGL((k_particle_step_agents2<WAVES, __VA_ARGS__>), dim3(blocks2), dim3(WAVES * 64), 0, stream, p.state_in,  \
                      p.goals_in, p.meta_in, (const int32_t *)p.episode, p.E, p.flags | xf2, p.E0, p.EN, p.max_steps,         \
                      (const int32_t *)p.actions, p)
+        const bool early = wt && (size_t)(p.EN - p.E0) <= kAgents2EarlyMaxEnvs;
         if (live) {
-          if (wt) CM3_LAUNCH_AGENTS2(kWt, true);
+          if (early) CM3_LAUNCH_AGENTS2(kWt, true, true);
+          else if (wt) CM3_LAUNCH_AGENTS2(kWt, true);
           else if (nt) CM3_LAUNCH_AGENTS2(kNt, true);
           else CM3_LAUNCH_AGENTS2(kSpPlain, true);
         } else {
-          if (wt) CM3_LAUNCH_AGENTS2(kWt);
+          if (early) CM3_LAUNCH_AGENTS2(kWt, false, true);
+          else if (wt) CM3_LAUNCH_AGENTS2(kWt);
           else if (nt) CM3_LAUNCH_AGENTS2(kNt);
           else CM3_LAUNCH_AGENTS2(kSpPlain);
         }
