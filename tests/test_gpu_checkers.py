@@ -54,10 +54,12 @@ def test_bit_exact_vs_reference_golden(name, padded):
 
 
 @pytest.mark.parametrize("cfg_name,E,lo,hi", [("checkers_stage2.json", 8192, 0, 5), ("checkers_stage2.json", 1000, -1, 7),
-                                              ("checkers_stage1.json", 4096 + 13, 0, 5), ("checkers_stage1.json", 1, 0, 5)])
+                                              ("checkers_stage1.json", 4096 + 13, 0, 5), ("checkers_stage1.json", 1, 0, 5),
+                                              ("checkers_stage2.json", 10007, 0, 5)])   # 313 workgroups: XCD 256-tiles, ragged
 @pytest.mark.parametrize("padded", [True, False])
 def test_bit_exact_vs_oracle_full_episodes(cfg_name, E, lo, hi, padded):
-    """BASELINE C3 (N=2, E=8192) and ragged sizes: 33 free-running ticks, 100 % of ticks compared."""
+    """BASELINE C3 (N=2, E=8192) and ragged sizes (32 envs per workgroup: 1000 -> plain block order, 4109 / 8192 -> eighths, 10007 ->
+    tiles of 256 with idle logical blocks; csrc/common.h): 33 free-running ticks, 100 % of ticks compared."""
     cfg = load_cfg(cfg_name)
     N = cfg["n_agents"]
     i = cfg["init"]

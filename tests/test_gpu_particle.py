@@ -461,6 +461,35 @@ def test_both_kernel_mappings_agree_bitwise(N, cfg_name, dtype, other):
     assert torch.equal(a.terminal_obs_others, b.terminal_obs_others)
 
 
+@pytest.mark.parametrize("N,cfg_name,E,other", [
+    (8, "particle_merge8.json", 5003, "agent"),    # two lanes per agent: 313 workgroups -> 256-tiles, 199 idle logical blocks
+    (8, "particle_merge8.json", 2051, "agent"),    # 129 workgroups -> eighths (G = 17), ragged last block
+    (8, "particle_merge8.json", 3001, "pair"),     # one env per wave: 751 workgroups -> tiles, ragged
+    (4, "particle_stage2_cross.json", 5121, "pair"),    # 257 workgroups: one block into the second tile
+    (4, "particle_stage2_cross.json", 1270, "pair"),    # 64 workgroups: the smallest launch that takes the XCD order
+    (5, "particle_merge8.json", 20011, "agent"),   # one lane per agent, 8 lanes per env: tiles, ragged
+])
+def test_xcd_block_order_covers_ragged_batches(N, cfg_name, E, other):
+    """The XCD-aware block order (csrc/common.h: plain below 64 workgroups, eighths up to 256, tiles of 256 above; grids rounded up,
+    logical blocks beyond the batch idle) must cover every env exactly once whatever the batch size: batches chosen at the edges
+    of the three modes, stepped 12 ticks with in-kernel actions and auto-reset, against the lane-per-env kernel (plain order)."""
+    cfg = load_cfg(cfg_name)
+    a = _env(cfg, N, E, seed=5, auto_reset=True, max_steps=5, kernel="env")
+    b = _env(cfg, N, E, seed=5, auto_reset=True, max_steps=5, kernel=other)
+    a.enable_terminal_capture()
+    b.enable_terminal_capture()
+    a.reset()
+    b.reset()
+    for t in range(12):
+        ra, rb = a.step(), b.step()
+        for x, y in zip(ra, rb):
+            assert torch.equal(x, y), t
+        assert torch.equal(a.last_actions, b.last_actions)
+        assert torch.equal(a.collisions, b.collisions) and torch.equal(a.steps, b.steps) and torch.equal(a.episode, b.episode)
+    assert torch.equal(a.terminal_state, b.terminal_state) and torch.equal(a.terminal_obs_others, b.terminal_obs_others)
+    assert int(a.episode.min()) >= 2           # every env went through resets: none was skipped
+
+
 @pytest.mark.parametrize("N", [1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("kernel", KERNELS)
 def test_f64_free_running_random_configs_all_agent_counts(N, kernel):
