@@ -726,9 +726,10 @@ class CheckersRollout(object):
         _copy_pairs([(s["grid_raw"], self._grid_raw[T]), (s["obs_self_t_raw"], self._obst_raw[T]), (s["vec"], self.vec[T]),
                      (s["obs_others"], self.obs_others[T]), (s["obs_self_v"], self.obs_self_v[T]),
                      (s["actions"], self.actions[T - 1])], env._stream())
-        # actions_prev of the next collect()'s first transition: the last actions, zeros where that tick ended an episode
-        keep = (self.done[self.T - 1] == 0).unsqueeze(1)
-        self._next_prev0 = torch.where(keep, self.actions[self.T - 1], torch.zeros_like(self.actions[0]))
+        # actions_prev of the next collect()'s first transition (the last actions, zeros where that tick ended an episode) is worked
+        # out by the next collect() that continues without a reset -- from done / actions of this rollout, which it has not yet
+        # overwritten by then; a collector that resets every time (episode-synchronous envs) never pays those launches
+        self._next_prev0 = None
 
     def collect(self, goals=None, policy=None, epsilon=0.0, reset=None):
         """goals: one-hot [N,2] / [E,N,2] (train_onpolicy.py:287-293); needed whenever the env is reset.
@@ -745,6 +746,9 @@ class CheckersRollout(object):
             env.reset(goals)
             self.prev0.zero_()
         elif self._started:
+            if self._next_prev0 is None:
+                keep = (self.done[self.T - 1] == 0).unsqueeze(1)
+                self._next_prev0 = torch.where(keep, self.actions[self.T - 1], torch.zeros_like(self.actions[0]))
             self.prev0.copy_(self._next_prev0)
         self._started = True
         self._load_slot0()
