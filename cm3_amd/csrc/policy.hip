@@ -173,6 +173,15 @@ template <int N, int BF16> __global__ void __launch_bounds__(256) k_policy_rollo
       r4 &= dpp_i32<kDppXor1>(r4);
       r4 &= dpp_i32<kDppXor2>(r4);
       all_reached = r4 != 0;
+    } else if constexpr (N == 8) {  // an env is half a DPP row: sums over its 8 lanes by xor 1, xor 2, half mirror (lane i <-> 7 - i)
+      hit_sum = hits + dpp_i32<kDppXor1>(hits);
+      hit_sum += dpp_i32<kDppXor2>(hit_sum);
+      hit_sum += dpp_i32<kDppHalfMirror>(hit_sum);
+      int r8 = (int)reached;
+      r8 &= dpp_i32<kDppXor1>(r8);
+      r8 &= dpp_i32<kDppXor2>(r8);
+      r8 &= dpp_i32<kDppHalfMirror>(r8);
+      all_reached = r8 != 0;
     } else {
 #pragma unroll
       for (int a = 0; a < N; ++a) {  // per-env reductions over the N part-0 lanes of this env
@@ -182,7 +191,16 @@ template <int N, int BF16> __global__ void __launch_bounds__(256) k_policy_rollo
       }
     }
     collisions += hit_sum;
-    const float reward = sum_agents<float, N>(rews);
+    float reward;
+    if constexpr (N == 8) {
+      // NumPy's pairwise tree for 8 values, ((v0+v1)+(v2+v3)) + ((v4+v5)+(v6+v7)) (sum_agents), by the same three DPP steps: every
+      // partial sum meets its partner with the operands possibly swapped, and float addition is commutative bit for bit
+      float tsum = rew + dpp_f32<kDppXor1>(rew);
+      tsum = tsum + dpp_f32<kDppXor2>(tsum);
+      reward = tsum + dpp_f32<kDppHalfMirror>(tsum);
+    } else {
+      reward = sum_agents<float, N>(rews);
+    }
     const bool done = (steps == p.max_steps) || all_reached;
     if (writer) reinterpret_cast<float *>(tick_ptr(p.reward_n, p.st_reward_n, t))[r] = rew;
     if (head_lane) {
