@@ -471,15 +471,21 @@ def pmc_traffic(tag):
     return rec["hbm_bytes_per_launch"], rec
 
 
+SPAN_FILE = "r04_kernel_span.json"
+
+
 def span_record(tag):
-    """The undisturbed kernel-duration record of this workload (profiles/r03_kernel_span.json, written by tools/kernel_span.py
+    """The undisturbed kernel-duration record of this workload (profiles/r0N_kernel_span.json, written by tools/kernel_span.py
     from the two-stamp build on an UNPROFILED 330-launch hipGraph): per-launch span (first wave in -> last wave out) and
     start-to-start; None if absent.  rocprofv3's kernel-trace average is not used for this: it exceeds the unprofiled time per
     launch (the profiler stretches every dispatch of a launch-bound graph)."""
-    path = os.path.join(ROOT, "profiles", "r03_kernel_span.json")
-    if not os.path.exists(path):
-        return None
-    return json.load(open(path)).get(tag)
+    global SPAN_FILE
+    for name in ("r04_kernel_span.json", "r03_kernel_span.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            SPAN_FILE = name
+            return json.load(open(path)).get(tag)
+    return None
 
 
 def _free_port():
@@ -521,6 +527,96 @@ def pin_rank_to_gpu_numa_node(device_index):
         return "%s: NUMA node %d, %d CPUs" % (bdf, node, len(cpus))
     except Exception as exc:
         return "not pinned (%s)" % type(exc).__name__
+
+
+def measure_other_config(name, args, device, steps=6, cpu_budget_s=6.0):
+    """One of the OTHER BASELINE workloads (c3 / c5 / c4), timed inside the default `bench.py --gpus 1` run exactly like the
+    headline -- the product's own collector in trajectory mode, one step launch per tick, hipGraph replays, wall clock between
+    two device synchronisations with the HIP-event time of the same region beside it -- so that the driver's record carries a
+    driver-timed number for every BASELINE config, each with its own roofline (algorithmic bytes per launch / time per launch
+    against 8 TB/s) and the citations of its committed kernel-span / PMC records.  c3 also times the scalar dense NumPy port
+    of env/checkers.py:228-262 on one host core (cpu_baseline_checkers)."""
+    import torch
+    import cm3_amd
+    kind, cfg_name, E, wl_desc = WORKLOADS[name]
+    cfg = cm3_amd.load_config(cfg_name)
+    N = cfg["n_agents"]
+    a2 = argparse.Namespace(**vars(args))
+    a2.mode, a2.fused, a2.no_graph, a2.kernel, a2.workload = "trajectory", False, False, "auto", name
+    st, tps, bps, dtype_name, mode = build_headline(a2, kind, cfg, N, E, device, 0, 1)
+    if kind == "particle_adv":
+        steps = steps * 10                      # a c4 step is one 33-tick rollout: time as many ticks as the others
+    K = steps * tps
+    st.run(2 * tps)
+    torch.cuda.synchronize(device)
+    stream = torch.cuda.current_stream(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record(stream)
+    st.run(K)
+    e1.record(stream)
+    torch.cuda.synchronize(device)
+    wall = time.perf_counter() - t0
+    ev_s = e0.elapsed_time(e1) * 1e-3
+    launch_s = wall / K
+    bytes_per_launch = float(bps) * E
+    achieved = bytes_per_launch / launch_s / 1e9
+    live = bool(getattr(getattr(st, "ro", None), "_live", False))
+    st.close()
+    del st
+    torch.cuda.empty_cache()
+    kname = {"c3": "k_checkers_step_fast<2,false,true,8>", "c5": "k_particle_step_agents2<4,wt,live,early>",
+             "c4": "k_particle_step_pairs<float,4,4,false,plain> (+ k_returns_partials_keep + k_fold_normalize per rollout)"}[name]
+    rec = {
+        "workload": "%s, %d vectorised envs, max_steps=33, auto-reset, trajectory mode incl. terminal capture, one step-kernel "
+                    "launch per tick, %s" % (wl_desc, E, "one hipGraph replay per 33-tick rollout + advantage normalisation"
+                                             if kind == "particle_adv" else "hipGraph of %d ticks per replay" % tps),
+        "envs_per_gpu": E, "n_agents": N, "dtype": dtype_name, "steps": steps, "ticks_per_step": tps, "ticks_timed": K,
+        "ms_per_step": wall / steps * 1e3, "us_per_tick": launch_s * 1e6, "env_steps_per_s": E / launch_s, "live_state": live,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                     "traffic": None, "kernel": kname, "algorithmic_bytes_per_launch": bytes_per_launch,
+                     "avg_launch_us": launch_s * 1e6, "avg_launch_us_hip_events": ev_s / K * 1e6,
+                     "clock": "wall clock between two device synchronisations (the headline's clock); c4: the two launches of "
+                              "the advantage step and the replay boundary are inside the time, the bytes count the step launches only"},
+    }
+    tag = {"c3": "c3_trajectory_n2_e8192", "c5": "c5_trajectory_n8_e8192"}.get(name)
+    if tag:
+        traffic, trec = pmc_traffic(tag)
+        if traffic is not None:
+            rec["roofline"]["traffic"] = traffic
+            rec["roofline"]["traffic_source"] = "profiles/pmc_traffic.json: %s (committed rocprofv3 --pmc passes of this workload)" % tag
+    sp = span_record("c4_rollout" if name == "c4" else "%s_trajectory" % name)
+    if sp:
+        rec["roofline"]["kernel_span"] = {"span_us": sp["span_us_mean"], "start_to_start_us": sp["start_to_start_us_mean"],
+                                          "gap_us": sp["gap_us_mean"], "source": "profiles/%s (two-stamp build, unprofiled)" % SPAN_FILE}
+    if name == "c3" and not args.no_cpu_baseline:
+        rec["cpu_baseline_checkers"] = cpu_baseline_checkers(cfg, budget_s=cpu_budget_s)
+    return rec
+
+
+def rccl_report(dist, torch, device, local_rank, world):
+    """What the first multi-GPU record should answer by itself: did RCCL see `world` ranks, does a collective over them give
+    the right answer, and which peers can every rank's GPU reach directly (P2P over xGMI)."""
+    rep = {"rccl_world_size": dist.get_world_size(), "backend": dist.get_backend()}
+    try:
+        rep["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+    except Exception as exc:
+        rep["rccl_version"] = "unknown (%s)" % type(exc).__name__
+    probe = torch.full((1,), float(dist.get_rank() + 1), dtype=torch.float64, device=device)
+    dist.all_reduce(probe)
+    rep["all_reduce_sum_of_rank_plus_1"] = float(probe[0])
+    rep["all_reduce_ok"] = float(probe[0]) == world * (world + 1) / 2.0
+    n_dev = torch.cuda.device_count()
+    mine = torch.zeros(8, dtype=torch.int32, device=device)
+    for j in range(min(n_dev, 8)):
+        ok = 1 if j == local_rank else int(torch.cuda.can_device_access_peer(local_rank, j))
+        mine[j] = ok
+    allp = torch.empty(world * 8, dtype=torch.int32, device=device)
+    dist.all_gather_into_tensor(allp, mine)
+    rep["p2p_access"] = [{"rank": r, "visible_devices": n_dev, "can_access_peer": row[:min(n_dev, 8)]}
+                         for r, row in enumerate(allp.view(world, 8).cpu().tolist())]
+    rep["p2p_all_pairs"] = all(all(row["can_access_peer"][:world]) for row in rep["p2p_access"]) if n_dev >= world else False
+    return rep
 
 
 def build_headline(args, kind, cfg, N, E, device, rank, n_chains):
@@ -574,6 +670,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-sweep", action="store_true", help="skip the E-sweep (extra 'sweep' field)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short c3 / c5 / c4 runs that the default c2 line carries as 'other_configs'")
     ap.add_argument("--no-extras", action="store_true",
                     help="headline only: skip the in-place / chains / fused / policy-rollout / launch-floor extras (clean profiles)")
     ap.add_argument("--fused", action="store_true",
@@ -656,6 +754,7 @@ def main():
         per_rank = gathered.view(world, 2).cpu().tolist()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall_max, ev_max = float(t[0]), float(t[1])
+    rccl = rccl_report(dist, torch, device, local_rank, world) if use_dist else None    # (every rank takes part; rank 0 prints it)
 
     total_env_steps = float(E) * K * world
     value = total_env_steps / wall_max                       # ONE clock for the metric and the roofline: the wall clock
@@ -709,6 +808,9 @@ def main():
                          for r, (w_, e_) in enumerate(per_rank)],
             "rank0_host_affinity": pinned,
         }
+        if rccl is not None:
+            out["rccl"] = rccl
+            out["rccl_world_size"] = rccl["rccl_world_size"]
         if kind == "particle_adv":
             out["collective"] = {
                 "what": "all_gather_into_tensor of 3 float64 per rank (advantage moments), once per rollout",
@@ -734,7 +836,7 @@ def main():
                 "span_us": rec["span_us_mean"], "start_to_start_us": rec["start_to_start_us_mean"], "gap_us": rec["gap_us_mean"],
                 "achieved_GBps_over_span": bytes_per_launch / (rec["span_us_mean"] * 1e-6) / 1e9,
                 "frac_of_peak_over_span": bytes_per_launch / (rec["span_us_mean"] * 1e-6) / 1e9 / HBM_PEAK_GBPS,
-                "source": "profiles/r03_kernel_span.json (tools/kernel_span.py, two-stamp build, unprofiled 330-launch hipGraph): "
+                "source": "profiles/" + SPAN_FILE + " (tools/kernel_span.py, two-stamp build, unprofiled 330-launch hipGraph): "
                           "span = first wave in -> last wave out; start-to-start includes the dependent-launch boundary and is "
                           "what roofline.avg_launch_us of THIS run measures live"}
     extras = world == 1 and rank == 0 and not args.no_extras and not args.fused
@@ -943,6 +1045,18 @@ def main():
                        "counted for the network itself against the float32 matrix-core peak, zero padding of the MFMA tiles "
                        "excluded) + reset + step per tick with full trajectory storage (tests/test_gpu_actor_checkers.py)")
         out["policy_rollout"] = pol
+    if world == 1 and rank == 0 and args.workload == "c2" and mode == "trajectory" and not args.no_other_configs \
+            and not args.no_extras and not args.fused and n_chains == 1 and not args.envs_per_gpu:
+        # the other BASELINE workloads, driver-timed in the same run (each a short run of ITS configuration; the headline stays c2)
+        if stepper is not None:
+            stepper.close()
+            del stepper
+            stepper = None
+            torch.cuda.empty_cache()
+        out["other_configs"] = {name: measure_other_config(name, args, device) for name in ("c3", "c5", "c4")}
+        out["other_configs"]["note"] = ("each: the workload's own BASELINE configuration through the product's collector, >= 6 hipGraph "
+                                        "replays after 2 warm-up ones, same clock as the headline; `python bench.py --workload cN` "
+                                        "runs the long form with its extras")
     if world == 1 and rank == 0:
         bw_read, bw_copy = measure_bandwidth(device)
         out["roofline"]["measured_read_GBps"] = bw_read
@@ -995,15 +1109,19 @@ def main():
                 # SURVEY.md section 8(d) "Extra sweep": the same kernels (a) streaming into a trajectory (every tick its own
                 # slot: nothing is re-used, non-temporal / write-through stores), (b) reading policy-provided actions instead of
                 # drawing them, (c) launched eagerly instead of as a hipGraph
-                for log2e in (12, 16, 18, 20):
+                for log2e in (12, 16, 18, 20, 22):
                     Es = 1 << log2e
                     T = EP_TICKS
+                    slot_bytes = lambda T_: ((T_ + 1) * Es * (16 * N + 8 * N + 16 * N * max(N - 1, 1)) + T_ * Es * (8 * N + 9) +  # noqa: E731
+                                             T_ * Es * (16 * N + 16 * N * max(N - 1, 1) + 4))
+                    free_b = torch.cuda.mem_get_info(device)[0]
+                    while T > 4 and slot_bytes(T) > 0.6 * free_b:      # 2^22 envs x 33 ticks = 83 GB of slots: fits 288 GB
+                        T //= 2
                     st = TrajectoryStepper(cfg, N, Es, device, kernel=args.kernel, phase_ticks=T)
-                    slots = (T + 1) * Es * (16 * N + 8 * N + 16 * N * max(N - 1, 1)) + T * Es * (8 * N + 9) + \
-                        T * Es * (16 * N + 16 * N * max(N - 1, 1) + 4)
+                    slots = slot_bytes(T)
                     point(Es, "trajectory", st, T * (10 if log2e <= 16 else 3), slots,
-                          "trajectory mode: slots t -> t+1 of a [34, E, ...] device trajectory incl. terminal capture, one hipGraph "
-                          "replay per 33-tick collect")
+                          "trajectory mode: slots t -> t+1 of a [%d, E, ...] device trajectory incl. terminal capture, one hipGraph "
+                          "replay per %d-tick collect" % (T + 1, T))
                 for log2e in (12, 16, 20):
                     Es = 1 << log2e
                     st = ParticleStepper(cfg, N, Es, device, kernel=args.kernel, tensor_actions=True)

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # CM3_AMD_LIB: load another build of the SAME ABI instead (tools/*_ab.py compare two builds on one box)
 LIB_PATH = os.environ.get("CM3_AMD_LIB") or os.path.join(_HERE, "libcm3_hip.so")
 MAX_AGENTS = 8
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 FLAG_AUTO_RESET = 1
 FLAG_GEN_ACTIONS = 2
@@ -137,6 +137,7 @@ SYMBOLS = {
     "cm3_abi_version": (ctypes.c_int, []),
     "cm3_source_id": (ctypes.c_char_p, []),
     "cm3_last_error": (ctypes.c_char_p, []),
+    "cm3_last_kernel_variant": (ctypes.c_char_p, []),
     "cm3_device_count": (ctypes.c_int, []),
     "cm3_device_name": (ctypes.c_int, [ctypes.c_int, ctypes.c_char_p, ctypes.c_int]),
     "cm3_particle_step_f32": (ctypes.c_int, [P(ParticleDesc), P(ParticleBufs), c_void_p]),
@@ -247,6 +248,11 @@ def source_id():
         with open(f, "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
+
+
+def last_kernel_variant():
+    """The kernel instantiation the most recent env call of this thread launched (cm3_last_kernel_variant): a debug / test query."""
+    return lib().cm3_last_kernel_variant().decode()
 
 
 def check(rc):

@@ -9,7 +9,8 @@ OUT="${CM3_OUT:-${OUT}}"
 mkdir -p "${HERE}/_obj"
 # identity of the sources this library is built from (cm3_source_id(); cm3_amd/_lib.py refuses a library whose id differs from
 # the sources next to it: a test run against a stale build proves nothing)
-SRC_ID="$(cat $(ls "${HERE}"/*.hip "${HERE}"/*.h | LC_ALL=C sort) "${HERE}/../../include/cm3_amd.h" | sha256sum | cut -c1-16)"
+# (names in byte order, as _lib.source_id() sorts them; quoted throughout: a checkout path may contain blanks)
+SRC_ID="$(cd "${HERE}" && { for f in $(LC_ALL=C ls *.hip *.h | LC_ALL=C sort); do cat "./${f}"; done; cat "../../include/cm3_amd.h"; } | sha256sum | cut -c1-16)"
 pids=()
 "${HIPCC}" ${FLAGS} -mllvm -amdgpu-kernarg-preload-count=16 -DCM3_PARTICLE_F32 -c "${HERE}/particle.hip" -o "${HERE}/_obj/particle_f32.o" &
 pids+=($!)

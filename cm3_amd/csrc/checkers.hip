@@ -1285,6 +1285,8 @@ template <int N> static int ck_launch(const CheckersParams &p, bool step, hipStr
   hipLaunchKernelGGL((k_checkers_step_fast<N, __VA_ARGS__>), dim3(fblocks), dim3(256), 0, stream, (const uint64_t *)p.mask,    \
                      (const uint32_t *)p.agents, (const int32_t *)p.steps, (const int32_t *)p.episode, (const uint8_t *)p.goals, \
                      p.E, p.flags | xf, p)
+    note_variant(step ? "k_checkers_step_fast" : "k_checkers_reset_fast", 0, N, 4, step && p.n_ticks > 1, step && nt ? 1 : 0, 0, 0, 0,
+                 step ? (nt ? kCkGStream : kCkG) : 0);
     if (step && p.n_ticks > 1) {
       if (nt) CM3_LAUNCH_CKF(true, true, kCkGStream);
       else CM3_LAUNCH_CKF(true);
@@ -1298,6 +1300,7 @@ template <int N> static int ck_launch(const CheckersParams &p, bool step, hipStr
     return CM3_OK;
   }
   const unsigned blocks = (unsigned)(((size_t)p.E + 63) / 64);
+  note_variant(step ? "k_checkers_step" : "k_checkers_reset", 0, N, 1, 0, 0, 0, 0);
   if (step)
     hipLaunchKernelGGL((k_checkers_step<N>), dim3(blocks), dim3(64), 0, stream, p);
   else

@@ -132,6 +132,31 @@ template <typename T> __device__ __forceinline__ T *at32(const void *base, uint3
 char *last_error_buf();  // thread-local, 512 bytes
 int fail(int code, const char *fmt, ...);
 
+// ---- which instantiation ran (cm3_last_kernel_variant; tests/test_gpu_dispatch_sizes.py) ------
+// The launchers of the env kernels choose among size-gated builds of one template (mapping, waves per workgroup, store policy,
+// live-state, the max-ILP translation unit ...).  Every launcher records its choice in a thread-local POD -- a handful of host
+// stores per launch, formatted only when asked for -- so that a test can assert WHICH build it just checked.
+struct KernelVariant {
+  const char *kernel;  // template name
+  int real_bytes;      // 4 / 8 (0: not a template parameter)
+  int n, waves, fused, sp, live, tu, early, g;
+};
+KernelVariant &last_variant();  // thread-local (util.hip)
+static inline void note_variant(const char *kernel, int real_bytes, int n, int waves, int fused, int sp, int live, int tu,
+                                int early = 0, int g = 0) {
+  KernelVariant &v = last_variant();
+  v.kernel = kernel;
+  v.real_bytes = real_bytes;
+  v.n = n;
+  v.waves = waves;
+  v.fused = fused;
+  v.sp = sp;
+  v.live = live;
+  v.tu = tu;
+  v.early = early;
+  v.g = g;
+}
+
 #define CM3_HIP_CHECK(expr)                                                                  \
   do {                                                                                       \
     hipError_t _e = (expr);                                                                  \

@@ -1672,6 +1672,8 @@ static int launch_one(const ParticleParams &p, ParticleOp op, hipStream_t stream
       const bool nt = sizeof(R) == 4 && (p.flags & kFlagObsStoreNt);   // streaming-size trajectory (obs_store_nt)
       // a launch that writes >= kWtMinObsBytes of observation rows writes them through (kSpWt; per-tick launches only)
       const bool wt = sizeof(R) == 4 && (size_t)(p.EN - p.E0) * ObsGeom<R, N>::REC * sizeof(R) >= kWtMinObsBytes && !p.state_copy;
+      note_variant("k_particle_step", (int)sizeof(R), N, WAVES, p.n_ticks > 1,
+                   p.n_ticks > 1 ? (nt ? kNt : kSpPlain) : (wt ? kWt : (nt ? kNt : kSpPlain)), 0, CM3_PARTICLE_TU);
       if (p.n_ticks > 1) {
         if (nt) hipLaunchKernelGGL((k_particle_step<R, N, WAVES, true, kNt>), dim3(blocks), dim3(per_block), 0, stream, p);
         else hipLaunchKernelGGL((k_particle_step<R, N, WAVES, true>), dim3(blocks), dim3(per_block), 0, stream, p);
@@ -1683,9 +1685,11 @@ static int launch_one(const ParticleParams &p, ParticleOp op, hipStream_t stream
       break;
     }
     case kReset:
+      note_variant("k_particle_reset", (int)sizeof(R), N, WAVES, 0, kSpPlain, 0, CM3_PARTICLE_TU);
       hipLaunchKernelGGL((k_particle_reset<R, N, WAVES>), dim3(blocks), dim3(per_block), 0, stream, p);
       break;
     case kObserve:
+      note_variant("k_particle_observe", (int)sizeof(R), N, WAVES, 0, kSpPlain, 0, CM3_PARTICLE_TU);
       hipLaunchKernelGGL((k_particle_observe<R, N, WAVES>), dim3(blocks), dim3(per_block), 0, stream, p);
       break;
   }
@@ -1710,6 +1714,8 @@ template <typename R, int N, int WAVES> static int launch_pairs(const ParticlePa
       return fail(CM3_ERR_INVALID, "the lane-per-pair kernel addresses at most 4 GiB per array: %d envs x %d agents is too large "
                   "(use the default kernel choice)", p.E, N);
     const bool live = p.state_copy != nullptr;   // cm3_particle_traj.state_live (per-tick launches only)
+    note_variant("k_particle_step_pairs", (int)sizeof(R), N, WAVES, p.n_ticks > 1, nt ? kF32 : kSpPlain, p.n_ticks == 1 && live,
+                 CM3_PARTICLE_TU);
     if (p.n_ticks > 1) {
       if (nt) CM3_LAUNCH_PAIRS(true, kF32);
       else CM3_LAUNCH_PAIRS(true, kSpPlain);
@@ -1760,6 +1766,7 @@ template <typename R, int N, int WAVES> static int launch_agents(const ParticleP
                      p.goals_in, p.meta_in, (const int32_t *)p.episode, p.E, p.flags | xf2, p.E0, p.EN, p.max_steps,         \
                      (const int32_t *)p.actions, p)
         const bool early = wt && (size_t)(p.EN - p.E0) <= kAgents2EarlyMaxEnvs;
+        note_variant("k_particle_step_agents2", 4, 8, WAVES, 0, wt ? kWt : (nt ? kNt : kSpPlain), live, CM3_PARTICLE_TU, early);
         if (live) {
           if (early) CM3_LAUNCH_AGENTS2(kWt, true, true);
           else if (wt) CM3_LAUNCH_AGENTS2(kWt, true);
@@ -1776,6 +1783,8 @@ template <typename R, int N, int WAVES> static int launch_agents(const ParticleP
         return CM3_OK;
       }
     }
+    note_variant("k_particle_step_agents", (int)sizeof(R), N, WAVES, p.n_ticks > 1,
+                 p.n_ticks > 1 ? (nt ? kNt : kSpPlain) : (wt ? kWt : (nt ? kNt : kSpPlain)), p.n_ticks == 1 && live, CM3_PARTICLE_TU);
     if (p.n_ticks > 1) {
       if (nt) CM3_LAUNCH_AGENTS(true, kNt);
       else CM3_LAUNCH_AGENTS(true, kSpPlain);

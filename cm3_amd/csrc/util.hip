@@ -10,6 +10,11 @@ char *last_error_buf() {
   return buf;
 }
 
+KernelVariant &last_variant() {
+  static thread_local KernelVariant v = {"none", 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  return v;
+}
+
 int fail(int code, const char *fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -156,6 +161,16 @@ int cm3_abi_version(void) { return CM3_ABI_VERSION; }
 const char *cm3_source_id(void) { return CM3_SOURCE_ID; }
 
 const char *cm3_last_error(void) { return cm3::last_error_buf(); }
+
+const char *cm3_last_kernel_variant(void) {
+  static thread_local char buf[160];
+  const cm3::KernelVariant &v = cm3::last_variant();
+  static const char *const sp[] = {"plain", "nt", "wt"};
+  snprintf(buf, sizeof(buf), "%s<%s,N=%d,waves=%d,fused=%d,sp=%s,live=%d,early=%d,g=%d,tu=%s>", v.kernel,
+           v.real_bytes == 4 ? "f32" : (v.real_bytes == 8 ? "f64" : "-"), v.n, v.waves, v.fused, sp[v.sp >= 0 && v.sp <= 2 ? v.sp : 0],
+           v.live, v.early, v.g, v.tu ? "ilp" : "default");
+  return buf;
+}
 
 int cm3_device_count(void) {
   int n = 0;

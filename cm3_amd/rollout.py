@@ -65,15 +65,19 @@ def _pairs_aligned(pairs):
 
 
 def _copy_pairs(pairs, stream):
-    """(dst, src) tensor pairs: ONE cm3_copy_list launch per 8 regions when every region is 16-byte sized / aligned,
-    torch copies (on torch's current stream) otherwise."""
+    """(dst, src) tensor pairs ON `stream`: ONE cm3_copy_list launch per 8 regions when every region is 16-byte sized /
+    aligned, torch copies otherwise -- issued on `stream` too (an ExternalStream context), so that they are ordered with the
+    launches around them and, while `stream` is being captured into a hipGraph, become nodes of that graph instead of
+    running once, unordered, at capture time."""
     ok = _pairs_aligned(pairs)
     if ok:
         for k in range(0, len(pairs), 8):
             _lib.copy_list(pairs[k:k + 8], stream)
     else:
-        for d, s_ in pairs:
-            d.copy_(s_)
+        dev = pairs[0][0].device
+        with torch.cuda.stream(torch.cuda.ExternalStream(int(stream), device=dev)):
+            for d, s_ in pairs:
+                d.copy_(s_)
 
 
 class _ActorGraphCache(object):
@@ -344,8 +348,11 @@ class ParticleRollout(object):
                                                         and not self.fused_policy_tick))
         live = self._live = (self.goals is not None and small and not self.fused and not policy_episode
                              and not (self.fused_policy_tick and policy is not None))
-        if live and self._live_cur != env._cur:    # captured graphs hold the live buffer's address
-            self._drop_graphs()
+        if self._live_cur != env._cur:    # captured graphs may hold the address of the env's current buffers (env.step() flips them)
+            if live:
+                self._drop_graphs()
+            else:
+                self._drop_norm_graph()   # (collect()'s own non-live graphs touch trajectory slots and un-flipped buffers only)
             self._live_cur = env._cur
         if policy is None:
             flags = base | FLAG_GEN_ACTIONS
@@ -427,7 +434,9 @@ class ParticleRollout(object):
         es = self.state.element_size()
         small = env.n * env.E * 4 * es <= (1 << 20) and env.E * env.n * env.L * es * self.T >= (128 << 20)
         live = self._live = bool(small if self.live_state is None else self.live_state)
-        if live and self._live_cur != env._cur:
+        # The captured graph bakes in the addresses of env._state[env._cur] / env._obs_others[env._cur] (tick 0 reads them, the
+        # slot bookkeeping writes them) -- live or not -- and VecParticleEnv.step() flips env._cur: re-capture after a flip.
+        if self._live_cur != env._cur:
             self._drop_graphs()
             self._live_cur = env._cur
         flags = FLAG_AUTO_RESET | env.kernel_flags | FLAG_GEN_ACTIONS

@@ -46,7 +46,8 @@
 extern "C" {
 #endif
 
-#define CM3_ABI_VERSION 4
+#define CM3_ABI_VERSION 5   /* 5: cm3_last_kernel_variant; cm3_returns_moments_* takes a zero-initialised-once scratch (see there);
+                               cm3_returns_normalize_*, cm3_copy_shift, cm3_source_id, actor precision 2 (all added under 4) */
 #define CM3_MAX_AGENTS 8
 
 #define CM3_OK 0
@@ -79,6 +80,12 @@ int cm3_abi_version(void);
  * then this header), baked in by csrc/build.sh.  The Python binding compares it with the sources next to it and refuses a stale build. */
 const char *cm3_source_id(void);
 const char *cm3_last_error(void);
+/* Debug / test query (ABI 5): the kernel instantiation that the most recent cm3_particle_* / cm3_checkers_* call ON THE CALLING
+ * THREAD launched last, e.g. "k_particle_step_pairs<f32,N=4,waves=4,fused=0,sp=nt,live=1,early=0,g=0,tu=ilp>" -- the launchers
+ * choose among size-gated builds of one template (mapping, waves per workgroup, observation store policy plain / nt / wt, the
+ * live-state variant, the max-ILP translation unit); tests/test_gpu_dispatch_sizes.py asserts which build it checked.
+ * Thread-local storage, valid until the next call on the thread.  No reference counterpart. */
+const char *cm3_last_kernel_variant(void);
 /* Number of visible HIP devices (0 when none); fills name (<= len bytes) of device `dev` if name != NULL. */
 int cm3_device_count(void);
 int cm3_device_name(int dev, char *name, int len);

@@ -51,6 +51,9 @@ def test_bench_under_torchrun_one_rank(workload):
     out = _json_line(r.stdout)
     assert out["n_gpus"] == 1 and out["scaling"] == "weak" and out["value"] > 1e6
     assert len(out["per_rank"]) == 1 and out["per_rank"][0]["rank"] == 0
+    # the line says by itself what RCCL saw: world size from the process group, a checked all-reduce, the P2P matrix
+    assert out["rccl_world_size"] == 1 and out["rccl"]["backend"] == "nccl" and out["rccl"]["all_reduce_ok"] is True
+    assert out["rccl"]["p2p_access"][0]["can_access_peer"][0] == 1
     assert abs(out["per_rank"][0]["avg_launch_us"] - out["roofline"]["avg_launch_us"]) < 1e-6
     if workload == "c4":
         assert "all-gather" in out["config"]["parallelism"]
@@ -173,3 +176,85 @@ def test_collect_normalized_is_collect_followed_by_normalized_returns(use_graph)
     assert float(raw.abs().max()) > 1.0
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("E", [777, 1031])
+def test_collect_normalized_after_env_step_flips_the_buffers(E):
+    """VecParticleEnv.step() flips the env's double buffer; the graph captured by collect_normalized holds the addresses of the
+    buffers that were current at capture time, so a collect_normalized -> env.step() -> collect_normalized sequence must
+    re-capture (it replayed on the stale buffer).  E = 1031: N * E is odd for the 8-byte goal rows, so the slot
+    copies are not 16-byte sized and take the torch-copy path INSIDE the capture."""
+    import cm3_amd
+    from cm3_amd.particle import VecParticleEnv
+    from cm3_amd.rollout import ParticleRollout
+    from cm3_amd.shard import normalized_returns
+    N = 4 if E == 777 else 3
+    cfg = cm3_amd.load_config("particle_stage2_cross" if N == 4 else "particle_merge8")
+    T = 12
+    envs = [VecParticleEnv(cfg, N, 0.2, 7, E, device="cuda:0", auto_reset=True, seed=77) for _ in range(2)]
+    for e in envs:
+        e.reset()
+    a, b = (ParticleRollout(e, n_ticks=T, use_graph=True) for e in envs)
+    for k in range(4):
+        a.collect(reset=False)
+        want, (m, s, n) = normalized_returns(a.reward_n, a.done, None, gamma=0.99)
+        got, (m2, s2, n2) = b.collect_normalized(gamma=0.99)
+        for name in ("state", "obs_others", "actions", "reward_n", "done", "goals", "term_state"):
+            assert torch.equal(getattr(a, name), getattr(b, name)), (k, name)
+        assert torch.equal(want, got), k
+        assert float(m) == float(m2) and float(s) == float(s2)
+        assert torch.equal(envs[0].global_state, envs[1].global_state), k
+        assert torch.equal(envs[0].get_obs()[1], envs[1].get_obs()[1]), k
+        for e in envs:                       # an odd number of env.step() calls between two collections
+            for _ in range(1 if k % 2 == 0 else 3):
+                e.step()
+        assert torch.equal(envs[0].global_state, envs[1].global_state), k
+    a.close()
+    b.close()
+
+
+def test_c4_shards_moments_combine_to_the_single_process_statistics():
+    """BASELINE configs[3] over G ranks = every rank's collect_normalized up to its moments, ONE all-gather of the (sum, sum of
+    squares, count) triples, cm3_normalize_* over the G triples in rank order.  Here G = 2 shards on one GPU (env_id_base = the
+    shard's first global env id) against one process collecting all envs through the one-graph path: the RAW returns of the
+    shards are, bit for bit, the columns of the whole batch; the triples add up to the whole batch's triple (the count exactly,
+    the sums to the last bits of their different summation trees); normalising the shards with the combined triples gives the
+    single process's normalised returns to float32 rounding."""
+    import cm3_amd
+    from cm3_amd import _lib
+    from cm3_amd.particle import VecParticleEnv
+    from cm3_amd.rollout import ParticleRollout
+    cfg = cm3_amd.load_config("particle_stage2_cross")
+    T, E = 33, 1024 + 64
+    halves = [(0, 512 + 64), (512 + 64, 512)]
+
+    def run(base, n, normalize):
+        env = VecParticleEnv(cfg, 4, 0.2, 33, n, device="cuda:0", auto_reset=True, env_id_base=base, seed=12341)
+        env.reset()
+        ro = ParticleRollout(env, n_ticks=T, use_graph=True)
+        out, stats = ro.collect_normalized(gamma=0.99, normalize=normalize)
+        res = dict(out=out.clone(), moments=ro._norm.moments.clone(), stats=[float(x) for x in stats], reward_n=ro.reward_n.clone())
+        ro.close()
+        return res
+
+    whole = run(0, E, True)
+    whole_raw = run(0, E, False)
+    parts = [run(b, n, False) for b, n in halves]
+    assert torch.equal(torch.cat([p["reward_n"] for p in parts], dim=1), whole["reward_n"])
+    assert torch.equal(torch.cat([p["out"] for p in parts], dim=1), whole_raw["out"])           # raw returns: shard-invariant
+    gathered = torch.cat([p["moments"] for p in parts])                                         # what the all-gather delivers
+    tot = gathered.view(2, 3)[0] + gathered.view(2, 3)[1]
+    assert float(tot[2]) == float(whole["moments"][2]) == float(T * E * 4)
+    assert abs(float(tot[0]) - float(whole["moments"][0])) <= 1e-12 * abs(float(whole["moments"][0]))
+    assert abs(float(tot[1]) - float(whole["moments"][1])) <= 1e-12 * abs(float(whole["moments"][1]))
+    lib = _lib.lib()
+    stats = torch.zeros(3, dtype=torch.float64, device="cuda:0")
+    normed = []
+    for p in parts:                         # every rank: cm3_normalize_f32 over the G gathered triples, rank order
+        x = p["out"].clone()
+        _lib.check(lib.cm3_normalize_f32(x.data_ptr(), 0, gathered.data_ptr(), 2, stats.data_ptr(), x.numel(), 4, 1e-8, 1,
+                                         _lib.current_stream_handle(x.device)))
+        normed.append(x)
+    assert abs(float(stats[0]) - whole["stats"][0]) <= 1e-12 * abs(whole["stats"][0])
+    assert abs(float(stats[1]) - whole["stats"][1]) <= 1e-12 * abs(whole["stats"][1])
+    assert torch.allclose(torch.cat(normed, dim=1), whole["out"], rtol=1e-6, atol=1e-6)
