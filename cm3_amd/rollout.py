@@ -75,7 +75,9 @@ def _copy_pairs(pairs, stream):
             _lib.copy_list(pairs[k:k + 8], stream)
     else:
         dev = pairs[0][0].device
-        with torch.cuda.stream(torch.cuda.ExternalStream(int(stream), device=dev)):
+        # (handle 0 = the legacy default stream: torch.cuda.ExternalStream(0) would hand out a fresh POOL stream instead)
+        ts = torch.cuda.ExternalStream(int(stream), device=dev) if stream else torch.cuda.default_stream(dev)
+        with torch.cuda.stream(ts):
             for d, s_ in pairs:
                 d.copy_(s_)
 

@@ -237,7 +237,9 @@ def test_reset_of_the_four_wave_build_matches_the_philox_spec(N, E, dtype):
     gs, oo, _, done = env.reset()
     v = _variant()
     assert v["kernel"] == "k_particle_reset" and v["waves"] == 4 and v["n"] == N, v["raw"]
-    tol = 1e-12 if dtype == torch.float64 else 5e-7           # float Box-Muller in the float32 kernel
+    # float32 kernel: Box-Muller in float (|rad| <= ~5.5 at 1.2 M draws, cosf / logf at ~1 ulp) + the rounding of the position
+    # itself; 5e-7 holds at the 1024 envs of test_gpu_particle.py, the largest of 1.2 M x 2 draws here measured 6.4e-7
+    tol = 1e-12 if dtype == torch.float64 else 1.5e-6
     ids = np.arange(E)
     pos, lm, rnd = philox.expected_reset(seed, ids, 1, cfg, N, 0.2)
     g = gs.cpu().numpy().astype(np.float64)
