@@ -36,6 +36,59 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # same guide: v_mfma_f32_16x16x4_f32 / 32x32x2_f32, dense (= the FP32 vector peak)
+MFMA_F16_PEAK_TFLOPS = 2500.0  # same guide: FP16 / BF16 MFMA, dense (the 5 PF figure is 2:1 sparsity)
+
+
+def particle_actor_mfma_work(n_agents, precision):
+    """EXECUTED matrix-core work of one agent row and tick of the particle actor (csrc/actor.hip), per pipe, in MACs -- the
+    padded tiles as the instructions run them, not the network's own 6*64 + L*128 + 192*64 + 64*5:
+      first layers   v_mfma_f32_16x16x4_f32: K = 6 -> 8 for branch_self (64 units), K = L for actor_others (128 units)
+      second layer   f32: 192 x 64 on the f32 pipe; f16x3: THREE float16 passes (hi hi + hi lo + lo hi) on the f16 pipe; bf16: one
+      output layer   v_mfma_f32_16x16x4_f32: 64 x 16 (5 actions padded to a 16-column tile)
+    -> (f32 MACs, f16/bf16 MACs, network MACs)"""
+    L = 4 * max(n_agents - 1, 1)
+    f32 = 64 * 8 + 128 * L + 64 * 16
+    second = 192 * 64
+    net = 6 * 64 + L * 128 + second + 64 * 5
+    if precision == "f32":
+        return f32 + second, 0, net
+    return f32, second * (3 if precision == "f16x3" else 1), net
+
+
+def checkers_actor_mfma_work(n_agents, precision):
+    """Executed matrix-core MACs per agent row of the Checkers actor (csrc/actor_checkers.hip: tile widths of its layers) ->
+    (f32 MACs, f16/bf16 MACs, network MACs).  f32: every layer on v_mfma_f32_16x16x4_f32 (K padded to 16s: conv 80 x 160 Toeplitz,
+    conv_linear 160 x 32, branch_self 48 x 256, branch_others 16 x 256, the two 256 x 256, out 256 x 16); f16x3: every layer as
+    float16 passes with K padded to 32s -- two passes for the conv (its int8 input is exact in float16), three for the others."""
+    net = 25 * 6 * 27 + 150 * 32 + 43 * 256 + (2 * max(n_agents - 1, 1) * 256 + 256 * 256 if n_agents > 1 else 0) + 256 * 256 + 256 * 5
+    small_f32 = 80 * 160 + 160 * 32 + 48 * 256 + 16 * 256 + 256 * 16
+    big = 2 * 256 * 256
+    if precision == "f32":
+        return small_f32 + big, 0, net
+    if precision == "bf16":
+        return small_f32, big, net
+    return 0, 96 * 160 * 2 + (160 * 32 + 64 * 256 + 32 * 256 + big + 256 * 16) * 3, net
+
+
+def mfma_roofline(rows_per_tick, us_per_tick, f32_macs, f16_macs, net_macs):
+    """The matrix-core roofline of a policy tick: every pass divided by the peak of the pipe it runs on.  `matrix_time_us` is the
+    time the executed instructions need at those peaks; frac = matrix_time / tick time (what share of the tick the matrix cores
+    are the bound of).  The network's own FLOP rate is reported beside it as `network_TFLOPs` (never against a peak: its
+    padded / split passes run on two different pipes)."""
+    t = us_per_tick * 1e-6
+    f32_tf = 2.0 * f32_macs * rows_per_tick / t / 1e12
+    f16_tf = 2.0 * f16_macs * rows_per_tick / t / 1e12
+    matrix_us = (2.0 * f32_macs * rows_per_tick / (MFMA_F32_PEAK_TFLOPS * 1e12) +
+                 2.0 * f16_macs * rows_per_tick / (MFMA_F16_PEAK_TFLOPS * 1e12)) * 1e6
+    return {"bound": "mfma", "achieved": f32_tf + f16_tf, "unit": "TFLOP/s", "frac": matrix_us / us_per_tick,
+            "peak": (f32_tf + f16_tf) / max(matrix_us / us_per_tick, 1e-12),
+            "executed_f32_mfma_TFLOPs": f32_tf, "f32_peak": MFMA_F32_PEAK_TFLOPS, "frac_of_f32_peak": f32_tf / MFMA_F32_PEAK_TFLOPS,
+            "executed_f16_mfma_TFLOPs": f16_tf, "f16_peak": MFMA_F16_PEAK_TFLOPS, "frac_of_f16_peak": f16_tf / MFMA_F16_PEAK_TFLOPS,
+            "matrix_time_us": matrix_us, "network_TFLOPs": 2.0 * net_macs * rows_per_tick / t / 1e12,
+            "note": "executed MFMA FLOPs per pipe (padded tiles, three float16 passes for f16x3) against that pipe's dense peak; "
+                    "frac = time the executed matrix instructions need at peak / time per tick; `peak` = the blended peak "
+                    "that makes achieved / peak equal frac.  A small frac means the tick is latency-bound, not MFMA-bound"}
+
 EP_TICKS = 33                 # ticks of one episode (config.json max_steps)
 PHASE_EPISODES = 10           # episodes_per_train (alg/config.json; train_onpolicy.py:359): one collection phase
 PHASE_TICKS = EP_TICKS * PHASE_EPISODES
@@ -929,9 +982,9 @@ def main():
                 e1.record()
                 e1.synchronize()
                 us = e0.elapsed_time(e1) * 1e3 / (reps * EP_TICKS)
-                tfl = 2.0 * macs * E * N / (us * 1e-6) / 1e12
                 sub[label] = {"us_per_tick": us, "env_steps_per_s": E / us * 1e6,
-                              "network_TFLOPs": tfl, "frac_of_f32_mfma_peak": tfl / MFMA_F32_PEAK_TFLOPS}
+                              "roofline": mfma_roofline(E * N, us, *particle_actor_mfma_work(N, prec))}
+                sub[label]["network_TFLOPs"] = sub[label]["roofline"]["network_TFLOPs"]
                 ro.close()
             # the actor kernel alone (hipGraph of 100 launches: start-to-start, no host allocation inside)
             penv = VecParticleEnv(cfg, N, 0.2, 33, E, device=device, auto_reset=True)
@@ -958,20 +1011,16 @@ def main():
             a_us = e0.elapsed_time(e1) * 1e3 / 1000
             torch.cuda.synchronize(device)
             _l.lib().cm3_graph_destroy(g)
-            tfl = 2.0 * macs * E * N / (a_us * 1e-6) / 1e12
             sub["actor_kernel"] = {"kernel": "k_actor_particle<%d, %s>" % (N, prec), "avg_launch_us": a_us, "rows": E * N,
                                    "macs_per_row": macs,
-                                   "roofline": {"bound": "mfma", "achieved": tfl, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                                "frac": tfl / MFMA_F32_PEAK_TFLOPS},
-                                   "note": "start-to-start inside a hipGraph of 100 launches; FLOPs of the network itself against "
-                                           "the float32 matrix-core peak (f16x3 runs its second layer as three float16 passes)"}
+                                   "roofline": mfma_roofline(E * N, a_us, *particle_actor_mfma_work(N, prec)),
+                                   "note": "start-to-start inside a hipGraph of 100 launches"}
             pol[prec] = sub
         best = pol["f16x3"]["one_launch_per_episode"]
         pol["headline"] = {"what": "policy-driven collection (train_onpolicy.py:311-313), the default of "
                                    "ParticleRollout.collect(policy=actor): one launch per episode, actor precision f16x3",
                            "us_per_tick": best["us_per_tick"], "env_steps_per_s": best["env_steps_per_s"],
-                           "roofline": {"bound": "mfma", "achieved": best["network_TFLOPs"], "peak": MFMA_F32_PEAK_TFLOPS,
-                                        "unit": "TFLOP/s", "frac": best["frac_of_f32_mfma_peak"]}}
+                           "roofline": best["roofline"]}
         pol["note"] = ("second headline: actor (networks.actor_particle; second layer exact float32 MFMA (f32) or split float16 "
                        "(f16x3, same 2e-5 parity bound)) + env step per tick with full trajectory storage.  launch_per_tick = an "
                        "actor launch then a step launch per tick; fused_launch_per_tick = ONE launch per tick doing both; "
@@ -1013,7 +1062,6 @@ def main():
             e1.record()
             e1.synchronize()
             a_us = e0.elapsed_time(e1) * 1e3 / reps
-            tflops = 2.0 * macs * E * Nc / (a_us * 1e-6) / 1e12
             ro = CheckersRollout(cenv, n_ticks=EP_TICKS, use_graph=True)
             for _ in range(2):
                 ro.collect(goals, policy=actor, epsilon=0.1)
@@ -1026,24 +1074,21 @@ def main():
             e1.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / (reps * EP_TICKS)
             ro.close()
-            t_tfl = 2.0 * macs * E * Nc / (us * 1e-6) / 1e12
+            work = checkers_actor_mfma_work(Nc, prec)
             pol[prec] = {
-                "launch_per_tick": {"us_per_tick": us, "env_steps_per_s": E / us * 1e6, "network_TFLOPs": t_tfl,
-                                    "frac_of_f32_mfma_peak": t_tfl / MFMA_F32_PEAK_TFLOPS},
+                "launch_per_tick": {"us_per_tick": us, "env_steps_per_s": E / us * 1e6, "roofline": mfma_roofline(E * Nc, us, *work)},
                 "actor_kernel": {"kernel": "k_ck_actor<%s>" % prec, "avg_launch_us": a_us, "rows": E * Nc, "macs_per_row": macs,
-                                 "roofline": {"bound": "mfma", "achieved": tflops, "peak": MFMA_F32_PEAK_TFLOPS,
-                                              "unit": "TFLOP/s", "frac": tflops / MFMA_F32_PEAK_TFLOPS}}}
+                                 "roofline": mfma_roofline(E * Nc, a_us, *work)}}
+            pol[prec]["launch_per_tick"]["network_TFLOPs"] = pol[prec]["launch_per_tick"]["roofline"]["network_TFLOPs"]
             del cenv, actor
         best = pol["f16x3"]["launch_per_tick"]
         pol["headline"] = {"what": "policy-driven Checkers collection (train_onpolicy.py:309-321): actor launch + step launch per "
                                    "tick in one hipGraph, actor precision f16x3",
                            "us_per_tick": best["us_per_tick"], "env_steps_per_s": best["env_steps_per_s"],
-                           "roofline": {"bound": "mfma", "achieved": best["network_TFLOPs"], "peak": MFMA_F32_PEAK_TFLOPS,
-                                        "unit": "TFLOP/s", "frac": best["frac_of_f32_mfma_peak"]}}
+                           "roofline": best["roofline"]}
         pol["note"] = ("extra, not the headline: actor (networks.actor_checkers; the two 256x256 layers = 86 %% of its FLOPs on the "
-                       "exact-f32 MFMA (f32) or as three float16 MFMAs over hi + lo splits (f16x3, same 2e-5 parity bound); FLOPs "
-                       "counted for the network itself against the float32 matrix-core peak, zero padding of the MFMA tiles "
-                       "excluded) + reset + step per tick with full trajectory storage (tests/test_gpu_actor_checkers.py)")
+                       "exact-f32 MFMA (f32) or as three float16 MFMAs over hi + lo splits (f16x3, same 2e-5 parity bound); the "
+                       "roofline counts the EXECUTED matrix instructions per pipe against that pipe's peak) + reset + step per tick with full trajectory storage (tests/test_gpu_actor_checkers.py)")
         out["policy_rollout"] = pol
     if world == 1 and rank == 0 and args.workload == "c2" and mode == "trajectory" and not args.no_other_configs \
             and not args.no_extras and not args.fused and n_chains == 1 and not args.envs_per_gpu:

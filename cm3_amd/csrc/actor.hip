@@ -54,6 +54,12 @@ template <int N> struct PackLayout {
   static constexpr int kTotal = kW2x + 4 * 64 * (KU / 4);
 };
 
+// Split float16 (kPrecF16x3): x = hi + lo with hi = f16(x) and the residual stored SCALED, lo' = f16((x - hi) * 2^11).  |x - hi| is at
+// most 2^-11 |x|, so lo' lives in hi's own exponent range: without the scale the residual of every |x| < 0.125 fell into float16's
+// subnormals (absolute error ~3e-8 per factor whatever x is -- ADVICE r3) and small weights against large activations could leave
+// the 2e-5 bound.  The two small products are accumulated apart from hi x hi and folded in with one exact multiply by 2^-11.
+constexpr float kLoScale = 2048.0f, kLoUnscale = 1.0f / 2048.0f;
+
 template <int N> __global__ void __launch_bounds__(256) k_actor_pack(const ActorParams p, float *out) {
   using PL = PackLayout<N>;
   const bool stage2 = p.stage > 1;
@@ -97,7 +103,7 @@ template <int N> __global__ void __launch_bounds__(256) k_actor_pack(const Actor
         const int k = 32 * s + 8 * (lane >> 4) + q, j = 16 * w + (lane & 15);
         const float wv = k < kH1S ? p.w_self_h2[k * kH2 + j] : (stage2 ? p.w_oth_h2[(k - kH1S) * kH2 + j] : 0.0f);
         const _Float16 hi = (_Float16)wv;
-        pair[h] = part == 0 ? hi : (_Float16)(wv - (float)hi);
+        pair[h] = part == 0 ? hi : (_Float16)((wv - (float)hi) * kLoScale);   // (the residual is kept scaled: see kLoScale)
       }
       __builtin_memcpy(&v, pair, 4);
     }
@@ -140,7 +146,18 @@ template <int N> __global__ void __launch_bounds__(256) k_actor_pack(const Actor
 //                that (weights ~3 orders of magnitude above anything a trained policy holds) saturates instead of matching.
 constexpr int kPrecF32 = 0, kPrecBf16 = 1, kPrecF16x3 = 2;
 
-template <int N, int PREC> struct ActorGeom {
+// relu as ONE v_max_f32: fmaxf(x, 0) first canonicalises x (a second v_max_f32 x, x) because the build honours signalling NaNs;
+// matrix-core outputs are never signalling, and a quiet NaN comes out as 0 either way (v_max returns the non-NaN operand)
+__device__ __forceinline__ float relu_f32(float x) {
+  float r;
+  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+
+// RT = 16-row tiles per workgroup (4: 64 agent rows, the one-tick actor kernel; the fused policy rollout also runs 2 or 1 so that a
+// small batch still puts several workgroups on every CU, see policy.hip)
+template <int N, int PREC, int RT = 4> struct ActorGeom {
+  static constexpr int ROWS = 16 * RT;
   static constexpr bool BF16 = PREC != kPrecF32;     // activations stored as bf16 (one plane, or hi + lo planes)
   static constexpr int PLANES = PREC == kPrecF16x3 ? 2 : 1;
   static constexpr int L = 4 * (N > 1 ? N - 1 : 1);
@@ -150,14 +167,14 @@ template <int N, int PREC> struct ActorGeom {
   static constexpr int HB = KU + 8;       // bf16 row: 200 halfwords = 400 B (16-byte aligned rows)
   static constexpr int XW = 6 + L + 1;    // input tile row: [v_obs(4) | v_goal(2) | obs_others(L)], odd stride
   static constexpr int HS = KU + 2;        // f32 row: 194 floats (8-byte aligned rows; reads of 16 rows x 2 k hit 32 distinct banks)
-  static constexpr int kH1Floats = BF16 ? PLANES * (64 * HB) / 2 : 64 * HS;
-  static_assert(64 * (kH2 + 1) <= kH1Floats, "h2 must fit into the h1 storage");
+  static constexpr int kH1Floats = BF16 ? PLANES * (ROWS * HB) / 2 : ROWS * HS;
+  static_assert(ROWS * (kH2 + 1) <= kH1Floats, "h2 must fit into the h1 storage");
 };
 
 // Views into the workgroup's LDS (declared by the kernel with CM3_ACTOR_LDS).  h2 reuses the h1 storage once every wave
 // is done reading h1, which keeps the workgroup at 66 KB (f32) / 42 KB (bf16) so that two workgroups fit a CU.
-template <int N, int PREC> struct ActorLds {
-  using G = ActorGeom<N, PREC>;
+template <int N, int PREC, int RT = 4> struct ActorLds {
+  using G = ActorGeom<N, PREC, RT>;
   float (*ws_self)[G::SW];
   float (*ws_oth)[G::OW];
   const float *wout;
@@ -171,12 +188,12 @@ template <int N, int PREC> struct ActorLds {
   float *tables;
 };
 
-#define CM3_ACTOR_LDS(N_, BF16_, name)                                                                         \
+#define CM3_ACTOR_LDS_RT(N_, BF16_, RT_, name)                                                                 \
   __shared__ __attribute__((aligned(16))) float name##_tables[PackLayout<N_>::kTables];                        \
-  __shared__ __attribute__((aligned(16))) float name##_h1raw[ActorGeom<N_, BF16_>::kH1Floats];                 \
-  __shared__ float name##_xs[64][ActorGeom<N_, BF16_>::XW];                                                    \
-  __shared__ float name##_lg[64][8];                                                                           \
-  ActorLds<N_, BF16_> name;                                                                                    \
+  __shared__ __attribute__((aligned(16))) float name##_h1raw[ActorGeom<N_, BF16_, RT_>::kH1Floats];            \
+  __shared__ float name##_xs[16 * RT_][ActorGeom<N_, BF16_, RT_>::XW];                                         \
+  __shared__ float name##_lg[16 * RT_][8];                                                                     \
+  ActorLds<N_, BF16_, RT_> name;                                                                               \
   name.lg = name##_lg;                                                                                         \
   name.tables = name##_tables;                                                                                 \
   name.ws_self = reinterpret_cast<float (*)[ActorGeom<N_, BF16_>::SW]>(&name##_tables[PackLayout<N_>::kSelf]); \
@@ -185,13 +202,14 @@ template <int N, int PREC> struct ActorLds {
   name.h1s = reinterpret_cast<float (*)[ActorGeom<N_, BF16_>::HS]>(name##_h1raw);                              \
   name.h1b = reinterpret_cast<__bf16 (*)[ActorGeom<N_, BF16_>::HB]>(name##_h1raw);                             \
   name.h1h = reinterpret_cast<_Float16 (*)[ActorGeom<N_, BF16_>::HB]>(name##_h1raw);                           \
-  name.h1l = reinterpret_cast<_Float16 (*)[ActorGeom<N_, BF16_>::HB]>(name##_h1raw) + 64;                      \
+  name.h1l = reinterpret_cast<_Float16 (*)[ActorGeom<N_, BF16_>::HB]>(name##_h1raw) + 16 * RT_;                \
   name.h2s = reinterpret_cast<float (*)[kH2 + 1]>(name##_h1raw);                                               \
   name.xs = name##_xs
+#define CM3_ACTOR_LDS(N_, BF16_, name) CM3_ACTOR_LDS_RT(N_, BF16_, 4, name)
 
 // first-layer tables + output layer -> LDS: straight 16-byte copies of the packed prefix
-template <int N, int PREC>
-__device__ __forceinline__ void actor_stage_tables(const ActorLds<N, PREC> &lds, const float *packed, int tid) {
+template <int N, int PREC, int RT>
+__device__ __forceinline__ void actor_stage_tables(const ActorLds<N, PREC, RT> &lds, const float *packed, int tid) {
   const float4 *src = reinterpret_cast<const float4 *>(packed);
   float4 *dst = reinterpret_cast<float4 *>(lds.tables);
   for (int t = tid; t < PackLayout<N>::kTables / 4; t += 256) dst[t] = src[t];
@@ -268,20 +286,19 @@ __device__ __forceinline__ void actor_first_b(const T *self_tab, const T *oth_ta
 // xs tile + tables ready and synchronised on entry; h2s ready and synchronised on exit (3 barriers inside).  The lane's
 // phase-A B operands are read from the LDS tables ONCE, up front (measured -0.9 % per launch against reading them inside each
 // block: 8.80 -> 8.72 us at 16 384 rows, same box).
-template <int N, int PREC>
-__device__ __forceinline__ void actor_mlp(const ActorLds<N, PREC> &lds, const ActorB<N, PREC> &b, int w, int lane,
-                                          bool stage2) {
-  using G = ActorGeom<N, PREC>;
+template <int N, int PREC, int RT>
+__device__ __forceinline__ void actor_mlp(const ActorLds<N, PREC, RT> &lds, const ActorB<N, PREC> &b, const ActorFirstB<N> &f1, int w,
+                                          int lane, bool stage2) {
+  using G = ActorGeom<N, PREC, RT>;
   constexpr bool BF16 = G::BF16;
   constexpr int L = G::L, KU = G::KU;
   const int col = lane & 15, hi = lane >> 4, c0 = 16 * w;
-  ActorFirstB<N> f1;
-  actor_first_b<N, float>(&lds.ws_self[0][0], &lds.ws_oth[0][0], w, lane, stage2, f1);
+  (void)stage2;   // (f1 = the lane's first-layer operands, actor_first_b: read from the LDS tables ONCE per launch by the caller)
   // ---- phase A: dense(6 -> 64) units [16w, 16w+16) and dense(L -> 128) units [32w, 32w+32) (networks.py:520-529) ------
   {
-    float ax[4][2], ao[4][L / 4];
+    float ax[RT][2], ao[RT][L / 4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < RT; ++t) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) ax[t][s] = (4 * s + hi < 6) ? lds.xs[16 * t + col][4 * s + hi] : 0.0f;
 #pragma unroll
@@ -293,15 +310,26 @@ __device__ __forceinline__ void actor_mlp(const ActorLds<N, PREC> &lds, const Ac
     // ds_write_b64 per four float16 values (two for hi + lo), two per four float32 values -- 24 LDS stores per wave instead of 96 / 48.
     auto put4 = [&](int row, int unit0, const float (&h)[4]) {
       if constexpr (PREC == kPrecF16x3) {
-        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-        h4 vh, vl;
+        // hi = f16(h) (packed convert), lo' = f16((h - hi) * 2^11) as ONE mixed-precision fma per value on the packed hi pair:
+        // fma(hi, -2^11, h * 2^11) is exact before its single rounding to float16 -- the same bits as subtract, scale, convert
+        // (7.2 -> 4 VALU instructions per value of the layer's epilogue, the largest block of the tick)
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        uint2 vh, vl;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          vh[r] = (_Float16)h[r];
-          vl[r] = (_Float16)(h[r] - (float)vh[r]);
+        for (int r2 = 0; r2 < 2; ++r2) {
+          h2 hp;
+          hp[0] = (_Float16)h[2 * r2];
+          hp[1] = (_Float16)h[2 * r2 + 1];
+          uint32_t hw, lw;
+          __builtin_memcpy(&hw, &hp, 4);
+          typedef float f2 __attribute__((ext_vector_type(2)));
+          const f2 sc = f2{h[2 * r2], h[2 * r2 + 1]} * kLoScale;     // (one packed multiply)
+          asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lw) : "v"(hw), "v"(-kLoScale), "v"(sc[0]));
+          asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lw) : "v"(hw), "v"(-kLoScale), "v"(sc[1]));
+          if (r2 == 0) { vh.x = hw; vl.x = lw; } else { vh.y = hw; vl.y = lw; }
         }
-        *reinterpret_cast<h4 *>(&lds.h1h[row][unit0]) = vh;
-        *reinterpret_cast<h4 *>(&lds.h1l[row][unit0]) = vl;
+        *reinterpret_cast<uint2 *>(&lds.h1h[row][unit0]) = vh;
+        *reinterpret_cast<uint2 *>(&lds.h1l[row][unit0]) = vl;
       } else if constexpr (BF16) {
         typedef __bf16 b4 __attribute__((ext_vector_type(4)));
         b4 vb;
@@ -313,28 +341,39 @@ __device__ __forceinline__ void actor_mlp(const ActorLds<N, PREC> &lds, const Ac
         *reinterpret_cast<float2 *>(&lds.h1s[row][unit0 + 2]) = make_float2(h[2], h[3]);
       }
     };
+    // Per 16-unit column tile: all its matrix instructions first, every row tile into its OWN accumulator, s-major (two
+    // instructions on the same accumulator are RT issues apart), then the epilogues (round 4: one accumulator shared by all
+    // twelve tiles made them a serial chain of issue / wait / read-out).  The bias rides in as the accumulator's start value.
     {  // branch_self: units 16w .. 16w + 15
+      f32x4 c[RT];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        f32x4 c = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      for (int t = 0; t < RT; ++t) c[t] = f32x4{f1.bias_s[0], f1.bias_s[1], f1.bias_s[2], f1.bias_s[3]};
 #pragma unroll
-        for (int s = 0; s < 2; ++s) c = __builtin_amdgcn_mfma_f32_16x16x4f32(f1.bs[s], ax[t][s], c, 0, 0, 0);
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int t = 0; t < RT; ++t) c[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(f1.bs[s], ax[t][s], c[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < RT; ++t) {
         float h[4];
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) h[reg] = fmaxf(c[reg] + f1.bias_s[reg], 0.0f);
+        for (int reg = 0; reg < 4; ++reg) h[reg] = relu_f32(c[t][reg]);
         put4(16 * t + col, 16 * w + 4 * hi, h);
       }
     }
 #pragma unroll
-    for (int cq = 0; cq < 2; ++cq) {  // actor_others: two 16-unit tiles, units 32w + 16cq .. + 15
+    for (int cq = 0; cq < 2; ++cq) {  // actor_others: two 16-unit tiles, units 32w + 16cq .. + 15 (stage 1: exactly 0, no others branch)
+      f32x4 d[RT];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        f32x4 c = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      for (int t = 0; t < RT; ++t) d[t] = f32x4{f1.bias_o[cq][0], f1.bias_o[cq][1], f1.bias_o[cq][2], f1.bias_o[cq][3]};
 #pragma unroll
-        for (int s = 0; s < L / 4; ++s) c = __builtin_amdgcn_mfma_f32_16x16x4f32(f1.bo[cq][s], ao[t][s], c, 0, 0, 0);
+      for (int s = 0; s < L / 4; ++s)
+#pragma unroll
+        for (int t = 0; t < RT; ++t) d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(f1.bo[cq][s], ao[t][s], d[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < RT; ++t) {
         float h[4];
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) h[reg] = fmaxf(c[reg] + f1.bias_o[cq][reg], 0.0f);  // stage 1: exactly 0, no others branch
+        for (int reg = 0; reg < 4; ++reg) h[reg] = relu_f32(d[t][reg]);
         put4(16 * t + col, kH1S + 32 * w + 16 * cq + 4 * hi, h);
       }
     }
@@ -343,32 +382,39 @@ __device__ __forceinline__ void actor_mlp(const ActorLds<N, PREC> &lds, const Ac
   __syncthreads();
   CM3_STAMP(4, false);
   // ---- phase B: second layer on the matrix cores (networks.py:522-531: both matmuls, add_n) ---------------------------
-  f32x4 acc[4];
+  f32x4 acc[RT];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  for (int t = 0; t < RT; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   if constexpr (PREC == kPrecF16x3) {
+    f32x4 accs[RT];   // hi x lo' + lo' x hi, scaled by 2^11 (kLoScale)
+#pragma unroll
+    for (int t = 0; t < RT; ++t) accs[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int s = 0; s < KU / 32; ++s) {
-      // the two small terms first, then hi x hi -- each product over all four row tiles before the next, so that two MFMAs on the
-      // same accumulator are four issues apart (back to back they wait for each other: measured on the Checkers actor)
-      f16x8 ah[4], al[4];
+      // each product over all row tiles before the next, the small terms in their own accumulators: two MFMAs on the same
+      // accumulator are at least 2 RT issues apart (back to back they wait for each other: measured on the Checkers actor)
+      f16x8 ah[RT], al[RT];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
+      for (int t = 0; t < RT; ++t) {
         ah[t] = *reinterpret_cast<const f16x8 *>(&lds.h1h[16 * t + col][32 * s + 8 * hi]);
         al[t] = *reinterpret_cast<const f16x8 *>(&lds.h1l[16 * t + col][32 * s + 8 * hi]);
       }
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], b.bwh[s], acc[t], 0, 0, 0);
+      for (int t = 0; t < RT; ++t) accs[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], b.bwh[s], accs[t], 0, 0, 0);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], b.bwl[s], acc[t], 0, 0, 0);
+      for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], b.bwh[s], acc[t], 0, 0, 0);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], b.bwh[s], acc[t], 0, 0, 0);
+      for (int t = 0; t < RT; ++t) accs[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], b.bwl[s], accs[t], 0, 0, 0);
     }
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) acc[t][reg] = fmaf(accs[t][reg], kLoUnscale, acc[t][reg]);   // (the scale is a power of two: exact)
   } else if constexpr (BF16) {
 #pragma unroll
     for (int s = 0; s < KU / 32; ++s) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
+      for (int t = 0; t < RT; ++t) {
         const bf16x8 a = *reinterpret_cast<const bf16x8 *>(&lds.h1b[16 * t + col][32 * s + 8 * hi]);
         acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b.bwb[s], acc[t], 0, 0, 0);
       }
@@ -377,7 +423,7 @@ __device__ __forceinline__ void actor_mlp(const ActorLds<N, PREC> &lds, const Ac
 #pragma unroll
     for (int s = 0; s < KU / 4; ++s) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < RT; ++t)
         acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(lds.h1s[16 * t + col][4 * s + hi], b.bw[s], acc[t], 0, 0, 0);
     }
   }
@@ -385,9 +431,9 @@ __device__ __forceinline__ void actor_mlp(const ActorLds<N, PREC> &lds, const Ac
   __syncthreads();  // all waves have consumed h1: its storage becomes h2
   // ---- h2 = relu(add_n + b) (networks.py:533-534): C tile -> LDS rows --------------------------------------------------
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+  for (int t = 0; t < RT; ++t)
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) lds.h2s[16 * t + 4 * hi + reg][c0 + col] = fmaxf(acc[t][reg] + b.bias_h2, 0.0f);
+    for (int reg = 0; reg < 4; ++reg) lds.h2s[16 * t + 4 * hi + reg][c0 + col] = relu_f32(acc[t][reg] + b.bias_h2);
   __syncthreads();
   CM3_STAMP(6, false);
 }
@@ -420,12 +466,17 @@ __device__ __forceinline__ void actor_head_load(const float *wout, int lane, Act
 __device__ __forceinline__ void actor_head_probs(const float (*h2s)[kH2 + 1], const ActorHeadB &hb, float (*lg)[8], int w,
                                                  int lane, float eps, float (&pr)[kA]) {
   const int col = lane & 15, hi = lane >> 4;
-  f32x4 acc = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  // two accumulators (even / odd k-steps), added at the end: sixteen instructions on ONE accumulator each waited for its
+  // predecessor's eight passes (round 4: ~200 of the head's ~2000 cycles); the bias starts the even chain
+  f32x4 acc = f32x4{hb.bias, hb.bias, hb.bias, hb.bias}, acc1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-  for (int s = 0; s < kH2 / 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(h2s[16 * w + col][4 * s + hi], hb.wo[s], acc, 0, 0, 0);
+  for (int s = 0; s < kH2 / 4; s += 2) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(h2s[16 * w + col][4 * s + hi], hb.wo[s], acc, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(h2s[16 * w + col][4 * (s + 1) + hi], hb.wo[s + 1], acc1, 0, 0, 0);
+  }
   if (col < kA) {
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) lg[16 * w + 4 * hi + reg][col] = acc[reg] + hb.bias;
+    for (int reg = 0; reg < 4; ++reg) lg[16 * w + 4 * hi + reg][col] = acc[reg] + acc1[reg];
   }
   wave_sync_lds();
   float o[kA];
@@ -472,7 +523,7 @@ template <int N, int PREC> __global__ void __launch_bounds__(256) k_actor_partic
   // first-layer operands straight from global memory into registers instead of the table copy (+9 %: the entry is bound by the
   // request throughput of 256 workgroups reading the same few KB of L2, and narrow per-lane requests are worse than the wide
   // copy), the Philox draw before the first barrier (+0.5 %), input rows staged by all four waves (+-0), both (+1.1 %).
-  actor_stage_tables<N, PREC>(lds, p.packed, tid);
+  actor_stage_tables<N, PREC, 4>(lds, p.packed, tid);
   CM3_STAMP(8, false);
   if (w == 0) {  // wave 0 stages the 64 input rows [v_obs(4) | v_goal(2) | obs_others(L)] into LDS, one row per lane
     const size_t r = row_base + lane;
@@ -500,7 +551,9 @@ template <int N, int PREC> __global__ void __launch_bounds__(256) k_actor_partic
   CM3_STAMP(2, false);
   ActorHeadB hb;
   actor_head_load(lds.wout, lane, hb);      // (the tables are in LDS: synchronised above)
-  actor_mlp<N, PREC>(lds, b, w, lane, p.stage > 1);
+  ActorFirstB<N> f1;
+  actor_first_b<N, float>(&lds.ws_self[0][0], &lds.ws_oth[0][0], w, lane, p.stage > 1, f1);
+  actor_mlp<N, PREC, 4>(lds, b, f1, w, lane, p.stage > 1);
   float pr[kA];
   // the uniform first: its Philox rounds are VALU work that can issue between the head's dependent MFMAs
   const float u = actor_uniform(p.seed, (uint64_t)(p.env_id_base + (int64_t)he), head_episode, head_steps, hi_agent);

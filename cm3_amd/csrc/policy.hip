@@ -22,6 +22,7 @@
 #define CM3_PARTICLE_F32 1
 #include "particle.hip"
 #include "actor.hip"
+#include <stdlib.h>
 
 namespace cm3 {
 
@@ -35,23 +36,38 @@ struct PolicyParams {
   int stage;
 };
 
-template <int N, int BF16> __global__ void __launch_bounds__(256) k_policy_rollout(const PolicyParams q) {
-  using G = ActorGeom<N, BF16>;
+// RT = 16-row tiles per workgroup: 4 (64 agent rows) where that already gives every CU several workgroups; 2 or 1 for smaller
+// batches, so that two or more workgroups share a CU and one's matrix-core phases run under the other's physics / LDS staging
+// (round 4: the per-env chain actor -> physics -> observation is serial, and at one wave per SIMD the tick was latency-bound:
+// ~1 us of matrix time inside 5.0 us).  Waves w >= RT take part in the layers (every wave owns 16 columns of all row tiles) and
+// in the barriers, but have no rows of their own in the head and the physics.
+template <int N, int BF16, int RT> __global__ void __launch_bounds__(256) k_policy_rollout(const PolicyParams q) {
+  using G = ActorGeom<N, BF16, RT>;
   using V4 = float4;
   using V2 = float2;
   constexpr int L = G::L, NO = N > 1 ? N - 1 : 1;
   const ParticleParams &p = q.p;
-  CM3_ACTOR_LDS(N, BF16, lds);
-  __shared__ __attribute__((aligned(16))) float4 ns[64];  // post-step (vx, vy, px, py) of every row, exchanged inside a wave
+  CM3_ACTOR_LDS_RT(N, BF16, RT, lds);
+  __shared__ __attribute__((aligned(16))) float4 ns[16 * RT];  // post-step (vx, vy, px, py) of every row, exchanged inside a wave
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const size_t E = (size_t)p.E;
   const size_t rows = E * N;
-  const size_t row_base = (size_t)blockIdx.x * 64;
+  const size_t row_base = (size_t)blockIdx.x * (16 * RT);
 
-  // the row this lane owns in the head and in the physics: rl = 16w + (l&15); only part 0 (l < 16) writes
-  const int rl = 16 * w + (lane & 15);
-  const bool part0 = (lane >> 4) == 0;
+  // the row this lane owns in the head and in the physics: rl = 16w + (l&15); only part 0 (l < 16) of the waves w < RT writes
+  // Which waves own rows: w < RT -- and, for two-tile workgroups, waves 2, 3 in every other group of 256 workgroups.  Wave w of a
+  // workgroup runs on SIMD w of its CU, and two such workgroups share a CU once a batch has more than 256 of them (workgroup b and
+  // b + 256, as the dispatcher fills the chip): the head and the physics of both would otherwise pile up on SIMDs 0 and 1 while
+  // SIMDs 2 and 3 idle for 60 % of every tick (stamped build, profiles/r04_policy_row_tiles.txt).  Speed only: results do not
+  // depend on the placement.
+#ifndef CM3_POLICY_SHIFT_BIT
+#define CM3_POLICY_SHIFT_BIT 8     // (macro: build variant for the measurement)
+#endif
+  const int wr = RT == 2 ? ((w + 2 * (int)((blockIdx.x >> CM3_POLICY_SHIFT_BIT) & 1u)) & 3) : w;
+  const bool row_wave = wr < RT;
+  const int rl = row_wave ? 16 * wr + (lane & 15) : (lane & 15);
+  const bool part0 = (lane >> 4) == 0 && row_wave;
   size_t r = row_base + rl;
   const bool row_ok = r < rows;
   r = row_ok ? r : rows - 1;
@@ -63,7 +79,7 @@ template <int N, int BF16> __global__ void __launch_bounds__(256) k_policy_rollo
   const bool head_lane = writer && i == 0;
 
   // ---- once per launch: weights, live counters, the input tile ---------------------------------------------------------
-  actor_stage_tables<N, BF16>(lds, q.packed, tid);
+  actor_stage_tables<N, BF16, RT>(lds, q.packed, tid);
   ActorB<N, BF16> b;
   actor_load_b<N, BF16>(q.packed, w, lane, b);
   const int2 meta = reinterpret_cast<const int2 *>(p.meta_in)[e];
@@ -87,16 +103,21 @@ template <int N, int BF16> __global__ void __launch_bounds__(256) k_policy_rollo
   __syncthreads();
   ActorHeadB hb;
   actor_head_load(lds.wout, lane, hb);      // output-layer operands of this lane, once per launch
+  ActorFirstB<N> f1;                        // ... and its first-layer operands (round 4: they were re-read from LDS every tick)
+  actor_first_b<N, float>(&lds.ws_self[0][0], &lds.ws_oth[0][0], w, lane, q.stage > 1, f1);
 
   const float kDt = 0.1f, kKeep = 1.0f - 0.25f;
 #pragma unroll 1
   for (int t = 0; t < p.n_ticks; ++t) {
     // ---- policy: forward pass, probabilities and the sampled action of row rl (alg_credit.py:113-122) -----------------
-    actor_mlp<N, BF16>(lds, b, w, lane, q.stage > 1);
+    CM3_STAMP(0, false);
+    actor_mlp<N, BF16, RT>(lds, b, f1, w, lane, q.stage > 1);
+    if (row_wave) {   // (wave-uniform; no workgroup barrier inside)
     float pr[kA];
     const float u = actor_uniform(p.seed, genv, episode, steps, i);  // (Philox: VALU work between the head's dependent MFMAs)
-    actor_head_probs(lds.h2s, hb, lds.lg, w, lane, q.eps, pr);
+    actor_head_probs(lds.h2s, hb, lds.lg, wr, lane, q.eps, pr);
     const int act = actor_pick(pr, u);
+    CM3_STAMP(7, false);
     if (writer) {
       tick_ptr(p.actions, p.st_actions, t)[r] = act;
       if (q.probs) {
@@ -142,6 +163,7 @@ template <int N, int BF16> __global__ void __launch_bounds__(256) k_policy_rollo
       oth[k] = ns[rl - i + j];
     }
 
+    CM3_STAMP(8, false);
     // ---- reward / reached / collisions (multi-goal_spread.py:114-143) ----------------------------------------------------------
     float rew;
     bool reached;
@@ -209,6 +231,7 @@ template <int N, int BF16> __global__ void __launch_bounds__(256) k_policy_rollo
       if (p.collisions_tick) tick_ptr(p.collisions_tick, p.st_coll, t)[e] = collisions;
     }
 
+    CM3_STAMP(9, false);
     // ---- same-tick re-initialisation of finished episodes (CM3_FLAG_AUTO_RESET) ------------------------------------------------
     bool was_reset = false;
     if (auto_reset && done) {
@@ -243,6 +266,7 @@ template <int N, int BF16> __global__ void __launch_bounds__(256) k_policy_rollo
       }
     }
 
+    CM3_STAMP(10, false);
     // ---- trajectory stores + the LDS tile of the next tick ---------------------------------------------------------------------
     if (part0) {
       if (row_ok) {
@@ -263,7 +287,10 @@ template <int N, int BF16> __global__ void __launch_bounds__(256) k_policy_rollo
       lds.xs[rl][0] = si.x; lds.xs[rl][1] = si.y; lds.xs[rl][2] = si.z; lds.xs[rl][3] = si.w;
       lds.xs[rl][4] = gl.x; lds.xs[rl][5] = gl.y;
     }
+    CM3_STAMP(11, false);
+    }  // row_wave
     __syncthreads();  // the tile (and the h1/h2 storage) is free for the next tick's phase A
+    CM3_STAMP(12, false);
   }
 
   if (head_lane) {
@@ -275,17 +302,39 @@ template <int N, int BF16> __global__ void __launch_bounds__(256) k_policy_rollo
   }
 }
 
-template <int N> static int policy_launch(const PolicyParams &q, int prec, hipStream_t s) {
+template <int N, int RT> static int policy_launch_rt(const PolicyParams &q, int prec, hipStream_t s) {
   const size_t rows = (size_t)q.p.E * N;
-  const unsigned blocks = (unsigned)((rows + 63) / 64);
+  const unsigned blocks = (unsigned)((rows + 16 * RT - 1) / (16 * RT));
+  note_variant("k_policy_rollout", 4, N, 4, q.p.n_ticks > 1, prec, 0, 0, 0, RT);
   if (prec == kPrecF16x3)
-    hipLaunchKernelGGL((k_policy_rollout<N, kPrecF16x3>), dim3(blocks), dim3(256), 0, s, q);
+    hipLaunchKernelGGL((k_policy_rollout<N, kPrecF16x3, RT>), dim3(blocks), dim3(256), 0, s, q);
   else if (prec == kPrecBf16)
-    hipLaunchKernelGGL((k_policy_rollout<N, kPrecBf16>), dim3(blocks), dim3(256), 0, s, q);
+    hipLaunchKernelGGL((k_policy_rollout<N, kPrecBf16, RT>), dim3(blocks), dim3(256), 0, s, q);
   else
-    hipLaunchKernelGGL((k_policy_rollout<N, kPrecF32>), dim3(blocks), dim3(256), 0, s, q);
+    hipLaunchKernelGGL((k_policy_rollout<N, kPrecF32, RT>), dim3(blocks), dim3(256), 0, s, q);
   CM3_HIP_CHECK(hipGetLastError());
   return CM3_OK;
+}
+
+// Row tiles per workgroup from the batch (measured on MI355X, N = 4, f16x3, us per tick at RT = 4 / 2 / 1 --
+// profiles/r04_policy_row_tiles.txt): 2048 envs 5.0 / 3.4 / 3.8, 4096 envs (C2) 4.82 / 4.60 / 6.9, 8192 envs 7.04 / 8.83 / 13.3,
+// 65536 envs 48.8 / 70 / 102.  A lone workgroup per CU is latency-bound and the smaller one is faster (fewer matrix instructions
+// per wave and tick); once a CU holds several, the 64-row workgroup does the most work per instruction issued.  So: 64-row
+// workgroups when they already give every CU more than one, else 32-row ones, 16-row ones below a quarter of that.
+// CM3_POLICY_RT = 1 | 2 | 4 overrides the choice (measurements only).
+constexpr size_t kPolicyCus = 256;
+template <int N> static int policy_launch(const PolicyParams &q, int prec, hipStream_t s) {
+  const size_t rows = (size_t)q.p.E * N, wg64 = (rows + 63) / 64;
+  int rt = wg64 > kPolicyCus ? 4 : (wg64 > kPolicyCus / 4 ? 2 : 1);
+  if (const char *e = getenv("CM3_POLICY_RT")) {
+    const int v = atoi(e);
+    if (v == 1 || v == 2 || v == 4) rt = v;
+  }
+  switch (rt) {
+    case 1: return policy_launch_rt<N, 1>(q, prec, s);
+    case 2: return policy_launch_rt<N, 2>(q, prec, s);
+  }
+  return policy_launch_rt<N, 4>(q, prec, s);
 }
 
 }  // namespace cm3
