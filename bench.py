@@ -274,11 +274,15 @@ class CheckersTrajectoryStepper(object):
 
 
 class RolloutAdvStepper(object):
-    """BASELINE configs[3] (C4): 33-tick trajectory collection (ParticleRollout: slot copies + 33 step launches as
-    one hipGraph replay) followed by the advantage-normalisation step -- discounted returns + moments kernel, ONE
-    all-gather of 3 float64 per rank (RCCL), normalise kernel."""
+    """BASELINE configs[3] (C4): 33-tick trajectory collection followed by the advantage-normalisation step -- discounted
+    returns + moments, ONE all-gather of 3 float64 per rank and rollout (RCCL), normalisation.  The rollouts of one collection
+    phase (episodes_per_train = 10, train_onpolicy.py:359) are ONE hipGraph replay: 330 step launches + the two launches of
+    cm3_returns_normalize_segments_* for the ten rollouts' ten advantage steps (round 4; with several ranks the graph ends at the
+    ten moment triples, one all-gather carries them all).  A bench step stays one rollout + its normalisation; a number of steps
+    that is not a multiple of ten finishes on the single-rollout graph of round 3."""
 
-    def __init__(self, cfg, n_agents, n_envs, device, env_id_base=0, kernel="auto", fused=False, n_chains=1):
+    def __init__(self, cfg, n_agents, n_envs, device, env_id_base=0, kernel="auto", fused=False, n_chains=1,
+                 phase_rollouts=PHASE_EPISODES):
         import torch
         from cm3_amd.particle import VecParticleEnv
         from cm3_amd.rollout import ParticleRollout
@@ -286,7 +290,13 @@ class RolloutAdvStepper(object):
         self.env = VecParticleEnv(cfg, n_agents, 0.2, EP_TICKS, n_envs, device=device, dtype=torch.float32, auto_reset=True,
                                   env_id_base=env_id_base, kernel=kernel)
         self.env.reset()
-        self.ro = ParticleRollout(self.env, n_ticks=EP_TICKS, use_graph=True, fused=fused, n_chains=n_chains)
+        self.K = int(phase_rollouts)
+        self.ro = ParticleRollout(self.env, n_ticks=EP_TICKS * self.K, use_graph=True, fused=fused, n_chains=n_chains)
+        self.ro1 = ParticleRollout(self.env, n_ticks=EP_TICKS, use_graph=True, fused=fused, n_chains=n_chains)
+        # set-up, not a step: both graphs are captured here, so that no capture (milliseconds) lands in a timed region whatever
+        # the warm-up / step counts are
+        self.ro.collect_normalized(gamma=0.99, segments=self.K)
+        self.ro1.collect_normalized(gamma=0.99)
         self.device = self.env.device
         self.last = None
         self.launches_per_tick = int(n_chains)
@@ -297,15 +307,19 @@ class RolloutAdvStepper(object):
 
     def run(self, n_ticks):
         assert n_ticks % EP_TICKS == 0, "c4 runs whole 33-tick rollouts"
-        for _ in range(n_ticks // EP_TICKS):
-            # one rank: slot copies + 33 step launches + returns / moments + normalise = ONE hipGraph replay; several ranks:
-            # the graph ends at the moments, the 24-byte all-gather (RCCL) and the normalise launch follow
-            *self.last, t_coll = self.ro.collect_normalized(gamma=0.99, time_collective=True)
+        phases, rest = divmod(n_ticks // EP_TICKS, self.K)
+        for _ in range(phases):
+            *self.last, t_coll = self.ro.collect_normalized(gamma=0.99, time_collective=True, segments=self.K)
+            self.collective_s += t_coll
+            self.rollouts += self.K
+        for _ in range(rest):
+            *self.last, t_coll = self.ro1.collect_normalized(gamma=0.99, time_collective=True)
             self.collective_s += t_coll
             self.rollouts += 1
 
     def close(self):
         self.ro.close()
+        self.ro1.close()
 
 
 WORKLOADS = {
@@ -622,7 +636,7 @@ def measure_other_config(name, args, device, steps=6, cpu_budget_s=6.0):
              "c4": "k_particle_step_pairs<float,4,4,false,plain> (+ k_returns_partials_keep + k_fold_normalize per rollout)"}[name]
     rec = {
         "workload": "%s, %d vectorised envs, max_steps=33, auto-reset, trajectory mode incl. terminal capture, one step-kernel "
-                    "launch per tick, %s" % (wl_desc, E, "one hipGraph replay per 33-tick rollout + advantage normalisation"
+                    "launch per tick, %s" % (wl_desc, E, "one hipGraph replay per phase of 10 rollouts x 33 ticks + their advantage normalisations"
                                              if kind == "particle_adv" else "hipGraph of %d ticks per replay" % tps),
         "envs_per_gpu": E, "n_agents": N, "dtype": dtype_name, "steps": steps, "ticks_per_step": tps, "ticks_timed": K,
         "ms_per_step": wall / steps * 1e3, "us_per_tick": launch_s * 1e6, "env_steps_per_s": E / launch_s, "live_state": live,
@@ -820,7 +834,8 @@ def main():
     out = None
     if rank == 0:
         if kind == "particle_adv":
-            launch_desc = "hipGraph of %d ticks per rollout" % EP_TICKS
+            launch_desc = ("hipGraph of %d rollouts x %d ticks + their advantage steps per replay (one collection phase)"
+                           % (PHASE_EPISODES, EP_TICKS))
         elif args.no_graph:
             launch_desc = "eager launches"
         else:
@@ -866,10 +881,11 @@ def main():
             out["rccl_world_size"] = rccl["rccl_world_size"]
         if kind == "particle_adv":
             out["collective"] = {
-                "what": "all_gather_into_tensor of 3 float64 per rank (advantage moments), once per rollout",
+                "what": "all_gather_into_tensor of 3 float64 per rank and rollout (advantage moments); the %d rollouts of a phase "
+                        "travel in ONE collective" % PHASE_EPISODES,
                 "host_us_per_rollout_rank0": stepper.collective_s / max(stepper.rollouts, 1) * 1e6,
                 "share_of_step_rank0": stepper.collective_s / max(wall, 1e-12),
-                "note": ("one rank: the collective is the identity and the whole rollout + normalisation is ONE hipGraph replay"
+                "note": ("one rank: the collective is the identity and a whole phase (10 rollouts + their normalisations) is ONE hipGraph replay"
                          if world == 1 else "host time of the all-gather call (enqueue + any wait it implies), rank 0")}
     traffic_tag = {("c2", 4096, "trajectory"): "c2_trajectory_n4_e4096", ("c2", 4096, "in-place"): "c2_particle_antipodal_n4_e4096",
                    ("c3", 8192, "in-place"): "c3_checkers_stage2_n2_e8192", ("c3", 8192, "trajectory"): "c3_trajectory_n2_e8192",

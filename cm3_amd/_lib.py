@@ -176,6 +176,17 @@ SYMBOLS = {
                                                  c_int32, c_int32, c_int32, c_double, c_double, c_int32, c_void_p, c_void_p]),
     "cm3_returns_normalize_f64": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                  c_int32, c_int32, c_int32, c_double, c_double, c_int32, c_void_p, c_void_p]),
+    "cm3_returns_segments_scratch_bytes": (c_size_t, [c_int32]),
+    "cm3_returns_normalize_segments_f32": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                          c_int32, c_int32, c_int32, c_int32, c_double, c_double, c_int32, c_void_p,
+                                                          c_void_p]),
+    "cm3_returns_normalize_segments_f64": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                          c_int32, c_int32, c_int32, c_int32, c_double, c_double, c_int32, c_void_p,
+                                                          c_void_p]),
+    "cm3_normalize_segments_f32": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_size_t, c_int32,
+                                                  c_double, c_int32, c_void_p]),
+    "cm3_normalize_segments_f64": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_size_t, c_int32,
+                                                  c_double, c_int32, c_void_p]),
     "cm3_copy_list": (ctypes.c_int, [c_int32, P(c_void_p), P(c_void_p), P(c_size_t), c_void_p]),
     "cm3_hbm_read_bench": (ctypes.c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
     "cm3_hbm_bench_sink_words": (ctypes.c_int, []),

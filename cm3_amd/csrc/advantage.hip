@@ -117,16 +117,25 @@ __global__ void __launch_bounds__(kAdvBlock) k_returns_moments(const R *__restri
 // x <- (x - mean) / (std + eps) with the statistics of ALL ranks: `parts` holds n_parts (sum, sum of squares, count)
 // triples (this rank's, or the all-gathered ones), summed here in rank order -- every rank computes identical values.
 // stats (optional) receives (mean, std, count).
+// Segments (blockIdx.y; round 4): x is n_seg consecutive slabs of n_elem elements -- the rollouts of one collection phase -- each
+// normalised with its OWN statistics; parts is [n_parts ranks][n_seg][3] (what one all-gather of every rank's [n_seg][3] delivers),
+// stats [n_seg][3].  One segment = the original call.
 template <typename R>
 __global__ void __launch_bounds__(kAdvBlock) k_normalize(R *__restrict__ x, const uint8_t *__restrict__ valid,
                                                          const double *__restrict__ parts, int n_parts,
                                                          double *__restrict__ stats, size_t n_elem, int C, double eps,
                                                          int apply) {
+  const int seg = blockIdx.y, n_seg = gridDim.y;
+  x += (size_t)seg * n_elem;
+  if (valid) valid += (size_t)seg * (n_elem / C);
+  if (stats) stats += 3 * seg;
+  parts += 3 * seg;
+  const int rs = 3 * n_seg;   // stride between two ranks' triples of this segment
   double tot0 = parts[0], tot1 = parts[1], tot2 = parts[2];
   for (int r = 1; r < n_parts; ++r) {
-    tot0 = tot0 + parts[3 * r + 0];
-    tot1 = tot1 + parts[3 * r + 1];
-    tot2 = tot2 + parts[3 * r + 2];
+    tot0 = tot0 + parts[rs * r + 0];
+    tot1 = tot1 + parts[rs * r + 1];
+    tot2 = tot2 + parts[rs * r + 2];
   }
   const double cnt = tot2 > 1.0 ? tot2 : 1.0;
   const double mean = tot0 / cnt;
@@ -228,8 +237,16 @@ __global__ void __launch_bounds__(kAdvBlock) k_returns_partials(const R *__restr
                                                                 const uint8_t *__restrict__ valid, R *__restrict__ out,
                                                                 double *__restrict__ partials, int T, int E, int C, R gamma,
                                                                 const CopyShift cs) {
-  copy_shift_run(cs);
+  if (blockIdx.y == 0) copy_shift_run(cs);
   const size_t cols = (size_t)E * C;
+  {  // segment blockIdx.y: T ticks of the time-major arrays starting at tick blockIdx.y * T; its partials follow the previous segment's
+    const size_t seg = blockIdx.y;
+    x += seg * T * cols;
+    out += seg * T * cols;
+    done += seg * T * (size_t)E;
+    if (valid) valid += seg * T * (size_t)E;
+    partials += seg * 3 * gridDim.x;
+  }
   double s = 0.0, s2 = 0.0, n = 0.0;
   for (size_t col = (size_t)blockIdx.x * kAdvBlock + threadIdx.x; col < cols; col += (size_t)gridDim.x * kAdvBlock) {
     const size_t e = col / C;
@@ -278,6 +295,14 @@ __global__ void __launch_bounds__(kAdvBlock) k_returns_partials_keep(const R *__
                                                                      int col_blocks, const CopyShift cs) {
   static_assert(TK <= 64, "done / valid are kept as bit masks");
   const size_t cols = (size_t)E * C;
+  {  // segment blockIdx.y (see k_returns_partials)
+    const size_t seg = blockIdx.y;
+    x += seg * T * cols;
+    out += seg * T * cols;
+    done += seg * T * (size_t)E;
+    if (valid) valid += seg * T * (size_t)E;
+    partials += seg * 3 * gridDim.x;
+  }
   const size_t col = (size_t)blockIdx.x * kAdvBlock + threadIdx.x;
   const bool act = (int)blockIdx.x < col_blocks && col < cols;
   const size_t cc = act ? col : 0, e = cc / C;
@@ -297,7 +322,7 @@ __global__ void __launch_bounds__(kAdvBlock) k_returns_partials_keep(const R *__
 #pragma unroll
       for (int t = 0; t < TK; ++t) vm |= (unsigned long long)(vs[t] != 0) << t;
     }
-    copy_shift_run(cs);   // while the column is in flight
+    if (blockIdx.y == 0) copy_shift_run(cs);   // while the column is in flight
 #pragma unroll
     for (int t = 0; t < TK; ++t) dm |= (unsigned long long)(ds[t] != 0) << t;
   }
@@ -326,6 +351,14 @@ __global__ void __launch_bounds__(kAdvBlock) k_fold_normalize(R *__restrict__ x,
                                                               const double *__restrict__ partials, int n_partials,
                                                               double *__restrict__ moments, double *__restrict__ stats,
                                                               size_t n_elem, int C, double eps, int apply) {
+  {  // segment blockIdx.y: its slab of n_elem returns, its n_partials partial triples, its moments / stats
+    const size_t seg = blockIdx.y;
+    x += seg * n_elem;
+    if (valid) valid += seg * (n_elem / C);
+    partials += seg * 3 * n_partials;
+    moments += 3 * seg;
+    if (stats) stats += 3 * seg;
+  }
   __shared__ double tot[3];
   if (threadIdx.x < 64) {
     double fs = 0.0, fs2 = 0.0, fn = 0.0;
@@ -374,9 +407,10 @@ __global__ void __launch_bounds__(kAdvBlock) k_fold_normalize(R *__restrict__ x,
 template <typename R>
 static int returns_normalize(const void *x, const uint8_t *done, const uint8_t *valid, void *out, void *scratch,
                              double *moments, double *stats, int T, int E, int C, double gamma, double eps, int apply,
-                             const cm3_copy_shift *shift, void *stream) {
+                             const cm3_copy_shift *shift, void *stream, int n_seg = 1) {
   CM3_REQUIRE(x && done && out && scratch && moments, "null pointer");
   CM3_REQUIRE(T >= 1 && E >= 1 && C >= 1, "T, E, C must be positive");
+  CM3_REQUIRE(n_seg >= 1 && n_seg <= 4096, "n_segments must be in 1..4096");
   CopyShift cs;
   memset(&cs, 0, sizeof(cs));
   if (shift) {
@@ -399,18 +433,18 @@ static int returns_normalize(const void *x, const uint8_t *done, const uint8_t *
   int n_partials;
   if (T <= kKeepTicks && blocks <= kAdvMaxBlocks) {
     n_partials = cs.n > 0 && blocks < kKeepCopyBlocks ? kKeepCopyBlocks : blocks;
-    hipLaunchKernelGGL((k_returns_partials_keep<R, kKeepTicks>), dim3(n_partials), dim3(kAdvBlock), 0, s, (const R *)x, done, valid,
+    hipLaunchKernelGGL((k_returns_partials_keep<R, kKeepTicks>), dim3(n_partials, n_seg), dim3(kAdvBlock), 0, s, (const R *)x, done, valid,
                        (R *)out, (double *)scratch, T, E, C, (R)gamma, blocks, cs);
   } else {
     n_partials = blocks > kAdvMaxBlocks ? kAdvMaxBlocks : blocks;
-    hipLaunchKernelGGL((k_returns_partials<R>), dim3(n_partials), dim3(kAdvBlock), 0, s, (const R *)x, done, valid, (R *)out,
+    hipLaunchKernelGGL((k_returns_partials<R>), dim3(n_partials, n_seg), dim3(kAdvBlock), 0, s, (const R *)x, done, valid, (R *)out,
                        (double *)scratch, T, E, C, (R)gamma, cs);
   }
   CM3_HIP_CHECK(hipGetLastError());
   const size_t n_elem = (size_t)T * cols;
   size_t nblocks = apply ? (n_elem + kAdvBlock - 1) / kAdvBlock : 1;
   if (nblocks > 2048) nblocks = 2048;
-  hipLaunchKernelGGL((k_fold_normalize<R>), dim3((unsigned)nblocks), dim3(kAdvBlock), 0, s, (R *)out, valid,
+  hipLaunchKernelGGL((k_fold_normalize<R>), dim3((unsigned)nblocks, n_seg), dim3(kAdvBlock), 0, s, (R *)out, valid,
                      (const double *)scratch, n_partials, moments, stats, n_elem, C, eps, apply);
   CM3_HIP_CHECK(hipGetLastError());
   return CM3_OK;
@@ -436,13 +470,14 @@ static int returns_moments(const void *x, const uint8_t *done, const uint8_t *va
 
 template <typename R>
 static int normalize(void *x, const uint8_t *valid, const double *parts, int n_parts, double *stats, size_t n_elem, int C,
-                     double eps, int apply, void *stream) {
+                     double eps, int apply, void *stream, int n_seg = 1) {
   CM3_REQUIRE(parts && n_parts >= 1, "null moments / n_parts < 1");
+  CM3_REQUIRE(n_seg >= 1 && n_seg <= 4096, "n_segments must be in 1..4096");
   CM3_REQUIRE(!apply || x, "null pointer");
   CM3_REQUIRE(n_elem >= 1 && C >= 1, "n_elem and C must be positive");
   size_t blocks = apply ? (n_elem + kAdvBlock - 1) / kAdvBlock : 1;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL((k_normalize<R>), dim3((unsigned)blocks), dim3(kAdvBlock), 0, (hipStream_t)stream, (R *)x, valid,
+  hipLaunchKernelGGL((k_normalize<R>), dim3((unsigned)blocks, n_seg), dim3(kAdvBlock), 0, (hipStream_t)stream, (R *)x, valid,
                      parts, n_parts, stats, n_elem, C, eps, apply);
   CM3_HIP_CHECK(hipGetLastError());
   return CM3_OK;
@@ -477,6 +512,27 @@ int cm3_returns_normalize_f64(const void *x, const uint8_t *done, const uint8_t 
                               double *moments, double *stats, int32_t T, int32_t E, int32_t C, double gamma, double eps,
                               int32_t apply, const cm3_copy_shift *shift, void *stream) {
   return cm3::returns_normalize<double>(x, done, valid, out, scratch, moments, stats, T, E, C, gamma, eps, apply, shift, stream);
+}
+size_t cm3_returns_segments_scratch_bytes(int32_t n_segments) {
+  return (size_t)(n_segments < 1 ? 1 : n_segments) * cm3::kAdvMaxBlocks * 3 * sizeof(double) + 16;
+}
+int cm3_returns_normalize_segments_f32(const void *x, const uint8_t *done, const uint8_t *valid, void *out, void *scratch,
+                                       double *moments, double *stats, int32_t T, int32_t n_segments, int32_t E, int32_t C,
+                                       double gamma, double eps, int32_t apply, const cm3_copy_shift *shift, void *stream) {
+  return cm3::returns_normalize<float>(x, done, valid, out, scratch, moments, stats, T, E, C, gamma, eps, apply, shift, stream, n_segments);
+}
+int cm3_returns_normalize_segments_f64(const void *x, const uint8_t *done, const uint8_t *valid, void *out, void *scratch,
+                                       double *moments, double *stats, int32_t T, int32_t n_segments, int32_t E, int32_t C,
+                                       double gamma, double eps, int32_t apply, const cm3_copy_shift *shift, void *stream) {
+  return cm3::returns_normalize<double>(x, done, valid, out, scratch, moments, stats, T, E, C, gamma, eps, apply, shift, stream, n_segments);
+}
+int cm3_normalize_segments_f32(void *x, const uint8_t *valid, const double *parts, int32_t n_parts, int32_t n_segments, double *stats,
+                               size_t n_elem, int32_t C, double eps, int32_t apply, void *stream) {
+  return cm3::normalize<float>(x, valid, parts, n_parts, stats, n_elem, C, eps, apply, stream, n_segments);
+}
+int cm3_normalize_segments_f64(void *x, const uint8_t *valid, const double *parts, int32_t n_parts, int32_t n_segments, double *stats,
+                               size_t n_elem, int32_t C, double eps, int32_t apply, void *stream) {
+  return cm3::normalize<double>(x, valid, parts, n_parts, stats, n_elem, C, eps, apply, stream, n_segments);
 }
 int cm3_copy_list(int32_t n, void *const *dst, const void *const *src, const size_t *bytes, void *stream) {
   using namespace cm3;

@@ -412,14 +412,19 @@ class ParticleRollout(object):
         self.collected = True
         return self
 
-    def collect_normalized(self, gamma=0.99, eps=1e-8, normalize=True, group=None, time_collective=False):
+    def collect_normalized(self, gamma=0.99, eps=1e-8, normalize=True, group=None, time_collective=False, segments=1):
         """Random-action collection (continuous mode) FOLLOWED by the advantage-normalisation step over reward_n -- BASELINE
         configs[3]: discounted returns + this rank's float64 moments, ONE 24-byte all-gather over the ranks, normalisation
         with the global statistics (cm3_amd.shard).  With one rank the collective is the identity and the whole step --
         slot copy in, T step launches, slot copy out, returns + moments, normalise -- is ONE hipGraph replay; with several
         ranks the graph ends at the moments, the all-gather and the normalise launch follow eagerly (RCCL / gloo).
         Returns (normalised returns [T,E,N], (mean, std, count) device scalars); with time_collective=True also the seconds
-        the host spent in the all-gather call (0.0 for one rank)."""
+        the host spent in the all-gather call (0.0 for one rank).
+        segments = K > 1 (round 4): the T ticks are K consecutive rollouts of T / K ticks -- one collection phase
+        (train_onpolicy.py:359: episodes_per_train rollouts between two training steps) -- each with its own returns and its own
+        normalisation statistics ((mean, std, count) become [K] tensors); the K advantage steps are the same two launches at the
+        end of ONE chain of T step launches, the whole phase one hipGraph replay, and with several ranks the K moment triples
+        travel in ONE all-gather.  Values per rollout are bit-identical to K calls with segments = 1 on a T / K-tick collector."""
         import time
         from .shard import ReturnsNormalizer, gather_moments
         import torch.distributed as dist
@@ -427,10 +432,10 @@ class ParticleRollout(object):
         if not self.auto_reset or self.fused or self.n_chains != 1:
             raise Cm3Error("collect_normalized runs the continuous, one-launch-per-tick random-action collection")
         world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
-        key = (float(gamma), float(eps), bool(normalize), world > 1)
+        key = (float(gamma), float(eps), bool(normalize), world > 1, int(segments))
         if getattr(self, "_norm_key", None) != key:
             self._drop_norm_graph()
-            self._norm = ReturnsNormalizer(self.reward_n, self.done, gamma, eps, normalize)
+            self._norm = ReturnsNormalizer(self.reward_n, self.done, gamma, eps, normalize, segments=segments)
             self._norm_key = key
         self._finished0 = None
         es = self.state.element_size()
@@ -463,9 +468,10 @@ class ParticleRollout(object):
             _copy_pairs(pairs, s)
             self._enqueue(0, self.T, flags, s, live=live)
             _copy_pairs(back, s)
-            self._norm.enqueue_moments(s)
             if world == 1:
-                self._norm.enqueue_normalize(s)
+                self._norm.enqueue_fused(s)        # (= enqueue_moments + enqueue_normalize on the own moments, bit for bit)
+            else:
+                self._norm.enqueue_moments(s)
 
         stream = env._stream()
         if self.use_graph:
@@ -481,7 +487,8 @@ class ParticleRollout(object):
             t_coll = time.perf_counter() - t0
             self._norm.enqueue_normalize(stream, parts, n_parts)
         self.collected = True
-        res = (self._norm.out, (self._norm.stats[0], self._norm.stats[1], self._norm.stats[2]))
+        st = self._norm.stats
+        res = (self._norm.out, (st[0], st[1], st[2]) if st.dim() == 1 else (st[:, 0], st[:, 1], st[:, 2]))
         return res + (t_coll,) if time_collective else res
 
     def _drop_norm_graph(self):

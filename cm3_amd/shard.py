@@ -48,12 +48,12 @@ def gather_moments(m, group=None):
     if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
         return m, 1
     world = dist.get_world_size(group)
-    m = m.contiguous()
+    m = m.contiguous().view(-1)          # [3], or [n_segments * 3]: the rollouts of a phase travel in ONE collective
     if m.device.type == "cuda" and dist.get_backend(group) == "gloo":
-        host = torch.empty(world * 3, dtype=torch.float64)
+        host = torch.empty(world * m.numel(), dtype=torch.float64)
         dist.all_gather_into_tensor(host, m.cpu(), group=group)
         return host.to(m.device), world
-    parts = torch.empty(world * 3, dtype=torch.float64, device=m.device)
+    parts = torch.empty(world * m.numel(), dtype=torch.float64, device=m.device)
     dist.all_gather_into_tensor(parts, m, group=group)
     return parts, world
 
@@ -141,34 +141,44 @@ def normalized_returns(reward, done, valid=None, gamma=0.99, eps=1e-8, group=Non
 class ReturnsNormalizer(object):
     """normalized_returns() with PERSISTENT buffers and separately enqueueable halves, so that a collector can capture
     `collect -> returns + moments -> (all-gather) -> normalise` into hipGraphs (ParticleRollout.collect_normalized):
-        enqueue_moments(stream)            cm3_returns_moments_*  -> self.out (returns), self.moments (this rank's triple)
+        enqueue_moments(stream)            returns -> self.out, this rank's triple(s) -> self.moments
         enqueue_normalize(stream, parts)   cm3_normalize_* over `parts` (self.moments itself when there is one rank)
-    reward [T,E] or [T,E,C] float32/float64 and done uint8 [T,E] are the trajectory's own tensors (read in place)."""
+        enqueue_fused(stream, shift)       both for ONE rank, two launches (+ the rollout's slot bookkeeping)
+    reward [T,E] or [T,E,C] float32/float64 and done uint8 [T,E] are the trajectory's own tensors (read in place).
+    segments = K > 1: the trajectory holds K consecutive rollouts of T / K ticks (one collection phase); every rollout gets its
+    own returns (zero beyond its last tick), moments [K,3] and statistics [K,3] -- the K rollouts' advantage steps are the SAME
+    two launches (cm3_returns_normalize_segments_*), and with several ranks ONE all-gather of K triples."""
 
-    def __init__(self, reward, done, gamma=0.99, eps=1e-8, normalize=True):
+    def __init__(self, reward, done, gamma=0.99, eps=1e-8, normalize=True, segments=1):
         from . import _lib
         if reward.device.type != "cuda" or not reward.is_contiguous() or done.dtype != torch.uint8 or not done.is_contiguous():
             raise _lib.Cm3Error("ReturnsNormalizer needs contiguous device tensors (reward float, done uint8)")
         self._lib_mod, self.lib = _lib, _lib.lib()
         self.reward, self.done = reward, done
-        self.T, self.E = int(reward.shape[0]), int(reward.shape[1])
+        self.K = int(segments)
+        if self.K < 1 or int(reward.shape[0]) % self.K:
+            raise _lib.Cm3Error("segments must divide the %d ticks of the trajectory" % int(reward.shape[0]))
+        self.T, self.E = int(reward.shape[0]) // self.K, int(reward.shape[1])      # T = ticks per segment
         self.C = 1 if reward.dim() == 2 else int(reward.shape[2])
         self.suffix = {torch.float32: "f32", torch.float64: "f64"}[reward.dtype]
         self.gamma, self.eps, self.apply = float(gamma), float(eps), 1 if normalize else 0
         self.out = torch.empty_like(reward)
-        self.buf = torch.zeros(6, dtype=torch.float64, device=reward.device)
-        self.moments, self.stats = self.buf[0:3], self.buf[3:6]
-        self.scratch = torch.zeros(self.lib.cm3_returns_scratch_bytes() // 8, dtype=torch.float64, device=reward.device)
+        self.buf = torch.zeros(2, self.K, 3, dtype=torch.float64, device=reward.device)
+        self.moments, self.stats = self.buf[0], self.buf[1]                      # [K, 3] each
+        if self.K == 1:
+            self.moments, self.stats = self.buf[0, 0], self.buf[1, 0]            # [3]: the single-rollout interface
+        self.scratch = torch.zeros(self.lib.cm3_returns_segments_scratch_bytes(self.K) // 8, dtype=torch.float64,
+                                   device=reward.device)
 
     def enqueue_moments(self, stream):
-        self._lib_mod.check(getattr(self.lib, "cm3_returns_moments_" + self.suffix)(
-            self.reward.data_ptr(), self.done.data_ptr(), 0, self.out.data_ptr(), self.scratch.data_ptr(),
-            self.moments.data_ptr(), self.T, self.E, self.C, self.gamma, stream))
+        if self.K == 1:
+            self._lib_mod.check(getattr(self.lib, "cm3_returns_moments_" + self.suffix)(
+                self.reward.data_ptr(), self.done.data_ptr(), 0, self.out.data_ptr(), self.scratch.data_ptr(),
+                self.moments.data_ptr(), self.T, self.E, self.C, self.gamma, stream))
+        else:       # returns + per-segment moments, nothing applied (the all-gather and cm3_normalize_segments_* follow)
+            self._segments_call(stream, None, 0)
 
-    def enqueue_fused(self, stream, shift=None):
-        """enqueue_moments + enqueue_normalize on this rank's own moments (cm3_returns_normalize_*: two launches, the first of them
-        in one memory round trip for T <= 40), bit for bit; shift: optional list of up to 4 (first_dst, mid, last_src) tensor
-        triples -- first_dst <- mid, then mid <- last_src, done by the first launch (include/cm3_amd.h cm3_copy_shift)."""
+    def _segments_call(self, stream, shift, apply):
         cs = None
         if shift:
             cs = self._lib_mod.CopyShift()
@@ -177,16 +187,22 @@ class ReturnsNormalizer(object):
                 cs.first_dst[r], cs.mid[r], cs.last_src[r] = a.data_ptr(), m.data_ptr(), c.data_ptr()
                 cs.bytes[r] = m.numel() * m.element_size()
         import ctypes
-        self._lib_mod.check(getattr(self.lib, "cm3_returns_normalize_" + self.suffix)(
+        self._lib_mod.check(getattr(self.lib, "cm3_returns_normalize_segments_" + self.suffix)(
             self.reward.data_ptr(), self.done.data_ptr(), 0, self.out.data_ptr(), self.scratch.data_ptr(),
-            self.moments.data_ptr(), self.stats.data_ptr(), self.T, self.E, self.C, self.gamma, self.eps, self.apply,
+            self.moments.data_ptr(), self.stats.data_ptr(), self.T, self.K, self.E, self.C, self.gamma, self.eps, int(apply),
             ctypes.byref(cs) if cs is not None else None, stream))
+
+    def enqueue_fused(self, stream, shift=None):
+        """enqueue_moments + enqueue_normalize on this rank's own moments (two launches, the first of them in one memory round
+        trip for T <= 40), bit for bit; shift: optional list of up to 4 (first_dst, mid, last_src) tensor triples -- first_dst <-
+        mid, then mid <- last_src, done by the first launch (include/cm3_amd.h cm3_copy_shift)."""
+        self._segments_call(stream, shift, self.apply)
 
     def enqueue_normalize(self, stream, parts=None, n_parts=1):
         parts = self.moments if parts is None else parts
-        self._lib_mod.check(getattr(self.lib, "cm3_normalize_" + self.suffix)(
-            self.out.data_ptr(), 0, parts.data_ptr(), int(n_parts), self.stats.data_ptr(), self.out.numel(), self.C,
-            self.eps, self.apply, stream))
+        self._lib_mod.check(getattr(self.lib, "cm3_normalize_segments_" + self.suffix)(
+            self.out.data_ptr(), 0, parts.data_ptr(), int(n_parts), self.K, self.stats.data_ptr(),
+            self.out.numel() // self.K, self.C, self.eps, self.apply, stream))
 
 
 _SCRATCH = {}

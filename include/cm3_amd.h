@@ -476,6 +476,26 @@ int cm3_returns_normalize_f32(const void *x, const uint8_t *done, const uint8_t 
 int cm3_returns_normalize_f64(const void *x, const uint8_t *done, const uint8_t *valid, void *out, void *scratch,
                               double *moments, double *stats, int32_t T, int32_t E, int32_t C, double gamma, double eps,
                               int32_t apply, const cm3_copy_shift *shift, void *stream);
+/* The same two launches for n_segments consecutive rollouts of ONE collection phase (ABI 5; train_onpolicy.py:359: episodes_per_train
+ * rollouts between two training steps): x / out are time-major over n_segments * T ticks, done / valid likewise; segment k = ticks
+ * [k T, (k + 1) T) has its own returns (G = 0 beyond its last tick), moments[k][3] and stats[k][3] and is normalised with its own
+ * statistics -- bit for bit what n_segments calls of cm3_returns_normalize_* on the slices give.  A phase of K rollouts is then ONE
+ * chain of K T step launches + 2, and one hipGraph replay, instead of K chains of T + 2 and K replay boundaries.
+ * scratch >= cm3_returns_segments_scratch_bytes(n_segments); `shift` is applied once (by segment 0's blocks).
+ * apply = 0 leaves the raw returns in `out` and only fills moments / stats: the multi-rank form, followed by ONE all-gather of every
+ * rank's moments[n_segments][3] and cm3_normalize_segments_* with parts = [n_parts ranks][n_segments][3]. */
+size_t cm3_returns_segments_scratch_bytes(int32_t n_segments);
+int cm3_returns_normalize_segments_f32(const void *x, const uint8_t *done, const uint8_t *valid, void *out, void *scratch,
+                                       double *moments, double *stats, int32_t T, int32_t n_segments, int32_t E, int32_t C,
+                                       double gamma, double eps, int32_t apply, const cm3_copy_shift *shift, void *stream);
+int cm3_returns_normalize_segments_f64(const void *x, const uint8_t *done, const uint8_t *valid, void *out, void *scratch,
+                                       double *moments, double *stats, int32_t T, int32_t n_segments, int32_t E, int32_t C,
+                                       double gamma, double eps, int32_t apply, const cm3_copy_shift *shift, void *stream);
+/* x: n_segments slabs of n_elem elements; parts [n_parts][n_segments][3]; stats (optional) [n_segments][3]. */
+int cm3_normalize_segments_f32(void *x, const uint8_t *valid, const double *parts, int32_t n_parts, int32_t n_segments, double *stats,
+                               size_t n_elem, int32_t C, double eps, int32_t apply, void *stream);
+int cm3_normalize_segments_f64(void *x, const uint8_t *valid, const double *parts, int32_t n_parts, int32_t n_segments, double *stats,
+                               size_t n_elem, int32_t C, double eps, int32_t apply, void *stream);
 /* Up to 8 device-to-device copies (16-byte aligned pointers and sizes) in ONE launch: trajectory slot <-> live env buffers
  * of the collection loop (train_onpolicy.py:340-343 "state = next_state" across rollouts). */
 int cm3_copy_list(int32_t n, void *const *dst, const void *const *src, const size_t *bytes, void *stream);

@@ -258,3 +258,72 @@ def test_c4_shards_moments_combine_to_the_single_process_statistics():
     assert abs(float(stats[0]) - whole["stats"][0]) <= 1e-12 * abs(whole["stats"][0])
     assert abs(float(stats[1]) - whole["stats"][1]) <= 1e-12 * abs(whole["stats"][1])
     assert torch.allclose(torch.cat(normed, dim=1), whole["out"], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("E,N,cfg_name", [(777, 4, "particle_stage2_cross"), (300, 2, "particle_stage2_merge")])
+def test_collect_normalized_segments_equal_rollout_by_rollout(E, N, cfg_name):
+    """K rollouts of one collection phase in ONE hipGraph replay (collect_normalized(segments=K): K T step launches + the two
+    launches of cm3_returns_normalize_segments_*) against K replays of the single-rollout graph on a twin env: trajectories,
+    per-rollout normalised returns and statistics, the env left behind -- bit for bit, phase after phase."""
+    import cm3_amd
+    from cm3_amd.particle import VecParticleEnv
+    from cm3_amd.rollout import ParticleRollout
+    cfg = cm3_amd.load_config(cfg_name)
+    K, S = 5, 9
+    envs = [VecParticleEnv(cfg, N, 0.2, 7, E, device="cuda:0", auto_reset=True, seed=4242) for _ in range(2)]
+    for e in envs:
+        e.reset()
+    a = ParticleRollout(envs[0], n_ticks=K * S, use_graph=True)
+    b = ParticleRollout(envs[1], n_ticks=S, use_graph=True)
+    for phase in range(3):
+        out, (mean, std, cnt) = a.collect_normalized(gamma=0.97, segments=K)
+        assert tuple(mean.shape) == (K,)
+        for k in range(K):
+            o1, (m1, s1, n1) = b.collect_normalized(gamma=0.97)
+            sl = slice(k * S, (k + 1) * S)
+            assert torch.equal(out[sl], o1), (phase, k)
+            assert float(mean[k]) == float(m1) and float(std[k]) == float(s1) and float(cnt[k]) == float(n1) == float(S * E * N)
+            for name in ("actions", "reward_n", "reward", "done", "collisions"):
+                assert torch.equal(getattr(a, name)[sl], getattr(b, name)), (phase, k, name)
+            d = b.done.bool()                  # terminal captures are written where an episode ended (stale elsewhere)
+            assert int(d.sum()) > 0
+            assert torch.equal(a.term_state[sl].permute(0, 2, 1, 3)[d], b.term_state.permute(0, 2, 1, 3)[d]), (phase, k)
+            assert torch.equal(a.term_obs_others[sl][d], b.term_obs_others[d]), (phase, k)
+            for name in ("state", "obs_others", "goals"):
+                assert torch.equal(getattr(a, name)[k * S:(k + 1) * S + 1], getattr(b, name)), (phase, k, name)
+        assert torch.equal(envs[0].global_state, envs[1].global_state), phase
+        assert torch.equal(envs[0].get_obs()[1], envs[1].get_obs()[1]) and torch.equal(envs[0].goals, envs[1].goals)
+        assert torch.equal(envs[0].steps, envs[1].steps) and torch.equal(envs[0].episode, envs[1].episode)
+    raw, _ = a.collect_normalized(gamma=0.97, segments=K, normalize=False)        # (another key re-captures)
+    assert float(raw.abs().max()) > 1.0
+    a.close()
+    b.close()
+
+
+def test_two_rank_segmented_phase_on_one_gpu(tmp_path):
+    """world size 2, K = 3 rollouts per phase: each rank's graph ends at its K moment triples, ONE all-gather carries them
+    (gloo group, both ranks on cuda:0), cm3_normalize_segments_* applies the global statistics per rollout.  Both ranks must hold
+    identical statistics, equal to the single process's over all envs (to the last bits of the different summation trees), and the
+    normalised shards must be the single process's columns."""
+    import cm3_amd
+    from cm3_amd.particle import VecParticleEnv
+    from cm3_amd.rollout import ParticleRollout
+    E, K = 1000 + 24, 3
+    r = _torchrun(2, [os.path.join("tests", "workers", "two_rank_adv_worker.py"), str(tmp_path), str(E), str(K)])
+    assert r.returncode == 0, r.stderr[-3000:]
+    parts = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % k)) for k in range(2)]
+    for key in ("mean", "std", "count"):
+        assert torch.equal(parts[0][key], parts[1][key]), key
+    assert parts[0]["count"].tolist() == [float(11 * E * 4)] * K
+    cfg = cm3_amd.load_config("particle_stage2_cross")
+    env = VecParticleEnv(cfg, 4, 0.2, 33, E, device="cuda:0", auto_reset=True, seed=12341)
+    env.reset()
+    ro = ParticleRollout(env, n_ticks=11 * K, use_graph=True)
+    for rep in range(2):
+        out, (mean, std, cnt) = ro.collect_normalized(gamma=0.99, segments=K)
+    assert torch.equal(torch.cat([p["reward_n"] for p in parts], dim=1).cuda(), ro.reward_n)
+    assert torch.allclose(parts[0]["mean"].cuda(), mean, rtol=1e-12, atol=0) and torch.allclose(parts[0]["std"].cuda(), std, rtol=1e-12, atol=0)
+    assert torch.allclose(torch.cat([p["norm"] for p in parts], dim=1).cuda(), out, rtol=1e-6, atol=1e-6)
+    tot = parts[0]["moments"] + parts[1]["moments"]
+    assert torch.allclose(tot.cuda(), ro._norm.moments, rtol=1e-12, atol=0)
+    ro.close()

@@ -26,6 +26,20 @@ def main():
     cfg = cm3_amd.load_config("particle_stage2_cross")
     env = VecParticleEnv(cfg, 4, 0.2, 33, count, device="cuda:0", auto_reset=True, env_id_base=base, seed=12341)
     env.reset()
+    if len(sys.argv) > 3:
+        # the collector's own multi-rank path: K rollouts of 11 ticks in one hipGraph (graph ends at the K moment triples), ONE
+        # all-gather of K x 3 float64 per rank, cm3_normalize_segments_* over [world][K][3]
+        K = int(sys.argv[3])
+        ro = ParticleRollout(env, n_ticks=11 * K, use_graph=True)
+        for rep in range(2):          # the second call replays the captured graph
+            out, (mean, std, cnt) = ro.collect_normalized(gamma=0.99, segments=K)
+        torch.cuda.synchronize()
+        torch.save({"reward_n": ro.reward_n.cpu(), "done": ro.done.cpu(), "norm": out.cpu(), "mean": mean.cpu(), "std": std.cpu(),
+                    "count": cnt.cpu(), "moments": ro._norm.moments.cpu(), "base": base, "n": count},
+                   os.path.join(out_dir, "rank%d.pt" % rank))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     ro = ParticleRollout(env, n_ticks=33, use_graph=True).collect(reset=False)
     out, (mean, std, cnt) = normalized_returns(ro.reward_n, ro.done, None, gamma=0.99)
     torch.cuda.synchronize()
