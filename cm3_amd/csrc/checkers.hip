@@ -55,6 +55,8 @@ struct CheckersParams {
   const uint8_t *reset_mask;
   int grid_rec, obst_rec;        // payload bytes per env of grid / obs_self_t
   int grid_stride, obst_stride;  // bytes between consecutive env records (>= payload)
+  // the observation of a FRESH episode (fast kernel, N <= 2; filled by the host, ck_fresh_fill): see CkFresh
+  alignas(16) uint32_t fresh[104];
   // tick loop inside one launch (CM3_FLAG_FUSED_TICKS, fast kernel only): tick t uses <pointer> + t * <stride in
   // bytes>; the observation pointers then address slot 1 of their trajectories.  n_ticks == 1 with zero strides
   // is the plain one-launch-per-tick step.
@@ -891,11 +893,14 @@ template <int N, int G> struct CkLanePlan {
 // the wave's private copy of kCkBoardTab in LDS (48 x 16 bytes, written by lanes 0..47) and the lane's plan: ALL loads are
 // requested before the first of them is waited for (the LDS write placed right behind its load made the wave wait for the table
 // before it had even requested its plan: a second memory round trip on the critical path)
-template <int N, int G> __device__ __forceinline__ void ckf_plan_load(int g, int lane, uint4 *lds_tab, CkLanePlan<N, G> &pl) {
+template <int N, int G> __device__ __forceinline__ void ckf_plan_load(int g, int lane, uint4 *lds_tab, CkLanePlan<N, G> &pl,
+                                                                      uint4 *lds_fresh = nullptr, const uint4 *fresh_src = nullptr) {
   using T = CkPlanTab<N>;
   using P = CkLanePlan<N, G>;
   const CkPlanTab<N> *tab = &kCkPlanTab<N>;
   const uint4 board_vec = reinterpret_cast<const uint4 *>(&kCkBoardTab)[lane < 48 ? lane : 47];
+  uint4 fresh_vec = make_uint4(0u, 0u, 0u, 0u);
+  if (fresh_src) fresh_vec = fresh_src[lane < 26 ? lane : 25];   // (the fresh-episode record, CkFresh: 26 vectors at most)
   uint4 c01[P::NSLOT], c23[P::NSLOT], gv[P::NGV];
 #pragma unroll
   for (int it = 0; it < P::NSLOT; ++it) {
@@ -909,6 +914,7 @@ template <int N, int G> __device__ __forceinline__ void ckf_plan_load(int g, int
     gv[it] = *reinterpret_cast<const uint4 *>(&tab->gv[j < T::NGV ? j : T::NGV][0]);
   }
   if (lane < 48) lds_tab[lane] = board_vec;
+  if (lds_fresh && lane < 26) lds_fresh[lane] = fresh_vec;
 #pragma unroll
   for (int it = 0; it < P::NSLOT; ++it) {
     const uint32_t w0[4] = {c01[it].x, c01[it].z, c23[it].x, c23[it].z}, w1[4] = {c01[it].y, c01[it].w, c23[it].y, c23[it].w};
@@ -933,12 +939,129 @@ template <int N, int G> __device__ __forceinline__ void ckf_plan_load(int g, int
   }
 }
 
-template <int N, bool NT = false, int G = kCkG>
+// ---- the observation of a fresh episode as a constant record (round 4) ---------------------------------------------------------
+// A Checkers env restarts from a state that is a constant of (geometry, start cells) -- and, for N = 1, of the goal bit, which picks
+// the start row (checkers.py:265-291 / ck_init).  With auto-reset a wave that held ONE finished env used to run the whole emit twice
+// (terminal observation, then the observation of the reset state), and a launch lasts as long as its slowest wave: 3.35 -> 3.52 us
+// per tick at C3, 4.02 with rare resets (profiles/r03_checkers_table_emit.txt, end).  Now the host works the fresh observation out
+// once per call (ck_fresh_fill: the expressions of the emit on the start state), it travels in the kernel-argument segment, every
+// wave stages it into LDS in the shadow of its state loads, and a finished env's lanes COPY it to the slot (11 dword stores per
+// lane at N = 2); the one emit of such a wave writes the terminal slot for finished envs and the regular slot for the others.
+// Layout (dwords): obs_self_t payload | grid (14) | vec | obs_self_v | obs_others, padded to 16 bytes; N = 1: two variants (goal 0, 1).
+template <int N> struct CkFresh {
+  static constexpr bool kOn = N <= 2;
+  static constexpr int NO = N > 1 ? N - 1 : 1;
+  static constexpr int OD = (75 * N + 3) / 4, GD = 14, VD = 4 * N, SD = 8 * N, XD = 4 * N * NO;
+  static constexpr int oObst = 0, oGrid = OD, oVec = oGrid + GD, oSelf = oVec + VD, oOth = oSelf + SD, FD = oOth + XD;
+  static constexpr int FDP = (FD + 3) / 4 * 4, NVAR = N == 1 ? 2 : 1;
+  static constexpr int VECS = FDP * NVAR / 4;   // 16-byte vectors a wave stages
+  static_assert(!kOn || FDP * NVAR <= 104, "CheckersParams::fresh");
+};
+
+constexpr CkBoardTab kCkBoardTabHost = CkBoardTab();
+
+// host: the fresh observation(s) of this call's configuration into p.fresh (fast geometry: 3 x 8 band, n_obs 2)
+static void ck_fresh_fill(CheckersParams &p, int n) {
+  memset(p.fresh, 0, sizeof(p.fresh));
+  if (n > 2) return;
+  const int NO = n > 1 ? n - 1 : 1;
+  const int OD = (75 * n + 3) / 4, oGrid = OD, oVec = oGrid + 14, oSelf = oVec + 4 * n, oOth = oSelf + 8 * n, FD = oOth + 4 * n * NO;
+  const int FDP = (FD + 3) / 4 * 4;
+  for (int var = 0; var < (n == 1 ? 2 : 1); ++var) {
+    uint32_t *rec = p.fresh + var * FDP;
+    int r[2], c[2];
+    for (int i = 0; i < n; ++i) {
+      r[i] = p.start_r[i];
+      c[i] = p.start_c[i];
+    }
+    if (n == 1) r[0] = (var == 0 ? 0 : 2) + 2;     // ck_init: the goal picks the start row
+    uint8_t *ob = reinterpret_cast<uint8_t *>(rec);
+    for (int i = 0; i < n; ++i)                      // get_obs (checkers.py:97-109): 5 x 5 x 3 window, nothing collected yet
+      for (int dr = 0; dr < 5; ++dr)
+        for (int dc = 0; dc < 5; ++dc) {
+          const int rr = r[i] - 2 + dr, cc = c[i] - 2 + dc;
+          const uint32_t en = kCkBoardTabHost.board[rr * 16 + cc];
+          bool agent = false;
+          for (int a = 0; a < n; ++a) agent = agent || (r[a] == rr && c[a] == cc);
+          uint8_t *cell = ob + ((i * 25 + dr * 5 + dc) * 3);
+          cell[0] = (uint8_t)(en & 0xffu);
+          cell[1] = (uint8_t)((en >> 8) & 0xffu);
+          cell[2] = (uint8_t)(((en >> 16) & 0xffu) | ((agent && !(dr == 2 && dc == 2)) ? 0xffu : 0u));
+        }
+    uint8_t *gr = reinterpret_cast<uint8_t *>(rec + oGrid);   // get_valid_grid (checkers.py:66-76): 3 x 9 cells x 2 channels
+    for (int k = 0; k < 3; ++k)
+      for (int j = 0; j < 8; ++j) gr[(k * 9 + j) * 2 + ((k + j) & 1)] = 0xffu;
+    for (int i = 0; i < n; ++i) {
+      rec[oVec + 4 * i + 0] = (uint32_t)r[i];
+      rec[oVec + 4 * i + 1] = (uint32_t)c[i];
+      double v[4] = {kCkBoardTabHost.norm[r[i]], kCkBoardTabHost.norm[7 + c[i]], kCkBoardTabHost.norm[20], kCkBoardTabHost.norm[20]};
+      memcpy(rec + oSelf + 8 * i, v, 32);
+      for (int k = 0; k < NO; ++k) {
+        const int a = n > 1 ? (k < i ? k : k + 1) : 0;
+        double o[2] = {kCkBoardTabHost.norm[r[a]], kCkBoardTabHost.norm[7 + c[a]]};
+        memcpy(rec + oOth + 4 * (i * NO + k), o, 16);
+      }
+    }
+  }
+}
+
+// the explicit arguments of k_checkers_step_fast as they lie in the kernel-argument segment: gives the offset of `p`
+struct CkFastKernArgs {
+  const uint64_t *mask;
+  const uint32_t *agents;
+  const int32_t *steps;
+  const int32_t *episode;
+  const uint8_t *goals;
+  int E;
+  uint32_t flags;
+  CheckersParams p;
+};
+__device__ __forceinline__ const uint4 *ck_fresh_kernarg() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const char *args = (const char *)__builtin_amdgcn_kernarg_segment_ptr();
+  return reinterpret_cast<const uint4 *>(args + offsetof(CkFastKernArgs, p) + offsetof(CheckersParams, fresh));
+#else
+  return nullptr;
+#endif
+}
+
+// a finished env's G lanes copy the fresh record (variant var of the wave's LDS copy) to the slot `out`
+template <int N, bool NT, int G>
+__device__ __forceinline__ void ckf_fresh_copy(const CheckersParams &p, const uint4 *lds_fresh, int var, int g, uint32_t e, const CkOut &out) {
+  using FR = CkFresh<N>;
+  const uint32_t *rec = reinterpret_cast<const uint32_t *>(lds_fresh) + var * FR::FDP;
+  auto run = [&](void *base, uint32_t row, int off, int nd) {
+#pragma unroll
+    for (int d0 = 0; d0 < nd; d0 += G) {
+      const int d = d0 + g;
+      if (d < nd) ck_st<NT>(at32<uint32_t>(base, row + 4u * d), rec[off + d]);
+    }
+  };
+  run(out.obs_self_t, e * (uint32_t)p.obst_stride, FR::oObst, FR::OD);
+  run(out.grid, e * (uint32_t)p.grid_stride, FR::oGrid, FR::GD);
+  run(out.vec, e * (uint32_t)(FR::VD * 4), FR::oVec, FR::VD);
+  run(out.obs_self_v, e * (uint32_t)(FR::SD * 4), FR::oSelf, FR::SD);
+  run(out.obs_others, e * (uint32_t)(FR::XD * 4), FR::oOth, FR::XD);
+}
+
+// SEL: a lane's five observation arrays are `alt` instead of `out` where use_alt is set (the one emit of a wave that holds finished
+// envs: their terminal slot) -- the addresses then are per-lane 64-bit values instead of a uniform base plus a 32-bit lane offset,
+// which is why the common case (no finished env in the wave) keeps the plain instantiation.
+template <int N, bool NT = false, int G = kCkG, bool SEL = false>
 __device__ __forceinline__ void ckf_emit_tab(const CheckersParams &p, const CkState<N> &s, const CkLanePlan<N, G> &pl,
-                                             const uint4 *lds_tab, int g, uint32_t e, bool env_ok, const CkOut &out) {
+                                             const uint4 *lds_tab, int g, uint32_t e, bool env_ok, const CkOut &out_in,
+                                             const CkOut *alt = nullptr, bool use_alt = false) {
   using T = CkPlanTab<N>;
   using P = CkLanePlan<N, G>;
   if (!env_ok) return;
+  CkOut out = out_in;
+  if constexpr (SEL) {
+    out.grid = use_alt ? alt->grid : out.grid;
+    out.vec = use_alt ? alt->vec : out.vec;
+    out.obs_others = use_alt ? alt->obs_others : out.obs_others;
+    out.obs_self_t = use_alt ? alt->obs_self_t : out.obs_self_t;
+    out.obs_self_v = use_alt ? alt->obs_self_v : out.obs_self_v;
+  }
   const char *tab = reinterpret_cast<const char *>(lds_tab);
   const uint32_t m32 = (uint32_t)s.mask;  // 24 collected bits
   uint32_t rc[N], base[N], word[N];
@@ -1068,12 +1191,16 @@ __global__ void __launch_bounds__(256)
   CkState<N> s;
   CkLive<N> lv;
   __shared__ __attribute__((aligned(16))) uint4 lds_tab_all[4][48];
+  __shared__ __attribute__((aligned(16))) uint4 lds_fresh_all[4][CkFresh<N>::kOn ? 26 : 1];
   uint4 *lds_tab = &lds_tab_all[wave][0];
+  uint4 *lds_fresh = &lds_fresh_all[wave][0];
+  constexpr bool kFresh = CkFresh<N>::kOn;
   CM3_STAMP(0, false);
   ck_load_env<N>(hd, ec, s, lv);
   // while those loads are in flight: the wave's copy of the board / norm table and this lane's plan (see ckf_emit_tab)
   CkLanePlan<N, G> pl;
-  ckf_plan_load<N, G>(g, lane, lds_tab, pl);
+  if constexpr (kFresh) ckf_plan_load<N, G>(g, lane, lds_tab, pl, lds_fresh, (h_flags & CM3_FLAG_AUTO_RESET) ? ck_fresh_kernarg() : nullptr);
+  else ckf_plan_load<N, G>(g, lane, lds_tab, pl);
   ck_wave_sync();
   CM3_SPAN_MARK(0, true);   // loads back
   // the kernel arguments the tick needs, requested while the state loads are in flight (fetched at their first use they made
@@ -1092,11 +1219,27 @@ __global__ void __launch_bounds__(256)
                                                 );
     CM3_STAMP(4, false);
     CM3_SPAN_MARK(1, false);  // draw + agents act done
-    if (ended) {  // AUTO_RESET: terminal observation (train_onpolicy.py:336-347), then the fresh episode
-      if (p.term_grid) ckf_emit_tab<N, NT, G>(p, s, pl, lds_tab, g, e, env_ok, ck_out_term(p, t));
-      ck_restart_env<N>(p, e, ec, writer, s, lv);
+    if constexpr (kFresh) {
+      if (!__any(ended)) {
+        ckf_emit_tab<N, NT, G>(p, s, pl, lds_tab, g, e, env_ok, ck_out_tick(p, t));
+      } else {
+        // a wave with finished envs: ONE emit of the post-step state -- into the terminal slot for the finished envs (the next_*
+        // columns of their last transition, train_onpolicy.py:336-347; nowhere without terminal capture), into the regular slot
+        // for the others -- then the finished envs restart and their regular slot gets the fresh-episode record by copy (CkFresh)
+        const CkOut o_tick = ck_out_tick(p, t), o_term = ck_out_term(p, t);
+        ckf_emit_tab<N, NT, G, true>(p, s, pl, lds_tab, g, e, env_ok && (!ended || p.term_grid != nullptr), o_tick, &o_term, ended);
+        if (ended) {
+          ck_restart_env<N>(p, e, ec, writer, s, lv);
+          if (env_ok) ckf_fresh_copy<N, NT, G>(p, lds_fresh, N == 1 ? (int)lv.goal[0] : 0, g, e, o_tick);
+        }
+      }
+    } else {
+      if (ended) {  // AUTO_RESET: terminal observation (train_onpolicy.py:336-347), then the fresh episode
+        if (p.term_grid) ckf_emit_tab<N, NT, G>(p, s, pl, lds_tab, g, e, env_ok, ck_out_term(p, t));
+        ck_restart_env<N>(p, e, ec, writer, s, lv);
+      }
+      ckf_emit_tab<N, NT, G>(p, s, pl, lds_tab, g, e, env_ok, ck_out_tick(p, t));
     }
-    ckf_emit_tab<N, NT, G>(p, s, pl, lds_tab, g, e, env_ok, ck_out_tick(p, t));
     CM3_STAMP(8, false);
     CM3_SPAN_MARK(2, false);  // observation stores issued
     if (p.goals_next && writer) {
@@ -1260,6 +1403,7 @@ static int ck_fill(const cm3_checkers_desc *d, const cm3_checkers_bufs *b, const
   p.term_obs_self_v = b->term_obs_self_v;
   p.goals_next = b->goals_next;
   p.reset_mask = mask;
+  if (step && ck_fast_ok(p) && (p.flags & CM3_FLAG_AUTO_RESET)) ck_fresh_fill(p, d->n_agents);
   if (step) CM3_SPAN_SET(p);
   return CM3_OK;
 }
