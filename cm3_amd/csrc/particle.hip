@@ -649,6 +649,9 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step(const ParticlePara
         for (int i = 0; i < N; ++i) store_obs_vec<SP>(reinterpret_cast<V4 *>(p.state_copy) + ((size_t)i * E + e), s[i]);
 #pragma unroll
         for (int i = 0; i < N; ++i) reinterpret_cast<V2 *>(p.goals_copy)[(size_t)i * E + e] = g[i];
+      } else if (was_reset && p.goals_copy) {  // sparse goal slots (cm3_particle_traj.goals_live alone): written where an env restarts
+#pragma unroll
+        for (int i = 0; i < N; ++i) reinterpret_cast<V2 *>(p.goals_copy)[(size_t)i * E + e] = g[i];
       }
     }
 
@@ -911,6 +914,8 @@ __global__ void __launch_bounds__(WAVES * 64)
         if constexpr (LIVE) {  // live-state rollout (a compile-time variant: the others carry none of it): the slot gets a copy
           store_obs_vec<SP>(at32<V4>(p.state_copy, (row_i + e) * (uint32_t)sizeof(V4)), si);
           *at32<V2>(p.goals_copy, (row_i + e) * (uint32_t)sizeof(V2)) = gl;
+        } else if constexpr (!FUSED) {
+          if (was_reset && p.goals_copy) *at32<V2>(p.goals_copy, (row_i + e) * (uint32_t)sizeof(V2)) = gl;   // sparse goal slots
         }
       }
       // observation (multi-goal_spread.py:145-154): vector (i,k) of env e; lanes of a wave cover whole records
@@ -1135,6 +1140,8 @@ __global__ void __launch_bounds__(WAVES * 64)
         if constexpr (LIVE) {  // live-state rollout (a compile-time variant: the others carry none of it): the slot gets a copy
           store_obs_vec<SP>(at32<V4>(p.state_copy, (row_i + e) * (uint32_t)sizeof(V4)), si);
           *at32<V2>(p.goals_copy, (row_i + e) * (uint32_t)sizeof(V2)) = gl;
+        } else if constexpr (!FUSED) {
+          if (fresh_goals && p.goals_copy) *at32<V2>(p.goals_copy, (row_i + e) * (uint32_t)sizeof(V2)) = gl;   // sparse goal slots
         }
       }
     };
@@ -1445,6 +1452,8 @@ __global__ void __launch_bounds__(WAVES * 64)
       if constexpr (LIVE) {
         store_obs_vec<SP>(at32<V4>(p.state_copy, (row_i + e) * (uint32_t)sizeof(V4)), si);
         *at32<V2>(p.goals_copy, (row_i + e) * (uint32_t)sizeof(V2)) = gl;
+      } else {
+        if (fresh_goals && p.goals_copy) *at32<V2>(p.goals_copy, (row_i + e) * (uint32_t)sizeof(V2)) = gl;   // sparse goal slots
       }
     }
   };
@@ -1924,8 +1933,8 @@ static int particle_rollout(const cm3_particle_desc *d, const cm3_particle_traj 
   CM3_REQUIRE(n_ticks >= 1, "n_ticks must be >= 1");
   CM3_REQUIRE(t->state && t->goals && t->obs_others && t->actions && t->reward_n && t->reward && t->done && t->meta,
               "rollout: trajectory base pointers are required");
-  CM3_REQUIRE((t->state_live == nullptr) == (t->goals_live == nullptr), "rollout: state_live and goals_live go together");
-  CM3_REQUIRE(!t->state_live || (t->state_stride != 0 && t->goals_stride != 0),
+  CM3_REQUIRE(!t->state_live || t->goals_live, "rollout: state_live needs goals_live (goals_live alone = sparse goal slots)");
+  CM3_REQUIRE(!t->goals_live || (t->goals_stride != 0 && (!t->state_live || t->state_stride != 0)),
               "rollout: live buffers are for slot trajectories (state_stride / goals_stride must be non-zero)");
   auto at = [](void *base, size_t stride, int k) -> void * {
     return base ? (void *)((char *)base + stride * (size_t)k) : nullptr;
@@ -1973,10 +1982,11 @@ static int particle_rollout(const cm3_particle_desc *d, const cm3_particle_traj 
     cm3_particle_bufs b;
     memset(&b, 0, sizeof(b));
     const bool live = t->state_live != nullptr;
+    const bool sparse_goals = !live && t->goals_live != nullptr;   // goals live in place, slot k + 1 only where an env restarts
     b.state_in = live ? t->state_live : at(t->state, t->state_stride, k);
     b.state_out = live ? t->state_live : at(t->state, t->state_stride, k + 1);
-    b.goals_in = live ? t->goals_live : at(t->goals, t->goals_stride, k);
-    b.goals_out = live ? t->goals_live : at(t->goals, t->goals_stride, k + 1);
+    b.goals_in = (live || sparse_goals) ? t->goals_live : at(t->goals, t->goals_stride, k);
+    b.goals_out = (live || sparse_goals) ? t->goals_live : at(t->goals, t->goals_stride, k + 1);
     b.meta_in = t->meta;
     b.meta_out = t->meta;
     b.episode = t->episode;
@@ -1994,6 +2004,8 @@ static int particle_rollout(const cm3_particle_desc *d, const cm3_particle_traj 
     p.flags |= obs_store_nt(t->obs_others_stride, n_ticks);
     if (live) {
       p.state_copy = at(t->state, t->state_stride, k + 1);
+      p.goals_copy = at(t->goals, t->goals_stride, k + 1);
+    } else if (sparse_goals) {
       p.goals_copy = at(t->goals, t->goals_stride, k + 1);
     }
     rc = launch<R>(p, d->n_agents, kStep, (hipStream_t)stream);

@@ -120,7 +120,7 @@ class ParticleRollout(object):
     """
 
     def __init__(self, env, n_ticks=None, use_graph=True, fused=False, n_chains=1, record_collisions=True,
-                 fused_policy_tick=False, live_state=None, policy_mode="auto"):
+                 fused_policy_tick=False, live_state=None, policy_mode="auto", sparse_goals=None):
         self.env = env
         self.T = int(n_ticks or env.max_steps)
         self.use_graph = bool(use_graph)
@@ -147,6 +147,13 @@ class ParticleRollout(object):
         # live_state: None = by size (see collect); True / False force stepping in place on the env's buffers with slot copies /
         # chaining the ticks through the slots.  Identical trajectories either way (tests/test_gpu_rollout.py).
         self.live_state = live_state
+        # sparse_goals: random-action collection at streaming sizes writes a goals slot only where an env restarts (landmarks move
+        # only at an episode start; cm3_particle_traj.goals_live alone) instead of all of them every tick -- 7 % of the bytes of a
+        # tick that runs at the chip's copy rate (profiles/r04_trajectory_stream.txt).  None = by size (see collect), True / False
+        # force it.  `goals` (and as_reference_batch) look the same either way: the dense array is filled in on first access.
+        self.sparse_goals = sparse_goals
+        self._goals_sparse = False
+        self._goal_src = None
         self.n_chains = int(n_chains)
         if not (1 <= self.n_chains <= 16):
             raise Cm3Error("n_chains must be in 1..16")
@@ -161,11 +168,11 @@ class ParticleRollout(object):
         self.done = z(T, E, d=torch.uint8)
         self.auto_reset = env.auto_reset
         if self.auto_reset:
-            self.goals = z(T + 1, N, E, 2)
+            self._goals_buf = z(T + 1, N, E, 2)
             self.term_state = z(T, N, E, 4)
             self.term_obs_others = z(T, E, N, L)
         else:
-            self.goals = None
+            self._goals_buf = None
             self.term_state = self.term_obs_others = None
         # scenario.collisions after every tick, before any same-launch reset: the per-episode value the reference reads
         # at train_onpolicy.py:356 sits at the tick that ends the episode
@@ -193,7 +200,7 @@ class ParticleRollout(object):
             self._finished &= ~m
 
     # ---- plumbing ------------------------------------------------------------------------------------
-    def _traj(self, t0=0, live=False):
+    def _traj(self, t0=0, live=False, sparse_goals=False):
         """live: per-tick launches step IN PLACE on the env's own state / goals buffers and write every tick's state / goals
         to its slot as a copy (cm3_particle_traj.state_live): a tick then loads lines its predecessor read and overwrote
         instead of a fresh slot that was only ever written -- 0.19 us of 2.83 per tick at C2 (tools/trajectory_gap.py)."""
@@ -205,9 +212,11 @@ class ParticleRollout(object):
             t.goals_live = env._goals.data_ptr()
         t.state = self.state[t0].data_ptr()
         t.state_stride = N * E * 4 * es
-        if self.goals is not None:
-            t.goals = self.goals[t0].data_ptr()
+        if self._goals_buf is not None:
+            t.goals = self._goals_buf[t0].data_ptr()
             t.goals_stride = N * E * 2 * es
+            if sparse_goals:
+                t.goals_live = env._goals.data_ptr()
         else:
             t.goals = env._goals.data_ptr()
             t.goals_stride = 0
@@ -233,10 +242,10 @@ class ParticleRollout(object):
             t.collisions_stride = E * 4
         return t
 
-    def _enqueue(self, t0, n, flags, stream=None, chains=False, live=False):
+    def _enqueue(self, t0, n, flags, stream=None, chains=False, live=False, sparse_goals=False):
         env = self.env
         env._desc.flags = flags
-        traj = self._traj(t0, live)
+        traj = self._traj(t0, live, sparse_goals)
         stream = env._stream() if stream is None else stream
         if chains and self.n_chains > 1:
             fn = getattr(self._lib, "cm3_particle_rollout_chains_" + env._suffix)
@@ -255,7 +264,7 @@ class ParticleRollout(object):
         b.state_in = env._state[env._cur].data_ptr()
         b.state_out = self.state[1].data_ptr()
         b.goals_in = env._goals.data_ptr()
-        b.goals_out = self.goals[1].data_ptr() if self.goals is not None else env._goals.data_ptr()
+        b.goals_out = self._goals_buf[1].data_ptr() if self._goals_buf is not None else env._goals.data_ptr()
         b.meta_in = b.meta_out = env._meta.data_ptr()
         b.episode = env._episode.data_ptr()
         b.actions = self.actions[0].data_ptr()
@@ -279,8 +288,8 @@ class ParticleRollout(object):
     def _load_slot0(self):
         env = self.env
         pairs = [(self.state[0], env._state[env._cur]), (self.obs_others[0], env._obs_others[env._cur])]
-        if self.goals is not None:
-            pairs.append((self.goals[0], env._goals))
+        if self._goals_buf is not None:
+            pairs.append((self._goals_buf[0], env._goals))
         self._copy(pairs)
 
     def _store_back(self, live=False):
@@ -288,8 +297,8 @@ class ParticleRollout(object):
         pairs = [(env._obs_others[env._cur], self.obs_others[self.T])]
         if not live:    # (live: the env's state / goals buffers ARE the final state)
             pairs.append((env._state[env._cur], self.state[self.T]))
-            if self.goals is not None:
-                pairs.append((env._goals, self.goals[self.T]))
+            if self._goals_buf is not None and not self._goals_sparse:     # (sparse goal slots: the live goals array is current)
+                pairs.append((env._goals, self._goals_buf[self.T]))
         self._copy(pairs)
 
     # ---- collection ------------------------------------------------------------------------------------
@@ -299,7 +308,7 @@ class ParticleRollout(object):
         env = self.env
         live = self._live
         for t in range(self.T):
-            goals = self.goals[t] if self.goals is not None else env._goals
+            goals = self._goals_buf[t] if self._goals_buf is not None else env._goals
             actor.enqueue(env.E, self.obs_others[t], self.state[t], goals, env._meta, env._episode, self.actions[t],
                           epsilon, stream=stream, env_id_base=env.env_id_base)
             self._enqueue(t, 1, base_flags, stream, live=live)
@@ -348,8 +357,15 @@ class ParticleRollout(object):
         policy_episode = dev_policy and (self.fused or (self.policy_mode in ("auto", "episode") and env.n in (1, 2, 4, 8)
                                                         and getattr(policy, "seed", None) == env.seed and self.n_chains == 1
                                                         and not self.fused_policy_tick))
-        live = self._live = (self.goals is not None and small and not self.fused and not policy_episode
+        live = self._live = (self._goals_buf is not None and small and not self.fused and not policy_episode
                              and not (self.fused_policy_tick and policy is not None))
+        # sparse goal slots: the random-action branch, one launch per tick, slot-chained, at streaming sizes (or when forced)
+        stream_size = env.E * env.n * env.L * es * self.T >= (128 << 20)
+        sparse = (policy is None and self._goals_buf is not None and not self.fused and not live and self.n_chains == 1 and
+                  bool(stream_size if self.sparse_goals is None else self.sparse_goals))
+        if sparse != self._goals_sparse and self._graph is not None:
+            self._drop_graphs()
+        self._goals_sparse, self._goal_src = sparse, None
         if self._live_cur != env._cur:    # captured graphs may hold the address of the env's current buffers (env.step() flips them)
             if live:
                 self._drop_graphs()
@@ -362,11 +378,11 @@ class ParticleRollout(object):
                 self._enqueue(0, self.T, flags | _lib.FLAG_FUSED_TICKS, chains=True)
             elif self.use_graph:
                 if self._graph is None:
-                    self._graph = _lib.capture_graph(env.device,
-                                                     lambda s: self._enqueue(0, self.T, flags, s, chains=True, live=live))
+                    self._graph = _lib.capture_graph(env.device, lambda s: self._enqueue(0, self.T, flags, s, chains=True, live=live,
+                                                                                         sparse_goals=sparse))
                 _lib.check(self._lib.cm3_graph_launch(self._graph, env._stream()))
             else:
-                self._enqueue(0, self.T, flags, chains=True, live=live)
+                self._enqueue(0, self.T, flags, chains=True, live=live, sparse_goals=sparse)
         elif hasattr(policy, "enqueue") and hasattr(policy, "act"):      # on-device actor (cm3_amd.actor)
             if env.dtype != torch.float32:
                 raise Cm3Error("the device actor reads float32 env buffers")
@@ -402,7 +418,7 @@ class ParticleRollout(object):
                 self._enqueue_actor_rollout(policy, epsilon, base, env._stream())
         else:
             for t in range(self.T):
-                goals = (self.goals[t] if self.goals is not None else env._goals).permute(1, 0, 2)
+                goals = (self._goals_buf[t] if self._goals_buf is not None else env._goals).permute(1, 0, 2)
                 a = policy(self.obs_others[t], self.state[t].permute(1, 0, 2), goals)
                 self.actions[t].copy_(torch.as_tensor(a, device=env.device).reshape(env.E, env.n))
                 self._enqueue(t, 1, base, live=live)
@@ -438,6 +454,7 @@ class ParticleRollout(object):
             self._norm = ReturnsNormalizer(self.reward_n, self.done, gamma, eps, normalize, segments=segments)
             self._norm_key = key
         self._finished0 = None
+        self._goals_sparse, self._goal_src = False, None     # (this path writes every goals slot)
         es = self.state.element_size()
         small = env.n * env.E * 4 * es <= (1 << 20) and env.E * env.n * env.L * es * self.T >= (128 << 20)
         live = self._live = bool(small if self.live_state is None else self.live_state)
@@ -450,10 +467,10 @@ class ParticleRollout(object):
 
         def enqueue(s):
             pairs = [(self.state[0], env._state[env._cur]), (self.obs_others[0], env._obs_others[env._cur]),
-                     (self.goals[0], env._goals)]
+                     (self._goals_buf[0], env._goals)]
             back = [(env._obs_others[env._cur], self.obs_others[self.T])]
             if not live:
-                back += [(env._state[env._cur], self.state[self.T]), (env._goals, self.goals[self.T])]
+                back += [(env._state[env._cur], self.state[self.T]), (env._goals, self._goals_buf[self.T])]
             if not live and world == 1 and _pairs_aligned(pairs + back):
                 # one rank, one graph: tick 0 reads the env's buffers directly (not slot 0), and the launch that computes the
                 # returns and their partial moments also records slot 0 from the env's buffers and then leaves slot T in them --
@@ -463,7 +480,7 @@ class ParticleRollout(object):
                     self._enqueue(1, self.T - 1, flags, s, live=False)
                 self._norm.enqueue_fused(s, [(self.state[0], env._state[env._cur], self.state[self.T]),
                                              (self.obs_others[0], env._obs_others[env._cur], self.obs_others[self.T]),
-                                             (self.goals[0], env._goals, self.goals[self.T])])
+                                             (self._goals_buf[0], env._goals, self._goals_buf[self.T])])
                 return
             _copy_pairs(pairs, s)
             self._enqueue(0, self.T, flags, s, live=live)
@@ -509,6 +526,31 @@ class ParticleRollout(object):
         self._drop_graphs()
 
     # ---- views --------------------------------------------------------------------------------------------
+    @property
+    def goals(self):
+        """[T + 1, N, E, 2] landmark positions per slot (None for an episode-synchronous collector: they do not change).  After a
+        collection with sparse goal slots the array is completed here, once, on first access."""
+        if self._goals_sparse:
+            idx = self._goal_source_slots().view(self.T + 1, 1, self.env.E, 1).expand_as(self._goals_buf)
+            self._goals_buf.copy_(self._goals_buf.gather(0, idx))
+            self._goals_sparse = False
+        return self._goals_buf
+
+    @goals.setter
+    def goals(self, value):
+        self._goals_buf, self._goals_sparse = value, False
+
+    def _goal_source_slots(self):
+        """int64 [T + 1, E]: the slot that holds the goals in effect at slot t of env e -- the last slot <= t that was written
+        (slot 0, or slot k + 1 of a tick k that ended an episode)."""
+        if self._goal_src is None:
+            T, E = self.T, self.env.E
+            src = torch.zeros(T + 1, E, dtype=torch.int64, device=self.env.device)
+            ticks = torch.arange(1, T + 1, device=self.env.device, dtype=torch.int64).view(T, 1)
+            src[1:] = torch.where(self.done.bool(), ticks, torch.zeros_like(ticks))
+            self._goal_src = torch.cummax(src, dim=0).values
+        return self._goal_src
+
     @property
     def valid(self):
         """bool [T, E]"""
@@ -569,8 +611,12 @@ class ParticleRollout(object):
         ee = torch.as_tensor(ee, device=self.env.device, dtype=torch.long)
         state = self.state[tt, :, ee]                                   # [B, N, 4]
         nxt_state = self._next("state", tt, ee)
-        goals = (self.goals[tt, :, ee] if self.goals is not None
-                 else self.env._goals[:, ee].permute(1, 0, 2))          # [B, N, 2]
+        if self._goals_buf is None:
+            goals = self.env._goals[:, ee].permute(1, 0, 2)             # [B, N, 2]
+        elif self._goals_sparse:                                        # (gathered from the last written slot: nothing is filled in)
+            goals = self._goals_buf[self._goal_source_slots()[tt, ee], :, ee]
+        else:
+            goals = self._goals_buf[tt, :, ee]
         cols = dict(
             v_global=state, obs_others=self.obs_others[tt, ee], v_local=state,
             actions=self.actions[tt, ee], reward=self.reward[tt, ee], reward_local=self.reward_n[tt, ee],

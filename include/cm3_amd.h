@@ -180,6 +180,11 @@ typedef struct cm3_particle_traj {
      4096 envs x 4 agents (tools/trajectory_gap.py). */
   void *state_live;
   void *goals_live;
+  /* goals_live WITHOUT state_live (ABI 5): SPARSE goal slots.  Landmarks move only when an episode starts (multi-goal_spread.py:
+     88-91), yet a slot trajectory wrote all of them every tick: 8 N of the ~450 bytes a tick moves per env at streaming sizes, where
+     the launch runs at the chip's copy rate (profiles/r04_trajectory_stream.txt).  Here the goals live in goals_live (read and, on a
+     restart, updated in place) and slot k + 1 of `goals` is written ONLY for the envs re-initialised at tick k: the goals in effect
+     at slot t are those of the last written slot <= t (slot 0 is the caller's).  Per-tick launches only. */
 } cm3_particle_traj;
 
 int cm3_particle_rollout_f32(const cm3_particle_desc *desc, const cm3_particle_traj *traj, int32_t n_ticks,

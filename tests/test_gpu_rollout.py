@@ -442,3 +442,42 @@ def test_live_state_rollout_equals_slot_chained_rollout(kernel, N, E, use_graph)
         assert torch.equal(envs[0].get_obs()[1], envs[1].get_obs()[1])
     for ro in ros:
         ro.close()
+
+
+@pytest.mark.parametrize("kernel,N,E,cfg", [("env", 4, 3001, "particle_stage2_cross.json"), ("pair", 4, 1000, "particle_stage2_antipodal.json"),
+                                            ("agent", 8, 700, "particle_merge8.json"), ("agent", 5, 900, "particle_merge8.json"),
+                                            ("env", 2, 5000, "particle_stage2_merge.json")])
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_sparse_goal_slots_equal_dense_goal_slots(kernel, N, E, cfg, use_graph):
+    """cm3_particle_traj.goals_live alone: the goals slot of a tick is written only for the envs that restart in it (landmarks move
+    only at an episode start, multi-goal_spread.py:88-91).  Same trajectories as the dense collector; as_reference_batch gathers the
+    goals from the last written slot WITHOUT completing the array; `ro.goals` completes it on first access; the env is left alike."""
+    from cm3_amd.particle import VecParticleEnv
+    from cm3_amd.rollout import ParticleRollout
+    c = load_cfg(cfg)
+    T = 40
+    envs = [VecParticleEnv(c, N, 0.5, 7, E, device="cuda:0", auto_reset=True, seed=31, kernel=kernel) for _ in range(2)]
+    for e in envs:
+        e.reset()
+    a = ParticleRollout(envs[0], n_ticks=T, use_graph=use_graph, sparse_goals=False, live_state=False)
+    b = ParticleRollout(envs[1], n_ticks=T, use_graph=use_graph, sparse_goals=True, live_state=False)
+    for rep in range(3):
+        a.collect(reset=False)
+        b.collect(reset=False)
+        assert b._goals_sparse and not a._goals_sparse
+        tt = torch.randint(0, T, (4000,), device="cuda:0")
+        ee = torch.randint(0, E, (4000,), device="cuda:0")
+        ca, cb = a.as_reference_batch(tt, ee, numpy=False), b.as_reference_batch(tt, ee, numpy=False)
+        assert b._goals_sparse                                   # the gather did not need the dense array
+        for k in ca:
+            assert torch.equal(ca[k], cb[k]), (rep, k)
+        written = int((b._goals_buf[1:] != a._goals_buf[1:]).any(dim=1).any(dim=-1).sum())
+        assert written > 0 or rep == 0                           # the sparse buffer really is incomplete before the fill
+        assert torch.equal(a.goals, b.goals), rep                # first access completes it
+        assert not b._goals_sparse
+        for name in ("state", "obs_others", "actions", "reward_n", "done", "collisions"):
+            assert torch.equal(getattr(a, name), getattr(b, name)), (rep, name)
+        assert torch.equal(envs[0].goals, envs[1].goals) and torch.equal(envs[0].global_state, envs[1].global_state)
+    assert int(a.done.sum()) > E
+    a.close()
+    b.close()
