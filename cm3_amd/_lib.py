@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # CM3_AMD_LIB: load another build of the SAME ABI instead (tools/*_ab.py compare two builds on one box)
 LIB_PATH = os.environ.get("CM3_AMD_LIB") or os.path.join(_HERE, "libcm3_hip.so")
-MAX_AGENTS = 8
+MAX_AGENTS = 10
 ABI_VERSION = 5
 
 FLAG_AUTO_RESET = 1

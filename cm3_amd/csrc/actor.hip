@@ -604,6 +604,8 @@ static size_t packed_floats_for(int n) {
     case 6: return packed_floats<6>();
     case 7: return packed_floats<7>();
     case 8: return packed_floats<8>();
+    case 9: return packed_floats<9>();
+    case 10: return packed_floats<10>();
   }
   return 0;
 }
@@ -643,6 +645,8 @@ extern "C" int cm3_actor_particle_pack(const cm3_actor_particle_desc *d, const c
     case 6: return pack_launch<6>(p, (float *)packed, s);
     case 7: return pack_launch<7>(p, (float *)packed, s);
     case 8: return pack_launch<8>(p, (float *)packed, s);
+    case 9: return pack_launch<9>(p, (float *)packed, s);
+    case 10: return pack_launch<10>(p, (float *)packed, s);
   }
   return fail(CM3_ERR_INVALID, "n_agents %d unsupported", d->n_agents);
 }
@@ -687,6 +691,8 @@ extern "C" int cm3_actor_particle_f32(const cm3_actor_particle_desc *d, const cm
     case 6: return actor_launch<6>(p, s);
     case 7: return actor_launch<7>(p, s);
     case 8: return actor_launch<8>(p, s);
+    case 9: return actor_launch<9>(p, s);
+    case 10: return actor_launch<10>(p, s);
   }
   return fail(CM3_ERR_INVALID, "n_agents %d unsupported", d->n_agents);
 }

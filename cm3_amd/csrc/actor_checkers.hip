@@ -933,7 +933,7 @@ __global__ void __launch_bounds__(256) k_ck_actor_x3(const CkActorParams p) {
 static int ck_actor_check(const cm3_actor_checkers_desc *d) {
   using namespace ck_actor;
   CM3_REQUIRE(d, "null desc");
-  CM3_REQUIRE(d->n_agents >= 1 && d->n_agents <= CM3_MAX_AGENTS, "n_agents must be in 1..%d", CM3_MAX_AGENTS);
+  CM3_REQUIRE(d->n_agents >= 1 && d->n_agents <= 8, "Checkers actor: n_agents must be in 1..8");
   CM3_REQUIRE(d->conv_f == kConvF && d->n_conv_linear == kLin && d->n_h1 == kH1 && d->n_h2 == kH2 && d->n_actions == kA,
               "supported Checkers actor widths are conv_f 6 / conv_linear 32 / h1 256 / h2 256 / 5 actions "
               "(config_checkers_stage*.json nn block); got %d/%d/%d/%d/%d",

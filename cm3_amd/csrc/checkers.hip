@@ -1324,7 +1324,7 @@ static int ck_fill(const cm3_checkers_desc *d, const cm3_checkers_bufs *b, const
                    CheckersParams &p) {
   CM3_REQUIRE(d && b, "null desc/bufs");
   CM3_REQUIRE(d->n_envs > 0, "n_envs must be positive");
-  CM3_REQUIRE(d->n_agents >= 1 && d->n_agents <= CM3_MAX_AGENTS, "n_agents must be in 1..%d", CM3_MAX_AGENTS);
+  CM3_REQUIRE(d->n_agents >= 1 && d->n_agents <= 8, "Checkers: n_agents must be in 1..8");
   CM3_REQUIRE(d->n_rows >= 1 && d->n_rows % 2 == 1, "n_rows must be odd (checkers.py:16)");
   CM3_REQUIRE(d->n_columns >= 2 && d->n_columns % 2 == 0, "n_columns must be even (checkers.py:17)");
   CM3_REQUIRE(d->n_rows * d->n_columns <= 64, "n_rows*n_columns must be <= 64 (collected-mask width)");

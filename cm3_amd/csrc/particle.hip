@@ -238,8 +238,11 @@ template <typename R, int N> __device__ __forceinline__ R sum_agents(const R (&v
     for (int i = 1; i < N; ++i) acc = acc + v[i];
     return acc;
   } else {
-    static_assert(N == 8, "CM3_MAX_AGENTS is 8");
-    return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    static_assert(N < 16, "one block of eight accumulators, then the remainder one by one (NumPy's pairwise sum below 128 values)");
+    R acc = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+#pragma unroll
+    for (int i = 8; i < N; ++i) acc = acc + v[i];
+    return acc;
   }
 }
 
@@ -1707,7 +1710,7 @@ static int launch_one(const ParticleParams &p, ParticleOp op, hipStream_t stream
 }
 
 template <typename R, int N, int WAVES> static int launch_pairs(const ParticleParams &p, hipStream_t stream) {
-  if constexpr (N >= 2) {
+  if constexpr (N >= 2 && N <= 8) {   // (N (N - 1) pair lanes must fit a wave)
     const size_t envs_per_block = (size_t)WAVES * PairGeom<N>::EPW;
     const unsigned raw_blocks = (unsigned)(((size_t)(p.EN - p.E0) + envs_per_block - 1) / envs_per_block);
     const unsigned blocks = cm3_xcd_grid(raw_blocks);          // XCD-aware block order (common.h)
@@ -1739,7 +1742,7 @@ template <typename R, int N, int WAVES> static int launch_pairs(const ParticlePa
     CM3_HIP_CHECK(hipGetLastError());
     return CM3_OK;
   } else {
-    return fail(CM3_ERR_INVALID, "the lane-per-pair kernel needs n_agents >= 2");
+    return fail(CM3_ERR_INVALID, "the lane-per-pair kernel needs n_agents in 2..8");
   }
 }
 
@@ -1848,13 +1851,14 @@ template <typename R, int N> static int launch_n(const ParticleParams &p, Partic
     // ... and once more on the final build (max-ILP pair / agent kernels; profiles/r02_mapping_sweep_final_build.txt):
     //   N = 2: pair up to 32768 envs (16384: 2.57 / - / 2.68; 32768: 2.89 / - / 3.01); N = 6: agent from 6144 (4.27 / 4.11);
     //   N = 7, 8: agent from 4096 (N = 8: 5.12 / 4.57, N = 7: 4.73 / 4.34; at 2048 pair: 3.83 / 4.29)
-    constexpr size_t kPairMax = N == 2 ? 32768 : (N == 3 ? 24576 : (N == 4 ? 12288 : kPairsMaxEnvs));
+    constexpr size_t kPairMax = N > 8 ? 0 : (N == 2 ? 32768 : (N == 3 ? 24576 : (N == 4 ? 12288 : kPairsMaxEnvs)));
     // round 3: N = 8 with two lanes per agent (k_particle_step_agents2; profiles/r03_two_lanes_per_agent.txt) moved its crossover
     // to 2048 envs; the XCD-aware block order (common.h) then sped the pair mapping up most at exactly these sizes
     // (profiles/r03_xcd_block_order.txt; pair / agent, in place): N = 8: 2048 3.42 / 3.74, 4096 4.47 / 3.84 -> agent from 4096;
     // N = 7: 4096 4.12 / 4.31, 6144 5.03 / 4.29 -> agent from 6144; N = 6: 6144 3.86 / 4.14, 8192 4.37 / 4.11 -> agent from 8192
     // N = 5: 8192 3.86 / 4.02, 12288 4.74 / 4.42 -> agent from 10240 (profiles/r03_mapping_sweep_xcd.txt)
-    constexpr size_t kAgentLo = N == 4 ? 12289 : (N == 5 ? 10240 : (N == 6 ? 8192 : (N == 7 ? 6144 : (N == 8 ? 4096 : kInf))));
+    // N = 9, 10 (round 4; no pair mapping: N (N - 1) lanes do not fit a wave): lane per agent from 1024 envs (256 waves), as N = 8 above
+    constexpr size_t kAgentLo = N == 4 ? 12289 : (N == 5 ? 10240 : (N == 6 ? 8192 : (N == 7 ? 6144 : (N == 8 ? 4096 : (N > 8 ? 1024 : kInf)))));
     // round 3, large batches after the write-through observation stores (profiles/r03_mapping_sweep_large.txt; env / agent):
     //   N = 6: 2^17 17.7 / 17.4, 2^19 66.3 / 62.3, 2^20 125.5 / 121.9, 2^21 290 / 326   -> agent up to 1.5 M envs (was 65536)
     //   N = 7: 2^19 89 / 80, 2^20 164-170 / 153-217 (the agent mapping is bimodal there: it depends on where the allocator
@@ -1868,6 +1872,7 @@ template <typename R, int N> static int launch_n(const ParticleParams &p, Partic
     if ((size_t)p.E * N * (N - 1) * 4 * sizeof(R) >= ((size_t)1 << 32)) pairs = agents = false;
     if (p.flags & CM3_FLAG_KERNEL_LANE_PER_ENV) pairs = agents = false;
     if (p.flags & CM3_FLAG_KERNEL_LANE_PER_PAIR) { pairs = true; agents = false; }
+    if (N > 8 && pairs) return fail(CM3_ERR_INVALID, "the lane-per-pair kernel needs n_agents in 2..8");
     if (p.flags & CM3_FLAG_KERNEL_LANE_PER_AGENT) agents = true;
     if (agents) {
       const size_t waves = ((size_t)p.E + AgentGeom<(N >= 2 ? N : 2)>::EPW - 1) / AgentGeom<(N >= 2 ? N : 2)>::EPW;
@@ -1882,7 +1887,8 @@ template <typename R, int N> static int launch_n(const ParticleParams &p, Partic
       // 4 waves per workgroup (one per SIMD of a CU) measured faster than 1 or 2 from 1024 waves up
       // (tools/probes/step_timeline.hip: 4.38 vs 4.82 us at E=4096, 6.36 vs 7.32 us at E=16384, stamped build);
       // below 256 waves single-wave workgroups spread the work over more CUs.
-      const size_t waves = ((size_t)p.E + PairGeom<(N >= 2 ? N : 2)>::EPW - 1) / PairGeom<(N >= 2 ? N : 2)>::EPW;
+      constexpr int NP = (N >= 2 && N <= 8) ? N : 2;
+      const size_t waves = ((size_t)p.E + PairGeom<NP>::EPW - 1) / PairGeom<NP>::EPW;
 #ifndef CM3_PARTICLE_ILP_TU
       if constexpr (sizeof(R) == 4 && N >= 2)
         if (waves <= kIlpMaxWaves) return particle_ilp_launch_pairs_f32(p, N, waves < 256 ? 1 : CM3_PAIR_WAVES, stream);
@@ -1907,6 +1913,8 @@ template <typename R> static int launch(const ParticleParams &p, int n_agents, P
     case 6: return launch_n<R, 6>(p, op, stream);
     case 7: return launch_n<R, 7>(p, op, stream);
     case 8: return launch_n<R, 8>(p, op, stream);
+    case 9: return launch_n<R, 9>(p, op, stream);
+    case 10: return launch_n<R, 10>(p, op, stream);
   }
   return fail(CM3_ERR_INVALID, "n_agents %d unsupported", n_agents);
 }
@@ -2112,6 +2120,8 @@ int particle_ilp_launch_agents_f32(const ParticleParams &p, int n_agents, int w,
     case 6: return ilp_agents_n<6>(p, w, s);
     case 7: return ilp_agents_n<7>(p, w, s);
     case 8: return ilp_agents_n<8>(p, w, s);
+    case 9: return ilp_agents_n<9>(p, w, s);
+    case 10: return ilp_agents_n<10>(p, w, s);
   }
   return fail(CM3_ERR_INVALID, "n_agents %d unsupported", n_agents);
 }

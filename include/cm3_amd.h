@@ -48,7 +48,8 @@ extern "C" {
 
 #define CM3_ABI_VERSION 5   /* 5: cm3_last_kernel_variant; cm3_returns_moments_* takes a zero-initialised-once scratch (see there);
                                cm3_returns_normalize_*, cm3_copy_shift, cm3_source_id, actor precision 2 (all added under 4) */
-#define CM3_MAX_AGENTS 8
+#define CM3_MAX_AGENTS 10   /* the reference's make_world takes up to ten agents (its colour table, multi-goal_spread.py:7-16);
+                              8 until ABI 5.  Checkers, the lane-per-pair mapping and the fused policy rollout stay at <= 8 */
 
 #define CM3_OK 0
 #define CM3_ERR_INVALID (-1)     /* bad argument / unsupported configuration */

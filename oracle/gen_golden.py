@@ -233,6 +233,7 @@ def checkers_scripts_stage1():
 def main():
     ns = H.load_reference()
     os.makedirs(OUT_DIR, exist_ok=True)
+    only = sys.argv[1] if len(sys.argv) > 1 else None     # `gen_golden.py particle_ring`: rewrite only the fixtures with that prefix
     fixtures = {}
     # --- particle: the four reference configs + the build-defined 8-agent one --------------
     fixtures['particle_stage1_uniform'] = record_particle(ns, 'particle_stage1.json', 1, 0.2, 12341, 12, 'uniform')
@@ -246,6 +247,13 @@ def main():
     fixtures['particle_merge_greedy'] = record_particle(ns, 'particle_stage2_merge.json', 2, 0.2, 12347, 24, 'greedy')
     fixtures['particle_merge8_greedy'] = record_particle(ns, 'particle_merge8.json', 8, 0.2, 12348, 10, 'greedy')
     fixtures['particle_merge8_uniform'] = record_particle(ns, 'particle_merge8.json', 8, 0.2, 12341, 4, 'uniform')
+    # --- the reference's largest worlds (make_world takes up to 10 agents: its colour table has ten rows,
+    #     multi-goal_spread.py:7-16) on the build-defined ring config; 9 agents = its first nine entries ---------
+    fixtures['particle_ring10_greedy'] = record_particle(ns, 'particle_ring10.json', 10, 0.2, 12349, 8, 'greedy')
+    fixtures['particle_ring10_uniform'] = record_particle(ns, 'particle_ring10.json', 10, 0.2, 12341, 3, 'uniform')
+    ring = load_cfg('particle_ring10.json')
+    ring9 = dict(ring, n_agents=9, **{k: ring[k][:9] for k in ('agents_x', 'agents_y', 'landmarks_x', 'landmarks_y')})
+    fixtures['particle_ring9_greedy'] = record_particle(ns, 'particle_ring10.json[:9]', 9, 0.2, 12350, 6, 'greedy', config_override=ring9)
     # --- KAT-P1: head-on 2-agent collision -----------------------------------
     kat_cfg = dict(n_agents=2, agents_x=[-0.2, 0.2], agents_y=[0, 0], landmarks_x=[0.9, -0.9],
                    landmarks_y=[0, 0], initial_std=0)
@@ -281,6 +289,8 @@ def main():
                                                          scripts=s1, goals_list=g1)
     total = 0
     for name, arrs in fixtures.items():
+        if only and not name.startswith(only):
+            continue
         path = os.path.join(OUT_DIR, name + '.npz')
         np.savez_compressed(path, **arrs)
         sz = os.path.getsize(path)

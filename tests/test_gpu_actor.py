@@ -16,7 +16,8 @@ def _env(E, N, cfg, max_steps=33, **kw):
 
 
 @pytest.mark.parametrize("N,cfg,stage", [(4, "particle_stage2_antipodal.json", 2), (2, "particle_stage2_merge.json", 2),
-                                         (1, "particle_stage1.json", 1), (8, "particle_merge8.json", 2)])
+                                         (1, "particle_stage1.json", 1), (8, "particle_merge8.json", 2),
+                                         (10, "particle_ring10.json", 2), (9, "particle_ring10.json", 2)])
 @pytest.mark.parametrize("eps", [0.0, 0.3])
 @pytest.mark.parametrize("precision", ["f32", "f16x3"])
 def test_actor_probs_and_samples_match_oracle(N, cfg, stage, eps, precision):

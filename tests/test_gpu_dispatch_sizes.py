@@ -26,7 +26,8 @@ from tests.helpers import load_cfg
 gpu = pytest.mark.gpu       # (the table-scan test below needs no GPU and also runs in the CPU suite)
 
 CFG = {2: "particle_stage2_merge.json", 3: "particle_merge8.json", 4: "particle_stage2_cross.json", 5: "particle_merge8.json",
-       6: "particle_merge8.json", 7: "particle_merge8.json", 8: "particle_merge8.json"}
+       6: "particle_merge8.json", 7: "particle_merge8.json", 8: "particle_merge8.json", 9: "particle_ring10.json",
+       10: "particle_ring10.json"}
 ONE_WAVE_MAX = 128 * 1024          # launch_n: lane-per-env runs one wave per workgroup up to here, four above
 WT_MIN = 3 << 20                   # kWtMinObsBytes
 ILP_MAX_WAVES = 16384              # kIlpMaxWaves
@@ -44,9 +45,9 @@ def expected_variant(N, E, forced=None):
     (n_ticks = 1, no streaming flag): the fields of cm3_last_kernel_variant() that the choice determines."""
     NO = max(N - 1, 1)
     obs_bytes = E * N * NO * 16
-    pair_max = {2: 32768, 3: 24576, 4: 12288}.get(N, 16384)
-    agent_lo = {4: 12289, 5: 10240, 6: 8192, 7: 6144, 8: 4096}.get(N)
-    agent_hi = {4: 40960, 5: 40960, 6: 1572864, 7: 786432, 8: 786432}.get(N, 0)
+    pair_max = {2: 32768, 3: 24576, 4: 12288, 9: 0, 10: 0}.get(N, 16384)      # (N > 8: no pair mapping -- N (N - 1) lanes exceed a wave)
+    agent_lo = {4: 12289, 5: 10240, 6: 8192, 7: 6144, 8: 4096, 9: 1024, 10: 1024}.get(N, 1 << 62)
+    agent_hi = {4: 40960, 5: 40960, 6: 1572864, 7: 786432, 8: 786432, 9: 786432, 10: 786432}.get(N, 0)
     pairs = N >= 2 and E <= pair_max
     agents = N >= 4 and agent_lo <= E <= agent_hi
     if forced == "env":
@@ -123,13 +124,17 @@ CROSSOVERS = [
     (6, 510), (6, 8191), (6, ONE_WAVE_MAX), (6, 1572864),
     (7, 255), (7, 6143), (7, ONE_WAVE_MAX), (7, 786432),
     (8, 255), (8, 4095), (8, 16384), (8, 32768), (8, ONE_WAVE_MAX), (8, 786432),
+    # N = 9, 10: lane per env -> lane per agent (16 lanes per env); plain -> write-through rows at 3 MiB; max-ILP -> default unit at
+    # 16 384 waves of 4 envs; -> lane per env
+    (9, 1023), (9, 2730), (9, 65536), (9, 786432),
+    (10, 1023), (10, 2184), (10, 65536), (10, 786432),
 ]
 
 
 def test_the_crossover_list_covers_every_change_of_the_table():
     """The sizes below are where expected_variant() changes -- checked by scanning the table itself, so an edit of the
     restatement without an edit of CROSSOVERS fails here (no GPU work)."""
-    for N in range(2, 9):
+    for N in range(2, 11):
         marks = sorted(c for n, c in CROSSOVERS if n == N)
         probe = sorted(set([1, 2, 3] + [m + d for m in marks for d in (-1, 0, 1, 2)] +
                            [1 << k for k in range(3, 22)] + [3 << k for k in range(3, 20)] + [2 ** 21 + 1]))
@@ -187,6 +192,7 @@ def _random_states(rng, E, N, crowd=0.5):
     (8, 1000003, None),      # lane-per-env above kAgentHi
     (6, 300007, None), (7, 200003, None),
     (2, 1 << 20, None), (3, 500009, None), (5, 262147, None),
+    (10, 100003, None), (9, 20011, None), (10, 900001, None),
 ])
 def test_large_batch_builds_vs_f64_oracle_teacher_forced(N, E, forced):
     """One tick of environment.py:81-123 from injected random (crowded) float32-representable states with actions in -1..6,

@@ -57,6 +57,8 @@ def _margins(pos, landmarks):
 def test_f32_teacher_forced_vs_reference_golden(name, kernel):
     g = load_golden(name)
     m = g["meta"]
+    if kernel == "pair" and m["n_agents"] > 8:
+        pytest.skip("the lane-per-pair mapping holds N (N - 1) <= 64 lanes per env: N <= 8")
     N, Ep, T = m["n_agents"], len(g["ep_len"]), int(g["ep_len"].max())
     env = _env(m["config"], N, Ep, prob_random=m["prob_random"], kernel=kernel)
     prev_gs, prev_col = g["init_gs"], np.zeros(Ep, np.int64)
@@ -95,6 +97,8 @@ def test_f64_free_running_vs_reference_golden(name, kernel):
     """Whole episodes in the float64 instantiation, no re-injection: state, rewards, done, collisions."""
     g = load_golden(name)
     m = g["meta"]
+    if kernel == "pair" and m["n_agents"] > 8:
+        pytest.skip("the lane-per-pair mapping holds N (N - 1) <= 64 lanes per env: N <= 8")
     N, Ep, T = m["n_agents"], len(g["ep_len"]), int(g["ep_len"].max())
     env = _env(m["config"], N, Ep, dtype=torch.float64, prob_random=m["prob_random"], kernel=kernel)
     gs0 = g["init_gs"]
@@ -129,6 +133,10 @@ def test_f64_free_running_vs_reference_golden(name, kernel):
 # greedy whole-episode drift recorded but not bounded.  These are regression bounds on a characterised quantity, NOT a
 # parity claim: parity is the per-tick teacher-forced 1e-5 test above and the float64 free-running test.
 DRIFT32_T10 = 2e-5          # first 10 free-running ticks, every fixture (measured max 7.3e-6)
+# Round 4: the 9- / 10-agent ring fixtures (every path crosses the centre; greedy policy: all agents pressed against each other from
+# tick ~5 on) measured 3.4e-5 after 10 ticks -- the same chaotic multi-body contact as merge8_greedy, reached earlier.  Their bar
+# at that horizon is set from the measurement, like the others; per-tick parity (1e-5) and float64 free-running parity hold on them.
+DRIFT32_T10_RING_GREEDY = 1e-4
 DRIFT32_RANDOM = 1e-4       # whole episode, random-action fixtures (measured max 1.8e-5)
 
 
@@ -157,6 +165,8 @@ def test_f32_free_running_drift_vs_reference_golden(name, kernel):
     fixture's numbers are written to gpurun_out/f32_free_running_drift.txt before anything asserts."""
     g = load_golden(name)
     m = g["meta"]
+    if kernel == "pair" and m["n_agents"] > 8:
+        pytest.skip("the lane-per-pair mapping holds N (N - 1) <= 64 lanes per env: N <= 8")
     N, Ep, T = m["n_agents"], len(g["ep_len"]), int(g["ep_len"].max())
     env = _env(m["config"], N, Ep, prob_random=m["prob_random"], kernel=kernel)
     gs0 = g["init_gs"]
@@ -187,7 +197,8 @@ def test_f32_free_running_drift_vs_reference_golden(name, kernel):
         if not np.array_equal(env.collisions.cpu().numpy()[safe], g["collisions"][safe, t]):
             failures.append(("collisions", t))
     _record_drift(name, kernel, worst, worst_rew, worst10, n_safe, n_live)
-    assert np.isfinite(worst) and worst10 < DRIFT32_T10, (name, worst10)
+    t10 = DRIFT32_T10_RING_GREEDY if (greedy and name.startswith("particle_ring")) else DRIFT32_T10
+    assert np.isfinite(worst) and worst10 < t10, (name, worst10)
     if not greedy:
         assert worst < DRIFT32_RANDOM, (name, worst)
         assert worst_rew < 2 * DRIFT32_RANDOM, (name, worst_rew)     # |d dist| <= sqrt(2) |d pos|
@@ -267,10 +278,13 @@ def _random_states(rng, E, N, crowd=0.5):
                                            ("particle_stage2_cross.json", 4, 4096 + 37),
                                            ("particle_merge8.json", 8, 8192), ("particle_merge8.json", 3, 777),
                                            ("particle_merge8.json", 5, 300), ("particle_merge8.json", 6, 129),
-                                           ("particle_merge8.json", 7, 64)])
+                                           ("particle_merge8.json", 7, 64), ("particle_ring10.json", 9, 2000),
+                                           ("particle_ring10.json", 10, 4099)])
 @pytest.mark.parametrize("kernel", KERNELS)
 def test_f32_random_states_vs_oracle(cfg_name, N, E, kernel):
     """BASELINE configs C1/C2/C4(per-GPU)/C5(per-GPU) + ragged sizes and every agent count."""
+    if kernel == "pair" and N > 8:
+        pytest.skip("the lane-per-pair mapping needs N <= 8")
     cfg = load_cfg(cfg_name)
     rng = np.random.default_rng(1234 + N * 1000 + E)
     env = _env(cfg, N, E, kernel=kernel)
@@ -427,16 +441,19 @@ def test_bad_arguments_raise():
     with pytest.raises(Cm3Error):
         env.step(torch.zeros(8, 3, dtype=torch.int32))
     with pytest.raises(Cm3Error):
-        _env(cfg, 9, 8)
+        _env(cfg, 11, 8)
 
 
 @pytest.mark.parametrize("N,cfg_name", [(2, "particle_stage2_merge.json"), (4, "particle_stage2_cross.json"),
-                                        (8, "particle_merge8.json"), (5, "particle_merge8.json")])
+                                        (8, "particle_merge8.json"), (5, "particle_merge8.json"),
+                                        (9, "particle_ring10.json"), (10, "particle_ring10.json")])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 @pytest.mark.parametrize("other", ["pair", "agent"])
 def test_both_kernel_mappings_agree_bitwise(N, cfg_name, dtype, other):
     """Same inputs, same bits: 40 free-running ticks with in-kernel actions and auto-reset (max_steps 7) through
     the lane-per-env kernel and the lane-per-pair / lane-per-agent kernels, including terminal capture."""
+    if other == "pair" and N > 8:
+        pytest.skip("the lane-per-pair mapping needs N <= 8")
     cfg = load_cfg(cfg_name)
     E = 1000
     a = _env(cfg, N, E, dtype=dtype, seed=21, auto_reset=True, max_steps=7, kernel="env")
@@ -490,13 +507,13 @@ def test_xcd_block_order_covers_ragged_batches(N, cfg_name, E, other):
     assert int(a.episode.min()) >= 2           # every env went through resets: none was skipped
 
 
-@pytest.mark.parametrize("N", [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("N", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 @pytest.mark.parametrize("kernel", KERNELS)
 def test_f64_free_running_random_configs_all_agent_counts(N, kernel):
     """33 free-running ticks in float64 from random crowded states, random (also out-of-range) actions, for every
     agent count and both kernel mappings: state / obs / rewards / done / collisions against the NumPy oracle."""
-    if N == 1 and kernel in ("pair", "agent"):
-        pytest.skip("the pair mapping needs at least two agents")
+    if (N == 1 and kernel in ("pair", "agent")) or (N > 8 and kernel == "pair"):
+        pytest.skip("the pair mapping needs 2 .. 8 agents")
     rng = np.random.default_rng(100 + N)
     cfg = dict(n_agents=N, agents_x=rng.uniform(-1, 1, N).tolist(), agents_y=rng.uniform(-1, 1, N).tolist(),
                landmarks_x=rng.uniform(-1, 1, N).tolist(), landmarks_y=rng.uniform(-1, 1, N).tolist(), initial_std=0.1)
