@@ -12,19 +12,25 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-// action ~ multinomial(probs) (alg_credit.py:120): inverse CDF in action order, one uniform from the Philox stream
-// keyed (seed, global env id, episode, step | agent)
-// the uniform of (seed, global env id, episode, step | agent): depends on nothing the network computes, so a kernel can draw it
-// while its loads are in flight
-__device__ __forceinline__ float actor_uniform(uint64_t seed, uint64_t genv, uint32_t episode, int steps, int agent) {
+// action ~ multinomial(probs) (alg_credit.py:120): inverse CDF in action order, one uniform per (seed, global env id, episode,
+// step, agent) from the two-stage stream of philox.h -- stage 1 (actor_block_word: the agent's word of the env's Philox block with
+// the policy purpose bit) depends on nothing loaded or computed, so a kernel draws it once, ahead of time (the fused policy rollout:
+// once per LAUNCH, for all its ticks); stage 2 (actor_uniform_from) mixes the episode / step counters in, ~10 instructions.
+__device__ __forceinline__ uint32_t actor_block_word(uint64_t seed, uint64_t genv, int agent) {
   u32x4 ctr;
   ctr.x = (uint32_t)genv;
   ctr.y = (uint32_t)(genv >> 32);
-  ctr.z = episode;
-  ctr.w = kPurposePolicy | ((uint32_t)(agent >> 2) << 24) | ((uint32_t)steps & 0x00FFFFFFu);
+  ctr.z = 0u;
+  ctr.w = kPurposePolicy | ((uint32_t)(agent >> 2) << 24);
   const u32x4 wd = philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
   const int q = agent & 3;
-  return (float)u01(q == 0 ? wd.x : (q == 1 ? wd.y : (q == 2 ? wd.z : wd.w)));
+  return q == 0 ? wd.x : (q == 1 ? wd.y : (q == 2 ? wd.z : wd.w));
+}
+__device__ __forceinline__ float actor_uniform_from(uint32_t block_word, uint32_t episode, int steps) {
+  return (float)u01(action_word(block_word, episode, (uint32_t)steps));
+}
+__device__ __forceinline__ float actor_uniform(uint64_t seed, uint64_t genv, uint32_t episode, int steps, int agent) {
+  return actor_uniform_from(actor_block_word(seed, genv, agent), episode, steps);
 }
 
 __device__ __forceinline__ int actor_pick(const float (&pr)[kA], float u) {

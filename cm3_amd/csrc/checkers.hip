@@ -349,10 +349,10 @@ __device__ __forceinline__ bool ck_tick_env(const CheckersParams &p, int t, size
   const uint64_t genv = (uint64_t)(p.env_id_base + (int64_t)ec);
   int32_t *actions_t = ck_tick_ptr(p.actions, p.st_actions, t);
   if (p.flags & CM3_FLAG_GEN_ACTIONS) {
-    uint32_t words[4 * ((N + 3) / 4)];
+    uint32_t words[4 * ((N + 3) / 4)];   // (the one-stage draw: see action_words_direct in philox.h)
 #pragma unroll
     for (int c = 0; c < (N + 3) / 4; ++c) {
-      const u32x4 w = action_words(p.seed, genv, episode, (uint32_t)steps, (uint32_t)c);
+      const u32x4 w = action_words_direct(p.seed, genv, episode, (uint32_t)steps, (uint32_t)c);
       words[4 * c + 0] = w.x;
       words[4 * c + 1] = w.y;
       words[4 * c + 2] = w.z;

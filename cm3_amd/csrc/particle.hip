@@ -513,6 +513,18 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step(const ParticlePara
   if (gen || (p.flags & CM3_FLAG_AUTO_RESET)) episode = (uint32_t)p.episode[ec];
   const uint32_t episode_in = episode;
   const uint64_t genv = (uint64_t)(p.env_id_base + (int64_t)ec);
+  // stage 1 of the action stream (philox.h): the Philox blocks of this env depend on nothing the launch loads
+  uint32_t ablock[4 * ((N + 3) / 4)];
+  if (gen) {
+#pragma unroll
+    for (int c = 0; c < (N + 3) / 4; ++c) {
+      const u32x4 w = action_block(p.seed, genv, (uint32_t)c);
+      ablock[4 * c + 0] = w.x;
+      ablock[4 * c + 1] = w.y;
+      ablock[4 * c + 2] = w.z;
+      ablock[4 * c + 3] = w.w;
+    }
+  }
   const R kDt = R(0.1), kKeep = R(1 - 0.25);
   if constexpr (N >= 2)  // (measured: N = 2..4 at 16 384 - 65 536 envs 1.5-4 % faster with it, N = 1 3 % slower)
     CM3_FETCH_EARLY(p.state_out, p.goals_out, p.actions, p.reward_n, p.reward, p.done, p.obs_others, p.meta_out, p.collisions_tick,
@@ -527,17 +539,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step(const ParticlePara
     int act[N];
     int32_t *actions_t = tick_ptr(p.actions, p.st_actions, t);
     if (gen) {  // train_onpolicy.py:305-307
-      uint32_t words[4 * ((N + 3) / 4)];
 #pragma unroll
-      for (int c = 0; c < (N + 3) / 4; ++c) {
-        const u32x4 w = action_words(p.seed, genv, episode, (uint32_t)steps, (uint32_t)c);
-        words[4 * c + 0] = w.x;
-        words[4 * c + 1] = w.y;
-        words[4 * c + 2] = w.z;
-        words[4 * c + 3] = w.w;
-      }
-#pragma unroll
-      for (int i = 0; i < N; ++i) act[i] = rand5(words[i]);
+      for (int i = 0; i < N; ++i) act[i] = rand5(action_word(ablock[i], episode, (uint32_t)steps));   // stage 2
       if (active) store_row<int32_t, N>(actions_t, e, act);
     } else {
       load_row<int32_t, N>(actions_t, ec, act);
@@ -647,12 +650,11 @@ __global__ void __launch_bounds__(WAVES * 64) k_particle_step(const ParticlePara
 #pragma unroll
         for (int i = 0; i < N; ++i) gout2[(size_t)i * E + e] = g[i];
       }
-      if (p.state_copy) {  // live-state rollout: the trajectory slot gets a copy (write-only stream)
+      if (p.state_copy) {  // live-state rollout: the trajectory slot gets a copy of the state (write-only stream)
 #pragma unroll
         for (int i = 0; i < N; ++i) store_obs_vec<SP>(reinterpret_cast<V4 *>(p.state_copy) + ((size_t)i * E + e), s[i]);
-#pragma unroll
-        for (int i = 0; i < N; ++i) reinterpret_cast<V2 *>(p.goals_copy)[(size_t)i * E + e] = g[i];
-      } else if (was_reset && p.goals_copy) {  // sparse goal slots (cm3_particle_traj.goals_live alone): written where an env restarts
+      }
+      if (was_reset && p.goals_copy) {  // goal slots are SPARSE wherever the goals live in place: written where an env restarts
 #pragma unroll
         for (int i = 0; i < N; ++i) reinterpret_cast<V2 *>(p.goals_copy)[(size_t)i * E + e] = g[i];
       }
@@ -763,6 +765,10 @@ __global__ void __launch_bounds__(WAVES * 64)
   CM3_FETCH_EARLY(p.state_out, p.goals_out, p.goals_in, p.collisions_tick, p.reward_n, p.reward, p.done, p.obs_others, p.meta_out);
   if constexpr (LIVE) CM3_FETCH_EARLY(p.state_copy, p.goals_copy);
   const uint64_t genv = (uint64_t)(p.env_id_base + (int64_t)ec);
+  // stage 1 of the action stream (philox.h): this agent's word of its env's Philox block -- ten rounds that depend on nothing the
+  // launch loads, computed while the loads are in flight (until round 3 the whole draw waited for `steps` / `episode`)
+  uint32_t aword = 0;
+  if (gen) aword = pick_word(action_block(p.seed, genv, (uint32_t)(i >> 2)), i & 3);
   const R kDt = R(0.1), kKeep = R(1 - 0.25);
 
   CM3_STAMP(1, true);
@@ -775,8 +781,7 @@ __global__ void __launch_bounds__(WAVES * 64)
     int act = 0;
     R f_x, f_y;
     if (gen) {  // train_onpolicy.py:305-307
-      const u32x4 w = action_words(p.seed, genv, episode, (uint32_t)steps, (uint32_t)(i >> 2));
-      act = rand5(pick_word(w, i & 3));  // (stored with the other per-agent outputs at the end of the tick)
+      act = rand5(action_word(aword, episode, (uint32_t)steps));  // stage 2 (stored with the other per-agent outputs at the end of the tick)
     } else {
       act = *at32<const int32_t>(actions_t, (ec * N + i) * 4u);
     }
@@ -914,11 +919,10 @@ __global__ void __launch_bounds__(WAVES * 64)
         *at32<V4>(tick_ptr(p.state_out, p.st_state, t), (row_i + e) * (uint32_t)sizeof(V4)) = si;
         if (p.goals_out != p.goals_in || was_reset)
           *at32<V2>(tick_ptr(p.goals_out, p.st_goals, t), (row_i + e) * (uint32_t)sizeof(V2)) = gl;
-        if constexpr (LIVE) {  // live-state rollout (a compile-time variant: the others carry none of it): the slot gets a copy
+        if constexpr (LIVE)   // live-state rollout (a compile-time variant: the others carry none of it): the slot gets a copy
           store_obs_vec<SP>(at32<V4>(p.state_copy, (row_i + e) * (uint32_t)sizeof(V4)), si);
-          *at32<V2>(p.goals_copy, (row_i + e) * (uint32_t)sizeof(V2)) = gl;
-        } else if constexpr (!FUSED) {
-          if (was_reset && p.goals_copy) *at32<V2>(p.goals_copy, (row_i + e) * (uint32_t)sizeof(V2)) = gl;   // sparse goal slots
+        if constexpr (!FUSED) {   // goal slots are SPARSE wherever the goals live in place (live state, or goals_live alone)
+          if (was_reset && p.goals_copy) *at32<V2>(p.goals_copy, (row_i + e) * (uint32_t)sizeof(V2)) = gl;
         }
       }
       // observation (multi-goal_spread.py:145-154): vector (i,k) of env e; lanes of a wave cover whole records
@@ -1018,6 +1022,9 @@ __global__ void __launch_bounds__(WAVES * 64)
   CM3_FETCH_EARLY(p.state_out, p.goals_out, p.goals_in, p.collisions_tick, p.reward_n, p.reward, p.done, p.obs_others, p.meta_out);
   if constexpr (LIVE) CM3_FETCH_EARLY(p.state_copy, p.goals_copy);
   const uint64_t genv = (uint64_t)(p.env_id_base + (int64_t)ec);
+  // stage 1 of the action stream (philox.h): this agent's word of its env's Philox block, computed while the loads are in flight
+  uint32_t aword = 0;
+  if (gen) aword = pick_word(action_block(p.seed, genv, (uint32_t)(i >> 2)), i & 3);
   const R kDt = R(0.1), kKeep = R(1 - 0.25);
 
   // rows of the wave's obs tile that exist (envs past the launch's range are not stored)
@@ -1067,8 +1074,7 @@ __global__ void __launch_bounds__(WAVES * 64)
     int32_t *actions_t = tick_ptr(p.actions, p.st_actions, t);
     int act;
     if (gen) {  // train_onpolicy.py:305-307
-      const u32x4 w = action_words(p.seed, genv, episode, (uint32_t)steps, (uint32_t)(i >> 2));
-      act = rand5(pick_word(w, i & 3));
+      act = rand5(action_word(aword, episode, (uint32_t)steps));   // stage 2 of the action stream
       if (mine) store_small<SP>(at32<int32_t>(actions_t, (e * N + i) * 4u), act);
     } else {
       act = *at32<const int32_t>(actions_t, (ec * N + i) * 4u);
@@ -1140,11 +1146,10 @@ __global__ void __launch_bounds__(WAVES * 64)
         *at32<V4>(tick_ptr(p.state_out, p.st_state, t), (row_i + e) * (uint32_t)sizeof(V4)) = si;
         if (p.goals_out != p.goals_in || fresh_goals)
           *at32<V2>(tick_ptr(p.goals_out, p.st_goals, t), (row_i + e) * (uint32_t)sizeof(V2)) = gl;
-        if constexpr (LIVE) {  // live-state rollout (a compile-time variant: the others carry none of it): the slot gets a copy
+        if constexpr (LIVE)   // live-state rollout (a compile-time variant: the others carry none of it): the slot gets a copy
           store_obs_vec<SP>(at32<V4>(p.state_copy, (row_i + e) * (uint32_t)sizeof(V4)), si);
-          *at32<V2>(p.goals_copy, (row_i + e) * (uint32_t)sizeof(V2)) = gl;
-        } else if constexpr (!FUSED) {
-          if (fresh_goals && p.goals_copy) *at32<V2>(p.goals_copy, (row_i + e) * (uint32_t)sizeof(V2)) = gl;   // sparse goal slots
+        if constexpr (!FUSED) {   // goal slots are SPARSE wherever the goals live in place (live state, or goals_live alone)
+          if (fresh_goals && p.goals_copy) *at32<V2>(p.goals_copy, (row_i + e) * (uint32_t)sizeof(V2)) = gl;
         }
       }
     };
@@ -1313,6 +1318,9 @@ __global__ void __launch_bounds__(WAVES * 64)
   CM3_FETCH_EARLY(p.state_out, p.goals_out, p.goals_in, p.collisions_tick, p.reward_n, p.reward, p.done, p.obs_others, p.meta_out);
   if constexpr (LIVE) CM3_FETCH_EARLY(p.state_copy, p.goals_copy);
   const uint64_t genv = (uint64_t)(p.env_id_base + (int64_t)ec);
+  // stage 1 of the action stream (philox.h): this agent's word of its env's Philox block, computed while the loads are in flight
+  uint32_t aword = 0;
+  if (gen) aword = pick_word(action_block(p.seed, genv, (uint32_t)(i >> 2)), i & 3);
   const R kDt = R(0.1), kKeep = R(1 - 0.25);
   long envs_here = (long)EN - (long)e0;
   envs_here = envs_here < 0 ? 0 : (envs_here > EPW ? EPW : envs_here);
@@ -1351,8 +1359,7 @@ __global__ void __launch_bounds__(WAVES * 64)
   int32_t *actions_t = p.actions;
   int act;
   if (gen) {  // train_onpolicy.py:305-307
-    const u32x4 w = action_words(p.seed, genv, episode, (uint32_t)steps, (uint32_t)(i >> 2));
-    act = rand5(pick_word(w, i & 3));
+    act = rand5(action_word(aword, episode, (uint32_t)steps));   // stage 2 of the action stream
     if (mine) store_small<SP>(at32<int32_t>(actions_t, (e * N + i) * 4u), act);
   } else {
     act = *at32<const int32_t>(actions_t, (ec * N + i) * 4u);
@@ -1452,12 +1459,8 @@ __global__ void __launch_bounds__(WAVES * 64)
     if (mine) {
       *at32<V4>(p.state_out, (row_i + e) * (uint32_t)sizeof(V4)) = si;
       if (p.goals_out != p.goals_in || fresh_goals) *at32<V2>(p.goals_out, (row_i + e) * (uint32_t)sizeof(V2)) = gl;
-      if constexpr (LIVE) {
-        store_obs_vec<SP>(at32<V4>(p.state_copy, (row_i + e) * (uint32_t)sizeof(V4)), si);
-        *at32<V2>(p.goals_copy, (row_i + e) * (uint32_t)sizeof(V2)) = gl;
-      } else {
-        if (fresh_goals && p.goals_copy) *at32<V2>(p.goals_copy, (row_i + e) * (uint32_t)sizeof(V2)) = gl;   // sparse goal slots
-      }
+      if constexpr (LIVE) store_obs_vec<SP>(at32<V4>(p.state_copy, (row_i + e) * (uint32_t)sizeof(V4)), si);
+      if (fresh_goals && p.goals_copy) *at32<V2>(p.goals_copy, (row_i + e) * (uint32_t)sizeof(V2)) = gl;   // sparse goal slots
     }
   };
   if constexpr (EARLY) emit_state(false);

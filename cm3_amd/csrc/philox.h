@@ -67,15 +67,61 @@ __host__ __device__ inline uint32_t pick_word(const u32x4 &w, int q) {
   return (w.x & m0) | (w.y & m1) | (w.z & m2) | (w.w & m3);
 }
 
-// actions of agents 4c..4c+3 of (env, episode, step) come from call c
-__host__ __device__ inline u32x4 action_words(uint64_t seed, uint64_t env, uint32_t episode, uint32_t step,
-                                              uint32_t call) {
+// ---- the action stream: TWO stages (round 4) --------------------------------------------------------------------------------
+// The uniform actions of the reference's random-action branch (train_onpolicy.py:305-307) are drawn in-kernel, keyed (seed,
+// global env id, episode, step, agent).  Until round 3 that was one Philox4x32-10 block over all of them -- and (episode, step)
+// are env state, LOADED by the step launch: the ten rounds (~340 cycles of a 2860-cycle wave at BASELINE sizes) could only start
+// once the launch's initial loads were back.  Now:
+//   stage 1  action_block(seed, env, call): Philox4x32-10 over (env id, call) keyed by the seed -- four words, one per agent
+//            4 call .. 4 call + 3, a per-env constant that depends on NOTHING the launch loads: the kernels compute it while
+//            their state loads are in flight;
+//   stage 2  action_word(a, episode, step) = fmix32((a ^ step) + episode * 0x9E3779B1): MurmurHash3's 32-bit finaliser (a
+//            bijection with full avalanche) over the agent's stage-1 word offset by the episode / step counters -- SplitMix-style
+//            counter hashing with a Philox-random 32-bit offset per (env, agent); ~10 instructions behind the loads.
+// rand5 of that word is the action.  Same properties as before where they matter: a pure function of (seed, global env id,
+// episode, step, agent) -- independent of sharding, launch geometry and launch mode -- restated bit for bit by
+// oracle/philox.py, uniform and serially uncorrelated (tests/test_philox.py).  The reset stream keeps the full Philox block
+// per draw (reset_words): it is off the per-tick path.
+__host__ __device__ inline uint32_t fmix32(uint32_t h) {
+  h ^= h >> 16;
+  h *= 0x85EBCA6Bu;
+  h ^= h >> 13;
+  h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return h;
+}
+__host__ __device__ inline u32x4 action_block(uint64_t seed, uint64_t env, uint32_t call) {
+  u32x4 c;
+  c.x = (uint32_t)env;
+  c.y = (uint32_t)(env >> 32);
+  c.z = 0u;
+  c.w = kPurposeAction | (call << 24);
+  return philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+__host__ __device__ inline uint32_t action_word(uint32_t a, uint32_t episode, uint32_t step) {
+  return fmix32((a ^ step) + episode * 0x9E3779B1u);
+}
+// The Checkers step kernel keeps the ONE-stage draw of rounds 1-3 (a full Philox block over (env, episode, step | call)): its
+// prologue is instruction-bound -- table staging and plan decoding leave ~250 idle cycles behind its loads, the ten rounds take
+// ~550 -- so stage 1 cannot hide there and the extra mix only costs (same-box A/B: C3 3.51 -> 3.62 us per tick with the two-stage
+// draw, C2 2.52 -> 2.43; profiles/r04_two_stage_action_stream.txt).
+__host__ __device__ inline u32x4 action_words_direct(uint64_t seed, uint64_t env, uint32_t episode, uint32_t step, uint32_t call) {
   u32x4 c;
   c.x = (uint32_t)env;
   c.y = (uint32_t)(env >> 32);
   c.z = episode;
   c.w = kPurposeAction | (call << 24) | (step & 0x00FFFFFFu);
   return philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+// actions of agents 4c..4c+3 of (env, episode, step) come from call c
+__host__ __device__ inline u32x4 action_words(uint64_t seed, uint64_t env, uint32_t episode, uint32_t step,
+                                              uint32_t call) {
+  u32x4 w = action_block(seed, env, call);
+  w.x = action_word(w.x, episode, step);
+  w.y = action_word(w.y, episode, step);
+  w.z = action_word(w.z, episode, step);
+  w.w = action_word(w.w, episode, step);
+  return w;
 }
 
 __host__ __device__ inline u32x4 reset_words(uint64_t seed, uint64_t env, uint32_t episode, uint32_t call) {

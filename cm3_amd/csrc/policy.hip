@@ -103,6 +103,7 @@ template <int N, int BF16, int RT> __global__ void __launch_bounds__(256) k_poli
   __syncthreads();
   ActorHeadB hb;
   actor_head_load(lds.wout, lane, hb);      // output-layer operands of this lane, once per launch
+  const uint32_t ublock = actor_block_word(p.seed, genv, i);   // stage 1 of the sampling uniforms: once per launch (actor_common.h)
   ActorFirstB<N> f1;                        // ... and its first-layer operands (round 4: they were re-read from LDS every tick)
   actor_first_b<N, float>(&lds.ws_self[0][0], &lds.ws_oth[0][0], w, lane, q.stage > 1, f1);
 
@@ -114,7 +115,7 @@ template <int N, int BF16, int RT> __global__ void __launch_bounds__(256) k_poli
     actor_mlp<N, BF16, RT>(lds, b, f1, w, lane, q.stage > 1);
     if (row_wave) {   // (wave-uniform; no workgroup barrier inside)
     float pr[kA];
-    const float u = actor_uniform(p.seed, genv, episode, steps, i);  // (Philox: VALU work between the head's dependent MFMAs)
+    const float u = actor_uniform_from(ublock, episode, steps);
     actor_head_probs(lds.h2s, hb, lds.lg, wr, lane, q.eps, pr);
     const int act = actor_pick(pr, u);
     CM3_STAMP(7, false);

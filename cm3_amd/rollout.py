@@ -308,7 +308,7 @@ class ParticleRollout(object):
         env = self.env
         live = self._live
         for t in range(self.T):
-            goals = self._goals_buf[t] if self._goals_buf is not None else env._goals
+            goals = self._goals_buf[t] if (self._goals_buf is not None and not live) else env._goals   # (live: goals in place)
             actor.enqueue(env.E, self.obs_others[t], self.state[t], goals, env._meta, env._episode, self.actions[t],
                           epsilon, stream=stream, env_id_base=env.env_id_base)
             self._enqueue(t, 1, base_flags, stream, live=live)
@@ -361,8 +361,10 @@ class ParticleRollout(object):
                              and not (self.fused_policy_tick and policy is not None))
         # sparse goal slots: the random-action branch, one launch per tick, slot-chained, at streaming sizes (or when forced)
         stream_size = env.E * env.n * env.L * es * self.T >= (128 << 20)
-        sparse = (policy is None and self._goals_buf is not None and not self.fused and not live and self.n_chains == 1 and
-                  bool(stream_size if self.sparse_goals is None else self.sparse_goals))
+        #   ... and ALWAYS with the live-state rollout, whoever acts: its goals live in place (ABI 5: the kernels write a goals slot
+        #   only where an env restarts; a device actor reads the live goals array, see _enqueue_actor_rollout)
+        sparse = self._goals_buf is not None and not self.fused and (
+            live or (policy is None and self.n_chains == 1 and bool(stream_size if self.sparse_goals is None else self.sparse_goals)))
         if sparse != self._goals_sparse and self._graph is not None:
             self._drop_graphs()
         self._goals_sparse, self._goal_src = sparse, None
@@ -418,7 +420,7 @@ class ParticleRollout(object):
                 self._enqueue_actor_rollout(policy, epsilon, base, env._stream())
         else:
             for t in range(self.T):
-                goals = (self._goals_buf[t] if self._goals_buf is not None else env._goals).permute(1, 0, 2)
+                goals = (self._goals_buf[t] if (self._goals_buf is not None and not live) else env._goals).permute(1, 0, 2)
                 a = policy(self.obs_others[t], self.state[t].permute(1, 0, 2), goals)
                 self.actions[t].copy_(torch.as_tensor(a, device=env.device).reshape(env.E, env.n))
                 self._enqueue(t, 1, base, live=live)
@@ -454,10 +456,10 @@ class ParticleRollout(object):
             self._norm = ReturnsNormalizer(self.reward_n, self.done, gamma, eps, normalize, segments=segments)
             self._norm_key = key
         self._finished0 = None
-        self._goals_sparse, self._goal_src = False, None     # (this path writes every goals slot)
         es = self.state.element_size()
         small = env.n * env.E * 4 * es <= (1 << 20) and env.E * env.n * env.L * es * self.T >= (128 << 20)
         live = self._live = bool(small if self.live_state is None else self.live_state)
+        self._goals_sparse, self._goal_src = live, None      # (the live-state launches write a goals slot only where an env restarts)
         # The captured graph bakes in the addresses of env._state[env._cur] / env._obs_others[env._cur] (tick 0 reads them, the
         # slot bookkeeping writes them) -- live or not -- and VecParticleEnv.step() flips env._cur: re-capture after a flip.
         if self._live_cur != env._cur:

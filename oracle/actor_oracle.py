@@ -65,18 +65,19 @@ def mixed_probs(probs, epsilon):
 
 
 def policy_uniforms(seed, env_ids, episode, step, n_agents):
-    """float32 uniforms in (0,1) [E, N] the kernel draws for (env, episode, step): Philox words of call c=i//4
-    with the policy purpose bit, (word + 0.5) * 2^-32 rounded to float32."""
+    """float32 uniforms in (0,1) [E, N] the kernel draws for (env, episode, step): the two-stage stream of csrc/philox.h with
+    the policy purpose bit -- the agent's word of the Philox block over (env id, call c = i // 4), mixed with the episode / step
+    counters (philox.action_word), (word + 0.5) * 2^-32 rounded to float32."""
     env_ids = np.asarray(env_ids)
     out = np.zeros((env_ids.shape[0], n_agents), np.float64)
     lo, hi = philox._split(env_ids)
     for call in range((n_agents + 3) // 4):
-        c3 = (np.asarray(step, dtype=np.uint64) & np.uint64(0x00FFFFFF)) | np.uint64(PURPOSE_POLICY | (call << 24))
-        w = philox.philox4x32_10(lo, hi, np.asarray(episode, np.uint64), c3, seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+        c3 = np.uint64(PURPOSE_POLICY | (call << 24))
+        w = philox.philox4x32_10(lo, hi, np.uint64(0), c3, seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
         for k in range(4):
             i = 4 * call + k
             if i < n_agents:
-                out[:, i] = philox.u01(w[k])
+                out[:, i] = philox.u01(philox.action_word(w[k], episode, step))
     return out.astype(np.float32)
 
 

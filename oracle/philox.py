@@ -1,6 +1,7 @@
 """TEST INFRASTRUCTURE ONLY -- NumPy restatement of the build's own counter-based RNG
-(cm3_amd/csrc/philox.h: Philox4x32-10, Salmon et al. SC'11) and of the draws the kernels make
-with it.  This has NO counterpart in the reference (which uses global MT19937 streams,
+(cm3_amd/csrc/philox.h: Philox4x32-10, Salmon et al. SC'11; since round 4 the per-tick action stream is a
+Philox block per (env, call) followed by a MurmurHash3-finaliser mix of the episode / step counters) and of
+the draws the kernels make with it.  This has NO counterpart in the reference (which uses global MT19937 streams,
 multi-goal_spread.py:75-91, train_onpolicy.py:307): it pins the build-defined stream so tests can
 check in-kernel random actions / resets exactly and prove shard-invariance.
 
@@ -38,7 +39,39 @@ def _split(v):
     return v & MASK32, v >> np.uint64(32)
 
 
+def fmix32(h):
+    """MurmurHash3's 32-bit finaliser (a bijection with full avalanche), on uint32 arrays."""
+    h = np.asarray(h, dtype=np.uint64) & MASK32
+    h = h ^ (h >> np.uint64(16))
+    h = (h * np.uint64(0x85EBCA6B)) & MASK32
+    h = h ^ (h >> np.uint64(13))
+    h = (h * np.uint64(0xC2B2AE35)) & MASK32
+    h = h ^ (h >> np.uint64(16))
+    return h.astype(np.uint32)
+
+
+def action_block(seed, env, call):
+    """stage 1 of the action stream (csrc/philox.h): Philox4x32-10 over (env id, call), keyed by the seed."""
+    lo, hi = _split(env)
+    c3 = np.uint64(PURPOSE_ACTION | (int(call) << 24))
+    return philox4x32_10(lo, hi, np.uint64(0), c3, seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+
+
+def action_word(a, episode, step):
+    """stage 2: fmix32((a ^ step) + episode * 0x9E3779B1) in uint32 arithmetic."""
+    a = np.asarray(a, dtype=np.uint64) & MASK32
+    st = np.asarray(step, dtype=np.uint64) & MASK32
+    ep = np.asarray(episode, dtype=np.uint64) & MASK32
+    return fmix32(((a ^ st) + ((ep * np.uint64(0x9E3779B1)) & MASK32)) & MASK32)
+
+
 def action_words(seed, env, episode, step, call):
+    return [action_word(w, episode, step) for w in action_block(seed, env, call)]
+
+
+def action_words_direct(seed, env, episode, step, call):
+    """the ONE-stage draw the Checkers step kernel keeps (csrc/philox.h action_words_direct): a Philox block over
+    (env, episode, step | call)."""
     lo, hi = _split(env)
     w = PURPOSE_ACTION | (int(call) << 24)
     c3 = (np.asarray(step, dtype=np.uint64) & np.uint64(0x00FFFFFF)) | np.uint64(w)
@@ -59,12 +92,13 @@ def rand5(r):
     return ((r.astype(np.uint64) * np.uint64(5)) >> np.uint64(32)).astype(np.int64)
 
 
-def expected_actions(seed, env_ids, episode, step, n_agents):
-    """int64 [E, N]: what CM3_FLAG_GEN_ACTIONS writes for (env, episode, step)."""
+def expected_actions(seed, env_ids, episode, step, n_agents, checkers=False):
+    """int64 [E, N]: what CM3_FLAG_GEN_ACTIONS writes for (env, episode, step) -- the particle kernels' two-stage stream, or
+    (checkers=True) the one-stage draw of the Checkers step kernel."""
     env_ids = np.asarray(env_ids)
     out = np.zeros((env_ids.shape[0], n_agents), np.int64)
     for call in range((n_agents + 3) // 4):
-        w = action_words(seed, env_ids, episode, step, call)
+        w = (action_words_direct if checkers else action_words)(seed, env_ids, episode, step, call)
         for k in range(4):
             i = 4 * call + k
             if i < n_agents:

@@ -146,7 +146,7 @@ def test_generated_actions_and_auto_reset():
     ref.reset(np.eye(2))
     for t in range(6):
         a = env.step()
-        want = philox.expected_actions(seed, np.arange(E), 1, t, N)      # reset() made this episode 1
+        want = philox.expected_actions(seed, np.arange(E), 1, t, N, checkers=True)      # reset() made this episode 1
         assert np.array_equal(env.last_actions.cpu().numpy(), want)
         b = ref.step(env.last_actions)
         assert torch.equal(a[4], b[4]) and torch.equal(a[5], b[5]) and torch.equal(a[6], b[6])

@@ -34,3 +34,39 @@ def test_reset_distribution_matches_reference_semantics():
     assert abs(noise.std() - 0.05) < 0.002 and abs(noise.mean()) < 0.002
     assert np.all(np.abs(pos[rnd]) < 1) and np.all(np.abs(lm[rnd]) < 1)
     assert abs(pos[rnd].std() - (1 / 3) ** 0.5) < 0.02
+
+
+def test_two_stage_action_stream_is_uniform_and_uncorrelated_over_time():
+    """The action stream of round 4 (Philox block per env + fmix32 over the episode / step counters): per-agent marginals,
+    the joint distribution of CONSECUTIVE steps of one agent (25 cells), of two agents of one env, and of the same (agent, step)
+    in consecutive episodes -- chi-square against uniform at the 99.9 % level."""
+    E, N, T = 4096, 4, 64
+    ids = np.arange(E) + 1000
+    a = np.stack([philox.expected_actions(99, ids, 7, t, N) for t in range(T)])          # [T, E, N]
+    b = philox.expected_actions(99, ids, 8, 5, N)
+
+    def chi2(counts):
+        exp = counts.sum() / counts.size
+        return float(((counts - exp) ** 2 / exp).sum())
+
+    assert chi2(np.bincount(a.ravel(), minlength=5)) < 18.5                                 # 4 dof
+    pair_t = np.bincount((a[:-1] * 5 + a[1:]).ravel(), minlength=25)
+    assert chi2(pair_t) < 51.2                                                              # 24 dof
+    pair_ag = np.bincount((a[..., 0] * 5 + a[..., 1]).ravel(), minlength=25)
+    assert chi2(pair_ag) < 51.2
+    pair_ep = np.bincount((a[5] * 5 + b).ravel(), minlength=25)
+    assert chi2(pair_ep) < 51.2
+    # lag-k autocorrelation of one agent's action sequence, averaged over envs
+    x = a[..., 0].astype(np.float64) - 2.0
+    for lag in (1, 2, 3, 8):
+        r = float((x[:-lag] * x[lag:]).mean() / x.var())
+        assert abs(r) < 0.01, (lag, r)
+    # a different seed / env id gives an unrelated stream
+    c = philox.expected_actions(100, ids, 7, 3, N)
+    assert 0.15 < float((c == a[3]).mean()) < 0.25
+
+
+def test_fmix32_known_answers():
+    # MurmurHash3 fmix32 reference values
+    got = [int(x) for x in philox.fmix32(np.array([0, 1, 0xFFFFFFFF, 0xDEADBEEF], dtype=np.uint64))]
+    assert got == [0x00000000, 0x514E28B7, 0x81F16F39, 0x0DE5C6A9]
