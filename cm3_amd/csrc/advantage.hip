@@ -398,6 +398,23 @@ __global__ void __launch_bounds__(kAdvBlock) k_fold_normalize(R *__restrict__ x,
   }
   if (!apply) return;
   const R m = (R)mean, den = (R)(sd + eps);
+  if constexpr (sizeof(R) == 4) {
+    // four elements per lane and trip where nothing is masked and the slab is 16-byte aligned (round 4: one element per lane in
+    // 2048 blocks per segment spent its time on the per-block fold -- 26 us per 330-tick C4 phase for 43 MB -- not on the elements)
+    if (!valid && (n_elem & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+      float4 *x4 = reinterpret_cast<float4 *>(x);
+      const size_t n4 = n_elem >> 2;
+      for (size_t i = (size_t)blockIdx.x * kAdvBlock + threadIdx.x; i < n4; i += (size_t)gridDim.x * kAdvBlock) {
+        float4 v = x4[i];
+        v.x = (v.x - m) / den;
+        v.y = (v.y - m) / den;
+        v.z = (v.z - m) / den;
+        v.w = (v.w - m) / den;
+        x4[i] = v;
+      }
+      return;
+    }
+  }
   for (size_t i = (size_t)blockIdx.x * kAdvBlock + threadIdx.x; i < n_elem; i += (size_t)gridDim.x * kAdvBlock) {
     const bool v = valid ? (valid[i / C] != 0) : true;
     x[i] = v ? (x[i] - m) / den : R(0);
@@ -442,8 +459,10 @@ static int returns_normalize(const void *x, const uint8_t *done, const uint8_t *
   }
   CM3_HIP_CHECK(hipGetLastError());
   const size_t n_elem = (size_t)T * cols;
-  size_t nblocks = apply ? (n_elem + kAdvBlock - 1) / kAdvBlock : 1;
-  if (nblocks > 2048) nblocks = 2048;
+  size_t nblocks = apply ? (n_elem / 4 + kAdvBlock - 1) / kAdvBlock : 1;   // (four elements per lane: see k_fold_normalize)
+  const size_t cap = n_seg > 1 ? (size_t)((2048 + n_seg - 1) / n_seg < 64 ? 64 : (2048 + n_seg - 1) / n_seg) : 2048;
+  if (nblocks > cap) nblocks = cap;
+  if (nblocks < 1) nblocks = 1;
   hipLaunchKernelGGL((k_fold_normalize<R>), dim3((unsigned)nblocks, n_seg), dim3(kAdvBlock), 0, s, (R *)out, valid,
                      (const double *)scratch, n_partials, moments, stats, n_elem, C, eps, apply);
   CM3_HIP_CHECK(hipGetLastError());
