@@ -1854,6 +1854,10 @@ template <typename R, int N> static int launch_n(const ParticleParams &p, Partic
     // ... and once more on the final build (max-ILP pair / agent kernels; profiles/r02_mapping_sweep_final_build.txt):
     //   N = 2: pair up to 32768 envs (16384: 2.57 / - / 2.68; 32768: 2.89 / - / 3.01); N = 6: agent from 6144 (4.27 / 4.11);
     //   N = 7, 8: agent from 4096 (N = 8: 5.12 / 4.57, N = 7: 4.73 / 4.34; at 2048 pair: 3.83 / 4.29)
+    // round 4, after the two-stage action draw shortened every mapping's path: re-swept (profiles/r04_mapping_sweep.txt, merge8
+    // positions): `auto` within ~1 % of the best mapping at 88 of 91 (N, E) points.  The two candidates for a move -- N = 2 pair up
+    // to 65536, N = 4 agent up to 65536 -- were tried and taken back: on the antipodal config of the bench N = 4 at 65536 envs ran
+    // 6.11 us with the agent mapping against 5.70 with lane-per-env; the crossovers depend on how crowded a config is.
     constexpr size_t kPairMax = N > 8 ? 0 : (N == 2 ? 32768 : (N == 3 ? 24576 : (N == 4 ? 12288 : kPairsMaxEnvs)));
     // round 3: N = 8 with two lanes per agent (k_particle_step_agents2; profiles/r03_two_lanes_per_agent.txt) moved its crossover
     // to 2048 envs; the XCD-aware block order (common.h) then sped the pair mapping up most at exactly these sizes
