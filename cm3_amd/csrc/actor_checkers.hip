@@ -22,6 +22,12 @@
 //               matrices run on v_mfma_f32_16x16x32_bf16 (f32 accumulation, 16x the f32 MFMA rate); everything else stays f32.
 //   precision = 2 (split float16, a parity path; k_ck_actor_x3): EVERY layer as hi * hi + hi * lo + lo * hi on
 //               v_mfma_f32_16x16x32_f16 with activations and weights split into float16 hi + lo (22 significand bits per factor).
+//               Limit: the residual lo = f16(x - hi) is NOT kept scaled here (the particle actor's is, actor.hip
+//               kLoScale: it has the accumulator registers to spare, this kernel's 4 x 4 tiles do not), so for |x| < 0.125 it
+//               falls into float16's subnormals: an ABSOLUTE error of ~3e-8 per factor instead of a relative 2^-22.  Held to the
+//               2e-5 bound with second-layer weights of ~6e-5 against first-layer activations of ~1e2
+//               (tests/test_gpu_actor_checkers.py::test_split_precision_small_weights_large_activations); beyond
+//               |w| |x| ~ 1e3 / 3e-8 products the bound is not guaranteed, and float16 saturates at 65504: use precision = 0 there.
 //   wave tiles: conv 2 row x 5 col tiles, conv_linear 2 x 1, branch_self / branch_others / h2: 4 x 4 (all 64 rows x 64
 //               columns per wave, 64 accumulator VGPRs), actor_out: wave w finishes rows [16w, 16w+16).
 #include "actor_common.h"

@@ -215,3 +215,39 @@ def test_device_actor_matches_vectors_from_the_reference_function_body(tag, N, s
     ParticleActor(w, N, stage=stage, device=dev, precision=precision).enqueue(E, obs, state, goals, meta, episode, actions,
                                                                              0.0, probs)
     assert np.abs(probs.reshape(rows, 5).cpu().numpy() - want).max() < 2e-5
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("w2_scale,w1_scale", [(1e-3, 60.0), (3e-5, 300.0), (0.05, 1.0)])
+def test_actor_split_precision_with_small_weights_and_large_activations(precision, w2_scale, w1_scale):
+    """the float16 split x = hi + lo loses its residual to float16's subnormals once |x| < 0.125 unless the residual
+    is kept scaled (csrc/actor.hip kLoScale).  Second-layer weights of 1e-3 / 3e-5 against first-layer activations of 1e2 / 1e3
+    (logits still O(1)), and the reference's own scale: every probability within 2e-5 of a FLOAT64 evaluation of the network."""
+    from cm3_amd.actor import ParticleActor
+    N, E, seed = 4, 512, 5
+    rng = np.random.default_rng(17)
+    w = AO.init_weights(rng, N, stage=2, scale=1.0)
+    for k in ("actor_branch_self/kernel", "actor_branch_self/bias", "stage-2/actor_others/kernel", "stage-2/actor_others/bias"):
+        w[k] = (w[k] * w1_scale).astype(np.float32)
+    for k in ("W_branch_self_h2", "stage-2/W_others_h2"):
+        w[k] = (w[k] * w2_scale / (w1_scale * 4.0)).astype(np.float32) if w2_scale >= 0.05 else (w[k] * w2_scale).astype(np.float32)
+    w["b"] = (w["b"] * 0.1).astype(np.float32)
+    env = _env(E, N, "particle_stage2_antipodal.json", seed=seed)
+    env.reset()
+    for _ in range(3):
+        env.step()
+    actor = ParticleActor(w, N, stage=2, device="cuda:0", seed=seed, precision=precision)
+    _, probs = actor.act(env, 0.0, return_probs=True)
+    gs, oo = env.get_obs()
+    rows = E * N
+    f64 = lambda a: np.asarray(a, dtype=np.float64)      # noqa: E731
+    x = np.concatenate([f64(gs.reshape(rows, 4).cpu().numpy()), f64(env.goals.reshape(rows, 2).cpu().numpy())], axis=1)
+    h_self = np.maximum(x @ f64(w["actor_branch_self/kernel"]) + f64(w["actor_branch_self/bias"]), 0)
+    h_oth = np.maximum(f64(oo.reshape(rows, -1).cpu().numpy()) @ f64(w["stage-2/actor_others/kernel"]) + f64(w["stage-2/actor_others/bias"]), 0)
+    h2 = np.maximum(h_self @ f64(w["W_branch_self_h2"]) + h_oth @ f64(w["stage-2/W_others_h2"]) + f64(w["b"]), 0)
+    out = h2 @ f64(w["actor_out/kernel"]) + f64(w["actor_out/bias"])
+    out = out - out.max(axis=1, keepdims=True)
+    want = np.exp(out) / np.exp(out).sum(axis=1, keepdims=True)
+    assert float(h_self.max()) > 20 * w1_scale / 60.0                 # the activations really are large
+    assert 0.02 < float(want.max(axis=1).mean()) < 0.999               # ... and the policy neither uniform nor saturated everywhere
+    assert np.abs(probs.reshape(rows, 5).cpu().numpy().astype(np.float64) - want).max() < 2e-5

@@ -320,3 +320,32 @@ def test_split_float16_layers_stay_in_the_float32_error_class(stage):
     u = AO.policy_uniforms(8, np.arange(E), env._episode.cpu().numpy(), env.steps.cpu().numpy(), N).reshape(E * N)
     safe = np.abs(np.cumsum(want, axis=1) - u[:, None]).min(axis=1) > 1e-4
     assert np.array_equal(out["f32"][0][safe], out["f16x3"][0][safe])
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("w2_scale,w1_scale", [(1e-3, 100.0), (1.0, 1.0)])
+def test_split_precision_small_weights_large_activations(precision, w2_scale, w1_scale):
+    """ADVICE r3 (the Checkers actor keeps the UNSCALED float16 split x = hi + lo in every layer: the residual of a value below
+    0.125 falls into float16's subnormals, an absolute error of ~3e-8 per factor): second-layer weights of ~1e-3 / sqrt(256)
+    against first-layer activations of ~1e2 -- logits still O(1) -- must stay inside the 2e-5 bound of the float32 path.  The
+    float32 oracle's own rounding is part of the budget here (both paths are held to the same bar against it)."""
+    from cm3_amd.actor import CheckersActor
+    seed, E, stage = 91, 600, 2
+    rng = np.random.default_rng(123)
+    env, N = _env(E, stage, seed=seed)
+    w = AO.init_weights(rng, N, stage=stage)
+    for k in ("branch_self/kernel", "branch_self/bias", "stage-2/branch_others/kernel", "stage-2/branch_others/bias"):
+        w[k] = (w[k] * w1_scale).astype(np.float32)
+    for k in ("W_self_h2", "stage-2/W_others_h2"):
+        w[k] = (w[k] * w2_scale).astype(np.float32)
+    env.reset(_goals(rng, E, N))
+    for _ in range(5):
+        env.step()
+    actor = CheckersActor(w, N, stage=stage, device="cuda:0", seed=seed, precision=precision)
+    prev = rng.integers(0, 5, (E, N))
+    _, probs = actor.act(env, 0.0, actions_prev=prev, return_probs=True)
+    rows = E * N
+    want = _oracle_probs(w, env, prev, 0.0)
+    got = probs.reshape(rows, 5).cpu().numpy()
+    assert np.abs(got - want).max() < 2e-5, float(np.abs(got - want).max())
+    assert np.ptp(want, axis=1).mean() > 0.02
