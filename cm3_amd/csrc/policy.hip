@@ -317,16 +317,19 @@ template <int N, int RT> static int policy_launch_rt(const PolicyParams &q, int 
   return CM3_OK;
 }
 
-// Row tiles per workgroup from the batch (measured on MI355X, N = 4, f16x3, us per tick at RT = 4 / 2 / 1 --
-// profiles/r04_policy_row_tiles.txt): 2048 envs 5.0 / 3.4 / 3.8, 4096 envs (C2) 4.82 / 4.60 / 6.9, 8192 envs 7.04 / 8.83 / 13.3,
-// 65536 envs 48.8 / 70 / 102.  A lone workgroup per CU is latency-bound and the smaller one is faster (fewer matrix instructions
-// per wave and tick); once a CU holds several, the 64-row workgroup does the most work per instruction issued.  So: 64-row
-// workgroups when they already give every CU more than one, else 32-row ones, 16-row ones below a quarter of that.
+// Row tiles per workgroup from the batch (measured on MI355X with the final kernel, f16x3, us per tick at RT = 4 / 2 / 1 --
+// profiles/r04_policy_row_tiles.txt):  N = 4: 2048 envs 4.47 / 3.29 / 3.13, 4096 envs (C2) 4.63 / 4.41 / 5.70, 8192 envs 6.58 / 8.06 /
+// 10.8, 65536 envs 45.8 / 59.2 / 83.0;  N = 8: 2048 envs 5.93 / 8.14 / 7.65, 8192 envs 22.8 / 31.3 / 28.9;  N = 2 at 8192 envs 4.00 /
+// 3.98 / 5.18;  N = 1 at 16384 envs 3.87 / 3.74 / 4.78.  A lone workgroup per CU is latency-bound and the smaller one is faster
+// (fewer matrix instructions per wave and tick); once a CU holds several, the 64-row workgroup does the most work per instruction
+// issued.  So: 64-row workgroups when they already give every CU more than one, 32-row ones down to half a workgroup per CU,
+// 16-row ones below.  N = 8 stays at 64 rows from half a workgroup per CU on: its 32-row build needs 261 registers, one wave per SIMD.
 // CM3_POLICY_RT = 1 | 2 | 4 overrides the choice (measurements only).
 constexpr size_t kPolicyCus = 256;
 template <int N> static int policy_launch(const PolicyParams &q, int prec, hipStream_t s) {
   const size_t rows = (size_t)q.p.E * N, wg64 = (rows + 63) / 64;
-  int rt = wg64 > kPolicyCus ? 4 : (wg64 > kPolicyCus / 4 ? 2 : 1);
+  int rt = wg64 > kPolicyCus ? 4 : (wg64 > kPolicyCus / 2 ? 2 : 1);
+  if (N == 8 && wg64 >= kPolicyCus / 2) rt = 4;
   if (const char *e = getenv("CM3_POLICY_RT")) {
     const int v = atoi(e);
     if (v == 1 || v == 2 || v == 4) rt = v;
