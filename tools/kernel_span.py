@@ -160,17 +160,18 @@ def main():
         cfg = cm3_amd.load_config(cfg_name)
         N = cfg["n_agents"]
         if kind == "particle_adv":
-            # one replay = 33 step launches (tick 0 reads the env buffers) + the two launches of cm3_returns_normalize_* (the first
-            # also does the slot bookkeeping): the stamps cover the 33 step launches, the rest of the replay period (HIP events) is
-            # those two launches + the replay boundary
-            TT = bench.EP_TICKS
-            run_stepper("%s_rollout" % wl, lambda: bench.RolloutAdvStepper(cfg, N, E, dev), TT, steps * 10, warm * 10,
-                        "%s, %d envs, one hipGraph replay per 33-tick rollout + normalisation" % (desc, E), out)
+            # round 4: one replay = one collection phase = 330 step launches (ten 33-tick rollouts) + the slot copies + the two launches
+            # of cm3_returns_normalize_segments_* for the ten advantage steps: the stamps cover the 330 step launches, the rest of
+            # the replay period (HIP events) is the tail launches + the replay boundary.  (The stepper also captures its
+            # single-rollout graph at set-up: 33 more slots are handed out, none of them runs here.)
+            TT = bench.PHASE_TICKS
+            run_stepper("%s_rollout" % wl, lambda: bench.RolloutAdvStepper(cfg, N, E, dev), TT, steps, warm,
+                        "%s, %d envs, one hipGraph replay per phase of 10 rollouts x 33 ticks + their normalisations" % (desc, E), out)
             r = out["%s_rollout" % wl]
             period = r["hip_event_us_per_launch"] * TT
             inside = r["start_to_start_us_mean"] * (TT - 1) + r["span_us_mean"]
-            print("   replay period %.2f us; first step wave in -> last step wave out %.2f us; outside the step launches (the two "
-                  "advantage launches + the replay boundary) %.2f us" % (period, inside, period - inside))
+            print("   replay period %.2f us; first step wave in -> last step wave out %.2f us; outside the step launches (slot copies, the "
+                  "two advantage launches, the replay boundary) %.2f us" % (period, inside, period - inside))
             r["replay_period_us"], r["step_launches_us"] = period, inside
             continue
         for mode in ("trajectory", "in-place"):
