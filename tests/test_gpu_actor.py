@@ -251,3 +251,37 @@ def test_actor_split_precision_with_small_weights_and_large_activations(precisio
     assert float(h_self.max()) > 20 * w1_scale / 60.0                 # the activations really are large
     assert 0.02 < float(want.max(axis=1).mean()) < 0.999               # ... and the policy neither uniform nor saturated everywhere
     assert np.abs(probs.reshape(rows, 5).cpu().numpy().astype(np.float64) - want).max() < 2e-5
+
+
+@pytest.mark.parametrize("N,cfg", [(4, "particle_stage2_cross.json"), (8, "particle_merge8.json"), (3, "particle_merge8.json")])
+@pytest.mark.parametrize("graph", [True, False])
+def test_policy_launch_per_tick_on_the_live_state_rollout(N, cfg, graph):
+    """Policy-driven collection, an actor launch and a step launch per tick, with the LIVE-state rollout forced (the env's state and
+    goals step in place, the slots get copies; since ABI 5 a goals slot is written only where an env restarts, and the actor reads the
+    live goals array): same trajectories -- goals completed on access -- as the slot-chained rollout, and, for N in {4, 8}, as the
+    whole episode in one launch."""
+    from cm3_amd.actor import ParticleActor
+    from cm3_amd.rollout import ParticleRollout
+    E, T, seed = 500, 30, 29
+    w = AO.init_weights(np.random.default_rng(N), N, stage=2)
+    outs = []
+    modes = [dict(policy_mode="tick", live_state=True), dict(policy_mode="tick", live_state=False)]
+    if N in (4, 8):
+        modes.append(dict(policy_mode="episode"))
+    for kw in modes:
+        env = _env(E, N, cfg, seed=seed, auto_reset=True, max_steps=7)
+        env.reset()
+        actor = ParticleActor(w, N, stage=2, device="cuda:0", seed=seed, precision="f32")
+        ro = ParticleRollout(env, n_ticks=T, use_graph=graph, **kw)
+        for _ in range(2):
+            ro.collect(policy=actor, epsilon=0.2, reset=False)
+        outs.append((ro, env))
+    a, ea = outs[0]
+    assert a._live and not outs[1][0]._live
+    for b, eb in outs[1:]:
+        for name in ("actions", "state", "obs_others", "reward", "reward_n", "done", "collisions", "goals"):
+            assert torch.equal(getattr(a, name), getattr(b, name)), name
+        assert torch.equal(ea.global_state, eb.global_state) and torch.equal(ea.goals, eb.goals) and torch.equal(ea.episode, eb.episode)
+    assert int(a.done.sum()) >= 3 * E
+    for ro, _ in outs:
+        ro.close()
