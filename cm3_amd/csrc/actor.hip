@@ -184,7 +184,6 @@ template <int N, int PREC, int RT = 4> struct ActorLds {
   _Float16 (*h1l)[G::HB];   // ... and the lo plane
   float (*h2s)[kH2 + 1];
   float (*xs)[G::XW];
-  float (*lg)[8];          // logits of the 64 rows (head: C tile -> row per lane)
   float *tables;
 };
 
@@ -192,9 +191,7 @@ template <int N, int PREC, int RT = 4> struct ActorLds {
   __shared__ __attribute__((aligned(16))) float name##_tables[PackLayout<N_>::kTables];                        \
   __shared__ __attribute__((aligned(16))) float name##_h1raw[ActorGeom<N_, BF16_, RT_>::kH1Floats];            \
   __shared__ float name##_xs[16 * RT_][ActorGeom<N_, BF16_, RT_>::XW];                                         \
-  __shared__ float name##_lg[16 * RT_][8];                                                                     \
   ActorLds<N_, BF16_, RT_> name;                                                                               \
-  name.lg = name##_lg;                                                                                         \
   name.tables = name##_tables;                                                                                 \
   name.ws_self = reinterpret_cast<float (*)[ActorGeom<N_, BF16_>::SW]>(&name##_tables[PackLayout<N_>::kSelf]); \
   name.ws_oth = reinterpret_cast<float (*)[ActorGeom<N_, BF16_>::OW]>(&name##_tables[PackLayout<N_>::kOth]);   \
@@ -438,50 +435,58 @@ __device__ __forceinline__ void actor_mlp(const ActorLds<N, PREC, RT> &lds, cons
   CM3_STAMP(6, false);
 }
 
-// Final layer, all four waves: wave w finishes rows [16w, 16w+16) on the matrix cores (round 3) -- one 16 x 16 tile, K = 64:
-//   A[i = l&15][k = l>>4] = h2[16w + (l&15)][4s + (l>>4)]   one ds_read_b32 per k-step
-//   B[k = l>>4][j = l&15] = w_out[4s + (l>>4)][j] for j < 5, else 0   (16 VGPRs per lane, ActorHeadB, loaded once per launch)
-// 16 v_mfma_f32_16x16x4_f32 = a k-ordered fmaf chain per logit (exact float32, like the other layers), + bias.  The C tile
-// (col = action, row = 4 (l>>4) + reg) goes through a 2 KB LDS tile so that lane l continues with ALL five logits of row
-// 16w + (l&15): softmax (networks.py:536-537), epsilon mix (alg_credit.py:119).  (The first version gave every lane a quarter of
-// the 64 units: 80 broadcast LDS reads of w_out + 16 of h2 + 80 FMAs + 10 shuffles per lane -- 3.5k of the wave's ~14k cycles per
-// tick; profiles/r03_actor_*.)
-__device__ __forceinline__ void wave_sync_lds() {
-  // LDS operations of one wave execute in issue order; this only keeps the compiler from moving them across the hand-off
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
+// Final layer: wave w finishes rows [16w, 16w+16) on the matrix cores (round 3) -- one 16 x 16 tile, K = 64, TRANSPOSED like the
+// first layer's tiles (round 4): C[i = action][j = row] = sum_k w_out[k][i] h2[row j][k]
+//   A[i = l&15][k = l>>4] = w_out[4s + (l>>4)][i] for i < 5, else 0   (16 VGPRs per lane, ActorHeadB, loaded once per launch)
+//   B[k = l>>4][j = l&15] = h2[16w + (l&15)][4s + (l>>4)]             one ds_read_b32 per k-step, all sixteen requested up front
+// 16 v_mfma_f32_16x16x4_f32 = a k-ordered fmaf chain per logit (exact float32, like the other layers), bias as the start value.
+// Lane l then holds actions 4 (l>>4) + reg of row 16w + (l&15): logits 0..3 of a row sit in its lane of the first 16, logit 4 in
+// register 0 of the lane 16 further on -- ONE v_permlane16_swap brings it over, and lanes 0..15 continue with all five: softmax
+// (networks.py:536-537), epsilon mix (alg_credit.py:119).  (Before: C[row][action] through a 2 KB LDS tile -- four stores, a
+// wave-level hand-over and two loads on the path of every tick.  The first version gave every lane a quarter of the 64 units: 80
+// broadcast LDS reads of w_out + 16 of h2 + 80 FMAs + 10 shuffles per lane -- 3.5k of the wave's ~14k cycles per tick;
+// profiles/r03_actor_*.)  Only lanes 0..15 return probabilities; the other lanes' values are unspecified (finite).
 struct ActorHeadB {
   float wo[kH2 / 4];
-  float bias;
+  float bias4[4];
 };
 __device__ __forceinline__ void actor_head_load(const float *wout, int lane, ActorHeadB &hb) {
   const int j = lane & 15, hi = lane >> 4;
 #pragma unroll
   for (int s = 0; s < kH2 / 4; ++s) hb.wo[s] = j < kA ? wout[(4 * s + hi) * kA + j] : 0.0f;
-  hb.bias = j < kA ? wout[kH2 * kA + j] : 0.0f;
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) hb.bias4[reg] = 4 * hi + reg < kA ? wout[kH2 * kA + 4 * hi + reg] : 0.0f;
 }
 
-__device__ __forceinline__ void actor_head_probs(const float (*h2s)[kH2 + 1], const ActorHeadB &hb, float (*lg)[8], int w,
-                                                 int lane, float eps, float (&pr)[kA]) {
+__device__ __forceinline__ void actor_head_probs(const float (*h2s)[kH2 + 1], const ActorHeadB &hb, int w, int lane, float eps,
+                                                 float (&pr)[kA]) {
   const int col = lane & 15, hi = lane >> 4;
   // two accumulators (even / odd k-steps), added at the end: sixteen instructions on ONE accumulator each waited for its
   // predecessor's eight passes (round 4: ~200 of the head's ~2000 cycles); the bias starts the even chain
-  f32x4 acc = f32x4{hb.bias, hb.bias, hb.bias, hb.bias}, acc1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  f32x4 acc = f32x4{hb.bias4[0], hb.bias4[1], hb.bias4[2], hb.bias4[3]}, acc1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  // all sixteen B operands first (the compiler otherwise reads two, waits, issues two instructions, eight times over: eight LDS
+  // round trips in a row on the path every tick of the rollout waits for)
+  float hx[kH2 / 4];
+#pragma unroll
+  for (int s = 0; s < kH2 / 4; ++s) hx[s] = h2s[16 * w + col][4 * s + hi];
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int s = 0; s < kH2 / 4; s += 2) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(h2s[16 * w + col][4 * s + hi], hb.wo[s], acc, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(h2s[16 * w + col][4 * (s + 1) + hi], hb.wo[s + 1], acc1, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(hb.wo[s], hx[s], acc, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(hb.wo[s + 1], hx[s + 1], acc1, 0, 0, 0);
   }
-  if (col < kA) {
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) lg[16 * w + 4 * hi + reg][col] = acc[reg] + acc1[reg];
-  }
-  wave_sync_lds();
   float o[kA];
 #pragma unroll
-  for (int a = 0; a < kA; ++a) o[a] = lg[16 * w + col][a];
+  for (int a = 0; a < 4; ++a) o[a] = acc[a] + acc1[a];
+  {
+    // rows of 16 lanes: the odd rows of the first operand change places with the even rows of the second, so the second result's
+    // lanes 0..15 hold what lanes 16..31 had -- action 4 of the same matrix row
+    uint32_t x;
+    __builtin_memcpy(&x, &o[0], 4);
+    const auto sw = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+    const uint32_t y = sw[1];
+    __builtin_memcpy(&o[4], &y, 4);
+  }
   float m = o[0];
 #pragma unroll
   for (int a = 1; a < kA; ++a) m = fmaxf(m, o[a]);
@@ -494,9 +499,18 @@ __device__ __forceinline__ void actor_head_probs(const float (*h2s)[kH2 + 1], co
     o[a] = __builtin_amdgcn_exp2f((o[a] - m) * 1.44269504088896340736f);
     sum += o[a];
   }
-  const float inv = 1.0f / sum;
+  // (hardware reciprocal, 1 ulp: the sum is in [1, 5]; the IEEE division was ten instructions on the same path)
+  const float inv = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
   for (int a = 0; a < kA; ++a) pr[a] = (1.0f - eps) * (o[a] * inv) + eps / (float)kA;
+}
+
+// The value lanes 0..15 hold, in all four 16-lane rows (lane l gets lane l & 15's): two swaps, no LDS
+__device__ __forceinline__ int bcast_row0(int v) {
+  uint32_t x = (uint32_t)v;
+  x = __builtin_amdgcn_permlane16_swap(x, x, false, false)[0];   // row 1 <- row 0 (and row 3 <- row 2)
+  x = __builtin_amdgcn_permlane32_swap(x, x, false, false)[0];   // rows 2, 3 <- rows 0, 1
+  return (int)x;
 }
 
 template <int N, int PREC> __global__ void __launch_bounds__(256) k_actor_particle(const ActorParams p) {
@@ -557,7 +571,7 @@ template <int N, int PREC> __global__ void __launch_bounds__(256) k_actor_partic
   float pr[kA];
   // the uniform first: its Philox rounds are VALU work that can issue between the head's dependent MFMAs
   const float u = actor_uniform(p.seed, (uint64_t)(p.env_id_base + (int64_t)he), head_episode, head_steps, hi_agent);
-  actor_head_probs(lds.h2s, hb, lds.lg, w, lane, p.eps_dev ? *p.eps_dev : p.eps, pr);
+  actor_head_probs(lds.h2s, hb, w, lane, p.eps_dev ? *p.eps_dev : p.eps, pr);
   const int act = actor_pick(pr, u);
   if (head_ok) {
     p.actions[hr] = act;

@@ -34,16 +34,15 @@ __device__ __forceinline__ float actor_uniform(uint64_t seed, uint64_t genv, uin
 }
 
 __device__ __forceinline__ int actor_pick(const float (&pr)[kA], float u) {
-  int act = kA - 1;
+  // first action whose cumulative probability exceeds u, the last one otherwise.  The running sum never decreases (pr >= 0), so
+  // the comparisons that fail form a prefix and the index is their count: no branches (the if-chain compiled to four exec-mask
+  // regions on the path of every tick)
+  int act = 0;
   float cdf = 0.0f;
-  bool chosen = false;
 #pragma unroll
   for (int a = 0; a < kA - 1; ++a) {
     cdf += pr[a];
-    if (!chosen && u < cdf) {
-      act = a;
-      chosen = true;
-    }
+    act += (u < cdf) ? 0 : 1;
   }
   return act;
 }

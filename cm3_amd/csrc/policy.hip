@@ -116,8 +116,10 @@ template <int N, int BF16, int RT> __global__ void __launch_bounds__(256) k_poli
     if (row_wave) {   // (wave-uniform; no workgroup barrier inside)
     float pr[kA];
     const float u = actor_uniform_from(ublock, episode, steps);
-    actor_head_probs(lds.h2s, hb, lds.lg, wr, lane, q.eps, pr);
-    const int act = actor_pick(pr, u);
+    actor_head_probs(lds.h2s, hb, wr, lane, q.eps, pr);
+    // (the head leaves the row's probabilities in lanes 0..15 only; lanes 16..63 repeat the physics of lane l & 15 -- their
+    // copies of the post-step state meet in the same LDS slots -- so they need the same action)
+    const int act = bcast_row0(actor_pick(pr, u));
     CM3_STAMP(7, false);
     if (writer) {
       tick_ptr(p.actions, p.st_actions, t)[r] = act;
