@@ -146,12 +146,16 @@ template <int N> __global__ void __launch_bounds__(256) k_actor_pack(const Actor
 //                that (weights ~3 orders of magnitude above anything a trained policy holds) saturates instead of matching.
 constexpr int kPrecF32 = 0, kPrecBf16 = 1, kPrecF16x3 = 2;
 
-// relu as ONE v_max_f32: fmaxf(x, 0) first canonicalises x (a second v_max_f32 x, x) because the build honours signalling NaNs;
-// matrix-core outputs are never signalling, and a quiet NaN comes out as 0 either way (v_max returns the non-NaN operand)
+// relu as ONE instruction: fmaxf(x, 0) first canonicalises x (a second v_max_f32 x, x) because the build honours signalling NaNs
+// (v_med3_f32 against 0 and +inf is folded back into the same pair).  On the bit patterns it is a signed-integer maximum: a float
+// with the sign bit set is a negative integer (-0.0 included, a NaN with the sign bit too; a positive NaN stays what it is), every
+// other float is its own non-negative integer.  Plain C rather than inline assembly: the compiler's hazard recogniser does not look
+// into an asm statement, and with the accumulators in architectural VGPRs (build.sh) the operand is the matrix instruction's own
+// destination -- an opaque "v_max_f32" read it before the passes were through (caught by tests/test_gpu_actor.py on the first
+// build with that flag).
 __device__ __forceinline__ float relu_f32(float x) {
-  float r;
-  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
-  return r;
+  const int xi = __builtin_bit_cast(int, x);
+  return __builtin_bit_cast(float, xi > 0 ? xi : 0);
 }
 
 // RT = 16-row tiles per workgroup (4: 64 agent rows, the one-tick actor kernel; the fused policy rollout also runs 2 or 1 so that a
@@ -169,6 +173,11 @@ template <int N, int PREC, int RT = 4> struct ActorGeom {
   static constexpr int HS = KU + 2;        // f32 row: 194 floats (8-byte aligned rows; reads of 16 rows x 2 k hit 32 distinct banks)
   static constexpr int kH1Floats = BF16 ? PLANES * (ROWS * HB) / 2 : ROWS * HS;
   static_assert(ROWS * (kH2 + 1) <= kH1Floats, "h2 must fit into the h1 storage");
+  // one- and two-tile workgroups (the fused policy rollout on small batches) keep h2 in LDS of its own: the barrier between the
+  // second layer's last read of h1 and the first store of h2 goes away, one of the tick's four (+8 KB at two tiles; several such
+  // workgroups still share a CU).  Four-tile workgroups stay at two per CU by reusing the h1 storage.
+  static constexpr bool H2SEP = RT <= 2;
+  static constexpr int kH2Floats = H2SEP ? ROWS * (kH2 + 1) : 1;
 };
 
 // Views into the workgroup's LDS (declared by the kernel with CM3_ACTOR_LDS).  h2 reuses the h1 storage once every wave
@@ -191,6 +200,7 @@ template <int N, int PREC, int RT = 4> struct ActorLds {
   __shared__ __attribute__((aligned(16))) float name##_tables[PackLayout<N_>::kTables];                        \
   __shared__ __attribute__((aligned(16))) float name##_h1raw[ActorGeom<N_, BF16_, RT_>::kH1Floats];            \
   __shared__ float name##_xs[16 * RT_][ActorGeom<N_, BF16_, RT_>::XW];                                         \
+  __shared__ float name##_h2raw[ActorGeom<N_, BF16_, RT_>::kH2Floats];                                         \
   ActorLds<N_, BF16_, RT_> name;                                                                               \
   name.tables = name##_tables;                                                                                 \
   name.ws_self = reinterpret_cast<float (*)[ActorGeom<N_, BF16_>::SW]>(&name##_tables[PackLayout<N_>::kSelf]); \
@@ -200,7 +210,7 @@ template <int N, int PREC, int RT = 4> struct ActorLds {
   name.h1b = reinterpret_cast<__bf16 (*)[ActorGeom<N_, BF16_>::HB]>(name##_h1raw);                             \
   name.h1h = reinterpret_cast<_Float16 (*)[ActorGeom<N_, BF16_>::HB]>(name##_h1raw);                           \
   name.h1l = reinterpret_cast<_Float16 (*)[ActorGeom<N_, BF16_>::HB]>(name##_h1raw) + 16 * RT_;                \
-  name.h2s = reinterpret_cast<float (*)[kH2 + 1]>(name##_h1raw);                                               \
+  name.h2s = reinterpret_cast<float (*)[kH2 + 1]>(ActorGeom<N_, BF16_, RT_>::H2SEP ? name##_h2raw : name##_h1raw); \
   name.xs = name##_xs
 #define CM3_ACTOR_LDS(N_, BF16_, name) CM3_ACTOR_LDS_RT(N_, BF16_, 4, name)
 
@@ -280,7 +290,8 @@ __device__ __forceinline__ void actor_first_b(const T *self_tab, const T *oth_ta
   }
 }
 
-// xs tile + tables ready and synchronised on entry; h2s ready and synchronised on exit (3 barriers inside).  The lane's
+// xs tile + tables ready and synchronised on entry; h2s ready and synchronised on exit (3 barriers inside, 2 where h2 has
+// storage of its own: ActorGeom::H2SEP).  The lane's
 // phase-A B operands are read from the LDS tables ONCE, up front (measured -0.9 % per launch against reading them inside each
 // block: 8.80 -> 8.72 us at 16 384 rows, same box).
 template <int N, int PREC, int RT>
@@ -425,7 +436,7 @@ __device__ __forceinline__ void actor_mlp(const ActorLds<N, PREC, RT> &lds, cons
     }
   }
   CM3_STAMP(5, true);
-  __syncthreads();  // all waves have consumed h1: its storage becomes h2
+  if constexpr (!G::H2SEP) __syncthreads();  // all waves have consumed h1: its storage becomes h2
   // ---- h2 = relu(add_n + b) (networks.py:533-534): C tile -> LDS rows --------------------------------------------------
 #pragma unroll
   for (int t = 0; t < RT; ++t)

@@ -23,8 +23,15 @@ pids+=($!)
 # Checkers: max-ILP scheduling throughout (C3 4.26 -> 4.16 us per tick; 2^16 .. 2^20 envs within 1 %)
 "${HIPCC}" ${FLAGS} -mllvm -amdgpu-kernarg-preload-count=16 -mllvm -amdgpu-sched-strategy=${CM3_HOT_SCHED:-max-ilp} ${CM3_HOT_FLAGS:-} -c "${HERE}/checkers.hip" -o "${HERE}/_obj/checkers.o" &
 pids+=($!)
-for f in util advantage actor actor_checkers policy; do
+for f in util advantage; do
   "${HIPCC}" ${FLAGS} -DCM3_SOURCE_ID="\"${SRC_ID}\"" -c "${HERE}/${f}.hip" -o "${HERE}/_obj/${f}.o" &
+  pids+=($!)
+done
+# the matrix-core kernels: accumulators in the architectural VGPRs (gfx90a and later take them there), so that the layers' epilogues
+# read them directly instead of through one v_accvgpr_read per value (60 per tick of the policy rollout), and no kernel is left
+# above 256 registers (one wave per SIMD): k_ck_actor_x3 304 -> 236, k_policy_rollout<8, ., 4> 296 -> 251
+for f in actor actor_checkers policy; do
+  "${HIPCC}" ${FLAGS} -mllvm -amdgpu-mfma-vgpr-form=${CM3_MFMA_VGPR:-1} -DCM3_SOURCE_ID="\"${SRC_ID}\"" -c "${HERE}/${f}.hip" -o "${HERE}/_obj/${f}.o" &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait "$p"; done

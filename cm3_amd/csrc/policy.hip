@@ -11,7 +11,7 @@
 // re-stage the weights, ~3 us are launch boundaries and ~2 us re-load state/observations.  Here a workgroup owns
 // 64 agent rows = 64/N whole envs for all T ticks:
 //   * weights: first-layer tables + output layer in LDS, W2 B-operands in VGPRs -- staged ONCE per launch;
-//   * per tick: actor_mlp (phase A / phase B on the matrix cores, 3 barriers) -> head: probabilities + action of row
+//   * per tick: actor_mlp (phase A / phase B on the matrix cores, 2 or 3 barriers) -> head: probabilities + action of row
 //     16w + (l&15) in the 16 "part 0" lanes of wave w -> the same lanes advance their agent: own-side contact forces
 //     against the other agents of the env (positions read from the LDS input tile), integration, reward / collision /
 //     reached, per-env reductions with wave shuffles, optional same-tick re-initialisation, and the next observation is
@@ -61,6 +61,12 @@ template <int N, int BF16, int RT> __global__ void __launch_bounds__(256) k_poli
   // b + 256, as the dispatcher fills the chip): the head and the physics of both would otherwise pile up on SIMDs 0 and 1 while
   // SIMDs 2 and 3 idle for 60 % of every tick (stamped build, profiles/r04_policy_row_tiles.txt).  Speed only: results do not
   // depend on the placement.
+#ifndef CM3_POLICY_PRIO
+#define CM3_POLICY_PRIO 2          // (macros: build variants for the measurement)
+#endif
+#ifndef CM3_POLICY_PRIO_MLP
+#define CM3_POLICY_PRIO_MLP 0
+#endif
 #ifndef CM3_POLICY_SHIFT_BIT
 #define CM3_POLICY_SHIFT_BIT 8     // (macro: build variant for the measurement)
 #endif
@@ -114,6 +120,11 @@ template <int N, int BF16, int RT> __global__ void __launch_bounds__(256) k_poli
     CM3_STAMP(0, false);
     actor_mlp<N, BF16, RT>(lds, b, f1, w, lane, q.stage > 1);
     if (row_wave) {   // (wave-uniform; no workgroup barrier inside)
+    // The head, the physics and the stores of the rows are the part of the tick only this wave can do while its workgroup waits at
+    // the closing barrier: it goes first on its SIMD, ahead of the matrix phases of the workgroup that shares the CU (measured,
+    // same box, three alternating rounds: 4.31 -> 4.15 us per tick at 4 096 x 4, 45.1 -> 44.6 at 65 536 x 4; levels 1, 2, 3 are
+    // the same, raising the priority for the WHOLE tick loses the gain; profiles/r04_policy_head.txt)
+    __builtin_amdgcn_s_setprio(CM3_POLICY_PRIO);
     float pr[kA];
     const float u = actor_uniform_from(ublock, episode, steps);
     actor_head_probs(lds.h2s, hb, wr, lane, q.eps, pr);
@@ -291,6 +302,7 @@ template <int N, int BF16, int RT> __global__ void __launch_bounds__(256) k_poli
       lds.xs[rl][4] = gl.x; lds.xs[rl][5] = gl.y;
     }
     CM3_STAMP(11, false);
+    __builtin_amdgcn_s_setprio(CM3_POLICY_PRIO_MLP);
     }  // row_wave
     __syncthreads();  // the tile (and the h1/h2 storage) is free for the next tick's phase A
     CM3_STAMP(12, false);
