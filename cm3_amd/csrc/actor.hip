@@ -197,7 +197,7 @@ template <int N, int PREC, int RT = 4> struct ActorLds {
 };
 
 #define CM3_ACTOR_LDS_RT(N_, BF16_, RT_, name)                                                                 \
-  __shared__ __attribute__((aligned(16))) float name##_tables[PackLayout<N_>::kTables];                        \
+  __shared__ __attribute__((aligned(16))) float name##_tables[ActorTabRegs<N_>::kPadded];                      \
   __shared__ __attribute__((aligned(16))) float name##_h1raw[ActorGeom<N_, BF16_, RT_>::kH1Floats];            \
   __shared__ float name##_xs[16 * RT_][ActorGeom<N_, BF16_, RT_>::XW];                                         \
   __shared__ float name##_h2raw[ActorGeom<N_, BF16_, RT_>::kH2Floats];                                         \
@@ -214,12 +214,34 @@ template <int N, int PREC, int RT = 4> struct ActorLds {
   name.xs = name##_xs
 #define CM3_ACTOR_LDS(N_, BF16_, name) CM3_ACTOR_LDS_RT(N_, BF16_, 4, name)
 
-// first-layer tables + output layer -> LDS: straight 16-byte copies of the packed prefix
+// first-layer tables + output layer -> LDS: straight 16-byte copies of the packed prefix, in two halves -- every request of the
+// kernel's entry is issued before the first wait (round 4: the copy was a loop of load / wait / store, 2.8 trips at N = 4 = three
+// memory round trips in a row before the weight slice and the input rows were even requested; 6 000 - 7 000 cycles from the
+// first instruction to the barrier, tools/probes/policy_timeline.hip)
+template <int N> struct ActorTabRegs {
+  static constexpr int kT4 = PackLayout<N>::kTables / 4;
+  static constexpr int NV = (kT4 + 255) / 256;
+  static constexpr int kPadded = NV * 256 * 4;   // floats of the LDS copy: whole trips of 256 lanes x 16 bytes (see actor_tables_store)
+  f32x4 v[NV];
+};
+template <int N> __device__ __forceinline__ void actor_tables_fetch(const float *packed, int tid, ActorTabRegs<N> &r) {
+  const f32x4 *src = reinterpret_cast<const f32x4 *>(packed);
+#pragma unroll
+  for (int k = 0; k < ActorTabRegs<N>::NV; ++k) {
+    const int idx = tid + 256 * k;   // (the last trip reads a clamped index instead of branching: straight-line requests)
+    r.v[k] = src[256 * (k + 1) <= ActorTabRegs<N>::kT4 ? idx : (idx < ActorTabRegs<N>::kT4 ? idx : ActorTabRegs<N>::kT4 - 1)];
+  }
+}
 template <int N, int PREC, int RT>
-__device__ __forceinline__ void actor_stage_tables(const ActorLds<N, PREC, RT> &lds, const float *packed, int tid) {
-  const float4 *src = reinterpret_cast<const float4 *>(packed);
-  float4 *dst = reinterpret_cast<float4 *>(lds.tables);
-  for (int t = tid; t < PackLayout<N>::kTables / 4; t += 256) dst[t] = src[t];
+__device__ __forceinline__ void actor_tables_store(const ActorLds<N, PREC, RT> &lds, int tid, const ActorTabRegs<N> &r) {
+  f32x4 *dst = reinterpret_cast<f32x4 *>(lds.tables);
+#pragma unroll
+  for (int k = 0; k < ActorTabRegs<N>::NV; ++k) {
+    // (unconditional: the LDS array is padded to whole trips and the lanes past the end store their clamped copy into the padding.
+    // With the store under a branch the compiler sank the last request into that branch -- a second round trip behind a
+    // wait for everything)
+    dst[tid + 256 * k] = r.v[k];
+  }
 }
 
 // B operands of this wave's 16 columns of W2 = [W_branch_self_h2 ; W_others_h2] and their bias, kept in VGPRs
@@ -543,34 +565,44 @@ template <int N, int PREC> __global__ void __launch_bounds__(256) k_actor_partic
   const int head_steps = p.meta[2 * he];
   const uint32_t head_episode = (uint32_t)p.episode[he];
 
-  // Kernel entry: tables -> LDS (wide, coalesced copies), wave 0 stages the input rows, the W2 slice is requested last.
+  // Kernel entry: every global request first (tables, wave 0's input rows, the W2 slice), then the LDS stores.
   // Measured and REJECTED in round 2 (tools/probes/actor_timeline.hip, 16 384 rows, same box, three repeats):
   // first-layer operands straight from global memory into registers instead of the table copy (+9 %: the entry is bound by the
   // request throughput of 256 workgroups reading the same few KB of L2, and narrow per-lane requests are worse than the wide
   // copy), the Philox draw before the first barrier (+0.5 %), input rows staged by all four waves (+-0), both (+1.1 %).
-  actor_stage_tables<N, PREC, 4>(lds, p.packed, tid);
+  ActorTabRegs<N> tab;
+  actor_tables_fetch<N>(p.packed, tid, tab);
   CM3_STAMP(8, false);
-  if (w == 0) {  // wave 0 stages the 64 input rows [v_obs(4) | v_goal(2) | obs_others(L)] into LDS, one row per lane
+  // the 64 input rows [v_obs(4) | v_goal(2) | obs_others(L)], one row per lane: wave 0 stages them into LDS; the other waves
+  // request the same (coalesced, cached) lines rather than branch around the loads
+  float4 in_s, in_o[L / 4];
+  float2 in_g;
+  {
     const size_t r = row_base + lane;
     const size_t rc = r < rows ? r : rows - 1;
     const size_t e = rc / N;
     const int i = (int)(rc - e * N);
-    const float4 s = reinterpret_cast<const float4 *>(p.state)[(size_t)i * p.E + e];
-    const float2 g = reinterpret_cast<const float2 *>(p.goals)[(size_t)i * p.E + e];
-    lds.xs[lane][0] = s.x; lds.xs[lane][1] = s.y; lds.xs[lane][2] = s.z; lds.xs[lane][3] = s.w;
-    lds.xs[lane][4] = g.x; lds.xs[lane][5] = g.y;
+    in_s = reinterpret_cast<const float4 *>(p.state)[(size_t)i * p.E + e];
+    in_g = reinterpret_cast<const float2 *>(p.goals)[(size_t)i * p.E + e];
     const float4 *o4 = reinterpret_cast<const float4 *>(p.obs_others + rc * L);
 #pragma unroll
-    for (int k = 0; k < L / 4; ++k) {
-      const float4 v = o4[k];
-      lds.xs[lane][6 + 4 * k + 0] = v.x; lds.xs[lane][6 + 4 * k + 1] = v.y;
-      lds.xs[lane][6 + 4 * k + 2] = v.z; lds.xs[lane][6 + 4 * k + 3] = v.w;
-    }
+    for (int k = 0; k < L / 4; ++k) in_o[k] = o4[k];
   }
   CM3_STAMP(9, false);
   ActorB<N, PREC> b;
   actor_load_b<N, PREC>(p.packed, w, lane, b);
   CM3_STAMP(10, false);
+  // ... everything is on its way: now the LDS side
+  actor_tables_store<N, PREC, 4>(lds, tid, tab);
+  if (w == 0) {
+    lds.xs[lane][0] = in_s.x; lds.xs[lane][1] = in_s.y; lds.xs[lane][2] = in_s.z; lds.xs[lane][3] = in_s.w;
+    lds.xs[lane][4] = in_g.x; lds.xs[lane][5] = in_g.y;
+#pragma unroll
+    for (int k = 0; k < L / 4; ++k) {
+      lds.xs[lane][6 + 4 * k + 0] = in_o[k].x; lds.xs[lane][6 + 4 * k + 1] = in_o[k].y;
+      lds.xs[lane][6 + 4 * k + 2] = in_o[k].z; lds.xs[lane][6 + 4 * k + 3] = in_o[k].w;
+    }
+  }
   CM3_STAMP(1, true);
   __syncthreads();
   CM3_STAMP(2, false);

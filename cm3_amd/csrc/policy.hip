@@ -54,6 +54,7 @@ template <int N, int BF16, int RT> __global__ void __launch_bounds__(256) k_poli
   const size_t E = (size_t)p.E;
   const size_t rows = E * N;
   const size_t row_base = (size_t)blockIdx.x * (16 * RT);
+  CM3_STAMP(13, false);   // kernel entry (probes only)
 
   // the row this lane owns in the head and in the physics: rl = 16w + (l&15); only part 0 (l < 16) of the waves w < RT writes
   // Which waves own rows: w < RT -- and, for two-tile workgroups, waves 2, 3 in every other group of 256 workgroups.  Wave w of a
@@ -85,31 +86,43 @@ template <int N, int BF16, int RT> __global__ void __launch_bounds__(256) k_poli
   const bool head_lane = writer && i == 0;
 
   // ---- once per launch: weights, live counters, the input tile ---------------------------------------------------------
-  actor_stage_tables<N, BF16, RT>(lds, q.packed, tid);
+  // every global request of the entry first (tables, the wave's W2 slice, counters, the rows' state / goals / observation), the
+  // sampling key's Philox block while they are in flight, then the LDS stores: one memory round trip before the barrier
+  // (the W2 slice first: it keeps its registers for the whole launch, and requested after the table copy the register allocator
+  // parked the copy in those very registers -- a wait for the tables, a move, and only then the slice's requests)
   ActorB<N, BF16> b;
   actor_load_b<N, BF16>(q.packed, w, lane, b);
+  ActorTabRegs<N> tab;
+  actor_tables_fetch<N>(q.packed, tid, tab);
   const int2 meta = reinterpret_cast<const int2 *>(p.meta_in)[e];
-  int steps = meta.x, collisions = meta.y;
   const bool auto_reset = (p.flags & CM3_FLAG_AUTO_RESET) != 0;
   uint32_t episode = (uint32_t)p.episode[e];
-  const uint32_t episode_in = episode;
-  if (part0) {
-    const V4 s0 = reinterpret_cast<const V4 *>(p.state_in)[(size_t)i * E + e];
-    const V2 g0 = reinterpret_cast<const V2 *>(p.goals_in)[(size_t)i * E + e];
-    lds.xs[rl][0] = s0.x; lds.xs[rl][1] = s0.y; lds.xs[rl][2] = s0.z; lds.xs[rl][3] = s0.w;
-    lds.xs[rl][4] = g0.x; lds.xs[rl][5] = g0.y;
+  V4 s0, o0[L / 4];   // (every lane requests its row -- lanes outside part 0 repeat one of part 0's -- rather than branch)
+  V2 g0;
+  {
+    s0 = reinterpret_cast<const V4 *>(p.state_in)[(size_t)i * E + e];
+    g0 = reinterpret_cast<const V2 *>(p.goals_in)[(size_t)i * E + e];
     const V4 *o4 = reinterpret_cast<const V4 *>(q.obs_in + r * L);
 #pragma unroll
+    for (int k = 0; k < L / 4; ++k) o0[k] = o4[k];
+  }
+  const uint32_t ublock = actor_block_word(p.seed, genv, i);   // stage 1 of the sampling uniforms: once per launch (actor_common.h)
+  int steps = meta.x, collisions = meta.y;
+  const uint32_t episode_in = episode;
+  actor_tables_store<N, BF16, RT>(lds, tid, tab);
+  if (part0) {
+    lds.xs[rl][0] = s0.x; lds.xs[rl][1] = s0.y; lds.xs[rl][2] = s0.z; lds.xs[rl][3] = s0.w;
+    lds.xs[rl][4] = g0.x; lds.xs[rl][5] = g0.y;
+#pragma unroll
     for (int k = 0; k < L / 4; ++k) {
-      const V4 v = o4[k];
-      lds.xs[rl][6 + 4 * k + 0] = v.x; lds.xs[rl][6 + 4 * k + 1] = v.y;
-      lds.xs[rl][6 + 4 * k + 2] = v.z; lds.xs[rl][6 + 4 * k + 3] = v.w;
+      lds.xs[rl][6 + 4 * k + 0] = o0[k].x; lds.xs[rl][6 + 4 * k + 1] = o0[k].y;
+      lds.xs[rl][6 + 4 * k + 2] = o0[k].z; lds.xs[rl][6 + 4 * k + 3] = o0[k].w;
     }
   }
   __syncthreads();
+  CM3_STAMP(14, true);    // tables, weights and the input tile are in
   ActorHeadB hb;
   actor_head_load(lds.wout, lane, hb);      // output-layer operands of this lane, once per launch
-  const uint32_t ublock = actor_block_word(p.seed, genv, i);   // stage 1 of the sampling uniforms: once per launch (actor_common.h)
   ActorFirstB<N> f1;                        // ... and its first-layer operands (round 4: they were re-read from LDS every tick)
   actor_first_b<N, float>(&lds.ws_self[0][0], &lds.ws_oth[0][0], w, lane, q.stage > 1, f1);
 
@@ -315,6 +328,7 @@ template <int N, int BF16, int RT> __global__ void __launch_bounds__(256) k_poli
     reinterpret_cast<int2 *>(p.meta_out)[e] = m;
     if (episode != episode_in) p.episode[e] = (int32_t)episode;
   }
+  CM3_STAMP(15, true);    // last store acknowledged
 }
 
 template <int N, int RT> static int policy_launch_rt(const PolicyParams &q, int prec, hipStream_t s) {
@@ -332,18 +346,18 @@ template <int N, int RT> static int policy_launch_rt(const PolicyParams &q, int 
 }
 
 // Row tiles per workgroup from the batch (measured on MI355X with the final kernel, f16x3, us per tick at RT = 4 / 2 / 1 --
-// profiles/r04_policy_row_tiles.txt):  N = 4: 2048 envs 4.47 / 3.29 / 3.13, 4096 envs (C2) 4.63 / 4.41 / 5.70, 8192 envs 6.58 / 8.06 /
-// 10.8, 65536 envs 45.8 / 59.2 / 83.0;  N = 8: 2048 envs 5.93 / 8.14 / 7.65, 8192 envs 22.8 / 31.3 / 28.9;  N = 2 at 8192 envs 4.00 /
-// 3.98 / 5.18;  N = 1 at 16384 envs 3.87 / 3.74 / 4.78.  A lone workgroup per CU is latency-bound and the smaller one is faster
-// (fewer matrix instructions per wave and tick); once a CU holds several, the 64-row workgroup does the most work per instruction
-// issued.  So: 64-row workgroups when they already give every CU more than one, 32-row ones down to half a workgroup per CU,
-// 16-row ones below.  N = 8 stays at 64 rows from half a workgroup per CU on: its 32-row build needs 261 registers, one wave per SIMD.
-// CM3_POLICY_RT = 1 | 2 | 4 overrides the choice (measurements only).
+// profiles/r04_policy_row_tiles.txt, re-swept after the accumulators moved to architectural VGPRs):  N = 4: 2048 envs 4.17 / 3.05 /
+// 2.86, 4096 envs (C2) 4.32 / 3.97 / 5.12, 8192 envs 6.00 / 7.21 / 9.68, 65536 envs 43.3 / 54.0 / 73.8;  N = 8: 512 envs 5.38 /
+// 3.94 / 3.23, 1024 envs 5.43 / 4.06 / 3.84, 2048 envs 5.63 / 5.37 / 6.99, 4096 envs 8.09 / 9.91 / 13.4, 8192 envs 15.2 / 19.4 /
+// 26.4;  N = 2 at 8192 envs 3.85 / 3.62 / 4.72;  N = 1 at 16384 envs 3.58 / 3.36 / 4.43.  A lone workgroup per CU is latency-bound
+// and the smaller one is faster (fewer matrix instructions per wave and tick); once a CU holds several, the 64-row workgroup does
+// the most work per instruction issued.  So: 64-row workgroups when they already give every CU more than one, 32-row ones down to
+// half a workgroup per CU, 16-row ones below -- for every N (N = 8 had a rule of its own while its 32-row build needed 261
+// registers, one wave per SIMD; every build is under 256 now).  CM3_POLICY_RT = 1 | 2 | 4 overrides the choice (measurements only).
 constexpr size_t kPolicyCus = 256;
 template <int N> static int policy_launch(const PolicyParams &q, int prec, hipStream_t s) {
   const size_t rows = (size_t)q.p.E * N, wg64 = (rows + 63) / 64;
   int rt = wg64 > kPolicyCus ? 4 : (wg64 > kPolicyCus / 2 ? 2 : 1);
-  if (N == 8 && wg64 >= kPolicyCus / 2) rt = 4;
   if (const char *e = getenv("CM3_POLICY_RT")) {
     const int v = atoi(e);
     if (v == 1 || v == 2 || v == 4) rt = v;

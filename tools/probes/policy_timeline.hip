@@ -9,6 +9,7 @@ __device__ long long *cm3_stamp_buf;
 #include <vector>
 int main(int argc, char **argv) {
   const int E = argc > 1 ? atoi(argv[1]) : 4096, N = 4, L = 12, T = 33;
+  const int TL = argc > 3 ? atoi(argv[3]) : T;   // ticks per launch (1 = the launch-per-tick mode of the fused kernel)
   const int prec = argc > 2 ? atoi(argv[2]) : 2;
   float *w; long long *stamps;
   const size_t nw = 6 * 64 + 64 + 64 * 64 + L * 128 + 128 + 128 * 64 + 64 + 64 * 5 + 5;
@@ -61,15 +62,15 @@ int main(int argc, char **argv) {
   }
   hipDeviceSynchronize();
   hipStream_t s; hipStreamCreate(&s);
-  for (int k = 0; k < 3; ++k) if (cm3_policy_rollout_f32(&d, &t, &ad, &wt, nullptr, 0, T, s)) { printf("%s\n", cm3_last_error()); return 1; }
+  for (int k = 0; k < 3; ++k) if (cm3_policy_rollout_f32(&d, &t, &ad, &wt, nullptr, 0, TL, s)) { printf("%s\n", cm3_last_error()); return 1; }
   hipStreamSynchronize(s);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   hipEventRecord(e0, s);
   const int reps = 20;
-  for (int k = 0; k < reps; ++k) cm3_policy_rollout_f32(&d, &t, &ad, &wt, nullptr, 0, T, s);
+  for (int k = 0; k < reps; ++k) cm3_policy_rollout_f32(&d, &t, &ad, &wt, nullptr, 0, TL, s);
   hipEventRecord(e1, s); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
-  printf("E=%d prec=%d %s: %.3f us per tick (33-tick launches back to back)\n", E, prec, cm3_last_kernel_variant(), ms * 1e3 / (reps * T));
+  printf("E=%d prec=%d %s: %.3f us per tick (%d-tick launches back to back)\n", E, prec, cm3_last_kernel_variant(), ms * 1e3 / (reps * TL), TL);
 #ifdef CM3_STAMPS
   const char *v = cm3_last_kernel_variant();
   const char *g = strstr(v, "g="); const int rt = g ? atoi(g + 2) : 4;
@@ -81,6 +82,15 @@ int main(int argc, char **argv) {
   const int order[] = {0, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12};
   const char *names[] = {"phase A (first layers + split)", "barrier", "phase B (second layer)", "h2 -> LDS + barrier", "head: logits, softmax, pick",
                          "physics: forces, integrate, exchange", "rewards / done / stores", "reset (if any)", "trajectory + tile stores", "end barrier"};
+  {  // launch prologue / epilogue: 13 kernel entry | 14 staged | 0 first... (slot 0 holds the LAST tick's start: prologue end only when TL == 1) | 15 out
+    double pro = 0, stage = 0, epi = 0, life = 0; int c = 0;
+    for (int wv = 0; wv < waves; ++wv) {
+      const long long *q = &h[(size_t)wv * 16];
+      if (!q[13] || !q[14] || !q[15] || !q[12]) continue;
+      stage += (double)(q[14] - q[13]); if (TL == 1) pro += (double)(q[0] - q[13]); epi += (double)(q[15] - q[12]); life += (double)(q[15] - q[13]); c++;
+    }
+    if (c) printf("  launch: entry -> staged %.0f | entry -> first tick %.0f (TL == 1 only) | last tick end -> out %.0f | wave life %.0f cycles (%d waves)\n", stage / c, pro / c, epi / c, life / c, c);
+  }
   for (int which = 0; which < 2; ++which) {
     double seg[10] = {0}; int c = 0;
     for (int wv = 0; wv < waves; ++wv) {
