@@ -764,8 +764,12 @@ def main():
         raise SystemExit("rank %d: launched with WORLD_SIZE=%d but --gpus %d" % (rank, world, args.gpus))
     n_visible = torch.cuda.device_count()
     if local_rank >= n_visible:
-        raise SystemExit("rank %d: --gpus %d needs %d GPUs on this node, only %d visible (local rank %d has no device)"
+        sys.stderr.write("rank %d: --gpus %d needs %d GPUs on this node, only %d visible (local rank %d has no device)\n"
                          % (rank, args.gpus, args.gpus, n_visible, local_rank))
+        sys.stderr.flush()
+        if under_launcher:
+            time.sleep(2.0)     # the launcher ends the other ranks at the first exit: let every rank say which device it lacks
+        raise SystemExit(1)
     if rank == 0:
         graft.build()
     torch.cuda.set_device(local_rank)
