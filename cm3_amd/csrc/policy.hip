@@ -358,6 +358,11 @@ constexpr size_t kPolicyCus = 256;
 template <int N> static int policy_launch(const PolicyParams &q, int prec, hipStream_t s) {
   const size_t rows = (size_t)q.p.E * N, wg64 = (rows + 63) / 64;
   int rt = wg64 > kPolicyCus ? 4 : (wg64 > kPolicyCus / 2 ? 2 : 1);
+  // One or two ticks per launch (the launch-per-tick mode): the entry -- 58 KB of tables and weight slice per workgroup through the
+  // CU's L1 path -- is as long as the tick, so the larger workgroup wins one step earlier (N = 4, one tick per launch, RT = 4 / 2 / 1:
+  // 1024 envs 8.34 / 7.50 / 6.75, 2048 envs 8.46 / 7.43 / 8.47, 4096 envs 8.72 / 9.71 / 14.2, 8192 envs 11.8 / 16.6 / 24.5 us;
+  // tools/probes/policy_tick_tiles.sh, profiles/r04_policy_head.txt)
+  if (q.p.n_ticks <= 2) rt = wg64 >= kPolicyCus ? 4 : (wg64 >= kPolicyCus / 2 ? 2 : 1);
   if (const char *e = getenv("CM3_POLICY_RT")) {
     const int v = atoi(e);
     if (v == 1 || v == 2 || v == 4) rt = v;
