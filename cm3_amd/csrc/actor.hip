@@ -20,6 +20,8 @@
 namespace cm3 {
 
 constexpr int kH1S = 64, kH1O = 128, kH2 = 64;
+constexpr int kH2W = kH2 + 4;   // h2 row in LDS: 68 floats = 16-byte aligned rows (the second layer stores four units at once); the head
+                                // reads a column of 16 rows x 4 k: 4 row + k is a distinct bank for rows 0..7, rows 8..15 share them two-way
 
 struct ActorParams {
   int E, stage;
@@ -172,12 +174,12 @@ template <int N, int PREC, int RT = 4> struct ActorGeom {
   static constexpr int XW = 6 + L + 1;    // input tile row: [v_obs(4) | v_goal(2) | obs_others(L)], odd stride
   static constexpr int HS = KU + 2;        // f32 row: 194 floats (8-byte aligned rows; reads of 16 rows x 2 k hit 32 distinct banks)
   static constexpr int kH1Floats = BF16 ? PLANES * (ROWS * HB) / 2 : ROWS * HS;
-  static_assert(ROWS * (kH2 + 1) <= kH1Floats, "h2 must fit into the h1 storage");
+  static_assert(ROWS * kH2W <= kH1Floats, "h2 must fit into the h1 storage");
   // one- and two-tile workgroups (the fused policy rollout on small batches) keep h2 in LDS of its own: the barrier between the
   // second layer's last read of h1 and the first store of h2 goes away, one of the tick's four (+8 KB at two tiles; several such
   // workgroups still share a CU).  Four-tile workgroups stay at two per CU by reusing the h1 storage.
   static constexpr bool H2SEP = RT <= 2;
-  static constexpr int kH2Floats = H2SEP ? ROWS * (kH2 + 1) : 1;
+  static constexpr int kH2Floats = H2SEP ? ROWS * kH2W : 4;
 };
 
 // Views into the workgroup's LDS (declared by the kernel with CM3_ACTOR_LDS).  h2 reuses the h1 storage once every wave
@@ -191,7 +193,7 @@ template <int N, int PREC, int RT = 4> struct ActorLds {
   __bf16 (*h1b)[G::HB];     // kPrecBf16: bf16 activations
   _Float16 (*h1h)[G::HB];   // kPrecF16x3: the hi plane ...
   _Float16 (*h1l)[G::HB];   // ... and the lo plane
-  float (*h2s)[kH2 + 1];
+  float (*h2s)[kH2W];
   float (*xs)[G::XW];
   float *tables;
 };
@@ -200,7 +202,7 @@ template <int N, int PREC, int RT = 4> struct ActorLds {
   __shared__ __attribute__((aligned(16))) float name##_tables[ActorTabRegs<N_>::kPadded];                      \
   __shared__ __attribute__((aligned(16))) float name##_h1raw[ActorGeom<N_, BF16_, RT_>::kH1Floats];            \
   __shared__ float name##_xs[16 * RT_][ActorGeom<N_, BF16_, RT_>::XW];                                         \
-  __shared__ float name##_h2raw[ActorGeom<N_, BF16_, RT_>::kH2Floats];                                         \
+  __shared__ __attribute__((aligned(16))) float name##_h2raw[ActorGeom<N_, BF16_, RT_>::kH2Floats];                                         \
   ActorLds<N_, BF16_, RT_> name;                                                                               \
   name.tables = name##_tables;                                                                                 \
   name.ws_self = reinterpret_cast<float (*)[ActorGeom<N_, BF16_>::SW]>(&name##_tables[PackLayout<N_>::kSelf]); \
@@ -210,7 +212,7 @@ template <int N, int PREC, int RT = 4> struct ActorLds {
   name.h1b = reinterpret_cast<__bf16 (*)[ActorGeom<N_, BF16_>::HB]>(name##_h1raw);                             \
   name.h1h = reinterpret_cast<_Float16 (*)[ActorGeom<N_, BF16_>::HB]>(name##_h1raw);                           \
   name.h1l = reinterpret_cast<_Float16 (*)[ActorGeom<N_, BF16_>::HB]>(name##_h1raw) + 16 * RT_;                \
-  name.h2s = reinterpret_cast<float (*)[kH2 + 1]>(ActorGeom<N_, BF16_, RT_>::H2SEP ? name##_h2raw : name##_h1raw); \
+  name.h2s = reinterpret_cast<float (*)[kH2W]>(ActorGeom<N_, BF16_, RT_>::H2SEP ? name##_h2raw : name##_h1raw); \
   name.xs = name##_xs
 #define CM3_ACTOR_LDS(N_, BF16_, name) CM3_ACTOR_LDS_RT(N_, BF16_, 4, name)
 
@@ -251,7 +253,7 @@ template <int N, int PREC> struct ActorB {
   bf16x8 bwb[PREC == kPrecBf16 ? G::KU / 32 : 1];       // kPrecBf16: bf16 weights
   f16x8 bwh[PREC == kPrecF16x3 ? G::KU / 32 : 1];       // kPrecF16x3: the hi parts ...
   f16x8 bwl[PREC == kPrecF16x3 ? G::KU / 32 : 1];       // ... and the lo parts
-  float bias_h2;
+  float bias_h2[4];   // units 16w + 4 (l>>4) + reg: the transposed second-layer tile holds four consecutive units of one row per lane
 };
 
 template <int N, int PREC>
@@ -281,7 +283,8 @@ __device__ __forceinline__ void actor_load_b(const float *packed, int w, int lan
       b.bw[4 * s4 + 0] = v.x; b.bw[4 * s4 + 1] = v.y; b.bw[4 * s4 + 2] = v.z; b.bw[4 * s4 + 3] = v.w;
     }
   }
-  b.bias_h2 = packed[PL::kBh2 + 16 * w + (lane & 15)];
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) b.bias_h2[reg] = packed[PL::kBh2 + 16 * w + 4 * (lane >> 4) + reg];
 }
 
 // Phase-A B operands of one lane: unit 16w + col of branch_self and units 32w + 16cq + col of actor_others, k = 4s + hi
@@ -412,6 +415,9 @@ __device__ __forceinline__ void actor_mlp(const ActorLds<N, PREC, RT> &lds, cons
   __syncthreads();
   CM3_STAMP(4, false);
   // ---- phase B: second layer on the matrix cores (networks.py:522-531: both matmuls, add_n) ---------------------------
+  // TRANSPOSED like the first layer (round 4, late): C[i = unit][j = row], the weight slice as the A operand and the activation
+  // rows as B -- the per-lane registers of both operands are the ones the untransposed form used, the products and their k order
+  // are the same, so the values are bit-identical; a lane ends with units c0 + 4 (l>>4) .. + 3 of row 16t + (l&15).
   f32x4 acc[RT];
 #pragma unroll
   for (int t = 0; t < RT; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -430,11 +436,11 @@ __device__ __forceinline__ void actor_mlp(const ActorLds<N, PREC, RT> &lds, cons
         al[t] = *reinterpret_cast<const f16x8 *>(&lds.h1l[16 * t + col][32 * s + 8 * hi]);
       }
 #pragma unroll
-      for (int t = 0; t < RT; ++t) accs[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], b.bwh[s], accs[t], 0, 0, 0);
+      for (int t = 0; t < RT; ++t) accs[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b.bwh[s], al[t], accs[t], 0, 0, 0);
 #pragma unroll
-      for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], b.bwh[s], acc[t], 0, 0, 0);
+      for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b.bwh[s], ah[t], acc[t], 0, 0, 0);
 #pragma unroll
-      for (int t = 0; t < RT; ++t) accs[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], b.bwl[s], accs[t], 0, 0, 0);
+      for (int t = 0; t < RT; ++t) accs[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b.bwl[s], ah[t], accs[t], 0, 0, 0);
     }
 #pragma unroll
     for (int t = 0; t < RT; ++t)
@@ -446,7 +452,7 @@ __device__ __forceinline__ void actor_mlp(const ActorLds<N, PREC, RT> &lds, cons
 #pragma unroll
       for (int t = 0; t < RT; ++t) {
         const bf16x8 a = *reinterpret_cast<const bf16x8 *>(&lds.h1b[16 * t + col][32 * s + 8 * hi]);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b.bwb[s], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b.bwb[s], a, acc[t], 0, 0, 0);
       }
     }
   } else {
@@ -454,16 +460,19 @@ __device__ __forceinline__ void actor_mlp(const ActorLds<N, PREC, RT> &lds, cons
     for (int s = 0; s < KU / 4; ++s) {
 #pragma unroll
       for (int t = 0; t < RT; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(lds.h1s[16 * t + col][4 * s + hi], b.bw[s], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.bw[s], lds.h1s[16 * t + col][4 * s + hi], acc[t], 0, 0, 0);
     }
   }
   CM3_STAMP(5, true);
   if constexpr (!G::H2SEP) __syncthreads();  // all waves have consumed h1: its storage becomes h2
   // ---- h2 = relu(add_n + b) (networks.py:533-534): C tile -> LDS rows --------------------------------------------------
 #pragma unroll
-  for (int t = 0; t < RT; ++t)
+  for (int t = 0; t < RT; ++t) {
+    f32x4 v;
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) lds.h2s[16 * t + 4 * hi + reg][c0 + col] = relu_f32(acc[t][reg] + b.bias_h2);
+    for (int reg = 0; reg < 4; ++reg) v[reg] = relu_f32(acc[t][reg] + b.bias_h2[reg]);
+    *reinterpret_cast<f32x4 *>(&lds.h2s[16 * t + col][c0 + 4 * hi]) = v;   // (one 16-byte store per tile: was four 4-byte ones)
+  }
   __syncthreads();
   CM3_STAMP(6, false);
 }
@@ -491,7 +500,7 @@ __device__ __forceinline__ void actor_head_load(const float *wout, int lane, Act
   for (int reg = 0; reg < 4; ++reg) hb.bias4[reg] = 4 * hi + reg < kA ? wout[kH2 * kA + 4 * hi + reg] : 0.0f;
 }
 
-__device__ __forceinline__ void actor_head_probs(const float (*h2s)[kH2 + 1], const ActorHeadB &hb, int w, int lane, float eps,
+__device__ __forceinline__ void actor_head_probs(const float (*h2s)[kH2W], const ActorHeadB &hb, int w, int lane, float eps,
                                                  float (&pr)[kA]) {
   const int col = lane & 15, hi = lane >> 4;
   // two accumulators (even / odd k-steps), added at the end: sixteen instructions on ONE accumulator each waited for its

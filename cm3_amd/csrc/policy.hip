@@ -145,14 +145,6 @@ template <int N, int BF16, int RT> __global__ void __launch_bounds__(256) k_poli
     // copies of the post-step state meet in the same LDS slots -- so they need the same action)
     const int act = bcast_row0(actor_pick(pr, u));
     CM3_STAMP(7, false);
-    if (writer) {
-      tick_ptr(p.actions, p.st_actions, t)[r] = act;
-      if (q.probs) {
-        float *pt = tick_ptr(q.probs, q.st_probs, t) + r * kA;
-#pragma unroll
-        for (int a = 0; a < kA; ++a) pt[a] = pr[a];
-      }
-    }
 
     // ---- physics of agent i (environment.py:81-123), lanes of part 0 ------------------------------------------------------
     V4 si;
@@ -251,7 +243,6 @@ template <int N, int BF16, int RT> __global__ void __launch_bounds__(256) k_poli
       reward = sum_agents<float, N>(rews);
     }
     const bool done = (steps == p.max_steps) || all_reached;
-    if (writer) reinterpret_cast<float *>(tick_ptr(p.reward_n, p.st_reward_n, t))[r] = rew;
     if (head_lane) {
       reinterpret_cast<float *>(tick_ptr(p.reward, p.st_reward, t))[e] = reward;
       tick_ptr(p.done, p.st_done, t)[e] = done ? 1 : 0;
@@ -296,7 +287,15 @@ template <int N, int BF16, int RT> __global__ void __launch_bounds__(256) k_poli
     CM3_STAMP(10, false);
     // ---- trajectory stores + the LDS tile of the next tick ---------------------------------------------------------------------
     if (part0) {
-      if (row_ok) {
+      if (row_ok) {   // every per-row store of the tick in ONE exec region (the action, its probabilities and the reward used to have
+                      // regions of their own further up: ~6 scalar instructions and a branch each on the row waves' path)
+        tick_ptr(p.actions, p.st_actions, t)[r] = act;
+        if (q.probs) {
+          float *pt = tick_ptr(q.probs, q.st_probs, t) + r * kA;
+#pragma unroll
+          for (int a = 0; a < kA; ++a) pt[a] = pr[a];
+        }
+        reinterpret_cast<float *>(tick_ptr(p.reward_n, p.st_reward_n, t))[r] = rew;
         reinterpret_cast<V4 *>(tick_ptr(p.state_out, p.st_state, t))[(size_t)i * E + e] = si;
         if (p.goals_out != p.goals_in || was_reset)
           reinterpret_cast<V2 *>(tick_ptr(p.goals_out, p.st_goals, t))[(size_t)i * E + e] = gl;
