@@ -776,17 +776,35 @@ __global__ void __launch_bounds__(256) k_ck_actor_x3(const CkActorParams p) {
   const int trow = tid >> 2, part = tid & 3;
   size_t row_t = row_base + trow;
   row_t = row_t < rows ? row_t : rows - 1;
-  double tv[4] = {0.0, 0.0, 0.0, 0.0};
-  int ap = 0, gl = 0;
-  if (part == 0) {
+  // Every lane requests ALL of its row's tail (the four lanes of a row repeat each other's addresses: same cache lines) instead of
+  // each part branching to its own loads.  The branches were executed one after the other, each with its own wait: prev_done ->
+  // actions_prev (two dependent round trips), then v_obs_others in a loop of load / wait per value -- four memory round trips
+  // behind each other in a phase that was a sixth of the launch (round 4, late; same disease as the particle actor's table copy).
+  double tv[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) tv[k] = p.obs_self_v[row_t * 4 + k];
-  } else if (part == 1) {
-    // a fresh episode starts from actions_prev = zeros (train_onpolicy.py:295)
-    const size_t e = row_t / N;
-    ap = (p.actions_prev && !(p.prev_done && p.prev_done[e])) ? p.actions_prev[row_t] : 0;
-    gl = p.goals[row_t];
+  for (int k = 0; k < 4; ++k) tv[k] = p.obs_self_v[row_t * 4 + k];
+  // v_obs_others: Lo = 2 (N - 1) <= 14 doubles per row (ck_actor_check), requested as pairs with a CLAMPED pair index -- straight-line
+  // loads (a predicate per value compiled to a branch, a load and a wait each)
+  constexpr int kLoMax = 14;
+  typedef double ck_dbl2 __attribute__((ext_vector_type(2)));
+  ck_dbl2 ov2[kLoMax / 2];
+  {
+    const int pairs = p.Lo >> 1;
+    const double *orow = p.obs_others + row_t * p.Lo;
+#pragma unroll
+    for (int j = 0; j < kLoMax / 2; ++j) {
+      const int jc = j < pairs ? j : (pairs > 0 ? pairs - 1 : 0);
+      ck_dbl2 v;
+      __builtin_memcpy(&v, orow + 2 * jc, 16);
+      ov2[j] = v;
+    }
   }
+  // a fresh episode starts from actions_prev = zeros (train_onpolicy.py:295)
+  const int prev_done_t = p.prev_done ? (int)p.prev_done[row_t / N] : 0;
+  const int prev_act_t = p.actions_prev ? (int)p.actions_prev[row_t] : 0;
+  const int gl = p.goals[row_t];
+  // (no `ap = prev_done ? 0 : prev_act` here: a select with a loaded operand is turned back into a branch around the load, i.e.
+  // into the dependent round trip this block removes -- the one-hot below tests both values instead)
   // zero fills: the k padding of X0, the tail of X2 (units 32 .. 63: values follow below, same wave, program order), the XO rows
   if (dwords) {
     for (int idx = tid; idx < 64 * (kKConvX - kObs); idx += 256) {
@@ -816,11 +834,14 @@ __global__ void __launch_bounds__(256) k_ck_actor_x3(const CkActorParams p) {
     for (int k = 0; k < 4; ++k) put_split(sX2h, sX2l, at0 + k, (float)tv[k]);
   } else if (part == 1) {
 #pragma unroll
-    for (int k = 0; k < kA; ++k) sX2h[at0 + 4 + k] = ap == k ? (_Float16)1.0f : (_Float16)0.0f;
+    for (int k = 0; k < kA; ++k)
+      sX2h[at0 + 4 + k] = (_Float16)(float)(int)((k == 0 ? (prev_act_t == 0) | (prev_done_t != 0) : (prev_act_t == k) & (prev_done_t == 0)));
     sX2h[at0 + 9] = gl == 0 ? (_Float16)1.0f : (_Float16)0.0f;
     sX2h[at0 + 10] = gl == 0 ? (_Float16)0.0f : (_Float16)1.0f;
   } else if (part == 3) {
-    for (int k = 0; k < p.Lo; ++k) put_split(sXOh, sXOl, trow * kLhXO + k, (float)p.obs_others[row_t * p.Lo + k]);
+#pragma unroll
+    for (int k = 0; k < kLoMax; ++k)
+      if (k < p.Lo) put_split(sXOh, sXOl, trow * kLhXO + k, (float)ov2[k >> 1][k & 1]);
   }
   if (dwords) {
     // window bytes -> float16 (values in {-1, 0, 1}): each dword's four bytes go to their (row, k) slots
