@@ -20,8 +20,7 @@
 namespace cm3 {
 
 constexpr int kH1S = 64, kH1O = 128, kH2 = 64;
-constexpr int kH2W = kH2 + 4;   // h2 row in LDS: 68 floats = 16-byte aligned rows (the second layer stores four units at once); the head
-                                // reads a column of 16 rows x 4 k: 4 row + k is a distinct bank for rows 0..7, rows 8..15 share them two-way
+constexpr int kH2W = kH2 + 1;   // h2 row in LDS (odd stride)
 
 struct ActorParams {
   int E, stage;
@@ -253,7 +252,7 @@ template <int N, int PREC> struct ActorB {
   bf16x8 bwb[PREC == kPrecBf16 ? G::KU / 32 : 1];       // kPrecBf16: bf16 weights
   f16x8 bwh[PREC == kPrecF16x3 ? G::KU / 32 : 1];       // kPrecF16x3: the hi parts ...
   f16x8 bwl[PREC == kPrecF16x3 ? G::KU / 32 : 1];       // ... and the lo parts
-  float bias_h2[4];   // units 16w + 4 (l>>4) + reg: the transposed second-layer tile holds four consecutive units of one row per lane
+  float bias_h2;
 };
 
 template <int N, int PREC>
@@ -283,8 +282,7 @@ __device__ __forceinline__ void actor_load_b(const float *packed, int w, int lan
       b.bw[4 * s4 + 0] = v.x; b.bw[4 * s4 + 1] = v.y; b.bw[4 * s4 + 2] = v.z; b.bw[4 * s4 + 3] = v.w;
     }
   }
-#pragma unroll
-  for (int reg = 0; reg < 4; ++reg) b.bias_h2[reg] = packed[PL::kBh2 + 16 * w + 4 * (lane >> 4) + reg];
+  b.bias_h2 = packed[PL::kBh2 + 16 * w + (lane & 15)];
 }
 
 // Phase-A B operands of one lane: unit 16w + col of branch_self and units 32w + 16cq + col of actor_others, k = 4s + hi
@@ -343,22 +341,25 @@ __device__ __forceinline__ void actor_mlp(const ActorLds<N, PREC, RT> &lds, cons
     // ds_write_b64 per four float16 values (two for hi + lo), two per four float32 values -- 24 LDS stores per wave instead of 96 / 48.
     auto put4 = [&](int row, int unit0, const float (&h)[4]) {
       if constexpr (PREC == kPrecF16x3) {
-        // hi = f16(h) (packed convert), lo' = f16((h - hi) * 2^11) as ONE mixed-precision fma per value on the packed hi pair:
-        // fma(hi, -2^11, h * 2^11) is exact before its single rounding to float16 -- the same bits as subtract, scale, convert
-        // (7.2 -> 4 VALU instructions per value of the layer's epilogue, the largest block of the tick)
+        // hi = f16(h) (packed convert), lo' = f16((h - hi) * 2^11) as fma(hi, -2^11, h * 2^11) on the pair: exact before its single
+        // rounding to float16 -- the same bits as subtract, scale, convert
         typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        typedef float f2 __attribute__((ext_vector_type(2)));
         uint2 vh, vl;
 #pragma unroll
         for (int r2 = 0; r2 < 2; ++r2) {
-          h2 hp;
-          hp[0] = (_Float16)h[2 * r2];
-          hp[1] = (_Float16)h[2 * r2 + 1];
+          // Plain vector C, NOT inline assembly (round 4 had v_fma_mixlo / mixhi_f16 in asm statements here, one instruction less
+          // per value): with the accumulators in architectural VGPRs an asm statement's registers can be ones a matrix instruction in
+          // flight still reads or writes, and the hazard recogniser does not look into asm (how the inline relu failed, see
+          // relu_f32).  No failure was traced to those two; this form cannot have one.  (hi as float) * -2^11 + h * 2^11 is exact in
+          // float32 (the residual of an 11-bit rounding has at most 13 significant bits), so the one rounding is the conversion.
+          const f2 hv = f2{h[2 * r2], h[2 * r2 + 1]};
+          const h2 hp = __builtin_convertvector(hv, h2);
+          const f2 res = __builtin_elementwise_fma(__builtin_convertvector(hp, f2), f2{-kLoScale, -kLoScale}, hv * kLoScale);
+          const h2 lp = __builtin_convertvector(res, h2);
           uint32_t hw, lw;
           __builtin_memcpy(&hw, &hp, 4);
-          typedef float f2 __attribute__((ext_vector_type(2)));
-          const f2 sc = f2{h[2 * r2], h[2 * r2 + 1]} * kLoScale;     // (one packed multiply)
-          asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lw) : "v"(hw), "v"(-kLoScale), "v"(sc[0]));
-          asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lw) : "v"(hw), "v"(-kLoScale), "v"(sc[1]));
+          __builtin_memcpy(&lw, &lp, 4);
           if (r2 == 0) { vh.x = hw; vl.x = lw; } else { vh.y = hw; vl.y = lw; }
         }
         *reinterpret_cast<uint2 *>(&lds.h1h[row][unit0]) = vh;
@@ -415,9 +416,11 @@ __device__ __forceinline__ void actor_mlp(const ActorLds<N, PREC, RT> &lds, cons
   __syncthreads();
   CM3_STAMP(4, false);
   // ---- phase B: second layer on the matrix cores (networks.py:522-531: both matmuls, add_n) ---------------------------
-  // TRANSPOSED like the first layer (round 4, late): C[i = unit][j = row], the weight slice as the A operand and the activation
-  // rows as B -- the per-lane registers of both operands are the ones the untransposed form used, the products and their k order
-  // are the same, so the values are bit-identical; a lane ends with units c0 + 4 (l>>4) .. + 3 of row 16t + (l&15).
+  // NOT transposed like the first layer.  Tried (round 4, late: weights as A, one 16-byte h2 store per tile): no faster, and with two
+  // N = 8 workgroups per CU a handful of rows per 65 536 came out wrong in launches of several ticks -- only then, only in float16
+  // split precision, gone with the workgroup alone on its CU or with this operand order; the generated code reads the matrix
+  // results through packed VALU instructions there.  Root cause not established; tests/test_gpu_actor.py::
+  // test_policy_rollout_row_tile_rule_at_the_baseline_sizes is the test that caught it (profiles/r04_policy_head.txt (7)).
   f32x4 acc[RT];
 #pragma unroll
   for (int t = 0; t < RT; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -436,11 +439,11 @@ __device__ __forceinline__ void actor_mlp(const ActorLds<N, PREC, RT> &lds, cons
         al[t] = *reinterpret_cast<const f16x8 *>(&lds.h1l[16 * t + col][32 * s + 8 * hi]);
       }
 #pragma unroll
-      for (int t = 0; t < RT; ++t) accs[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b.bwh[s], al[t], accs[t], 0, 0, 0);
+      for (int t = 0; t < RT; ++t) accs[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], b.bwh[s], accs[t], 0, 0, 0);
 #pragma unroll
-      for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b.bwh[s], ah[t], acc[t], 0, 0, 0);
+      for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], b.bwh[s], acc[t], 0, 0, 0);
 #pragma unroll
-      for (int t = 0; t < RT; ++t) accs[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b.bwl[s], ah[t], accs[t], 0, 0, 0);
+      for (int t = 0; t < RT; ++t) accs[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], b.bwl[s], accs[t], 0, 0, 0);
     }
 #pragma unroll
     for (int t = 0; t < RT; ++t)
@@ -452,7 +455,7 @@ __device__ __forceinline__ void actor_mlp(const ActorLds<N, PREC, RT> &lds, cons
 #pragma unroll
       for (int t = 0; t < RT; ++t) {
         const bf16x8 a = *reinterpret_cast<const bf16x8 *>(&lds.h1b[16 * t + col][32 * s + 8 * hi]);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b.bwb[s], a, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b.bwb[s], acc[t], 0, 0, 0);
       }
     }
   } else {
@@ -460,19 +463,16 @@ __device__ __forceinline__ void actor_mlp(const ActorLds<N, PREC, RT> &lds, cons
     for (int s = 0; s < KU / 4; ++s) {
 #pragma unroll
       for (int t = 0; t < RT; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.bw[s], lds.h1s[16 * t + col][4 * s + hi], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(lds.h1s[16 * t + col][4 * s + hi], b.bw[s], acc[t], 0, 0, 0);
     }
   }
   CM3_STAMP(5, true);
   if constexpr (!G::H2SEP) __syncthreads();  // all waves have consumed h1: its storage becomes h2
   // ---- h2 = relu(add_n + b) (networks.py:533-534): C tile -> LDS rows --------------------------------------------------
 #pragma unroll
-  for (int t = 0; t < RT; ++t) {
-    f32x4 v;
+  for (int t = 0; t < RT; ++t)
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) v[reg] = relu_f32(acc[t][reg] + b.bias_h2[reg]);
-    *reinterpret_cast<f32x4 *>(&lds.h2s[16 * t + col][c0 + 4 * hi]) = v;   // (one 16-byte store per tile: was four 4-byte ones)
-  }
+    for (int reg = 0; reg < 4; ++reg) lds.h2s[16 * t + 4 * hi + reg][c0 + col] = relu_f32(acc[t][reg] + b.bias_h2);
   __syncthreads();
   CM3_STAMP(6, false);
 }

@@ -49,6 +49,10 @@ template <int N, int BF16, int RT> __global__ void __launch_bounds__(256) k_poli
   const ParticleParams &p = q.p;
   CM3_ACTOR_LDS_RT(N, BF16, RT, lds);
   __shared__ __attribute__((aligned(16))) float4 ns[16 * RT];  // post-step (vx, vy, px, py) of every row, exchanged inside a wave
+#ifdef CM3_POLICY_PADLDS
+  __shared__ float lds_pad[10000];   // (experiment: one workgroup per CU)
+  if (threadIdx.x == 0 && q.p.n_ticks < 0) lds_pad[q.p.E % 10000] = 1.0f;
+#endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const size_t E = (size_t)p.E;

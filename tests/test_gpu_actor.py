@@ -194,6 +194,71 @@ def test_fused_policy_rollout_equals_launch_per_tick(N, cfg, auto_reset, precisi
         ro.close()
 
 
+def _policy_run(E, N, cfg, precision, T, mode, seed=21, **kw):
+    from cm3_amd import _lib
+    from cm3_amd.actor import ParticleActor
+    from cm3_amd.rollout import ParticleRollout
+    stage = 1 if N == 1 else 2
+    w = AO.init_weights(np.random.default_rng(N + 100), N, stage=stage)
+    env = _env(E, N, cfg, seed=seed, auto_reset=True, max_steps=7)
+    env.reset()
+    actor = ParticleActor(w, N, stage=stage, device="cuda:0", seed=seed, precision=precision)
+    ro = ParticleRollout(env, n_ticks=T, use_graph=False, policy_mode=mode, **kw)
+    ro.collect(policy=actor, epsilon=0.15, reset=False)
+    torch.cuda.synchronize()
+    return ro, env, _lib.last_kernel_variant()
+
+
+def _same_rollout(a, ea, b, eb):
+    for name in ("actions", "state", "obs_others", "reward", "reward_n", "done", "collisions", "goals"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    d = a.done.bool()
+    assert int(d.sum()) > 0
+    assert torch.equal(a.term_state.permute(0, 2, 1, 3)[d], b.term_state.permute(0, 2, 1, 3)[d])
+    assert torch.equal(ea.steps, eb.steps) and torch.equal(ea.collisions, eb.collisions)
+    assert torch.equal(ea.episode, eb.episode) and torch.equal(ea.global_state, eb.global_state)
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("N,cfg", [(4, "particle_stage2_cross.json"), (8, "particle_merge8.json"), (2, "particle_stage2_merge.json")])
+def test_every_row_tile_build_of_the_policy_rollout_is_the_same_rollout(N, cfg, precision, monkeypatch):
+    """k_policy_rollout<N, prec, RT>: 16 / 32 / 64 agent rows per workgroup are three builds of the kernel (policy.hip picks one by
+    batch size; the small test batches elsewhere only ever reach RT = 1).  CM3_POLICY_RT forces each in turn on ONE batch: all three
+    must reproduce the alternating actor / step launches bit for bit, and cm3_last_kernel_variant() must name the build that ran."""
+    E, T = 600, 16            # ragged: 600 x N rows is no multiple of 64
+    monkeypatch.delenv("CM3_POLICY_RT", raising=False)
+    ref, eref, _ = _policy_run(E, N, cfg, precision, T, "tick")
+    for rt in (1, 2, 4):
+        monkeypatch.setenv("CM3_POLICY_RT", str(rt))
+        ro, env, variant = _policy_run(E, N, cfg, precision, T, "episode")
+        assert variant.startswith("k_policy_rollout<") and ("g=%d," % rt) in variant, variant
+        _same_rollout(ref, eref, ro, env)
+        ro.close()
+    ref.close()
+
+
+@pytest.mark.parametrize("E,N,cfg,rt,rt_tick", [(4096, 4, "particle_stage2_antipodal.json", 2, 4),     # C2: two 32-row workgroups per CU
+                                                (8192, 4, "particle_stage2_antipodal.json", 4, 4),
+                                                (2048, 4, "particle_stage2_antipodal.json", 1, 2),
+                                                (8192, 8, "particle_merge8.json", 4, 4),              # C5
+                                                (2048, 8, "particle_merge8.json", 2, 4)])
+def test_policy_rollout_row_tile_rule_at_the_baseline_sizes(E, N, cfg, rt, rt_tick, monkeypatch):
+    """The rule itself (policy_launch): which build a whole-episode launch and a one-tick launch take at the BASELINE batch sizes,
+    and that those launches equal the alternating actor / step launches there too."""
+    monkeypatch.delenv("CM3_POLICY_RT", raising=False)
+    T = 9
+    ref, eref, _ = _policy_run(E, N, cfg, "f16x3", T, "tick")
+    ro, env, variant = _policy_run(E, N, cfg, "f16x3", T, "episode")
+    assert ("g=%d," % rt) in variant and "fused=1" in variant, variant
+    _same_rollout(ref, eref, ro, env)
+    ro.close()
+    ro, env, variant = _policy_run(E, N, cfg, "f16x3", T, "tick", fused_policy_tick=True)
+    assert ("g=%d," % rt_tick) in variant and "fused=0" in variant, variant
+    _same_rollout(ref, eref, ro, env)
+    ro.close()
+    ref.close()
+
+
 @pytest.mark.parametrize("precision", ["f32", "f16x3"])
 @pytest.mark.parametrize("tag,N,stage", [("n4_stage2", 4, 2), ("n1_stage1", 1, 1), ("n8_stage2", 8, 2)])
 def test_device_actor_matches_vectors_from_the_reference_function_body(tag, N, stage, precision):
