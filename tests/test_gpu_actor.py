@@ -194,6 +194,37 @@ def test_fused_policy_rollout_equals_launch_per_tick(N, cfg, auto_reset, precisi
         ro.close()
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("E,N,cfg", [(16384, 4, "particle_stage2_antipodal.json"), (8192, 8, "particle_merge8.json"),
+                                     (32768, 2, "particle_stage2_merge.json")])
+def test_actor_on_a_large_batch_equals_the_same_rows_in_small_batches(E, N, cfg, precision):
+    """65 536 agent rows = 1024 workgroups, several per CU at once (the oracle tests above run 1-32 workgroups, alone on their
+    CUs): every row's probabilities and action must be the bits the same row gets when its env shard is evaluated on its own
+    (env_id_base: a shard of a batch is that part of the batch, tests/test_gpu_multirank.py), and a second launch must repeat the
+    first -- rows are independent, so any difference is a fault of the launch, not of the arithmetic."""
+    from cm3_amd.actor import ParticleActor
+    seed, eps, Es = 17, 0.1, 512
+    w = AO.init_weights(np.random.default_rng(N), N)
+
+    def run(n, base):
+        env = _env(n, N, cfg, seed=seed, env_id_base=base)
+        env.reset()
+        for _ in range(3):
+            env.step()
+        actor = ParticleActor(w, N, device="cuda:0", seed=seed, precision=precision)
+        a, p = actor.act(env, eps, return_probs=True)
+        a2, p2 = actor.act(env, eps, return_probs=True)
+        assert torch.equal(a, a2) and torch.equal(p, p2)
+        return a, p
+
+    a_big, p_big = run(E, 0)
+    assert np.abs(p_big.sum(-1).cpu().numpy() - 1).max() < 1e-5
+    for base in (0, E // 2 - Es, E - Es):
+        a, p = run(Es, base)
+        assert torch.equal(p, p_big[base:base + Es]), base
+        assert torch.equal(a, a_big[base:base + Es]), base
+
+
 def _policy_run(E, N, cfg, precision, T, mode, seed=21, **kw):
     from cm3_amd import _lib
     from cm3_amd.actor import ParticleActor

@@ -62,6 +62,34 @@ def test_actor_probs_and_samples_match_oracle(stage, eps, E, precision):
 
 
 @pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_actor_on_a_large_batch_equals_the_same_rows_in_small_batches(precision):
+    """32 768 envs x 2 agents = 1024 workgroups (the oracle tests run at most 32): every row must get the bits it gets when its env
+    shard is evaluated alone, and a second launch must repeat the first."""
+    from cm3_amd.actor import CheckersActor
+    seed, eps, E, Es, stage = 23, 0.1, 32768, 512, 2
+    rng = np.random.default_rng(5)
+    w = AO.init_weights(rng, 2, stage=stage)
+    prev_all = rng.integers(0, 5, (E, 2))
+
+    def run(n, base):
+        env, N = _env(n, stage, seed=seed, env_id_base=base)
+        env.reset(_goals(np.random.default_rng(1), n, N))
+        for _ in range(4):
+            env.step()
+        actor = CheckersActor(w, N, stage=stage, device="cuda:0", seed=seed, precision=precision)
+        a, p = actor.act(env, eps, actions_prev=prev_all[base:base + n], return_probs=True)
+        a2, p2 = actor.act(env, eps, actions_prev=prev_all[base:base + n], return_probs=True)
+        assert torch.equal(a, a2) and torch.equal(p, p2)
+        return a, p
+
+    a_big, p_big = run(E, 0)
+    for base in (0, E // 2 - Es, E - Es):
+        a, p = run(Es, base)
+        assert torch.equal(p, p_big[base:base + Es]), base
+        assert torch.equal(a, a_big[base:base + Es]), base
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
 def test_unpadded_env_records_take_the_byte_path(precision):
     """obs_self_t records of 150 bytes (not dword-aligned) go through the generic staging loop: same probabilities."""
     from cm3_amd.actor import CheckersActor
