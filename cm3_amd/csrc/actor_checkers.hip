@@ -740,6 +740,11 @@ __global__ void __launch_bounds__(256) k_ck_actor_x3(const CkActorParams p) {
   _Float16 *sX0 = sH, *sC1h = sH + 64 * kLhX0, *sC1l = sC1h + 64 * kLhC1;
   _Float16 *sX2h = sX2, *sX2l = sX2 + 64 * kLhX2, *sXOh = sXO, *sXOl = sXO + 64 * kLhXO;
   static_assert(64 * kLhX0 + 2 * 64 * kLhC1 <= 2 * 64 * kLdHb, "X0 and the C1 planes must fit into the H storage");
+  // One workgroup per CU, i.e. one wave per SIMD: gemm_x3 feeds the activations as the B operand and reloads them from LDS inside
+  // its k loop -- the pattern that produced wrong rows in the particle actor's second layer once two workgroups shared a CU
+  // (actor.hip, phase B; profiles/r04_policy_head.txt (9)).  Shrinking this kernel's LDS below half a CU's must come with the
+  // operands swapped back or with that cause found.
+  static_assert(sizeof(sH) + sizeof(sX2) + sizeof(sXO) > 80 * 1024, "k_ck_actor_x3 relies on being alone on its CU");
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
