@@ -272,7 +272,9 @@ def test_every_row_tile_build_of_the_policy_rollout_is_the_same_rollout(N, cfg, 
                                                 (8192, 4, "particle_stage2_antipodal.json", 4, 4),
                                                 (2048, 4, "particle_stage2_antipodal.json", 1, 2),
                                                 (8192, 8, "particle_merge8.json", 4, 4),              # C5
-                                                (2048, 8, "particle_merge8.json", 2, 4)])
+                                                (2048, 8, "particle_merge8.json", 2, 4),
+                                                (16384, 2, "particle_stage2_merge.json", 4, 4),       # two 64-row workgroups per CU, N = 2 ...
+                                                (32768, 1, "particle_stage1.json", 4, 4)])            # ... and N = 1
 def test_policy_rollout_row_tile_rule_at_the_baseline_sizes(E, N, cfg, rt, rt_tick, monkeypatch):
     """The rule itself (policy_launch): which build a whole-episode launch and a one-tick launch take at the BASELINE batch sizes,
     and that those launches equal the alternating actor / step launches there too."""
