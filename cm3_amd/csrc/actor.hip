@@ -416,9 +416,9 @@ __device__ __forceinline__ void actor_mlp(const ActorLds<N, PREC, RT> &lds, cons
   __syncthreads();
   CM3_STAMP(4, false);
   // ---- phase B: second layer on the matrix cores (networks.py:522-531: both matmuls, add_n) ---------------------------
-  // NOT transposed like the first layer.  Tried (round 4, late: weights as A, one 16-byte h2 store per tile): no faster, and once a
-  // CU ran more than one N = 8 workgroup of a launch a handful of rows per 65 536 came out wrong in launches of several ticks -- only
-  // then, only in float16 split precision, gone with this operand order or with the LDS padded so that a CU holds one workgroup,
+  // NOT transposed like the first layer.  Tried (round 4, late: weights as A, one 16-byte h2 store per tile): no faster, and with two
+  // N = 8 workgroups resident on a CU a handful of rows per 65 536 came out wrong in launches of several ticks -- only
+  // then, only in float16 split precision, gone with this operand order or with the LDS padded so that a CU holds one workgroup at a time,
   // NOT gone with the old scalar stores or with wait states before the epilogue / before the operand reloads.  Root cause not
   // established (profiles/r04_policy_head.txt (9)); until it is, activations reloaded inside a k loop stay on the A side.
   // tests/test_gpu_actor.py::test_policy_rollout_row_tile_rule_at_the_baseline_sizes is the test that caught it.
