@@ -177,7 +177,11 @@ template <int N, int BF16, int RT> __global__ void __launch_bounds__(256) k_poli
     si.z = si.z + si.x * kDt;
     si.w = si.w + si.y * kDt;
     steps += 1;
-    ns[rl] = si;      // (one 16-byte LDS store; the other agents' rows come back as 16-byte reads, once, for collisions AND observation)
+    // (one 16-byte LDS store; the other agents' rows come back as 16-byte reads, once, for collisions AND observation.  Lanes 0..15
+    // only: lanes 16..63 repeat their physics and used to store their copy into the same slot -- harmless while every copy
+    // is identical, but then the result hangs on the action broadcast above reaching all four copies; this way nothing a copy
+    // computes is ever stored)
+    if (part0) ns[rl] = si;
     wave_lds_sync();  // the other agents of this env live in the same wave
     V4 oth[NO];
 #pragma unroll
@@ -277,7 +281,7 @@ template <int N, int BF16, int RT> __global__ void __launch_bounds__(256) k_poli
       steps = 0;
       collisions = 0;
       was_reset = true;
-      ns[rl] = si;
+      if (part0) ns[rl] = si;
       wave_lds_sync();
     }
     if (auto_reset && __any(done)) {  // fresh episodes in this wave: the observation is that of the reset states
