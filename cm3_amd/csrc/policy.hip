@@ -145,8 +145,8 @@ template <int N, int BF16, int RT> __global__ void __launch_bounds__(256) k_poli
     float pr[kA];
     const float u = actor_uniform_from(ublock, episode, steps);
     actor_head_probs(lds.h2s, hb, wr, lane, q.eps, pr);
-    // (the head leaves the row's probabilities in lanes 0..15 only; lanes 16..63 repeat the physics of lane l & 15 -- their
-    // copies of the post-step state meet in the same LDS slots -- so they need the same action)
+    // (the head leaves the row's probabilities in lanes 0..15 only; lanes 16..63 repeat the physics of lane l & 15 and get its
+    // action so that they take the same branches -- nothing they compute is stored: see the exchange slot below)
     const int act = bcast_row0(actor_pick(pr, u));
     CM3_STAMP(7, false);
 
