@@ -10,7 +10,9 @@ import tests.test_gpu_actor as TA
 
 budget = 60.0 * float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 cases = [(4096, 4, "particle_stage2_antipodal.json"), (8192, 8, "particle_merge8.json"), (8192, 4, "particle_stage2_cross.json"),
-         (2048, 8, "particle_merge8.json"), (16384, 2, "particle_stage2_merge.json"), (4096, 8, "particle_merge8.json")]
+         (2048, 8, "particle_merge8.json"), (16384, 2, "particle_stage2_merge.json"), (4096, 8, "particle_merge8.json"),
+         (4099, 4, "particle_stage2_cross.json"), (8191, 8, "particle_merge8.json"), (32771, 1, "particle_stage1.json"),
+         (65536, 4, "particle_stage2_antipodal.json")]
 t0, runs, bad = time.time(), 0, 0
 seed = 1000
 while time.time() - t0 < budget:
