@@ -178,9 +178,8 @@ template <int N, int BF16, int RT> __global__ void __launch_bounds__(256) k_poli
     si.w = si.w + si.y * kDt;
     steps += 1;
     // (one 16-byte LDS store; the other agents' rows come back as 16-byte reads, once, for collisions AND observation.  Lanes 0..15
-    // only: lanes 16..63 repeat their physics and used to store their copy into the same slot -- harmless while every copy
-    // is identical, but then the result hangs on the action broadcast above reaching all four copies; this way nothing a copy
-    // computes is ever stored)
+    // only: lanes 16..63 repeat their physics and used to store their copy into the same slot -- the same value by the code,
+    // but this way nothing a copy computes is ever stored; profiles/r04_policy_head.txt (11))
     if (part0) ns[rl] = si;
     wave_lds_sync();  // the other agents of this env live in the same wave
     V4 oth[NO];
