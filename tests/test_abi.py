@@ -142,3 +142,23 @@ def test_library_carries_the_identity_of_its_sources(built):
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT,
                          env={k: v for k, v in os.environ.items() if k not in ("CM3_AMD_LIB", "CM3_AMD_ALLOW_STALE")})
     assert "REFUSED" in out.stdout, out.stdout + out.stderr
+
+
+def test_matrix_kernel_sources_hold_no_inline_assembly():
+    """csrc/build.sh compiles actor.hip / actor_checkers.hip / policy.hip with the matrix accumulators in architectural VGPRs
+    (-amdgpu-mfma-vgpr-form): there an asm statement's registers can be ones a matrix instruction in flight still reads or
+    writes, and the compiler's hazard recogniser does not look into asm statements (round 4: an inline `v_max_f32` relu read a
+    result before its passes were through; profiles/r04_policy_head.txt (4)).  The rule is enforced here, on the sources.
+    (policy.hip also includes particle.hip: its one asm statement, the write-through store, only READS registers that ordinary
+    VALU instructions produced.)"""
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cm3_amd", "csrc")
+    build = open(os.path.join(root, "build.sh")).read()
+    m = re.search(r"for f in ([a-z_ ]+); do\s*\n\s*\"\$\{HIPCC\}\" \$\{FLAGS\} -mllvm -amdgpu-mfma-vgpr-form", build)
+    assert m, "build.sh: the loop that compiles the matrix translation units with -amdgpu-mfma-vgpr-form was not found"
+    units = m.group(1).split()
+    assert set(units) == {"actor", "actor_checkers", "policy"}
+    for name in units + ["actor_common"]:
+        path = os.path.join(root, name + (".h" if name == "actor_common" else ".hip"))
+        code = re.sub(r"//[^\n]*", "", open(path).read())          # (comments may talk about asm)
+        assert not re.search(r"\basm\s*(volatile\s*)?\(", code), "%s: inline assembly in a matrix translation unit" % name
