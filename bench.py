@@ -661,6 +661,139 @@ def measure_other_config(name, args, device, steps=6, cpu_budget_s=6.0):
     return rec
 
 
+LINE_LIMIT = 4000            # bytes: the driver keeps an 8 KB stdout tail; round 4's 24 KB line was cut and never parsed
+EXTRAS_FILE = "bench_extras.json"
+
+
+def _sig(x, digits=6):
+    """numbers of the driver line carry six significant digits: enough for every quoted figure, a third of repr()'s bytes"""
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    if x != x or x in (float("inf"), float("-inf")):
+        return None
+    return float("%.*g" % (digits, x))
+
+
+def _pick(d, keys):
+    return {k: _sig(d[k]) for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def compact_line(out):
+    """The driver's line: `out` (everything this run measured, tens of KB with the extras) cut down to the contract's keys
+    + numbers -- headline, roofline, cpu_baseline, the other BASELINE configs and the policy-driven collection as plain
+    figures, no prose.  Everything dropped here is in bench_extras.json / the earlier `extras_summary` stdout line.
+    Always < LINE_LIMIT bytes (tests/test_bench_line.py builds it from recorded runs)."""
+    c = out.get("config", {})
+    line = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling"))
+    line["vs_baseline"] = out.get("vs_baseline")
+    line["dtype"] = str(out.get("dtype", ""))[:64]
+    line["data"] = "synthetic"
+    line["config"] = {"workload": str(c.get("workload", ""))[:200]}
+    line["config"].update(_pick(c, ("envs_per_gpu", "n_agents", "global_envs", "mode", "live_state", "ticks_per_launch")))
+    line["config"]["parallelism"] = str(c.get("parallelism", ""))[:80]
+    line["config"]["ticks_per_step"] = out.get("ticks_per_step")
+    line["us_per_tick"] = _sig(out.get("us_per_tick"))
+    r = out.get("roofline", {})
+    roof = _pick(r, ("bound", "achieved", "peak", "unit", "frac"))
+    roof["traffic"] = _sig(r.get("traffic"))
+    roof.update(_pick(r, ("algorithmic_bytes_per_launch", "avg_launch_us", "avg_launch_us_hip_events", "measured_read_GBps",
+                          "frac_of_measured_read")))
+    roof["kernel"] = str(r.get("kernel", ""))[:96]
+    if r.get("traffic") is not None:
+        roof["traffic_kind"] = "committed rocprofv3 --pmc passes (profiles/pmc_traffic.json), not this run"
+    if isinstance(r.get("kernel_span"), dict):
+        roof["kernel_span"] = _pick(r["kernel_span"], ("span_us", "gap_us", "start_to_start_us"))
+    if isinstance(r.get("launch_floor"), dict):
+        roof["launch_floor"] = _pick(r["launch_floor"], ("same_traffic_us", "empty_launch_us", "frac_of_floor"))
+    line["roofline"] = roof
+    cb = out.get("cpu_baseline")
+    if isinstance(cb, dict):
+        line["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind"))
+        line["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:160]
+        for k, short in (("vectorised_numpy", "vectorised_numpy"), ("scalar_port_all_cores", "all_cores")):
+            if isinstance(cb.get(k), dict):
+                line["cpu_baseline"][short] = _pick(cb[k], ("value", "cores"))
+    oc = out.get("other_configs")
+    if isinstance(oc, dict):
+        line["other_configs"] = {}
+        for name, rec in oc.items():
+            if not isinstance(rec, dict):
+                continue
+            o = _pick(rec, ("envs_per_gpu", "n_agents", "us_per_tick", "live_state"))
+            o["value"] = _sig(rec.get("env_steps_per_s"))
+            rr = rec.get("roofline", {})
+            o.update(_pick(rr, ("frac", "achieved", "algorithmic_bytes_per_launch", "avg_launch_us_hip_events")))
+            o["traffic"] = _sig(rr.get("traffic"))
+            if isinstance(rr.get("kernel_span"), dict):
+                o["kernel_span"] = _pick(rr["kernel_span"], ("span_us", "gap_us"))
+            if isinstance(rec.get("cpu_baseline_checkers"), dict):
+                o["cpu_baseline"] = _pick(rec["cpu_baseline_checkers"], ("value", "cores", "kind"))
+            line["other_configs"][name] = o
+    pr = out.get("policy_rollout")
+    if isinstance(pr, dict) and isinstance(pr.get("headline"), dict):
+        h = pr["headline"]
+        line["policy_rollout"] = _pick(h, ("us_per_tick", "env_steps_per_s"))
+        if isinstance(h.get("roofline"), dict):
+            line["policy_rollout"].update({"mfma_" + k: v for k, v in _pick(h["roofline"], ("frac", "matrix_time_us")).items()})
+    if isinstance(out.get("collective"), dict):
+        line["collective"] = _pick(out["collective"], ("host_us_per_rollout_rank0", "share_of_step_rank0"))
+    if "per_rank" in out and len(out["per_rank"]) > 1:
+        line["per_rank_wall_s"] = [_sig(p.get("wall_s")) for p in out["per_rank"]]
+    if isinstance(out.get("rccl"), dict):
+        line["rccl"] = _pick(out["rccl"], ("rccl_world_size", "backend", "rccl_version", "all_reduce_ok", "p2p_all_pairs"))
+    line["extras"] = EXTRAS_FILE
+    # belt and braces: whatever a future key adds, the line stays under the limit -- optional groups go first
+    for k in ("rccl", "per_rank_wall_s", "collective", "policy_rollout", "other_configs"):
+        if len(json.dumps(line)) < LINE_LIMIT:
+            break
+        line.pop(k, None)
+    return line
+
+
+def extras_summary(out):
+    """Second-to-last stdout line (also < LINE_LIMIT): the sweep and the launch modes as bare numbers, so that the driver's
+    tail shows the streaming-size roofline points next to the headline."""
+    s = {"extras_summary": True}
+    if isinstance(out.get("sweep"), list):
+        s["sweep_cols"] = ["log2_envs", "variant", "avg_launch_us", "frac_of_peak"]
+        s["sweep"] = [[int(p["envs"]).bit_length() - 1, str(p.get("variant", "in-place"))[:28], _sig(p["avg_launch_us"], 5),
+                       _sig(p["frac_of_peak"], 4)] for p in out["sweep"]]
+    lm = out.get("launch_modes")
+    if isinstance(lm, dict):
+        s["launch_modes"] = {k: _pick(v, ("us_per_tick", "frac_of_peak")) for k, v in lm.items() if isinstance(v, dict)}
+    if isinstance(out.get("fused_rollout"), dict):
+        s["fused_rollout"] = _pick(out["fused_rollout"], ("value", "avg_launch_us", "frac_of_peak"))
+    pr = out.get("policy_rollout")
+    if isinstance(pr, dict):
+        s["policy_us_per_tick"] = {prec: {m: _sig(v.get("us_per_tick", v.get("avg_launch_us")), 5) for m, v in sub.items() if isinstance(v, dict)}
+                                   for prec, sub in pr.items() if prec in ("f32", "f16x3") and isinstance(sub, dict)}
+    if isinstance(out.get("host_side"), dict):
+        s["host_side"] = out["host_side"]
+    while len(json.dumps(s)) >= LINE_LIMIT and s.get("sweep"):
+        s["sweep"].pop()
+    return s
+
+
+def emit(out):
+    """rank 0: bench_extras.json (the whole record; also under gpurun_out/ when that exists), then the summary line, then THE line."""
+    full = json.dumps(out, indent=1)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, EXTRAS_FILE), "w") as fh:
+                    fh.write(full)
+            except OSError as exc:
+                sys.stderr.write("bench: could not write %s in %s (%s)\n" % (EXTRAS_FILE, d, exc))
+    summary = extras_summary(out)
+    if len(summary) > 1:
+        print(json.dumps(summary))
+    line = compact_line(out)
+    text = json.dumps(line)
+    assert len(text) < LINE_LIMIT, len(text)
+    print(text)
+    sys.stdout.flush()
+
+
 def rccl_report(dist, torch, device, local_rank, world):
     """What the first multi-GPU record should answer by itself: did RCCL see `world` ranks, does a collective over them give
     the right answer, and which peers can every rank's GPU reach directly (P2P over xGMI)."""
@@ -1200,7 +1333,7 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_checkers(cfg) if kind == "checkers" else cpu_baseline(cfg, N)
     if rank == 0:
-        print(json.dumps(out))
+        emit(out)
     if use_dist:
         dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
