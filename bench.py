@@ -16,7 +16,9 @@ collection object (cm3_amd.rollout.ParticleRollout), replayed as one hipGraph pe
 drawn in-kernel (train_onpolicy.py:305-307), auto-reset at max_steps.  --steps K times exactly K phases after --warmup W.
 Env instances shard across ranks with NO data-path collective => "weak" scaling.
 
-One JSON line on rank 0:  metric = env-steps/s summed over all GPUs (max-over-ranks wall clock between two barriers);
+Rank 0 prints the driver's line LAST and keeps it under 4 KB (compact_line(): contract keys + numbers); everything else this
+run measured goes to bench_extras.json and, as bare numbers, to the stdout line before it (extras_summary()).
+The line:  metric = env-steps/s summed over all GPUs (max-over-ranks wall clock between two barriers);
 roofline  = algorithmic bytes of the timed launches (400 B x E per launch for N=4) / the SAME wall
             clock, against the 8 TB/s HBM3E peak (the HIP-event time of the same region is reported beside it);
 cpu_baseline = the reference-shaped scalar NumPy port (oracle.particle_oracle.ParticleEnvOracle) timed on the host
@@ -774,16 +776,18 @@ def extras_summary(out):
     return s
 
 
-def emit(out):
-    """rank 0: bench_extras.json (the whole record; also under gpurun_out/ when that exists), then the summary line, then THE line."""
+def emit(out, extras_file=None):
+    """rank 0: bench_extras.json (the whole record; also under gpurun_out/ when that exists; `--extras-file` names another place),
+    then the summary line, then THE line."""
     full = json.dumps(out, indent=1)
-    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
-        if os.path.isdir(d):
-            try:
-                with open(os.path.join(d, EXTRAS_FILE), "w") as fh:
-                    fh.write(full)
-            except OSError as exc:
-                sys.stderr.write("bench: could not write %s in %s (%s)\n" % (EXTRAS_FILE, d, exc))
+    targets = [extras_file] if extras_file else [os.path.join(d, EXTRAS_FILE) for d in (ROOT, os.path.join(ROOT, "gpurun_out"))
+                                                 if os.path.isdir(d)]
+    for path in targets:
+        try:
+            with open(path, "w") as fh:
+                fh.write(full)
+        except OSError as exc:
+            sys.stderr.write("bench: could not write %s (%s)\n" % (path, exc))
     summary = extras_summary(out)
     if len(summary) > 1:
         print(json.dumps(summary))
@@ -874,6 +878,8 @@ def main():
                     help="skip the short c3 / c5 / c4 runs that the default c2 line carries as 'other_configs'")
     ap.add_argument("--no-extras", action="store_true",
                     help="headline only: skip the in-place / chains / fused / policy-rollout / launch-floor extras (clean profiles)")
+    ap.add_argument("--extras-file", default=None,
+                    help="where the full record goes (default: %s next to bench.py and under gpurun_out/)" % EXTRAS_FILE)
     ap.add_argument("--fused", action="store_true",
                     help="random-action rollouts with all ticks of a phase in ONE launch (CM3_FLAG_FUSED_TICKS); "
                          "the default keeps one launch per tick")
@@ -1333,7 +1339,7 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_checkers(cfg) if kind == "checkers" else cpu_baseline(cfg, N)
     if rank == 0:
-        emit(out)
+        emit(out, args.extras_file)
     if use_dist:
         dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()

@@ -42,13 +42,21 @@ def _json_line(stdout):
 
 
 @pytest.mark.parametrize("workload", ["c4", "c2", "c5", "c3"])
-def test_bench_under_torchrun_one_rank(workload):
+def test_bench_under_torchrun_one_rank(workload, tmp_path):
     """The driver's N > 1 command shape with N = 1: nccl (= RCCL) init, barriers, the all-gather of the per-rank clocks and
-    (c4) of the advantage moments all execute on the box."""
+    (c4) of the advantage moments all execute on the box.  The LAST stdout line is the driver's compact record (< 4 KB); the full
+    record is the extras file."""
+    extras = str(tmp_path / "extras.json")
     r = _torchrun(1, ["bench.py", "--gpus", "1", "--workload", workload, "--steps", "3", "--warmup", "1", "--no-extras",
-                      "--no-sweep", "--no-cpu-baseline"])
+                      "--no-sweep", "--no-cpu-baseline", "--extras-file", extras])
     assert r.returncode == 0, r.stderr[-3000:]
-    out = _json_line(r.stdout)
+    line = _json_line(r.stdout)
+    assert len(r.stdout.strip().splitlines()[-1]) < 4096
+    assert line["n_gpus"] == 1 and line["value"] > 1e6 and line["roofline"]["frac"] > 0 and "workload" in line["config"]
+    assert line["rccl"]["rccl_world_size"] == 1 and line["rccl"]["all_reduce_ok"] is True
+    with open(extras) as fh:
+        out = json.load(fh)
+    assert out["value"] == pytest.approx(line["value"], rel=1e-5)
     assert out["n_gpus"] == 1 and out["scaling"] == "weak" and out["value"] > 1e6
     assert len(out["per_rank"]) == 1 and out["per_rank"][0]["rank"] == 0
     # the line says by itself what RCCL saw: world size from the process group, a checked all-reduce, the P2P matrix
