@@ -556,7 +556,7 @@ __device__ __forceinline__ int bcast_row0(int v) {
   return (int)x;
 }
 
-template <int N, int PREC> __global__ void __launch_bounds__(256) k_actor_particle(const ActorParams p) {
+template <int N, int PREC> __global__ void CM3_MATRIX_KERNEL k_actor_particle(const ActorParams p) {
   using G = ActorGeom<N, PREC>;
   constexpr int L = G::L;
   CM3_ACTOR_LDS(N, PREC, lds);

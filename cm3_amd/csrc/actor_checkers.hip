@@ -411,7 +411,7 @@ __device__ __forceinline__ void ck_actor_head(const CkActorParams &p, const floa
 }
 
 // BF16: the two 256 x 256 layers on the bf16 matrix cores (precision = 1, not a parity path); otherwise float32 throughout
-template <bool BF16> __global__ void __launch_bounds__(256) k_ck_actor(const CkActorParams p) {
+template <bool BF16> __global__ void CM3_MATRIX_KERNEL k_ck_actor(const CkActorParams p) {
   using namespace ck_actor;
   // H: [64][260] first-layer activations / h2; before that it holds X0 [64][84] and C1 [64][164]
   __shared__ __attribute__((aligned(16))) float sH[64 * kLdH];
@@ -729,7 +729,7 @@ __device__ __forceinline__ void put_split(_Float16 *h, _Float16 *l, int at, floa
   l[at] = (_Float16)(v - (float)vh);
 }
 
-__global__ void __launch_bounds__(256) k_ck_actor_x3(const CkActorParams p) {
+__global__ void CM3_MATRIX_KERNEL k_ck_actor_x3(const CkActorParams p) {
   using namespace ck_actor;
   // H planes [64][264] hi | lo (first-layer activations, then h2); before that the same storage holds X0 (hi only) and C1 hi | lo
   __shared__ __attribute__((aligned(16))) _Float16 sH[2 * 64 * kLdHb];

@@ -8,6 +8,13 @@ namespace cm3 {
 constexpr int kA = 5;  // l_action
 constexpr uint32_t kPurposePolicy = 0x40000000u;
 
+// The matrix kernels are built for TWO waves per SIMD.  With that as the declared minimum occupancy the register budget is 256 and
+// the compiler's default selection keeps the matrix accumulators in architectural VGPRs (no v_accvgpr_read per value in the
+// epilogues) -- round 4 forced the same code with the experimental -amdgpu-mfma-vgpr-form=1; round 5 showed that the attribute
+// gives it by the standard path (tools/probes/policy_fault_variants.sh, variant agpr2w) and dropped the flag.  Consequence that
+// stays: NO inline assembly may read a matrix instruction's result (the hazard recogniser does not see into asm statements).
+#define CM3_MATRIX_KERNEL __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));

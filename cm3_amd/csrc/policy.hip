@@ -41,7 +41,7 @@ struct PolicyParams {
 // (round 4: the per-env chain actor -> physics -> observation is serial, and at one wave per SIMD the tick was latency-bound:
 // ~1 us of matrix time inside 5.0 us).  Waves w >= RT take part in the layers (every wave owns 16 columns of all row tiles) and
 // in the barriers, but have no rows of their own in the head and the physics.
-template <int N, int BF16, int RT> __global__ void __launch_bounds__(256) k_policy_rollout(const PolicyParams q) {
+template <int N, int BF16, int RT> __global__ void CM3_MATRIX_KERNEL k_policy_rollout(const PolicyParams q) {
   using G = ActorGeom<N, BF16, RT>;
   using V4 = float4;
   using V2 = float2;

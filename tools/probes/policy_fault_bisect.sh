@@ -27,6 +27,7 @@ for v in "$@"; do
   python3 tools/probes/policy_fault_patch.py "$v" "$W/$v/csrc"
   extra=""
   if [ "$v" = nopk ]; then extra="-Xclang -target-feature -Xclang -packed-fp32-ops"; fi
+  if [ "$v" = noslp ]; then extra="-fno-slp-vectorize"; fi
   build "$v" 1 $extra &
 done
 wait

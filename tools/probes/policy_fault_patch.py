@@ -144,7 +144,7 @@ elif variant == "final_mul_scalar":
                        "    asm(\"v_mul_f32 %0, %1, %2\" : \"=v\"(f_y) : \"v\"(qy), \"v\"(pen));\n"
                        "  } else {\n    f_x = qx * pen;\n    f_y = qy * pen;\n  }\n", 1)
     open(d + "/particle.hip", "w").write(q)
-elif variant in ("ctrl2", "nopk"):
+elif variant in ("ctrl2", "nopk", "noslp"):
     pass
 else:
     raise SystemExit("unknown variant " + variant)
