@@ -145,8 +145,8 @@ def test_library_carries_the_identity_of_its_sources(built):
 
 
 def test_matrix_kernel_sources_hold_no_inline_assembly():
-    """csrc/build.sh compiles actor.hip / actor_checkers.hip / policy.hip with the matrix accumulators in architectural VGPRs
-    (-amdgpu-mfma-vgpr-form): there an asm statement's registers can be ones a matrix instruction in flight still reads or
+    """actor.hip / actor_checkers.hip / policy.hip keep the matrix accumulators in architectural VGPRs (CM3_MATRIX_KERNEL: two
+    waves per SIMD declared): there an asm statement's registers can be ones a matrix instruction in flight still reads or
     writes, and the compiler's hazard recogniser does not look into asm statements (round 4: an inline `v_max_f32` relu read a
     result before its passes were through; profiles/r04_policy_head.txt (4)).  The rule is enforced here, on the sources.
     (policy.hip also includes particle.hip: its one asm statement, the write-through store, only READS registers that ordinary
@@ -154,11 +154,39 @@ def test_matrix_kernel_sources_hold_no_inline_assembly():
     import re
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cm3_amd", "csrc")
     build = open(os.path.join(root, "build.sh")).read()
-    m = re.search(r"for f in ([a-z_ ]+); do\s*\n\s*\"\$\{HIPCC\}\" \$\{FLAGS\} -mllvm -amdgpu-mfma-vgpr-form", build)
-    assert m, "build.sh: the loop that compiles the matrix translation units with -amdgpu-mfma-vgpr-form was not found"
+    m = re.search(r"for f in ([a-z_ ]+); do\s*\n\s*\"\$\{HIPCC\}\" \$\{FLAGS\} \$\{PHYS\} \$\{MFMA_FORM\}", build)
+    assert m, "build.sh: the loop that compiles the matrix translation units was not found"
     units = m.group(1).split()
     assert set(units) == {"actor", "actor_checkers", "policy"}
+    assert "amdgpu-mfma-vgpr-form=1" not in re.sub(r"#[^\n]*", "", build), "the experimental flag is not part of the default build"
     for name in units + ["actor_common"]:
         path = os.path.join(root, name + (".h" if name == "actor_common" else ".hip"))
         code = re.sub(r"//[^\n]*", "", open(path).read())          # (comments may talk about asm)
         assert not re.search(r"\basm\s*(volatile\s*)?\(", code), "%s: inline assembly in a matrix translation unit" % name
+    for name, kernels in (("actor", ["k_actor_particle"]), ("actor_checkers", ["k_ck_actor", "k_ck_actor_x3"]), ("policy", ["k_policy_rollout"])):
+        code = open(os.path.join(root, name + ".hip")).read()
+        for k in kernels:
+            assert re.search(r"__global__ void CM3_MATRIX_KERNEL %s\(" % k, code), k
+
+
+def test_device_code_holds_no_packed_float32_cross_half_select():
+    """Round 5 (profiles/r05_policy_fault.txt): `v_pk_mul_f32 ... op_sel:[0,1]` returned a wrong low result in lanes 48..63 on the
+    chip.  csrc/build.sh builds the physics without SLP vectorisation so that the compiler does not create that form, and
+    tools/isa_lint.py checks every device code object of the build for it; here the lint runs on the objects of the library under
+    test, and its pattern is checked on the instruction that failed."""
+    import glob
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_lint
+    assert isa_lint.BAD.search("v_pk_mul_f32 v[80:81], v[84:85], v[80:81] op_sel:[0,1]")
+    assert isa_lint.BAD.search("v_pk_add_f32 v[46:47], v[46:47], v[46:47] op_sel:[0,1] op_sel_hi:[1,0]")
+    assert not isa_lint.BAD.search("v_pk_mul_f32 v[84:85], v[84:85], v[86:87] op_sel_hi:[1,0]")
+    assert not isa_lint.BAD.search("v_pk_fma_f32 v[72:73], v[72:73], s[80:81], v[92:93] op_sel_hi:[1,0,1]")
+    build = open(os.path.join(ROOT, "cm3_amd", "csrc", "build.sh")).read()
+    assert "-fno-slp-vectorize" in build and "isa_lint.py" in build
+    objs = sorted(glob.glob(os.path.join(ROOT, "cm3_amd", "csrc", "_obj", "*.o")))
+    if not objs or not os.path.exists(os.path.join(isa_lint.LLVM, "llvm-objdump")):
+        pytest.skip("no build objects / no llvm-objdump here (the build itself runs the lint)")
+    seen, bad = isa_lint.lint(objs)
+    assert seen >= 9 and not bad, bad[:5]

@@ -292,6 +292,26 @@ def test_policy_rollout_row_tile_rule_at_the_baseline_sizes(E, N, cfg, rt, rt_ti
     ref.close()
 
 
+def test_policy_rollout_soak_with_two_workgroups_per_cu():
+    """The short soak (tools/probes/policy_soak.py is the long one): whole-episode launches against alternating actor / step
+    launches on the batches that put two N = 8 workgroups on every CU -- the occupancy at which round 4's withdrawn layer returned
+    wrong rows (root cause found in round 5: a packed float32 multiply with a cross-half select, profiles/r05_policy_fault.txt;
+    the build no longer contains that instruction form, tests/test_abi.py) -- fresh seeds, both precisions, full 33-tick episodes
+    with terminal capture.  About 15 s."""
+    n = 0
+    for seed in range(500, 503):
+        for E, N, cfg in ((8192, 8, "particle_merge8.json"), (4096, 8, "particle_merge8.json"), (4096, 4, "particle_stage2_antipodal.json")):
+            for prec in ("f16x3", "f32"):
+                ref, eref, _ = _policy_run(E, N, cfg, prec, 33, "tick", seed=seed)
+                ro, env, v = _policy_run(E, N, cfg, prec, 33, "episode", seed=seed)
+                for name in ("actions", "state", "obs_others", "reward", "reward_n", "done", "collisions"):
+                    assert torch.equal(getattr(ref, name), getattr(ro, name)), (E, N, prec, seed, name, v)
+                ro.close()
+                ref.close()
+                n += 1
+    assert n == 18
+
+
 @pytest.mark.parametrize("precision", ["f32", "f16x3"])
 @pytest.mark.parametrize("tag,N,stage", [("n4_stage2", 4, 2), ("n1_stage1", 1, 1), ("n8_stage2", 8, 2)])
 def test_device_actor_matches_vectors_from_the_reference_function_body(tag, N, stage, precision):
