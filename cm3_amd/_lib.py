@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # CM3_AMD_LIB: load another build of the SAME ABI instead (tools/*_ab.py compare two builds on one box)
 LIB_PATH = os.environ.get("CM3_AMD_LIB") or os.path.join(_HERE, "libcm3_hip.so")
 MAX_AGENTS = 10
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 FLAG_AUTO_RESET = 1
 FLAG_GEN_ACTIONS = 2
@@ -60,6 +60,16 @@ class ParticleTraj(ctypes.Structure):
                 ("term_obs_others", c_void_p), ("term_obs_others_stride", c_size_t),
                 ("collisions", c_void_p), ("collisions_stride", c_size_t),
                 ("state_live", c_void_p), ("goals_live", c_void_p)]
+
+
+class TransitionCols(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in ("state", "obs_others", "actions", "reward", "reward_n", "next_state", "next_obs_others",
+                                        "done", "goals")]
+
+
+class RowCols(ctypes.Structure):
+    _fields_ = [("n_cols", c_int32), ("reserved", c_int32), ("dst", c_void_p * 16), ("src", c_void_p * 16),
+                ("row_bytes", ctypes.c_uint32 * 16)]
 
 
 class CopyShift(ctypes.Structure):
@@ -159,6 +169,11 @@ SYMBOLS = {
                                               c_void_p]),
     "cm3_policy_rollout_f32": (ctypes.c_int, [P(ParticleDesc), P(ParticleTraj), P(ActorParticleDesc),
                                               P(ActorParticleWeights), c_void_p, c_size_t, c_int32, c_void_p]),
+    "cm3_policy_force_row_tiles": (ctypes.c_int, [c_int32]),
+    "cm3_transitions_gather_f32": (ctypes.c_int, [P(ParticleDesc), P(ParticleTraj), c_void_p, c_size_t, c_void_p, c_void_p, c_int64,
+                                                  P(TransitionCols), c_void_p]),
+    "cm3_rows_scatter": (ctypes.c_int, [P(RowCols), c_int64, c_void_p, c_int64, c_int64, c_void_p]),
+    "cm3_rows_gather": (ctypes.c_int, [P(RowCols), c_int64, c_void_p, c_void_p]),
     "cm3_actor_checkers_packed_bytes": (c_size_t, []),
     "cm3_actor_checkers_pack": (ctypes.c_int, [P(ActorCheckersDesc), P(ActorCheckersWeights), c_void_p, c_void_p]),
     "cm3_actor_checkers_f32": (ctypes.c_int, [P(ActorCheckersDesc), P(ActorCheckersWeights), P(ActorCheckersBufs),
@@ -284,6 +299,37 @@ def copy_list(pairs, stream):
     src = (c_void_p * n)(*[s.data_ptr() for _, s in pairs])
     nb = (c_size_t * n)(*[d.numel() * d.element_size() for d, _ in pairs])
     check(lib().cm3_copy_list(n, dst, src, nb, stream))
+
+
+def row_cols(pairs):
+    """cm3_row_cols for (dst tensor, src tensor) pairs: rows = leading dim, row_bytes from the trailing dims (contiguous tensors)."""
+    if not 1 <= len(pairs) <= 16:
+        raise Cm3Error("1..16 columns per launch")
+    rc = RowCols()
+    rc.n_cols = len(pairs)
+    for k, (d, s_) in enumerate(pairs):
+        if not (d.is_contiguous() and s_.is_contiguous()) or d.dtype != s_.dtype or tuple(d.shape[1:]) != tuple(s_.shape[1:]):
+            raise Cm3Error("row columns must be contiguous and agree in dtype / row shape (column %d)" % k)
+        rc.dst[k], rc.src[k] = d.data_ptr(), s_.data_ptr()
+        rb = d.element_size()
+        for n in d.shape[1:]:
+            rb *= int(n)
+        rc.row_bytes[k] = rb
+    return rc
+
+
+def rows_scatter(pairs, n_rows, stream, dst_row=None, ring_start=0, ring_size=0):
+    """ONE launch: dst[row(b)] = src[b] for every (dst, src) column pair (cm3_rows_scatter)."""
+    for k in range(0, len(pairs), 16):
+        rc = row_cols(pairs[k:k + 16])
+        check(lib().cm3_rows_scatter(ctypes.byref(rc), int(n_rows), ptr(dst_row), int(ring_start), int(ring_size), stream))
+
+
+def rows_gather(pairs, n_rows, src_row, stream):
+    """ONE launch: dst[b] = src[src_row[b]] for every (dst, src) column pair (cm3_rows_gather)."""
+    for k in range(0, len(pairs), 16):
+        rc = row_cols(pairs[k:k + 16])
+        check(lib().cm3_rows_gather(ctypes.byref(rc), int(n_rows), ptr(src_row), stream))
 
 
 def current_stream_handle(device):

@@ -1,0 +1,231 @@
+// Data movement of the rows SURVEY.md section 8(f2) / (f4) as single launches (round 5):
+//   cm3_transitions_gather_f32   every column of the reference's 11-field transition (alg/train_onpolicy.py:338, consumed by
+//                                alg_credit.process_batch, alg_credit.py:458-470) for a list of (tick, env) pairs, straight out of the
+//                                time-major trajectory: next_* = slot t + 1 or the captured terminal values where the env restarted
+//                                in the same launch, goals from the slot that last wrote them (sparse goal slots) -- ONE launch
+//                                instead of the ~25 indexing / where launches of the torch composition;
+//   cm3_rows_scatter             the columns of a batch of transitions into ring positions (replay_buffer.py:11-16 `add`, and the
+//                                dual buffer's two rings, replay_buffer_dual.py:12-38) -- all columns in one launch;
+//   cm3_rows_gather              the columns of sampled transitions out of a ring (replay_buffer.py:28-37) -- all columns in one launch.
+// Pure byte movement: HBM-bound, no arithmetic, no matrix cores.  A wave copies whole rows with 16-byte (or 8- / 4- / 1-byte, by the
+// row size) units, consecutive lanes on consecutive units, so that the side with contiguous rows is fully coalesced.
+#include "common.h"
+
+namespace cm3 {
+
+constexpr int kMaxRowCols = 16;
+
+struct RowCols {
+  int n;
+  void *dst[kMaxRowCols];
+  const void *src[kMaxRowCols];
+  uint32_t row_bytes[kMaxRowCols];
+  uint32_t unit[kMaxRowCols];   // bytes per lane: 16, 8, 4 or 1 (largest that divides the row size and both base addresses)
+};
+
+template <typename U> __device__ __forceinline__ void copy_units(void *dst, const void *src, size_t n_rows, uint32_t units_per_row,
+                                                                 const int64_t *dst_row, const int64_t *src_row, int64_t ring_start,
+                                                                 int64_t ring_size) {
+  const size_t total = n_rows * units_per_row, stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+    const size_t b = g / units_per_row;
+    const uint32_t u = (uint32_t)(g - b * units_per_row);
+    int64_t d = (int64_t)b, s = (int64_t)b;
+    if (dst_row) {
+      d = dst_row[b];
+    } else if (ring_size > 0) {
+      d = ring_start + (int64_t)b;
+      d = d >= ring_size ? d - ring_size : d;
+    }
+    if (src_row) s = src_row[b];
+    if (d < 0 || s < 0) continue;     // (a negative row index = skip: how the dual buffer's two rings share one flag pass)
+    reinterpret_cast<U *>(dst)[(size_t)d * units_per_row + u] = reinterpret_cast<const U *>(src)[(size_t)s * units_per_row + u];
+  }
+}
+
+__global__ void __launch_bounds__(256) k_rows_copy(const RowCols c, size_t n_rows, const int64_t *dst_row, const int64_t *src_row,
+                                                   int64_t ring_start, int64_t ring_size) {
+  const int col = blockIdx.y;
+  const uint32_t unit = c.unit[col], upr = c.row_bytes[col] / unit;
+  if (unit == 16)
+    copy_units<uint4>(c.dst[col], c.src[col], n_rows, upr, dst_row, src_row, ring_start, ring_size);
+  else if (unit == 8)
+    copy_units<uint2>(c.dst[col], c.src[col], n_rows, upr, dst_row, src_row, ring_start, ring_size);
+  else if (unit == 4)
+    copy_units<uint32_t>(c.dst[col], c.src[col], n_rows, upr, dst_row, src_row, ring_start, ring_size);
+  else
+    copy_units<uint8_t>(c.dst[col], c.src[col], n_rows, upr, dst_row, src_row, ring_start, ring_size);
+}
+
+static int rows_copy(const cm3_row_cols *cols, int64_t n_rows, const int64_t *dst_row, const int64_t *src_row, int64_t ring_start,
+                     int64_t ring_size, hipStream_t s) {
+  CM3_REQUIRE(cols && cols->n_cols >= 1 && cols->n_cols <= kMaxRowCols, "row columns: 1..%d columns", kMaxRowCols);
+  CM3_REQUIRE(n_rows >= 0, "n_rows must be >= 0");
+  if (n_rows == 0) return CM3_OK;
+  RowCols c;
+  memset(&c, 0, sizeof(c));
+  c.n = cols->n_cols;
+  size_t most = 0;
+  for (int k = 0; k < c.n; ++k) {
+    CM3_REQUIRE(cols->dst[k] && cols->src[k] && cols->row_bytes[k] > 0, "row columns: column %d is null / empty", k);
+    c.dst[k] = cols->dst[k];
+    c.src[k] = cols->src[k];
+    c.row_bytes[k] = cols->row_bytes[k];
+    const uintptr_t a = (uintptr_t)cols->dst[k] | (uintptr_t)cols->src[k] | (uintptr_t)cols->row_bytes[k];
+    c.unit[k] = (a % 16 == 0) ? 16u : (a % 8 == 0) ? 8u : (a % 4 == 0) ? 4u : 1u;
+    const size_t units = (size_t)n_rows * (c.row_bytes[k] / c.unit[k]);
+    most = units > most ? units : most;
+  }
+  size_t blocks = (most + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+  hipLaunchKernelGGL(k_rows_copy, dim3((unsigned)blocks, (unsigned)c.n), dim3(256), 0, s, c, (size_t)n_rows, dst_row, src_row, ring_start,
+                     ring_size);
+  CM3_HIP_CHECK(hipGetLastError());
+  return CM3_OK;
+}
+
+// ---- the reference's transition, gathered from the trajectory ---------------------------------------------------------------------
+struct TransParams {
+  const float *state, *obs, *reward_n, *reward, *term_state, *term_obs, *goals;
+  const int32_t *actions, *goal_slot;
+  const uint8_t *done;
+  size_t st_state, st_obs, st_actions, st_reward_n, st_reward, st_done, st_term_state, st_term_obs, st_goals, st_goal_slot;   // bytes per tick
+  const int64_t *tt, *ee;
+  float *o_state, *o_obs, *o_reward_n, *o_reward, *o_next_state, *o_next_obs, *o_goals;
+  int32_t *o_actions;
+  uint8_t *o_done;
+  size_t n, E;
+  int N, L;
+};
+
+template <typename T> __device__ __forceinline__ const T *tick_of(const T *base, size_t stride, int64_t t) {
+  return reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + stride * (size_t)t);
+}
+
+// One wave per transition at a time; lane u copies unit u of the transition's record:
+//   [0, N)                state row of agent u          16 B      state[t][u][e]            -> o_state[b][u]
+//   [N, 2N)               next state                    16 B      done ? term_state[t] : state[t + 1]
+//   [2N, 2N + NV)         obs_others, NV = N L / 4      16 B      obs[t][e][...]            -> o_obs[b][...]   (contiguous both sides)
+//   [.., + NV)            next obs_others               16 B      done ? term_obs[t] : obs[t + 1]
+//   then N goal pairs (8 B), N actions, N local rewards (4 B), the reward (4 B) and done (1 B)
+__global__ void __launch_bounds__(256) k_transitions_gather(const TransParams p) {
+  const int lane = threadIdx.x & 63;
+  const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+  const int N = p.N, NV = N * p.L / 4;
+  const int U = 2 * N + 2 * NV + 3 * N + 2;
+  for (size_t b = wave; b < p.n; b += n_waves) {
+    const int64_t t = p.tt[b];
+    const size_t e = (size_t)p.ee[b];
+    const bool d = tick_of(p.done, p.st_done, t)[e] != 0;
+    const bool term = d && p.term_state != nullptr;
+    for (int u = lane; u < U; u += 64) {
+      int v = u;
+      if (v < 2 * N) {
+        const bool nxt = v >= N;
+        const int i = nxt ? v - N : v;
+        const float *src = nxt ? (term ? tick_of(p.term_state, p.st_term_state, t) : tick_of(p.state, p.st_state, t + 1))
+                               : tick_of(p.state, p.st_state, t);
+        const float4 x = reinterpret_cast<const float4 *>(src)[(size_t)i * p.E + e];
+        reinterpret_cast<float4 *>(nxt ? p.o_next_state : p.o_state)[b * N + i] = x;
+        continue;
+      }
+      v -= 2 * N;
+      if (v < 2 * NV) {
+        const bool nxt = v >= NV;
+        const int k = nxt ? v - NV : v;
+        const float *src = nxt ? ((d && p.term_obs) ? tick_of(p.term_obs, p.st_term_obs, t) : tick_of(p.obs, p.st_obs, t + 1))
+                               : tick_of(p.obs, p.st_obs, t);
+        const float4 x = reinterpret_cast<const float4 *>(src)[e * NV + k];
+        reinterpret_cast<float4 *>(nxt ? p.o_next_obs : p.o_obs)[b * NV + k] = x;
+        continue;
+      }
+      v -= 2 * NV;
+      if (v < N) {   // goals [slot][N][E][2]: the slot that last wrote this env's landmarks (goal_slot), or the only one (stride 0)
+        const int64_t gs = p.goal_slot ? (int64_t)tick_of(p.goal_slot, p.st_goal_slot, t)[e] : t;
+        reinterpret_cast<float2 *>(p.o_goals)[b * N + v] = reinterpret_cast<const float2 *>(tick_of(p.goals, p.st_goals, gs))[(size_t)v * p.E + e];
+        continue;
+      }
+      v -= N;
+      if (v < N) {
+        p.o_actions[b * N + v] = tick_of(p.actions, p.st_actions, t)[e * N + v];
+        continue;
+      }
+      v -= N;
+      if (v < N) {
+        p.o_reward_n[b * N + v] = tick_of(p.reward_n, p.st_reward_n, t)[e * N + v];
+        continue;
+      }
+      v -= N;
+      if (v == 0)
+        p.o_reward[b] = tick_of(p.reward, p.st_reward, t)[e];
+      else
+        p.o_done[b] = d ? 1 : 0;
+    }
+  }
+}
+
+}  // namespace cm3
+
+extern "C" {
+int cm3_rows_scatter(const cm3_row_cols *cols, int64_t n_rows, const int64_t *dst_row, int64_t ring_start, int64_t ring_size,
+                     void *stream) {
+  using namespace cm3;
+  CM3_REQUIRE(dst_row || (ring_size > 0 && ring_start >= 0 && ring_start < ring_size && n_rows <= ring_size),
+              "rows_scatter: either dst_row or a ring (0 <= ring_start < ring_size, n_rows <= ring_size)");
+  return rows_copy(cols, n_rows, dst_row, nullptr, ring_start, dst_row ? 0 : ring_size, (hipStream_t)stream);
+}
+
+int cm3_rows_gather(const cm3_row_cols *cols, int64_t n_rows, const int64_t *src_row, void *stream) {
+  using namespace cm3;
+  CM3_REQUIRE(src_row, "rows_gather: src_row is NULL");
+  return rows_copy(cols, n_rows, nullptr, src_row, 0, 0, (hipStream_t)stream);
+}
+
+int cm3_transitions_gather_f32(const cm3_particle_desc *desc, const cm3_particle_traj *traj, const int32_t *goal_slot,
+                               size_t goal_slot_stride, const int64_t *tt, const int64_t *ee, int64_t n,
+                               const cm3_transition_cols *out, void *stream) {
+  using namespace cm3;
+  CM3_REQUIRE(desc && traj && out && (n == 0 || (tt && ee)), "null argument");
+  CM3_REQUIRE(n >= 0, "n must be >= 0");
+  CM3_REQUIRE(desc->n_agents >= 1 && desc->n_agents <= CM3_MAX_AGENTS, "n_agents out of range");
+  CM3_REQUIRE(traj->state && traj->obs_others && traj->actions && traj->reward_n && traj->reward && traj->done && traj->goals,
+              "trajectory base pointers are required");
+  CM3_REQUIRE((traj->term_state == nullptr) == (traj->term_obs_others == nullptr), "term_state and term_obs_others: both or neither");
+  CM3_REQUIRE(out->state && out->obs_others && out->actions && out->reward && out->reward_n && out->next_state && out->next_obs_others &&
+                  out->done && out->goals,
+              "output columns are required");
+  if (n == 0) return CM3_OK;
+  TransParams p;
+  memset(&p, 0, sizeof(p));
+  p.state = (const float *)traj->state;             p.st_state = traj->state_stride;
+  p.obs = (const float *)traj->obs_others;          p.st_obs = traj->obs_others_stride;
+  p.actions = traj->actions;                        p.st_actions = traj->actions_stride;
+  p.reward_n = (const float *)traj->reward_n;       p.st_reward_n = traj->reward_n_stride;
+  p.reward = (const float *)traj->reward;           p.st_reward = traj->reward_stride;
+  p.done = traj->done;                              p.st_done = traj->done_stride;
+  p.term_state = (const float *)traj->term_state;   p.st_term_state = traj->term_state_stride;
+  p.term_obs = (const float *)traj->term_obs_others; p.st_term_obs = traj->term_obs_others_stride;
+  p.goals = (const float *)traj->goals;             p.st_goals = traj->goals_stride;
+  p.goal_slot = goal_slot;                          p.st_goal_slot = goal_slot_stride;
+  p.tt = tt;
+  p.ee = ee;
+  p.o_state = (float *)out->state;
+  p.o_obs = (float *)out->obs_others;
+  p.o_actions = out->actions;
+  p.o_reward = (float *)out->reward;
+  p.o_reward_n = (float *)out->reward_n;
+  p.o_next_state = (float *)out->next_state;
+  p.o_next_obs = (float *)out->next_obs_others;
+  p.o_done = out->done;
+  p.o_goals = (float *)out->goals;
+  p.n = (size_t)n;
+  p.E = (size_t)desc->n_envs;
+  p.N = desc->n_agents;
+  p.L = 4 * (desc->n_agents > 1 ? desc->n_agents - 1 : 1);
+  size_t blocks = ((size_t)n + 3) / 4;     // four waves per workgroup, one transition per wave and trip
+  blocks = blocks > 8192 ? 8192 : blocks;
+  hipLaunchKernelGGL(k_transitions_gather, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+  CM3_HIP_CHECK(hipGetLastError());
+  return CM3_OK;
+}
+}

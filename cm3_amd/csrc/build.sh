@@ -30,7 +30,7 @@ pids+=($!)
 # Checkers: max-ILP scheduling throughout (C3 4.26 -> 4.16 us per tick; 2^16 .. 2^20 envs within 1 %)
 "${HIPCC}" ${FLAGS} -mllvm -amdgpu-kernarg-preload-count=16 -mllvm -amdgpu-sched-strategy=${CM3_HOT_SCHED:-max-ilp} ${CM3_HOT_FLAGS:-} -c "${HERE}/checkers.hip" -o "${HERE}/_obj/checkers.o" &
 pids+=($!)
-for f in util advantage; do
+for f in util advantage batch; do
   "${HIPCC}" ${FLAGS} -DCM3_SOURCE_ID="\"${SRC_ID}\"" -c "${HERE}/${f}.hip" -o "${HERE}/_obj/${f}.o" &
   pids+=($!)
 done
@@ -48,5 +48,5 @@ if [ "${CM3_SKIP_ISA_LINT:-0}" != 1 ]; then
   python3 "${HERE}/../../tools/isa_lint.py" "${HERE}"/_obj/*.o
 fi
 "${HIPCC}" --offload-arch=gfx950 -shared -fPIC -o "${OUT}" "${HERE}/_obj/particle_f32.o" "${HERE}/_obj/particle_f32_ilp.o" "${HERE}/_obj/particle_f64.o" \
-  "${HERE}/_obj/checkers.o" "${HERE}/_obj/util.o" "${HERE}/_obj/advantage.o" "${HERE}/_obj/actor.o" "${HERE}/_obj/actor_checkers.o" "${HERE}/_obj/policy.o"
+  "${HERE}/_obj/checkers.o" "${HERE}/_obj/util.o" "${HERE}/_obj/advantage.o" "${HERE}/_obj/batch.o" "${HERE}/_obj/actor.o" "${HERE}/_obj/actor_checkers.o" "${HERE}/_obj/policy.o"
 echo "built ${OUT}"

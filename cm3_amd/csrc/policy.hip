@@ -23,6 +23,7 @@
 #include "particle.hip"
 #include "actor.hip"
 #include <stdlib.h>
+#include <atomic>
 
 namespace cm3 {
 
@@ -49,10 +50,6 @@ template <int N, int BF16, int RT> __global__ void CM3_MATRIX_KERNEL k_policy_ro
   const ParticleParams &p = q.p;
   CM3_ACTOR_LDS_RT(N, BF16, RT, lds);
   __shared__ __attribute__((aligned(16))) float4 ns[16 * RT];  // post-step (vx, vy, px, py) of every row, exchanged inside a wave
-#ifdef CM3_POLICY_PADLDS
-  __shared__ float lds_pad[10000];   // (experiment: one workgroup per CU)
-  if (threadIdx.x == 0 && q.p.n_ticks < 0) lds_pad[q.p.E % 10000] = 1.0f;
-#endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const size_t E = (size_t)p.E;
@@ -66,16 +63,7 @@ template <int N, int BF16, int RT> __global__ void CM3_MATRIX_KERNEL k_policy_ro
   // b + 256, as the dispatcher fills the chip): the head and the physics of both would otherwise pile up on SIMDs 0 and 1 while
   // SIMDs 2 and 3 idle for 60 % of every tick (stamped build, profiles/r04_policy_row_tiles.txt).  Speed only: results do not
   // depend on the placement.
-#ifndef CM3_POLICY_PRIO
-#define CM3_POLICY_PRIO 2          // (macros: build variants for the measurement)
-#endif
-#ifndef CM3_POLICY_PRIO_MLP
-#define CM3_POLICY_PRIO_MLP 0
-#endif
-#ifndef CM3_POLICY_SHIFT_BIT
-#define CM3_POLICY_SHIFT_BIT 8     // (macro: build variant for the measurement)
-#endif
-  const int wr = RT == 2 ? ((w + 2 * (int)((blockIdx.x >> CM3_POLICY_SHIFT_BIT) & 1u)) & 3) : w;
+  const int wr = RT == 2 ? ((w + 2 * (int)((blockIdx.x >> 8) & 1u)) & 3) : w;
   const bool row_wave = wr < RT;
   const int rl = row_wave ? 16 * wr + (lane & 15) : (lane & 15);
   const bool part0 = (lane >> 4) == 0 && row_wave;
@@ -141,7 +129,7 @@ template <int N, int BF16, int RT> __global__ void CM3_MATRIX_KERNEL k_policy_ro
     // the closing barrier: it goes first on its SIMD, ahead of the matrix phases of the workgroup that shares the CU (measured,
     // same box, three alternating rounds: 4.31 -> 4.15 us per tick at 4 096 x 4, 45.1 -> 44.6 at 65 536 x 4; levels 1, 2, 3 are
     // the same, raising the priority for the WHOLE tick loses the gain; profiles/r04_policy_head.txt)
-    __builtin_amdgcn_s_setprio(CM3_POLICY_PRIO);
+    __builtin_amdgcn_s_setprio(2);
     float pr[kA];
     const float u = actor_uniform_from(ublock, episode, steps);
     actor_head_probs(lds.h2s, hb, wr, lane, q.eps, pr);
@@ -321,7 +309,7 @@ template <int N, int BF16, int RT> __global__ void CM3_MATRIX_KERNEL k_policy_ro
       lds.xs[rl][4] = gl.x; lds.xs[rl][5] = gl.y;
     }
     CM3_STAMP(11, false);
-    __builtin_amdgcn_s_setprio(CM3_POLICY_PRIO_MLP);
+    __builtin_amdgcn_s_setprio(0);
     }  // row_wave
     __syncthreads();  // the tile (and the h1/h2 storage) is free for the next tick's phase A
     CM3_STAMP(12, false);
@@ -359,8 +347,22 @@ template <int N, int RT> static int policy_launch_rt(const PolicyParams &q, int 
 // and the smaller one is faster (fewer matrix instructions per wave and tick); once a CU holds several, the 64-row workgroup does
 // the most work per instruction issued.  So: 64-row workgroups when they already give every CU more than one, 32-row ones down to
 // half a workgroup per CU, 16-row ones below -- for every N (N = 8 had a rule of its own while its 32-row build needed 261
-// registers, one wave per SIMD; every build is under 256 now).  CM3_POLICY_RT = 1 | 2 | 4 overrides the choice (measurements only).
+// registers, one wave per SIMD; every build is under 256 now).  cm3_policy_force_row_tiles(1 | 2 | 4) overrides the choice (tests and
+// measurements; its initial value is the environment's CM3_POLICY_RT, read ONCE -- not per launch).
 constexpr size_t kPolicyCus = 256;
+static std::atomic<int> g_policy_rt_override{-1};   // -1: not initialised, 0: the rule decides
+static int policy_rt_override() {
+  int v = g_policy_rt_override.load(std::memory_order_relaxed);
+  if (v < 0) {
+    const char *e = getenv("CM3_POLICY_RT");
+    v = e ? atoi(e) : 0;
+    if (v != 1 && v != 2 && v != 4) v = 0;
+    int expected = -1;
+    g_policy_rt_override.compare_exchange_strong(expected, v);
+    v = g_policy_rt_override.load(std::memory_order_relaxed);
+  }
+  return v;
+}
 template <int N> static int policy_launch(const PolicyParams &q, int prec, hipStream_t s) {
   const size_t rows = (size_t)q.p.E * N, wg64 = (rows + 63) / 64;
   int rt = wg64 > kPolicyCus ? 4 : (wg64 > kPolicyCus / 2 ? 2 : 1);
@@ -369,10 +371,7 @@ template <int N> static int policy_launch(const PolicyParams &q, int prec, hipSt
   // 1024 envs 8.34 / 7.50 / 6.75, 2048 envs 8.46 / 7.43 / 8.47, 4096 envs 8.72 / 9.71 / 14.2, 8192 envs 11.8 / 16.6 / 24.5 us;
   // tools/probes/policy_tick_tiles.sh, profiles/r04_policy_head.txt)
   if (q.p.n_ticks <= 2) rt = wg64 >= kPolicyCus ? 4 : (wg64 >= kPolicyCus / 2 ? 2 : 1);
-  if (const char *e = getenv("CM3_POLICY_RT")) {
-    const int v = atoi(e);
-    if (v == 1 || v == 2 || v == 4) rt = v;
-  }
+  if (const int v = policy_rt_override()) rt = v;
   switch (rt) {
     case 1: return policy_launch_rt<N, 1>(q, prec, s);
     case 2: return policy_launch_rt<N, 2>(q, prec, s);
@@ -381,6 +380,13 @@ template <int N> static int policy_launch(const PolicyParams &q, int prec, hipSt
 }
 
 }  // namespace cm3
+
+extern "C" int cm3_policy_force_row_tiles(int32_t row_tiles) {
+  using namespace cm3;
+  CM3_REQUIRE(row_tiles == 0 || row_tiles == 1 || row_tiles == 2 || row_tiles == 4, "row_tiles must be 0 (rule), 1, 2 or 4; got %d", row_tiles);
+  g_policy_rt_override.store(row_tiles, std::memory_order_relaxed);
+  return CM3_OK;
+}
 
 extern "C" int cm3_policy_rollout_f32(const cm3_particle_desc *d, const cm3_particle_traj *t,
                                       const cm3_actor_particle_desc *ad, const cm3_actor_particle_weights *wt,

@@ -5,55 +5,115 @@
                                      (particle: scenario.collisions != 0, train_onpolicy.py:356)
   log.csv / log_century.csv columns  alg/train_onpolicy.py:200-221, :399-429
 Transitions are the columns ParticleRollout / CheckersRollout export (numpy=False): each ring stores one tensor per
-column, so adding a whole vectorised rollout is a handful of index_copy calls and sampling is one gather.
+column; adding a whole vectorised rollout is ONE launch (cm3_rows_scatter, csrc/batch.hip), sampling is one gather launch.
 """
 import torch
+
+from . import _lib
+from ._lib import Cm3Error
+
+
+class RingIndex(object):
+    """The bookkeeping of replay_buffer.Replay_Buffer (alg/replay_buffer.py:11-16) without the data: where the next transitions
+    go and how many are stored.  Host logic (tests/test_replay.py replays the reference's recorded memory with it)."""
+
+    def __init__(self, size):
+        self.maxsize = int(size)
+        self.idx = 0
+        self.len = 0
+
+    def plan_add(self, n):
+        """n sequential adds -> (skip, start, kept): the first `skip` of them are overwritten again by the later ones of the same
+        batch (n > maxsize), the other `kept` land at ring positions start, start + 1, ... (mod maxsize)."""
+        n = int(n)
+        skip = max(0, n - self.maxsize)
+        start = (self.idx + skip) % self.maxsize
+        kept = n - skip
+        self.idx = (self.idx + n) % self.maxsize
+        self.len = min(self.len + n, self.maxsize)
+        return skip, start, kept
+
+
+def dual_take(n1, n2, size):
+    """How many transitions replay_buffer_dual.Replay_Buffer.sample_batch(size) takes from memory_1 (bad) and memory_2 (good)
+    holding n1 / n2 transitions (alg/replay_buffer_dual.py:40-63) -> (k1, all1, k2, all2): k sampled without replacement, or
+    everything in storage order when the flag is set."""
+    half = int(size / 2.0)
+    if half <= n1 and half > n2:
+        return min(n1, size - n2), False, n2, True
+    if half > n1 and half <= n2:
+        return n1, True, min(n2, size - n1), False
+    if n1 < half and n2 < half:
+        return n1, True, n2, True
+    return half, False, half, False
 
 
 class DeviceReplayBuffer(object):
     """replay_buffer.Replay_Buffer on the device: capacity `size` transitions, overwrite oldest when full
     (replay_buffer.py:11-16), sample_batch(size) = everything if len <= size else `size` distinct uniformly
-    (:28-37)."""
+    (:28-37).  One tensor per column; `add` is ONE launch for all columns (cm3_rows_scatter onto the ring positions),
+    sampling ONE launch (cm3_rows_gather).  There is no host path: the buffer lives on an AMD GPU."""
 
     def __init__(self, size=int(1e6), device="cuda:0"):
-        self.maxsize = int(size)
-        self.device = torch.device(device)
+        self.device = _lib.require_gpu(device)
+        self.ring = RingIndex(size)
         self.cols = None
-        self.idx = 0
-        self.len = 0
+
+    maxsize = property(lambda self: self.ring.maxsize)
+    idx = property(lambda self: self.ring.idx)
+    len = property(lambda self: self.ring.len)
 
     def __len__(self):
-        return self.len
+        return self.ring.len
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _alloc(self, cols):
+        if self.cols is None:
+            self.cols = {k: torch.zeros((self.maxsize,) + tuple(v.shape[1:]), dtype=v.dtype, device=self.device) for k, v in cols.items()}
+        elif set(cols) != set(self.cols):
+            raise Cm3Error("replay columns changed: %s vs %s" % (sorted(cols), sorted(self.cols)))
+
+    @staticmethod
+    def _src(v, device):
+        return v.to(device).contiguous()
 
     def add(self, cols):
         """cols: dict of tensors with a common leading batch dim (B transitions, in order)."""
         B = next(iter(cols.values())).shape[0]
         if B == 0:
             return
-        if self.cols is None:
-            self.cols = {k: torch.zeros((self.maxsize,) + tuple(v.shape[1:]), dtype=v.dtype, device=self.device)
-                         for k, v in cols.items()}
-        if B > self.maxsize:                       # only the last maxsize survive, as sequential adds would leave
-            cols = {k: v[B - self.maxsize:] for k, v in cols.items()}
-            self.idx = (self.idx + B - self.maxsize) % self.maxsize
-            B = self.maxsize
-        pos = (self.idx + torch.arange(B, device=self.device)) % self.maxsize
-        for k, v in cols.items():
-            self.cols[k].index_copy_(0, pos, v.to(self.device))
-        self.idx = (self.idx + B) % self.maxsize
-        self.len = min(self.len + B, self.maxsize)
+        self._alloc(cols)
+        skip, start, kept = self.ring.plan_add(B)
+        pairs = [(self.cols[k], self._src(v, self.device)[skip:]) for k, v in cols.items()]
+        _lib.rows_scatter(pairs, kept, self._stream(), ring_start=start, ring_size=self.maxsize)
+
+    def add_at(self, cols, dst_row, n_added):
+        """Rows b with dst_row[b] >= 0 go to ring position dst_row[b] (int64 on the device; computed by the caller, e.g. the dual
+        buffer's split); the ring advances by n_added sequential adds."""
+        self._alloc(cols)
+        B = next(iter(cols.values())).shape[0]
+        pairs = [(self.cols[k], self._src(v, self.device)) for k, v in cols.items()]
+        _lib.rows_scatter(pairs, B, self._stream(), dst_row=dst_row)
+        self.ring.plan_add(n_added)
 
     def _take(self, index):
-        return {k: v[index] for k, v in self.cols.items()}
+        index = index.to(torch.int64).contiguous()
+        n = index.numel()
+        out = {k: torch.empty((n,) + tuple(v.shape[1:]), dtype=v.dtype, device=self.device) for k, v in self.cols.items()}
+        if n:
+            _lib.rows_gather([(out[k], self.cols[k]) for k in self.cols], n, index, self._stream())
+        return out
 
     def all(self):
-        return self._take(torch.arange(self.len, device=self.device))
+        """Everything stored, in storage order (views of the ring: no copy)."""
+        return {k: v[:self.len] for k, v in self.cols.items()}
 
     def sample_batch(self, size, generator=None):
         if self.len <= size:
             return self.all()
-        pick = torch.randperm(self.len, generator=generator, device=self.device)[:size]
-        return self._take(pick)
+        return self.sample_n(size, generator)
 
     def sample_n(self, n, generator=None):
         n = min(int(n), self.len)
@@ -72,32 +132,36 @@ def _cat(a, b):
 class DeviceDualReplayBuffer(object):
     """replay_buffer_dual.Replay_Buffer: memory_1 holds transitions of "bad" episodes, memory_2 the others; a batch
     takes half from each when both have enough, else everything from the smaller one and the remainder from the larger
-    (replay_buffer_dual.py:40-63)."""
+    (replay_buffer_dual.py:40-63).  `add` splits a whole batch by its flag column on the device: ranks by a prefix sum, ring
+    positions for both memories, one scatter launch per memory -- one host read (the number of bad transitions)."""
 
     def __init__(self, size=int(5e4), device="cuda:0"):
         self.mem1 = DeviceReplayBuffer(size, device)
         self.mem2 = DeviceReplayBuffer(size, device)
 
     def add(self, cols, is_bad):
-        """is_bad: bool [B] per transition (all transitions of an episode carry the episode's flag)."""
-        bad = torch.as_tensor(is_bad, device=self.mem1.device).bool()
-        if bool(bad.any()):
-            self.mem1.add({k: v[bad] for k, v in cols.items()})
-        if bool((~bad).any()):
-            self.mem2.add({k: v[~bad] for k, v in cols.items()})
+        """is_bad: bool [B] per transition (all transitions of an episode carry the episode's flag; particle:
+        scenario.collisions != 0, train_onpolicy.py:356)."""
+        dev = self.mem1.device
+        bad = torch.as_tensor(is_bad, device=dev).bool()
+        B = bad.numel()
+        if B == 0:
+            return
+        n1 = int(bad.sum())            # the one host read
+        for mem, flag, n in ((self.mem1, bad, n1), (self.mem2, ~bad, B - n1)):
+            if n == 0:
+                continue
+            rank = torch.cumsum(flag, 0) - 1                                   # order among the transitions of this memory
+            keep = flag & (rank >= n - mem.maxsize)                             # (the earlier ones would be overwritten by this very batch)
+            pos = torch.where(keep, (rank + mem.ring.idx) % mem.maxsize, torch.full_like(rank, -1))
+            mem.add_at(cols, pos.contiguous(), n)
 
     def sample_batch(self, size, generator=None):
-        half = int(size / 2.0)
         n1, n2 = len(self.mem1), len(self.mem2)
-        e1 = self.mem1.all() if n1 else None
-        e2 = self.mem2.all() if n2 else None
-        if half <= n1 and half > n2:
-            return _cat(self.mem1.sample_n(min(n1, size - n2), generator), e2)
-        if half > n1 and half <= n2:
-            return _cat(e1, self.mem2.sample_n(min(n2, size - n1), generator))
-        if n1 < half and n2 < half:
-            return _cat(e1, e2)
-        return _cat(self.mem1.sample_n(half, generator), self.mem2.sample_n(half, generator))
+        k1, all1, k2, all2 = dual_take(n1, n2, size)
+        a = (self.mem1.all() if all1 else self.mem1.sample_n(k1, generator)) if n1 and k1 else None
+        b = (self.mem2.all() if all2 else self.mem2.sample_n(k2, generator)) if n2 and k2 else None
+        return _cat(a, b)
 
 
 class CsvLog(object):

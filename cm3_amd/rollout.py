@@ -153,7 +153,9 @@ class ParticleRollout(object):
         # force it.  `goals` (and as_reference_batch) look the same either way: the dense array is filled in on first access.
         self.sparse_goals = sparse_goals
         self._goals_sparse = False
+        self._graph_mode = None          # (live, sparse) the captured graphs were built with
         self._goal_src = None
+        self._goal_src32 = self._goal_src32_of = None
         self.n_chains = int(n_chains)
         if not (1 <= self.n_chains <= 16):
             raise Cm3Error("n_chains must be in 1..16")
@@ -365,8 +367,11 @@ class ParticleRollout(object):
         #   only where an env restarts; a device actor reads the live goals array, see _enqueue_actor_rollout)
         sparse = self._goals_buf is not None and not self.fused and (
             live or (policy is None and self.n_chains == 1 and bool(stream_size if self.sparse_goals is None else self.sparse_goals)))
-        if sparse != self._goals_sparse and self._graph is not None:
+        # the mode the captured graphs were built with is a field of its own: `_goals_sparse` only says whether the goal slots of
+        # the LAST collection still need completing (the `goals` getter clears it), it is not the graphs' key
+        if self._graph_mode is not None and self._graph_mode != (live, sparse):
             self._drop_graphs()
+        self._graph_mode = (live, sparse)
         self._goals_sparse, self._goal_src = sparse, None
         if self._live_cur != env._cur:    # captured graphs may hold the address of the env's current buffers (env.step() flips them)
             if live:
@@ -459,6 +464,9 @@ class ParticleRollout(object):
         es = self.state.element_size()
         small = env.n * env.E * 4 * es <= (1 << 20) and env.E * env.n * env.L * es * self.T >= (128 << 20)
         live = self._live = bool(small if self.live_state is None else self.live_state)
+        if self._graph_mode is not None and self._graph_mode != (live, live):
+            self._drop_graphs()
+        self._graph_mode = (live, live)
         self._goals_sparse, self._goal_src = live, None      # (the live-state launches write a goals slot only where an env restarts)
         # The captured graph bakes in the addresses of env._state[env._cur] / env._obs_others[env._cur] (tick 0 reads them, the
         # slot bookkeeping writes them) -- live or not -- and VecParticleEnv.step() flips env._cur: re-capture after a flip.
@@ -606,9 +614,43 @@ class ParticleRollout(object):
 
     def as_reference_batch(self, tt=None, ee=None, numpy=True):
         """Columns of the reference's transition batch for the (tick, env) pairs (tt, ee) (default: all valid
-        ones), each equal to np.stack(batch[:, k]) in alg_credit.process_batch (alg_credit.py:458-470)."""
+        ones), each equal to np.stack(batch[:, k]) in alg_credit.process_batch (alg_credit.py:458-470).
+        float32 trajectories: ONE launch of cm3_transitions_gather_f32 (csrc/batch.hip) fills all columns; the float64 parity
+        instantiation goes through the torch composition below (as_reference_batch_torch: same values, ~25 launches)."""
         if tt is None:
             tt, ee = self.valid_indices()
+        tt = torch.as_tensor(tt, device=self.env.device, dtype=torch.long).contiguous()
+        ee = torch.as_tensor(ee, device=self.env.device, dtype=torch.long).contiguous()
+        if self.state.dtype != torch.float32:
+            return self.as_reference_batch_torch(tt, ee, numpy)
+        env = self.env
+        B, N, L, dev = tt.numel(), env.n, env.L, env.device
+        f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)      # noqa: E731
+        state, obs, nstate, nobs = f(B, N, 4), f(B, N, L), f(B, N, 4), f(B, N, L)
+        reward, reward_n, goals = f(B), f(B, N), f(B, N, 2)
+        actions = torch.empty(B, N, dtype=torch.int32, device=dev)
+        done = torch.empty(B, dtype=torch.bool, device=dev)
+        traj = self._traj(0)
+        goal_slot, gs_stride = None, 0
+        if self._goals_buf is not None and self._goals_sparse:
+            if self._goal_src32 is None or self._goal_src32_of is not self._goal_source_slots():
+                self._goal_src32_of = self._goal_source_slots()
+                self._goal_src32 = self._goal_src32_of.to(torch.int32)
+            goal_slot, gs_stride = self._goal_src32, env.E * 4
+        out = _lib.TransitionCols()
+        out.state, out.obs_others, out.actions, out.reward, out.reward_n = (state.data_ptr(), obs.data_ptr(), actions.data_ptr(),
+                                                                            reward.data_ptr(), reward_n.data_ptr())
+        out.next_state, out.next_obs_others, out.done, out.goals = nstate.data_ptr(), nobs.data_ptr(), done.data_ptr(), goals.data_ptr()
+        _lib.check(self._lib.cm3_transitions_gather_f32(ctypes.byref(env._desc), ctypes.byref(traj), _lib.ptr(goal_slot), gs_stride,
+                                                        tt.data_ptr(), ee.data_ptr(), B, ctypes.byref(out), env._stream()))
+        cols = dict(v_global=state, obs_others=obs, v_local=state, actions=actions, reward=reward, reward_local=reward_n,
+                    v_global_next=nstate, obs_others_next=nobs, v_local_next=nstate, done=done, goals=goals)
+        if numpy:
+            cols = {k: v.detach().cpu().numpy() for k, v in cols.items()}
+        return cols
+
+    def as_reference_batch_torch(self, tt, ee, numpy=True):
+        """The same columns as a composition of torch indexing operations (any dtype; what the kernel path is tested against)."""
         tt = torch.as_tensor(tt, device=self.env.device, dtype=torch.long)
         ee = torch.as_tensor(ee, device=self.env.device, dtype=torch.long)
         state = self.state[tt, :, ee]                                   # [B, N, 4]

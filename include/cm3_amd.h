@@ -46,7 +46,12 @@
 extern "C" {
 #endif
 
-#define CM3_ABI_VERSION 5   /* 5: cm3_last_kernel_variant; cm3_returns_moments_* takes a zero-initialised-once scratch (see there);
+#define CM3_ABI_VERSION 6   /* 6: cm3_policy_force_row_tiles, cm3_rows_scatter / cm3_rows_gather / cm3_transitions_gather_f32 (round 5).
+                               5: the in-kernel ACTION STREAM of the particle kernels and the actors' sampling uniforms became two stages
+                               (Philox4x32-10 block per (seed, global env id, call) + fmix32((word ^ step) + episode * 0x9E3779B1);
+                               csrc/philox.h, oracle/philox.py) -- a given (seed, env, episode, step, agent) draws a DIFFERENT action
+                               than under ABI 4, whose counter layout masked `step & 0x00FFFFFF` into one Philox call; Checkers keeps
+                               the one-stage draw.  Also 5: cm3_last_kernel_variant; cm3_returns_moments_* takes a zero-initialised-once scratch (see there);
                                cm3_returns_normalize_*, cm3_copy_shift, cm3_source_id, actor precision 2 (all added under 4) */
 #define CM3_MAX_AGENTS 10   /* the reference's make_world takes up to ten agents (its colour table, multi-goal_spread.py:7-16);
                               8 until ABI 5.  Checkers, the lane-per-pair mapping and the fused policy rollout stay at <= 8 */
@@ -375,6 +380,11 @@ int cm3_actor_particle_f32(const cm3_actor_particle_desc *desc, const cm3_actor_
 int cm3_policy_rollout_f32(const cm3_particle_desc *desc, const cm3_particle_traj *traj,
                            const cm3_actor_particle_desc *actor_desc, const cm3_actor_particle_weights *weights,
                            float *probs, size_t probs_stride, int32_t n_ticks, void *stream);
+/* Test / measurement knob (ABI 6): 16-row tiles per workgroup of cm3_policy_rollout_f32 -- 1, 2 or 4 forces that build of the
+ * kernel for every later launch of the process, 0 gives the choice back to the library's rule (by batch size).  Results do not
+ * depend on it (tests/test_gpu_actor.py forces each build on one batch).  Initial value: the environment's CM3_POLICY_RT, read
+ * once at the first launch. */
+int cm3_policy_force_row_tiles(int32_t row_tiles);
 
 /* ------------------------------------------------------------------------------------------
  * On-device Checkers actor: networks.convnet_1 + networks.actor_checkers (networks.py:67-75, :549-578) + the
@@ -452,6 +462,10 @@ int cm3_actor_checkers_f32(const cm3_actor_checkers_desc *desc, const cm3_actor_
  *   stats (optional) receives (mean, std, count); apply = 0 only computes stats.
  * ---------------------------------------------------------------------------------------- */
 size_t cm3_returns_scratch_bytes(void);
+/* NOTE (scratch layout): cm3_returns_moments_* keeps its arrival ticket BEHIND 3 * 512 partial slots of `scratch`;
+ * cm3_returns_normalize_segments_* with n_segments >= 2 uses that range for partials.  Give the two entry-point families SEPARATE
+ * scratch buffers (cm3_returns_scratch_bytes / cm3_returns_segments_scratch_bytes): a shared one leaves a garbage ticket and the
+ * moments silently stale. */
 int cm3_returns_moments_f32(const void *x, const uint8_t *done, const uint8_t *valid, void *out, void *scratch,
                             double *moments, int32_t T, int32_t E, int32_t C, double gamma, void *stream);
 int cm3_returns_moments_f64(const void *x, const uint8_t *done, const uint8_t *valid, void *out, void *scratch,
@@ -506,6 +520,47 @@ int cm3_normalize_segments_f64(void *x, const uint8_t *valid, const double *part
 /* Up to 8 device-to-device copies (16-byte aligned pointers and sizes) in ONE launch: trajectory slot <-> live env buffers
  * of the collection loop (train_onpolicy.py:340-343 "state = next_state" across rollouts). */
 int cm3_copy_list(int32_t n, void *const *dst, const void *const *src, const size_t *bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Transition export and replay rings as single launches (ABI 6)
+ * ---------------------------------------------------------------------------------------- */
+/* The nine distinct columns of the reference's 11-field particle transition (alg/train_onpolicy.py:338; v_global == v_local ==
+ * state, alg_credit.py:458-470), each contiguous over the B gathered transitions. */
+typedef struct cm3_transition_cols {
+  void *state;            /* float [B][N][4]            global_state / local_self */
+  void *obs_others;       /* float [B][N][4 max(N-1,1)] */
+  int32_t *actions;       /* int32 [B][N] */
+  void *reward;           /* float [B] */
+  void *reward_n;         /* float [B][N] */
+  void *next_state;       /* float [B][N][4]   slot t + 1, or the captured terminal state where the env restarted in that launch */
+  void *next_obs_others;  /* float [B][N][L]   likewise */
+  uint8_t *done;          /* uint8 [B] */
+  void *goals;            /* float [B][N][2] */
+} cm3_transition_cols;
+/* Gathers transitions (tt[b], ee[b]), b < n, out of a time-major trajectory (the cm3_particle_traj the collector wrote: state
+ * [T+1][N][E][4], obs_others [T+1][E][N][L], actions / reward_n [T][E][N], reward / done [T][E], optional term_* [T][...]) in ONE
+ * launch.  goals: traj->goals with goals_stride bytes per slot (stride 0: one live array); goal_slot (optional, int32 with
+ * goal_slot_stride bytes per tick, [T+1][E]) names the slot that holds the goals in effect at (t, e) -- sparse goal slots; NULL:
+ * slot t itself.  desc supplies n_envs / n_agents only.  Replaces alg/replay_buffer.py's list-of-arrays + np.stack(batch[:, k]). */
+int cm3_transitions_gather_f32(const cm3_particle_desc *desc, const cm3_particle_traj *traj, const int32_t *goal_slot,
+                               size_t goal_slot_stride, const int64_t *tt, const int64_t *ee, int64_t n,
+                               const cm3_transition_cols *out, void *stream);
+
+/* Up to 16 columns of row-major records (row_bytes[k] bytes per row of column k), moved together. */
+typedef struct cm3_row_cols {
+  int32_t n_cols;
+  int32_t reserved;
+  void *dst[16];
+  const void *src[16];
+  uint32_t row_bytes[16];
+} cm3_row_cols;
+/* dst[k][row(b)] = src[k][b] for b < n_rows, every column in ONE launch.  row(b) = dst_row[b] when dst_row is given (a negative
+ * entry skips the row: the two rings of replay_buffer_dual.py:12-38 take the same batch with complementary index arrays), else the
+ * ring position (ring_start + b) mod ring_size (replay_buffer.py:11-16: overwrite the oldest; n_rows <= ring_size). */
+int cm3_rows_scatter(const cm3_row_cols *cols, int64_t n_rows, const int64_t *dst_row, int64_t ring_start, int64_t ring_size,
+                     void *stream);
+/* dst[k][b] = src[k][src_row[b]] (replay_buffer.py:28-37 sample_batch: the sampled transitions as contiguous columns). */
+int cm3_rows_gather(const cm3_row_cols *cols, int64_t n_rows, const int64_t *src_row, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Measurement and launch plumbing

@@ -1,0 +1,200 @@
+"""GPU: the device replay buffers and the single-launch transition export (f2).
+
+* DeviceReplayBuffer / DeviceDualReplayBuffer on cuda:0 against what the REAL reference classes hold after the same adds
+  (tests/golden/replay_csv.json, recorded from alg/replay_buffer.py:11-37 and alg/replay_buffer_dual.py:40-63): slot contents,
+  wrap-around, over-long batches, the dual buffer's split counts;
+* filled from a real ParticleRollout.as_reference_batch(numpy=False) with `scenario.collisions != 0` of the transition's episode as
+  the split flag (alg/train_onpolicy.py:356): every stored transition is found again in the rollout, in the right memory;
+* cm3_transitions_gather_f32 (one launch) against the torch composition it replaces, dense / sparse goal slots, terminal capture."""
+import json
+import os
+
+import pytest
+import torch
+
+from tests.helpers import GOLDEN, load_cfg
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _fixture():
+    return json.load(open(os.path.join(GOLDEN, "replay_csv.json")))
+
+
+def _cols(start, n):
+    i = torch.arange(start, start + n, device=DEV)
+    return {"id": i.clone(), "x": torch.stack([i.float(), -i.float()], dim=1), "flag": (i % 2 == 0), "w": i.to(torch.float64).view(n, 1, 1).repeat(1, 3, 2)}
+
+
+def test_ring_buffer_on_the_gpu_equals_recorded_reference_memory():
+    from cm3_amd.replay import DeviceReplayBuffer
+    for case in _fixture()["ring"]:
+        ours = DeviceReplayBuffer(size=case["size"], device=DEV)
+        start = 0
+        for chunk in case["chunks"]:
+            ours.add(_cols(start, chunk))
+            start += chunk
+        got = ours.all()
+        assert sorted(got["id"].tolist()) == sorted(case["memory"]), case
+        if max(case["chunks"]) <= case["size"]:                      # same slots too (an over-long chunk keeps the newest)
+            assert got["id"].tolist() == case["memory"], case
+        # every column moved with its row (16-, 8-, 4- and 1-byte row sizes)
+        assert torch.equal(got["x"][:, 0], got["id"].float()) and torch.equal(got["x"][:, 1], -got["id"].float())
+        assert torch.equal(got["flag"], got["id"] % 2 == 0)
+        assert torch.equal(got["w"], got["id"].to(torch.float64).view(-1, 1, 1).repeat(1, 3, 2))
+        if len(ours) > 3:
+            b = ours.sample_batch(3, generator=torch.Generator(device=DEV).manual_seed(1))
+            assert b["id"].shape == (3,) and len(set(b["id"].tolist())) == 3 and set(b["id"].tolist()) <= set(case["memory"])
+            assert torch.equal(b["x"][:, 0], b["id"].float()) and torch.equal(b["flag"], b["id"] % 2 == 0)
+        assert ours.sample_batch(10 ** 6)["id"].shape[0] == len(case["memory"])      # len <= size -> everything
+
+
+def test_dual_buffer_on_the_gpu_equals_recorded_reference_counts():
+    from cm3_amd.replay import DeviceDualReplayBuffer
+    for case in _fixture()["dual"]:
+        n1, n2 = case["n_bad"], case["n_good"]
+        buf = DeviceDualReplayBuffer(size=1000, device=DEV)
+        cols = _cols(0, n1 + n2)
+        perm = torch.randperm(n1 + n2, generator=torch.Generator(device=DEV).manual_seed(n1 * 131 + n2), device=DEV)
+        cols = {k: v[perm].contiguous() for k, v in cols.items()}            # bad and good transitions interleaved
+        buf.add(cols, cols["id"] < n1)
+        assert (len(buf.mem1), len(buf.mem2)) == (n1, n2)
+        if n1:
+            assert torch.equal(buf.mem1.all()["id"], cols["id"][cols["id"] < n1])     # order of arrival kept inside each memory
+        if n2:
+            assert torch.equal(buf.mem2.all()["id"], cols["id"][cols["id"] >= n1])
+        b = buf.sample_batch(case["size"], generator=torch.Generator(device=DEV).manual_seed(0))
+        if b is None:
+            assert case["taken_bad"] + case["taken_good"] == 0
+            continue
+        assert (int((b["id"] < n1).sum()), int((b["id"] >= n1).sum())) == (case["taken_bad"], case["taken_good"]), case
+        assert len(set(b["id"].tolist())) == b["id"].numel()
+        assert torch.equal(b["x"][:, 0], b["id"].float())
+
+
+def test_dual_buffer_wraps_like_sequential_adds():
+    """A batch with more bad transitions than the memory holds, on top of earlier contents: memory_1 ends up as after one
+    add_1() per bad transition in order (replay_buffer_dual.py:26-31)."""
+    from cm3_amd.replay import DeviceDualReplayBuffer
+    size = 7
+    buf = DeviceDualReplayBuffer(size=size, device=DEV)
+    mem1, idx1, mem2, idx2 = [], 0, [], 0
+    start = 0
+    for n in (5, 4, 23, 3):
+        cols = _cols(start, n)
+        bad = (cols["id"] % 3) != 1
+        buf.add(cols, bad)
+        for i, bflag in zip(cols["id"].tolist(), bad.tolist()):
+            if bflag:
+                if idx1 >= len(mem1):
+                    mem1.append(i)
+                else:
+                    mem1[idx1] = i
+                idx1 = (idx1 + 1) % size
+            else:
+                if idx2 >= len(mem2):
+                    mem2.append(i)
+                else:
+                    mem2[idx2] = i
+                idx2 = (idx2 + 1) % size
+        start += n
+        assert buf.mem1.all()["id"].tolist() == mem1 and buf.mem2.all()["id"].tolist() == mem2, n
+        assert (buf.mem1.idx, buf.mem2.idx) == (idx1, idx2)
+
+
+def _rollout(E=512, N=4, T=66, cfg="particle_stage2_cross.json", **kw):
+    from cm3_amd.particle import VecParticleEnv
+    from cm3_amd.rollout import ParticleRollout
+    env = VecParticleEnv(load_cfg(cfg), N, 0.2, 33, E, device=DEV, dtype=torch.float32, auto_reset=True, seed=77)
+    env.reset()
+    ro = ParticleRollout(env, n_ticks=T, use_graph=True, **kw)
+    ro.collect()
+    return env, ro
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(sparse_goals=True, live_state=False), dict(live_state=True)])
+@pytest.mark.parametrize("N,cfg", [(4, "particle_stage2_cross.json"), (8, "particle_merge8.json"), (1, "particle_stage1.json"), (3, "particle_merge8.json")])
+def test_single_launch_transition_export_equals_the_torch_composition(N, cfg, kw):
+    env, ro = _rollout(E=300, N=N, T=40, cfg=cfg, **kw)
+    tt, ee = ro.valid_indices()
+    a = ro.as_reference_batch(tt, ee, numpy=False)                 # cm3_transitions_gather_f32
+    b = ro.as_reference_batch_torch(tt, ee, numpy=False)
+    assert int(ro.done.sum()) > 0 and set(a) == set(b)
+    for k in b:
+        assert a[k].dtype == b[k].dtype and a[k].shape == b[k].shape, k
+        assert torch.equal(a[k], b[k]), k
+    pick = torch.randperm(tt.numel(), device=DEV)[:1000]
+    a = ro.as_reference_batch(tt[pick], ee[pick], numpy=False)
+    b = ro.as_reference_batch_torch(tt[pick], ee[pick], numpy=False)
+    for k in b:
+        assert torch.equal(a[k], b[k]), k
+    assert a["v_global"].data_ptr() == a["v_local"].data_ptr()     # the reference stores the same array twice (train_onpolicy.py:338)
+    ro.close()
+
+
+def test_replay_buffers_filled_from_a_real_rollout():
+    """The trainer's use (train_onpolicy.py:338-357): every transition of a collection goes into the buffer; with the dual buffer
+    the transitions of an episode go to memory_1 iff scenario.collisions != 0 at the episode's end."""
+    from cm3_amd.replay import DeviceDualReplayBuffer, DeviceReplayBuffer
+    env, ro = _rollout(E=256, N=4, T=99)
+    cols = ro.as_reference_batch(numpy=False)
+    B = cols["reward"].shape[0]
+    assert B == 99 * 256
+    # per-transition flag: the flag of the episode the transition belongs to = episode_is_bad() at the tick that ends it, carried
+    # backwards over the episode's ticks (an episode still running at the end of the collection: not bad yet)
+    bad_end, done = ro.episode_is_bad(), ro.done.bool()                      # [T, E]
+    flag = torch.zeros_like(done)
+    carry = torch.zeros(done.shape[1], dtype=torch.bool, device=DEV)
+    for t in range(done.shape[0] - 1, -1, -1):
+        carry = torch.where(done[t], bad_end[t], carry)
+        flag[t] = carry
+    tt, ee = ro.valid_indices()
+    is_bad = flag[tt, ee]
+    assert 0 < int(is_bad.sum()) < B
+
+    ring = DeviceReplayBuffer(size=B // 2 + 5, device=DEV)                   # wraps
+    ring.add(cols)
+    got = ring.all()
+    keep = torch.arange(B - ring.maxsize, B, device=DEV)
+    pos = (keep % ring.maxsize)
+    for k, v in cols.items():
+        assert torch.equal(got[k][pos], v[keep]), k
+    s = ring.sample_batch(128, generator=torch.Generator(device=DEV).manual_seed(3))
+    assert s["v_global"].shape == (128, 4, 4) and s["done"].dtype == torch.bool
+    # a sampled transition is one of the rollout's: its next state continues its state under the stored action for non-terminal rows
+    assert torch.isfinite(s["obs_others_next"]).all()
+
+    dual = DeviceDualReplayBuffer(size=B, device=DEV)
+    dual.add(cols, is_bad)
+    n1 = int(is_bad.sum())
+    assert (len(dual.mem1), len(dual.mem2)) == (n1, B - n1)
+    for k, v in cols.items():
+        assert torch.equal(dual.mem1.all()[k], v[is_bad]), k
+        assert torch.equal(dual.mem2.all()[k], v[~is_bad]), k
+    b = dual.sample_batch(128, generator=torch.Generator(device=DEV).manual_seed(4))
+    assert b["reward"].shape[0] == 128
+    ro.close()
+
+
+def test_reading_goals_between_collections_keeps_the_captured_graph():
+    """the `goals` getter clears the "slots incomplete" flag; that flag used to double as the key of the captured
+    hipGraph, so a loop that read ro.goals re-captured every collection -- and a toggled mode could replay a stale graph."""
+    env, ro = _rollout(E=256, N=4, T=33, sparse_goals=True, live_state=False)
+    g0 = ro._graph.value
+    for _ in range(3):
+        _ = ro.goals
+        assert not ro._goals_sparse
+        ro.collect(reset=False)
+        assert ro._goals_sparse and ro._graph.value == g0                     # same graph, slots sparse again
+    ref_env, ref = _rollout(E=256, N=4, T=33, sparse_goals=False, live_state=False)
+    for _ in range(3):
+        ref.collect(reset=False)
+    _ = ro.goals
+    ro.sparse_goals = False                                                   # toggled after a goals read: must re-capture, dense
+    ro.collect(reset=False)
+    ref.collect(reset=False)
+    assert not ro._goals_sparse and ro._graph.value != g0
+    assert torch.equal(ro.goals, ref.goals) and torch.equal(ro.state, ref.state) and torch.equal(env.goals, ref_env.goals)
+    ro.close()
+    ref.close()

@@ -1,27 +1,38 @@
-"""CPU: device replay buffers / CSV rows against the reference's own classes (container) and their documented
-semantics.  The buffers are torch-device agnostic; CPU tensors here, the GPU rollout tests feed them device columns."""
+"""CPU: the host logic of the device replay buffers (ring bookkeeping, the dual buffer's split rule) and the CSV rows against the
+reference's own classes (container) and against outputs recorded from them (tests/golden/replay_csv.json).  The buffers themselves
+live on the GPU: tests/test_gpu_replay.py runs the same fixtures, and a real rollout, through DeviceReplayBuffer /
+DeviceDualReplayBuffer on cuda:0."""
 import os
 import random
 import sys
 
 import pytest
-import torch
 
-from cm3_amd.replay import CsvLog, DeviceDualReplayBuffer, DeviceReplayBuffer
+from cm3_amd.replay import CsvLog, RingIndex, dual_take
 
 REF_ALG = "/root/reference/alg"
 
 
-def _cols(start, n):
-    i = torch.arange(start, start + n)
-    return {"id": i.clone(), "x": torch.stack([i.float(), -i.float()], dim=1)}
+class HostRing(object):
+    """RingIndex driving a Python list: what the ring positions mean (slot k of the device column tensors = memory[k])."""
+
+    def __init__(self, size):
+        self.ring, self.memory = RingIndex(size), [None] * int(size)
+
+    def add(self, items):
+        skip, start, kept = self.ring.plan_add(len(items))
+        for b in range(kept):
+            self.memory[(start + b) % self.ring.maxsize] = items[skip + b]
+
+    def stored(self):
+        return self.memory[:self.ring.len]
 
 
 def test_ring_semantics_match_reference_buffer():
-    ours = DeviceReplayBuffer(size=10, device="cpu")
+    ours = HostRing(10)
     start = 0                                      # 18 transitions into a ring of 10
     for chunk in (4, 5, 6, 3):
-        ours.add(_cols(start, chunk))
+        ours.add(list(range(start, start + chunk)))
         start += chunk
     if os.path.isdir(REF_ALG):
         sys.path.insert(0, REF_ALG)
@@ -30,34 +41,26 @@ def test_ring_semantics_match_reference_buffer():
         ref = replay_buffer.Replay_Buffer(size=10)
         for t in range(18):
             ref.add(t)
-        assert sorted(ours.all()["id"].tolist()) == sorted(ref.memory)
-        assert [ours.cols["id"][k].item() for k in range(10)] == ref.memory       # same slots, too
-    assert len(ours) == 10 and sorted(ours.all()["id"].tolist()) == list(range(8, 18))
-    b = ours.sample_batch(4, generator=torch.Generator().manual_seed(0))
-    assert b["id"].shape == (4,) and len(set(b["id"].tolist())) == 4
-    assert torch.equal(b["x"][:, 0], b["id"].float())
-    assert ours.sample_batch(100)["id"].shape == (10,)                            # len <= size -> everything
+        assert ours.stored() == ref.memory                                       # same slots
+    assert ours.ring.len == 10 and sorted(ours.stored()) == list(range(8, 18))
 
 
 def test_add_larger_than_capacity_keeps_the_newest():
-    ours = DeviceReplayBuffer(size=5, device="cpu")
-    ours.add(_cols(0, 12))
-    assert sorted(ours.all()["id"].tolist()) == [7, 8, 9, 10, 11]
+    ours = HostRing(5)
+    ours.add(list(range(12)))
+    assert sorted(ours.stored()) == [7, 8, 9, 10, 11]
+    assert ours.ring.idx == 12 % 5
 
 
 @pytest.mark.parametrize("n1,n2,size,want1,want2", [(100, 100, 20, 10, 10), (100, 3, 20, 17, 3), (4, 100, 20, 4, 16),
                                                     (4, 5, 20, 4, 5), (12, 3, 20, 12, 3)])
 def test_dual_buffer_split_rule(n1, n2, size, want1, want2):
     """replay_buffer_dual.py:40-63."""
-    buf = DeviceDualReplayBuffer(size=1000, device="cpu")
-    cols = _cols(0, n1 + n2)
-    bad = torch.arange(n1 + n2) < n1
-    buf.add(cols, bad)
-    b = buf.sample_batch(size)
-    got1 = int((b["id"] < n1).sum())
-    got2 = int((b["id"] >= n1).sum())
-    assert (got1, got2) == (want1, want2)
+    k1, all1, k2, all2 = dual_take(n1, n2, size)
+    assert (k1, k2) == (want1, want2)
+    assert (not all1 or k1 == n1) and (not all2 or k2 == n2)
     if os.path.isdir(REF_ALG):
+        import numpy as np      # noqa: F401
         sys.path.insert(0, REF_ALG)
         import replay_buffer_dual
         ref = replay_buffer_dual.Replay_Buffer(size=1000)
@@ -65,7 +68,7 @@ def test_dual_buffer_split_rule(n1, n2, size, want1, want2):
         ref.add(list(range(n1, n1 + n2)), is_bad=False)
         random.seed(0)
         r = ref.sample_batch(size)
-        assert (int((r < n1).sum()), int((r >= n1).sum())) == (got1, got2)
+        assert (int((r < n1).sum()), int((r >= n1).sum())) == (k1, k2)
 
 
 def test_csv_rows_have_the_reference_format(tmp_path):
@@ -107,26 +110,33 @@ def test_csv_headers_and_rows_equal_what_the_reference_writes(tmp_path):
     assert n_rows == 12
 
 
-def test_ring_buffer_equals_recorded_reference_memory():
-    """DeviceReplayBuffer slot contents after chunked adds == replay_buffer.Replay_Buffer.memory after the same sequence of
-    single adds (alg/replay_buffer.py:11-16), as recorded from the real class."""
+def test_ring_bookkeeping_equals_recorded_reference_memory():
+    """RingIndex positions after chunked adds == replay_buffer.Replay_Buffer.memory after the same sequence of single adds
+    (alg/replay_buffer.py:11-16), as recorded from the real class."""
     for case in _fixture()["ring"]:
-        ours = DeviceReplayBuffer(size=case["size"], device="cpu")
+        ours = HostRing(case["size"])
         start = 0
         for chunk in case["chunks"]:
-            ours.add(_cols(start, chunk))
+            ours.add(list(range(start, start + chunk)))
             start += chunk
-        assert sorted(ours.all()["id"].tolist()) == sorted(case["memory"]), case
+        assert sorted(ours.stored()) == sorted(case["memory"]), case
         if max(case["chunks"]) <= case["size"]:                      # same slots too (an over-long chunk keeps the newest)
-            assert [ours.cols["id"][k].item() for k in range(len(case["memory"]))] == case["memory"], case
+            assert ours.stored() == case["memory"], case
 
 
-def test_dual_buffer_split_equals_recorded_reference_counts():
-    """DeviceDualReplayBuffer.sample_batch takes as many `bad` / `good` transitions as replay_buffer_dual.Replay_Buffer does
+def test_dual_split_rule_equals_recorded_reference_counts():
+    """dual_take takes as many `bad` / `good` transitions as replay_buffer_dual.Replay_Buffer.sample_batch does
     (alg/replay_buffer_dual.py:40-63), as recorded from the real class, including empty halves."""
     for case in _fixture()["dual"]:
-        n1, n2 = case["n_bad"], case["n_good"]
-        buf = DeviceDualReplayBuffer(size=1000, device="cpu")
-        buf.add(_cols(0, n1 + n2), torch.arange(n1 + n2) < n1)
-        b = buf.sample_batch(case["size"])
-        assert (int((b["id"] < n1).sum()), int((b["id"] >= n1).sum())) == (case["taken_bad"], case["taken_good"]), case
+        k1, _, k2, _ = dual_take(case["n_bad"], case["n_good"], case["size"])
+        assert (k1, k2) == (case["taken_bad"], case["taken_good"]), case
+
+
+def test_device_buffers_have_no_host_path():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU box: tests/test_gpu_replay.py")
+    from cm3_amd._lib import Cm3Error
+    from cm3_amd.replay import DeviceReplayBuffer
+    with pytest.raises(Cm3Error):
+        DeviceReplayBuffer(size=4, device="cpu")
