@@ -254,17 +254,23 @@ def _same_rollout(a, ea, b, eb):
 @pytest.mark.parametrize("N,cfg", [(4, "particle_stage2_cross.json"), (8, "particle_merge8.json"), (2, "particle_stage2_merge.json")])
 def test_every_row_tile_build_of_the_policy_rollout_is_the_same_rollout(N, cfg, precision, monkeypatch):
     """k_policy_rollout<N, prec, RT>: 16 / 32 / 64 agent rows per workgroup are three builds of the kernel (policy.hip picks one by
-    batch size; the small test batches elsewhere only ever reach RT = 1).  CM3_POLICY_RT forces each in turn on ONE batch: all three
-    must reproduce the alternating actor / step launches bit for bit, and cm3_last_kernel_variant() must name the build that ran."""
+    batch size; the small test batches elsewhere only ever reach RT = 1).  cm3_policy_force_row_tiles forces each in turn on ONE
+    batch: all three must reproduce the alternating actor / step launches bit for bit, and cm3_last_kernel_variant() must name the
+    build that ran."""
+    from cm3_amd import _lib
     E, T = 600, 16            # ragged: 600 x N rows is no multiple of 64
-    monkeypatch.delenv("CM3_POLICY_RT", raising=False)
+    _lib.check(_lib.lib().cm3_policy_force_row_tiles(0))
     ref, eref, _ = _policy_run(E, N, cfg, precision, T, "tick")
-    for rt in (1, 2, 4):
-        monkeypatch.setenv("CM3_POLICY_RT", str(rt))
-        ro, env, variant = _policy_run(E, N, cfg, precision, T, "episode")
-        assert variant.startswith("k_policy_rollout<") and ("g=%d," % rt) in variant, variant
-        _same_rollout(ref, eref, ro, env)
-        ro.close()
+    try:
+        for rt in (1, 2, 4):
+            _lib.check(_lib.lib().cm3_policy_force_row_tiles(rt))
+            ro, env, variant = _policy_run(E, N, cfg, precision, T, "episode")
+            assert variant.startswith("k_policy_rollout<") and ("g=%d," % rt) in variant, variant
+            _same_rollout(ref, eref, ro, env)
+            ro.close()
+        assert _lib.lib().cm3_policy_force_row_tiles(3) != 0           # only 0, 1, 2, 4
+    finally:
+        _lib.check(_lib.lib().cm3_policy_force_row_tiles(0))
     ref.close()
 
 
@@ -278,7 +284,8 @@ def test_every_row_tile_build_of_the_policy_rollout_is_the_same_rollout(N, cfg, 
 def test_policy_rollout_row_tile_rule_at_the_baseline_sizes(E, N, cfg, rt, rt_tick, monkeypatch):
     """The rule itself (policy_launch): which build a whole-episode launch and a one-tick launch take at the BASELINE batch sizes,
     and that those launches equal the alternating actor / step launches there too."""
-    monkeypatch.delenv("CM3_POLICY_RT", raising=False)
+    from cm3_amd import _lib
+    _lib.check(_lib.lib().cm3_policy_force_row_tiles(0))
     T = 9
     ref, eref, _ = _policy_run(E, N, cfg, "f16x3", T, "tick")
     ro, env, variant = _policy_run(E, N, cfg, "f16x3", T, "episode")

@@ -22,19 +22,17 @@ def first_diff(a, b):
 
 for E, N, cfg, prec in [(8192, 8, "particle_merge8.json", "f16x3"), (8192, 8, "particle_merge8.json", "f32"), (4096, 8, "particle_merge8.json", "f16x3"),
                         (2048, 8, "particle_merge8.json", "f16x3"), (16384, 4, "particle_stage2_cross.json", "f16x3"), (16384, 2, "particle_stage2_merge.json", "f16x3")]:
-    os.environ.pop("CM3_POLICY_RT", None)
+    from cm3_amd import _lib as _L
+    _L.lib().cm3_policy_force_row_tiles(0)
     ref, eref, v0 = TA._policy_run(E, N, cfg, prec, 9, "tick")
     print(E, N, prec, "tick mode:", v0)
     for rt in ("", "4", "2", "1"):
-        if rt:
-            os.environ["CM3_POLICY_RT"] = rt
-        else:
-            os.environ.pop("CM3_POLICY_RT", None)
+        _L.lib().cm3_policy_force_row_tiles(int(rt) if rt else 0)
         ro, env, v = TA._policy_run(E, N, cfg, prec, 9, "episode")
         print("  RT=%s %s" % (rt or "auto", v))
         first_diff(ref, ro)
         ro.close()
-    os.environ.pop("CM3_POLICY_RT", None)
+    _L.lib().cm3_policy_force_row_tiles(0)
     ro, env, v = TA._policy_run(E, N, cfg, prec, 9, "tick", fused_policy_tick=True)
     print("  fused tick", v)
     first_diff(ref, ro)
