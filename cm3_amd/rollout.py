@@ -154,6 +154,7 @@ class ParticleRollout(object):
         self.sparse_goals = sparse_goals
         self._goals_sparse = False
         self._graph_mode = None          # (live, sparse) the captured graphs were built with
+        self.n_captures = 0              # hipGraph captures of the random-action collection so far (tests)
         self._goal_src = None
         self._goal_src32 = self._goal_src32_of = None
         self.n_chains = int(n_chains)
@@ -385,6 +386,7 @@ class ParticleRollout(object):
                 self._enqueue(0, self.T, flags | _lib.FLAG_FUSED_TICKS, chains=True)
             elif self.use_graph:
                 if self._graph is None:
+                    self.n_captures += 1
                     self._graph = _lib.capture_graph(env.device, lambda s: self._enqueue(0, self.T, flags, s, chains=True, live=live,
                                                                                          sparse_goals=sparse))
                 _lib.check(self._lib.cm3_graph_launch(self._graph, env._stream()))
