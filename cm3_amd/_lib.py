@@ -72,6 +72,15 @@ class RowCols(ctypes.Structure):
                 ("row_bytes", ctypes.c_uint32 * 16)]
 
 
+class TileCol(ctypes.Structure):
+    _fields_ = [("dst", c_void_p), ("src", c_void_p), ("n_rows", c_int64), ("elems_per_row", c_uint32), ("kind", c_uint32),
+                ("elem_bytes", c_uint32), ("others_n", c_uint32), ("others_divq", c_uint32), ("others_divn", c_uint32),
+                ("div", c_uint32 * 2), ("mod", c_uint32 * 2), ("mul", c_uint32 * 2)]
+
+
+TILE_COPY, TILE_F32_TO_F64, TILE_ONEHOT_I64, TILE_ONEHOT_F64, TILE_EYE_F64, TILE_NOT_I64 = range(6)
+
+
 class CopyShift(ctypes.Structure):
     _fields_ = [("n", c_int32), ("_pad", c_int32), ("first_dst", c_void_p * 4), ("mid", c_void_p * 4),
                 ("last_src", c_void_p * 4), ("bytes", c_size_t * 4)]
@@ -174,6 +183,7 @@ SYMBOLS = {
                                                   P(TransitionCols), c_void_p]),
     "cm3_rows_scatter": (ctypes.c_int, [P(RowCols), c_int64, c_void_p, c_int64, c_int64, c_void_p]),
     "cm3_rows_gather": (ctypes.c_int, [P(RowCols), c_int64, c_void_p, c_void_p]),
+    "cm3_rows_tile": (ctypes.c_int, [P(TileCol), c_int32, c_void_p]),
     "cm3_actor_checkers_packed_bytes": (c_size_t, []),
     "cm3_actor_checkers_pack": (ctypes.c_int, [P(ActorCheckersDesc), P(ActorCheckersWeights), c_void_p, c_void_p]),
     "cm3_actor_checkers_f32": (ctypes.c_int, [P(ActorCheckersDesc), P(ActorCheckersWeights), P(ActorCheckersBufs),

@@ -14,6 +14,90 @@ by the REAL reference functions, tests/golden/batch_particle.npz).
 import torch
 
 
+class _Tiler(object):
+    """Collects "destination row r <- source row f(r)" outputs and builds them 16 per launch (cm3_rows_tile, csrc/batch.hip)."""
+
+    def __init__(self, device):
+        self.device, self.specs, self.keep = device, [], []
+
+    def add(self, src, n_rows, epr, dtype, kind, terms=((1, 0, 1), (1, 0, 0)), others=None, shape=None):
+        from . import _lib
+        out = torch.empty((n_rows, epr) if shape is None else shape, dtype=dtype, device=self.device)
+        c = _lib.TileCol()
+        c.dst, c.src, c.n_rows, c.elems_per_row, c.kind = out.data_ptr(), (0 if src is None else src.data_ptr()), n_rows, epr, kind
+        c.elem_bytes = src.element_size() if (src is not None and kind == _lib.TILE_COPY) else 0
+        if others is not None:
+            c.others_n, c.others_divq, c.others_divn = others
+        else:
+            for i, (d, m, mul) in enumerate(terms):
+                c.div[i], c.mod[i], c.mul[i] = d, m, mul
+        self.specs.append(c)
+        self.keep.append(src)
+        return out
+
+    def run(self):
+        from . import _lib
+        import ctypes
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        for k in range(0, len(self.specs), 16):
+            chunk = self.specs[k:k + 16]
+            arr = (_lib.TileCol * len(chunk))(*chunk)
+            _lib.check(_lib.lib().cm3_rows_tile(arr, len(chunk), stream))
+        self.specs, self.keep = [], []
+
+
+def particle_static_feeds_device(cols, l_action=5):
+    """Every feed of the reference's train_step that does not depend on a network output (particle env, N > 1, Q-credit variant), from
+    the float32 columns of ParticleRollout.as_reference_batch(numpy=False), in TWO launches of cm3_rows_tile: process_actions /
+    process_global_state (alg_credit.py:406-443, :528-557), the n x n credit repeats (:614-658), the n x n x l_action counterfactual
+    tiling (:730-751).  Values and dtypes are those of the torch composition in train_step_feeds (tests/test_batch.py compares the two
+    and both with the arrays the REAL train_step fed)."""
+    from . import _lib
+    vg, vgn = cols["v_global"].contiguous(), cols["v_global_next"].contiguous()
+    B, N, l = vg.shape
+    A, R, dev = int(l_action), B * N, vg.device
+    actions = cols["actions"].to(torch.int32).contiguous()
+    done = cols["done"].contiguous()
+    done_u8 = done.view(torch.uint8) if done.dtype == torch.bool else done.to(torch.uint8)
+    goals = cols["goals"].contiguous()
+    lg = goals.shape[2]
+    reward, reward_local = cols["reward"].contiguous(), cols["reward_local"].contiguous()
+    f64, i64 = torch.float64, torch.int64
+    by_n = lambda outer=1: ((outer * N * N, 0, N), (outer, N, 1))          # noqa: E731  rows (b, m, n[, a]) <- row b N + n
+    by_m = lambda outer=1: ((outer * N, 0, 1), (1, 0, 0))                   # noqa: E731  rows (r, m[, a])    <- row r
+    t = _Tiler(dev)
+    S = {}
+    S["a1"] = t.add(actions, R, A, i64, _lib.TILE_ONEHOT_I64)
+    S["ao"] = t.add(actions, R * (N - 1), A, f64, _lib.TILE_ONEHOT_F64, others=(N, N * (N - 1), N - 1), shape=(R, N - 1, A))
+    S["reward_rep"] = t.add(reward, R, 1, reward.dtype, _lib.TILE_COPY, terms=by_m(), shape=(R,))
+    S["done_rep"] = t.add(done_u8, R, 1, torch.bool, _lib.TILE_COPY, terms=by_m(), shape=(R,))
+    S["not_done"] = t.add(done_u8, R, 1, i64, _lib.TILE_NOT_I64, terms=by_m(), shape=(R,))
+    S["others"] = t.add(vg, R * (N - 1), l, f64, _lib.TILE_F32_TO_F64, others=(N, N * (N - 1), N - 1), shape=(R, (N - 1) * l))
+    S["others_next"] = t.add(vgn, R * (N - 1), l, f64, _lib.TILE_F32_TO_F64, others=(N, N * (N - 1), N - 1), shape=(R, (N - 1) * l))
+    S["goals_self_rep"] = t.add(goals, R * N, lg, goals.dtype, _lib.TILE_COPY, terms=by_n())
+    S["one_next_rep_n"] = t.add(vgn, R * N, l, vgn.dtype, _lib.TILE_COPY, terms=by_n())
+    S["one_next_rep_m"] = t.add(vgn, R * N, l, vgn.dtype, _lib.TILE_COPY, terms=by_m())
+    S["others_next_rep_n"] = t.add(vgn, R * N * (N - 1), l, f64, _lib.TILE_F32_TO_F64, others=(N, N * N * (N - 1), N - 1),
+                                   shape=(R * N, (N - 1) * l))
+    S["r_rep"] = t.add(reward_local, R * N, 1, reward_local.dtype, _lib.TILE_COPY, terms=by_n(), shape=(R * N,))
+    # (done per time step -> per agent row -> repeated by n: row (b, m, n) <- done[b])
+    S["nd_rep"] = t.add(done_u8, R * N, 1, i64, _lib.TILE_NOT_I64, terms=((N * N, 0, 1), (1, 0, 0)), shape=(R * N,))
+    S["s_n_rep"] = t.add(vg, R * N, l, vg.dtype, _lib.TILE_COPY, terms=by_n())
+    S["s_m_rep"] = t.add(vg, R * N, l, vg.dtype, _lib.TILE_COPY, terms=by_m())
+    S["s_others_rep"] = t.add(vg, R * N * (N - 1), l, f64, _lib.TILE_F32_TO_F64, others=(N, N * N * (N - 1), N - 1),
+                              shape=(R * N, (N - 1) * l))
+    t.run()
+    S["a1_rep_m"] = t.add(actions, R * N, A, i64, _lib.TILE_ONEHOT_I64, terms=by_m())
+    S["cf_s_n"] = t.add(vg, R * N * A, l, vg.dtype, _lib.TILE_COPY, terms=by_n(A))
+    S["cf_goals"] = t.add(goals, R * N * A, lg, goals.dtype, _lib.TILE_COPY, terms=by_n(A))
+    S["cf_eye"] = t.add(None, R * N * A, A, f64, _lib.TILE_EYE_F64)
+    S["cf_s_m"] = t.add(vg, R * N * A, l, vg.dtype, _lib.TILE_COPY, terms=by_m(A))
+    S["cf_s_others"] = t.add(vg, R * N * A * (N - 1), l, f64, _lib.TILE_F32_TO_F64, others=(N, N * N * A * (N - 1), A * (N - 1)),
+                             shape=(R * N * A, (N - 1) * l))
+    t.run()
+    return S
+
+
 def others_index(n_agents, device=None):
     """[N, N-1] long: row n lists the other agents in ascending order (np.arange(N) != n)."""
     idx = [[j for j in range(n_agents) if j != n] for n in range(n_agents)]
@@ -108,7 +192,7 @@ def _rep_n(x, n):
     return repeat_indexed_by_n(x, n)
 
 
-def train_step_feeds(cols, run, gamma, epsilon, env="particle", use_Q_credit=True, use_V=True, l_action=5):
+def train_step_feeds(cols, run, gamma, epsilon, env="particle", use_Q_credit=True, use_V=True, l_action=5, device_tiling=True):
     """The data movement of the reference's train_step on the device: builds, in the reference's order, the feed_dict of
     every sess.run -- TD targets, the n x n credit repeats (alg_credit.py:614-658) and the n x n x l_action counterfactual
     tiling (:730-751; Checkers twin alg_credit_checkers.py:590-760) -- from the columns of
@@ -132,14 +216,34 @@ def train_step_feeds(cols, run, gamma, epsilon, env="particle", use_Q_credit=Tru
          obs_self_v_next, done, goals) = process_batch_checkers(cols, l_action)
         v_global, v_global_next = state_agents, state_agents_next
     else:
-        (n_steps, v_global, obs_others, v_local, actions_1hot, actions_others_1hot, reward, reward_local, v_global_next,
-         obs_others_next, v_local_next, done, goals) = process_batch(cols, l_action)
+        vg0 = cols["v_global"]
+        # float32 columns on the GPU: everything that does not depend on a network output comes from two launches of
+        # cm3_rows_tile (particle_static_feeds_device); other inputs (the float64 parity path, host tensors of the CPU tests, N = 1,
+        # the variants without Q-credit) go through the torch composition below -- the specification both are tested against
+        S = (particle_static_feeds_device(cols, l_action)
+             if (vg0.is_cuda and vg0.dtype == torch.float32 and vg0.shape[1] > 1 and use_Q_credit and device_tiling) else None)
+        if S is not None:
+            B_, N_ = vg0.shape[0], vg0.shape[1]
+            (n_steps, v_global, obs_others, v_local, actions_1hot, actions_others_1hot, reward, reward_local, v_global_next,
+             obs_others_next, v_local_next, done, goals) = (
+                B_, vg0, cols["obs_others"].reshape(B_ * N_, -1), cols["v_local"].reshape(B_ * N_, -1), S["a1"], S["ao"], S["reward_rep"],
+                cols["reward_local"].reshape(B_ * N_), cols["v_global_next"], cols["obs_others_next"].reshape(B_ * N_, -1),
+                cols["v_local_next"].reshape(B_ * N_, -1), S["done_rep"], cols["goals"])
+        else:
+            (n_steps, v_global, obs_others, v_local, actions_1hot, actions_others_1hot, reward, reward_local, v_global_next,
+             obs_others_next, v_local_next, done, goals) = process_batch(cols, l_action)
+    if checkers:
+        S = None
     N = v_global.shape[1]
-    goals_self, _ = process_goals(goals)
-    one, others, _ = process_global_state(v_global)
-    one_next, others_next, _ = process_global_state(v_global_next)
+    goals_self, _ = process_goals(goals) if S is None else (goals.reshape(-1, goals.shape[2]), None)
+    if S is None:
+        one, others, _ = process_global_state(v_global)
+        one_next, others_next, _ = process_global_state(v_global_next)
+    else:
+        one, others = v_global.reshape(-1, v_global.shape[2]), S["others"]
+        one_next, others_next = v_global_next.reshape(-1, v_global_next.shape[2]), S["others_next"]
     f64 = torch.float64
-    not_done = (-(done.to(torch.int64) - 1))                                       # if true, then 0, else 1 (:590)
+    not_done = (-(done.to(torch.int64) - 1)) if S is None else S["not_done"]      # if true, then 0, else 1 (:590)
 
     def actor_feed(oo, *obs):
         if checkers:
@@ -175,18 +279,24 @@ def train_step_feeds(cols, run, gamma, epsilon, env="particle", use_Q_credit=Tru
     rep_m = lambda x: x.repeat_interleave(N, dim=0)                                 # noqa: E731  things indexed by m
     s_n_rep = s_m_rep = s_others_rep = goals_self_rep = s_env_rep = ot_rep = ov_rep = None
     if N > 1 and use_Q_credit:      # ---- Q_n(s, a^m) (:616-674) ----
-        goals_self_rep = _rep_n(goals_self, N)
-        feed = {"v_state_one_agent": _rep_n(one_next, N), "v_goal": goals_self_rep, "action_one": rep_m(a_next),
-                "v_state_m": rep_m(one_next), "v_state_other_agents": _rep_n(others_next, N)}
+        goals_self_rep = _rep_n(goals_self, N) if S is None else S["goals_self_rep"]
+        feed = {"v_state_one_agent": _rep_n(one_next, N) if S is None else S["one_next_rep_n"], "v_goal": goals_self_rep,
+                "action_one": rep_m(a_next), "v_state_m": rep_m(one_next) if S is None else S["one_next_rep_m"],
+                "v_state_other_agents": _rep_n(others_next, N) if S is None else S["others_next_rep_n"]}
         if checkers:
             feed = with_env(feed, rep_m(state_env_next), rep_m(obs_self_t_next), rep_m(obs_self_v_next))
         qc_t = call(["Q_credit_target"], feed)[0]
-        r_rep = _rep_n(reward_local.reshape(-1, 1), N).reshape(-1)
-        nd_rep = -(_rep_n(done.reshape(-1, 1).to(torch.int64), N).reshape(-1) - 1)
+        if S is None:
+            r_rep = _rep_n(reward_local.reshape(-1, 1), N).reshape(-1)
+            nd_rep = -(_rep_n(done.reshape(-1, 1).to(torch.int64), N).reshape(-1) - 1)
+            s_n_rep, s_others_rep, s_m_rep = _rep_n(one, N), _rep_n(others, N), rep_m(one)
+        else:
+            r_rep, nd_rep = S["r_rep"], S["nd_rep"]
+            s_n_rep, s_others_rep, s_m_rep = S["s_n_rep"], S["s_others_rep"], S["s_m_rep"]
         td_c = r_rep.to(f64) + gamma * qc_t.reshape(-1) * nd_rep
-        s_n_rep, s_others_rep, s_m_rep = _rep_n(one, N), _rep_n(others, N), rep_m(one)
         feed = {"Q_credit_td_target": td_c, "v_state_one_agent": s_n_rep, "v_goal": goals_self_rep,
-                "action_one": rep_m(actions_1hot), "v_state_m": s_m_rep, "v_state_other_agents": s_others_rep}
+                "action_one": rep_m(actions_1hot) if S is None else S["a1_rep_m"], "v_state_m": s_m_rep,
+                "v_state_other_agents": s_others_rep}
         if checkers:
             s_env_rep, ot_rep, ov_rep = rep_m(state_env), rep_m(obs_self_t), rep_m(obs_self_v)
             feed = with_env(feed, s_env_rep, ot_rep, ov_rep)
@@ -213,9 +323,13 @@ def train_step_feeds(cols, run, gamma, epsilon, env="particle", use_Q_credit=Tru
         q_cf = call(["Q_global"], feed)[0].reshape(n_steps, l_action)
     elif use_Q_credit:
         probs = call(["probs"], actor_feed(obs_others, *pol_obs))[0].repeat_interleave(N, dim=0)
-        feed = {"v_state_one_agent": rep_a(s_n_rep), "v_goal": rep_a(goals_self_rep),
-                "action_one": eye.repeat(N * N * n_steps, 1), "v_state_m": rep_a(s_m_rep),
-                "v_state_other_agents": rep_a(s_others_rep)}
+        if S is None:
+            feed = {"v_state_one_agent": rep_a(s_n_rep), "v_goal": rep_a(goals_self_rep),
+                    "action_one": eye.repeat(N * N * n_steps, 1), "v_state_m": rep_a(s_m_rep),
+                    "v_state_other_agents": rep_a(s_others_rep)}
+        else:
+            feed = {"v_state_one_agent": S["cf_s_n"], "v_goal": S["cf_goals"], "action_one": S["cf_eye"], "v_state_m": S["cf_s_m"],
+                    "v_state_other_agents": S["cf_s_others"]}
         if checkers:
             feed = with_env(feed, rep_a(s_env_rep), rep_a(ot_rep), rep_a(ov_rep))
         q_cf = call(["Q_credit"], feed)[0].reshape(n_steps * N * N, l_action)

@@ -164,9 +164,110 @@ __global__ void __launch_bounds__(256) k_transitions_gather(const TransParams p)
   }
 }
 
+// ---- tiling: the n x n credit repeats and the n x n x l_action counterfactual tiling of train_step ------------------------------
+// (alg_credit.py:614-658 `np.repeat(np.reshape(x, [n_steps, n, d]), n, axis=0)` / `np.repeat(x, n, axis=0)`; :730-751 the same
+// repeated l_action times against np.tile(np.eye(l_action)); process_actions / process_global_state :406-443, :528-557 with their
+// `np.arange(N) != n` selections.)  Every output is "destination row r <- source row f(r)", f built from divisions and remainders of
+// r; up to 16 outputs per launch.
+struct TileCol {
+  void *dst;
+  const void *src;
+  unsigned long long n_rows;      // destination rows
+  uint32_t epr;                   // elements per row
+  uint32_t kind;                  // CM3_TILE_*
+  uint32_t es;                    // bytes per SOURCE element for CM3_TILE_COPY (1, 4, 8)
+  uint32_t div0, mod0, mul0, div1, mod1, mul1;   // source row = ((r / div0) % mod0) * mul0 + ((r / div1) % mod1) * mul1   (mod 0: no remainder)
+  uint32_t oth_n, oth_divq, oth_divn;            // oth_n = N > 0: source row = (r / divq) * N + j, j = k + (k >= n), k = r % (N - 1), n = (r / divn) % N
+};
+struct TileCols {
+  int n;
+  TileCol c[kMaxRowCols];
+};
+
+__global__ void __launch_bounds__(256) k_rows_tile(const TileCols a) {
+  const TileCol &c = a.c[blockIdx.y];
+  const size_t total = (size_t)c.n_rows * c.epr, stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+    const size_t r = g / c.epr;
+    const uint32_t e = (uint32_t)(g - r * c.epr);
+    size_t s;
+    if (c.oth_n) {
+      const uint32_t k = (uint32_t)(r % (c.oth_n - 1)), n = (uint32_t)((r / c.oth_divn) % c.oth_n);
+      s = (r / c.oth_divq) * c.oth_n + k + (k >= n ? 1u : 0u);
+    } else {
+      size_t q0 = r / c.div0, q1 = r / c.div1;
+      if (c.mod0) q0 %= c.mod0;
+      if (c.mod1) q1 %= c.mod1;
+      s = q0 * c.mul0 + q1 * c.mul1;
+    }
+    switch (c.kind) {
+      case CM3_TILE_COPY:
+        if (c.es == 4)
+          reinterpret_cast<uint32_t *>(c.dst)[g] = reinterpret_cast<const uint32_t *>(c.src)[s * c.epr + e];
+        else if (c.es == 8)
+          reinterpret_cast<uint64_t *>(c.dst)[g] = reinterpret_cast<const uint64_t *>(c.src)[s * c.epr + e];
+        else
+          reinterpret_cast<uint8_t *>(c.dst)[g] = reinterpret_cast<const uint8_t *>(c.src)[s * c.epr + e];
+        break;
+      case CM3_TILE_F32_TO_F64:
+        reinterpret_cast<double *>(c.dst)[g] = (double)reinterpret_cast<const float *>(c.src)[s * c.epr + e];
+        break;
+      case CM3_TILE_ONEHOT_I64:
+        reinterpret_cast<int64_t *>(c.dst)[g] = reinterpret_cast<const int32_t *>(c.src)[s] == (int32_t)e ? 1 : 0;
+        break;
+      case CM3_TILE_ONEHOT_F64:
+        reinterpret_cast<double *>(c.dst)[g] = reinterpret_cast<const int32_t *>(c.src)[s] == (int32_t)e ? 1.0 : 0.0;
+        break;
+      case CM3_TILE_EYE_F64:
+        reinterpret_cast<double *>(c.dst)[g] = (uint32_t)(r % c.epr) == e ? 1.0 : 0.0;
+        break;
+      default:   // CM3_TILE_NOT_I64: 1 - (byte != 0)   ("if true, then 0, else 1", alg_credit.py:590)
+        reinterpret_cast<int64_t *>(c.dst)[g] = reinterpret_cast<const uint8_t *>(c.src)[s * c.epr + e] ? 0 : 1;
+        break;
+    }
+  }
+}
+
 }  // namespace cm3
 
 extern "C" {
+int cm3_rows_tile(const cm3_tile_col *cols, int32_t n_cols, void *stream) {
+  using namespace cm3;
+  CM3_REQUIRE(cols && n_cols >= 1 && n_cols <= kMaxRowCols, "rows_tile: 1..%d columns", kMaxRowCols);
+  TileCols a;
+  memset(&a, 0, sizeof(a));
+  a.n = n_cols;
+  size_t most = 0;
+  for (int k = 0; k < n_cols; ++k) {
+    const cm3_tile_col &q = cols[k];
+    CM3_REQUIRE(q.dst && (q.src || q.kind == CM3_TILE_EYE_F64), "rows_tile: column %d is null", k);
+    CM3_REQUIRE(q.kind >= CM3_TILE_COPY && q.kind <= CM3_TILE_NOT_I64, "rows_tile: column %d: unknown kind %d", k, (int)q.kind);
+    CM3_REQUIRE(q.elems_per_row >= 1 && q.n_rows >= 0, "rows_tile: column %d: empty rows", k);
+    CM3_REQUIRE(q.kind != CM3_TILE_COPY || q.elem_bytes == 1 || q.elem_bytes == 4 || q.elem_bytes == 8,
+                "rows_tile: column %d: elem_bytes must be 1, 4 or 8", k);
+    CM3_REQUIRE(q.others_n == 0 || (q.others_n >= 2 && q.others_divq >= 1 && q.others_divn >= 1), "rows_tile: column %d: bad others spec", k);
+    CM3_REQUIRE(q.others_n != 0 || (q.div[0] >= 1 && q.div[1] >= 1), "rows_tile: column %d: divisors must be >= 1", k);
+    TileCol &c = a.c[k];
+    c.dst = q.dst;
+    c.src = q.src;
+    c.n_rows = (unsigned long long)q.n_rows;
+    c.epr = q.elems_per_row;
+    c.kind = q.kind;
+    c.es = q.elem_bytes;
+    c.div0 = q.div[0]; c.mod0 = q.mod[0]; c.mul0 = q.mul[0];
+    c.div1 = q.div[1]; c.mod1 = q.mod[1]; c.mul1 = q.mul[1];
+    c.oth_n = q.others_n; c.oth_divq = q.others_divq; c.oth_divn = q.others_divn;
+    const size_t total = (size_t)q.n_rows * q.elems_per_row;
+    most = total > most ? total : most;
+  }
+  if (most == 0) return CM3_OK;
+  size_t blocks = (most + 255) / 256;
+  blocks = blocks > 2048 ? 2048 : blocks;
+  hipLaunchKernelGGL(k_rows_tile, dim3((unsigned)blocks, (unsigned)n_cols), dim3(256), 0, (hipStream_t)stream, a);
+  CM3_HIP_CHECK(hipGetLastError());
+  return CM3_OK;
+}
+
 int cm3_rows_scatter(const cm3_row_cols *cols, int64_t n_rows, const int64_t *dst_row, int64_t ring_start, int64_t ring_size,
                      void *stream) {
   using namespace cm3;

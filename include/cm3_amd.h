@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define CM3_ABI_VERSION 6   /* 6: cm3_policy_force_row_tiles, cm3_rows_scatter / cm3_rows_gather / cm3_transitions_gather_f32 (round 5).
+#define CM3_ABI_VERSION 6   /* 6: cm3_policy_force_row_tiles, cm3_rows_scatter / cm3_rows_gather / cm3_rows_tile / cm3_transitions_gather_f32 (round 5).
                                5: the in-kernel ACTION STREAM of the particle kernels and the actors' sampling uniforms became two stages
                                (Philox4x32-10 block per (seed, global env id, call) + fmix32((word ^ step) + episode * 0x9E3779B1);
                                csrc/philox.h, oracle/philox.py) -- a given (seed, env, episode, step, agent) draws a DIFFERENT action
@@ -561,6 +561,31 @@ int cm3_rows_scatter(const cm3_row_cols *cols, int64_t n_rows, const int64_t *ds
                      void *stream);
 /* dst[k][b] = src[k][src_row[b]] (replay_buffer.py:28-37 sample_batch: the sampled transitions as contiguous columns). */
 int cm3_rows_gather(const cm3_row_cols *cols, int64_t n_rows, const int64_t *src_row, void *stream);
+
+/* Tiling of per-agent rows into the feeds of the reference's train_step (ABI 6): process_actions / process_global_state
+ * (alg/alg_credit.py:406-443, :528-557), the n x n credit repeats (:614-658) and the n x n x l_action counterfactual tiling
+ * (:730-751).  Every output column is "destination row r <- source row f(r)":
+ *   others_n == 0:  f(r) = ((r / div[0]) % mod[0]) * mul[0] + ((r / div[1]) % mod[1]) * mul[1]      (mod 0 = no remainder taken)
+ *   others_n == N:  f(r) = (r / others_divq) * N + j,  j = k + (k >= n),  k = r % (N - 1),  n = (r / others_divn) % N
+ *                   (the reference's `x[:, np.arange(N) != n]` selections, whatever repeats sit around them)
+ * and what is written per element depends on `kind`.  Up to 16 columns in ONE launch. */
+#define CM3_TILE_COPY 0         /* elements of elem_bytes (1, 4, 8) copied */
+#define CM3_TILE_F32_TO_F64 1   /* float -> double (the reference's float64 np.zeros targets) */
+#define CM3_TILE_ONEHOT_I64 2   /* source rows are ONE int32 each; destination rows elems_per_row int64: 1 at the value's index */
+#define CM3_TILE_ONEHOT_F64 3   /* ... as double */
+#define CM3_TILE_EYE_F64 4      /* np.tile(np.eye(elems_per_row)): row r has its 1.0 at r % elems_per_row (src unused) */
+#define CM3_TILE_NOT_I64 5      /* int64 1 - (byte != 0):  -(done.astype(int) - 1), alg_credit.py:590 */
+typedef struct cm3_tile_col {
+  void *dst;
+  const void *src;
+  int64_t n_rows;           /* destination rows */
+  uint32_t elems_per_row;   /* destination (= source, except the one-hot / eye kinds) elements per row */
+  uint32_t kind;            /* CM3_TILE_* */
+  uint32_t elem_bytes;      /* CM3_TILE_COPY only */
+  uint32_t others_n, others_divq, others_divn;
+  uint32_t div[2], mod[2], mul[2];
+} cm3_tile_col;
+int cm3_rows_tile(const cm3_tile_col *cols, int32_t n_cols, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Measurement and launch plumbing

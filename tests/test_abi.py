@@ -37,7 +37,7 @@ STRUCTS = {"cm3_particle_desc": "ParticleDesc", "cm3_particle_bufs": "ParticleBu
            "cm3_actor_particle_desc": "ActorParticleDesc", "cm3_actor_particle_weights": "ActorParticleWeights",
            "cm3_actor_particle_bufs": "ActorParticleBufs", "cm3_actor_checkers_desc": "ActorCheckersDesc",
            "cm3_actor_checkers_weights": "ActorCheckersWeights", "cm3_actor_checkers_bufs": "ActorCheckersBufs",
-           "cm3_copy_shift": "CopyShift", "cm3_transition_cols": "TransitionCols", "cm3_row_cols": "RowCols"}
+           "cm3_copy_shift": "CopyShift", "cm3_transition_cols": "TransitionCols", "cm3_row_cols": "RowCols", "cm3_tile_col": "TileCol"}
 
 
 def test_struct_layouts_match_header(built, tmp_path):

@@ -133,3 +133,64 @@ def test_train_step_feeds_equal_the_real_train_step(tag):
             assert np.array_equal(got, want), (c, ops, k)
             n_arrays += 1
     assert n_arrays >= 30
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("source", ["golden_n4", "rollout_n4", "rollout_n8", "rollout_n2"])
+def test_device_tiling_equals_the_torch_composition(source):
+    """train_step_feeds with the static feeds from two launches of cm3_rows_tile (float32 columns on the GPU: process_actions /
+    process_global_state, the n x n credit repeats, the n x n x l_action counterfactual tiling) against the torch composition that
+    tests above pin to the arrays the REAL reference train_step fed: every feed of every sess.run, values, shapes and dtypes."""
+    import json
+    from cm3_amd import batch as BR
+    from tests.helpers import GOLDEN, load_cfg
+    dev = "cuda:0"
+    if source == "golden_n4":
+        z = np.load(os.path.join(GOLDEN, "trainstep_particle_n4.npz"))
+        cols = {k[3:]: torch.as_tensor(z[k]).to(dev) for k in z.files if k.startswith("in_")}
+        cols = {k: (v.to(torch.float32) if v.dtype == torch.float64 else v) for k, v in cols.items()}
+    else:
+        from cm3_amd.particle import VecParticleEnv
+        from cm3_amd.rollout import ParticleRollout
+        N = int(source[-1])
+        cfg = {8: "particle_merge8.json", 4: "particle_stage2_cross.json", 2: "particle_stage2_merge.json"}[N]
+        env = VecParticleEnv(load_cfg(cfg), N, 0.2, 33, 64, device=dev, dtype=torch.float32, auto_reset=True, seed=9)
+        env.reset()
+        ro = ParticleRollout(env, n_ticks=40, use_graph=False).collect()
+        cols = ro.sample_batch(333, generator=torch.Generator(device=dev).manual_seed(2), numpy=False)
+        ro.close()
+    N = cols["v_global"].shape[1]
+
+    def make_run():
+        g = torch.Generator(device=dev).manual_seed(5)
+
+        def run(ops, feed):
+            rows = max([v.shape[0] for v in feed.values() if torch.is_tensor(v) and v.dim() > 0] or [1])
+            outs = []
+            for op in ops:
+                if op.endswith("_op") or op == "list_update_target_ops":
+                    outs.append(None)
+                elif op == "action_samples_target":
+                    outs.append(torch.randint(0, 5, (cols["v_global"].shape[0] * N,), generator=g, device=dev))
+                elif op == "probs":
+                    outs.append(torch.rand(rows, 5, generator=g, device=dev, dtype=torch.float64))
+                elif op == "Q_credit":
+                    outs.append(torch.rand(rows, generator=g, device=dev, dtype=torch.float64))
+                else:
+                    outs.append(torch.rand(rows, generator=g, device=dev, dtype=torch.float64))
+            return outs
+        return run
+    a = BR.train_step_feeds(cols, make_run(), 0.99, 0.1, device_tiling=True)
+    b = BR.train_step_feeds(cols, make_run(), 0.99, 0.1, device_tiling=False)
+    assert [c[0] for c in a] == [c[0] for c in b] and len(a) >= 9
+    n = 0
+    for (ops, fa), (_, fb) in zip(a, b):
+        assert sorted(fa) == sorted(fb), ops
+        for k in fb:
+            if torch.is_tensor(fb[k]):
+                assert fa[k].dtype == fb[k].dtype and fa[k].shape == fb[k].shape, (ops, k, fa[k].dtype, fb[k].dtype, fa[k].shape, fb[k].shape)
+                assert torch.equal(fa[k], fb[k]), (ops, k)
+                n += 1
+            else:
+                assert fa[k] == fb[k]
+    assert n >= 40
