@@ -770,7 +770,9 @@ def extras_summary(out):
         s["policy_us_per_tick"] = {prec: {m: _sig(v.get("us_per_tick", v.get("avg_launch_us")), 5) for m, v in sub.items() if isinstance(v, dict)}
                                    for prec, sub in pr.items() if prec in ("f32", "f16x3") and isinstance(sub, dict)}
     if isinstance(out.get("host_side"), dict):
-        s["host_side"] = out["host_side"]
+        s["host_side_cols"] = ["ms", "ratio_to_copy_rate_floor"]
+        s["host_side"] = {k: [_sig(v["ms"], 4), _sig(v.get("ratio_to_floor", 0.0), 3)] for k, v in out["host_side"].items()
+                          if isinstance(v, dict) and "ms" in v}
     while len(json.dumps(s)) >= LINE_LIMIT and s.get("sweep"):
         s["sweep"].pop()
     return s
@@ -1336,6 +1338,19 @@ def main():
                     point(Es, "in-place, eager launches", st, EP_TICKS * (10 if log2e <= 16 else 3), per_tick(Es),
                           "in place, in-kernel actions, 33 eager launches per enqueue (no hipGraph)")
             out["sweep"] = sweep
+        if extras and args.workload == "c2" and not args.envs_per_gpu:
+            # the rows SURVEY.md section 8(f2)-(f4) on one collection phase of this workload: transition export, train_step feeds,
+            # replay rings, batched evaluation -- each with the bytes it moves and the time those take at the measured copy rate
+            try:
+                if stepper is not None:
+                    stepper.close()
+                    stepper = None
+                torch.cuda.empty_cache()
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import host_side_timing
+                out["host_side"] = host_side_timing.measure(device, copy_gbps=bw_copy)
+            except Exception as exc:                     # (an extra: never costs the run its headline)
+                out["host_side"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_checkers(cfg) if kind == "checkers" else cpu_baseline(cfg, N)
     if rank == 0:

@@ -23,13 +23,14 @@ struct RowCols {
   uint32_t unit[kMaxRowCols];   // bytes per lane: 16, 8, 4 or 1 (largest that divides the row size and both base addresses)
 };
 
-template <typename U> __device__ __forceinline__ void copy_units(void *dst, const void *src, size_t n_rows, uint32_t units_per_row,
-                                                                 const int64_t *dst_row, const int64_t *src_row, int64_t ring_start,
-                                                                 int64_t ring_size) {
-  const size_t total = n_rows * units_per_row, stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
-    const size_t b = g / units_per_row;
-    const uint32_t u = (uint32_t)(g - b * units_per_row);
+// (I = uint32_t whenever the unit count fits: a 64-bit division per unit costs more than the copy)
+template <typename U, typename I> __device__ __forceinline__ void copy_units(void *dst, const void *src, size_t n_rows, uint32_t units_per_row,
+                                                                             const int64_t *dst_row, const int64_t *src_row,
+                                                                             int64_t ring_start, int64_t ring_size) {
+  const I total = (I)(n_rows * units_per_row), stride = (I)((size_t)gridDim.x * blockDim.x);
+  for (I g = (I)((size_t)blockIdx.x * blockDim.x + threadIdx.x); g < total; g += stride) {
+    const I b = g / (I)units_per_row;
+    const uint32_t u = (uint32_t)(g - b * (I)units_per_row);
     int64_t d = (int64_t)b, s = (int64_t)b;
     if (dst_row) {
       d = dst_row[b];
@@ -43,18 +44,18 @@ template <typename U> __device__ __forceinline__ void copy_units(void *dst, cons
   }
 }
 
-__global__ void __launch_bounds__(256) k_rows_copy(const RowCols c, size_t n_rows, const int64_t *dst_row, const int64_t *src_row,
-                                                   int64_t ring_start, int64_t ring_size) {
+template <typename I> __global__ void __launch_bounds__(256) k_rows_copy(const RowCols c, size_t n_rows, const int64_t *dst_row,
+                                                                         const int64_t *src_row, int64_t ring_start, int64_t ring_size) {
   const int col = blockIdx.y;
   const uint32_t unit = c.unit[col], upr = c.row_bytes[col] / unit;
   if (unit == 16)
-    copy_units<uint4>(c.dst[col], c.src[col], n_rows, upr, dst_row, src_row, ring_start, ring_size);
+    copy_units<uint4, I>(c.dst[col], c.src[col], n_rows, upr, dst_row, src_row, ring_start, ring_size);
   else if (unit == 8)
-    copy_units<uint2>(c.dst[col], c.src[col], n_rows, upr, dst_row, src_row, ring_start, ring_size);
+    copy_units<uint2, I>(c.dst[col], c.src[col], n_rows, upr, dst_row, src_row, ring_start, ring_size);
   else if (unit == 4)
-    copy_units<uint32_t>(c.dst[col], c.src[col], n_rows, upr, dst_row, src_row, ring_start, ring_size);
+    copy_units<uint32_t, I>(c.dst[col], c.src[col], n_rows, upr, dst_row, src_row, ring_start, ring_size);
   else
-    copy_units<uint8_t>(c.dst[col], c.src[col], n_rows, upr, dst_row, src_row, ring_start, ring_size);
+    copy_units<uint8_t, I>(c.dst[col], c.src[col], n_rows, upr, dst_row, src_row, ring_start, ring_size);
 }
 
 static int rows_copy(const cm3_row_cols *cols, int64_t n_rows, const int64_t *dst_row, const int64_t *src_row, int64_t ring_start,
@@ -78,8 +79,12 @@ static int rows_copy(const cm3_row_cols *cols, int64_t n_rows, const int64_t *ds
   }
   size_t blocks = (most + 255) / 256;
   blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
-  hipLaunchKernelGGL(k_rows_copy, dim3((unsigned)blocks, (unsigned)c.n), dim3(256), 0, s, c, (size_t)n_rows, dst_row, src_row, ring_start,
-                     ring_size);
+  if (most + blocks * 256 < (size_t)1 << 32)
+    hipLaunchKernelGGL(k_rows_copy<uint32_t>, dim3((unsigned)blocks, (unsigned)c.n), dim3(256), 0, s, c, (size_t)n_rows, dst_row, src_row,
+                       ring_start, ring_size);
+  else
+    hipLaunchKernelGGL(k_rows_copy<size_t>, dim3((unsigned)blocks, (unsigned)c.n), dim3(256), 0, s, c, (size_t)n_rows, dst_row, src_row,
+                       ring_start, ring_size);
   CM3_HIP_CHECK(hipGetLastError());
   return CM3_OK;
 }
@@ -102,65 +107,65 @@ template <typename T> __device__ __forceinline__ const T *tick_of(const T *base,
   return reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + stride * (size_t)t);
 }
 
-// One wave per transition at a time; lane u copies unit u of the transition's record:
+// A lane per (transition, unit): unit u of transition b's record is
 //   [0, N)                state row of agent u          16 B      state[t][u][e]            -> o_state[b][u]
 //   [N, 2N)               next state                    16 B      done ? term_state[t] : state[t + 1]
 //   [2N, 2N + NV)         obs_others, NV = N L / 4      16 B      obs[t][e][...]            -> o_obs[b][...]   (contiguous both sides)
 //   [.., + NV)            next obs_others               16 B      done ? term_obs[t] : obs[t + 1]
 //   then N goal pairs (8 B), N actions, N local rewards (4 B), the reward (4 B) and done (1 B)
+// (round 5, first form: a wave per transition looping over its units -- 46 of 64 lanes busy at N = 4 and one dependent chain of
+// index -> done -> data loads per wave at a time: 1.23 ms for the 1.35 M transitions of a C2 phase, hardly faster than the torch
+// composition; flattened, every lane has its own chain in flight)
 __global__ void __launch_bounds__(256) k_transitions_gather(const TransParams p) {
-  const int lane = threadIdx.x & 63;
-  const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
   const int N = p.N, NV = N * p.L / 4;
-  const int U = 2 * N + 2 * NV + 3 * N + 2;
-  for (size_t b = wave; b < p.n; b += n_waves) {
-    const int64_t t = p.tt[b];
-    const size_t e = (size_t)p.ee[b];
+  const uint32_t U = (uint32_t)(2 * N + 2 * NV + 3 * N + 2);
+  const size_t total = p.n * U, stride = (size_t)gridDim.x * blockDim.x;
+  const bool small = total + stride < ((size_t)1 << 32);
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+    const size_t b = small ? (size_t)((uint32_t)g / U) : g / U;
+    int v = (int)(g - b * U);
+    // (tt == NULL: every transition of the trajectory in time-major order, b = t E + e -- no index arrays to build or read)
+    const int64_t t = p.tt ? p.tt[b] : (int64_t)(small ? (size_t)((uint32_t)b / (uint32_t)p.E) : b / p.E);
+    const size_t e = p.tt ? (size_t)p.ee[b] : b - (size_t)t * p.E;
     const bool d = tick_of(p.done, p.st_done, t)[e] != 0;
-    const bool term = d && p.term_state != nullptr;
-    for (int u = lane; u < U; u += 64) {
-      int v = u;
-      if (v < 2 * N) {
-        const bool nxt = v >= N;
-        const int i = nxt ? v - N : v;
-        const float *src = nxt ? (term ? tick_of(p.term_state, p.st_term_state, t) : tick_of(p.state, p.st_state, t + 1))
-                               : tick_of(p.state, p.st_state, t);
-        const float4 x = reinterpret_cast<const float4 *>(src)[(size_t)i * p.E + e];
-        reinterpret_cast<float4 *>(nxt ? p.o_next_state : p.o_state)[b * N + i] = x;
-        continue;
-      }
-      v -= 2 * N;
-      if (v < 2 * NV) {
-        const bool nxt = v >= NV;
-        const int k = nxt ? v - NV : v;
-        const float *src = nxt ? ((d && p.term_obs) ? tick_of(p.term_obs, p.st_term_obs, t) : tick_of(p.obs, p.st_obs, t + 1))
-                               : tick_of(p.obs, p.st_obs, t);
-        const float4 x = reinterpret_cast<const float4 *>(src)[e * NV + k];
-        reinterpret_cast<float4 *>(nxt ? p.o_next_obs : p.o_obs)[b * NV + k] = x;
-        continue;
-      }
-      v -= 2 * NV;
-      if (v < N) {   // goals [slot][N][E][2]: the slot that last wrote this env's landmarks (goal_slot), or the only one (stride 0)
-        const int64_t gs = p.goal_slot ? (int64_t)tick_of(p.goal_slot, p.st_goal_slot, t)[e] : t;
-        reinterpret_cast<float2 *>(p.o_goals)[b * N + v] = reinterpret_cast<const float2 *>(tick_of(p.goals, p.st_goals, gs))[(size_t)v * p.E + e];
-        continue;
-      }
-      v -= N;
-      if (v < N) {
-        p.o_actions[b * N + v] = tick_of(p.actions, p.st_actions, t)[e * N + v];
-        continue;
-      }
-      v -= N;
-      if (v < N) {
-        p.o_reward_n[b * N + v] = tick_of(p.reward_n, p.st_reward_n, t)[e * N + v];
-        continue;
-      }
-      v -= N;
-      if (v == 0)
-        p.o_reward[b] = tick_of(p.reward, p.st_reward, t)[e];
-      else
-        p.o_done[b] = d ? 1 : 0;
+    if (v < 2 * N) {
+      const bool nxt = v >= N;
+      const int i = nxt ? v - N : v;
+      const float *src = nxt ? ((d && p.term_state) ? tick_of(p.term_state, p.st_term_state, t) : tick_of(p.state, p.st_state, t + 1))
+                             : tick_of(p.state, p.st_state, t);
+      reinterpret_cast<float4 *>(nxt ? p.o_next_state : p.o_state)[b * N + i] = reinterpret_cast<const float4 *>(src)[(size_t)i * p.E + e];
+      continue;
     }
+    v -= 2 * N;
+    if (v < 2 * NV) {
+      const bool nxt = v >= NV;
+      const int k = nxt ? v - NV : v;
+      const float *src = nxt ? ((d && p.term_obs) ? tick_of(p.term_obs, p.st_term_obs, t) : tick_of(p.obs, p.st_obs, t + 1))
+                             : tick_of(p.obs, p.st_obs, t);
+      reinterpret_cast<float4 *>(nxt ? p.o_next_obs : p.o_obs)[b * NV + k] = reinterpret_cast<const float4 *>(src)[e * NV + k];
+      continue;
+    }
+    v -= 2 * NV;
+    if (v < N) {   // goals [slot][N][E][2]: the slot that last wrote this env's landmarks (goal_slot), or the only one (stride 0)
+      const int64_t gs = p.goal_slot ? (int64_t)tick_of(p.goal_slot, p.st_goal_slot, t)[e] : t;
+      reinterpret_cast<float2 *>(p.o_goals)[b * N + v] = reinterpret_cast<const float2 *>(tick_of(p.goals, p.st_goals, gs))[(size_t)v * p.E + e];
+      continue;
+    }
+    v -= N;
+    if (v < N) {
+      p.o_actions[b * N + v] = tick_of(p.actions, p.st_actions, t)[e * N + v];
+      continue;
+    }
+    v -= N;
+    if (v < N) {
+      p.o_reward_n[b * N + v] = tick_of(p.reward_n, p.st_reward_n, t)[e * N + v];
+      continue;
+    }
+    v -= N;
+    if (v == 0)
+      p.o_reward[b] = tick_of(p.reward, p.st_reward, t)[e];
+    else
+      p.o_done[b] = d ? 1 : 0;
   }
 }
 
@@ -184,18 +189,18 @@ struct TileCols {
   TileCol c[kMaxRowCols];
 };
 
-__global__ void __launch_bounds__(256) k_rows_tile(const TileCols a) {
+template <typename I> __global__ void __launch_bounds__(256) k_rows_tile(const TileCols a) {
   const TileCol &c = a.c[blockIdx.y];
-  const size_t total = (size_t)c.n_rows * c.epr, stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
-    const size_t r = g / c.epr;
-    const uint32_t e = (uint32_t)(g - r * c.epr);
-    size_t s;
+  const I total = (I)((size_t)c.n_rows * c.epr), stride = (I)((size_t)gridDim.x * blockDim.x);
+  for (I g = (I)((size_t)blockIdx.x * blockDim.x + threadIdx.x); g < total; g += stride) {
+    const I r = g / (I)c.epr;
+    const uint32_t e = (uint32_t)(g - r * (I)c.epr);
+    I s;
     if (c.oth_n) {
-      const uint32_t k = (uint32_t)(r % (c.oth_n - 1)), n = (uint32_t)((r / c.oth_divn) % c.oth_n);
-      s = (r / c.oth_divq) * c.oth_n + k + (k >= n ? 1u : 0u);
+      const uint32_t k = (uint32_t)(r % (I)(c.oth_n - 1)), n = (uint32_t)((r / (I)c.oth_divn) % (I)c.oth_n);
+      s = (r / (I)c.oth_divq) * (I)c.oth_n + k + (k >= n ? 1u : 0u);
     } else {
-      size_t q0 = r / c.div0, q1 = r / c.div1;
+      I q0 = r / (I)c.div0, q1 = r / (I)c.div1;
       if (c.mod0) q0 %= c.mod0;
       if (c.mod1) q1 %= c.mod1;
       s = q0 * c.mul0 + q1 * c.mul1;
@@ -263,7 +268,10 @@ int cm3_rows_tile(const cm3_tile_col *cols, int32_t n_cols, void *stream) {
   if (most == 0) return CM3_OK;
   size_t blocks = (most + 255) / 256;
   blocks = blocks > 2048 ? 2048 : blocks;
-  hipLaunchKernelGGL(k_rows_tile, dim3((unsigned)blocks, (unsigned)n_cols), dim3(256), 0, (hipStream_t)stream, a);
+  if (most + blocks * 256 < (size_t)1 << 32)
+    hipLaunchKernelGGL(k_rows_tile<uint32_t>, dim3((unsigned)blocks, (unsigned)n_cols), dim3(256), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(k_rows_tile<size_t>, dim3((unsigned)blocks, (unsigned)n_cols), dim3(256), 0, (hipStream_t)stream, a);
   CM3_HIP_CHECK(hipGetLastError());
   return CM3_OK;
 }
@@ -286,7 +294,7 @@ int cm3_transitions_gather_f32(const cm3_particle_desc *desc, const cm3_particle
                                size_t goal_slot_stride, const int64_t *tt, const int64_t *ee, int64_t n,
                                const cm3_transition_cols *out, void *stream) {
   using namespace cm3;
-  CM3_REQUIRE(desc && traj && out && (n == 0 || (tt && ee)), "null argument");
+  CM3_REQUIRE(desc && traj && out && ((tt == nullptr) == (ee == nullptr)), "null argument (tt and ee: both or neither)");
   CM3_REQUIRE(n >= 0, "n must be >= 0");
   CM3_REQUIRE(desc->n_agents >= 1 && desc->n_agents <= CM3_MAX_AGENTS, "n_agents out of range");
   CM3_REQUIRE(traj->state && traj->obs_others && traj->actions && traj->reward_n && traj->reward && traj->done && traj->goals,
@@ -323,8 +331,9 @@ int cm3_transitions_gather_f32(const cm3_particle_desc *desc, const cm3_particle
   p.E = (size_t)desc->n_envs;
   p.N = desc->n_agents;
   p.L = 4 * (desc->n_agents > 1 ? desc->n_agents - 1 : 1);
-  size_t blocks = ((size_t)n + 3) / 4;     // four waves per workgroup, one transition per wave and trip
-  blocks = blocks > 8192 ? 8192 : blocks;
+  const size_t units = (size_t)n * (size_t)(2 * p.N + 2 * (p.N * p.L / 4) + 3 * p.N + 2);
+  size_t blocks = (units + 255) / 256;
+  blocks = blocks > 16384 ? 16384 : blocks;
   hipLaunchKernelGGL(k_transitions_gather, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
   CM3_HIP_CHECK(hipGetLastError());
   return CM3_OK;

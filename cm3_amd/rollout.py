@@ -619,14 +619,16 @@ class ParticleRollout(object):
         ones), each equal to np.stack(batch[:, k]) in alg_credit.process_batch (alg_credit.py:458-470).
         float32 trajectories: ONE launch of cm3_transitions_gather_f32 (csrc/batch.hip) fills all columns; the float64 parity
         instantiation goes through the torch composition below (as_reference_batch_torch: same values, ~25 launches)."""
-        if tt is None:
+        everything = tt is None and self.auto_reset and self.state.dtype == torch.float32     # (all T x E transitions are valid)
+        if tt is None and not everything:
             tt, ee = self.valid_indices()
-        tt = torch.as_tensor(tt, device=self.env.device, dtype=torch.long).contiguous()
-        ee = torch.as_tensor(ee, device=self.env.device, dtype=torch.long).contiguous()
+        if not everything:
+            tt = torch.as_tensor(tt, device=self.env.device, dtype=torch.long).contiguous()
+            ee = torch.as_tensor(ee, device=self.env.device, dtype=torch.long).contiguous()
         if self.state.dtype != torch.float32:
             return self.as_reference_batch_torch(tt, ee, numpy)
         env = self.env
-        B, N, L, dev = tt.numel(), env.n, env.L, env.device
+        B, N, L, dev = (self.T * env.E if everything else tt.numel()), env.n, env.L, env.device
         f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)      # noqa: E731
         state, obs, nstate, nobs = f(B, N, 4), f(B, N, L), f(B, N, 4), f(B, N, L)
         reward, reward_n, goals = f(B), f(B, N), f(B, N, 2)
@@ -644,7 +646,8 @@ class ParticleRollout(object):
                                                                             reward.data_ptr(), reward_n.data_ptr())
         out.next_state, out.next_obs_others, out.done, out.goals = nstate.data_ptr(), nobs.data_ptr(), done.data_ptr(), goals.data_ptr()
         _lib.check(self._lib.cm3_transitions_gather_f32(ctypes.byref(env._desc), ctypes.byref(traj), _lib.ptr(goal_slot), gs_stride,
-                                                        tt.data_ptr(), ee.data_ptr(), B, ctypes.byref(out), env._stream()))
+                                                        None if everything else tt.data_ptr(), None if everything else ee.data_ptr(), B,
+                                                        ctypes.byref(out), env._stream()))
         cols = dict(v_global=state, obs_others=obs, v_local=state, actions=actions, reward=reward, reward_local=reward_n,
                     v_global_next=nstate, obs_others_next=nobs, v_local_next=nstate, done=done, goals=goals)
         if numpy:

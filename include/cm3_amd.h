@@ -541,7 +541,8 @@ typedef struct cm3_transition_cols {
  * [T+1][N][E][4], obs_others [T+1][E][N][L], actions / reward_n [T][E][N], reward / done [T][E], optional term_* [T][...]) in ONE
  * launch.  goals: traj->goals with goals_stride bytes per slot (stride 0: one live array); goal_slot (optional, int32 with
  * goal_slot_stride bytes per tick, [T+1][E]) names the slot that holds the goals in effect at (t, e) -- sparse goal slots; NULL:
- * slot t itself.  desc supplies n_envs / n_agents only.  Replaces alg/replay_buffer.py's list-of-arrays + np.stack(batch[:, k]). */
+ * slot t itself.  tt == ee == NULL: ALL transitions of ticks [0, n / E) in time-major order (b = t E + e).  desc supplies n_envs /
+ * n_agents only.  Replaces alg/replay_buffer.py's list-of-arrays + np.stack(batch[:, k]). */
 int cm3_transitions_gather_f32(const cm3_particle_desc *desc, const cm3_particle_traj *traj, const int32_t *goal_slot,
                                size_t goal_slot_stride, const int64_t *tt, const int64_t *ee, int64_t n,
                                const cm3_transition_cols *out, void *stream);

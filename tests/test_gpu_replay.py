@@ -130,6 +130,10 @@ def test_single_launch_transition_export_equals_the_torch_composition(N, cfg, kw
     for k in b:
         assert torch.equal(a[k], b[k]), k
     assert a["v_global"].data_ptr() == a["v_local"].data_ptr()     # the reference stores the same array twice (train_onpolicy.py:338)
+    a = ro.as_reference_batch(numpy=False)                         # no index arrays at all: every transition, time-major
+    b = ro.as_reference_batch_torch(tt, ee, numpy=False)
+    for k in b:
+        assert torch.equal(a[k], b[k]), k
     ro.close()
 
 

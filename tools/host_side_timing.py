@@ -72,6 +72,9 @@ def measure(device, copy_gbps=None, n_envs=4096, n_agents=4, cfg_name="particle_
     nb = _nbytes(cols)
     out["export_phase"] = rec(s, 2 * nb, "ParticleRollout.as_reference_batch(numpy=False), %d transitions: read + write of the columns"
                               % cols["reward"].shape[0], transitions=int(cols["reward"].shape[0]), column_bytes=int(nb))
+    tt_all, ee_all = ro.valid_indices()
+    s, _ = _time(lambda: ro.as_reference_batch_torch(tt_all, ee_all, numpy=False), device, reps=2, warm=1)
+    out["export_phase_torch_composition"] = rec(s, 2 * nb, "the same columns as ~25 torch indexing launches (what round 4 shipped)")
     # minibatch export: 128 transitions (batch_size of alg/config.json), as the on-policy cadence samples them
     g = torch.Generator(device=device).manual_seed(0)
     s, mb = _time(lambda: ro.sample_batch(128, generator=g, numpy=False), device, reps=20)
@@ -102,7 +105,12 @@ def measure(device, copy_gbps=None, n_envs=4096, n_agents=4, cfg_name="particle_
         s, calls = _time(lambda: B.train_step_feeds(c, run, 0.99, 0.1), device, reps=10)
         fb = sum(_nbytes(f) for _, f in calls)
         out["train_step_feeds_" + label] = rec(s, _nbytes(c) + fb, "cm3_amd.batch.train_step_feeds (process_batch, n x n credit repeats, "
-                                               "n x n x l_action counterfactual tiling) with a stand-in session", feed_bytes=int(fb), sess_runs=len(calls))
+                                               "n x n x l_action counterfactual tiling; static feeds from two cm3_rows_tile launches) with a "
+                                               "stand-in session", feed_bytes=int(fb), sess_runs=len(calls))
+        s, _ = _time(lambda: B.train_step_feeds(c, run, 0.99, 0.1, device_tiling=False), device, reps=10)
+        out["train_step_feeds_" + label + "_torch_composition"] = rec(s, _nbytes(c) + fb, "the same feeds as a composition of torch operations")
+        s, S = _time(lambda: B.particle_static_feeds_device(c), device, reps=20)
+        out["static_feeds_" + label] = rec(s, _nbytes(c) + _nbytes(S), "particle_static_feeds_device alone: 22 feed tensors, two launches")
     # (f4) replay: add the whole phase, sample 128
     cols = ro.as_reference_batch(numpy=False)
     B_all = cols["reward"].shape[0]
