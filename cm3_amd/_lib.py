@@ -98,7 +98,7 @@ class CheckersBufs(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in (
         "mask", "agents", "steps", "episode", "goals", "actions", "grid", "vec", "obs_others",
         "obs_self_t", "obs_self_v", "local_rewards", "reward", "done",
-        "term_grid", "term_vec", "term_obs_others", "term_obs_self_t", "term_obs_self_v", "goals_next")]
+        "term_grid", "term_vec", "term_obs_others", "term_obs_self_t", "term_obs_self_v", "goals_next", "action_block")]
 
 
 class CheckersTraj(ctypes.Structure):
@@ -114,7 +114,7 @@ class CheckersTraj(ctypes.Structure):
                  ("term_obs_others", c_void_p), ("term_obs_others_stride", c_size_t),
                  ("term_obs_self_t", c_void_p), ("term_obs_self_t_slot_stride", c_size_t),
                  ("term_obs_self_v", c_void_p), ("term_obs_self_v_stride", c_size_t),
-                 ("goals_slots", c_void_p), ("goals_slots_stride", c_size_t)])
+                 ("goals_slots", c_void_p), ("goals_slots_stride", c_size_t), ("action_block", c_void_p)])
 
 
 class ActorParticleDesc(ctypes.Structure):
@@ -172,6 +172,7 @@ SYMBOLS = {
     "cm3_checkers_step": (ctypes.c_int, [P(CheckersDesc), P(CheckersBufs), c_void_p]),
     "cm3_checkers_rollout": (ctypes.c_int, [P(CheckersDesc), P(CheckersTraj), c_int32, c_void_p]),
     "cm3_checkers_reset": (ctypes.c_int, [P(CheckersDesc), P(CheckersBufs), c_void_p, c_void_p]),
+    "cm3_checkers_action_blocks": (ctypes.c_int, [P(CheckersDesc), c_void_p, c_void_p]),
     "cm3_actor_particle_packed_bytes": (c_size_t, [c_int32]),
     "cm3_actor_particle_pack": (ctypes.c_int, [P(ActorParticleDesc), P(ActorParticleWeights), c_void_p, c_void_p]),
     "cm3_actor_particle_f32": (ctypes.c_int, [P(ActorParticleDesc), P(ActorParticleWeights), P(ActorParticleBufs),

@@ -78,6 +78,12 @@ class VecCheckersEnv(object):
             d.agents_r[i] = int(init["agents_r"][i]) if i < N else 0
             d.agents_c[i] = int(init["agents_c"][i]) if i < N else 0
         self._lib = _lib.lib()
+        # stage 1 of the in-kernel action stream: a Philox block per env, a constant of (seed, global env id) -- computed once here,
+        # loaded by every step launch with its state (cm3_checkers_bufs.action_block)
+        import ctypes
+        self._action_block = torch.zeros(E, 4, dtype=torch.int32, device=dev)
+        _lib.check(self._lib.cm3_checkers_action_blocks(ctypes.byref(d), self._action_block.data_ptr(),
+                                                        torch.cuda.current_stream(dev).cuda_stream))
 
     def grid_view(self, raw):
         """[..., E, grid_stride] int8 storage -> [..., E, R, C+1, 2] view without the padding bytes."""
@@ -94,6 +100,7 @@ class VecCheckersEnv(object):
         b.steps = self._steps.data_ptr()
         b.episode = self._episode.data_ptr()
         b.goals = self._goals.data_ptr()
+        b.action_block = self._action_block.data_ptr()
         for k in ("actions", "vec", "obs_others", "obs_self_v", "local_rewards", "reward", "done"):
             setattr(b, k, s[k].data_ptr())
         b.grid = s["grid_raw"].data_ptr()

@@ -35,6 +35,7 @@ struct CheckersParams {
   int32_t *steps;
   int32_t *episode;
   uint8_t *goals;
+  const uint32_t *ablock;   // optional uint32 [E][4]: stage 1 of the action stream per env (cm3_checkers_action_blocks); NULL: computed here
   int32_t *actions;
   int8_t *grid;
   int32_t *vec;
@@ -257,12 +258,16 @@ struct CkHead {
   const int32_t *steps;
   const int32_t *episode;
   const uint8_t *goals;
+  const uint32_t *ablock;
   int E;
   uint32_t flags;
+  int64_t env_id_base;     // (only read when ablock is NULL and the actions are drawn in-kernel)
+  uint64_t seed;
 };
 __device__ __forceinline__ CkHead ck_head(const CheckersParams &p) {
   CkHead h;
-  h.mask = p.mask; h.agents = p.agents; h.steps = p.steps; h.episode = p.episode; h.goals = p.goals; h.E = p.E; h.flags = p.flags;
+  h.mask = p.mask; h.agents = p.agents; h.steps = p.steps; h.episode = p.episode; h.goals = p.goals; h.ablock = p.ablock; h.E = p.E;
+  h.flags = p.flags; h.env_id_base = p.env_id_base; h.seed = p.seed;
   return h;
 }
 
@@ -304,6 +309,7 @@ template <int N> struct CkLive {
   int steps;
   uint32_t episode, episode_in;
   uint8_t goal[N];
+  uint32_t aword[N];   // stage 1 of the in-kernel action stream: this env's Philox words, one per agent (philox.h)
 };
 
 template <int N>
@@ -315,6 +321,40 @@ __device__ __forceinline__ void ck_load_env(const CkHead &p, size_t ec, CkState<
   lv.episode = 0;
   if (p.flags & (CM3_FLAG_GEN_ACTIONS | CM3_FLAG_AUTO_RESET)) lv.episode = (uint32_t)p.episode[ec];
   lv.episode_in = lv.episode;
+#pragma unroll
+  for (int i = 0; i < N; ++i) lv.aword[i] = 0u;
+  if (p.flags & CM3_FLAG_GEN_ACTIONS) {
+    // Round 5: the two-stage action stream of the particle kernels here too.  Stage 1 (a Philox block per env: a constant of
+    // (seed, global env id)) comes from the env's table -- ONE more load in the round trip of the state loads -- and only the
+    // ten-instruction counter mix of stage 2 follows them; the one-stage draw put ten Philox rounds (~550 cycles of a 4500-cycle
+    // wave at C3) behind the loads, and computing stage 1 in the prologue instead measured SLOWER in round 4 (the prologue is
+    // instruction-bound: profiles/r04_two_stage_action_stream.txt).  Without a table (ablock == NULL) the block is computed here.
+    auto put = [&](int idx, uint32_t v) {
+      if (idx < N) lv.aword[idx < N ? idx : 0] = v;
+    };
+    const uint64_t genv = (uint64_t)(p.env_id_base + (int64_t)ec);
+    if constexpr (N <= 2) {
+      uint2 w;
+      if (p.ablock) {
+        w = reinterpret_cast<const uint2 *>(p.ablock)[2 * ec];
+      } else {
+        const u32x4 b = action_block(p.seed, genv, 0u);
+        w.x = b.x;
+        w.y = b.y;
+      }
+      put(0, w.x);
+      put(1, w.y);
+    } else {
+#pragma unroll
+      for (int c = 0; c < (N + 3) / 4; ++c) {   // (agents 4 .. 7 have a block of their own: the table holds the first, the second is computed)
+        const u32x4 w = (c == 0 && p.ablock) ? *reinterpret_cast<const u32x4 *>(p.ablock + 4 * ec) : action_block(p.seed, genv, (uint32_t)c);
+        put(4 * c + 0, w.x);
+        put(4 * c + 1, w.y);
+        put(4 * c + 2, w.z);
+        put(4 * c + 3, w.w);
+      }
+    }
+  }
 }
 
 template <int N>
@@ -346,21 +386,11 @@ __device__ __forceinline__ bool ck_tick_env(const CheckersParams &p, int t, size
 #pragma unroll
   for (int i = 0; i < N; ++i) goal[i] = lv.goal[i];
   int act[N];
-  const uint64_t genv = (uint64_t)(p.env_id_base + (int64_t)ec);
   int32_t *actions_t = ck_tick_ptr(p.actions, p.st_actions, t);
   if (p.flags & CM3_FLAG_GEN_ACTIONS) {
-    uint32_t words[4 * ((N + 3) / 4)];   // (the one-stage draw: see action_words_direct in philox.h)
-#pragma unroll
-    for (int c = 0; c < (N + 3) / 4; ++c) {
-      const u32x4 w = action_words_direct(p.seed, genv, episode, (uint32_t)steps, (uint32_t)c);
-      words[4 * c + 0] = w.x;
-      words[4 * c + 1] = w.y;
-      words[4 * c + 2] = w.z;
-      words[4 * c + 3] = w.w;
-    }
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-      act[i] = rand5(words[i]);
+      act[i] = rand5(action_word(lv.aword[i], episode, (uint32_t)steps));   // stage 2 (philox.h); stage 1 came with the state loads
       if (active) {
         if constexpr (FAST) *at32<int32_t>(actions_t, ((uint32_t)e * N + i) * 4u) = act[i];
         else actions_t[e * N + i] = act[i];
@@ -1012,6 +1042,7 @@ struct CkFastKernArgs {
   const int32_t *steps;
   const int32_t *episode;
   const uint8_t *goals;
+  const uint32_t *ablock;
   int E;
   uint32_t flags;
   CheckersParams p;
@@ -1175,11 +1206,12 @@ __device__ __forceinline__ void ckf_emit_tab(const CheckersParams &p, const CkSt
 template <int N, bool FUSED, bool NT = false, int G = kCkG>
 __global__ void __launch_bounds__(256)
     k_checkers_step_fast(const uint64_t *h_mask, const uint32_t *h_agents, const int32_t *h_steps, const int32_t *h_episode,
-                         const uint8_t *h_goals, const int h_E, const uint32_t h_flags, const CheckersParams p) {
+                         const uint8_t *h_goals, const uint32_t *h_ablock, const int h_E, const uint32_t h_flags, const CheckersParams p) {
   using F = CkFast<N, G>;
   CM3_SPAN_IN();
   CkHead hd;   // leading, preloaded kernel arguments (see CkHead)
-  hd.mask = h_mask; hd.agents = h_agents; hd.steps = h_steps; hd.episode = h_episode; hd.goals = h_goals; hd.E = h_E; hd.flags = h_flags;
+  hd.mask = h_mask; hd.agents = h_agents; hd.steps = h_steps; hd.episode = h_episode; hd.goals = h_goals; hd.ablock = h_ablock; hd.E = h_E;
+  hd.flags = h_flags; hd.env_id_base = p.env_id_base; hd.seed = p.seed;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane & (F::G - 1), sub = lane / F::G;
   // 32-bit env index and byte offsets (every per-tick array below 4 GiB, checked by ck_launch): addresses are
@@ -1382,6 +1414,7 @@ static int ck_fill(const cm3_checkers_desc *d, const cm3_checkers_bufs *b, const
   p.steps = b->steps;
   p.episode = b->episode;
   p.goals = const_cast<uint8_t *>(b->goals);
+  p.ablock = b->action_block;
   p.actions = b->actions;
   p.grid = b->grid;
   p.vec = b->vec;
@@ -1428,7 +1461,7 @@ template <int N> static int ck_launch(const CheckersParams &p, bool step, hipStr
 #define CM3_LAUNCH_CKF(...)                                                                                                  \
   hipLaunchKernelGGL((k_checkers_step_fast<N, __VA_ARGS__>), dim3(fblocks), dim3(256), 0, stream, (const uint64_t *)p.mask,    \
                      (const uint32_t *)p.agents, (const int32_t *)p.steps, (const int32_t *)p.episode, (const uint8_t *)p.goals, \
-                     p.E, p.flags | xf, p)
+                     p.ablock, p.E, p.flags | xf, p)
     note_variant(step ? "k_checkers_step_fast" : "k_checkers_reset_fast", 0, N, 4, step && p.n_ticks > 1, step && nt ? 1 : 0, 0, 0, 0,
                  step ? (nt ? kCkGStream : kCkG) : 0);
     if (step && p.n_ticks > 1) {
@@ -1487,6 +1520,7 @@ static int ck_rollout(const cm3_checkers_desc *d, const cm3_checkers_traj *t, in
     b.steps = t->steps;
     b.episode = t->episode;
     b.goals = t->goals;
+    b.action_block = t->action_block;
     b.actions = (int32_t *)at(t->actions, t->actions_stride, k);
     b.grid = (int8_t *)at(t->grid, t->grid_slot_stride, k + 1);
     b.vec = (int32_t *)at(t->vec, t->vec_stride, k + 1);
@@ -1553,6 +1587,26 @@ extern "C" {
 int cm3_checkers_rollout(const cm3_checkers_desc *d, const cm3_checkers_traj *t, int32_t n_ticks, void *stream) {
   return cm3::ck_rollout(d, t, n_ticks, stream);
 }
+namespace cm3 {
+__global__ void __launch_bounds__(256) k_checkers_action_blocks(uint32_t *out, int E, int64_t env_id_base, uint64_t seed) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= E) return;
+  const u32x4 w = action_block(seed, (uint64_t)(env_id_base + (int64_t)e), 0u);
+  reinterpret_cast<u32x4 *>(out)[e] = w;
+}
+}  // namespace cm3
+
+int cm3_checkers_action_blocks(const cm3_checkers_desc *d, uint32_t *out, void *stream) {
+  using namespace cm3;
+  CM3_REQUIRE(d && out, "null argument");
+  CM3_REQUIRE(d->n_envs > 0, "n_envs must be positive");
+  CM3_REQUIRE(((uintptr_t)out % 16) == 0, "the table must be 16-byte aligned");
+  hipLaunchKernelGGL(k_checkers_action_blocks, dim3((unsigned)((d->n_envs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, d->n_envs,
+                     d->env_id_base, d->seed);
+  CM3_HIP_CHECK(hipGetLastError());
+  return CM3_OK;
+}
+
 int cm3_checkers_step(const cm3_checkers_desc *d, const cm3_checkers_bufs *b, void *stream) {
   return cm3::ck_call(d, b, nullptr, true, stream);
 }

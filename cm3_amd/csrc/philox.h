@@ -101,18 +101,10 @@ __host__ __device__ inline u32x4 action_block(uint64_t seed, uint64_t env, uint3
 __host__ __device__ inline uint32_t action_word(uint32_t a, uint32_t episode, uint32_t step) {
   return fmix32((a ^ step) + episode * 0x9E3779B1u);
 }
-// The Checkers step kernel keeps the ONE-stage draw of rounds 1-3 (a full Philox block over (env, episode, step | call)): its
-// prologue is instruction-bound -- table staging and plan decoding leave ~250 idle cycles behind its loads, the ten rounds take
-// ~550 -- so stage 1 cannot hide there and the extra mix only costs (same-box A/B: C3 3.51 -> 3.62 us per tick with the two-stage
-// draw, C2 2.52 -> 2.43; profiles/r04_two_stage_action_stream.txt).
-__host__ __device__ inline u32x4 action_words_direct(uint64_t seed, uint64_t env, uint32_t episode, uint32_t step, uint32_t call) {
-  u32x4 c;
-  c.x = (uint32_t)env;
-  c.y = (uint32_t)(env >> 32);
-  c.z = episode;
-  c.w = kPurposeAction | (call << 24) | (step & 0x00FFFFFFu);
-  return philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-}
+// (Until round 4 the Checkers step kernel kept a ONE-stage draw -- a full Philox block over (env, episode, step | call) -- because
+// computing stage 1 in its instruction-bound prologue measured slower, profiles/r04_two_stage_action_stream.txt.  Round 5: stage 1 is
+// a per-env constant, so the env object computes it ONCE (cm3_checkers_action_blocks) and a step launch LOADS it with its state;
+// one definition of the stream for every kernel.)
 // actions of agents 4c..4c+3 of (env, episode, step) come from call c
 __host__ __device__ inline u32x4 action_words(uint64_t seed, uint64_t env, uint32_t episode, uint32_t step,
                                               uint32_t call) {

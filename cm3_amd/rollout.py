@@ -774,6 +774,7 @@ class CheckersRollout(object):
         t = _lib.CheckersTraj()
         t.mask, t.agents, t.steps = env._mask.data_ptr(), env._agents.data_ptr(), env._steps.data_ptr()
         t.episode, t.goals = env._episode.data_ptr(), env._goals.data_ptr()
+        t.action_block = env._action_block.data_ptr()
         def slot(x):
             return x.data_ptr(), x[0].numel() * x.element_size()
         t.actions, t.actions_stride = slot(self.actions)

@@ -49,9 +49,9 @@ extern "C" {
 #define CM3_ABI_VERSION 6   /* 6: cm3_policy_force_row_tiles, cm3_rows_scatter / cm3_rows_gather / cm3_rows_tile / cm3_transitions_gather_f32 (round 5).
                                5: the in-kernel ACTION STREAM of the particle kernels and the actors' sampling uniforms became two stages
                                (Philox4x32-10 block per (seed, global env id, call) + fmix32((word ^ step) + episode * 0x9E3779B1);
-                               csrc/philox.h, oracle/philox.py) -- a given (seed, env, episode, step, agent) draws a DIFFERENT action
-                               than under ABI 4, whose counter layout masked `step & 0x00FFFFFF` into one Philox call; Checkers keeps
-                               the one-stage draw.  Also 5: cm3_last_kernel_variant; cm3_returns_moments_* takes a zero-initialised-once scratch (see there);
+                               csrc/philox.h, oracle/philox.py; since ABI 6 the Checkers kernels too) -- a given (seed, env, episode, step, agent) draws a DIFFERENT action
+                               than under ABI 4, whose counter layout masked `step & 0x00FFFFFF` into one Philox call (Checkers kept
+                               that one-stage draw until ABI 6).  Also 5: cm3_last_kernel_variant; cm3_returns_moments_* takes a zero-initialised-once scratch (see there);
                                cm3_returns_normalize_*, cm3_copy_shift, cm3_source_id, actor precision 2 (all added under 4) */
 #define CM3_MAX_AGENTS 10   /* the reference's make_world takes up to ten agents (its colour table, multi-goal_spread.py:7-16);
                               8 until ABI 5.  Checkers, the lane-per-pair mapping and the fused policy rollout stay at <= 8 */
@@ -277,6 +277,10 @@ typedef struct cm3_checkers_bufs {
   double *term_obs_self_v;
   uint8_t *goals_next; /* optional uint8 [E][N]: the goals in effect AFTER this tick -- the goals column of the NEXT
                           transition (they change only when a single-agent env restarts, train_onpolicy.py:288-291) */
+  const uint32_t *action_block; /* optional (ABI 6), uint32 [E][4], 16-byte aligned, filled ONCE per (seed, env_id_base) by
+                          cm3_checkers_action_blocks: stage 1 of the in-kernel action stream (CM3_FLAG_GEN_ACTIONS), a constant per env.
+                          With it a step launch loads the block with its state instead of running ten Philox rounds behind the
+                          loads; NULL: the kernel computes the same block itself (identical actions). */
 } cm3_checkers_bufs;
 
 /* Trajectory collection for Checkers (train_onpolicy.py:302-350, 16-column transitions): n_ticks step launches over
@@ -303,10 +307,15 @@ typedef struct cm3_checkers_traj {
   double *term_obs_self_v;  size_t term_obs_self_v_stride;
   uint8_t *goals_slots;     size_t goals_slots_stride; /* optional, n_ticks+1 slots of uint8 [E][N]; slot 0 is the caller's,
                                                           tick t writes slot t+1 (cm3_checkers_bufs.goals_next) */
+  const uint32_t *action_block;  /* optional (ABI 6): see cm3_checkers_bufs.action_block */
 } cm3_checkers_traj;
 
 int cm3_checkers_rollout(const cm3_checkers_desc *desc, const cm3_checkers_traj *traj, int32_t n_ticks, void *stream);
 
+/* Stage 1 of the in-kernel action stream for every env of `desc` (seed, env_id_base, n_envs): out = uint32 [E][4], the Philox block
+ * action_block(seed, global env id, 0) of csrc/philox.h.  Once per env object (ABI 6; since round 5 the Checkers kernels draw with
+ * the particle kernels' two-stage stream: action = rand5(fmix32((word ^ step) + episode * 0x9E3779B1))). */
+int cm3_checkers_action_blocks(const cm3_checkers_desc *desc, uint32_t *out, void *stream);
 /* Replaces Checkers.step (checkers.py:228-262): agents act sequentially in index order inside one lane. */
 int cm3_checkers_step(const cm3_checkers_desc *desc, const cm3_checkers_bufs *bufs, void *stream);
 /* Replaces Checkers.reset (checkers.py:265-291) for the envs selected by mask (NULL = all). */

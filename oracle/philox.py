@@ -70,7 +70,7 @@ def action_words(seed, env, episode, step, call):
 
 
 def action_words_direct(seed, env, episode, step, call):
-    """the ONE-stage draw the Checkers step kernel keeps (csrc/philox.h action_words_direct): a Philox block over
+    """the ONE-stage draw the Checkers step kernel used until round 4 (no longer in csrc/philox.h): a Philox block over
     (env, episode, step | call)."""
     lo, hi = _split(env)
     w = PURPOSE_ACTION | (int(call) << 24)
@@ -93,12 +93,13 @@ def rand5(r):
 
 
 def expected_actions(seed, env_ids, episode, step, n_agents, checkers=False):
-    """int64 [E, N]: what CM3_FLAG_GEN_ACTIONS writes for (env, episode, step) -- the particle kernels' two-stage stream, or
-    (checkers=True) the one-stage draw of the Checkers step kernel."""
+    """int64 [E, N]: what CM3_FLAG_GEN_ACTIONS writes for (env, episode, step) -- the two-stage stream of csrc/philox.h, the same for
+    the particle and (since round 5 / ABI 6) the Checkers kernels; checkers=True is accepted for old callers and changes nothing
+    (action_words_direct, the one-stage draw the Checkers kernel used until round 4, stays here as a restatement only)."""
     env_ids = np.asarray(env_ids)
     out = np.zeros((env_ids.shape[0], n_agents), np.int64)
     for call in range((n_agents + 3) // 4):
-        w = (action_words_direct if checkers else action_words)(seed, env_ids, episode, step, call)
+        w = action_words(seed, env_ids, episode, step, call)
         for k in range(4):
             i = 4 * call + k
             if i < n_agents:
