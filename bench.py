@@ -189,7 +189,7 @@ class TrajectoryStepper(object):
     step launches (x n_chains independent sub-batch chains), slot copy out."""
 
     def __init__(self, cfg, n_agents, n_envs, device, env_id_base=0, kernel="auto", n_chains=1, phase_ticks=PHASE_TICKS,
-                 use_graph=True, fused=False):
+                 use_graph=True, fused=False, live_state=None):
         import torch
         from cm3_amd.particle import VecParticleEnv
         from cm3_amd.rollout import ParticleRollout
@@ -197,7 +197,7 @@ class TrajectoryStepper(object):
         self.env = VecParticleEnv(cfg, n_agents, 0.2, EP_TICKS, n_envs, device=device, dtype=torch.float32, auto_reset=True,
                                   env_id_base=env_id_base, kernel=kernel)
         self.env.reset()
-        self.ro = ParticleRollout(self.env, n_ticks=phase_ticks, use_graph=use_graph, fused=fused, n_chains=n_chains)
+        self.ro = ParticleRollout(self.env, n_ticks=phase_ticks, use_graph=use_graph, fused=fused, n_chains=n_chains, live_state=live_state)
         self.device = self.env.device
         self.phase_ticks = int(phase_ticks)
         self.launches_per_tick = int(n_chains)
@@ -836,7 +836,8 @@ def build_headline(args, kind, cfg, N, E, device, rank, n_chains):
             bps -= (16 * N + 8 * N + 8) * (EP_TICKS - 1) / float(EP_TICKS)
         if args.mode == "trajectory":
             st = TrajectoryStepper(cfg, N, E, device, env_id_base=rank * E, kernel=args.kernel, n_chains=n_chains,
-                                   use_graph=not args.no_graph, fused=args.fused)
+                                   use_graph=not args.no_graph, fused=args.fused,
+                                   live_state={"auto": None, "on": True, "off": False}[getattr(args, "live_state", "auto")])
         else:
             st = ParticleStepper(cfg, N, E, device, env_id_base=rank * E, kernel=args.kernel, fused=args.fused,
                                  n_chains=n_chains)
@@ -880,6 +881,9 @@ def main():
                     help="skip the short c3 / c5 / c4 runs that the default c2 line carries as 'other_configs'")
     ap.add_argument("--no-extras", action="store_true",
                     help="headline only: skip the in-place / chains / fused / policy-rollout / launch-floor extras (clean profiles)")
+    ap.add_argument("--live-state", choices=["auto", "on", "off"], default="auto",
+                    help="trajectory mode of the particle workloads: step in place on the env's buffers and copy every tick's state to "
+                         "its slot (on), chain the ticks through the slots (off), or by size (auto, the product's rule)")
     ap.add_argument("--extras-file", default=None,
                     help="where the full record goes (default: %s next to bench.py and under gpurun_out/)" % EXTRAS_FILE)
     ap.add_argument("--fused", action="store_true",

@@ -372,8 +372,23 @@ __device__ __forceinline__ void store_obs_others_direct(const typename Vec<R>::v
 
 // ---- episode initialisation (multi-goal_spread.py:65-93), double arithmetic for both reals ---------
 // One Bernoulli(prob_random) per episode shared by agents AND landmarks (:75).
+__device__ __forceinline__ bool episode_is_random(const ParticleParams &p, uint64_t genv, uint32_t episode, uint64_t seed) {
+  return u01(reset_words(seed, genv, episode, 0).x) < p.prob_random;
+}
 __device__ __forceinline__ bool episode_is_random(const ParticleParams &p, uint64_t genv, uint32_t episode) {
-  return u01(reset_words(p.seed, genv, episode, 0).x) < p.prob_random;
+  return episode_is_random(p, genv, episode, p.seed);
+}
+// The seed as the same-launch reset of a step kernel sees it: the same value behind an empty asm statement, taken INSIDE the reset
+// branch.  The reset stream and the per-tick action stream share the Philox key, and left to itself the compiler computes the key
+// schedule (18 scalar adds) once at kernel entry and -- short of scalar registers across the tick -- carries it to the reset branch
+// in VGPRs: 18 v_mov_b32 on the path of EVERY tick of the C2 kernel (7 % of its ~240 vector instructions) for a branch an env takes
+// once per episode (round 5, tools/isa_dump.py).  Behind the asm the schedule is a different value: it is computed where it is used.
+__device__ __forceinline__ uint64_t reset_seed(const ParticleParams &p) {
+  uint32_t lo = (uint32_t)p.seed, hi = (uint32_t)(p.seed >> 32);
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(lo), "+v"(hi));   // (a vector register: an "s" constraint is refused where the value already lives in one)
+#endif
+  return ((uint64_t)hi << 32) | lo;
 }
 
 // Agent i (and its landmark) of the fresh episode.  `i` may be a run-time value: the config arrays are read
@@ -384,8 +399,10 @@ __device__ __forceinline__ bool episode_is_random(const ParticleParams &p, uint6
 // on the main path (81 SGPR spill moves per launch in the lane-per-agent kernel at N = 8).
 template <typename R, int N, bool TABLE = false>
 __device__ __forceinline__ void init_agent(const ParticleParams &p, uint64_t genv, uint32_t episode, bool rnd, int i,
-                                           typename Vec<R>::v4 &s, typename Vec<R>::v2 &g, const double *presets = nullptr) {
-  const u32x4 a = reset_words(p.seed, genv, episode, 1u + (uint32_t)i);
+                                           typename Vec<R>::v4 &s, typename Vec<R>::v2 &g, const double *presets = nullptr,
+                                           const uint64_t *seed_in = nullptr) {
+  const uint64_t seed = seed_in ? *seed_in : p.seed;
+  const u32x4 a = reset_words(seed, genv, episode, 1u + (uint32_t)i);
   double x, y;
   if (rnd) {  // :77-78
     x = 2.0 * u01(a.x) - 1.0;
@@ -419,7 +436,7 @@ __device__ __forceinline__ void init_agent(const ParticleParams &p, uint64_t gen
   s.z = R(x);
   s.w = R(y);
   if (rnd) {  // :88-89
-    const u32x4 l = reset_words(p.seed, genv, episode, 1u + (uint32_t)N + (uint32_t)i);
+    const u32x4 l = reset_words(seed, genv, episode, 1u + (uint32_t)N + (uint32_t)i);
     g.x = R(2.0 * u01(l.x) - 1.0);
     g.y = R(2.0 * u01(l.y) - 1.0);
   } else {  // :91
@@ -898,10 +915,11 @@ __global__ void __launch_bounds__(WAVES * 64)
         if (term_obs && slot_ok) *at32<V4>(term_obs, (e * SLOTS + vslot) * (uint32_t)sizeof(V4)) = sub4<R, V4>(sj, si);
       }
       episode += 1;
-      const bool rnd = episode_is_random(p, genv, episode);
+      const uint64_t rseed = reset_seed(p);
+      const bool rnd = episode_is_random(p, genv, episode, rseed);
       V2 gj;
-      init_agent<R, N, true>(p, genv, episode, rnd, i, si, gl, preset_table());
-      init_agent<R, N, true>(p, genv, episode, rnd, j, sj, gj, preset_table());
+      init_agent<R, N, true>(p, genv, episode, rnd, i, si, gl, preset_table(), &rseed);
+      init_agent<R, N, true>(p, genv, episode, rnd, j, sj, gj, preset_table(), &rseed);
       steps = 0;
       collisions = 0;
       was_reset = true;
@@ -1232,8 +1250,9 @@ __global__ void __launch_bounds__(WAVES * 64)
         }
         if (done) {
           episode += 1;
-          const bool rnd = episode_is_random(p, genv, episode);
-          init_agent<R, N, true>(p, genv, episode, rnd, i, si, gl, preset_table());
+          const uint64_t rseed = reset_seed(p);
+          const bool rnd = episode_is_random(p, genv, episode, rseed);
+          init_agent<R, N, true>(p, genv, episode, rnd, i, si, gl, preset_table(), &rseed);
           steps = 0;
           collisions = 0;
           was_reset = true;
@@ -1518,8 +1537,9 @@ __global__ void __launch_bounds__(WAVES * 64)
       }
       if (done) {
         episode += 1;
-        const bool rnd = episode_is_random(p, genv, episode);
-        init_agent<R, N, true>(p, genv, episode, rnd, i, si, gl, preset_table());
+        const uint64_t rseed = reset_seed(p);
+        const bool rnd = episode_is_random(p, genv, episode, rseed);
+        init_agent<R, N, true>(p, genv, episode, rnd, i, si, gl, preset_table(), &rseed);
         steps = 0;
         collisions = 0;
         was_reset = true;
