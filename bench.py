@@ -598,7 +598,7 @@ def pin_rank_to_gpu_numa_node(device_index):
         return "not pinned (%s)" % type(exc).__name__
 
 
-def measure_other_config(name, args, device, steps=6, cpu_budget_s=6.0):
+def measure_other_config(name, args, device, steps=20, cpu_budget_s=6.0):
     """One of the OTHER BASELINE workloads (c3 / c5 / c4), timed inside the default `bench.py --gpus 1` run exactly like the
     headline -- the product's own collector in trajectory mode, one step launch per tick, hipGraph replays, wall clock between
     two device synchronisations with the HIP-event time of the same region beside it -- so that the driver's record carries a
@@ -616,7 +616,7 @@ def measure_other_config(name, args, device, steps=6, cpu_budget_s=6.0):
     if kind == "particle_adv":
         steps = steps * 10                      # a c4 step is one 33-tick rollout: time as many ticks as the others
     K = steps * tps
-    st.run(2 * tps)
+    st.run(5 * tps * (10 if kind == "particle_adv" else 1))       # warm-up as the headline's: 5 collection phases
     torch.cuda.synchronize(device)
     stream = torch.cuda.current_stream(device)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -1264,9 +1264,9 @@ def main():
             stepper = None
             torch.cuda.empty_cache()
         out["other_configs"] = {name: measure_other_config(name, args, device) for name in ("c3", "c5", "c4")}
-        out["other_configs"]["note"] = ("each: the workload's own BASELINE configuration through the product's collector, >= 6 hipGraph "
-                                        "replays after 2 warm-up ones, same clock as the headline; `python bench.py --workload cN` "
-                                        "runs the long form with its extras")
+        out["other_configs"]["note"] = ("each: the workload's own BASELINE configuration through the product's collector, 20 hipGraph "
+                                        "replays (collection phases) after 5 warm-up ones as the headline, same clock; "
+                                        "`python bench.py --workload cN` runs it as the headline with its extras")
     if world == 1 and rank == 0:
         bw_read, bw_copy = measure_bandwidth(device)
         out["roofline"]["measured_read_GBps"] = bw_read
