@@ -64,6 +64,9 @@ __device__ __forceinline__ uint32_t mix(uint32_t x) {
 template <int AGG, int VICTIM> __global__ void __launch_bounds__(256) k_probe(unsigned *counts, float *sink, int iters, int victims_blocks) {
   __shared__ __attribute__((aligned(16))) _Float16 acts[64][200 + 8];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+#ifdef PROBE_BIG_REGS
+  asm volatile("" ::: "v254");    // the failing kernel allocates 255 registers: the SIMD's second wave lives in the upper half of the file
+#endif
   for (int i = tid; i < 64 * 208; i += 256) (&acts[0][0])[i] = (_Float16)(0.001f * (float)((i * 7) % 13));
   __syncthreads();
   const bool victim = (int)blockIdx.x < victims_blocks || AGG == 5;

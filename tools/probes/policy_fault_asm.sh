@@ -17,6 +17,6 @@ for v in "$@"; do
       -input=/dev/null -input="$d/dev.out" -output="$d/policy.hipfb"
   /opt/rocm/bin/hipcc $FLAGS --cuda-host-only -Xclang -fcuda-include-gpubinary -Xclang "$d/policy.hipfb" -c "$SRC/policy.hip" -o "$d/policy.o"
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$R/cm3_amd/libcm3_hip_pf_asm_$v.so" "$OBJ/particle_f32.o" "$OBJ/particle_f32_ilp.o" \
-      "$OBJ/particle_f64.o" "$OBJ/checkers.o" "$OBJ/util.o" "$OBJ/advantage.o" "$OBJ/actor.o" "$OBJ/actor_checkers.o" "$d/policy.o"
+      "$OBJ/particle_f64.o" "$OBJ/checkers.o" "$OBJ/util.o" "$OBJ/advantage.o" "$OBJ/batch.o" "$OBJ/actor.o" "$OBJ/actor_checkers.o" "$d/policy.o"
   echo "built asm_$v"
 done

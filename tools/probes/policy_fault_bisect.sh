@@ -19,7 +19,7 @@ build() {
   "$HIPCC" $FLAGS -mllvm -amdgpu-mfma-vgpr-form="$form" -DCM3_SOURCE_ID="\"pf_$v\"" "$@" -Rpass-analysis=kernel-resource-usage \
       -c "$W/$v/csrc/policy.hip" -o "$W/$v/policy.o" 2> "$W/$v/resource_usage.txt"
   "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$R/cm3_amd/libcm3_hip_pf_$v.so" "$OBJ/particle_f32.o" "$OBJ/particle_f32_ilp.o" \
-      "$OBJ/particle_f64.o" "$OBJ/checkers.o" "$OBJ/util.o" "$OBJ/advantage.o" "$OBJ/actor.o" "$OBJ/actor_checkers.o" "$W/$v/policy.o"
+      "$OBJ/particle_f64.o" "$OBJ/checkers.o" "$OBJ/util.o" "$OBJ/advantage.o" "$OBJ/batch.o" "$OBJ/actor.o" "$OBJ/actor_checkers.o" "$W/$v/policy.o"
   echo "== $v"; python3 tools/probes/resource_usage.py "$W/$v/resource_usage.txt" k_policy_rolloutILi8ELi2ELi4
 }
 for v in "$@"; do

@@ -144,8 +144,63 @@ elif variant == "final_mul_scalar":
                        "    asm(\"v_mul_f32 %0, %1, %2\" : \"=v\"(f_y) : \"v\"(qy), \"v\"(pen));\n"
                        "  } else {\n    f_x = qx * pen;\n    f_y = qy * pen;\n  }\n", 1)
     open(d + "/particle.hip", "w").write(q)
+elif variant.startswith("agg_"):
+    # WHICH part of the other wave's second layer does the fault need?  The lane-copy counters are the detector (they do not depend on
+    # the layer computing the right thing); the layer is changed:
+    #   agg_nomfma   no matrix instruction in it (the LDS reloads stay, their values are summed with vector adds)
+    #   agg_nolds    the matrix instructions stay, their B operands are loaded ONCE (s = 0) instead of reloaded every k-step
+    #   agg_swap     operands the other way round (activations as A, weights as B): the order of the clean build, everything else as it is
+    #   agg_one      ONE product per k-step instead of three (a third of the matrix instructions)
+    counters()
+    rep("    steps += 1;\n    ns[rl] = si;", '''    steps += 1;
+    {
+      const int src = lane & 15, grp = lane >> 4;
+      auto ne = [&](float v) { return __float_as_uint(__shfl(v, src, 64)) != __float_as_uint(v); };
+      if (ne(si.x) || ne(si.y) || ne(si.z) || ne(si.w)) atomicAdd(&cm3_dbg[4 + grp], 1u);
+      if (lane == 0) atomicAdd(&cm3_dbg[31], 1u);
+    }
+    ns[rl] = si;''')
+    q = open(d + "/actor.hip").read()
+    old = """      for (int t = 0; t < RT; ++t) accs[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b.bwh[s], al[t], accs[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b.bwh[s], ah[t], acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < RT; ++t) accs[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b.bwl[s], ah[t], accs[t], 0, 0, 0);
+"""
+    assert old in q
+    if variant == "agg_nomfma":
+        new = """      for (int t = 0; t < RT; ++t) {
+        acc[t][0] += (float)ah[t][0] + (float)al[t][1]; acc[t][1] += (float)ah[t][2] + (float)al[t][3];
+        acc[t][2] += (float)ah[t][4] + (float)al[t][5]; acc[t][3] += (float)ah[t][6] + (float)al[t][7];
+        accs[t][0] += (float)b.bwh[s][0]; accs[t][1] += (float)b.bwl[s][1];
+      }
+"""
+        q = q.replace(old, new)
+    elif variant == "agg_swap":
+        q = q.replace(old, old.replace("(b.bwh[s], al[t],", "(al[t], b.bwh[s],").replace("(b.bwh[s], ah[t],", "(ah[t], b.bwh[s],").replace("(b.bwl[s], ah[t],", "(ah[t], b.bwl[s],"))
+    elif variant == "agg_one":
+        q = q.replace(old, """      for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b.bwh[s], ah[t], acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < RT; ++t) accs[t][0] += (float)al[t][0] + (float)b.bwl[s][0];
+""")
+    elif variant == "agg_nolds":
+        ld = """      f16x8 ah[RT], al[RT];
+#pragma unroll
+      for (int t = 0; t < RT; ++t) {
+        ah[t] = *reinterpret_cast<const f16x8 *>(&lds.h1h[16 * t + col][32 * s + 8 * hi]);
+        al[t] = *reinterpret_cast<const f16x8 *>(&lds.h1l[16 * t + col][32 * s + 8 * hi]);
+      }
+"""
+        assert ld in q
+        q = q.replace(ld, ld.replace("[32 * s + 8 * hi]", "[8 * hi]"))      # the same address every k-step: the compiler hoists the loads
+    else:
+        raise SystemExit("unknown variant " + variant)
+    open(d + "/actor.hip", "w").write(q)
 elif variant in ("ctrl2", "nopk", "noslp"):
     pass
 else:
     raise SystemExit("unknown variant " + variant)
+# the old sources predate ABI 6: the entry point the current binding requires, as a stub
+if "cm3_policy_force_row_tiles" not in s:
+    s += '\nextern "C" int cm3_policy_force_row_tiles(int32_t) { return 0; }\n'
 open(p, "w").write(s)
