@@ -116,9 +116,9 @@ class DeviceReplayBuffer(object):
         return self.sample_n(size, generator)
 
     def sample_n(self, n, generator=None):
+        from .rollout import sample_distinct
         n = min(int(n), self.len)
-        pick = torch.randperm(self.len, generator=generator, device=self.device)[:n]
-        return self._take(pick)
+        return self._take(sample_distinct(self.len, n, 1, generator, self.device)[0])
 
 
 def _cat(a, b):

@@ -202,3 +202,36 @@ def test_reading_goals_between_collections_keeps_the_captured_graph():
     assert torch.equal(ro.goals, ref.goals) and torch.equal(ro.state, ref.state) and torch.equal(env.goals, ref_env.goals)
     ro.close()
     ref.close()
+
+
+def test_on_policy_minibatches_are_one_export_of_distinct_transitions():
+    """train_onpolicy.py:359-377: 24 minibatches of 128 per collection phase -- drawn together, exported by one launch; every
+    minibatch holds distinct transitions and exactly the columns of the transitions it names."""
+    env, ro = _rollout(E=2048, N=4, T=66)
+    g = torch.Generator(device=DEV).manual_seed(8)
+    mbs = list(ro.on_policy_minibatches(epochs=24, batch_size=128, generator=g))
+    pos = ro.last_sample_positions
+    assert len(mbs) == 24 and pos.shape == (24, 128)
+    E = env.E
+    for m, mb in enumerate(mbs):
+        assert len(set(pos[m].tolist())) == 128
+        want = ro.as_reference_batch_torch(torch.div(pos[m], E, rounding_mode="floor"), pos[m] % E, numpy=False)
+        for k in want:
+            assert torch.equal(mb[k], want[k]), (m, k)
+    assert len(set(pos.reshape(-1).tolist())) > 24 * 128 * 0.95          # independent draws: hardly any overlap between minibatches
+    one = ro.sample_batch(128, generator=g, numpy=False)
+    assert one["reward"].shape == (128,)
+    ro.close()
+    # episode-synchronous collection: only the transitions before each env's `done` are candidates
+    from cm3_amd.particle import VecParticleEnv
+    from cm3_amd.rollout import ParticleRollout
+    env2 = VecParticleEnv(load_cfg("particle_stage2_cross.json"), 4, 0.2, 12, 700, device=DEV, dtype=torch.float32, auto_reset=False, seed=5)
+    ro2 = ParticleRollout(env2, use_graph=False).collect()
+    mbs = list(ro2.on_policy_minibatches(epochs=3, batch_size=64, generator=g))
+    tt, ee = ro2.valid_indices()
+    pos = ro2.last_sample_positions
+    for m, mb in enumerate(mbs):
+        want = ro2.as_reference_batch_torch(tt[pos[m]], ee[pos[m]], numpy=False)
+        for k in want:
+            assert torch.equal(mb[k], want[k]), (m, k)
+    ro2.close()

@@ -90,3 +90,29 @@ def test_gpu_particle_momentum_and_idempotent_observe():
         gs, *_ = env.step(torch.zeros(E, N, dtype=torch.int32))
         after = gs[..., 0:2].sum(1)
         assert torch.allclose(after, 0.75 * before, rtol=0, atol=1e-8)
+
+
+def test_sample_distinct_is_sampling_without_replacement():
+    """cm3_amd.rollout.sample_distinct (the minibatch sampler of the on-policy cadence, replay_buffer.py:28-37 random.sample): every
+    row distinct and in range on both of its paths (permutation for small n, first distinct draws for n >> size), marginals uniform."""
+    import torch
+    from cm3_amd.rollout import sample_distinct
+    g = torch.Generator().manual_seed(3)
+    for n, size, rows in ((1_000_000, 128, 24), (64 * 128, 128, 300), (500, 128, 7), (129, 128, 5)):
+        o = sample_distinct(n, size, rows, g, "cpu")
+        assert o.shape == (rows, size) and o.dtype == torch.int64
+        assert int(o.min()) >= 0 and int(o.max()) < n
+        assert all(len(set(r.tolist())) == size for r in o)
+    n, size = 64 * 8, 8                                 # the rejection path at its smallest n / size ratio
+    cnt = torch.zeros(n)
+    draws = 3000
+    for _ in range(draws):
+        cnt += torch.bincount(sample_distinct(n, size, 8, g, "cpu").reshape(-1), minlength=n)
+    expected = draws * 8 * size / n
+    chi2 = float(((cnt - expected) ** 2 / expected).sum())
+    assert abs(chi2 - (n - 1)) < 6 * (2 * (n - 1)) ** 0.5, chi2          # chi-square with n - 1 degrees of freedom, 6 sigma
+    # first position uniform as well (the ORDER of a sample is random too)
+    firsts = torch.cat([sample_distinct(n, size, 64, g, "cpu")[:, 0] for _ in range(200)])
+    c0 = torch.bincount(firsts, minlength=n).float()
+    e0 = firsts.numel() / n
+    assert abs(float(((c0 - e0) ** 2 / e0).sum()) - (n - 1)) < 6 * (2 * (n - 1)) ** 0.5

@@ -79,6 +79,9 @@ def measure(device, copy_gbps=None, n_envs=4096, n_agents=4, cfg_name="particle_
     g = torch.Generator(device=device).manual_seed(0)
     s, mb = _time(lambda: ro.sample_batch(128, generator=g, numpy=False), device, reps=20)
     out["sample_minibatch_128"] = rec(s, 2 * _nbytes(mb), "ParticleRollout.sample_batch(128, numpy=False)")
+    s, mbs = _time(lambda: list(ro.on_policy_minibatches(epochs=24, batch_size=128, generator=g)), device, reps=10)
+    out["on_policy_minibatches_24x128"] = rec(s, 2 * sum(_nbytes(m) for m in mbs) / 1.0, "ParticleRollout.on_policy_minibatches(24, 128): all "
+                                              "minibatches of a phase drawn together and exported by one launch (train_onpolicy.py:359-377)")
     # (f2) process_batch + the feeds of train_step with a stand-in session, on a 128-transition minibatch and on 16 384 transitions
     for label, nb_rows in (("minibatch_128", 128), ("batch_16384", 16384)):
         tt = torch.randint(0, ticks, (nb_rows,), device=device)
