@@ -416,11 +416,13 @@ __device__ __forceinline__ void actor_mlp(const ActorLds<N, PREC, RT> &lds, cons
   __syncthreads();
   CM3_STAMP(4, false);
   // ---- phase B: second layer on the matrix cores (networks.py:522-531: both matmuls, add_n) ---------------------------
-  // NOT transposed like the first layer.  Tried (round 4, late: weights as A, one 16-byte h2 store per tile): no faster, and with two
-  // N = 8 workgroups resident on a CU a handful of rows per 65 536 came out wrong in launches of several ticks -- only
-  // then, only in float16 split precision, gone with this operand order or with the LDS padded so that a CU holds one workgroup at a time,
-  // NOT gone with the old scalar stores or with wait states before the epilogue / before the operand reloads.  Root cause not
-  // established (profiles/r04_policy_head.txt (9)); until it is, activations reloaded inside a k loop stay on the A side.
+  // NOT transposed like the first layer.  Tried (round 4, late: weights as A, one 16-byte h2 store per tile): no faster -- and it is
+  // the form under which round 4 saw a handful of wrong rows per launch with two N = 8 workgroups on a CU.  Round 5 traced those to
+  // the PHYSICS of the wave that shares the SIMD, not to this layer: a packed float32 multiply with a cross-half operand select
+  // (v_pk_mul_f32 ... op_sel:[0,1], made by the SLP vectoriser out of the contact chain) returns a wrong low half in lanes 48..63
+  // while the other wave executes v_mfma_f32_16x16x32_f16 -- ~100 x more often with the activations as the B operand than with this
+  // order, never without these matrix instructions (profiles/r05_policy_fault.txt).  The build no longer contains that instruction
+  // form (csrc/build.sh: -fno-slp-vectorize, tools/isa_lint.py); the operand order stays as it was measured.
   // tests/test_gpu_actor.py::test_policy_rollout_row_tile_rule_at_the_baseline_sizes is the test that caught it.
   f32x4 acc[RT];
 #pragma unroll

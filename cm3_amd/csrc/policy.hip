@@ -167,7 +167,8 @@ template <int N, int BF16, int RT> __global__ void CM3_MATRIX_KERNEL k_policy_ro
     steps += 1;
     // (one 16-byte LDS store; the other agents' rows come back as 16-byte reads, once, for collisions AND observation.  Lanes 0..15
     // only: lanes 16..63 repeat their physics and used to store their copy into the same slot -- the same value by the code,
-    // but this way nothing a copy computes is ever stored; profiles/r04_policy_head.txt (11))
+    // but this way nothing a copy computes is ever stored.  Round 5 found what made copies differ: a packed multiply of the contact
+    // chain returning a wrong low half in lanes 48..63 under a co-resident matrix wave, profiles/r05_policy_fault.txt)
     if (part0) ns[rl] = si;
     wave_lds_sync();  // the other agents of this env live in the same wave
     V4 oth[NO];
