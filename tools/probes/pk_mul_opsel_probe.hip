@@ -1,4 +1,6 @@
-// Round 5: minimal reproducer attempt for the k_policy_rollout fault (profiles/r05_policy_fault.txt).
+// Round 5: FIRST reproducer attempts for the k_policy_rollout fault (profiles/r05_policy_fault.txt) -- superseded by
+// pk_opsel_mfma_repro.hip, which reproduces it; kept because its null results are part of the record: aggressor waves that keep
+// the matrix pipe BUSY never trigger the fault, the alternating-phase variant (PROBE_TICKS=1) does.
 //
 // In the failing builds ONE instruction computes a wrong value, in lanes 48..63 only, a handful of times per launch:
 //     v_div_fixup_f32 v84, v83, v71, v84
@@ -141,7 +143,89 @@ template <int AGG, int VICTIM> __global__ void __launch_bounds__(256) k_probe(un
   }
 }
 
+// v2 (after the cuts of the real kernel still failed with only the matrix layer, a barrier and ONE contact chain left): every
+// workgroup alternates, tick after tick, between the matrix phase (the transposed float16 k-loop, LDS reloads) and the victim
+// phase (the packed multiply under a partial exec mask, checked against v_mul_f32), with workgroup barriers between them -- two
+// workgroups per CU drift against each other as the real ones do.  AGG here: 1 = with the matrix phase, 0 = without.
+template <int AGG, int VICTIM> __global__ void __launch_bounds__(256) k_probe_ticks(unsigned *counts, float *sink, int ticks, int per_tick, int mode) {
+  __shared__ __attribute__((aligned(16))) _Float16 acts[64][200 + 8];
+  __shared__ float pad[8192];     // ~57 KB per workgroup with acts: two workgroups per CU, not more than a few
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (int i = tid; i < 64 * 208; i += 256) (&acts[0][0])[i] = (_Float16)(0.001f * (float)((i * 7) % 13));
+  if (tid == 0 && ticks < 0) pad[0] = 1.0f;
+  __syncthreads();
+  const int col = lane & 15, hi = lane >> 4;
+  f16x8 wgt[6];
+  for (int s = 0; s < 6; ++s)
+    for (int j = 0; j < 8; ++j) wgt[s][j] = (_Float16)(0.01f * (float)((lane + s + j) % 7));
+  f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}, accs[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  unsigned bad_lo = 0, bad_hi = 0;
+  // mode 0: every workgroup alternates between the two phases (the real kernel's structure)
+  //      1: workgroups >= 256 run only matrix phases, the others only victim phases -- after ONE matrix phase at tick 0
+  //      2: the same split, the victim workgroups never execute a matrix instruction
+  //      3: mode 0 without the workgroup barriers
+  const bool agg_only = (mode == 1 || mode == 2) && blockIdx.x >= 256, vic_only = (mode == 1 || mode == 2) && blockIdx.x < 256;
+  for (int t = 0; t < ticks; ++t) {
+    if (AGG != 0 && !(vic_only && (mode == 2 || t > 0))) {
+#pragma unroll
+      for (int s = 0; s < 6; ++s) {
+        f16x8 ah[4], al[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          ah[q] = *reinterpret_cast<const f16x8 *>(&acts[16 * q + col][32 * s + 8 * hi]);
+          al[q] = *reinterpret_cast<const f16x8 *>(&acts[(16 * q + col + 7) & 63][32 * s + 8 * hi]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) accs[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wgt[s], al[q], accs[q], 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wgt[s], ah[q], acc[q], 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) accs[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wgt[(s + 1) % 6], ah[q], accs[q], 0, 0, 0);
+      }
+      // EVERY accumulator register is read by a vector instruction the compiler can see (it inserts the wait states a matrix
+      // result needs), a little of the sum goes back into the activations, and 64 more wait states follow: no matrix instruction
+      // of THIS wave is in flight when the hand-written victim instructions below touch their fixed registers
+      float sum = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sum += acc[q][0] + acc[q][1] + acc[q][2] + acc[q][3] + accs[q][0] + accs[q][1] + accs[q][2] + accs[q][3];
+      acts[(lane + t) & 63][(tid >> 6) * 8 + (t & 7)] = (_Float16)(sum * 1e-9f);
+      asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    }
+    if (mode != 3) __syncthreads();
+    for (int it = 0; it < (agg_only ? 0 : per_tick); ++it) {
+      const uint32_t h = mix((uint32_t)(blockIdx.x * 256 + tid) * 2654435761u + (uint32_t)(t * per_tick + it));
+      const float qx = ((float)(int)(h & 0xffff) - 32768.0f) * (100.0f / 32768.0f) + 0.001f;
+      const float qy = ((float)(int)((h >> 16) & 0xffff) - 32768.0f) * (100.0f / 32768.0f) + 0.001f;
+      const float pen = 1e-9f + (float)(mix(h) & 0xffff) * (0.05f / 65536.0f);
+      const float junk = qy * 3.0f;
+      const bool active = VICTIM == 5 || ((mix(h + (uint32_t)(lane & 15) * 977u) >> 3) & 1u) != 0 || (lane & 15) < 2;
+      float rx = 0.0f, ry = 0.0f;
+      if (active) victim_op<VICTIM>(qx, qy, junk, pen, rx, ry);
+      if (active) {
+        float wx, wy;
+        asm volatile("v_mul_f32 %0, %2, %4\n\tv_mul_f32 %1, %3, %4" : "=&v"(wx), "=&v"(wy) : "v"(qx), "v"(qy), "v"(pen));
+        if (__float_as_uint(wx) != __float_as_uint(rx)) bad_lo += 1;
+        if (__float_as_uint(wy) != __float_as_uint(ry)) bad_hi += 1;
+      }
+    }
+    if (mode != 3) __syncthreads();
+  }
+  if (bad_lo) atomicAdd(&counts[lane >> 4], bad_lo);
+  if (bad_hi) atomicAdd(&counts[4 + (lane >> 4)], bad_hi);
+  if (lane == 0) atomicAdd(&counts[8], 1u);
+  float v = 0.0f;
+  for (int q = 0; q < 4; ++q) v += acc[q][0] + accs[q][1];
+  if (v == 123.456f) sink[tid] = v + pad[tid];
+}
+
 template <int AGG, int VICTIM> static void run(unsigned *counts, float *sink, int iters) {
+  if (getenv("PROBE_TICKS")) {
+    const int blocks = getenv("PROBE_BLOCKS") ? atoi(getenv("PROBE_BLOCKS")) : 512;
+    const int threads = getenv("PROBE_THREADS") ? atoi(getenv("PROBE_THREADS")) : 256;
+    const int mode = getenv("PROBE_MODE") ? atoi(getenv("PROBE_MODE")) : 0;
+    hipLaunchKernelGGL((k_probe_ticks<(AGG != 0), VICTIM>), dim3(blocks), dim3(threads), 0, 0, counts, sink, iters / 8, 8, mode);
+    return;
+  }
   const int victims = AGG == 0 ? 256 : 256, blocks = AGG == 0 ? 256 : 512;
   hipLaunchKernelGGL((k_probe<AGG, VICTIM>), dim3(blocks), dim3(256), 0, 0, counts, sink, iters, victims);
 }

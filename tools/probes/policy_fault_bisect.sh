@@ -28,6 +28,7 @@ for v in "$@"; do
   extra=""
   if [ "$v" = nopk ]; then extra="-Xclang -target-feature -Xclang -packed-fp32-ops"; fi
   if [ "$v" = noslp ]; then extra="-fno-slp-vectorize"; fi
+  case "$v" in cut*A*) extra="-fno-slp-vectorize";; esac
   build "$v" 1 $extra &
 done
 wait

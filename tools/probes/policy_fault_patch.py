@@ -144,6 +144,42 @@ elif variant == "final_mul_scalar":
                        "    asm(\"v_mul_f32 %0, %1, %2\" : \"=v\"(f_y) : \"v\"(qy), \"v\"(pen));\n"
                        "  } else {\n    f_x = qx * pen;\n    f_y = qy * pen;\n  }\n", 1)
     open(d + "/particle.hip", "w").write(q)
+elif variant.startswith("cut"):
+    # delta debugging of the failing kernel: the lane-copy counter stays, parts of the kernel go (round 5, towards a smaller reproducer)
+    counters()
+    rep("    steps += 1;\n    ns[rl] = si;", '''    steps += 1;
+    {
+      const int src = lane & 15, grp = lane >> 4;
+      auto ne = [&](float v) { return __float_as_uint(__shfl(v, src, 64)) != __float_as_uint(v); };
+      if (ne(si.x) || ne(si.y) || ne(si.z) || ne(si.w)) atomicAdd(&cm3_dbg[4 + grp], 1u);
+      if (lane == 0) atomicAdd(&cm3_dbg[31], 1u);
+    }
+    ns[rl] = si;''')
+    if "A" in variant:      # the instruction form forced (every chain ends in v_pk_mul_f32 ... op_sel:[0,1]) so that cuts cannot lose it
+        q = open(d + "/particle.hip").read()
+        old = "  f_x = kForce * dx / dist * pen;\n  f_y = kForce * dy / dist * pen;\n"
+        assert old in q
+        q = q.replace(old, """  if constexpr (sizeof(R) == 4) {
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    f2v qv = {kForce * dx / dist, kForce * dy / dist}, pv = {dist, pen}, fv;
+    asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(fv) : "v"(qv), "v"(pv));
+    f_x = fv[0];
+    f_y = fv[1];
+  } else {
+    f_x = kForce * dx / dist * pen;
+    f_y = kForce * dy / dist * pen;
+  }
+""", 1)
+        open(d + "/particle.hip", "w").write(q)
+    if "1" in variant:      # cut1: only the first contact pair is evaluated
+        rep("    for (int k = 0; k < N - 1; ++k) {  // the reference's accumulation order", "    for (int k = 0; k < 1; ++k) {  // the reference's accumulation order")
+    if "2" in variant:      # cut2: no rewards / collisions / resets / trajectory stores behind the exchange: straight to the next tick's tile
+        a = s.index("    CM3_STAMP(8, false);\n    // ---- reward / reached / collisions")
+        b = s.index("    CM3_STAMP(10, false);\n    // ---- trajectory stores + the LDS tile of the next tick")
+        s_ = s[:a] + "    float rew = 0.0f; bool was_reset = false; float pr_dummy = pr[0]; (void)pr_dummy;\n" + s[b:]
+        globals()["s"] = s_
+    if "3" in variant:      # cut3: the head's result is not used: action 1 for everyone (the head still runs)
+        rep("    const int act = bcast_row0(actor_pick(pr, u));", "    const int act = 1 + 0 * bcast_row0(actor_pick(pr, u));")
 elif variant.startswith("agg_"):
     # WHICH part of the other wave's second layer does the fault need?  The lane-copy counters are the detector (they do not depend on
     # the layer computing the right thing); the layer is changed:
