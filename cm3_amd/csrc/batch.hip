@@ -116,56 +116,112 @@ template <typename T> __device__ __forceinline__ const T *tick_of(const T *base,
 // (round 5, first form: a wave per transition looping over its units -- 46 of 64 lanes busy at N = 4 and one dependent chain of
 // index -> done -> data loads per wave at a time: 1.23 ms for the 1.35 M transitions of a C2 phase, hardly faster than the torch
 // composition; flattened, every lane has its own chain in flight)
+// (second form: each lane carries FOUR units at once -- their `done` bytes are requested together, then their data, then the stores:
+// a unit is two dependent memory round trips, and with one unit per lane in flight the export ran at 2 TB/s)
+struct TransUnit {
+  const void *src;
+  void *dst;
+  int bytes;   // 16, 8, 4, 1 (the done byte: written from the value already loaded), 0 (nothing: past the end)
+};
+__device__ __forceinline__ TransUnit trans_unit(const TransParams &p, size_t b, int v, int64_t t, size_t e, bool d, int N, int NV) {
+  TransUnit u;
+  if (v < 2 * N) {
+    const bool nxt = v >= N;
+    const int i = nxt ? v - N : v;
+    const float *src = nxt ? ((d && p.term_state) ? tick_of(p.term_state, p.st_term_state, t) : tick_of(p.state, p.st_state, t + 1))
+                           : tick_of(p.state, p.st_state, t);
+    u.src = reinterpret_cast<const float4 *>(src) + ((size_t)i * p.E + e);
+    u.dst = reinterpret_cast<float4 *>(nxt ? p.o_next_state : p.o_state) + (b * N + i);
+    u.bytes = 16;
+    return u;
+  }
+  v -= 2 * N;
+  if (v < 2 * NV) {
+    const bool nxt = v >= NV;
+    const int k = nxt ? v - NV : v;
+    const float *src = nxt ? ((d && p.term_obs) ? tick_of(p.term_obs, p.st_term_obs, t) : tick_of(p.obs, p.st_obs, t + 1))
+                           : tick_of(p.obs, p.st_obs, t);
+    u.src = reinterpret_cast<const float4 *>(src) + (e * NV + k);
+    u.dst = reinterpret_cast<float4 *>(nxt ? p.o_next_obs : p.o_obs) + (b * NV + k);
+    u.bytes = 16;
+    return u;
+  }
+  v -= 2 * NV;
+  if (v < N) {   // goals [slot][N][E][2]: the slot that last wrote this env's landmarks (goal_slot), or the only one (stride 0)
+    const int64_t gs = p.goal_slot ? (int64_t)tick_of(p.goal_slot, p.st_goal_slot, t)[e] : t;
+    u.src = reinterpret_cast<const float2 *>(tick_of(p.goals, p.st_goals, gs)) + ((size_t)v * p.E + e);
+    u.dst = reinterpret_cast<float2 *>(p.o_goals) + (b * N + v);
+    u.bytes = 8;
+    return u;
+  }
+  v -= N;
+  if (v < N) {
+    u.src = tick_of(p.actions, p.st_actions, t) + (e * N + v);
+    u.dst = p.o_actions + (b * N + v);
+    u.bytes = 4;
+    return u;
+  }
+  v -= N;
+  if (v < N) {
+    u.src = tick_of(p.reward_n, p.st_reward_n, t) + (e * N + v);
+    u.dst = p.o_reward_n + (b * N + v);
+    u.bytes = 4;
+    return u;
+  }
+  v -= N;
+  if (v == 0) {
+    u.src = tick_of(p.reward, p.st_reward, t) + e;
+    u.dst = p.o_reward + b;
+    u.bytes = 4;
+    return u;
+  }
+  u.src = nullptr;
+  u.dst = p.o_done + b;
+  u.bytes = 1;
+  return u;
+}
+
 __global__ void __launch_bounds__(256) k_transitions_gather(const TransParams p) {
+  constexpr int K = 4;
   const int N = p.N, NV = N * p.L / 4;
   const uint32_t U = (uint32_t)(2 * N + 2 * NV + 3 * N + 2);
   const size_t total = p.n * U, stride = (size_t)gridDim.x * blockDim.x;
-  const bool small = total + stride < ((size_t)1 << 32);
-  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
-    const size_t b = small ? (size_t)((uint32_t)g / U) : g / U;
-    int v = (int)(g - b * U);
-    // (tt == NULL: every transition of the trajectory in time-major order, b = t E + e -- no index arrays to build or read)
-    const int64_t t = p.tt ? p.tt[b] : (int64_t)(small ? (size_t)((uint32_t)b / (uint32_t)p.E) : b / p.E);
-    const size_t e = p.tt ? (size_t)p.ee[b] : b - (size_t)t * p.E;
-    const bool d = tick_of(p.done, p.st_done, t)[e] != 0;
-    if (v < 2 * N) {
-      const bool nxt = v >= N;
-      const int i = nxt ? v - N : v;
-      const float *src = nxt ? ((d && p.term_state) ? tick_of(p.term_state, p.st_term_state, t) : tick_of(p.state, p.st_state, t + 1))
-                             : tick_of(p.state, p.st_state, t);
-      reinterpret_cast<float4 *>(nxt ? p.o_next_state : p.o_state)[b * N + i] = reinterpret_cast<const float4 *>(src)[(size_t)i * p.E + e];
-      continue;
+  const bool small = total + (size_t)K * stride < ((size_t)1 << 32);
+  for (size_t g0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g0 < total; g0 += (size_t)K * stride) {
+    size_t bb[K], ee[K];
+    int64_t tt[K];
+    int vv[K];
+    uint8_t dd[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const size_t g = g0 + (size_t)k * stride, gc = g < total ? g : total - 1;
+      const size_t b = small ? (size_t)((uint32_t)gc / U) : gc / U;
+      bb[k] = b;
+      vv[k] = g < total ? (int)(gc - b * U) : -1;
+      // (tt == NULL: every transition of the trajectory in time-major order, b = t E + e -- no index arrays to build or read)
+      tt[k] = p.tt ? p.tt[b] : (int64_t)(small ? (size_t)((uint32_t)b / (uint32_t)p.E) : b / p.E);
+      ee[k] = p.tt ? (size_t)p.ee[b] : b - (size_t)tt[k] * p.E;
     }
-    v -= 2 * N;
-    if (v < 2 * NV) {
-      const bool nxt = v >= NV;
-      const int k = nxt ? v - NV : v;
-      const float *src = nxt ? ((d && p.term_obs) ? tick_of(p.term_obs, p.st_term_obs, t) : tick_of(p.obs, p.st_obs, t + 1))
-                             : tick_of(p.obs, p.st_obs, t);
-      reinterpret_cast<float4 *>(nxt ? p.o_next_obs : p.o_obs)[b * NV + k] = reinterpret_cast<const float4 *>(src)[e * NV + k];
-      continue;
+#pragma unroll
+    for (int k = 0; k < K; ++k) dd[k] = tick_of(p.done, p.st_done, tt[k])[ee[k]];
+    TransUnit u[K];
+    uint4 val[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      u[k] = trans_unit(p, bb[k], vv[k] < 0 ? 0 : vv[k], tt[k], ee[k], dd[k] != 0, N, NV);
+      if (vv[k] < 0) u[k].bytes = 0;
+      val[k] = uint4{0u, 0u, 0u, 0u};
+      if (u[k].bytes == 16) val[k] = *reinterpret_cast<const uint4 *>(u[k].src);
+      else if (u[k].bytes == 8) { const uint2 w = *reinterpret_cast<const uint2 *>(u[k].src); val[k].x = w.x; val[k].y = w.y; }
+      else if (u[k].bytes == 4) val[k].x = *reinterpret_cast<const uint32_t *>(u[k].src);
     }
-    v -= 2 * NV;
-    if (v < N) {   // goals [slot][N][E][2]: the slot that last wrote this env's landmarks (goal_slot), or the only one (stride 0)
-      const int64_t gs = p.goal_slot ? (int64_t)tick_of(p.goal_slot, p.st_goal_slot, t)[e] : t;
-      reinterpret_cast<float2 *>(p.o_goals)[b * N + v] = reinterpret_cast<const float2 *>(tick_of(p.goals, p.st_goals, gs))[(size_t)v * p.E + e];
-      continue;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      if (u[k].bytes == 16) *reinterpret_cast<uint4 *>(u[k].dst) = val[k];
+      else if (u[k].bytes == 8) *reinterpret_cast<uint2 *>(u[k].dst) = uint2{val[k].x, val[k].y};
+      else if (u[k].bytes == 4) *reinterpret_cast<uint32_t *>(u[k].dst) = val[k].x;
+      else if (u[k].bytes == 1) *reinterpret_cast<uint8_t *>(u[k].dst) = dd[k] ? 1 : 0;
     }
-    v -= N;
-    if (v < N) {
-      p.o_actions[b * N + v] = tick_of(p.actions, p.st_actions, t)[e * N + v];
-      continue;
-    }
-    v -= N;
-    if (v < N) {
-      p.o_reward_n[b * N + v] = tick_of(p.reward_n, p.st_reward_n, t)[e * N + v];
-      continue;
-    }
-    v -= N;
-    if (v == 0)
-      p.o_reward[b] = tick_of(p.reward, p.st_reward, t)[e];
-    else
-      p.o_done[b] = d ? 1 : 0;
   }
 }
 
@@ -332,8 +388,8 @@ int cm3_transitions_gather_f32(const cm3_particle_desc *desc, const cm3_particle
   p.N = desc->n_agents;
   p.L = 4 * (desc->n_agents > 1 ? desc->n_agents - 1 : 1);
   const size_t units = (size_t)n * (size_t)(2 * p.N + 2 * (p.N * p.L / 4) + 3 * p.N + 2);
-  size_t blocks = (units + 255) / 256;
-  blocks = blocks > 16384 ? 16384 : blocks;
+  size_t blocks = (units + 4 * 256 - 1) / (4 * 256);     // four units per lane
+  blocks = blocks < 1 ? 1 : (blocks > 16384 ? 16384 : blocks);
   hipLaunchKernelGGL(k_transitions_gather, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
   CM3_HIP_CHECK(hipGetLastError());
   return CM3_OK;
