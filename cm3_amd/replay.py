@@ -164,6 +164,21 @@ class DeviceDualReplayBuffer(object):
         return _cat(a, b)
 
 
+def off_policy_batches(rollout, buffer, n_chunks, batch_size=128, generator=None, **collect_kwargs):
+    """The off-policy cadence of alg/train_offpolicy.py:309-356 (the trainer the reference's README routes Checkers to): every
+    transition goes into a PERSISTENT replay buffer (:337-346), and every `steps_per_train` env steps (:348) a batch is sampled
+    from it (:350) for a training step.  Vectorised: `rollout` (a ParticleRollout / CheckersRollout in continuous mode with
+    n_ticks = steps_per_train) collects one chunk of ticks for all its envs, all transitions of the chunk are added to `buffer`
+    (DeviceReplayBuffer: ONE launch) and one batch is sampled -- yielded as device columns; `collect_kwargs` go to
+    rollout.collect() (policy=..., epsilon=..., goals=... for Checkers).  The buffer outlives the chunks: old transitions are
+    overwritten only when it is full (replay_buffer.py:11-16)."""
+    for _ in range(int(n_chunks)):
+        rollout.collect(**collect_kwargs)
+        cols = rollout.as_reference_batch(numpy=False)
+        buffer.add({k: v.contiguous() for k, v in cols.items()})
+        yield buffer.sample_batch(batch_size, generator=generator)
+
+
 class CsvLog(object):
     """The reference's two CSV logs with identical headers and row formats (train_onpolicy.py:200-221, :399-429)."""
 

@@ -235,3 +235,43 @@ def test_on_policy_minibatches_are_one_export_of_distinct_transitions():
         for k in want:
             assert torch.equal(mb[k], want[k]), (m, k)
     ro2.close()
+
+
+def test_off_policy_cadence_for_particle_and_checkers():
+    """train_offpolicy.py:309-356: a persistent buffer filled chunk by chunk (steps_per_train = 10 ticks, alg/config.json:58), one
+    batch of 128 sampled after each; the Checkers trainer of the reference's README takes this path."""
+    import numpy as np
+    from cm3_amd.checkers import VecCheckersEnv
+    from cm3_amd.particle import VecParticleEnv
+    from cm3_amd.replay import DeviceReplayBuffer, off_policy_batches
+    from cm3_amd.rollout import CheckersRollout, ParticleRollout
+    g = torch.Generator(device=DEV).manual_seed(11)
+    env = VecParticleEnv(load_cfg("particle_stage2_antipodal.json"), 4, 0.2, 33, 64, device=DEV, dtype=torch.float32, auto_reset=True, seed=3)
+    env.reset()
+    ro = ParticleRollout(env, n_ticks=10, use_graph=True)
+    buf = DeviceReplayBuffer(size=2000, device=DEV)              # 640 transitions per chunk: wraps in the fourth
+    seen = []
+    for k, batch in enumerate(off_policy_batches(ro, buf, 5, batch_size=128, generator=g, reset=False)):
+        assert batch["v_global"].shape == (128, 4, 4) and batch["actions"].dtype == torch.int32
+        assert len(buf) == min(640 * (k + 1), 2000)
+        seen.append(ro.as_reference_batch(numpy=False))
+    # ring contents = the newest 2000 transitions, in arrival order modulo the ring
+    allc = {name: torch.cat([c[name] for c in seen]) for name in seen[0]}
+    keep = torch.arange(5 * 640 - 2000, 5 * 640, device=DEV)
+    for name, v in allc.items():
+        assert torch.equal(buf.all()[name][keep % 2000], v[keep]), name
+    ro.close()
+    ck = load_cfg("checkers_stage2.json")
+    cenv = VecCheckersEnv(ck["init"], 2, 33, 96, device=DEV, auto_reset=True, seed=4)
+    cenv.reset(np.eye(2))
+    cro = CheckersRollout(cenv, n_ticks=10, use_graph=True)
+    cbuf = DeviceReplayBuffer(size=100000, device=DEV)
+    n = 0
+    for batch in off_policy_batches(cro, cbuf, 3, batch_size=128, generator=g, goals=np.eye(2)):
+        n += 960
+        assert len(cbuf) == n and batch["grid"].shape[0] == 128 and batch["done"].dtype == torch.bool
+        assert set(batch) == set(CheckersRollout.ORDER)
+    last = cro.as_reference_batch(numpy=False)
+    for name, v in last.items():
+        assert torch.equal(cbuf.all()[name][n - 960:n], v), name
+    cro.close()
