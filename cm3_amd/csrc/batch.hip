@@ -120,17 +120,19 @@ template <typename T> __device__ __forceinline__ const T *tick_of(const T *base,
 // a unit is two dependent memory round trips, and with one unit per lane in flight the export ran at 2 TB/s)
 struct TransUnit {
   const void *src;
+  const void *alt;   // next_* units under terminal capture: the source when the env restarted at this tick (needs the done byte); else NULL
   void *dst;
   int bytes;   // 16, 8, 4, 1 (the done byte: written from the value already loaded), 0 (nothing: past the end)
 };
-__device__ __forceinline__ TransUnit trans_unit(const TransParams &p, size_t b, int v, int64_t t, size_t e, bool d, int N, int NV) {
+__device__ __forceinline__ TransUnit trans_unit(const TransParams &p, size_t b, int v, int64_t t, size_t e, int N, int NV) {
   TransUnit u;
+  u.alt = nullptr;
   if (v < 2 * N) {
     const bool nxt = v >= N;
     const int i = nxt ? v - N : v;
-    const float *src = nxt ? ((d && p.term_state) ? tick_of(p.term_state, p.st_term_state, t) : tick_of(p.state, p.st_state, t + 1))
-                           : tick_of(p.state, p.st_state, t);
+    const float *src = nxt ? tick_of(p.state, p.st_state, t + 1) : tick_of(p.state, p.st_state, t);
     u.src = reinterpret_cast<const float4 *>(src) + ((size_t)i * p.E + e);
+    if (nxt && p.term_state) u.alt = reinterpret_cast<const float4 *>(tick_of(p.term_state, p.st_term_state, t)) + ((size_t)i * p.E + e);
     u.dst = reinterpret_cast<float4 *>(nxt ? p.o_next_state : p.o_state) + (b * N + i);
     u.bytes = 16;
     return u;
@@ -139,9 +141,9 @@ __device__ __forceinline__ TransUnit trans_unit(const TransParams &p, size_t b, 
   if (v < 2 * NV) {
     const bool nxt = v >= NV;
     const int k = nxt ? v - NV : v;
-    const float *src = nxt ? ((d && p.term_obs) ? tick_of(p.term_obs, p.st_term_obs, t) : tick_of(p.obs, p.st_obs, t + 1))
-                           : tick_of(p.obs, p.st_obs, t);
+    const float *src = nxt ? tick_of(p.obs, p.st_obs, t + 1) : tick_of(p.obs, p.st_obs, t);
     u.src = reinterpret_cast<const float4 *>(src) + (e * NV + k);
+    if (nxt && p.term_obs) u.alt = reinterpret_cast<const float4 *>(tick_of(p.term_obs, p.st_term_obs, t)) + (e * NV + k);
     u.dst = reinterpret_cast<float4 *>(nxt ? p.o_next_obs : p.o_obs) + (b * NV + k);
     u.bytes = 16;
     return u;
@@ -202,19 +204,29 @@ __global__ void __launch_bounds__(256) k_transitions_gather(const TransParams p)
       tt[k] = p.tt ? p.tt[b] : (int64_t)(small ? (size_t)((uint32_t)b / (uint32_t)p.E) : b / p.E);
       ee[k] = p.tt ? (size_t)p.ee[b] : b - (size_t)tt[k] * p.E;
     }
-#pragma unroll
-    for (int k = 0; k < K; ++k) dd[k] = tick_of(p.done, p.st_done, tt[k])[ee[k]];
     TransUnit u[K];
     uint4 val[K];
+    // Only the next_* units of a trajectory with terminal capture (and the done column itself) need the env's done byte before
+    // their data can be requested: the byte is requested for those alone, every other unit's data in the same round trip
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      u[k] = trans_unit(p, bb[k], vv[k] < 0 ? 0 : vv[k], tt[k], ee[k], dd[k] != 0, N, NV);
+      u[k] = trans_unit(p, bb[k], vv[k] < 0 ? 0 : vv[k], tt[k], ee[k], N, NV);
       if (vv[k] < 0) u[k].bytes = 0;
-      val[k] = uint4{0u, 0u, 0u, 0u};
-      if (u[k].bytes == 16) val[k] = *reinterpret_cast<const uint4 *>(u[k].src);
-      else if (u[k].bytes == 8) { const uint2 w = *reinterpret_cast<const uint2 *>(u[k].src); val[k].x = w.x; val[k].y = w.y; }
-      else if (u[k].bytes == 4) val[k].x = *reinterpret_cast<const uint32_t *>(u[k].src);
+      dd[k] = 0;
+      if (u[k].alt || u[k].bytes == 1) dd[k] = tick_of(p.done, p.st_done, tt[k])[ee[k]];
     }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      val[k] = uint4{0u, 0u, 0u, 0u};
+      if (!u[k].alt) {
+        if (u[k].bytes == 16) val[k] = *reinterpret_cast<const uint4 *>(u[k].src);
+        else if (u[k].bytes == 8) { const uint2 w = *reinterpret_cast<const uint2 *>(u[k].src); val[k].x = w.x; val[k].y = w.y; }
+        else if (u[k].bytes == 4) val[k].x = *reinterpret_cast<const uint32_t *>(u[k].src);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      if (u[k].alt) val[k] = *reinterpret_cast<const uint4 *>(dd[k] ? u[k].alt : u[k].src);      // (next state / next observation rows: 16 bytes)
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       if (u[k].bytes == 16) *reinterpret_cast<uint4 *>(u[k].dst) = val[k];
