@@ -64,7 +64,7 @@ class ParticleTraj(ctypes.Structure):
 
 class TransitionCols(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in ("state", "obs_others", "actions", "reward", "reward_n", "next_state", "next_obs_others",
-                                        "done", "goals")]
+                                        "done", "goals")] + [("ring_start", c_int64), ("ring_size", c_int64)]
 
 
 class RowCols(ctypes.Structure):

@@ -100,6 +100,7 @@ struct TransParams {
   int32_t *o_actions;
   uint8_t *o_done;
   size_t n, E;
+  size_t ring_start, ring_size;   // ring_size > 0: transition b goes to output row (ring_start + b) mod ring_size (a replay ring), else to row b
   int N, L;
 };
 
@@ -124,9 +125,14 @@ struct TransUnit {
   void *dst;
   int bytes;   // 16, 8, 4, 1 (the done byte: written from the value already loaded), 0 (nothing: past the end)
 };
-__device__ __forceinline__ TransUnit trans_unit(const TransParams &p, size_t b, int v, int64_t t, size_t e, int N, int NV) {
+__device__ __forceinline__ TransUnit trans_unit(const TransParams &p, size_t b_in, int v, int64_t t, size_t e, int N, int NV) {
   TransUnit u;
   u.alt = nullptr;
+  size_t b = b_in;                // output row
+  if (p.ring_size) {
+    b = p.ring_start + b_in;
+    b = b >= p.ring_size ? b - p.ring_size : b;
+  }
   if (v < 2 * N) {
     const bool nxt = v >= N;
     const int i = nxt ? v - N : v;
@@ -197,9 +203,31 @@ __global__ void __launch_bounds__(256) k_transitions_gather(const TransParams p)
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const size_t g = g0 + (size_t)k * stride, gc = g < total ? g : total - 1;
-      const size_t b = small ? (size_t)((uint32_t)gc / U) : gc / U;
+      size_t b;
+      int v;
+      if (p.tt) {   // an indexed gather: a transition's units on consecutive lanes
+        b = small ? (size_t)((uint32_t)gc / U) : gc / U;
+        v = (int)(gc - b * U);
+      } else {
+        // the whole trajectory in order (b = t E + e): the units whose SOURCE rows lie along the env index -- state, next state and
+        // goals are [slot][N][E][..] -- take consecutive lanes on consecutive ENVS (whole lines read; the 16- / 8-byte pieces a
+        // lane writes meet their neighbours of the same output line in the L2), the others stay transition-major.  With every
+        // lane of a transition reading its own state row the export read 4 lines for 64 bytes of them and ran at 2.4 TB/s.
+        const size_t nA = p.n * (size_t)(3 * N);
+        if (gc < nA) {
+          const size_t c = small ? (size_t)((uint32_t)gc / (uint32_t)p.n) : gc / p.n;
+          b = gc - c * p.n;
+          v = c < (size_t)(2 * N) ? (int)c : (int)c + 2 * NV;           // goals follow the observation units in the unit order
+        } else {
+          const size_t g2 = gc - nA;
+          const uint32_t UB = (uint32_t)(2 * NV + 2 * N + 2);
+          b = small ? (size_t)((uint32_t)g2 / UB) : g2 / UB;
+          const int w2 = (int)(g2 - b * UB);
+          v = w2 < 2 * NV ? 2 * N + w2 : w2 + 3 * N;                     // (2N + 2NV + N) + (w2 - 2NV)
+        }
+      }
       bb[k] = b;
-      vv[k] = g < total ? (int)(gc - b * U) : -1;
+      vv[k] = g < total ? v : -1;
       // (tt == NULL: every transition of the trajectory in time-major order, b = t E + e -- no index arrays to build or read)
       tt[k] = p.tt ? p.tt[b] : (int64_t)(small ? (size_t)((uint32_t)b / (uint32_t)p.E) : b / p.E);
       ee[k] = p.tt ? (size_t)p.ee[b] : b - (size_t)tt[k] * p.E;
@@ -396,6 +424,10 @@ int cm3_transitions_gather_f32(const cm3_particle_desc *desc, const cm3_particle
   p.o_done = out->done;
   p.o_goals = (float *)out->goals;
   p.n = (size_t)n;
+  CM3_REQUIRE(out->ring_size >= 0 && out->ring_start >= 0 && (out->ring_size == 0 || (out->ring_start < out->ring_size && n <= out->ring_size)),
+              "transition columns: ring_start / ring_size out of range (0 <= ring_start < ring_size, n <= ring_size)");
+  p.ring_start = (size_t)out->ring_start;
+  p.ring_size = (size_t)out->ring_size;
   p.E = (size_t)desc->n_envs;
   p.N = desc->n_agents;
   p.L = 4 * (desc->n_agents > 1 ? desc->n_agents - 1 : 1);

@@ -89,6 +89,25 @@ class DeviceReplayBuffer(object):
         pairs = [(self.cols[k], self._src(v, self.device)[skip:]) for k, v in cols.items()]
         _lib.rows_scatter(pairs, kept, self._stream(), ring_start=start, ring_size=self.maxsize)
 
+    def add_rollout(self, rollout):
+        """All transitions of a ParticleRollout's continuous float32 collection, straight from the trajectory into the ring: ONE
+        launch (cm3_transitions_gather_f32 with ring positions as its output rows) instead of an export followed by an add, and no
+        intermediate copy of the phase.  The reference stores the same array as v_global and v_local (train_onpolicy.py:338): so does
+        the ring (one tensor under both names)."""
+        env = rollout.env
+        B, N, L = rollout.T * env.E, env.n, env.L
+        if B > self.maxsize:                                   # (more than the ring holds: the newest survive, as sequential adds leave)
+            return self.add(rollout.as_reference_batch(numpy=False))
+        if self.cols is None:
+            z = lambda *shape, dt=torch.float32: torch.zeros((self.maxsize,) + shape, dtype=dt, device=self.device)   # noqa: E731
+            st, nst = z(N, 4), z(N, 4)
+            self.cols = dict(v_global=st, obs_others=z(N, L), v_local=st, actions=z(N, dt=torch.int32), reward=z(), reward_local=z(N),
+                             v_global_next=nst, obs_others_next=z(N, L), v_local_next=nst, done=z(dt=torch.bool), goals=z(N, 2))
+        elif self.cols["v_global"].data_ptr() != self.cols["v_local"].data_ptr():
+            return self.add(rollout.as_reference_batch(numpy=False))      # (a ring that add() allocated: separate v_local storage)
+        skip, start, kept = self.ring.plan_add(B)
+        rollout.export_into(self.cols, start, self.maxsize)
+
     def add_at(self, cols, dst_row, n_added):
         """Rows b with dst_row[b] >= 0 go to ring position dst_row[b] (int64 on the device; computed by the caller, e.g. the dual
         buffer's split); the ring advances by n_added sequential adds."""
@@ -174,8 +193,11 @@ def off_policy_batches(rollout, buffer, n_chunks, batch_size=128, generator=None
     overwritten only when it is full (replay_buffer.py:11-16)."""
     for _ in range(int(n_chunks)):
         rollout.collect(**collect_kwargs)
-        cols = rollout.as_reference_batch(numpy=False)
-        buffer.add({k: v.contiguous() for k, v in cols.items()})
+        if hasattr(rollout, "export_into") and rollout.auto_reset and rollout.state.dtype == torch.float32 and hasattr(buffer, "add_rollout"):
+            buffer.add_rollout(rollout)                                   # export + add in one launch
+        else:
+            cols = rollout.as_reference_batch(numpy=False)
+            buffer.add({k: v.contiguous() for k, v in cols.items()})
         yield buffer.sample_batch(batch_size, generator=generator)
 
 

@@ -654,6 +654,35 @@ class ParticleRollout(object):
             cols = {k: v.detach().cpu().numpy() for k, v in cols.items()}
         return cols
 
+    def export_into(self, columns, ring_start, ring_size):
+        """Every transition of the trajectory (continuous collection, float32) written straight into the rows (ring_start + b) mod
+        ring_size of `columns` -- a dict with the nine distinct tensors of as_reference_batch (v_global, obs_others, actions, reward,
+        reward_local, v_global_next, obs_others_next, done, goals), each with ring_size rows: export and replay add in ONE launch
+        (DeviceReplayBuffer.add_rollout).  Returns the number of transitions."""
+        env = self.env
+        if not (self.auto_reset and self.state.dtype == torch.float32):
+            raise Cm3Error("export_into needs a continuous float32 collection (every transition valid)")
+        B = self.T * env.E
+        traj = self._traj(0)
+        goal_slot, gs_stride = None, 0
+        if self._goals_buf is not None and self._goals_sparse:
+            if self._goal_src32 is None or self._goal_src32_of is not self._goal_source_slots():
+                self._goal_src32_of = self._goal_source_slots()
+                self._goal_src32 = self._goal_src32_of.to(torch.int32)
+            goal_slot, gs_stride = self._goal_src32, env.E * 4
+        out = _lib.TransitionCols()
+        for field, name in (("state", "v_global"), ("obs_others", "obs_others"), ("actions", "actions"), ("reward", "reward"),
+                            ("reward_n", "reward_local"), ("next_state", "v_global_next"), ("next_obs_others", "obs_others_next"),
+                            ("done", "done"), ("goals", "goals")):
+            t = columns[name]
+            if not t.is_contiguous() or t.shape[0] != ring_size:
+                raise Cm3Error("export_into: column %s must be contiguous with ring_size rows" % name)
+            setattr(out, field, t.data_ptr())
+        out.ring_start, out.ring_size = int(ring_start), int(ring_size)
+        _lib.check(self._lib.cm3_transitions_gather_f32(ctypes.byref(env._desc), ctypes.byref(traj), _lib.ptr(goal_slot), gs_stride,
+                                                        None, None, B, ctypes.byref(out), env._stream()))
+        return B
+
     def as_reference_batch_torch(self, tt, ee, numpy=True):
         """The same columns as a composition of torch indexing operations (any dtype; what the kernel path is tested against)."""
         tt = torch.as_tensor(tt, device=self.env.device, dtype=torch.long)

@@ -545,6 +545,8 @@ typedef struct cm3_transition_cols {
   void *next_obs_others;  /* float [B][N][L]   likewise */
   uint8_t *done;          /* uint8 [B] */
   void *goals;            /* float [B][N][2] */
+  int64_t ring_start;     /* ring_size > 0: the columns are REPLAY RINGS of ring_size rows and transition b is written to row */
+  int64_t ring_size;      /* (ring_start + b) mod ring_size -- export and replay_buffer.add in one launch; 0: row b */
 } cm3_transition_cols;
 /* Gathers transitions (tt[b], ee[b]), b < n, out of a time-major trajectory (the cm3_particle_traj the collector wrote: state
  * [T+1][N][E][4], obs_others [T+1][E][N][L], actions / reward_n [T][E][N], reward / done [T][E], optional term_* [T][...]) in ONE

@@ -275,3 +275,24 @@ def test_off_policy_cadence_for_particle_and_checkers():
     for name, v in last.items():
         assert torch.equal(cbuf.all()[name][n - 960:n], v), name
     cro.close()
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(sparse_goals=True, live_state=False), dict(live_state=True)])
+def test_add_rollout_is_export_plus_add_in_one_launch(kw):
+    """DeviceReplayBuffer.add_rollout (cm3_transitions_gather_f32 writing ring rows) leaves the ring exactly as
+    add(as_reference_batch()) does -- chunk after chunk, across the wrap-around."""
+    from cm3_amd.replay import DeviceReplayBuffer
+    env, ro = _rollout(E=200, N=4, T=20, **kw)
+    a, b = DeviceReplayBuffer(size=9000, device=DEV), DeviceReplayBuffer(size=9000, device=DEV)
+    for chunk in range(4):                                  # 4000 transitions per chunk: the third wraps
+        if chunk:
+            ro.collect(reset=False)
+        a.add_rollout(ro)
+        b.add(ro.as_reference_batch(numpy=False))
+        assert (len(a), a.idx) == (len(b), b.idx)
+        for name in b.cols:
+            assert torch.equal(a.all()[name], b.all()[name]), (chunk, name)
+    assert a.cols["v_global"].data_ptr() == a.cols["v_local"].data_ptr()
+    s1 = a.sample_batch(64, generator=torch.Generator(device=DEV).manual_seed(2))
+    assert s1["v_local"].shape == (64, 4, 4) and torch.equal(s1["v_local"], s1["v_global"])
+    ro.close()

@@ -120,6 +120,11 @@ def measure(device, copy_gbps=None, n_envs=4096, n_agents=4, cfg_name="particle_
     buf = DeviceReplayBuffer(size=B_all, device=device)
     s, _ = _time(lambda: buf.add(cols), device, reps=5)
     out["replay_add_phase"] = rec(s, 2 * _nbytes(cols), "DeviceReplayBuffer.add of the phase's %d transitions" % B_all)
+    buf2 = DeviceReplayBuffer(size=B_all, device=device)
+    s, _ = _time(lambda: buf2.add_rollout(ro), device, reps=5)
+    out["replay_add_rollout_phase"] = rec(s, 2 * _nbytes(cols), "DeviceReplayBuffer.add_rollout: the phase's transitions from the trajectory "
+                                          "straight into the ring, one launch (export + add)")
+    del buf2
     s, b = _time(lambda: buf.sample_batch(128, generator=g), device, reps=20)
     out["replay_sample_128"] = rec(s, 2 * _nbytes(b), "DeviceReplayBuffer.sample_batch(128)")
     bad = ro.episode_is_bad()
