@@ -296,3 +296,82 @@ def test_add_rollout_is_export_plus_add_in_one_launch(kw):
     s1 = a.sample_batch(64, generator=torch.Generator(device=DEV).manual_seed(2))
     assert s1["v_local"].shape == (64, 4, 4) and torch.equal(s1["v_local"], s1["v_global"])
     ro.close()
+
+
+def test_row_kernels_against_torch_indexing_on_random_layouts():
+    """cm3_rows_scatter / cm3_rows_gather / cm3_rows_tile (csrc/batch.hip) on random column sets -- row sizes that select the 16-, 8-,
+    4- and 1-byte copy units, more than 16 columns (two launches), negative (skipped) rows, ring wrap-around, and random
+    (divisor, modulus, multiplier) tilings of every kind -- against plain torch indexing."""
+    import ctypes
+    from cm3_amd import _lib
+    g = torch.Generator(device="cpu").manual_seed(17)
+    stream = torch.cuda.current_stream(DEV).cuda_stream
+    dtypes = [torch.float32, torch.float64, torch.int32, torch.int64, torch.uint8, torch.bool, torch.int16]
+    for trial in range(6):
+        n_cols = [3, 16, 19, 1, 7, 33][trial]
+        n_src, n_dst = int(torch.randint(50, 3000, (1,), generator=g)), int(torch.randint(50, 3000, (1,), generator=g))
+        srcs, dsts = [], []
+        for c in range(n_cols):
+            dt = dtypes[int(torch.randint(0, len(dtypes), (1,), generator=g))]
+            shape = tuple(int(x) for x in torch.randint(1, 6, (int(torch.randint(0, 3, (1,), generator=g)),), generator=g))
+            src = (torch.rand((n_src,) + shape, generator=g) * 100).to(dt).to(DEV)
+            srcs.append(src)
+            dsts.append(torch.zeros((n_dst,) + shape, dtype=dt, device=DEV))
+        # gather
+        idx = torch.randint(0, n_src, (n_dst,), generator=g).to(DEV)
+        _lib.rows_gather(list(zip(dsts, srcs)), n_dst, idx, stream)
+        for d, s in zip(dsts, srcs):
+            assert torch.equal(d, s[idx]), (trial, d.dtype, tuple(d.shape))
+        # scatter with skipped rows (distinct destinations)
+        perm = torch.randperm(n_dst, generator=g)[:min(n_src, n_dst)]
+        dst_row = torch.full((n_src,), -1, dtype=torch.int64)
+        dst_row[:perm.numel()] = perm
+        dst_row = dst_row[torch.randperm(n_src, generator=g)].to(DEV)
+        want = [d.clone() for d in dsts]
+        keep = dst_row >= 0
+        for w, s in zip(want, srcs):
+            w[dst_row[keep]] = s[keep]
+        _lib.rows_scatter(list(zip(dsts, srcs)), n_src, stream, dst_row=dst_row)
+        for d, w in zip(dsts, want):
+            assert torch.equal(d, w), (trial, d.dtype)
+        # ring positions
+        n_add = min(n_src, n_dst)
+        start = int(torch.randint(0, n_dst, (1,), generator=g))
+        pos = (start + torch.arange(n_add, device=DEV)) % n_dst
+        want = [d.clone() for d in dsts]
+        for w, s in zip(want, srcs):
+            w[pos] = s[:n_add]
+        _lib.rows_scatter([(d, s[:n_add].contiguous()) for d, s in zip(dsts, srcs)], n_add, stream, ring_start=start, ring_size=n_dst)
+        for d, w in zip(dsts, want):
+            assert torch.equal(d, w), (trial, "ring", d.dtype)
+    # tiling kinds
+    from cm3_amd.batch import _Tiler
+    for trial in range(8):
+        N = int(torch.randint(2, 9, (1,), generator=g))
+        B = int(torch.randint(1, 40, (1,), generator=g))
+        A = 5
+        x = torch.randn(B, N, 4, generator=g).to(DEV)
+        acts = torch.randint(0, A, (B, N), generator=g).to(torch.int32).to(DEV)
+        done = (torch.rand(B, generator=g) < 0.3).to(DEV)
+        t = _Tiler(torch.device(DEV))
+        R = B * N
+        rep_n = t.add(x, R * N, 4, x.dtype, _lib.TILE_COPY, terms=((N * N, 0, N), (1, N, 1)))
+        rep_m_a = t.add(x, R * N * A, 4, torch.float64, _lib.TILE_F32_TO_F64, terms=((A * N, 0, 1), (1, 0, 0)))
+        oh = t.add(acts, R, A, torch.int64, _lib.TILE_ONEHOT_I64)
+        oth = t.add(x, R * (N - 1), 4, torch.float64, _lib.TILE_F32_TO_F64, others=(N, N * (N - 1), N - 1), shape=(R, (N - 1) * 4))
+        oth_oh = t.add(acts, R * (N - 1), A, torch.float64, _lib.TILE_ONEHOT_F64, others=(N, N * (N - 1), N - 1), shape=(R, N - 1, A))
+        eye = t.add(None, R * A, A, torch.float64, _lib.TILE_EYE_F64)
+        nd = t.add(done.view(torch.uint8), R, 1, torch.int64, _lib.TILE_NOT_I64, terms=((N, 0, 1), (1, 0, 0)), shape=(R,))
+        t.run()
+        rows = x.reshape(R, 4)
+        assert torch.equal(rep_n, rows.reshape(B, N, 4).repeat_interleave(N, dim=0).reshape(-1, 4))
+        assert torch.equal(rep_m_a, rows.repeat_interleave(N, dim=0).repeat_interleave(A, dim=0).to(torch.float64))
+        assert torch.equal(oh, torch.nn.functional.one_hot(acts.long(), A).reshape(R, A))
+        idx = torch.tensor([[j for j in range(N) if j != n] for n in range(N)], device=DEV)
+        assert torch.equal(oth, x[:, idx].reshape(R, (N - 1) * 4).to(torch.float64))
+        assert torch.equal(oth_oh, torch.nn.functional.one_hot(acts.long(), A)[:, idx].reshape(R, N - 1, A).to(torch.float64))
+        assert torch.equal(eye, torch.eye(A, dtype=torch.float64, device=DEV).repeat(R, 1))
+        assert torch.equal(nd, 1 - done.repeat_interleave(N).to(torch.int64))
+    # argument checks
+    rc = _lib.RowCols()
+    assert _lib.lib().cm3_rows_gather(ctypes.byref(rc), 4, None, stream) != 0
