@@ -37,7 +37,6 @@ class _Tiler(object):
 
     def run(self):
         from . import _lib
-        import ctypes
         stream = torch.cuda.current_stream(self.device).cuda_stream
         for k in range(0, len(self.specs), 16):
             chunk = self.specs[k:k + 16]
