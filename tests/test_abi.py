@@ -190,3 +190,18 @@ def test_device_code_holds_no_packed_float32_cross_half_select():
         pytest.skip("no build objects / no llvm-objdump here (the build itself runs the lint)")
     seen, bad = isa_lint.lint(objs)
     assert seen >= 9 and not bad, bad[:5]
+
+
+def test_fault_reproducer_still_compiles(tmp_path):
+    """tools/probes/pk_opsel_mfma_repro.hip is the record of WHY the physics is built without SLP vectorisation
+    (profiles/r05_policy_fault_upstream_note.md): it must keep compiling for gfx950 with the toolchain of the image."""
+    import shutil
+    import subprocess
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc here")
+    src = os.path.join(ROOT, "tools", "probes", "pk_opsel_mfma_repro.hip")
+    out = tmp_path / "repro.o"
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-c", src, "-o", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert out.stat().st_size > 0 and shutil.which("python") is not None

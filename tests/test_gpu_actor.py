@@ -1,5 +1,7 @@
 """GPU: the device actor (cm3_amd/csrc/actor.hip) against the NumPy restatement of networks.actor_particle +
 the epsilon-mixed sampling of alg_credit.py:119-120 (oracle/actor_oracle.py)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -410,3 +412,31 @@ def test_policy_launch_per_tick_on_the_live_state_rollout(N, cfg, graph):
     assert int(a.done.sum()) >= 3 * E
     for ro, _ in outs:
         ro.close()
+
+
+def test_packed_multiply_reproducer_controls_are_clean(tmp_path):
+    """The standalone reproducer of round 5's hardware finding (tools/probes/pk_opsel_mfma_repro.hip): its CONTROL configurations --
+    no aggressor wave, and the packed multiply WITHOUT a cross-half select under the worst aggressor -- must give zero wrong
+    results on this box (if they did not, every comparison in this suite would be suspect).  The faulty form itself is run and
+    its count printed, not asserted: a fixed chip or firmware must not fail the suite."""
+    import subprocess
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "repro"
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-o", str(exe),
+                           os.path.join(root, "tools", "probes", "pk_opsel_mfma_repro.hip")])
+
+    def run(victim, aggressor):
+        out = subprocess.run([str(exe), str(victim), str(aggressor), "4000"], capture_output=True, text=True, timeout=120).stdout
+        nums = out.split("lanes 0-15 / 16-31 / 32-47 / 48-63:")[1].split("(")[0].split()
+        hi = out.split("wrong HIGH:")[1].split()
+        return [int(x) for x in nums], [int(x) for x in hi], out
+    lo, hi, _ = run(0, 0)
+    assert lo == [0, 0, 0, 0] and hi == [0, 0, 0, 0]
+    lo, hi, _ = run(2, 9)
+    assert lo == [0, 0, 0, 0] and hi == [0, 0, 0, 0]
+    lo, hi, text = run(0, 9)
+    print("v_pk_mul_f32 op_sel:[0,1] against one 32x32x16_f16 per ~64 cycles:", text.strip())
+    assert lo[:3] == [0, 0, 0]               # (only ever the last 16 lanes)
