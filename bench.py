@@ -22,7 +22,7 @@ The line:  metric = env-steps/s summed over all GPUs (max-over-ranks wall clock 
 roofline  = algorithmic bytes of the timed launches (400 B x E per launch for N=4) / the SAME wall
             clock, against the 8 TB/s HBM3E peak (the HIP-event time of the same region is reported beside it);
 cpu_baseline = the reference-shaped scalar NumPy port (oracle.particle_oracle.ParticleEnvOracle) timed on the host
-            cores of this box (rank 0, N=1 only).
+            cores of this box (rank 0, at every N; the other ranks wait at the closing barrier).
 """
 import argparse
 import ctypes
@@ -474,7 +474,7 @@ def cpu_baseline(cfg, n_agents, budget_s=12.0):
         vec.set_state(np.broadcast_to(pos0, (E, n_agents, 2)).copy(), np.zeros((E, n_agents, 2)),
                       np.broadcast_to(lm0, (E, n_agents, 2)).copy())
         t0, ticks = time.perf_counter(), 0
-        while time.perf_counter() - t0 < 3.0:
+        while time.perf_counter() - t0 < min(3.0, budget_s):
             vec.step(rng.integers(0, 5, (E, n_agents)))
             ticks += 1
         out["vectorised_numpy"] = {"value": E * ticks / (time.perf_counter() - t0), "unit": "env-steps/s", "cores": 1,
@@ -485,7 +485,7 @@ def cpu_baseline(cfg, n_agents, budget_s=12.0):
     # (plain subprocesses with a hard timeout: nothing here can hang or outlive the bench)
     try:
         procs = max(1, os.cpu_count() or 1)
-        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", cfg_name_of(cfg), str(n_agents), "3.0"]
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", cfg_name_of(cfg), str(n_agents), "%.2f" % min(3.0, budget_s)]
         env_vars = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1")
         children = [subprocess.Popen(cmd + [str(1000 + k)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env_vars)
                     for k in range(procs)]
@@ -498,8 +498,8 @@ def cpu_baseline(cfg, n_agents, budget_s=12.0):
             except Exception:
                 ch.kill()
         out["scalar_port_all_cores"] = {"value": float(sum(rates)), "unit": "env-steps/s", "cores": len(rates),
-                                        "sample": "%d processes (one per host core, os.cpu_count() = %d) x 3 s of the scalar port"
-                                                  % (len(rates), os.cpu_count() or 0)}
+                                        "sample": "%d processes (one per host core, os.cpu_count() = %d) x %.1f s of the scalar port"
+                                                  % (len(rates), os.cpu_count() or 0, min(3.0, budget_s))}
     except Exception as exc:
         out["scalar_port_all_cores"] = {"error": repr(exc)}
     return out
@@ -745,7 +745,7 @@ def compact_line(out):
         line["rccl"] = _pick(out["rccl"], ("rccl_world_size", "backend", "rccl_version", "all_reduce_ok", "p2p_all_pairs"))
     line["extras"] = EXTRAS_FILE
     # belt and braces: whatever a future key adds, the line stays under the limit -- optional groups go first
-    for k in ("rccl", "per_rank_wall_s", "collective", "policy_rollout", "other_configs"):
+    for k in ("policy_rollout", "other_configs", "collective", "per_rank_wall_s", "rccl"):
         if len(json.dumps(line)) < LINE_LIMIT:
             break
         line.pop(k, None)
@@ -823,6 +823,81 @@ def rccl_report(dist, torch, device, local_rank, world):
                          for r, row in enumerate(allp.view(world, 8).cpu().tolist())]
     rep["p2p_all_pairs"] = all(all(row["can_access_peer"][:world]) for row in rep["p2p_access"]) if n_dev >= world else False
     return rep
+
+
+def headline_record(*, world, steps, warm, K, ticks_per_step, wall_max, ev_max, per_rank, E, N, kind, mode, n_chains,
+                    fused_ticks, launches_per_tick, bytes_per_env_step, dtype_name, wl_desc, no_graph, pinned, live_state,
+                    rccl=None):
+    """The record rank 0 builds from the timed region, for ANY world size (main() calls it; tests/test_bench_line.py calls it with
+    world = 8 and recorded clocks).  `value`, `ms_per_step`, `roofline.avg_launch_us` and `roofline.achieved` come from ONE clock:
+    the max-over-ranks wall clock between the two barriers."""
+    total_env_steps = float(E) * K * world
+    value = total_env_steps / wall_max
+    launches = K / float(fused_ticks) * launches_per_tick          # step-kernel launches inside the timed region, per rank
+    launch_s = wall_max / launches                                   # time per launch (chains: launches overlap; this is rate^-1)
+    bytes_per_launch = bytes_per_env_step * E * fused_ticks / float(launches_per_tick)
+    achieved = bytes_per_launch / launch_s / 1e9
+    if kind == "particle_adv":
+        launch_desc = ("hipGraph of %d rollouts x %d ticks + their advantage steps per replay (one collection phase)"
+                       % (PHASE_EPISODES, EP_TICKS))
+    elif no_graph:
+        launch_desc = "eager launches"
+    else:
+        launch_desc = "hipGraph of %d ticks = one collection phase per replay" % PHASE_TICKS
+    kname = "k_checkers_step_fast" if kind == "checkers" else "k_particle_step(_pairs|_agents)<float,%d>" % N
+    out = {
+        "metric": "env-steps/s (all agents, whole node)", "value": value, "unit": "env-steps/s",
+        "n_gpus": world, "steps": steps, "warmup": warm, "ms_per_step": wall_max / steps * 1e3,
+        "ticks_per_step": ticks_per_step, "ticks_timed": K,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype_name,
+        "data": "synthetic (uniform random actions drawn in-kernel, Philox; preset/random resets, prob_random=0.2)",
+        "config": {"workload": "%s, %d vectorised envs per GPU, max_steps=33, auto-reset, %s mode (%s), %s"
+                               % (wl_desc, E, mode,
+                                  "every tick writes slot t+1 of a [%d+1, E, ...] device trajectory incl. terminal capture"
+                                  % ticks_per_step if mode == "trajectory" else "every tick overwrites the live buffers",
+                                  ("one step-kernel launch per tick" if n_chains == 1 else
+                                   "%d independent sub-batch chains, one launch per tick per chain" % n_chains)
+                                  if fused_ticks == 1 else "%d ticks fused per launch (random-action branch)" % fused_ticks),
+                   "envs_per_gpu": E, "n_agents": N, "global_envs": E * world, "mode": mode, "chains": n_chains,
+                   "launch": launch_desc, "ticks_per_launch": fused_ticks, "live_state": live_state,
+                   "step_definition": ("one 33-tick rollout + advantage normalisation" if kind == "particle_adv" else
+                                       "one collection phase = %d episodes x %d ticks (train_onpolicy.py:359-377)"
+                                       % (PHASE_EPISODES, EP_TICKS)),
+                   "parallelism": ("env-sharded x%d, one 24-byte moments all-gather (RCCL) per rollout" % world
+                                   if kind == "particle_adv" else "env-sharded x%d, no data-path collective" % world)},
+        "agent_steps_per_s": value * N,
+        "us_per_tick": wall_max / K * 1e6,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel": kname,
+                     "algorithmic_bytes_per_launch": bytes_per_launch,
+                     "avg_launch_us": launch_s * 1e6,
+                     "avg_launch_us_hip_events": ev_max / launches * 1e6,
+                     "per": "GPU: one rank's launch moves algorithmic_bytes_per_launch; every rank does the same work (weak scaling)",
+                     "clock": "wall clock of the timed region (max over ranks) for value, avg_launch_us and achieved alike; "
+                              "avg_launch_us_hip_events = HIP events on the launch stream around the same region"},
+        "per_rank": [{"rank": r, "wall_s": w_, "avg_launch_us": w_ / launches * 1e6,
+                      "avg_launch_us_hip_events": e_ / launches * 1e6, "env_id_base": r * E, "envs": E}
+                     for r, (w_, e_) in enumerate(per_rank)],
+        "rank0_host_affinity": pinned,
+    }
+    if rccl is not None:
+        out["rccl"] = rccl
+        out["rccl_world_size"] = rccl["rccl_world_size"]
+    return out
+
+
+def rank0_baselines(out, kind, cfg, N, world, device, no_cpu_baseline=False, measure_bw=None, cpu_budget_s=None):
+    """What rank 0 adds to the record at EVERY world size (round 6: a multi-GPU line without these was ungradeable): the read /
+    copy bandwidth measured on rank 0's GPU -- the denominator of `frac_of_measured_read` -- and the CPU baseline, a bounded sample
+    of the same workload on rank 0's host cores while the other ranks wait at the closing barrier (world > 1: a shorter sample)."""
+    bw_read, bw_copy = (measure_bw or measure_bandwidth)(device)
+    r = out["roofline"]
+    r["measured_read_GBps"], r["measured_copy_GBps"] = bw_read, bw_copy
+    r["frac_of_measured_read"] = r["achieved"] / bw_read
+    if not no_cpu_baseline:
+        budget = cpu_budget_s if cpu_budget_s is not None else (12.0 if world == 1 else 8.0)
+        out["cpu_baseline"] = cpu_baseline_checkers(cfg, budget_s=budget) if kind == "checkers" else cpu_baseline(cfg, N, budget_s=budget)
+    return bw_read, bw_copy
 
 
 def build_headline(args, kind, cfg, N, E, device, rank, n_chains):
@@ -972,62 +1047,18 @@ def main():
     wall_max, ev_max = float(t[0]), float(t[1])
     rccl = rccl_report(dist, torch, device, local_rank, world) if use_dist else None    # (every rank takes part; rank 0 prints it)
 
-    total_env_steps = float(E) * K * world
-    value = total_env_steps / wall_max                       # ONE clock for the metric and the roofline: the wall clock
     fused_ticks = ticks_per_step if (args.fused and kind != "particle_adv") else 1
-    launches = K / float(fused_ticks) * stepper.launches_per_tick     # step-kernel launches inside the timed region
-    launch_s = wall_max / launches                           # time per launch (chains: launches overlap; this is rate^-1)
+    # (the extras below quote the headline's time and bytes per launch; headline_record() derives the same from the same clock)
+    launch_s = wall_max / (K / float(fused_ticks) * stepper.launches_per_tick)
     bytes_per_launch = bytes_per_env_step * E * fused_ticks / float(stepper.launches_per_tick)
-    achieved = bytes_per_launch / launch_s / 1e9
 
     out = None
     if rank == 0:
-        if kind == "particle_adv":
-            launch_desc = ("hipGraph of %d rollouts x %d ticks + their advantage steps per replay (one collection phase)"
-                           % (PHASE_EPISODES, EP_TICKS))
-        elif args.no_graph:
-            launch_desc = "eager launches"
-        else:
-            launch_desc = "hipGraph of %d ticks = one collection phase per replay" % PHASE_TICKS
-        kname = "k_checkers_step_fast" if kind == "checkers" else "k_particle_step(_pairs|_agents)<float,%d>" % N
-        out = {
-            "metric": "env-steps/s (all agents, whole node)", "value": value, "unit": "env-steps/s",
-            "n_gpus": world, "steps": steps, "warmup": warm, "ms_per_step": wall_max / steps * 1e3,
-            "ticks_per_step": ticks_per_step, "ticks_timed": K,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype_name,
-            "data": "synthetic (uniform random actions drawn in-kernel, Philox; preset/random resets, prob_random=0.2)",
-            "config": {"workload": "%s, %d vectorised envs per GPU, max_steps=33, auto-reset, %s mode (%s), %s"
-                                   % (wl_desc, E, mode,
-                                      "every tick writes slot t+1 of a [%d+1, E, ...] device trajectory incl. terminal capture"
-                                      % ticks_per_step if mode == "trajectory" else "every tick overwrites the live buffers",
-                                      ("one step-kernel launch per tick" if n_chains == 1 else
-                                       "%d independent sub-batch chains, one launch per tick per chain" % n_chains)
-                                      if fused_ticks == 1 else "%d ticks fused per launch (random-action branch)" % fused_ticks),
-                       "envs_per_gpu": E, "n_agents": N, "global_envs": E * world, "mode": mode, "chains": n_chains,
-                       "launch": launch_desc, "ticks_per_launch": fused_ticks,
-                       "live_state": bool(getattr(getattr(stepper, "ro", None), "_live", False)),
-                       "step_definition": ("one 33-tick rollout + advantage normalisation" if kind == "particle_adv" else
-                                           "one collection phase = %d episodes x %d ticks (train_onpolicy.py:359-377)"
-                                           % (PHASE_EPISODES, EP_TICKS)),
-                       "parallelism": ("env-sharded x%d, one 24-byte moments all-gather (RCCL) per rollout" % world
-                                       if kind == "particle_adv" else "env-sharded x%d, no data-path collective" % world)},
-            "agent_steps_per_s": value * N,
-            "us_per_tick": wall_max / K * 1e6,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel": kname,
-                         "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "avg_launch_us": launch_s * 1e6,
-                         "avg_launch_us_hip_events": ev_max / launches * 1e6,
-                         "clock": "wall clock of the timed region (max over ranks) for value, avg_launch_us and achieved alike; "
-                                  "avg_launch_us_hip_events = HIP events on the launch stream around the same region"},
-            "per_rank": [{"rank": r, "wall_s": w_, "avg_launch_us": w_ / launches * 1e6,
-                          "avg_launch_us_hip_events": e_ / launches * 1e6, "env_id_base": r * E, "envs": E}
-                         for r, (w_, e_) in enumerate(per_rank)],
-            "rank0_host_affinity": pinned,
-        }
-        if rccl is not None:
-            out["rccl"] = rccl
-            out["rccl_world_size"] = rccl["rccl_world_size"]
+        out = headline_record(world=world, steps=steps, warm=warm, K=K, ticks_per_step=ticks_per_step, wall_max=wall_max,
+                              ev_max=ev_max, per_rank=per_rank, E=E, N=N, kind=kind, mode=mode, n_chains=n_chains,
+                              fused_ticks=fused_ticks, launches_per_tick=stepper.launches_per_tick,
+                              bytes_per_env_step=bytes_per_env_step, dtype_name=dtype_name, wl_desc=wl_desc, no_graph=args.no_graph,
+                              pinned=pinned, live_state=bool(getattr(getattr(stepper, "ro", None), "_live", False)), rccl=rccl)
         if kind == "particle_adv":
             out["collective"] = {
                 "what": "all_gather_into_tensor of 3 float64 per rank and rollout (advantage moments); the %d rollouts of a phase "
@@ -1267,11 +1298,13 @@ def main():
         out["other_configs"]["note"] = ("each: the workload's own BASELINE configuration through the product's collector, 20 hipGraph "
                                         "replays (collection phases) after 5 warm-up ones as the headline, same clock; "
                                         "`python bench.py --workload cN` runs it as the headline with its extras")
+    if rank == 0 and world > 1:
+        if stepper is not None:
+            stepper.close()
+            stepper = None
+        rank0_baselines(out, kind, cfg, N, world, device, args.no_cpu_baseline)
     if world == 1 and rank == 0:
-        bw_read, bw_copy = measure_bandwidth(device)
-        out["roofline"]["measured_read_GBps"] = bw_read
-        out["roofline"]["measured_copy_GBps"] = bw_copy
-        out["roofline"]["frac_of_measured_read"] = achieved / bw_read
+        bw_read, bw_copy = rank0_baselines(out, kind, cfg, N, world, device, no_cpu_baseline=True)   # (CPU baseline: last, below)
         if kind in ("particle", "checkers") and extras:
             # What one launch per tick cannot go below at this batch: the same number of 256-lane workgroups reading and
             # writing the same algorithmic bytes with NO arithmetic (load -> store skeleton), and an empty launch, both
