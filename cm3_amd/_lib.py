@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # CM3_AMD_LIB: load another build of the SAME ABI instead (tools/*_ab.py compare two builds on one box)
 LIB_PATH = os.environ.get("CM3_AMD_LIB") or os.path.join(_HERE, "libcm3_hip.so")
 MAX_AGENTS = 10
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 FLAG_AUTO_RESET = 1
 FLAG_GEN_ACTIONS = 2
@@ -187,6 +187,8 @@ SYMBOLS = {
     "cm3_rows_tile": (ctypes.c_int, [P(TileCol), c_int32, c_void_p]),
     "cm3_actor_checkers_packed_bytes": (c_size_t, []),
     "cm3_actor_checkers_pack": (ctypes.c_int, [P(ActorCheckersDesc), P(ActorCheckersWeights), c_void_p, c_void_p]),
+    "cm3_policy_rollout_checkers": (ctypes.c_int, [P(CheckersDesc), P(CheckersTraj), P(ActorCheckersDesc), P(ActorCheckersWeights),
+                                                   c_void_p, c_void_p, c_size_t, c_void_p, c_int32, c_void_p]),
     "cm3_actor_checkers_f32": (ctypes.c_int, [P(ActorCheckersDesc), P(ActorCheckersWeights), P(ActorCheckersBufs),
                                               c_void_p]),
     "cm3_returns_scratch_bytes": (c_size_t, []),

@@ -223,6 +223,22 @@ class CheckersActor(object):
         s = _lib.current_stream_handle(self.device) if stream is None else stream
         _lib.check(self._lib.cm3_actor_checkers_f32(ctypes.byref(d), ctypes.byref(self._wt), ctypes.byref(b), s))
 
+    def enqueue_rollout(self, env_desc, traj, n_envs, obst_stride, n_ticks, epsilon, prev0=None, probs=None, stream=None):
+        """The whole policy-driven rollout in ONE launch (cm3_policy_rollout_checkers): env_desc / traj are the env's descriptor and
+        the rollout's trajectory struct; probs: optional float32 [T, E, N, 5]."""
+        epsilon, eps_dev = _epsilon_args(epsilon)
+        d = self._desc(n_envs, epsilon, env_desc.env_id_base, obst_stride)
+        s = _lib.current_stream_handle(self.device) if stream is None else stream
+        _lib.check(self._lib.cm3_policy_rollout_checkers(
+            ctypes.byref(env_desc), ctypes.byref(traj), ctypes.byref(d), ctypes.byref(self._wt), _lib.ptr(prev0), _lib.ptr(probs),
+            0 if probs is None else probs[0].numel() * probs.element_size(), eps_dev, int(n_ticks), s))
+
+    def fused_rollout_ok(self, env):
+        """cm3_policy_rollout_checkers covers the reference's configurations: split-float16 actor, one agent at stage 1 or two at
+        stage 2, the 3 x 8 band with n_obs 2."""
+        return (self.precision == "f16x3" and env.n == self.n and env.n in (1, 2) and (self.stage > 1) == (env.n > 1)
+                and env.K == 5 and env.R == 3 and env.C == 8 and env.grid_stride % 4 == 0 and env.obst_stride % 4 == 0)
+
     def act(self, env, epsilon, actions_prev=None, return_probs=False):
         """Actions [E, N] int32 for the env's CURRENT observation (alg.run_actor); actions_prev None = zeros
         (train_onpolicy.py:295)."""

@@ -81,6 +81,10 @@ constexpr int kXOthL = kXOthH + kKOthX * kH1 / 2;
 constexpr int kXOutH = kXOthL + kKOthX * kH1 / 2;
 constexpr int kXOutL = kXOutH + kH2 * 16 / 2;
 constexpr int kPTotal = kXOutL + kH2 * 16 / 2;
+// two agents, stage 2: h2's accumulators after the others branch for each of the 7 x 13 cells the other agent can stand on
+// (k_ck_actor_others_table; float32 [96][256], rows 91..95 unused)
+constexpr int kPOthTab = kPTotal;
+constexpr int kPAll = kPOthTab + 96 * kH2;
 // float16 LDS planes of precision = 2: row strides in halfwords, K + 8 (= 4 x odd words: conflict-free 16-byte A reads)
 constexpr int kLhX0 = kKConvX + 8, kLhC1 = kNConv + 8, kLhX2 = kKSelfX + 8, kLhXO = kKOthX + 8;
 constexpr int kLdHb = kH1 + 8;  // bf16 / f16 activation row: 264 halfwords = 528 B (= 4 mod 64 words, 16-byte aligned rows)
@@ -118,6 +122,7 @@ __device__ __forceinline__ float ck_conv_toeplitz(const CkActorParams &p, int k,
   return p.conv_w[((dr * 3 + dc) * 3 + ch) * kConvF + f];
 }
 
+#ifndef CM3_NO_ENTRY_POINTS   // (non-template kernels: one definition per library; policy_checkers.hip includes this file for the device functions)
 __global__ void __launch_bounds__(256) k_ck_actor_pack(const CkActorParams p, float *out) {
   using namespace ck_actor;
   const bool stage2 = p.stage > 1;
@@ -232,6 +237,8 @@ __global__ void __launch_bounds__(256) k_ck_actor_pack(const CkActorParams p, fl
     out[t] = v;
   }
 }
+
+#endif  // CM3_NO_ENTRY_POINTS
 
 // ---- the tile loop -----------------------------------------------------------------------------------------------------
 // acc[t][c] += A[16 (rt0 + t) .. +16][0 .. 16 KG) x B[.., 16 (ct0 + c) .. +16].  A: LDS, row stride lda floats;
@@ -376,6 +383,24 @@ __device__ __forceinline__ void gemm_tiles_bf16(const __bf16 *A, int lda, const 
 // accumulation.  Activations and weights are split x = hi + lo with hi = (float16)x, lo = (float16)(x - hi): 22 of float32's 24
 // significand bits per factor, the error class of the exact-f32 path (tests hold the same 2e-5) at 16/3 of its MFMA rate.
 // softmax (networks.py:576), epsilon mix (alg_credit_checkers.py:112), sampling (:113): lane l < 16 takes row 16w + l
+// pr = (1 - eps) softmax(logits) + eps / 5 (networks.py:576, alg_credit_checkers.py:112) -- one definition for the stand-alone actor and
+// the whole-episode kernel (same bits)
+__device__ __forceinline__ void ck_actor_probs(const float (&logits)[kA], float eps, float (&pr)[kA]) {
+  float o[kA];
+  float m = logits[0];
+#pragma unroll
+  for (int a = 1; a < kA; ++a) m = fmaxf(m, logits[a]);
+  float sum = 0.0f;
+#pragma unroll
+  for (int a = 0; a < kA; ++a) {
+    o[a] = expf(logits[a] - m);
+    sum += o[a];
+  }
+  const float inv = 1.0f / sum;
+#pragma unroll
+  for (int a = 0; a < kA; ++a) pr[a] = (1.0f - eps) * (o[a] * inv) + eps / (float)kA;
+}
+
 __device__ __forceinline__ void ck_actor_head(const CkActorParams &p, const float (*sLG)[8], int w, int lane, size_t row_base,
                                               size_t rows) {
   const int N = p.N;
@@ -385,19 +410,7 @@ __device__ __forceinline__ void ck_actor_head(const CkActorParams &p, const floa
       float o[kA], pr[kA];
 #pragma unroll
       for (int a = 0; a < kA; ++a) o[a] = sLG[16 * w + lane][a];
-      float m = o[0];
-#pragma unroll
-      for (int a = 1; a < kA; ++a) m = fmaxf(m, o[a]);
-      float sum = 0.0f;
-#pragma unroll
-      for (int a = 0; a < kA; ++a) {
-        o[a] = expf(o[a] - m);
-        sum += o[a];
-      }
-      const float inv = 1.0f / sum;
-      const float eps = p.eps_dev ? *p.eps_dev : p.eps;
-#pragma unroll
-      for (int a = 0; a < kA; ++a) pr[a] = (1.0f - eps) * (o[a] * inv) + eps / (float)kA;
+      ck_actor_probs(o, p.eps_dev ? *p.eps_dev : p.eps, pr);
       const size_t e = row / N;
       const int i = (int)(row - e * N);
       const int act = actor_sample(pr, p.seed, (uint64_t)(p.env_id_base + (int64_t)e), (uint32_t)p.episode[e], p.steps[e], i);
@@ -617,12 +630,20 @@ template <bool BF16> __global__ void CM3_MATRIX_KERNEL k_ck_actor(const CkActorP
 // 23.3; every step in profiles/r03_checkers_actor_split_precision.txt).  Same tile loop for every layer: A from float16 hi / lo LDS planes, B from the packed hi / lo
 // tiles, three MFMAs per (row tile, column tile, k-step of 32) -- two where the activations are exact in float16 (the window
 // bytes are -1 / 0 / 1: no lo plane).
+// (probe builds only, tools/r6: -DCM3_PROBE_B_L1 makes every weight request of the split-float16 kernel hit ONE 1 KB block -- an L1
+// hit -- to tell the L2 -> L1 delivery of the 770 KB of weights apart from everything else; never defined in the product build)
+#ifdef CM3_PROBE_B_L1
+__device__ int cm3_probe_zero = 0;   // (a run-time zero: a literal one lets the compiler merge the MFMAs of column tiles that now read the same weights)
+#define CM3_PROBE_BIDX(x) ((x) * cm3_probe_zero)
+#else
+#define CM3_PROBE_BIDX(x) (x)
+#endif
 template <int CT, int KS>
 __device__ __forceinline__ void load_bx(const float *Bh, const float *Bl, int ct0, int lane, uint4 (&b0)[2][CT]) {
 #pragma unroll
   for (int c = 0; c < CT; ++c) {
-    b0[0][c] = (reinterpret_cast<const uint4 *>(Bh) + ((size_t)(ct0 + c) * KS) * 64 + lane)[0];
-    b0[1][c] = (reinterpret_cast<const uint4 *>(Bl) + ((size_t)(ct0 + c) * KS) * 64 + lane)[0];
+    b0[0][c] = (reinterpret_cast<const uint4 *>(Bh) + CM3_PROBE_BIDX((size_t)(ct0 + c) * KS) * 64 + lane)[0];
+    b0[1][c] = (reinterpret_cast<const uint4 *>(Bl) + CM3_PROBE_BIDX((size_t)(ct0 + c) * KS) * 64 + lane)[0];
   }
 }
 
@@ -637,8 +658,8 @@ __device__ __forceinline__ void gemm_x3(const _Float16 *Ah, const _Float16 *Al, 
   const uint4 *bsrc[2][CT];
 #pragma unroll
   for (int c = 0; c < CT; ++c) {
-    bsrc[0][c] = reinterpret_cast<const uint4 *>(Bh) + ((size_t)(ct0 + c) * KS) * 64 + lane;
-    bsrc[1][c] = reinterpret_cast<const uint4 *>(Bl) + ((size_t)(ct0 + c) * KS) * 64 + lane;
+    bsrc[0][c] = reinterpret_cast<const uint4 *>(Bh) + CM3_PROBE_BIDX((size_t)(ct0 + c) * KS) * 64 + lane;
+    bsrc[1][c] = reinterpret_cast<const uint4 *>(Bl) + CM3_PROBE_BIDX((size_t)(ct0 + c) * KS) * 64 + lane;
   }
   // weights of k-step st + 2 are requested before the MFMAs of step st issue (a ring of three: one step of MFMAs, 768 cycles for
   // the 4 x 4 tiles, is shorter than the L2 round trip of a lone workgroup)
@@ -648,8 +669,8 @@ __device__ __forceinline__ void gemm_x3(const _Float16 *Ah, const _Float16 *Al, 
     bq[0][0][c] = b0[0][c];
     bq[0][1][c] = b0[1][c];
     if (KS > 1) {
-      bq[1][0][c] = bsrc[0][c][64];
-      bq[1][1][c] = bsrc[1][c][64];
+      bq[1][0][c] = bsrc[0][c][CM3_PROBE_BIDX(64)];
+      bq[1][1][c] = bsrc[1][c][CM3_PROBE_BIDX(64)];
     }
   }
 #pragma unroll
@@ -657,8 +678,8 @@ __device__ __forceinline__ void gemm_x3(const _Float16 *Ah, const _Float16 *Al, 
     if (st + 2 < KS) {
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
-        bq[(st + 2) % 3][0][c] = bsrc[0][c][(st + 2) * 64];
-        bq[(st + 2) % 3][1][c] = bsrc[1][c][(st + 2) * 64];
+        bq[(st + 2) % 3][0][c] = bsrc[0][c][CM3_PROBE_BIDX((st + 2) * 64)];
+        bq[(st + 2) % 3][1][c] = bsrc[1][c][CM3_PROBE_BIDX((st + 2) * 64)];
       }
     }
     f16x8 ah[RT], al[RT];
@@ -729,33 +750,149 @@ __device__ __forceinline__ void put_split(_Float16 *h, _Float16 *l, int at, floa
   l[at] = (_Float16)(v - (float)vh);
 }
 
-__global__ void CM3_MATRIX_KERNEL k_ck_actor_x3(const CkActorParams p) {
+// LDS of the split-float16 forward pass: float16 hi | lo planes.  H [64][264] holds, one after the other, branch_others, C1 (the
+// conv's output, [64][168]), branch_self and h2; X0 (the window bytes, exact in float16: hi only), X2 (conv_linear | tail) and XO
+// (v_obs_others) have storage of their own.
+struct CkX3Planes {
+  _Float16 *Hh, *Hl, *X0, *C1h, *C1l, *X2h, *X2l, *XOh, *XOl;
+  float (*LG)[8];
+};
+constexpr int kCkX3HBytes = 2 * 64 * ck_actor::kLdHb * 2, kCkX3X0Bytes = 64 * ck_actor::kLhX0 * 2,
+              kCkX3X2Bytes = 2 * 64 * ck_actor::kLhX2 * 2, kCkX3XOBytes = 2 * 64 * ck_actor::kLhXO * 2;
+static_assert(2 * 64 * ck_actor::kLhC1 * 2 <= kCkX3HBytes, "the C1 planes must fit into the H storage");
+
+// ---- the forward pass of a 512-thread workgroup (8 waves: two per SIMD) that owns 64 agent rows --------------------------------------
+// Round 3's kernel ran 4 waves, one per SIMD, alone on its CU (98 KB of LDS): 16 k of its 49.5 k cycles on the matrix cores.  With 8
+// waves every layer's output tiles split eight ways (a wave's MFMAs, LDS reads and weight loads halve, the SIMD's other wave fills its
+// waits); each column tile still belongs to ONE wave, so the weights cross the CU's L1 once per workgroup.  Measured, same box: 23.5 ->
+// 22.7 us per launch at 16 384 rows, same bits (profiles/r06_checkers_policy.txt) -- the h2 passes are MFMA-bound now (19 cycles per
+// matrix instruction per SIMD), the rest of the launch is the serial chain of small layers.
+//   tiles (16 x 16) per layer:   conv 4 x 10   lin 4 x 2   branch_self / branch_others / h2 4 x 16   out 4 x 1
+//   per wave:                    conv 1 x 5    lin 1 x 1   4 x 2 (all rows, 32 units)              out: waves 0..3
+// ORDER (round 6): the others branch goes FIRST -- h2's accumulators start with branch_others W_others_h2 (k ascending) and the
+// branch_self terms follow -- so that what the others branch contributes is the accumulators' state after ck_x3_others(): a pure
+// function of a row's v_obs_others.  The whole-episode kernel (policy_checkers.hip) reads that state from a table instead
+// (cm3_actor_checkers_pack builds it with this very function over the 91 cells another agent can stand on), bit for bit.
+constexpr int kCkBCT = 2;   // column tiles per wave in the 256-wide layers
+
+// h2 accumulators <- branch_others W_others_h2.  Reads XO, uses the H planes.  Enter with XO visible to the workgroup; leaves BEHIND a
+// barrier: the H planes are free.
+__device__ __forceinline__ void ck_x3_others(const CkX3Planes &L, const float *pk, int w, int lane, f32x4 (&acc2)[4][kCkBCT]) {
   using namespace ck_actor;
-  // H planes [64][264] hi | lo (first-layer activations, then h2); before that the same storage holds X0 (hi only) and C1 hi | lo
-  __shared__ __attribute__((aligned(16))) _Float16 sH[2 * 64 * kLdHb];
-  __shared__ __attribute__((aligned(16))) _Float16 sX2[2 * 64 * kLhX2];
-  __shared__ __attribute__((aligned(16))) _Float16 sXO[2 * 64 * kLhXO];
-  __shared__ float sLG[64][8];
-  _Float16 *sHh = sH, *sHl = sH + 64 * kLdHb;
-  _Float16 *sX0 = sH, *sC1h = sH + 64 * kLhX0, *sC1l = sC1h + 64 * kLhC1;
-  _Float16 *sX2h = sX2, *sX2l = sX2 + 64 * kLhX2, *sXOh = sXO, *sXOl = sXO + 64 * kLhXO;
-  static_assert(64 * kLhX0 + 2 * 64 * kLhC1 <= 2 * 64 * kLdHb, "X0 and the C1 planes must fit into the H storage");
-  // One workgroup per CU, i.e. one wave per SIMD: gemm_x3 feeds the activations as the B operand and reloads them from LDS inside
-  // its k loop -- the pattern that produced wrong rows in the particle actor's second layer once two workgroups shared a CU
-  // (actor.hip, phase B; profiles/r04_policy_head.txt (9)).  Shrinking this kernel's LDS below half a CU's must come with the
-  // operands swapped back or with that cause found.
-  static_assert(sizeof(sH) + sizeof(sX2) + sizeof(sXO) > 80 * 1024, "k_ck_actor_x3 relies on being alone on its CU");
+  constexpr int BCT = kCkBCT;
+  uint4 b_oth[2][BCT], b_h2[2][BCT];
+  float4 bias_oth[BCT];
+  load_bx<BCT, 1>(pk + kXOthH, pk + kXOthL, BCT * w, lane, b_oth);
+  load_bias4<BCT>(pk + kPOthB, BCT * w, lane, bias_oth);
+  {
+    f32x4 acc[4][BCT];
+    zero_tiles(acc);
+    gemm_x3<4, BCT, 1, true>(L.XOh, L.XOl, kLhXO, 0, pk + kXOthH, pk + kXOthL, BCT * w, lane, b_oth, acc);
+    load_bx<BCT, 8>(pk + kPH2Oh, pk + kPH2Ol, BCT * w, lane, b_h2);
+    store_relu_x3<4, BCT>(L.Hh, L.Hl, kLdHb, 0, BCT * w, bias_oth, lane, acc);
+  }
+  __syncthreads();
+  CM3_STAMP(8, false);
+  gemm_x3<4, BCT, 8, true>(L.Hh, L.Hl, kLdHb, 0, pk + kPH2Oh, pk + kPH2Ol, BCT * w, lane, b_h2, acc2);
+  CM3_STAMP(9, true);
+  __syncthreads();
+}
 
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+// conv -> conv_linear -> branch_self -> h2 (+= on acc2) -> actor_out.  Enter with X0 and the tail of X2 visible and the H planes free;
+// b_conv: the conv's first weights, requested by the caller ahead of time.  Leaves the workgroup BEHIND its last barrier with the
+// logits of rows [16w, 16w + 16) written by wave w < 4 (not yet visible to other waves).
+// TABLE (the whole-episode kernel, two agents): acc2 is not an input -- it starts from the rows of the others-branch table
+// (k_ck_actor_others_table) named by cells[agent row], requested when branch_self begins (32 registers that need not live through
+// conv and conv_linear); stage 1 passes cells = NULL: zeros.
+template <bool TABLE = false>
+__device__ __forceinline__ void ck_x3_self_chain(const CkX3Planes &L, const float *pk, int w, int lane, const uint4 (&b_conv)[2][5],
+                                                 f32x4 (&acc2)[4][kCkBCT], const int32_t *cells = nullptr) {
+  using namespace ck_actor;
+  constexpr int BCT = kCkBCT;
+  const int s_rt0 = w & 3, s_half = w >> 2;
+  uint4 b_lin[2][1], b_self[2][BCT], b_h2[2][BCT], b_out[2][1];
+  // ---- conv (Toeplitz): X0 [64][96] -> C1 [64][160], relu ------------------------------------------------------------------------
+  {
+    f32x4 acc[1][5];
+    float4 bias[5];
+    load_bias4<5>(pk + kPConvB, 5 * s_half, lane, bias);
+    zero_tiles(acc);
+    gemm_x3<1, 5, kKConvX / 32, false>(L.X0, L.X0, kLhX0, s_rt0, pk + kXConvH, pk + kXConvL, 5 * s_half, lane, b_conv, acc);
+    load_bx<1, kKLin / 32>(pk + kXLinH, pk + kXLinL, s_half, lane, b_lin);
+    store_relu_x3<1, 5>(L.C1h, L.C1l, kLhC1, s_rt0, 5 * s_half, bias, lane, acc);
+  }
+  __syncthreads();
+  CM3_STAMP(3, false);
+  // ---- conv_linear: C1 [64][160] -> X2[:, 0:32], relu ---------------------------------------------------------------------------
+  {
+    f32x4 acc[1][1];
+    float4 bias[1];
+    load_bias4<1>(pk + kPLinB, s_half, lane, bias);
+    zero_tiles(acc);
+    gemm_x3<1, 1, kKLin / 32, true>(L.C1h, L.C1l, kLhC1, s_rt0, pk + kXLinH, pk + kXLinL, s_half, lane, b_lin, acc);
+    load_bx<BCT, kKSelfX / 32>(pk + kXSelfH, pk + kXSelfL, BCT * w, lane, b_self);
+    store_relu_x3<1, 1>(L.X2h, L.X2l, kLhX2, s_rt0, s_half, bias, lane, acc);
+  }
+  __syncthreads();
+  CM3_STAMP(4, false);
+  if constexpr (TABLE) {
+    if (cells) {
+      const float *tab = pk + kPOthTab;
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        const int cell = cells[16 * tt + (lane & 15)];
+#pragma unroll
+        for (int c = 0; c < BCT; ++c) {
+          const float4 v = *reinterpret_cast<const float4 *>(tab + (size_t)cell * kH2 + 16 * (BCT * w + c) + 4 * (lane >> 4));
+          acc2[tt][c] = f32x4{v.x, v.y, v.z, v.w};
+        }
+      }
+    } else {
+      zero_tiles(acc2);
+    }
+  }
+  // ---- branch_self: X2 [64][64] -> H [64][256], relu; wave w owns units [32w, 32w + 32) from here on ---------------------------------
+  {
+    f32x4 acc[4][BCT];
+    float4 bias[BCT];
+    load_bias4<BCT>(pk + kPSelfB, BCT * w, lane, bias);
+    zero_tiles(acc);
+    gemm_x3<4, BCT, kKSelfX / 32, true>(L.X2h, L.X2l, kLhX2, 0, pk + kXSelfH, pk + kXSelfL, BCT * w, lane, b_self, acc);
+    load_bx<BCT, 8>(pk + kPH2Sh, pk + kPH2Sl, BCT * w, lane, b_h2);
+    store_relu_x3<4, BCT>(L.Hh, L.Hl, kLdHb, 0, BCT * w, bias, lane, acc);
+  }
+  __syncthreads();
+  CM3_STAMP(5, false);
+  // ---- h2 = relu(branch_others W_others_h2 [already in acc2] + branch_self W_self_h2 + b) -----------------------------------------
+  gemm_x3<4, BCT, 8, true>(L.Hh, L.Hl, kLdHb, 0, pk + kPH2Sh, pk + kPH2Sl, BCT * w, lane, b_h2, acc2);
+  float4 bias_h2[BCT];
+  load_bias4<BCT>(pk + kPH2B, BCT * w, lane, bias_h2);
+  load_bx<1, 8>(pk + kXOutH, pk + kXOutL, 0, lane, b_out);
+  CM3_STAMP(6, true);
+  __syncthreads();  // every wave is done reading branch_self
+  CM3_STAMP(10, false);
+  store_relu_x3<4, BCT>(L.Hh, L.Hl, kLdHb, 0, BCT * w, bias_h2, lane, acc2);
+  __syncthreads();
+  CM3_STAMP(11, false);
+  // ---- actor_out: wave w < 4 finishes agent rows [16w, 16w + 16); transposed tile: lane (row l & 15) holds logits 4 (l >> 4) + reg ------
+  if (w < 4) {
+    f32x4 acc[1][1];
+    zero_tiles(acc);
+    gemm_x3<1, 1, 8, true>(L.Hh, L.Hl, kLdHb, w, pk + kXOutH, pk + kXOutL, 0, lane, b_out, acc);
+    const int col = lane & 15, hi = lane >> 4;
+    if (hi < 2) {
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) L.LG[16 * w + col][4 * hi + reg] = acc[0][0][reg] + pk[kPOutB + 4 * hi + reg];
+    }
+  }
+}
+
+// Staging of the stand-alone actor kernel's inputs from the env's output buffers, by threads tid < 256 (four lanes per agent row):
+// every global load is issued first, the zero fills run while they are in flight, then the scatter.
+__device__ __forceinline__ void ck_x3_stage_inputs(const CkActorParams &p, const CkX3Planes &L, int tid, size_t row_base, size_t rows) {
+  using namespace ck_actor;
   const int N = p.N;
-  const size_t rows = (size_t)p.E * N;
-  const size_t row_base = (size_t)blockIdx.x * 64;
-  const float *pk = p.packed;
-  CM3_STAMP(0, false);
-
-  uint4 b_conv[2][5];
-  load_bx<5, kKConvX / 32>(pk + kXConvH, pk + kXConvL, 5 * (w >> 1), lane, b_conv);
+  _Float16 *sX0 = L.X0, *sX2h = L.X2h, *sX2l = L.X2l, *sXOh = L.XOh, *sXOl = L.XOl;
   // ---- stage the inputs: every global load is issued first, the zero fills run while they are in flight, then the scatter ----------
   // (a lone workgroup per CU hides nothing: staged one dependent load after the other this phase was a fifth of the launch)
   // fast path: N a power of two <= 64 (the 64 rows are whole envs), dword-aligned env records, and 4 N lanes per env cover a
@@ -872,95 +1009,92 @@ __global__ void CM3_MATRIX_KERNEL k_ck_actor_x3(const CkActorParams p) {
       sX0[r * kLhX0 + k] = k < kObs ? (_Float16)(float)p.obs_self_t[e * (size_t)p.obst_stride + (size_t)i * kObs + k] : (_Float16)0.0f;
     }
   }
+}
+
+#ifndef CM3_NO_ENTRY_POINTS
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) k_ck_actor_x3(const CkActorParams p) {
+  using namespace ck_actor;
+  __shared__ __attribute__((aligned(16))) _Float16 sH[kCkX3HBytes / 2];
+  __shared__ __attribute__((aligned(16))) _Float16 sX0[kCkX3X0Bytes / 2];
+  __shared__ __attribute__((aligned(16))) _Float16 sX2[kCkX3X2Bytes / 2];
+  __shared__ __attribute__((aligned(16))) _Float16 sXO[kCkX3XOBytes / 2];
+  __shared__ float sLG[64][8];
+  CkX3Planes L;
+  L.Hh = sH; L.Hl = sH + 64 * kLdHb;
+  L.X0 = sX0; L.C1h = sH; L.C1l = sH + 64 * kLhC1;
+  L.X2h = sX2; L.X2l = sX2 + 64 * kLhX2; L.XOh = sXO; L.XOl = sXO + 64 * kLhXO;
+  L.LG = sLG;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const size_t rows = (size_t)p.E * p.N;
+  const size_t row_base = (size_t)blockIdx.x * 64;
+  const float *pk = p.packed;
+  CM3_STAMP(0, false);
+  uint4 b_conv[2][5];
+  load_bx<5, kKConvX / 32>(pk + kXConvH, pk + kXConvL, 5 * (w >> 2), lane, b_conv);
+  if (w < 4) ck_x3_stage_inputs(p, L, tid, row_base, rows);
   CM3_STAMP(1, true);
   __syncthreads();
   CM3_STAMP(2, false);
-
-  uint4 b_lin[2][1], b_self[2][4], b_h2[2][4], b_oth[2][4], b_out[2][1];
-  // ---- conv (Toeplitz): X0 [64][96] -> C1 [64][160], relu ------------------------------------------------------------------------
-  {
-    f32x4 acc[2][5];
-    float4 bias[5];
-    load_bias4<5>(pk + kPConvB, 5 * (w >> 1), lane, bias);
-    zero_tiles(acc);
-    gemm_x3<2, 5, kKConvX / 32, false>(sX0, sX0, kLhX0, 2 * (w & 1), pk + kXConvH, pk + kXConvL, 5 * (w >> 1), lane, b_conv, acc);
-    load_bx<1, kKLin / 32>(pk + kXLinH, pk + kXLinL, w >> 1, lane, b_lin);
-    store_relu_x3<2, 5>(sC1h, sC1l, kLhC1, 2 * (w & 1), 5 * (w >> 1), bias, lane, acc);
-  }
-  __syncthreads();
-  CM3_STAMP(3, false);
-  // ---- conv_linear: C1 [64][160] -> X2[:, 0:32], relu ---------------------------------------------------------------------------
-  {
-    f32x4 acc[2][1];
-    float4 bias[1];
-    load_bias4<1>(pk + kPLinB, w >> 1, lane, bias);
-    zero_tiles(acc);
-    gemm_x3<2, 1, kKLin / 32, true>(sC1h, sC1l, kLhC1, 2 * (w & 1), pk + kXLinH, pk + kXLinL, w >> 1, lane, b_lin, acc);
-    load_bx<4, kKSelfX / 32>(pk + kXSelfH, pk + kXSelfL, 4 * w, lane, b_self);
-    store_relu_x3<2, 1>(sX2h, sX2l, kLhX2, 2 * (w & 1), w >> 1, bias, lane, acc);
-  }
-  __syncthreads();
-  CM3_STAMP(4, false);
-  // ---- branch_self: X2 [64][64] -> H [64][256], relu; wave w owns units [64w, 64w + 64) from here on -------------------------------
-  {
-    f32x4 acc[4][4];
-    float4 bias[4];
-    load_bias4<4>(pk + kPSelfB, 4 * w, lane, bias);
-    zero_tiles(acc);
-    gemm_x3<4, 4, kKSelfX / 32, true>(sX2h, sX2l, kLhX2, 0, pk + kXSelfH, pk + kXSelfL, 4 * w, lane, b_self, acc);
-    load_bx<4, 8>(pk + kPH2Sh, pk + kPH2Sl, 4 * w, lane, b_h2);
-    store_relu_x3<4, 4>(sHh, sHl, kLdHb, 0, 4 * w, bias, lane, acc);
-  }
-  __syncthreads();
-  CM3_STAMP(5, false);
-  // ---- h2 = relu(branch_self W_self_h2 + branch_others W_others_h2 + b) ------------------------------------------------------------
-  f32x4 acc2[4][4];
+  f32x4 acc2[4][kCkBCT];
   zero_tiles(acc2);
-  gemm_x3<4, 4, 8, true>(sHh, sHl, kLdHb, 0, pk + kPH2Sh, pk + kPH2Sl, 4 * w, lane, b_h2, acc2);
-  const bool stage2 = p.stage > 1;
-  float4 bias_oth[4], bias_h2[4];
-  load_bias4<4>(pk + kPOthB, 4 * w, lane, bias_oth);
-  load_bias4<4>(pk + kPH2B, 4 * w, lane, bias_h2);
-  if (stage2) load_bx<4, 1>(pk + kXOthH, pk + kXOthL, 4 * w, lane, b_oth);
-  else load_bx<1, 8>(pk + kXOutH, pk + kXOutL, 0, lane, b_out);
-  CM3_STAMP(6, true);
-  __syncthreads();  // every wave is done reading branch_self
-  CM3_STAMP(7, false);
-  if (stage2) {
-    {
-      f32x4 acc[4][4];
-      zero_tiles(acc);
-      gemm_x3<4, 4, 1, true>(sXOh, sXOl, kLhXO, 0, pk + kXOthH, pk + kXOthL, 4 * w, lane, b_oth, acc);
-      load_bx<4, 8>(pk + kPH2Oh, pk + kPH2Ol, 4 * w, lane, b_h2);
-      store_relu_x3<4, 4>(sHh, sHl, kLdHb, 0, 4 * w, bias_oth, lane, acc);
-    }
-    __syncthreads();
-    CM3_STAMP(8, false);
-    gemm_x3<4, 4, 8, true>(sHh, sHl, kLdHb, 0, pk + kPH2Oh, pk + kPH2Ol, 4 * w, lane, b_h2, acc2);
-    load_bx<1, 8>(pk + kXOutH, pk + kXOutL, 0, lane, b_out);
-    CM3_STAMP(9, true);
-    __syncthreads();
+  if (p.stage > 1) ck_x3_others(L, pk, w, lane, acc2);
+  ck_x3_self_chain(L, pk, w, lane, b_conv, acc2);
+  if (w < 4) {
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    ck_actor_head(p, sLG, w, lane, row_base, rows);
   }
-  CM3_STAMP(10, false);
-  store_relu_x3<4, 4>(sHh, sHl, kLdHb, 0, 4 * w, bias_h2, lane, acc2);
-  __syncthreads();
-  CM3_STAMP(11, false);
-  // ---- actor_out: wave w finishes agent rows [16w, 16w + 16); transposed tile: lane (row l & 15) holds logits 4 (l >> 4) + reg ----------
-  {
-    f32x4 acc[1][1];
-    zero_tiles(acc);
-    gemm_x3<1, 1, 8, true>(sHh, sHl, kLdHb, w, pk + kXOutH, pk + kXOutL, 0, lane, b_out, acc);
-    const int col = lane & 15, hi = lane >> 4;
-    if (hi < 2) {
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) sLG[16 * w + col][4 * hi + reg] = acc[0][0][reg] + pk[kPOutB + 4 * hi + reg];
-    }
-  }
-  __builtin_amdgcn_s_waitcnt(0);
-  __builtin_amdgcn_wave_barrier();
-  ck_actor_head(p, sLG, w, lane, row_base, rows);
   CM3_STAMP(12, true);
 }
+
+// ---- the others branch as a table (round 6) -----------------------------------------------------------------------------------------
+// With two agents a row's v_obs_others is the normalised (row, column) of the ONE other agent: (r - 3.5) / 7 and (c - 6.5) / 13 with
+// r in 0..6, c in 0..12 (checkers.py:112-125, :139) -- 91 possible inputs, so branch_others W_others_h2 has 91 possible values per
+// unit.  This kernel evaluates ck_x3_others() -- the very function of the forward pass -- on those 91 inputs (as 2 x 64 rows) and
+// stores the accumulators: tab[r * 13 + c][unit], float32.  The whole-episode kernel starts h2's accumulators from that row instead
+// of running the branch: the same bits, 11 k of a tick's ~45 k cycles less.
+constexpr int kCkOthCells = 7 * 13;
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) k_ck_actor_others_table(const float *pk, float *tab) {
+  using namespace ck_actor;
+  __shared__ __attribute__((aligned(16))) _Float16 sH[kCkX3HBytes / 2];
+  __shared__ __attribute__((aligned(16))) _Float16 sXO[kCkX3XOBytes / 2];
+  CkX3Planes L;
+  memset(&L, 0, sizeof(L));
+  L.Hh = sH; L.Hl = sH + 64 * kLdHb;
+  L.XOh = sXO; L.XOl = sXO + 64 * kLhXO;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int idx = tid; idx < 2 * 64 * kLhXO; idx += 512) sXO[idx] = (_Float16)0.0f;
+  __syncthreads();
+  if (tid < 64) {
+    int cell = (int)blockIdx.x * 64 + tid;
+    cell = cell < kCkOthCells ? cell : kCkOthCells - 1;
+    const int r = cell / 13, c = cell - 13 * r;
+    // the env's own expressions (csrc/checkers.hip CkBoardTab::norm), cast to float32 like a TF feed, split like ck_x3_stage_inputs
+    const double vr = ((double)r - 7.0 / 2.0) / 7.0, vc = ((double)c - 13.0 / 2.0) / 13.0;
+    put_split(L.XOh, L.XOl, tid * kLhXO + 0, (float)vr);
+    put_split(L.XOh, L.XOl, tid * kLhXO + 1, (float)vc);
+  }
+  __syncthreads();
+  f32x4 acc2[4][kCkBCT];
+  zero_tiles(acc2);
+  ck_x3_others(L, pk, w, lane, acc2);
+  const int col = lane & 15, hi = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int c = 0; c < kCkBCT; ++c) {
+      const int cell = (int)blockIdx.x * 64 + 16 * t + col;
+      if (cell < kCkOthCells) {
+        float4 v;
+        v.x = acc2[t][c][0]; v.y = acc2[t][c][1]; v.z = acc2[t][c][2]; v.w = acc2[t][c][3];
+        *reinterpret_cast<float4 *>(tab + (size_t)cell * kH2 + 16 * (kCkBCT * w + c) + 4 * hi) = v;
+      }
+    }
+}
+
+#endif  // CM3_NO_ENTRY_POINTS
 
 static int ck_actor_check(const cm3_actor_checkers_desc *d) {
   using namespace ck_actor;
@@ -983,7 +1117,8 @@ static void ck_actor_weights(CkActorParams &p, const cm3_actor_checkers_weights 
 
 }  // namespace cm3
 
-extern "C" size_t cm3_actor_checkers_packed_bytes(void) { return (size_t)cm3::ck_actor::kPTotal * sizeof(float); }
+#ifndef CM3_NO_ENTRY_POINTS
+extern "C" size_t cm3_actor_checkers_packed_bytes(void) { return (size_t)cm3::ck_actor::kPAll * sizeof(float); }
 
 extern "C" int cm3_actor_checkers_pack(const cm3_actor_checkers_desc *d, const cm3_actor_checkers_weights *wt,
                                        void *packed, void *stream) {
@@ -1002,6 +1137,11 @@ extern "C" int cm3_actor_checkers_pack(const cm3_actor_checkers_desc *d, const c
   ck_actor_weights(p, wt);
   hipLaunchKernelGGL(k_ck_actor_pack, dim3(128), dim3(256), 0, (hipStream_t)stream, p, (float *)packed);
   CM3_HIP_CHECK(hipGetLastError());
+  if (d->stage > 1 && d->n_agents == 2) {   // the others branch as a table (see k_ck_actor_others_table), from the weights just packed
+    hipLaunchKernelGGL(k_ck_actor_others_table, dim3(2), dim3(512), 0, (hipStream_t)stream, (const float *)packed,
+                       (float *)packed + ck_actor::kPOthTab);
+    CM3_HIP_CHECK(hipGetLastError());
+  }
   return CM3_OK;
 }
 
@@ -1044,8 +1184,9 @@ extern "C" int cm3_actor_checkers_f32(const cm3_actor_checkers_desc *d, const cm
   const size_t rows = (size_t)p.E * p.N;
   const dim3 grid((unsigned)((rows + 63) / 64));
   if (d->precision == 1) hipLaunchKernelGGL(k_ck_actor<true>, grid, dim3(256), 0, (hipStream_t)stream, p);
-  else if (d->precision == 2) hipLaunchKernelGGL(k_ck_actor_x3, grid, dim3(256), 0, (hipStream_t)stream, p);
+  else if (d->precision == 2) hipLaunchKernelGGL(k_ck_actor_x3, grid, dim3(512), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(k_ck_actor<false>, grid, dim3(256), 0, (hipStream_t)stream, p);
   CM3_HIP_CHECK(hipGetLastError());
   return CM3_OK;
 }
+#endif  // CM3_NO_ENTRY_POINTS

@@ -40,14 +40,18 @@ done
 # experimental -amdgpu-mfma-vgpr-form=1 is gone.  CM3_MFMA_VGPR=0|1 still forces a form for A/B builds)
 MFMA_FORM=""
 if [ -n "${CM3_MFMA_VGPR:-}" ]; then MFMA_FORM="-mllvm -amdgpu-mfma-vgpr-form=${CM3_MFMA_VGPR}"; fi
-for f in actor actor_checkers policy; do
-  "${HIPCC}" ${FLAGS} ${PHYS} ${MFMA_FORM} -DCM3_SOURCE_ID="\"${SRC_ID}\"" -Rpass-analysis=kernel-resource-usage -c "${HERE}/${f}.hip" -o "${OBJ}/${f}.o" 2> "${OBJ}/${f}.resource_usage.txt" &
+for f in actor actor_checkers policy policy_checkers; do
+  "${HIPCC}" ${FLAGS} ${PHYS} ${MFMA_FORM} -DCM3_SOURCE_ID="\"${SRC_ID}\"" -Rpass-analysis=kernel-resource-usage -c "${HERE}/${f}.hip" -o "${OBJ}/${f}.o" 2> "${OBJ}/${f}.resource_usage.txt" \
+    || { grep -v "remark:" "${OBJ}/${f}.resource_usage.txt" >&2; exit 1; } &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait "$p"; done
+# the matrix units' diagnostics went to their resource-usage files with the remarks: show what is not a remark
+for f in actor actor_checkers policy policy_checkers; do grep -v "remark:" "${OBJ}/${f}.resource_usage.txt" | grep -E "warning|error" -A3 >&2 || true; done
+OBJS=("${OBJ}/particle_f32.o" "${OBJ}/particle_f32_ilp.o" "${OBJ}/particle_f64.o" "${OBJ}/checkers.o" "${OBJ}/util.o" "${OBJ}/advantage.o"
+      "${OBJ}/batch.o" "${OBJ}/actor.o" "${OBJ}/actor_checkers.o" "${OBJ}/policy.o" "${OBJ}/policy_checkers.o")
 if [ "${CM3_SKIP_ISA_LINT:-0}" != 1 ]; then
-  python3 "${HERE}/../../tools/isa_lint.py" "${OBJ}"/*.o
+  python3 "${HERE}/../../tools/isa_lint.py" "${OBJS[@]}"     # (the objects of THIS build, not whatever else sits in ${OBJ})
 fi
-"${HIPCC}" --offload-arch=gfx950 -shared -fPIC -o "${OUT}" "${OBJ}/particle_f32.o" "${OBJ}/particle_f32_ilp.o" "${OBJ}/particle_f64.o" \
-  "${OBJ}/checkers.o" "${OBJ}/util.o" "${OBJ}/advantage.o" "${OBJ}/batch.o" "${OBJ}/actor.o" "${OBJ}/actor_checkers.o" "${OBJ}/policy.o"
+"${HIPCC}" --offload-arch=gfx950 -shared -fPIC -o "${OUT}" "${OBJS[@]}"
 echo "built ${OUT}"

@@ -369,13 +369,15 @@ __device__ __forceinline__ void ck_store_env(const CheckersParams &p, size_t e, 
 // episode ended under CM3_FLAG_AUTO_RESET: the caller then captures the terminal observation (term_*) and calls
 // ck_restart_env.
 // FAST: the reference geometry (3 x 8 band, n_obs 2) as compile-time constants instead of kernel arguments.
-template <int N, bool FAST = false>
+// GIVEN: the actions are the caller's registers (the whole-episode policy kernel, policy_checkers.hip, which has just sampled and
+// stored them) instead of the tick's action slot.
+template <int N, bool FAST = false, bool GIVEN = false>
 __device__ __forceinline__ bool ck_tick_env(const CheckersParams &p, int t, size_t e, size_t ec, bool writer, CkState<N> &s,
                                             CkLive<N> &lv, const char *fast_tab = nullptr
 #ifdef CM3_SPAN_MARKS
                                             , unsigned long long *_span_mk = nullptr
 #endif
-                                            ) {
+                                            , const int *given = nullptr) {
   const int gO = FAST ? 2 : p.O, gR = FAST ? 3 : p.R, gC = FAST ? 8 : p.C;
   const int g_collectible = FAST ? 24 : p.max_collectible;
   const bool active = writer;
@@ -387,7 +389,10 @@ __device__ __forceinline__ bool ck_tick_env(const CheckersParams &p, int t, size
   for (int i = 0; i < N; ++i) goal[i] = lv.goal[i];
   int act[N];
   int32_t *actions_t = ck_tick_ptr(p.actions, p.st_actions, t);
-  if (p.flags & CM3_FLAG_GEN_ACTIONS) {
+  if constexpr (GIVEN) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) act[i] = given[i];
+  } else if (p.flags & CM3_FLAG_GEN_ACTIONS) {
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       act[i] = rand5(action_word(lv.aword[i], episode, (uint32_t)steps));   // stage 2 (philox.h); stage 1 came with the state loads
@@ -920,34 +925,34 @@ template <int N, int G> struct CkLanePlan {
   uint32_t vidx[NGV], vagent[NGV], vshift[NGV], voff[NGV];
 };
 
-// the wave's private copy of kCkBoardTab in LDS (48 x 16 bytes, written by lanes 0..47) and the lane's plan: ALL loads are
-// requested before the first of them is waited for (the LDS write placed right behind its load made the wave wait for the table
-// before it had even requested its plan: a second memory round trip on the critical path)
-template <int N, int G> __device__ __forceinline__ void ckf_plan_load(int g, int lane, uint4 *lds_tab, CkLanePlan<N, G> &pl,
-                                                                      uint4 *lds_fresh = nullptr, const uint4 *fresh_src = nullptr) {
+template <int N, int G> struct CkLanePlanRaw {
+  using P = CkLanePlan<N, G>;
+  uint4 c01[P::NSLOT], c23[P::NSLOT], gv[P::NGV];
+};
+// the lane's plan entries as loaded (requests only; nothing waits here) ...
+template <int N, int G> __device__ __forceinline__ void ckf_plan_fetch(int g, CkLanePlanRaw<N, G> &raw) {
   using T = CkPlanTab<N>;
   using P = CkLanePlan<N, G>;
   const CkPlanTab<N> *tab = &kCkPlanTab<N>;
-  const uint4 board_vec = reinterpret_cast<const uint4 *>(&kCkBoardTab)[lane < 48 ? lane : 47];
-  uint4 fresh_vec = make_uint4(0u, 0u, 0u, 0u);
-  if (fresh_src) fresh_vec = fresh_src[lane < 26 ? lane : 25];   // (the fresh-episode record, CkFresh: 26 vectors at most)
-  uint4 c01[P::NSLOT], c23[P::NSLOT], gv[P::NGV];
 #pragma unroll
   for (int it = 0; it < P::NSLOT; ++it) {
     const int q = it * G + g, qc = q < T::NQ ? q : T::NQ - 1;
-    c01[it] = *reinterpret_cast<const uint4 *>(&tab->cell[4 * qc][0]);
-    c23[it] = *reinterpret_cast<const uint4 *>(&tab->cell[4 * qc + 2][0]);
+    raw.c01[it] = *reinterpret_cast<const uint4 *>(&tab->cell[4 * qc][0]);
+    raw.c23[it] = *reinterpret_cast<const uint4 *>(&tab->cell[4 * qc + 2][0]);
   }
 #pragma unroll
   for (int it = 0; it < P::NGV; ++it) {
     const int j = it * G + g;
-    gv[it] = *reinterpret_cast<const uint4 *>(&tab->gv[j < T::NGV ? j : T::NGV][0]);
+    raw.gv[it] = *reinterpret_cast<const uint4 *>(&tab->gv[j < T::NGV ? j : T::NGV][0]);
   }
-  if (lane < 48) lds_tab[lane] = board_vec;
-  if (lds_fresh && lane < 26) lds_fresh[lane] = fresh_vec;
+}
+// ... and decoded into the fields the emit uses
+template <int N, int G> __device__ __forceinline__ void ckf_plan_decode(const CkLanePlanRaw<N, G> &raw, CkLanePlan<N, G> &pl) {
+  using P = CkLanePlan<N, G>;
 #pragma unroll
   for (int it = 0; it < P::NSLOT; ++it) {
-    const uint32_t w0[4] = {c01[it].x, c01[it].z, c23[it].x, c23[it].z}, w1[4] = {c01[it].y, c01[it].w, c23[it].y, c23[it].w};
+    const uint32_t w0[4] = {raw.c01[it].x, raw.c01[it].z, raw.c23[it].x, raw.c23[it].z};
+    const uint32_t w1[4] = {raw.c01[it].y, raw.c01[it].w, raw.c23[it].y, raw.c23[it].w};
 #pragma unroll
     for (int x = 0; x < 4; ++x) {
       pl.boff[it][x] = (uint32_t)__builtin_amdgcn_sbfe((int)w0[x], 0, 16);
@@ -959,14 +964,29 @@ template <int N, int G> __device__ __forceinline__ void ckf_plan_load(int g, int
   }
 #pragma unroll
   for (int it = 0; it < P::NGV; ++it) {
-    pl.gstatic[it] = gv[it].x;
-    pl.gb0[it] = gv[it].y & 0xffu;
-    pl.gb1[it] = gv[it].y >> 8;
-    pl.vidx[it] = gv[it].z & 0xffu;
-    pl.vagent[it] = (gv[it].z >> 8) & 0xffu;
-    pl.vshift[it] = gv[it].z >> 16;
-    pl.voff[it] = gv[it].w;
+    pl.gstatic[it] = raw.gv[it].x;
+    pl.gb0[it] = raw.gv[it].y & 0xffu;
+    pl.gb1[it] = raw.gv[it].y >> 8;
+    pl.vidx[it] = raw.gv[it].z & 0xffu;
+    pl.vagent[it] = (raw.gv[it].z >> 8) & 0xffu;
+    pl.vshift[it] = raw.gv[it].z >> 16;
+    pl.voff[it] = raw.gv[it].w;
   }
+}
+
+// the wave's private copy of kCkBoardTab in LDS (48 x 16 bytes, written by lanes 0..47) and the lane's plan: ALL loads are
+// requested before the first of them is waited for (the LDS write placed right behind its load made the wave wait for the table
+// before it had even requested its plan: a second memory round trip on the critical path)
+template <int N, int G> __device__ __forceinline__ void ckf_plan_load(int g, int lane, uint4 *lds_tab, CkLanePlan<N, G> &pl,
+                                                                      uint4 *lds_fresh = nullptr, const uint4 *fresh_src = nullptr) {
+  const uint4 board_vec = reinterpret_cast<const uint4 *>(&kCkBoardTab)[lane < 48 ? lane : 47];
+  uint4 fresh_vec = make_uint4(0u, 0u, 0u, 0u);
+  if (fresh_src) fresh_vec = fresh_src[lane < 26 ? lane : 25];   // (the fresh-episode record, CkFresh: 26 vectors at most)
+  CkLanePlanRaw<N, G> raw;
+  ckf_plan_fetch<N, G>(g, raw);
+  if (lane < 48) lds_tab[lane] = board_vec;
+  if (lds_fresh && lane < 26) lds_fresh[lane] = fresh_vec;
+  ckf_plan_decode<N, G>(raw, pl);
 }
 
 // ---- the observation of a fresh episode as a constant record (round 4) ---------------------------------------------------------
@@ -1507,36 +1527,58 @@ static int ck_call(const cm3_checkers_desc *d, const cm3_checkers_bufs *b, const
   return ck_dispatch(p, d->n_agents, step, (hipStream_t)stream);
 }
 
-static int ck_rollout(const cm3_checkers_desc *d, const cm3_checkers_traj *t, int32_t n_ticks, void *stream) {
-  CM3_REQUIRE(d && t, "null desc/traj");
-  CM3_REQUIRE(n_ticks >= 1, "n_ticks must be >= 1");
+// tick k of a trajectory as one step call's buffers: observation slot k + 1, per-tick outputs slot k
+static void ck_traj_bufs(const cm3_checkers_traj *t, int k, cm3_checkers_bufs &b) {
   auto at = [](void *base, size_t stride, int k) -> void * {
     return base ? (void *)((char *)base + stride * (size_t)k) : nullptr;
   };
-  auto bufs_for = [&](int k, cm3_checkers_bufs &b) {
-    memset(&b, 0, sizeof(b));
-    b.mask = t->mask;
-    b.agents = t->agents;
-    b.steps = t->steps;
-    b.episode = t->episode;
-    b.goals = t->goals;
-    b.action_block = t->action_block;
-    b.actions = (int32_t *)at(t->actions, t->actions_stride, k);
-    b.grid = (int8_t *)at(t->grid, t->grid_slot_stride, k + 1);
-    b.vec = (int32_t *)at(t->vec, t->vec_stride, k + 1);
-    b.obs_others = (double *)at(t->obs_others, t->obs_others_stride, k + 1);
-    b.obs_self_t = (int8_t *)at(t->obs_self_t, t->obs_self_t_slot_stride, k + 1);
-    b.obs_self_v = (double *)at(t->obs_self_v, t->obs_self_v_stride, k + 1);
-    b.local_rewards = (double *)at(t->local_rewards, t->local_rewards_stride, k);
-    b.reward = (double *)at(t->reward, t->reward_stride, k);
-    b.done = (uint8_t *)at(t->done, t->done_stride, k);
-    b.term_grid = (int8_t *)at(t->term_grid, t->term_grid_slot_stride, k);
-    b.term_vec = (int32_t *)at(t->term_vec, t->term_vec_stride, k);
-    b.term_obs_others = (double *)at(t->term_obs_others, t->term_obs_others_stride, k);
-    b.term_obs_self_t = (int8_t *)at(t->term_obs_self_t, t->term_obs_self_t_slot_stride, k);
-    b.term_obs_self_v = (double *)at(t->term_obs_self_v, t->term_obs_self_v_stride, k);
-    b.goals_next = (uint8_t *)at(t->goals_slots, t->goals_slots_stride, k + 1);
-  };
+  memset(&b, 0, sizeof(b));
+  b.mask = t->mask;
+  b.agents = t->agents;
+  b.steps = t->steps;
+  b.episode = t->episode;
+  b.goals = t->goals;
+  b.action_block = t->action_block;
+  b.actions = (int32_t *)at(t->actions, t->actions_stride, k);
+  b.grid = (int8_t *)at(t->grid, t->grid_slot_stride, k + 1);
+  b.vec = (int32_t *)at(t->vec, t->vec_stride, k + 1);
+  b.obs_others = (double *)at(t->obs_others, t->obs_others_stride, k + 1);
+  b.obs_self_t = (int8_t *)at(t->obs_self_t, t->obs_self_t_slot_stride, k + 1);
+  b.obs_self_v = (double *)at(t->obs_self_v, t->obs_self_v_stride, k + 1);
+  b.local_rewards = (double *)at(t->local_rewards, t->local_rewards_stride, k);
+  b.reward = (double *)at(t->reward, t->reward_stride, k);
+  b.done = (uint8_t *)at(t->done, t->done_stride, k);
+  b.term_grid = (int8_t *)at(t->term_grid, t->term_grid_slot_stride, k);
+  b.term_vec = (int32_t *)at(t->term_vec, t->term_vec_stride, k);
+  b.term_obs_others = (double *)at(t->term_obs_others, t->term_obs_others_stride, k);
+  b.term_obs_self_t = (int8_t *)at(t->term_obs_self_t, t->term_obs_self_t_slot_stride, k);
+  b.term_obs_self_v = (double *)at(t->term_obs_self_v, t->term_obs_self_v_stride, k);
+  b.goals_next = (uint8_t *)at(t->goals_slots, t->goals_slots_stride, k + 1);
+}
+
+// the tick loop of ONE launch over that trajectory (p filled from tick 0's buffers): tick k uses <pointer> + k * <stride>
+static void ck_traj_strides(const cm3_checkers_traj *t, int32_t n_ticks, CheckersParams &p) {
+  p.n_ticks = n_ticks;
+  p.st_actions = t->actions_stride;
+  p.st_grid = t->grid_slot_stride;
+  p.st_vec = t->vec_stride;
+  p.st_obs_others = t->obs_others_stride;
+  p.st_obs_self_t = t->obs_self_t_slot_stride;
+  p.st_obs_self_v = t->obs_self_v_stride;
+  p.st_local = t->local_rewards_stride;
+  p.st_reward = t->reward_stride;
+  p.st_done = t->done_stride;
+  p.st_term_grid = t->term_grid_slot_stride;
+  p.st_term_vec = t->term_vec_stride;
+  p.st_term_obs_others = t->term_obs_others_stride;
+  p.st_term_obs_self_t = t->term_obs_self_t_slot_stride;
+  p.st_term_obs_self_v = t->term_obs_self_v_stride;
+  p.st_goals_next = t->goals_slots_stride;
+}
+
+static int ck_rollout(const cm3_checkers_desc *d, const cm3_checkers_traj *t, int32_t n_ticks, void *stream) {
+  CM3_REQUIRE(d && t, "null desc/traj");
+  CM3_REQUIRE(n_ticks >= 1, "n_ticks must be >= 1");
   // the rollout's observation slots as a stream (>= 128 MB, beyond what the cache hierarchy keeps): non-temporal stores
   const size_t obs_bytes = (t->grid_slot_stride + t->vec_stride + t->obs_others_stride + t->obs_self_t_slot_stride +
                             t->obs_self_v_stride) * (size_t)n_ticks;
@@ -1545,32 +1587,17 @@ static int ck_rollout(const cm3_checkers_desc *d, const cm3_checkers_traj *t, in
   if (d->flags & CM3_FLAG_FUSED_TICKS) {
     CM3_REQUIRE((d->flags & CM3_FLAG_GEN_ACTIONS) || n_ticks == 1 || t->actions_stride != 0,
                 "fused rollout needs in-kernel actions or one pre-filled action slot per tick");
-    bufs_for(0, b);
+    ck_traj_bufs(t, 0, b);
     CheckersParams p;
     int rc = ck_fill(d, &b, nullptr, true, p);
     if (rc != CM3_OK) return rc;
     CM3_REQUIRE(ck_fast_ok(p), "fused Checkers rollouts need the fast kernel (3x8 band, n_obs 2, 4-byte padded records)");
-    p.n_ticks = n_ticks;
     p.flags |= nt_flag;
-    p.st_actions = t->actions_stride;
-    p.st_grid = t->grid_slot_stride;
-    p.st_vec = t->vec_stride;
-    p.st_obs_others = t->obs_others_stride;
-    p.st_obs_self_t = t->obs_self_t_slot_stride;
-    p.st_obs_self_v = t->obs_self_v_stride;
-    p.st_local = t->local_rewards_stride;
-    p.st_reward = t->reward_stride;
-    p.st_done = t->done_stride;
-    p.st_term_grid = t->term_grid_slot_stride;
-    p.st_term_vec = t->term_vec_stride;
-    p.st_term_obs_others = t->term_obs_others_stride;
-    p.st_term_obs_self_t = t->term_obs_self_t_slot_stride;
-    p.st_term_obs_self_v = t->term_obs_self_v_stride;
-    p.st_goals_next = t->goals_slots_stride;
+    ck_traj_strides(t, n_ticks, p);
     return ck_dispatch(p, d->n_agents, true, (hipStream_t)stream);
   }
   for (int k = 0; k < n_ticks; ++k) {
-    bufs_for(k, b);
+    ck_traj_bufs(t, k, b);
     CheckersParams p;
     int rc = ck_fill(d, &b, nullptr, true, p);
     if (rc != CM3_OK) return rc;
@@ -1583,6 +1610,7 @@ static int ck_rollout(const cm3_checkers_desc *d, const cm3_checkers_traj *t, in
 
 }  // namespace cm3
 
+#ifndef CM3_NO_ENTRY_POINTS
 extern "C" {
 int cm3_checkers_rollout(const cm3_checkers_desc *d, const cm3_checkers_traj *t, int32_t n_ticks, void *stream) {
   return cm3::ck_rollout(d, t, n_ticks, stream);
@@ -1614,3 +1642,4 @@ int cm3_checkers_reset(const cm3_checkers_desc *d, const cm3_checkers_bufs *b, c
   return cm3::ck_call(d, b, mask, false, stream);
 }
 }
+#endif  // CM3_NO_ENTRY_POINTS

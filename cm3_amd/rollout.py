@@ -794,11 +794,18 @@ class CheckersRollout(object):
         one stopped.
     """
 
-    def __init__(self, env, n_ticks=None, use_graph=True, fused=False):
+    def __init__(self, env, n_ticks=None, use_graph=True, fused=False, policy_mode="auto", record_probs=False):
+        """policy_mode (collect(policy=<CheckersActor>)): "auto" = the whole rollout in ONE launch (cm3_policy_rollout_checkers)
+        wherever that kernel applies (CheckersActor.fused_rollout_ok), else -- and with "tick" -- an actor launch and a step
+        launch per tick inside one hipGraph; the two produce the same bits.  record_probs: keep the mixed probabilities the
+        actions were drawn from, float32 [T, E, N, 5] (self.probs)."""
         self.env = env
         self.T = int(n_ticks or env.max_steps)
         self.use_graph = bool(use_graph)
         self.fused = bool(fused)      # random-action branch in ONE launch (CM3_FLAG_FUSED_TICKS; fast kernel only)
+        if policy_mode not in ("auto", "tick"):
+            raise Cm3Error("policy_mode must be 'auto' or 'tick'")
+        self.policy_mode = policy_mode
         self.auto_reset = bool(env.auto_reset)
         self._graph = None
         E, N, T, dev = env.E, env.n, self.T, env.device
@@ -815,6 +822,7 @@ class CheckersRollout(object):
         self.reward = z(T, E, d=torch.float64)
         self.done = z(T, E, d=torch.uint8)
         self.prev0 = z(E, N, d=torch.int32)                    # actions_prev of slot 0 (zeros at an episode start)
+        self.probs = z(T, E, N, 5, d=torch.float32) if record_probs else None
         if self.auto_reset:
             self._term_grid_raw = z(T, E, env.grid_stride, d=torch.int8)
             self._term_obst_raw = z(T, E, env.obst_stride, d=torch.int8)
@@ -894,11 +902,20 @@ class CheckersRollout(object):
             goals = self.goal_slots[t] if self.auto_reset else env._goals
             actor.enqueue(env.E, self._obst_raw[t], env.obst_stride, self.obs_self_v[t], self.obs_others[t], goals,
                           self.actions[t - 1] if t > 0 else self.prev0, env._steps, env._episode, self.actions[t], epsilon,
-                          stream=stream, env_id_base=env._desc.env_id_base,
+                          probs=None if self.probs is None else self.probs[t], stream=stream, env_id_base=env._desc.env_id_base,
                           prev_done=self.done[t - 1] if (t > 0 and self.auto_reset) else None)
             env._desc.flags = self._base_flags()
             b = self._bufs(t)
             _lib.check(self._lib.cm3_checkers_step(ctypes.byref(env._desc), ctypes.byref(b), stream))
+        env._desc.flags = 0
+
+    def _enqueue_policy_rollout(self, actor, epsilon, stream):
+        """The same T ticks as _enqueue_actor_rollout in ONE launch (csrc/policy_checkers.hip)."""
+        env = self.env
+        env._desc.flags = self._base_flags()
+        traj = self._traj()
+        actor.enqueue_rollout(env._desc, traj, env.E, env.obst_stride, self.T, epsilon, prev0=self.prev0, probs=self.probs,
+                              stream=stream)
         env._desc.flags = 0
 
     def _load_slot0(self):
@@ -959,7 +976,9 @@ class CheckersRollout(object):
             else:
                 self._enqueue_random(stream, False)
         elif hasattr(policy, "enqueue") and hasattr(policy, "act"):            # on-device actor
-            if self.use_graph:
+            if self.policy_mode == "auto" and policy.fused_rollout_ok(env):     # one launch: nothing to capture
+                self._enqueue_policy_rollout(policy, epsilon, stream)
+            elif self.use_graph:
                 cache = self._actor_graph
                 cache.launch(self._lib, policy, epsilon,
                              lambda st: self._enqueue_actor_rollout(policy, cache.eps, st), stream)

@@ -46,7 +46,10 @@
 extern "C" {
 #endif
 
-#define CM3_ABI_VERSION 6   /* 6: cm3_policy_force_row_tiles, cm3_rows_scatter / cm3_rows_gather / cm3_rows_tile / cm3_transitions_gather_f32 (round 5).
+#define CM3_ABI_VERSION 7   /* 7 (round 6): cm3_policy_rollout_checkers; cm3_actor_checkers_packed_bytes grew by the others-branch table; the
+                               precision-2 Checkers actor adds branch_others W_others_h2 to h2's accumulators BEFORE branch_self
+                               W_self_h2 (probabilities move in the last bits).
+                               6: cm3_policy_force_row_tiles, cm3_rows_scatter / cm3_rows_gather / cm3_rows_tile / cm3_transitions_gather_f32 (round 5).
                                5: the in-kernel ACTION STREAM of the particle kernels and the actors' sampling uniforms became two stages
                                (Philox4x32-10 block per (seed, global env id, call) + fmix32((word ^ step) + episode * 0x9E3779B1);
                                csrc/philox.h, oracle/philox.py; since ABI 6 the Checkers kernels too) -- a given (seed, env, episode, step, agent) draws a DIFFERENT action
@@ -455,6 +458,20 @@ int cm3_actor_checkers_pack(const cm3_actor_checkers_desc *desc, const cm3_actor
                             void *stream);
 int cm3_actor_checkers_f32(const cm3_actor_checkers_desc *desc, const cm3_actor_checkers_weights *weights,
                            const cm3_actor_checkers_bufs *bufs, void *stream);
+
+/* A whole POLICY-DRIVEN Checkers rollout in ONE launch (ABI 7; csrc/policy_checkers.hip): per tick the actor above (precision 2),
+ * epsilon-mixed sampling and Checkers.step with the actions just drawn -- train_onpolicy.py:309-347 / train_offpolicy.py:309-368 without
+ * leaving the kernel; env state in registers, the network's inputs written straight into LDS, the others branch of the two-agent
+ * network read from a table that cm3_actor_checkers_pack builds with the forward pass's own code.  `traj` as for
+ * cm3_checkers_rollout (slot 0 of the observation arrays = the caller's current observation is NOT read: the live state is);
+ * actions_prev0: optional int32 [E][N], actions_prev of tick 0 (NULL = zeros, train_onpolicy.py:295), later ticks use the actions
+ * just taken, zeros after a tick that ended an episode under CM3_FLAG_AUTO_RESET; probs: optional float [n_ticks][E][N][5] with
+ * probs_stride BYTES between ticks; epsilon_dev: optional device float read at launch instead of actor->epsilon.
+ * One or two agents (config_checkers_stage1 / stage2; actor->stage = n_agents), reference geometry, 4-byte padded records.
+ * Every output equals, bit for bit, what n_ticks x (cm3_actor_checkers_f32, cm3_checkers_step) write. */
+int cm3_policy_rollout_checkers(const cm3_checkers_desc *desc, const cm3_checkers_traj *traj, const cm3_actor_checkers_desc *actor,
+                                const cm3_actor_checkers_weights *weights, const int32_t *actions_prev0, float *probs,
+                                size_t probs_stride, const float *epsilon_dev, int32_t n_ticks, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Advantage normalisation (build-defined; the reference's advantage, alg_credit.py:334-357, is not normalised).

@@ -377,3 +377,99 @@ def test_split_precision_small_weights_large_activations(precision, w2_scale, w1
     got = probs.reshape(rows, 5).cpu().numpy()
     assert np.abs(got - want).max() < 2e-5, float(np.abs(got - want).max())
     assert np.ptp(want, axis=1).mean() > 0.02
+
+
+# ---- round 6: the whole policy-driven rollout in ONE launch (csrc/policy_checkers.hip) ------------------------------------------------
+_TRAJ = ("actions", "grid", "vec", "obs_others", "obs_self_t", "obs_self_v", "local_rewards", "reward", "done", "probs")
+_TERM = ("term_grid", "term_vec", "term_obs_others", "term_obs_self_t", "term_obs_self_v", "goal_slots")
+
+
+def _collect_twice(stage, E, seed, auto_reset, mode, max_steps=33, T=None, eps=0.15, collects=2):
+    from cm3_amd.actor import CheckersActor
+    from cm3_amd.rollout import CheckersRollout
+    env, N = _env(E, stage, seed=seed, max_steps=max_steps, auto_reset=auto_reset)
+    w = AO.init_weights(np.random.default_rng(5), N)
+    actor = CheckersActor(w, N, stage=stage, device="cuda:0", seed=seed, precision="f16x3")
+    assert actor.fused_rollout_ok(env)
+    ro = CheckersRollout(env, n_ticks=T, policy_mode=mode, record_probs=True)
+    rng = np.random.default_rng(1)
+    snaps = []
+    for _ in range(collects):
+        ro.collect(_goals(rng, E, N), policy=actor, epsilon=eps)
+        torch.cuda.synchronize()
+        snap = {k: getattr(ro, k).clone() for k in _TRAJ}
+        if auto_reset:
+            snap.update({k: getattr(ro, k).clone() for k in _TERM})
+        snap.update(mask=env._mask.clone(), agents=env._agents.clone(), steps=env._steps.clone(), episode=env._episode.clone(),
+                    goals=env._goals.clone(), prev0=ro.prev0.clone())
+        snaps.append(snap)
+    from cm3_amd import _lib
+    name = _lib.last_kernel_variant() if hasattr(_lib, "last_kernel_variant") else ""
+    ro.close()
+    return snaps, name
+
+
+@pytest.mark.parametrize("stage,E,auto_reset,max_steps,T", [
+    (2, 8192, False, 33, None),       # C3: config_checkers_stage2, 8192 envs, one reference episode per env and collect()
+    (2, 1000, True, 9, 33),           # continuous collection: every env restarts three times inside the launch (terminal capture,
+                                      #   fresh record, actions_prev = zeros after a restart), ragged last workgroup
+    (1, 4096, False, 33, None),       # stage 1: one agent, no others branch
+    (1, 777, True, 7, 20),            # ... with restarts: a fresh random goal per episode picks the start row
+])
+def test_checkers_policy_rollout_equals_launch_per_tick(stage, E, auto_reset, max_steps, T):
+    """The Checkers twin of test_fused_policy_rollout_equals_launch_per_tick: every array of the rollout -- actions, the mixed
+    probabilities they were drawn from, all observation slots, rewards, done flags, terminal captures, goal slots -- and the live
+    state the launch leaves behind equal, bit for bit, what alternating cm3_actor_checkers_f32 / cm3_checkers_step launches write.
+    The one-launch kernel builds the network's inputs in LDS from the env state and reads the others branch from the table
+    cm3_actor_checkers_pack made: this is the test that those are the same numbers."""
+    fused, kname = _collect_twice(stage, E, 31, auto_reset, "auto", max_steps, T)
+    ticks, _ = _collect_twice(stage, E, 31, auto_reset, "tick", max_steps, T)
+    assert "k_ck_policy_rollout" in kname or kname == ""
+    for k, (a, b) in enumerate(zip(fused, ticks)):
+        for name in a:
+            assert torch.equal(a[name], b[name]), "collect %d: %s differs" % (k, name)
+    if auto_reset:
+        assert int(fused[-1]["episode"].min()) >= 2          # restarts did happen inside the launches
+
+
+def test_checkers_policy_rollout_one_launch_against_the_two_oracles():
+    """The one-launch rollout (split float16) against the oracle actor + oracle env chained on the host, as
+    test_policy_rollout_against_oracle_env_and_oracle_actor does for the alternating float32 path: probabilities within 2e-5
+    at every tick, actions and env outputs equal for envs whose uniforms stay 1e-4 clear of a CDF boundary."""
+    from cm3_amd.actor import CheckersActor
+    from cm3_amd.rollout import CheckersRollout
+    from oracle.checkers_oracle import VecCheckersOracle
+    E, seed, eps = 256, 29, 0.1
+    env, N = _env(E, 2, seed=seed)
+    cfg = load_cfg("checkers_stage2.json")
+    w = AO.init_weights(np.random.default_rng(6), N)
+    actor = CheckersActor(w, N, device="cuda:0", seed=seed, precision="f16x3")
+    ro = CheckersRollout(env, record_probs=True).collect(np.eye(2), policy=actor, epsilon=eps)
+    i = cfg["init"]
+    orc = VecCheckersOracle(i["n_rows"], i["n_columns"], i["n_obs"], i["agents_r"], i["agents_c"], N, 33, E)
+    goals = np.broadcast_to(np.eye(2), (E, 2, 2))
+    grid, vec, oo, ot, ov = orc.reset(goals)
+    prev = np.zeros((E, N), int)
+    episode = env._episode.cpu().numpy()
+    ok, alive, rows, worst = np.ones(E, bool), np.ones(E, bool), E * N, 0.0
+    for t in range(33):
+        p = AO.mixed_probs(AO.actor_probs(w, prev.reshape(rows), ot.reshape(rows, 5, 5, 3), ov.reshape(rows, 4),
+                                          oo.reshape(rows, -1), goals.reshape(rows, 2)), eps)
+        u = AO.policy_uniforms(seed, np.arange(E), episode, np.full(E, t), N).reshape(rows)
+        a = AO.sample_actions(p, u).reshape(E, N)
+        near = (np.abs(np.cumsum(p, axis=1) - u[:, None]).min(axis=1) <= 1e-4).reshape(E, N).any(1)
+        ok &= ~(near & alive)
+        sel = ok & alive
+        worst = max(worst, float(np.abs(ro.probs[t].cpu().numpy().reshape(rows, 5) - p).reshape(E, N * 5)[sel].max()))
+        assert np.array_equal(ro.actions[t].cpu().numpy()[sel], a[sel]), t
+        grid, vec, oo, ot, ov, rew, lrew, done = orc.step(a)
+        assert np.array_equal(ro.grid[t + 1].cpu().numpy()[sel], grid[sel])
+        assert np.array_equal(ro.obs_self_t[t + 1].cpu().numpy()[sel], ot[sel])
+        assert np.array_equal(ro.obs_others[t + 1].cpu().numpy()[sel], oo[sel])
+        assert np.array_equal(ro.reward[t].cpu().numpy()[sel], rew[sel])
+        assert np.array_equal(ro.done[t].cpu().numpy().astype(bool)[sel], done[sel])
+        alive &= ~done
+        prev = a
+    assert worst < 2e-5, worst          # the stated float32 tolerance of the actor rows (SURVEY section 8f-1)
+    assert ok.mean() > 0.9
+    ro.close()

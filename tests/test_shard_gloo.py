@@ -99,6 +99,51 @@ def test_moments_all_gather_world2_gloo():
     assert dict(out) == {0: 1, 1: 1}
 
 
+def _segments_worker(rank, world, port, n_global, K, out):
+    """The collection phase's collective at `world` ranks: K rollouts' moment triples travel in ONE all-gather of 24 K bytes per
+    rank and come back as [world][K][3] in rank order -- the layout cm3_normalize_segments_* sums over."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(1)
+        T = 33
+        adv_all = torch.randn(K, T, n_global, 4, generator=g, dtype=torch.float64) * 2 - 0.5
+        spans = [shard_range(n_global, r, world) for r in range(world)]
+        base, cnt = spans[rank]
+        mine = torch.stack([local_moments(adv_all[k, :, base:base + cnt]) for k in range(K)])          # [K, 3]
+        parts, n_parts = gather_moments(mine)
+        ok = n_parts == world and parts.shape == (world * K * 3,)
+        parts = parts.view(world, K, 3)
+        for r, (b, c) in enumerate(spans):
+            for k in range(K):
+                ok = ok and bool(torch.equal(parts[r, k], local_moments(adv_all[k, :, b:b + c])))
+        tot = parts[0].clone()
+        for r in range(1, world):                     # rank order, as the device kernel adds them
+            tot = tot + parts[r]
+        mean = tot[:, 0] / tot[:, 2]
+        std = (tot[:, 1] / tot[:, 2] - mean * mean).clamp(min=0).sqrt()
+        for k in range(K):
+            ok = ok and abs(float(mean[k]) - float(adv_all[k].mean())) < 1e-12
+            ok = ok and abs(float(std[k]) - float(adv_all[k].std(unbiased=False))) < 1e-11
+            ok = ok and int(tot[k, 2]) == adv_all[k].numel()
+        every = [torch.zeros(K, 2, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(every, torch.stack([mean, std], dim=1))
+        ok = ok and all(torch.equal(every[0], e) for e in every)          # bit-identical statistics on every rank
+        out[rank] = 1 if ok else 0
+    finally:
+        dist.destroy_process_group()
+
+
+def test_segment_moments_all_gather_world8_gloo():
+    """the C4 phase's collective at the node's real rank count (8), K = 10 rollouts per phase, uneven shards."""
+    world, K = 8, 10
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_segments_worker, args=(world, _free_port(), 37, K, out), nprocs=world, join=True)
+    assert dict(out) == {r: 1 for r in range(world)}
+
+
 def test_single_process_path_needs_no_process_group():
     x = torch.arange(12.0).view(3, 4)
     mean, std, n = global_moments(x)

@@ -7,6 +7,8 @@ __device__ long long *cm3_stamp_buf;
 #include <vector>
 int main(int argc, char **argv) {
   const int E = argc > 1 ? atoi(argv[1]) : 8192, N = 2, Lo = 2, prec = argc > 2 ? atoi(argv[2]) : 0;   // prec: 0 f32, 1 bf16, 2 f16x3
+  const int nwaves = argc > 3 ? atoi(argv[3]) : 8;   // waves per workgroup of the f16x3 kernel (4 | 8)
+  if (prec == 2 && cm3_actor_checkers_force_waves(nwaves)) { printf("%s\n", cm3_last_error()); return 1; }
   int8_t *obst; double *obsv, *obso; uint8_t *goals; int32_t *steps, *episode, *actions; float *w; long long *stamps;
   hipMalloc((void **)&obst, (size_t)E * 152); hipMalloc((void **)&obsv, (size_t)E * N * 32); hipMalloc((void **)&obso, (size_t)E * N * Lo * 8);
   hipMalloc((void **)&goals, (size_t)E * N); hipMalloc((void **)&steps, (size_t)E * 4); hipMalloc((void **)&episode, (size_t)E * 4);
@@ -15,7 +17,7 @@ int main(int argc, char **argv) {
   hipMemset(goals, 0, (size_t)E * N); hipMemset(steps, 0, (size_t)E * 4); hipMemset(episode, 0, (size_t)E * 4);
   const size_t nw = 162 + 6 + 150 * 32 + 32 + 43 * 256 + 256 + 65536 + Lo * 256 + 256 + 65536 + 256 + 1280 + 5;
   hipMalloc((void **)&w, nw * 4); hipMemset(w, 0, nw * 4);
-  const int waves = ((E * N + 63) / 64) * 4;
+  const int waves = ((E * N + 63) / 64) * (prec == 2 ? nwaves : 4);
   hipMalloc((void **)&stamps, (size_t)waves * 16 * 8 + 4096);
 #ifdef CM3_STAMPS
   hipMemcpyToSymbol(HIP_SYMBOL(cm3_stamp_buf), &stamps, sizeof(stamps));
@@ -40,7 +42,7 @@ int main(int argc, char **argv) {
   for (int t = 0; t < 100; ++t) cm3_actor_checkers_f32(&d, &wt, &b, s);
   hipEventRecord(e1, s); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
-  printf("E=%d precision=%d: %.3f us per actor launch (back-to-back eager)\n", E, prec, ms * 1e3 / 100);
+  printf("E=%d precision=%d waves=%d: %.3f us per actor launch (back-to-back eager)\n", E, prec, nwaves, ms * 1e3 / 100);
 #ifdef CM3_STAMPS
   std::vector<long long> h((size_t)waves * 16);
   hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost);
