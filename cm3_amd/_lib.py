@@ -188,7 +188,7 @@ SYMBOLS = {
     "cm3_actor_checkers_packed_bytes": (c_size_t, []),
     "cm3_actor_checkers_pack": (ctypes.c_int, [P(ActorCheckersDesc), P(ActorCheckersWeights), c_void_p, c_void_p]),
     "cm3_policy_rollout_checkers": (ctypes.c_int, [P(CheckersDesc), P(CheckersTraj), P(ActorCheckersDesc), P(ActorCheckersWeights),
-                                                   c_void_p, c_void_p, c_size_t, c_void_p, c_int32, c_void_p]),
+                                                   c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, P(CheckersBufs), c_int32, c_void_p]),
     "cm3_actor_checkers_f32": (ctypes.c_int, [P(ActorCheckersDesc), P(ActorCheckersWeights), P(ActorCheckersBufs),
                                               c_void_p]),
     "cm3_returns_scratch_bytes": (c_size_t, []),

@@ -223,15 +223,18 @@ class CheckersActor(object):
         s = _lib.current_stream_handle(self.device) if stream is None else stream
         _lib.check(self._lib.cm3_actor_checkers_f32(ctypes.byref(d), ctypes.byref(self._wt), ctypes.byref(b), s))
 
-    def enqueue_rollout(self, env_desc, traj, n_envs, obst_stride, n_ticks, epsilon, prev0=None, probs=None, stream=None):
+    def enqueue_rollout(self, env_desc, traj, n_envs, obst_stride, n_ticks, epsilon, prev0=None, probs=None, stream=None,
+                        final_obs=None, prev0_next=None):
         """The whole policy-driven rollout in ONE launch (cm3_policy_rollout_checkers): env_desc / traj are the env's descriptor and
-        the rollout's trajectory struct; probs: optional float32 [T, E, N, 5]."""
+        the rollout's trajectory struct; probs: optional float32 [T, E, N, 5]; final_obs: optional _lib.CheckersBufs naming the env's
+        current-observation buffers, which then receive the state the rollout leaves."""
         epsilon, eps_dev = _epsilon_args(epsilon)
         d = self._desc(n_envs, epsilon, env_desc.env_id_base, obst_stride)
         s = _lib.current_stream_handle(self.device) if stream is None else stream
         _lib.check(self._lib.cm3_policy_rollout_checkers(
-            ctypes.byref(env_desc), ctypes.byref(traj), ctypes.byref(d), ctypes.byref(self._wt), _lib.ptr(prev0), _lib.ptr(probs),
-            0 if probs is None else probs[0].numel() * probs.element_size(), eps_dev, int(n_ticks), s))
+            ctypes.byref(env_desc), ctypes.byref(traj), ctypes.byref(d), ctypes.byref(self._wt), _lib.ptr(prev0), _lib.ptr(prev0_next), _lib.ptr(probs),
+            0 if probs is None else probs[0].numel() * probs.element_size(), eps_dev,
+            None if final_obs is None else ctypes.byref(final_obs), int(n_ticks), s))
 
     def fused_rollout_ok(self, env):
         """cm3_policy_rollout_checkers covers the reference's configurations: split-float16 actor, one agent at stage 1 or two at

@@ -801,12 +801,17 @@ __device__ __forceinline__ void ck_x3_others(const CkX3Planes &L, const float *p
 // conv -> conv_linear -> branch_self -> h2 (+= on acc2) -> actor_out.  Enter with X0 and the tail of X2 visible and the H planes free;
 // b_conv: the conv's first weights, requested by the caller ahead of time.  Leaves the workgroup BEHIND its last barrier with the
 // logits of rows [16w, 16w + 16) written by wave w < 4 (not yet visible to other waves).
-// TABLE (the whole-episode kernel, two agents): acc2 is not an input -- it starts from the rows of the others-branch table
-// (k_ck_actor_others_table) named by cells[agent row], requested when branch_self begins (32 registers that need not live through
-// conv and conv_linear); stage 1 passes cells = NULL: zeros.
-template <bool TABLE = false>
+// HOOKS: the whole-episode kernel starts acc2 from the others-branch table and fetches those rows along the way -- after_conv()
+// (behind the conv's barrier: X0 is dead, the conv's 120 registers of weights are gone), after_lin() (behind conv_linear's barrier)
+// and before_h2(acc2) (behind branch_self's barrier, ahead of the h2 pass); the stand-alone kernel passes none.
+struct CkNoHooks {
+  __device__ __forceinline__ void after_conv() const {}
+  __device__ __forceinline__ void after_lin() const {}
+  __device__ __forceinline__ void before_h2(f32x4 (&)[4][kCkBCT]) const {}
+};
+template <class HOOKS = CkNoHooks>
 __device__ __forceinline__ void ck_x3_self_chain(const CkX3Planes &L, const float *pk, int w, int lane, const uint4 (&b_conv)[2][5],
-                                                 f32x4 (&acc2)[4][kCkBCT], const int32_t *cells = nullptr) {
+                                                 f32x4 (&acc2)[4][kCkBCT], HOOKS hooks = HOOKS()) {
   using namespace ck_actor;
   constexpr int BCT = kCkBCT;
   const int s_rt0 = w & 3, s_half = w >> 2;
@@ -823,6 +828,7 @@ __device__ __forceinline__ void ck_x3_self_chain(const CkX3Planes &L, const floa
   }
   __syncthreads();
   CM3_STAMP(3, false);
+  hooks.after_conv();
   // ---- conv_linear: C1 [64][160] -> X2[:, 0:32], relu ---------------------------------------------------------------------------
   {
     f32x4 acc[1][1];
@@ -835,22 +841,7 @@ __device__ __forceinline__ void ck_x3_self_chain(const CkX3Planes &L, const floa
   }
   __syncthreads();
   CM3_STAMP(4, false);
-  if constexpr (TABLE) {
-    if (cells) {
-      const float *tab = pk + kPOthTab;
-#pragma unroll
-      for (int tt = 0; tt < 4; ++tt) {
-        const int cell = cells[16 * tt + (lane & 15)];
-#pragma unroll
-        for (int c = 0; c < BCT; ++c) {
-          const float4 v = *reinterpret_cast<const float4 *>(tab + (size_t)cell * kH2 + 16 * (BCT * w + c) + 4 * (lane >> 4));
-          acc2[tt][c] = f32x4{v.x, v.y, v.z, v.w};
-        }
-      }
-    } else {
-      zero_tiles(acc2);
-    }
-  }
+  hooks.after_lin();
   // ---- branch_self: X2 [64][64] -> H [64][256], relu; wave w owns units [32w, 32w + 32) from here on ---------------------------------
   {
     f32x4 acc[4][BCT];
@@ -863,6 +854,7 @@ __device__ __forceinline__ void ck_x3_self_chain(const CkX3Planes &L, const floa
   }
   __syncthreads();
   CM3_STAMP(5, false);
+  hooks.before_h2(acc2);
   // ---- h2 = relu(branch_others W_others_h2 [already in acc2] + branch_self W_self_h2 + b) -----------------------------------------
   gemm_x3<4, BCT, 8, true>(L.Hh, L.Hl, kLdHb, 0, pk + kPH2Sh, pk + kPH2Sl, BCT * w, lane, b_h2, acc2);
   float4 bias_h2[BCT];

@@ -1098,10 +1098,18 @@ __device__ __forceinline__ void ckf_fresh_copy(const CheckersParams &p, const ui
 // SEL: a lane's five observation arrays are `alt` instead of `out` where use_alt is set (the one emit of a wave that holds finished
 // envs: their terminal slot) -- the addresses then are per-lane 64-bit values instead of a uniform base plus a 32-bit lane offset,
 // which is why the common case (no finished env in the wave) keeps the plain instantiation.
-template <int N, bool NT = false, int G = kCkG, bool SEL = false>
+// SINK (the whole-episode policy kernel, policy_checkers.hip): the window cells and the normalised values this lane produces are
+// ALSO handed to sink.cell(agent, window cell, three channel bytes) / sink.value(others, index, value) -- that kernel's next network
+// inputs, written to LDS from the registers that hold them anyway (lanes writing a terminal slot, use_alt, hand over nothing).
+struct CkNoSink {
+  static constexpr bool kOn = false;
+  __device__ __forceinline__ void cell(uint32_t, int, uint32_t) const {}
+  __device__ __forceinline__ void value(bool, uint32_t, double) const {}
+};
+template <int N, bool NT = false, int G = kCkG, bool SEL = false, class SINK = CkNoSink>
 __device__ __forceinline__ void ckf_emit_tab(const CheckersParams &p, const CkState<N> &s, const CkLanePlan<N, G> &pl,
                                              const uint4 *lds_tab, int g, uint32_t e, bool env_ok, const CkOut &out_in,
-                                             const CkOut *alt = nullptr, bool use_alt = false) {
+                                             const CkOut *alt = nullptr, bool use_alt = false, const SINK &sink = SINK()) {
   using T = CkPlanTab<N>;
   using P = CkLanePlan<N, G>;
   if (!env_ok) return;
@@ -1173,6 +1181,9 @@ __device__ __forceinline__ void ckf_emit_tab(const CheckersParams &p, const CkSt
       uint32_t v = (en ^ (en & got & 0xfefeu)) | (agent ? pl.amask[it][x] : 0u);
       if ((it + 1) * G * 4 > T::KK * N) v = pl.invalid[it][x] ? 0u : v;  // (compile time: only the slots that can hold padding cells)
       c[x] = v;
+      if constexpr (SINK::kOn) {
+        if (q < T::NQ && !pl.invalid[it][x] && !(SEL && use_alt)) sink.cell(pl.agent[it][x], 4 * q + x - T::KK * (int)pl.agent[it][x], v);
+      }
     }
     if (q < T::NQ) {
       // bytes: c0[0..2] c1[0..2] c2[0..2] c3[0..2] -> three dwords (v_perm_b32: selector byte k picks byte k of {hi, lo})
@@ -1215,6 +1226,9 @@ __device__ __forceinline__ void ckf_emit_tab(const CheckersParams &p, const CkSt
         const uint32_t off = pl.voff[it] & 0x7fffffffu;
         if ((int)pl.voff[it] < 0) ck_st<NT>(at32<double>(out.obs_others, e * (uint32_t)(T::NOO * 8) + off), nval[it]);
         else ck_st<NT>(at32<double>(out.obs_self_v, e * (uint32_t)(T::NSV * 8) + off), nval[it]);
+        if constexpr (SINK::kOn) {
+          if (!(SEL && use_alt)) sink.value((int)pl.voff[it] < 0, off >> 3, nval[it]);
+        }
       }
     }
   }

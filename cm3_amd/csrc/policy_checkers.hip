@@ -22,9 +22,11 @@
 // Trajectories (every array of CheckersRollout, actions and probabilities included) are bit-identical to the alternating launches
 // (tests/test_gpu_actor_checkers.py::test_checkers_policy_rollout_equals_launch_per_tick).  Precision 2 (split float16) only; N = 1
 // (stage 1) or N = 2 (stage 2), the reference's Checkers configurations, reference geometry (3 x 8 band, n_obs 2).
+#ifndef CM3_POLICY_CHECKERS_BODY_ONLY   // (tools/probes/ck_policy_timeline.hip includes the two files WITH their entry points first)
 #define CM3_NO_ENTRY_POINTS 1
 #include "checkers.hip"
 #include "actor_checkers.hip"
+#endif
 
 namespace cm3 {
 
@@ -33,22 +35,44 @@ struct CkPolicyParams {
                           // a CM3_FLAG_FUSED_TICKS step (observation pointers = slot 1, per-tick outputs = slot 0)
   const float *packed;
   const int32_t *prev0;   // optional int32 [E][N]: actions_prev of tick 0 (NULL = zeros, train_onpolicy.py:295)
+  int32_t *prev0_next;    // optional int32 [E][N], out: actions_prev of the NEXT rollout's first tick (the last actions, zeros where the
+                          // last tick ended an episode under auto-reset)
   float *probs;           // optional float [T][E][N][5]
   size_t st_probs;
   const float *eps_dev;
   float eps;
   int stage;
+  // slot 0 of the observation arrays (+ of the goal slots): written at entry from the live state, i.e. what the env's current
+  // observation holds -- the caller need not copy it there
+  CkOut slot0;
+  uint8_t *goals_slot0;
+  // optional: the env's own current-observation buffers and last-actions buffer, written after the last tick (= slot n_ticks /
+  // the last action slot): the caller need not copy them back
+  CkOut final_obs;
+  int32_t *final_actions;
 };
 
-constexpr int kCkpG = 8;   // lanes per env (k_checkers_step_fast's)
+// Lanes per env: 8 N -- the 512 lanes of the workgroup over its 64 / N envs.  (The step kernel of the random-action path uses 8: every
+// lane repeats the short sequential update and produces 1 / G of the outputs.  Here the env phase sits on every tick's critical path
+// between two matrix passes and all eight waves would otherwise wait for four of them: with 16 lanes per two-agent env a lane's share
+// of the emit halves.)
+template <int N> struct CkpGeom { static constexpr int G = 8 * N; };
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is also a release fence for GLOBAL memory: behind the tick's
+// trajectory stores it made every wave wait for their acknowledgement (~1 k cycles, twice per tick).  Nothing in this kernel reads
+// back what it stored to global memory, so the two barriers that follow stores wait for the LDS only.
+__device__ __forceinline__ void ckp_barrier_lds() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 // the 5 x 5 x 3 windows of an env's agents -> float16 rows of X0 (what ck_x3_stage_inputs makes of the obs_self_t bytes): the cell
 // expressions of ckf_emit_tab, lane q of the env takes window cells 4q .. 4q + 3
 template <int N>
-__device__ __forceinline__ void ckp_windows_to_x0(const CkState<N> &s, const CkLanePlan<N, kCkpG> &pl, const uint4 *lds_tab, int g,
+__device__ __forceinline__ void ckp_windows_to_x0(const CkState<N> &s, const CkLanePlan<N, CkpGeom<N>::G> &pl, const uint4 *lds_tab, int g,
                                                   _Float16 *X0, int row0) {
   using T = CkPlanTab<N>;
-  using P = CkLanePlan<N, kCkpG>;
+  using P = CkLanePlan<N, CkpGeom<N>::G>;
+  constexpr int kCkpG = CkpGeom<N>::G;
   const char *tab = reinterpret_cast<const char *>(lds_tab);
   const uint32_t m32 = (uint32_t)s.mask;
   uint32_t rc[N], base[N];
@@ -99,6 +123,17 @@ __device__ __forceinline__ void ckp_windows_to_x0(const CkState<N> &s, const CkL
   }
 }
 
+// the k padding of an X0 row (window bytes 75 .. 95 of the 96 the conv contracts over): X0 shares its storage with the table rows of the
+// h2 pass, which overwrite it every tick -- and 0 x (whatever they left) must be 0
+__device__ __forceinline__ void ckp_zero_x0_pad(_Float16 *X0, int row) {
+  using namespace ck_actor;
+  static_assert(kObs == 75 && kKConvX == 96 && (kLhX0 * 2) % 8 == 0, "one 2-byte and five 8-byte stores per row");
+  _Float16 *r = X0 + row * kLhX0;
+  r[kObs] = (_Float16)0.0f;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) *reinterpret_cast<uint2 *>(r + kObs + 1 + 4 * k) = make_uint2(0u, 0u);
+}
+
 // lane g < N of an env: the tail of agent g's X2 row -- v_obs_self (the env's normalised values, cast to float32 like a TF feed and
 // split), the one-hots of a_prev and of the goal -- and, for two agents, the table row of the others branch: the OTHER agent's cell
 template <int N>
@@ -106,6 +141,7 @@ __device__ __forceinline__ void ckp_row_inputs(const CkState<N> &s, const uint8_
                                                int g, const CkX3Planes &L, int32_t *sCell, int row0) {
   using namespace ck_actor;
   if (g < N) {
+    ckp_zero_x0_pad(L.X0, row0 + g);
     int r = s.r[0], c = s.c[0], ng = s.ng[0], no = s.no[0], gl = goal[0], ap = aprev[0];
     int orr = s.r[N > 1 ? 1 : 0], occ = s.c[N > 1 ? 1 : 0];
 #pragma unroll
@@ -128,17 +164,109 @@ __device__ __forceinline__ void ckp_row_inputs(const CkState<N> &s, const uint8_
   }
 }
 
+// ... and the per-tick form: the emit hands its window cells and normalised values over (CkpSink, from the registers that hold them
+// anyway -- recomputing them as above cost 3.8 k cycles of every tick), lane g < N adds the one-hots and the others-branch cell
+struct CkpSink {
+  static constexpr bool kOn = true;
+  uint16_t *X0w;
+  _Float16 *X2h, *X2l;
+  int row0;
+  __device__ __forceinline__ void cell(uint32_t agent, int cw, uint32_t v) const {
+    // three channel bytes in {0xff, 0, 1} -> the HIGH bytes of their float16 values {0xbc, 0, 0x3c}, all three at once
+    const uint32_t hb = (v & 0x808080u) | ((v & 0x010101u) * 0x3cu);
+    const int at = (row0 + (int)agent) * ck_actor::kLhX0 + 3 * cw;
+    X0w[at] = (uint16_t)((hb & 0xffu) << 8);
+    X0w[at + 1] = (uint16_t)(hb & 0xff00u);
+    X0w[at + 2] = (uint16_t)((hb >> 8) & 0xff00u);
+  }
+  __device__ __forceinline__ void value(bool others, uint32_t idx, double val) const {
+    if (!others) put_split(X2h, X2l, (row0 + (int)(idx >> 2)) * ck_actor::kLhX2 + ck_actor::kLin + (int)(idx & 3u), (float)val);
+  }
+};
+template <int N>
+__device__ __forceinline__ void ckp_row_flags(const CkState<N> &s, const uint8_t (&goal)[N], const int (&aprev)[N], int g,
+                                              const CkX3Planes &L, int32_t *sCell, int row0) {
+  using namespace ck_actor;
+  if (g < N) {
+    ckp_zero_x0_pad(L.X0, row0 + g);
+    int gl = goal[0], ap = aprev[0];
+    int orr = s.r[N > 1 ? 1 : 0], occ = s.c[N > 1 ? 1 : 0];
+#pragma unroll
+    for (int a = 1; a < N; ++a) {
+      const bool me = g == a;
+      gl = me ? (int)goal[a] : gl; ap = me ? aprev[a] : ap;
+      orr = me ? s.r[0] : orr; occ = me ? s.c[0] : occ;
+    }
+    const int at0 = (row0 + g) * kLhX2 + kLin;
+#pragma unroll
+    for (int k = 0; k < kA; ++k) L.X2h[at0 + 4 + k] = ap == k ? (_Float16)1.0f : (_Float16)0.0f;
+    L.X2h[at0 + 9] = gl == 0 ? (_Float16)1.0f : (_Float16)0.0f;
+    L.X2h[at0 + 10] = gl == 0 ? (_Float16)0.0f : (_Float16)1.0f;
+    sCell[row0 + g] = orr * 13 + occ;
+  }
+}
+
+// h2's accumulators start from the others-branch table (two agents; stage 1: zeros): row = the OTHER agent's cell.  A lane's
+// accumulators cover 16 agent rows per tile -- read straight from the table that is 16 scattered 64-byte pieces per load, 128
+// cache-line requests per wave and tick, and cost 1.0 - 1.5 us of a 16.5 us tick.  Instead wave w fetches the eight WHOLE table rows
+// of agent rows [8w, 8w + 8) (one coalesced 1 KB load each) behind the conv, parks them in LDS behind conv_linear (row stride 260
+// floats: the 16 rows of a tile start 4 banks apart), and every wave picks its units out of LDS before the h2 pass.
+constexpr int kCkpTabLd = 260;
+struct CkpTableHooks {
+  const float *tab;     // NULL: stage 1, no others branch
+  const int32_t *sCell;
+  float *sT;
+  int w, lane;
+  float4 rows[8];
+  __device__ __forceinline__ void after_conv() {
+#ifndef CM3_PROBE_NO_TABLE
+    if (tab) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) rows[j] = reinterpret_cast<const float4 *>(tab + (size_t)sCell[8 * w + j] * ck_actor::kH2)[lane];
+    }
+#endif
+  }
+  __device__ __forceinline__ void after_lin() {
+#ifndef CM3_PROBE_NO_TABLE
+    if (tab) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) *reinterpret_cast<float4 *>(sT + (8 * w + j) * kCkpTabLd + 4 * lane) = rows[j];
+    }
+#endif
+  }
+  __device__ __forceinline__ void before_h2(f32x4 (&acc2)[4][kCkBCT]) {
+#ifndef CM3_PROBE_NO_TABLE
+    if (tab) {
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int c = 0; c < kCkBCT; ++c) {
+          const float4 v = *reinterpret_cast<const float4 *>(sT + (16 * tt + (lane & 15)) * kCkpTabLd + 16 * (kCkBCT * w + c) + 4 * (lane >> 4));
+          acc2[tt][c] = f32x4{v.x, v.y, v.z, v.w};
+        }
+      return;
+    }
+#endif
+    zero_tiles(acc2);
+  }
+};
+
 template <int N> __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) k_ck_policy_rollout(const CkPolicyParams q) {
   using namespace ck_actor;
-  constexpr int G = kCkpG, EPW = 64 / N, ENV_WAVES = EPW * G / 64;
+  constexpr int G = CkpGeom<N>::G, EPW = 64 / N, ENV_WAVES = EPW * G / 64;
+  static_assert(ENV_WAVES == 8, "every wave takes part in the env phase");
   static_assert(N == 1 || N == 2, "the whole-episode Checkers kernel covers the reference's configurations: one or two agents");
   const CheckersParams &p = q.ck;
   __shared__ __attribute__((aligned(16))) _Float16 sH[kCkX3HBytes / 2];
-  __shared__ __attribute__((aligned(16))) _Float16 sX0[kCkX3X0Bytes / 2];
+  __shared__ __attribute__((aligned(16))) float sT[64 * kCkpTabLd];    // the tick's 64 table rows; X0 lives in its first 13 KB
+                                                                       // (dead once the conv has run, rewritten by the env phase)
+  static_assert(kCkX3X0Bytes <= (int)sizeof(sT), "X0 inside the table staging");
+  _Float16 *sX0 = reinterpret_cast<_Float16 *>(sT);
   __shared__ __attribute__((aligned(16))) _Float16 sX2[kCkX3X2Bytes / 2];
   __shared__ float sLG[64][8];
   __shared__ __attribute__((aligned(16))) uint4 lds_tab[48];           // board / norm table (CkBoardTab), one copy per workgroup
   __shared__ __attribute__((aligned(16))) uint4 lds_fresh[26];         // the fresh-episode observation record (CkFresh)
+  __shared__ __attribute__((aligned(16))) uint4 sPlan[G][sizeof(CkLanePlanRaw<N, G>) / 16];   // the emit plan of lane g of ANY env
   __shared__ int32_t sAct[64], sCell[64];
   __shared__ int2 sMeta[EPW];                                          // {episode, steps} of every env, for the sampling uniforms
   CkX3Planes L;
@@ -195,11 +323,7 @@ template <int N> __global__ void __launch_bounds__(512) __attribute__((amdgpu_wa
   const bool head_lane = w < 4 && lane < 16;
   uint32_t ublock = 0u;
   if (head_lane) ublock = actor_block_word(p.seed, (uint64_t)(p.env_id_base + (int64_t)(e_h < (size_t)p.E ? e_h : (size_t)p.E - 1)), i_h);
-  // zero fills, once: the k padding of X0 (75 .. 95), the tail of X2 beyond the concat (43 .. 63) and the lo plane of its one-hots
-  for (int idx = tid; idx < 64 * (kKConvX - kObs); idx += 512) {
-    const int r = idx / (kKConvX - kObs), k = kObs + idx - r * (kKConvX - kObs);
-    sX0[r * kLhX0 + k] = (_Float16)0.0f;
-  }
+  // zero fill, once: the tail of X2 beyond the concat (43 .. 63) and the lo plane of its one-hots
   for (int idx = tid; idx < 64 * 32; idx += 512) {
     const int r = idx >> 5, k = kLin + (idx & 31);
     L.X2h[r * kLhX2 + k] = (_Float16)0.0f;
@@ -208,14 +332,20 @@ template <int N> __global__ void __launch_bounds__(512) __attribute__((amdgpu_wa
   __syncthreads();   // tables and zero fills are in
   if (env_wave) {
     // (the lane's emit plan -- which cells, which values it produces -- is NOT kept across the matrix phases: ~54 registers next to
-    // the gemm's; its 6 sixteen-byte entries are re-requested per tick and arrive while the agents act)
+    // the gemm's.  It depends on g alone: the first env's lanes park the 6 sixteen-byte entries in LDS, every tick re-reads them)
     CkLanePlanRaw<N, G> raw;
     CkLanePlan<N, G> pl;
     ckf_plan_fetch<N, G>(g, raw);
+    if (tid < G) *reinterpret_cast<CkLanePlanRaw<N, G> *>(&sPlan[g][0]) = raw;
     ckf_plan_decode<N, G>(raw, pl);
     ckp_windows_to_x0<N>(s, pl, lds_tab, g, sX0, row0);
     ckp_row_inputs<N>(s, lv.goal, aprev, lds_tab, g, L, sCell, row0);
     if (g == 0) sMeta[el] = make_int2((int)lv.episode, lv.steps);
+    ckf_emit_tab<N, false, G>(p, s, pl, lds_tab, g, e, env_ok, q.slot0);     // slot 0 = the observation the first tick acts on
+    if (q.goals_slot0 && writer) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) q.goals_slot0[(size_t)e * N + i] = lv.goal[i];
+    }
   }
   __syncthreads();
 
@@ -225,14 +355,16 @@ template <int N> __global__ void __launch_bounds__(512) __attribute__((amdgpu_wa
     // ---- policy ---------------------------------------------------------------------------------------------------------------
     // (a per-tick copy of the weight pointer the compiler cannot see through: with the loop-invariant one it hoisted every tile
     // address of every layer out of the tick loop and spilled ~100 vector registers to scratch memory)
+    CM3_STAMP(0, false);
     const float *pkt = pk;
     asm volatile("" : "+s"(pkt));
     // (the conv's first weights are requested here, not ahead of the env work: held across it or across the closing barrier they cost
     // the two-agent build 14 spilled registers)
     load_bx<5, kKConvX / 32>(pkt + kXConvH, pkt + kXConvL, 5 * (w >> 2), lane, b_conv);
     f32x4 acc2[4][kCkBCT];
-    // (two agents: h2's accumulators start from the others-branch table, row = the other agent's cell; stage 1: zeros)
-    ck_x3_self_chain<true>(L, pkt, w, lane, b_conv, acc2, stage2 ? sCell : nullptr);
+    CkpTableHooks hooks;
+    hooks.tab = stage2 ? pkt + kPOthTab : nullptr; hooks.sCell = sCell; hooks.sT = sT; hooks.w = w; hooks.lane = lane;
+    ck_x3_self_chain<CkpTableHooks &>(L, pkt, w, lane, b_conv, acc2, hooks);
     if (w < 4) {
       __builtin_amdgcn_s_waitcnt(0);
       __builtin_amdgcn_wave_barrier();
@@ -254,11 +386,12 @@ template <int N> __global__ void __launch_bounds__(512) __attribute__((amdgpu_wa
         }
       }
     }
-    __syncthreads();   // actions are in LDS; every wave is done with this tick's inputs and activations
+    CM3_STAMP(13, false);
+    ckp_barrier_lds();   // actions are in LDS; every wave is done with this tick's inputs and activations
+    CM3_STAMP(14, false);
     // ---- env step of the workgroup's envs (checkers.py:228-262): k_checkers_step_fast's tick with the actions just sampled --------
     if (env_wave) {
-      CkLanePlanRaw<N, G> raw;
-      ckf_plan_fetch<N, G>(g, raw);
+      const CkLanePlanRaw<N, G> raw = *reinterpret_cast<const CkLanePlanRaw<N, G> *>(&sPlan[g][0]);
       int act[N];
 #pragma unroll
       for (int i = 0; i < N; ++i) act[i] = sAct[row0 + i];
@@ -267,15 +400,19 @@ template <int N> __global__ void __launch_bounds__(512) __attribute__((amdgpu_wa
                                                         , nullptr
 #endif
                                                         , act);
+      CM3_STAMP(9, false);
       CkLanePlan<N, G> pl;
       ckf_plan_decode<N, G>(raw, pl);
+      CkpSink sink;
+      sink.X0w = reinterpret_cast<uint16_t *>(sX0); sink.X2h = L.X2h; sink.X2l = L.X2l; sink.row0 = row0;
       if (!__any(ended)) {
-        ckf_emit_tab<N, false, G>(p, s, pl, lds_tab, g, e, env_ok, ck_out_tick(p, t));
+        ckf_emit_tab<N, false, G, false, CkpSink>(p, s, pl, lds_tab, g, e, env_ok, ck_out_tick(p, t), nullptr, false, sink);
       } else {
         // a wave with finished envs (k_checkers_step_fast): ONE emit -- terminal slot for the finished envs, regular slot for the
         // others -- then the finished envs restart and their regular slot gets the fresh-episode record
         const CkOut o_tick = ck_out_tick(p, t), o_term = ck_out_term(p, t);
-        ckf_emit_tab<N, false, G, true>(p, s, pl, lds_tab, g, e, env_ok && (!ended || p.term_grid != nullptr), o_tick, &o_term, ended);
+        // (env_ok decides about the global stores only; the LDS inputs of a clamped lane's rows are never used)
+        ckf_emit_tab<N, false, G, true, CkpSink>(p, s, pl, lds_tab, g, e, env_ok && (!ended || p.term_grid != nullptr), o_tick, &o_term, ended, sink);
         if (ended) {
           ck_restart_env<N>(p, e, ec, writer, s, lv);
           if (env_ok) ckf_fresh_copy<N, false, G>(p, lds_fresh, N == 1 ? (int)lv.goal[0] : 0, g, e, o_tick);
@@ -286,16 +423,39 @@ template <int N> __global__ void __launch_bounds__(512) __attribute__((amdgpu_wa
 #pragma unroll
         for (int i = 0; i < N; ++i) *at32<uint8_t>(gn, e * N + i) = lv.goal[i];
       }
+      CM3_STAMP(12, false);
       // the next tick's inputs: a fresh episode starts from actions_prev = zeros (train_onpolicy.py:295), otherwise the actions just taken
 #pragma unroll
       for (int i = 0; i < N; ++i) aprev[i] = ended ? 0 : act[i];
-      ckp_windows_to_x0<N>(s, pl, lds_tab, g, sX0, row0);
-      ckp_row_inputs<N>(s, lv.goal, aprev, lds_tab, g, L, sCell, row0);
+      if (ended) {   // the fresh episode's observation was COPIED to the slot (CkFresh): its LDS form is worked out from the state
+        ckp_windows_to_x0<N>(s, pl, lds_tab, g, sX0, row0);
+        ckp_row_inputs<N>(s, lv.goal, aprev, lds_tab, g, L, sCell, row0);
+      } else {
+        ckp_row_flags<N>(s, lv.goal, aprev, g, L, sCell, row0);
+      }
       if (g == 0) sMeta[el] = make_int2((int)lv.episode, lv.steps);
+      CM3_STAMP(15, false);
     }
-    __syncthreads();
+    ckp_barrier_lds();
+    CM3_STAMP(8, false);
   }
-  if (writer) ck_store_env<N>(p, e, s, lv);
+  if (writer) {
+    ck_store_env<N>(p, e, s, lv);
+    if (q.prev0_next) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) q.prev0_next[(size_t)e * N + i] = aprev[i];
+    }
+  }
+  if (q.final_obs.grid && env_wave) {   // the env object's current observation <- the state the rollout leaves
+    const CkLanePlanRaw<N, G> raw = *reinterpret_cast<const CkLanePlanRaw<N, G> *>(&sPlan[g][0]);
+    CkLanePlan<N, G> pl;
+    ckf_plan_decode<N, G>(raw, pl);
+    ckf_emit_tab<N, false, G>(p, s, pl, lds_tab, g, e, env_ok, q.final_obs);
+    if (q.final_actions && writer) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) q.final_actions[(size_t)e * N + i] = sAct[row0 + i];
+    }
+  }
 }
 
 template <int N> static int ckp_launch(const CkPolicyParams &q, hipStream_t s) {
@@ -306,7 +466,7 @@ template <int N> static int ckp_launch(const CkPolicyParams &q, hipStream_t s) {
   if ((size_t)N * 32 > widest) widest = (size_t)N * 32;
   if ((size_t)q.ck.E * widest >= ((size_t)1 << 32))
     return fail(CM3_ERR_INVALID, "the Checkers step addresses at most 4 GiB per array: %d envs x %d agents is too large", q.ck.E, N);
-  note_variant("k_ck_policy_rollout", 0, N, 8, q.ck.n_ticks > 1, 2, 0, 0, 0, kCkpG);
+  note_variant("k_ck_policy_rollout", 0, N, 8, q.ck.n_ticks > 1, 2, 0, 0, 0, CkpGeom<N>::G);
   hipLaunchKernelGGL((k_ck_policy_rollout<N>), dim3((unsigned)((rows + 63) / 64)), dim3(512), 0, s, q);
   CM3_HIP_CHECK(hipGetLastError());
   return CM3_OK;
@@ -315,8 +475,9 @@ template <int N> static int ckp_launch(const CkPolicyParams &q, hipStream_t s) {
 }  // namespace cm3
 
 extern "C" int cm3_policy_rollout_checkers(const cm3_checkers_desc *d, const cm3_checkers_traj *t, const cm3_actor_checkers_desc *ad,
-                                           const cm3_actor_checkers_weights *wt, const int32_t *actions_prev0, float *probs,
-                                           size_t probs_stride, const float *epsilon_dev, int32_t n_ticks, void *stream) {
+                                           const cm3_actor_checkers_weights *wt, const int32_t *actions_prev0, int32_t *actions_prev_next, float *probs,
+                                           size_t probs_stride, const float *epsilon_dev, const cm3_checkers_bufs *final_obs,
+                                           int32_t n_ticks, void *stream) {
   using namespace cm3;
   CM3_REQUIRE(d && t && ad && wt, "null argument");
   CM3_REQUIRE(n_ticks >= 1, "n_ticks must be >= 1");
@@ -345,10 +506,21 @@ extern "C" int cm3_policy_rollout_checkers(const cm3_checkers_desc *d, const cm3
   ck_traj_strides(t, n_ticks, q.ck);
   q.packed = (const float *)wt->packed;
   q.prev0 = actions_prev0;
+  q.prev0_next = actions_prev_next;
   q.probs = probs;
   q.st_probs = probs_stride;
   q.eps = ad->epsilon;
   q.eps_dev = epsilon_dev;
   q.stage = ad->stage;
+  q.slot0.grid = t->grid; q.slot0.vec = t->vec; q.slot0.obs_others = t->obs_others; q.slot0.obs_self_t = t->obs_self_t;
+  q.slot0.obs_self_v = t->obs_self_v;
+  q.goals_slot0 = t->goals_slots;
+  if (final_obs) {
+    CM3_REQUIRE(final_obs->grid && final_obs->vec && final_obs->obs_others && final_obs->obs_self_t && final_obs->obs_self_v,
+                "final_obs needs the five observation arrays (actions optional)");
+    q.final_obs.grid = final_obs->grid; q.final_obs.vec = final_obs->vec; q.final_obs.obs_others = final_obs->obs_others;
+    q.final_obs.obs_self_t = final_obs->obs_self_t; q.final_obs.obs_self_v = final_obs->obs_self_v;
+    q.final_actions = final_obs->actions;
+  }
   return d->n_agents == 1 ? ckp_launch<1>(q, (hipStream_t)stream) : ckp_launch<2>(q, (hipStream_t)stream);
 }

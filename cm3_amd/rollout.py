@@ -821,7 +821,9 @@ class CheckersRollout(object):
         self.local_rewards = z(T, E, N, d=torch.float64)
         self.reward = z(T, E, d=torch.float64)
         self.done = z(T, E, d=torch.uint8)
-        self.prev0 = z(E, N, d=torch.int32)                    # actions_prev of slot 0 (zeros at an episode start)
+        self._prev_bufs = (z(E, N, d=torch.int32), z(E, N, d=torch.int32), z(E, N, d=torch.int32))
+        self.prev0 = self._prev_bufs[1]                        # actions_prev of slot 0 (zeros at an episode start)
+        self._rolled = None
         self.probs = z(T, E, N, 5, d=torch.float32) if record_probs else None
         if self.auto_reset:
             self._term_grid_raw = z(T, E, env.grid_stride, d=torch.int8)
@@ -835,6 +837,8 @@ class CheckersRollout(object):
         else:
             self.goal_slots = None
         self._started = False
+        self._goals_onehot = None
+        self._traj_cache = None               # (the ctypes structs of the one-launch rollout: the buffers never move)
         self._actor_graph = _ActorGraphCache(dev)
         self._lib = _lib.lib()
 
@@ -909,13 +913,16 @@ class CheckersRollout(object):
             _lib.check(self._lib.cm3_checkers_step(ctypes.byref(env._desc), ctypes.byref(b), stream))
         env._desc.flags = 0
 
-    def _enqueue_policy_rollout(self, actor, epsilon, stream):
-        """The same T ticks as _enqueue_actor_rollout in ONE launch (csrc/policy_checkers.hip)."""
+    def _enqueue_policy_rollout(self, actor, epsilon, stream, prev0_next=None):
+        """The same T ticks as _enqueue_actor_rollout in ONE launch (csrc/policy_checkers.hip), slot 0 and the env's
+        current-observation buffers (what _load_slot0 / _store_back copy for the other modes) included."""
         env = self.env
         env._desc.flags = self._base_flags()
-        traj = self._traj()
+        if self._traj_cache is None or self._traj_cache[0] != env._cur:
+            self._traj_cache = (env._cur, self._traj(), env._bufs(env._cur))
+        _, traj, final = self._traj_cache
         actor.enqueue_rollout(env._desc, traj, env.E, env.obst_stride, self.T, epsilon, prev0=self.prev0, probs=self.probs,
-                              stream=stream)
+                              stream=stream, final_obs=final, prev0_next=prev0_next)
         env._desc.flags = 0
 
     def _load_slot0(self):
@@ -936,34 +943,56 @@ class CheckersRollout(object):
         _copy_pairs([(s["grid_raw"], self._grid_raw[T]), (s["obs_self_t_raw"], self._obst_raw[T]), (s["vec"], self.vec[T]),
                      (s["obs_others"], self.obs_others[T]), (s["obs_self_v"], self.obs_self_v[T]),
                      (s["actions"], self.actions[T - 1])], env._stream())
-        # actions_prev of the next collect()'s first transition (the last actions, zeros where that tick ended an episode) is worked
-        # out by the next collect() that continues without a reset -- from done / actions of this rollout, which it has not yet
-        # overwritten by then; a collector that resets every time (episode-synchronous envs) never pays those launches
-        self._next_prev0 = None
 
     def collect(self, goals=None, policy=None, epsilon=0.0, reset=None):
         """goals: one-hot [N,2] / [E,N,2] (train_onpolicy.py:287-293); needed whenever the env is reset.
-        policy None = uniform random actions drawn in-kernel; a cm3_amd.actor.CheckersActor = the on-device policy (actor
-        and step launches alternate inside one hipGraph); else policy(actions_prev, obs_others, obs_self_t, obs_self_v,
-        goals) -> [E,N] on the host.  reset: None -> always for an episode-synchronous env, only the first time for a
-        continuous (auto-reset) one."""
+        policy None = uniform random actions drawn in-kernel; a cm3_amd.actor.CheckersActor = the on-device policy (the whole
+        rollout in one launch where that kernel applies, else actor and step launches alternating inside one hipGraph: policy_mode);
+        else policy(actions_prev, obs_others, obs_self_t, obs_self_v, goals) -> [E,N] on the host.  reset: None -> always for an
+        episode-synchronous env, only the first time for a continuous (auto-reset) one."""
         env = self.env
+        one_launch = (policy is not None and hasattr(policy, "enqueue_rollout") and self.policy_mode == "auto"
+                      and policy.fused_rollout_ok(env))
         if reset is None:
             reset = (not self.auto_reset) or (not self._started)
+        # actions_prev of tick 0 (self.prev0; train_onpolicy.py:295,345): zeros after a reset, else the previous rollout's last actions
+        # (zeros where its last tick ended an episode).  Three buffers: one that holds zeros and is never written, two that take
+        # turns -- the one-launch kernel writes the NEXT rollout's prev0 into the spare one, so nothing is launched for it here.
+        pz, pa, pb = self._prev_bufs
         if reset:
             if goals is None:
                 raise Cm3Error("collect() resets the env here and needs goals")
-            env.reset(goals)
-            self.prev0.zero_()
+            env.reset(goals, quiet=True)
+            if one_launch:
+                self.prev0 = pz
+            else:
+                self.prev0 = pa
+                self.prev0.zero_()
         elif self._started:
-            if self._next_prev0 is None:
-                keep = (self.done[self.T - 1] == 0).unsqueeze(1)
-                self._next_prev0 = torch.where(keep, self.actions[self.T - 1], torch.zeros_like(self.actions[0]))
-            self.prev0.copy_(self._next_prev0)
+            if self._rolled is not None and one_launch:
+                self.prev0 = self._rolled
+            else:
+                # (the launch-per-tick modes read prev0 from a CAPTURED graph: always the same buffer, pa)
+                if self._rolled is not None:
+                    nxt = self._rolled
+                else:
+                    keep = (self.done[self.T - 1] == 0).unsqueeze(1)
+                    nxt = torch.where(keep, self.actions[self.T - 1], torch.zeros_like(self.actions[0]))
+                self.prev0 = pa
+                if nxt is not pa:
+                    pa.copy_(nxt)
+        self._rolled = None
         self._started = True
-        self._load_slot0()
-        self.goals_onehot = env.goals.clone()
+        self._goals_onehot = None             # (lazy: see goals_onehot)
         stream = env._stream()
+        if one_launch:
+            # cm3_policy_rollout_checkers writes slot 0 from the live state and hands the state it leaves to the env's own
+            # current-observation buffers: no copies around the launch
+            spare = pa if self.prev0 is not pa else pb
+            self._enqueue_policy_rollout(policy, epsilon, stream, spare)
+            self._rolled = spare
+            return self
+        self._load_slot0()
         if policy is None:
             # random-action branch (train_onpolicy.py:305-307): cm3_checkers_rollout -- one fused launch, or T step
             # launches bound to their trajectory slots and replayed as one hipGraph
@@ -975,10 +1004,8 @@ class CheckersRollout(object):
                 _lib.check(self._lib.cm3_graph_launch(self._graph, stream))
             else:
                 self._enqueue_random(stream, False)
-        elif hasattr(policy, "enqueue") and hasattr(policy, "act"):            # on-device actor
-            if self.policy_mode == "auto" and policy.fused_rollout_ok(env):     # one launch: nothing to capture
-                self._enqueue_policy_rollout(policy, epsilon, stream)
-            elif self.use_graph:
+        elif hasattr(policy, "enqueue") and hasattr(policy, "act"):            # on-device actor, a launch pair per tick
+            if self.use_graph:
                 cache = self._actor_graph
                 cache.launch(self._lib, policy, epsilon,
                              lambda st: self._enqueue_actor_rollout(policy, cache.eps, st), stream)
@@ -995,6 +1022,14 @@ class CheckersRollout(object):
             env._desc.flags = 0
         self._store_back()
         return self
+
+    @property
+    def goals_onehot(self):
+        """[E,N,2] one-hot goals of the rollout's episodes when no goal slots are recorded (episode-synchronous envs: the goals the
+        env was reset with; they cannot change inside a collect()).  Built on first use: a collect() does not pay for it."""
+        if self._goals_onehot is None:
+            self._goals_onehot = self.env.goals.clone()
+        return self._goals_onehot
 
     def actions_prev_at(self, t):
         """int32 [E,N]: the actions_prev fed at tick t (train_onpolicy.py:295,345)."""

@@ -464,14 +464,16 @@ int cm3_actor_checkers_f32(const cm3_actor_checkers_desc *desc, const cm3_actor_
  * leaving the kernel; env state in registers, the network's inputs written straight into LDS, the others branch of the two-agent
  * network read from a table that cm3_actor_checkers_pack builds with the forward pass's own code.  `traj` as for
  * cm3_checkers_rollout (slot 0 of the observation arrays = the caller's current observation is NOT read: the live state is);
- * actions_prev0: optional int32 [E][N], actions_prev of tick 0 (NULL = zeros, train_onpolicy.py:295), later ticks use the actions
- * just taken, zeros after a tick that ended an episode under CM3_FLAG_AUTO_RESET; probs: optional float [n_ticks][E][N][5] with
+ * actions_prev0: optional int32 [E][N], actions_prev of tick 0 (NULL = zeros, train_onpolicy.py:295); later ticks use the actions just
+ * taken, zeros after a tick that ended an episode under CM3_FLAG_AUTO_RESET; actions_prev_next: optional int32 [E][N] output, the
+ * actions_prev of the NEXT rollout's first tick (a different buffer); probs: optional float [n_ticks][E][N][5] with
  * probs_stride BYTES between ticks; epsilon_dev: optional device float read at launch instead of actor->epsilon.
  * One or two agents (config_checkers_stage1 / stage2; actor->stage = n_agents), reference geometry, 4-byte padded records.
  * Every output equals, bit for bit, what n_ticks x (cm3_actor_checkers_f32, cm3_checkers_step) write. */
 int cm3_policy_rollout_checkers(const cm3_checkers_desc *desc, const cm3_checkers_traj *traj, const cm3_actor_checkers_desc *actor,
-                                const cm3_actor_checkers_weights *weights, const int32_t *actions_prev0, float *probs,
-                                size_t probs_stride, const float *epsilon_dev, int32_t n_ticks, void *stream);
+                                const cm3_actor_checkers_weights *weights, const int32_t *actions_prev0, int32_t *actions_prev_next, float *probs,
+                                size_t probs_stride, const float *epsilon_dev, const cm3_checkers_bufs *final_obs,
+                                int32_t n_ticks, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Advantage normalisation (build-defined; the reference's advantage, alg_credit.py:334-357, is not normalised).
