@@ -148,7 +148,12 @@ __global__ void __launch_bounds__(256) k_ck_actor_pack(const CkActorParams p, fl
           case 1: wv = k < 25 * kConvF ? p.lin_w[k * kLin + n] : 0.0f; break;
           case 2: wv = k < kCat ? p.self_w[k * kH1 + n] : 0.0f; break;
           case 3: wv = (stage2 && k < p.Lo) ? p.oth_w[k * kH1 + n] : 0.0f; break;
-          default: wv = n < kA ? p.out_w[k * kA + n] : 0.0f; break;
+          default: {   // actor_out: k-step st = the wave that owns units [32 st, 32 st + 32); slot 8 hi + q of it is unit
+                       // 32 st + 4 hi + q (q < 4: the lane's first column tile) or 32 st + 16 + 4 hi + q - 4 (its second)
+            const int hi4 = lane >> 4, unit = 32 * st + (q < 4 ? 4 * hi4 + q : 16 + 4 * hi4 + q - 4);
+            wv = n < kA ? p.out_w[unit * kA + n] : 0.0f;
+            break;
+          }
         }
         const _Float16 hi = (_Float16)wv;
         pair[h] = low ? (_Float16)(wv - (float)hi) : hi;
@@ -720,7 +725,43 @@ template <int CT> __device__ __forceinline__ void load_bias4(const float *bias, 
   for (int c = 0; c < CT; ++c) b[c] = *reinterpret_cast<const float4 *>(bias + 16 * (ct0 + c) + 4 * (lane >> 4));
 }
 
-// O[agent row][unit] = relu(acc + bias[unit]) as float16 hi / lo planes, transposed tiles (see gemm_x3)
+// The bias rides in as the accumulators' start value (round 6: one VALU instruction per value less in every epilogue; a unit's bias
+// is then the FIRST term of its sum instead of the last): a lane's four units of column tile c are the same for every row tile
+template <int RT, int CT> __device__ __forceinline__ void bias_tiles(const float4 (&bias)[CT], f32x4 (&acc)[RT][CT]) {
+#pragma unroll
+  for (int t = 0; t < RT; ++t)
+#pragma unroll
+    for (int c = 0; c < CT; ++c) acc[t][c] = f32x4{bias[c].x, bias[c].y, bias[c].z, bias[c].w};
+}
+
+// v = hi + lo + O(2^-22 v): hi = float16(v), lo = float16(v - hi)
+__device__ __forceinline__ void split4(const float (&v)[4], f16x4 &vh, f16x4 &vl) {
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    vh[reg] = (_Float16)v[reg];
+    vl[reg] = (_Float16)(v[reg] - (float)vh[reg]);
+  }
+}
+
+// O[agent row][unit] = relu(acc) as float16 hi / lo planes, transposed tiles (see gemm_x3); the bias is already in acc (bias_tiles)
+template <int RT, int CT>
+__device__ __forceinline__ void store_relu_x3b(_Float16 *Oh, _Float16 *Ol, int ldo, int rt0, int ct0, int lane, const f32x4 (&acc)[RT][CT]) {
+  const int col = lane & 15, hi = lane >> 4;
+#pragma unroll
+  for (int c = 0; c < CT; ++c) {
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      const float v[4] = {fmaxf(acc[t][c][0], 0.0f), fmaxf(acc[t][c][1], 0.0f), fmaxf(acc[t][c][2], 0.0f), fmaxf(acc[t][c][3], 0.0f)};
+      f16x4 vh, vl;
+      split4(v, vh, vl);
+      const int at = (16 * (rt0 + t) + col) * ldo + 16 * (ct0 + c) + 4 * hi;
+      *reinterpret_cast<f16x4 *>(Oh + at) = vh;
+      *reinterpret_cast<f16x4 *>(Ol + at) = vl;
+    }
+  }
+}
+
+// O[agent row][unit] = relu(acc + bias[unit]) as float16 hi / lo planes, transposed tiles (see gemm_x3) -- the f32 / bf16 kernels' form
 template <int RT, int CT>
 __device__ __forceinline__ void store_relu_x3(_Float16 *Oh, _Float16 *Ol, int ldo, int rt0, int ct0, const float4 (&bias)[CT], int lane,
                                               const f32x4 (&acc)[RT][CT]) {
@@ -774,8 +815,18 @@ static_assert(2 * 64 * ck_actor::kLhC1 * 2 <= kCkX3HBytes, "the C1 planes must f
 // function of a row's v_obs_others.  The whole-episode kernel (policy_checkers.hip) reads that state from a table instead
 // (cm3_actor_checkers_pack builds it with this very function over the 91 cells another agent can stand on), bit for bit.
 constexpr int kCkBCT = 2;   // column tiles per wave in the 256-wide layers
+#ifndef CM3_X3_CONV_STAMP
+#define CM3_X3_CONV_STAMP 3   // (probe builds: the timeline slot of "conv done"; the policy probe moves it off ck_tick_env's slot 3)
+#endif
 
-// h2 accumulators <- branch_others W_others_h2.  Reads XO, uses the H planes.  Enter with XO visible to the workgroup; leaves BEHIND a
+// h2's accumulators start from its bias b (wave w: units [32w, 32w + 32))
+__device__ __forceinline__ void ck_x3_h2_bias(const float *pk, int w, int lane, f32x4 (&acc2)[4][kCkBCT]) {
+  float4 bias_h2[kCkBCT];
+  load_bias4<kCkBCT>(pk + ck_actor::kPH2B, kCkBCT * w, lane, bias_h2);
+  bias_tiles(bias_h2, acc2);
+}
+
+// h2 accumulators += branch_others W_others_h2.  Reads XO, uses the H planes.  Enter with XO visible to the workgroup; leaves BEHIND a
 // barrier: the H planes are free.
 __device__ __forceinline__ void ck_x3_others(const CkX3Planes &L, const float *pk, int w, int lane, f32x4 (&acc2)[4][kCkBCT]) {
   using namespace ck_actor;
@@ -786,10 +837,10 @@ __device__ __forceinline__ void ck_x3_others(const CkX3Planes &L, const float *p
   load_bias4<BCT>(pk + kPOthB, BCT * w, lane, bias_oth);
   {
     f32x4 acc[4][BCT];
-    zero_tiles(acc);
+    bias_tiles(bias_oth, acc);
     gemm_x3<4, BCT, 1, true>(L.XOh, L.XOl, kLhXO, 0, pk + kXOthH, pk + kXOthL, BCT * w, lane, b_oth, acc);
     load_bx<BCT, 8>(pk + kPH2Oh, pk + kPH2Ol, BCT * w, lane, b_h2);
-    store_relu_x3<4, BCT>(L.Hh, L.Hl, kLdHb, 0, BCT * w, bias_oth, lane, acc);
+    store_relu_x3b<4, BCT>(L.Hh, L.Hl, kLdHb, 0, BCT * w, lane, acc);
   }
   __syncthreads();
   CM3_STAMP(8, false);
@@ -815,29 +866,29 @@ __device__ __forceinline__ void ck_x3_self_chain(const CkX3Planes &L, const floa
   using namespace ck_actor;
   constexpr int BCT = kCkBCT;
   const int s_rt0 = w & 3, s_half = w >> 2;
-  uint4 b_lin[2][1], b_self[2][BCT], b_h2[2][BCT], b_out[2][1];
+  uint4 b_lin[2][1], b_self[2][BCT], b_h2[2][BCT];
   // ---- conv (Toeplitz): X0 [64][96] -> C1 [64][160], relu ------------------------------------------------------------------------
   {
     f32x4 acc[1][5];
     float4 bias[5];
     load_bias4<5>(pk + kPConvB, 5 * s_half, lane, bias);
-    zero_tiles(acc);
+    bias_tiles(bias, acc);
     gemm_x3<1, 5, kKConvX / 32, false>(L.X0, L.X0, kLhX0, s_rt0, pk + kXConvH, pk + kXConvL, 5 * s_half, lane, b_conv, acc);
     load_bx<1, kKLin / 32>(pk + kXLinH, pk + kXLinL, s_half, lane, b_lin);
-    store_relu_x3<1, 5>(L.C1h, L.C1l, kLhC1, s_rt0, 5 * s_half, bias, lane, acc);
+    store_relu_x3b<1, 5>(L.C1h, L.C1l, kLhC1, s_rt0, 5 * s_half, lane, acc);
   }
   __syncthreads();
-  CM3_STAMP(3, false);
+  CM3_STAMP(CM3_X3_CONV_STAMP, false);
   hooks.after_conv();
   // ---- conv_linear: C1 [64][160] -> X2[:, 0:32], relu ---------------------------------------------------------------------------
   {
     f32x4 acc[1][1];
     float4 bias[1];
     load_bias4<1>(pk + kPLinB, s_half, lane, bias);
-    zero_tiles(acc);
+    bias_tiles(bias, acc);
     gemm_x3<1, 1, kKLin / 32, true>(L.C1h, L.C1l, kLhC1, s_rt0, pk + kXLinH, pk + kXLinL, s_half, lane, b_lin, acc);
     load_bx<BCT, kKSelfX / 32>(pk + kXSelfH, pk + kXSelfL, BCT * w, lane, b_self);
-    store_relu_x3<1, 1>(L.X2h, L.X2l, kLhX2, s_rt0, s_half, bias, lane, acc);
+    store_relu_x3b<1, 1>(L.X2h, L.X2l, kLhX2, s_rt0, s_half, lane, acc);
   }
   __syncthreads();
   CM3_STAMP(4, false);
@@ -847,35 +898,69 @@ __device__ __forceinline__ void ck_x3_self_chain(const CkX3Planes &L, const floa
     f32x4 acc[4][BCT];
     float4 bias[BCT];
     load_bias4<BCT>(pk + kPSelfB, BCT * w, lane, bias);
-    zero_tiles(acc);
+    bias_tiles(bias, acc);
     gemm_x3<4, BCT, kKSelfX / 32, true>(L.X2h, L.X2l, kLhX2, 0, pk + kXSelfH, pk + kXSelfL, BCT * w, lane, b_self, acc);
     load_bx<BCT, 8>(pk + kPH2Sh, pk + kPH2Sl, BCT * w, lane, b_h2);
-    store_relu_x3<4, BCT>(L.Hh, L.Hl, kLdHb, 0, BCT * w, bias, lane, acc);
+    store_relu_x3b<4, BCT>(L.Hh, L.Hl, kLdHb, 0, BCT * w, lane, acc);
   }
   __syncthreads();
   CM3_STAMP(5, false);
   hooks.before_h2(acc2);
-  // ---- h2 = relu(branch_others W_others_h2 [already in acc2] + branch_self W_self_h2 + b) -----------------------------------------
+  // ---- h2 = relu(b + branch_others W_others_h2 [both already in acc2] + branch_self W_self_h2) ------------------------------------
   gemm_x3<4, BCT, 8, true>(L.Hh, L.Hl, kLdHb, 0, pk + kPH2Sh, pk + kPH2Sl, BCT * w, lane, b_h2, acc2);
-  float4 bias_h2[BCT];
-  load_bias4<BCT>(pk + kPH2B, BCT * w, lane, bias_h2);
-  load_bx<1, 8>(pk + kXOutH, pk + kXOutL, 0, lane, b_out);
+  // ---- actor_out, round 6: every wave contracts ITS 32 units of h2 straight from the accumulator registers -- a lane's eight values of
+  // an agent row (two column tiles x four units) are the eight consecutive k of one float16 matrix instruction's B operand once the
+  // output weights are packed in that unit order (k_ck_actor_pack, layer 6) -- and leaves a partial logit per agent row in LDS; the
+  // row's wave adds the eight partials in wave order.  (Until round 6: relu(h2) -> LDS as float16 planes, barrier, waves 0..3 ran the
+  // 256-deep layer while waves 4..7 waited: 4.1 k cycles of a 37 k tick.)
+  uint4 wo[2];
+  wo[0] = (reinterpret_cast<const uint4 *>(pk + kXOutH) + (size_t)w * 64 + lane)[0];
+  wo[1] = (reinterpret_cast<const uint4 *>(pk + kXOutL) + (size_t)w * 64 + lane)[0];
+  f16x8 woh, wol;
+  __builtin_memcpy(&woh, &wo[0], 16);
+  __builtin_memcpy(&wol, &wo[1], 16);
+  f32x4 po[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    f16x4 h0, l0, h1, l1;
+    const float v0[4] = {fmaxf(acc2[t][0][0], 0.0f), fmaxf(acc2[t][0][1], 0.0f), fmaxf(acc2[t][0][2], 0.0f), fmaxf(acc2[t][0][3], 0.0f)};
+    const float v1[4] = {fmaxf(acc2[t][1][0], 0.0f), fmaxf(acc2[t][1][1], 0.0f), fmaxf(acc2[t][1][2], 0.0f), fmaxf(acc2[t][1][3], 0.0f)};
+    split4(v0, h0, l0);
+    split4(v1, h1, l1);
+    const f16x8 ah = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+    const f16x8 al = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+    f32x4 acc = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(woh, al, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wol, ah, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(woh, ah, acc, 0, 0, 0);
+    po[t] = acc;
+  }
   CM3_STAMP(6, true);
-  __syncthreads();  // every wave is done reading branch_self
+  __syncthreads();  // every wave is done reading branch_self: the H storage takes the partial logits, float [8 waves][64 rows][8]
   CM3_STAMP(10, false);
-  store_relu_x3<4, BCT>(L.Hh, L.Hl, kLdHb, 0, BCT * w, bias_h2, lane, acc2);
+  float *part = reinterpret_cast<float *>(L.Hh);
+  {
+    const int col = lane & 15, hi = lane >> 4;
+    if (hi < 2) {   // actions 4 hi .. 4 hi + 3 of agent row 16 t + col (actions 5 .. 7: zero weights)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        *reinterpret_cast<float4 *>(part + ((size_t)w * 64 + 16 * t + col) * 8 + 4 * hi) = make_float4(po[t][0], po[t][1], po[t][2], po[t][3]);
+    }
+  }
   __syncthreads();
   CM3_STAMP(11, false);
-  // ---- actor_out: wave w < 4 finishes agent rows [16w, 16w + 16); transposed tile: lane (row l & 15) holds logits 4 (l >> 4) + reg ------
-  if (w < 4) {
-    f32x4 acc[1][1];
-    zero_tiles(acc);
-    gemm_x3<1, 1, 8, true>(L.Hh, L.Hl, kLdHb, w, pk + kXOutH, pk + kXOutL, 0, lane, b_out, acc);
-    const int col = lane & 15, hi = lane >> 4;
-    if (hi < 2) {
+  if (w < 4 && lane < 16) {   // logits of agent row 16 w + lane: b_out + the eight partials in wave order
+    float lg[kA];
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) L.LG[16 * w + col][4 * hi + reg] = acc[0][0][reg] + pk[kPOutB + 4 * hi + reg];
+    for (int a = 0; a < kA; ++a) lg[a] = pk[kPOutB + a];
+#pragma unroll
+    for (int ww = 0; ww < 8; ++ww) {
+      const float4 p4 = *reinterpret_cast<const float4 *>(part + ((size_t)ww * 64 + 16 * w + lane) * 8);
+      const float p5 = part[((size_t)ww * 64 + 16 * w + lane) * 8 + 4];
+      lg[0] += p4.x; lg[1] += p4.y; lg[2] += p4.z; lg[3] += p4.w; lg[4] += p5;
     }
+#pragma unroll
+    for (int a = 0; a < kA; ++a) L.LG[16 * w + lane][a] = lg[a];
   }
 }
 
@@ -1029,7 +1114,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) k
   __syncthreads();
   CM3_STAMP(2, false);
   f32x4 acc2[4][kCkBCT];
-  zero_tiles(acc2);
+  ck_x3_h2_bias(pk, w, lane, acc2);
   if (p.stage > 1) ck_x3_others(L, pk, w, lane, acc2);
   ck_x3_self_chain(L, pk, w, lane, b_conv, acc2);
   if (w < 4) {
@@ -1070,7 +1155,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) k
   }
   __syncthreads();
   f32x4 acc2[4][kCkBCT];
-  zero_tiles(acc2);
+  ck_x3_h2_bias(pk, w, lane, acc2);
   ck_x3_others(L, pk, w, lane, acc2);
   const int col = lane & 15, hi = lane >> 4;
 #pragma unroll

@@ -214,6 +214,7 @@ __device__ __forceinline__ void ckp_row_flags(const CkState<N> &s, const uint8_t
 constexpr int kCkpTabLd = 260;
 struct CkpTableHooks {
   const float *tab;     // NULL: stage 1, no others branch
+  const float *pk;
   const int32_t *sCell;
   float *sT;
   int w, lane;
@@ -247,15 +248,26 @@ struct CkpTableHooks {
       return;
     }
 #endif
-    zero_tiles(acc2);
+    ck_x3_h2_bias(pk, w, lane, acc2);   // stage 1: no others branch, the accumulators start from h2's bias
   }
 };
 
-template <int N> __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) k_ck_policy_rollout(const CkPolicyParams q) {
+template <int N> __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) k_ck_policy_rollout(const CkPolicyParams q_arg) {
   using namespace ck_actor;
   constexpr int G = CkpGeom<N>::G, EPW = 64 / N, ENV_WAVES = EPW * G / 64;
   static_assert(ENV_WAVES == 8, "every wave takes part in the env phase");
   static_assert(N == 1 || N == 2, "the whole-episode Checkers kernel covers the reference's configurations: one or two agents");
+  // The ~45 pointers / strides of the arguments are read from the kernel-argument segment where they are used, through a pointer the
+  // compiler cannot see through inside the tick loop: kept in scalar registers for the whole launch, ~100 of them were spilled to
+  // vector-register lanes and came back one v_readlane at a time (98 in the conv phase, 111 in the env phase of every tick).
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef const __attribute__((address_space(4))) CkPolicyParams *CkpArgs;
+  const CkpArgs qa = (CkpArgs)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+  typedef const CkPolicyParams *CkpArgs;
+  const CkpArgs qa = &q_arg;
+#endif
+  const CkPolicyParams &q = *(const CkPolicyParams *)qa;
   const CheckersParams &p = q.ck;
   __shared__ __attribute__((aligned(16))) _Float16 sH[kCkX3HBytes / 2];
   __shared__ __attribute__((aligned(16))) float sT[64 * kCkpTabLd];    // the tick's 64 table rows; X0 lives in its first 13 KB
@@ -350,20 +362,31 @@ template <int N> __global__ void __launch_bounds__(512) __attribute__((amdgpu_wa
   __syncthreads();
 
   const int n_ticks = p.n_ticks;
+  const float *const pk_loop = pk;
 #pragma unroll 1
   for (int t = 0; t < n_ticks; ++t) {
+    CkpArgs qt = qa;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+s"(qt));
+#endif
+    const CkPolicyParams &q = *(const CkPolicyParams *)qt;   // (shadow the launch-wide references inside the loop)
+    const CheckersParams &p = q.ck;
+    const float *pk = pk_loop;
     // ---- policy ---------------------------------------------------------------------------------------------------------------
     // (a per-tick copy of the weight pointer the compiler cannot see through: with the loop-invariant one it hoisted every tile
-    // address of every layer out of the tick loop and spilled ~100 vector registers to scratch memory)
-    CM3_STAMP(0, false);
-    const float *pkt = pk;
-    asm volatile("" : "+s"(pkt));
+    // address of every layer out of the tick loop and spilled ~100 vector registers to scratch memory.  The copy is typed as a
+    // GLOBAL-memory pointer: through a plain one the compiler no longer knew the address space and every weight load became a
+    // flat_load, which counts on the LDS counter too -- each wait for an LDS read then waited for the weights in flight)
+    typedef const __attribute__((address_space(1))) float *CkpGlobalF;
+    CkpGlobalF pkg = (CkpGlobalF)pk;
+    asm volatile("" : "+s"(pkg));
+    const float *pkt = (const float *)pkg;
     // (the conv's first weights are requested here, not ahead of the env work: held across it or across the closing barrier they cost
     // the two-agent build 14 spilled registers)
     load_bx<5, kKConvX / 32>(pkt + kXConvH, pkt + kXConvL, 5 * (w >> 2), lane, b_conv);
     f32x4 acc2[4][kCkBCT];
     CkpTableHooks hooks;
-    hooks.tab = stage2 ? pkt + kPOthTab : nullptr; hooks.sCell = sCell; hooks.sT = sT; hooks.w = w; hooks.lane = lane;
+    hooks.tab = stage2 ? pkt + kPOthTab : nullptr; hooks.pk = pkt; hooks.sCell = sCell; hooks.sT = sT; hooks.w = w; hooks.lane = lane;
     ck_x3_self_chain<CkpTableHooks &>(L, pkt, w, lane, b_conv, acc2, hooks);
     if (w < 4) {
       __builtin_amdgcn_s_waitcnt(0);

@@ -3,6 +3,7 @@
 #ifdef CM3_STAMPS
 __device__ long long *cm3_stamp_buf;
 #endif
+#define CM3_X3_CONV_STAMP 7
 #include "../../cm3_amd/csrc/checkers.hip"
 #include "../../cm3_amd/csrc/actor_checkers.hip"
 #define CM3_POLICY_CHECKERS_BODY_ONLY 1
@@ -75,7 +76,7 @@ int main(int argc, char **argv) {
   std::vector<long long> h((size_t)waves * 16);
   hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost);
   struct Seg { int a, b; const char *name; bool env_only; };
-  const Seg segs[] = {{0, 3, "conv (+ weight fetch) + store + barrier", false}, {3, 4, "conv_linear + store + barrier", false},
+  const Seg segs[] = {{0, 7, "conv (+ weight fetch) + store + barrier", false}, {7, 4, "conv_linear + store + barrier", false},
                       {4, 5, "table rows + branch_self + store + barrier", false}, {5, 6, "h2 pass (self)", false}, {6, 10, "barrier", false},
                       {10, 11, "h2 relu -> LDS + barrier", false}, {11, 13, "actor_out + softmax + sample + stores", false},
                       {13, 14, "barrier (actions)", false}, {14, 9, "plan fetch + agents act + reward stores", true},
@@ -83,10 +84,10 @@ int main(int argc, char **argv) {
   for (const Seg &sg : segs) {
     double acc = 0; int n = 0;
     for (int wv = 0; wv < waves; ++wv) {
-      if (sg.env_only != ((wv & 7) < 4) && sg.a != 14 && sg.b != 8 || (sg.env_only && (wv & 7) >= 4)) continue;   // forward segments: waves 4..7 (the env waves' tick re-uses their slots)
+
       acc += (double)(h[wv * 16 + sg.b] - h[wv * 16 + sg.a]); ++n;
     }
-    printf("   %-52s %9.0f cycles%s\n", sg.name, acc / n, sg.env_only ? "  (env waves)" : "");
+    printf("   %-52s %9.0f cycles%s\n", sg.name, acc / n, sg.env_only ? "" : "");
   }
   double tt = 0;
   for (int wv = 0; wv < waves; ++wv) tt += (double)(h[wv * 16 + 8] - h[wv * 16 + 0]);
