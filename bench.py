@@ -57,7 +57,7 @@ def particle_actor_mfma_work(n_agents, precision):
     return f32, second * (3 if precision == "f16x3" else 1), net
 
 
-def checkers_actor_mfma_work(n_agents, precision):
+def checkers_actor_mfma_work(n_agents, precision, others_from_table=False):
     """Executed matrix-core MACs per agent row of the Checkers actor (csrc/actor_checkers.hip: tile widths of its layers) ->
     (f32 MACs, f16/bf16 MACs, network MACs).  f32: every layer on v_mfma_f32_16x16x4_f32 (K padded to 16s: conv 80 x 160 Toeplitz,
     conv_linear 160 x 32, branch_self 48 x 256, branch_others 16 x 256, the two 256 x 256, out 256 x 16); f16x3: every layer as
@@ -69,7 +69,10 @@ def checkers_actor_mfma_work(n_agents, precision):
         return small_f32 + big, 0, net
     if precision == "bf16":
         return small_f32, big, net
-    return 0, 96 * 160 * 2 + (160 * 32 + 64 * 256 + 32 * 256 + big + 256 * 16) * 3, net
+    # others_from_table: the one-launch rollout (csrc/policy_checkers.hip) reads branch_others W_others_h2 from a table -- neither the
+    # 32 x 256 first layer nor its 256 x 256 second layer is executed (stage 1 has no others branch at all)
+    others = 0 if (others_from_table or n_agents == 1) else 32 * 256 + 256 * 256
+    return 0, 96 * 160 * 2 + (160 * 32 + 64 * 256 + 256 * 256 + others + 256 * 16) * 3, net
 
 
 def mfma_roofline(rows_per_tick, us_per_tick, f32_macs, f16_macs, net_macs):
@@ -411,6 +414,28 @@ def measure_launch_floor(device, read_bytes, write_bytes, blocks, threads=256, n
     return res
 
 
+def step_traffic_bytes(kind, n_agents, n_envs):
+    """(read, written) algorithmic bytes of one step launch, rounded up to 16: the skeleton of the floor"""
+    if kind == "checkers":
+        rd, wr = 24 * n_envs, 376 * n_envs
+    else:
+        n = n_agents
+        rd, wr = (28 * n + 4) * n_envs, (20 * n + 16 * n * max(n - 1, 1) + 12) * n_envs
+    return (rd + 15) // 16 * 16, (wr + 15) // 16 * 16
+
+
+def launch_ceiling(device, kind, n_agents, n_envs, bytes_per_launch, launch_us):
+    """What ONE launch per tick allows at this batch: the same number of workgroups reading and writing the same algorithmic bytes
+    with no arithmetic, and an empty launch, each replayed as a hipGraph like the bench's phase (measure_launch_floor).
+    ceiling_frac = algorithmic bytes / same_traffic_us / peak: the roofline fraction a perfect step kernel would show with one launch
+    per tick; frac_of_floor = same_traffic_us / the step kernel's time per launch."""
+    rd, wr = step_traffic_bytes(kind, n_agents, n_envs)
+    floor = measure_launch_floor(device, rd, wr, blocks=max(1, min(2048, (n_envs * 16 + 255) // 256)), nodes=PHASE_TICKS)
+    floor["frac_of_floor"] = floor["same_traffic_us"] / launch_us
+    floor["ceiling_frac"] = bytes_per_launch / (floor["same_traffic_us"] * 1e-6) / 1e9 / HBM_PEAK_GBPS
+    return floor
+
+
 def cfg_name_of(cfg):
     """Name of the cm3_amd/configs file a loaded particle config came from (for the worker command line)."""
     import cm3_amd
@@ -526,6 +551,49 @@ def cpu_baseline_checkers(cfg, budget_s=10.0):
                 sample="%d episodes (%d env-steps) of Checkers stage 2 (N=%d, 33 ticks, uniform actions) in %.1f s on 1 of "
                        "%d host cores; scalar dense NumPy port of the reference's call structure"
                        % (episodes, steps, n, dt, os.cpu_count()))
+
+
+def run_c1(args):
+    """BASELINE config C1 (config_particle_stage1.json, 1 agent, 1 env; /root/reference/alg/config_particle_stage1.json:1-8): CPU
+    plumbing, no GPU -- (a) PARITY: the reference-shaped scalar port replays every episode of the stage-1 golden fixtures (recorded
+    from the reference's own MultiAgentEnv.step, tests/golden/particle_stage1_*.npz) and must reproduce global state, observations,
+    rewards, done flags and the collision counter bit for bit in float64; (b) the port's env-steps/s on one host core.  The port
+    is the checker being timed here by definition of C1; nothing of the GPU product is involved."""
+    import glob
+    import numpy as np
+    from oracle.particle_oracle import ParticleEnvOracle
+    checked, bad, files = 0, 0, []
+    for path in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "particle_stage1_*.npz"))):
+        g = np.load(path, allow_pickle=False)
+        meta = json.loads(str(g["meta"]))
+        files.append(os.path.basename(path))
+        env = ParticleEnvOracle(meta["n_agents"], meta["config"], meta["prob_random"], meta["max_steps"])
+        for ep in range(len(g["ep_len"])):
+            gs0 = g["init_gs"][ep]
+            env.set_state(gs0[:, 2:4], gs0[:, 0:2], g["landmarks"][ep])
+            for t in range(int(g["ep_len"][ep])):
+                gs, oo, os_, rew, rew_n, done = env.step(g["actions"][ep, t])
+                ok = (np.array_equal(gs, g["gs"][ep, t]) and np.array_equal(np.array(oo), g["obs_others"][ep, t])
+                      and np.array_equal(np.array(os_), g["obs_self"][ep, t]) and rew == g["reward"][ep, t]
+                      and np.array_equal(np.array(rew_n), g["reward_n"][ep, t]) and bool(done) == bool(g["done"][ep, t])
+                      and env.collisions == g["collisions"][ep, t])
+                checked += 1
+                bad += 0 if ok else 1
+    import cm3_amd
+    cfg = cm3_amd.load_config("particle_stage1")
+    cb = cpu_baseline(cfg, 1, budget_s=min(12.0, max(2.0, float(args.steps))))
+    out = {"metric": "env-steps/s (CPU port; C1 plumbing config, no GPU)", "value": cb["value"], "unit": "env-steps/s", "n_gpus": 0,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 / cb["value"], "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f64", "data": "synthetic (uniform random actions, MT19937 as the reference's loop)",
+           "config": {"workload": "config_particle_stage1.json: 1 agent, 1 env, CPU reference-shaped step() (BASELINE configs[0])",
+                      "envs_per_gpu": 0, "n_agents": 1, "global_envs": 1, "mode": "cpu", "parallelism": "none"},
+           "parity": {"pass": bad == 0 and checked > 0, "ticks_checked": checked, "ticks_differing": bad, "fixtures": files,
+                      "what": "float64 bit-exact replay of the reference-recorded stage-1 episodes by the scalar port"},
+           "roofline": {"bound": "hbm", "achieved": 0.0, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": 0.0, "traffic": None,
+                        "kernel": "none (C1 runs no kernel: CPU plumbing)"},
+           "cpu_baseline": cb}
+    print(json.dumps(out))
+    return 0 if out["parity"]["pass"] else 1
 
 
 def pmc_traffic(tag):
@@ -658,9 +726,53 @@ def measure_other_config(name, args, device, steps=20, cpu_budget_s=6.0):
     if sp:
         rec["roofline"]["kernel_span"] = {"span_us": sp["span_us_mean"], "start_to_start_us": sp["start_to_start_us_mean"],
                                           "gap_us": sp["gap_us_mean"], "source": "profiles/%s (two-stamp build, unprofiled)" % SPAN_FILE}
+    floor = launch_ceiling(device, "checkers" if kind == "checkers" else "particle", N, E, bytes_per_launch, launch_s * 1e6)
+    rec["roofline"]["launch_floor"] = floor
+    rec["roofline"]["ceiling_frac"] = floor["ceiling_frac"]
     if name == "c3" and not args.no_cpu_baseline:
         rec["cpu_baseline_checkers"] = cpu_baseline_checkers(cfg, budget_s=cpu_budget_s)
+    if name == "c3":
+        rec["policy"] = measure_checkers_policy(cfg, E, device)
     return rec
+
+
+def measure_checkers_policy(cfg, E, device, reps=20):
+    """POLICY-driven Checkers collection at the workload's BASELINE size (train_onpolicy.py:309-347, the branch the reference takes
+    after its 50 pretrain episodes): CheckersRollout.collect(goals, policy=actor) with the on-device split-float16 actor (random
+    float32 weights of the reference's shapes, epsilon 0.1), full trajectory storage, env reset per collect -- ONE launch per
+    33-tick rollout (csrc/policy_checkers.hip).  -> us per tick, env-steps/s and the matrix-core roofline of the instructions executed."""
+    import numpy as np
+    import torch
+    from cm3_amd.actor import CheckersActor
+    from cm3_amd.checkers import VecCheckersEnv
+    from cm3_amd.rollout import CheckersRollout
+    rng = np.random.default_rng(0)
+    Nc = cfg["n_agents"]
+    shapes = {"conv/Conv/weights": (3, 3, 3, 6), "conv/Conv/biases": (6,), "conv_linear/kernel": (150, 32),
+              "conv_linear/bias": (32,), "branch_self/kernel": (43, 256), "branch_self/bias": (256,),
+              "W_self_h2": (256, 256), "stage-2/branch_others/kernel": (2 * max(Nc - 1, 1), 256),
+              "stage-2/branch_others/bias": (256,), "stage-2/W_others_h2": (256, 256), "b": (256,),
+              "actor_out/kernel": (256, 5), "actor_out/bias": (5,)}
+    wts = {k: (rng.standard_normal(v) * 0.1).astype(np.float32) for k, v in shapes.items()}
+    goals = np.eye(2) if Nc > 1 else np.array([[1, 0]])
+    env = VecCheckersEnv(cfg["init"], Nc, 33, E, device=device)
+    actor = CheckersActor(wts, Nc, stage=2 if Nc > 1 else 1, device=device, precision="f16x3")
+    one = actor.fused_rollout_ok(env)
+    ro = CheckersRollout(env, n_ticks=EP_TICKS)
+    for _ in range(3):
+        ro.collect(goals, policy=actor, epsilon=0.1)
+    torch.cuda.synchronize(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        ro.collect(goals, policy=actor, epsilon=0.1)
+    e1.record()
+    e1.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / (reps * EP_TICKS)
+    ro.close()
+    roof = mfma_roofline(E * Nc, us, *checkers_actor_mfma_work(Nc, "f16x3", others_from_table=one))
+    return {"us_per_tick": us, "env_steps_per_s": E / us * 1e6, "mode": "one launch per rollout" if one else "actor + step launch per tick",
+            "actor_precision": "f16x3", "mfma_frac": roof["frac"], "mfma_matrix_time_us": roof["matrix_time_us"], "roofline": roof}
 
 
 LINE_LIMIT = 4000            # bytes: the driver keeps an 8 KB stdout tail; round 4's 24 KB line was cut and never parsed
@@ -699,7 +811,7 @@ def compact_line(out):
     roof = _pick(r, ("bound", "achieved", "peak", "unit", "frac"))
     roof["traffic"] = _sig(r.get("traffic"))
     roof.update(_pick(r, ("algorithmic_bytes_per_launch", "avg_launch_us", "avg_launch_us_hip_events", "measured_read_GBps",
-                          "frac_of_measured_read")))
+                          "frac_of_measured_read", "ceiling_frac")))
     roof["kernel"] = str(r.get("kernel", ""))[:96]
     if r.get("traffic") is not None:
         roof["traffic_kind"] = "committed rocprofv3 --pmc passes (profiles/pmc_traffic.json), not this run"
@@ -724,12 +836,17 @@ def compact_line(out):
             o = _pick(rec, ("envs_per_gpu", "n_agents", "us_per_tick", "live_state"))
             o["value"] = _sig(rec.get("env_steps_per_s"))
             rr = rec.get("roofline", {})
-            o.update(_pick(rr, ("frac", "achieved", "algorithmic_bytes_per_launch", "avg_launch_us_hip_events")))
+            o.update(_pick(rr, ("frac", "ceiling_frac", "achieved", "algorithmic_bytes_per_launch", "avg_launch_us_hip_events")))
+            if isinstance(rr.get("launch_floor"), dict):
+                o["floor_us"] = _sig(rr["launch_floor"].get("same_traffic_us"), 4)
             o["traffic"] = _sig(rr.get("traffic"))
             if isinstance(rr.get("kernel_span"), dict):
                 o["kernel_span"] = _pick(rr["kernel_span"], ("span_us", "gap_us"))
             if isinstance(rec.get("cpu_baseline_checkers"), dict):
                 o["cpu_baseline"] = _pick(rec["cpu_baseline_checkers"], ("value", "cores", "kind"))
+            if isinstance(rec.get("policy"), dict):
+                o["policy_us_per_tick"] = _sig(rec["policy"].get("us_per_tick"))
+                o["policy_mfma_frac"] = _sig(rec["policy"].get("mfma_frac"), 4)
             line["other_configs"][name] = o
     pr = out.get("policy_rollout")
     if isinstance(pr, dict) and isinstance(pr.get("headline"), dict):
@@ -940,8 +1057,9 @@ def main():
                     help="timed steps; one step = one collection phase of %d ticks (c4: one 33-tick rollout + normalisation)"
                          % PHASE_TICKS)
     ap.add_argument("--warmup", type=int, default=5, help="untimed warm-up steps")
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2",
-                    help="c2 (default, the configuration BASELINE.json's metric is quoted on) | c3 | c4 | c5")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS) + ["c1"], default="c2",
+                    help="c2 (default, the configuration BASELINE.json's metric is quoted on) | c3 | c4 | c5 | c1 (stage 1, one agent, one "
+                         "env: CPU only -- parity pass / fail against the reference-recorded fixtures + the port's env-steps/s)")
     ap.add_argument("--mode", choices=["trajectory", "in-place"], default="trajectory",
                     help="trajectory (default): every tick writes its slot of a device trajectory (the collection loop); "
                          "in-place: every tick overwrites the same live buffers (stepping only)")
@@ -968,6 +1086,8 @@ def main():
                     help="step-kernel mapping (auto = library heuristic)")
     args = ap.parse_args()
 
+    if args.workload == "c1":
+        return run_c1(args)
     under_launcher = "WORLD_SIZE" in os.environ and "RANK" in os.environ
     if args.gpus > 1 and not under_launcher:
         return self_spawn(args.gpus)
@@ -1114,8 +1234,32 @@ def main():
             st.close()
             del st
             torch.cuda.empty_cache()
+        if kind == "particle":
+            # the LITERAL drop-in of INTEGRATION.md section 2: the reference's loop calls env.step(actions) from Python every tick
+            # (train_onpolicy.py:321-323) -- VecParticleEnv.step with (a) device int32 actions (what ParticleActor.act returns) and
+            # (b) host int64 actions (what np.random.randint / a NumPy policy returns: one host-to-device copy per tick)
+            import numpy as np
+            from cm3_amd.particle import VecParticleEnv
+            penv = VecParticleEnv(cfg, N, 0.2, 33, E, device=device, auto_reset=True)
+            penv.reset()
+            a_dev = torch.randint(0, 5, (E, N), dtype=torch.int32, device=device)
+            a_host = np.random.default_rng(0).integers(0, 5, (E, N))
+            for label, act in (("python_step_device_int32", a_dev), ("python_step_host_int64", a_host)):
+                for _ in range(50):
+                    penv.step(act)
+                torch.cuda.synchronize(device)
+                t0 = time.perf_counter()
+                for _ in range(PHASE_TICKS):
+                    penv.step(act)
+                torch.cuda.synchronize(device)
+                us = (time.perf_counter() - t0) / PHASE_TICKS * 1e6
+                modes[label] = {"us_per_tick": us, "env_steps_per_s": E / us * 1e6,
+                                "achieved_GBps": bytes_per_env_step * E / (us * 1e-6) / 1e9,
+                                "frac_of_peak": bytes_per_env_step * E / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS}
+            del penv
         modes["note"] = ("extra, not the headline: same workload and graph length, HIP-event time.  in_place = every tick "
-                         "overwrites the live buffers (stepping only, no trajectory is stored)")
+                         "overwrites the live buffers (stepping only, no trajectory is stored); python_step_* = VecParticleEnv.step(actions) called "
+                         "from Python once per tick, wall clock (the reference's own loop shape, INTEGRATION.md section 2)")
         out["launch_modes"] = modes
         # the same workload with all ticks of an episode fused into ONE launch (random-action branch only)
         if kind == "particle":
@@ -1243,6 +1387,18 @@ def main():
         goals = np.eye(2) if Nc > 1 else np.array([[1, 0]])
         macs = 25 * 6 * 27 + 150 * 32 + 43 * 256 + (2 * max(Nc - 1, 1) * 256 + 256 * 256 if Nc > 1 else 0) + 256 * 256 + 256 * 5
         pol = {}
+        def time_collect(ro, actor, reps):
+            for _ in range(3):
+                ro.collect(goals, policy=actor, epsilon=0.1)
+            torch.cuda.synchronize(device)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                ro.collect(goals, policy=actor, epsilon=0.1)
+            e1.record()
+            e1.synchronize()
+            return e0.elapsed_time(e1) * 1e3 / (reps * EP_TICKS)
+
         for prec in ("f32", "f16x3"):
             cenv = VecCheckersEnv(cfg["init"], Nc, 33, E, device=device)
             cenv.reset(goals)
@@ -1258,17 +1414,8 @@ def main():
             e1.record()
             e1.synchronize()
             a_us = e0.elapsed_time(e1) * 1e3 / reps
-            ro = CheckersRollout(cenv, n_ticks=EP_TICKS, use_graph=True)
-            for _ in range(2):
-                ro.collect(goals, policy=actor, epsilon=0.1)
-            torch.cuda.synchronize(device)
-            reps = 5
-            e0.record()
-            for _ in range(reps):
-                ro.collect(goals, policy=actor, epsilon=0.1)
-            e1.record()
-            e1.synchronize()
-            us = e0.elapsed_time(e1) * 1e3 / (reps * EP_TICKS)
+            ro = CheckersRollout(cenv, n_ticks=EP_TICKS, use_graph=True, policy_mode="tick")
+            us = time_collect(ro, actor, 5)
             ro.close()
             work = checkers_actor_mfma_work(Nc, prec)
             pol[prec] = {
@@ -1276,15 +1423,32 @@ def main():
                 "actor_kernel": {"kernel": "k_ck_actor<%s>" % prec, "avg_launch_us": a_us, "rows": E * Nc, "macs_per_row": macs,
                                  "roofline": mfma_roofline(E * Nc, a_us, *work)}}
             pol[prec]["launch_per_tick"]["network_TFLOPs"] = pol[prec]["launch_per_tick"]["roofline"]["network_TFLOPs"]
+            if actor.fused_rollout_ok(cenv):
+                # the whole rollout in ONE launch (csrc/policy_checkers.hip; bit-identical to the launch pairs), (a) as the reference's
+                # loop runs it -- one episode per env and collect(), the env reset in between -- and (b) continuous (auto-reset) collection
+                twork = checkers_actor_mfma_work(Nc, prec, others_from_table=True)
+                for label, auto in (("one_launch_per_rollout", False), ("one_launch_per_rollout_continuous", True)):
+                    env1 = VecCheckersEnv(cfg["init"], Nc, 33, E, device=device, auto_reset=auto)
+                    ro1 = CheckersRollout(env1, n_ticks=EP_TICKS)
+                    us1 = time_collect(ro1, actor, 20)
+                    ro1.close()
+                    pol[prec][label] = {"us_per_tick": us1, "env_steps_per_s": E / us1 * 1e6, "roofline": mfma_roofline(E * Nc, us1, *twork),
+                                        "what": "cm3_policy_rollout_checkers: 33 ticks per launch, " +
+                                                ("auto-reset, collect() continues where the last one stopped" if auto else
+                                                 "env.reset + one launch per collect()")}
+                    del env1, ro1
             del cenv, actor
-        best = pol["f16x3"]["launch_per_tick"]
-        pol["headline"] = {"what": "policy-driven Checkers collection (train_onpolicy.py:309-321): actor launch + step launch per "
-                                   "tick in one hipGraph, actor precision f16x3",
+        best = pol["f16x3"].get("one_launch_per_rollout", pol["f16x3"]["launch_per_tick"])
+        pol["headline"] = {"what": "policy-driven Checkers collection (train_onpolicy.py:309-347), the default of CheckersRollout.collect("
+                                   "policy=actor): the whole 33-tick rollout in ONE launch, actor precision f16x3, env reset per collect",
                            "us_per_tick": best["us_per_tick"], "env_steps_per_s": best["env_steps_per_s"],
                            "roofline": best["roofline"]}
-        pol["note"] = ("extra, not the headline: actor (networks.actor_checkers; the two 256x256 layers = 86 %% of its FLOPs on the "
-                       "exact-f32 MFMA (f32) or as three float16 MFMAs over hi + lo splits (f16x3, same 2e-5 parity bound); the "
-                       "roofline counts the EXECUTED matrix instructions per pipe against that pipe's peak) + reset + step per tick with full trajectory storage (tests/test_gpu_actor_checkers.py)")
+        pol["note"] = ("extra, not the headline: actor (networks.actor_checkers; every layer in split float16 on the matrix cores (f16x3, "
+                       "same 2e-5 parity bound as the exact-f32 build) + env step per tick with full trajectory storage.  launch_per_tick = "
+                       "an actor launch and a step launch per tick in one hipGraph (round 5: 29.6 us); one_launch_per_rollout = "
+                       "cm3_policy_rollout_checkers, bit-identical (tests/test_gpu_actor_checkers.py::"
+                       "test_checkers_policy_rollout_equals_launch_per_tick); its roofline counts the matrix instructions it EXECUTES "
+                       "(the others branch of the two-agent network is a table lookup there)")
         out["policy_rollout"] = pol
     if world == 1 and rank == 0 and args.workload == "c2" and mode == "trajectory" and not args.no_other_configs \
             and not args.no_extras and not args.fused and n_chains == 1 and not args.envs_per_gpu:
@@ -1309,13 +1473,8 @@ def main():
             # What one launch per tick cannot go below at this batch: the same number of 256-lane workgroups reading and
             # writing the same algorithmic bytes with NO arithmetic (load -> store skeleton), and an empty launch, both
             # replayed as a hipGraph of the same length.
-            if kind == "particle":
-                rd, wr = (28 * N + 4) * E, (20 * N + 16 * N * max(N - 1, 1) + 12) * E
-            else:
-                rd, wr = 24 * E, 376 * E
-            rd, wr = (rd + 15) // 16 * 16, (wr + 15) // 16 * 16
-            floor = measure_launch_floor(device, rd, wr, blocks=max(1, min(2048, (E * 16 + 255) // 256)), nodes=PHASE_TICKS)
-            floor["frac_of_floor"] = floor["same_traffic_us"] / (launch_s * 1e6 * max(1, n_chains))   # floor is per whole tick
+            floor = launch_ceiling(device, kind, N, E, bytes_per_launch, launch_s * 1e6 * max(1, n_chains))   # (per whole tick)
+            out["roofline"]["ceiling_frac"] = floor["ceiling_frac"]
             out["roofline"]["launch_floor"] = floor
         if not args.no_sweep and kind == "particle":
             if stepper is not None:

@@ -62,7 +62,9 @@ template <int N> struct CkpGeom { static constexpr int G = 8 * N; };
 // trajectory stores it made every wave wait for their acknowledgement (~1 k cycles, twice per tick).  Nothing in this kernel reads
 // back what it stored to global memory, so the two barriers that follow stores wait for the LDS only.
 __device__ __forceinline__ void ckp_barrier_lds() {
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");   // LDS traffic only (no wait for global stores in flight)
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
 // the 5 x 5 x 3 windows of an env's agents -> float16 rows of X0 (what ck_x3_stage_inputs makes of the obs_self_t bytes): the cell
