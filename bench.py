@@ -890,6 +890,8 @@ def extras_summary(out):
         s["host_side_cols"] = ["ms", "ratio_to_copy_rate_floor"]
         s["host_side"] = {k: [_sig(v["ms"], 4), _sig(v.get("ratio_to_floor", 0.0), 3)] for k, v in out["host_side"].items()
                           if isinstance(v, dict) and "ms" in v}
+        if isinstance(out["host_side"].get("phase_total"), dict):
+            s["phase_total_ms"] = _sig(out["host_side"]["phase_total"]["ms"], 4)
     while len(json.dumps(s)) >= LINE_LIMIT and s.get("sweep"):
         s["sweep"].pop()
     return s

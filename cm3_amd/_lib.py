@@ -180,6 +180,7 @@ SYMBOLS = {
     "cm3_policy_rollout_f32": (ctypes.c_int, [P(ParticleDesc), P(ParticleTraj), P(ActorParticleDesc),
                                               P(ActorParticleWeights), c_void_p, c_size_t, c_int32, c_void_p]),
     "cm3_policy_force_row_tiles": (ctypes.c_int, [c_int32]),
+    "cm3_td_target_f64": (ctypes.c_int, [c_void_p, c_int32, c_void_p, c_void_p, ctypes.c_double, c_void_p, c_int64, c_void_p]),
     "cm3_transitions_gather_f32": (ctypes.c_int, [P(ParticleDesc), P(ParticleTraj), c_void_p, c_size_t, c_void_p, c_void_p, c_int64,
                                                   P(TransitionCols), c_void_p]),
     "cm3_rows_scatter": (ctypes.c_int, [P(RowCols), c_int64, c_void_p, c_int64, c_int64, c_void_p]),

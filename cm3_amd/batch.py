@@ -14,6 +14,12 @@ by the REAL reference functions, tests/golden/batch_particle.npz).
 import torch
 
 
+def rep_rows(x, n):
+    """every row of x repeated n times consecutively -- x.repeat_interleave(n, dim=0) as ONE copy launch (expand + reshape; torch's
+    repeat_interleave builds a repeats tensor, a cumulative sum and an index_select: four launches, and train_step has a dozen)."""
+    return x.unsqueeze(1).expand(x.shape[0], int(n), *x.shape[1:]).reshape(x.shape[0] * int(n), *x.shape[1:])
+
+
 class _Tiler(object):
     """Collects "destination row r <- source row f(r)" outputs and builds them 16 per launch (cm3_rows_tile, csrc/batch.hip)."""
 
@@ -97,6 +103,52 @@ def particle_static_feeds_device(cols, l_action=5):
     return S
 
 
+def phase_static_feeds(cols_all, n_minibatches, l_action=5):
+    """The static feeds of EVERY minibatch of an on-policy phase (train_onpolicy.py:359-377: 24 minibatches of 128) from the phase's
+    one export (ParticleRollout.on_policy_phase: columns [n_minibatches * batch_size, ...]) -- ONE pair of cm3_rows_tile launches;
+    returns a list of per-minibatch dicts of VIEWS (every feed is transition-major, so a minibatch is a contiguous block of rows).
+    Round 5 built them per minibatch: 24 x 0.09 ms of launch latency for 0.13 ms of work."""
+    S = particle_static_feeds_device(cols_all, l_action)
+    M = int(n_minibatches)
+    out = []
+    for k in range(M):
+        d = {}
+        for name, t in S.items():
+            r = t.shape[0] // M
+            d[name] = t[k * r:(k + 1) * r]
+        out.append(d)
+    return out
+
+
+def td_target(reward, q, multiplier, gamma):
+    """reward + gamma * q * multiplier in NumPy's order (alg_credit.py:594, :640, :684), float64: one launch of cm3_td_target_f64 for
+    device tensors (reward float32 / float64, multiplier int64), the torch composition otherwise -- the same bits."""
+    q = q.reshape(-1)
+    if (q.is_cuda and q.dtype == torch.float64 and q.is_contiguous() and multiplier.dtype == torch.int64 and multiplier.is_contiguous()
+            and reward.dtype in (torch.float32, torch.float64) and reward.is_contiguous() and reward.numel() == q.numel()):
+        from . import _lib
+        out = torch.empty_like(q)
+        _lib.check(_lib.lib().cm3_td_target_f64(reward.data_ptr(), 1 if reward.dtype == torch.float64 else 0, q.data_ptr(),
+                                                multiplier.data_ptr(), float(gamma), out.data_ptr(), q.numel(),
+                                                torch.cuda.current_stream(q.device).cuda_stream))
+        return out
+    return reward.to(torch.float64) + gamma * q * multiplier
+
+
+def process_actions_device(acts, n_steps, n_agents, l_action=5, rep_m=False):
+    """process_actions(acts.reshape(n_steps, N)) -- and optionally the one-hot rows repeated N times (`rep_m`, alg_credit.py:628) -- in
+    ONE cm3_rows_tile launch for a device tensor of sampled actions (any integer dtype)."""
+    from . import _lib
+    N, A, R = n_agents, int(l_action), n_steps * n_agents
+    a32 = acts.reshape(-1).to(torch.int32).contiguous()
+    t = _Tiler(acts.device)
+    one = t.add(a32, R, A, torch.int64, _lib.TILE_ONEHOT_I64)
+    others = t.add(a32, R * (N - 1), A, torch.float64, _lib.TILE_ONEHOT_F64, others=(N, N * (N - 1), N - 1), shape=(R, N - 1, A))
+    rep = t.add(a32, R * N, A, torch.int64, _lib.TILE_ONEHOT_I64, terms=((N, 0, 1), (1, 0, 0))) if rep_m else None
+    t.run()
+    return one, others, rep
+
+
 def others_index(n_agents, device=None):
     """[N, N-1] long: row n lists the other agents in ascending order (np.arange(N) != n)."""
     idx = [[j for j in range(n_agents) if j != n] for n in range(n_agents)]
@@ -131,7 +183,7 @@ def process_global_state(v_global):
     B, N, l = v_global.shape
     one = v_global.reshape(B * N, l)
     others = gather_others(v_global).reshape(B * N, (N - 1) * l).to(torch.float64)
-    state = v_global.reshape(B, N * l).repeat_interleave(N, dim=0)
+    state = rep_rows(v_global.reshape(B, N * l), N)
     return one, others, state
 
 
@@ -142,20 +194,20 @@ def process_batch(cols, l_action=5):
     B, N = v_global.shape[0], v_global.shape[1]
     a1, ao = process_actions(cols["actions"], l_action)
     return (B, v_global, cols["obs_others"].reshape(B * N, -1), cols["v_local"].reshape(B * N, -1), a1, ao,
-            cols["reward"].repeat_interleave(N, dim=0), cols["reward_local"].reshape(B * N),
+            rep_rows(cols["reward"], N), cols["reward_local"].reshape(B * N),
             cols["v_global_next"], cols["obs_others_next"].reshape(B * N, -1), cols["v_local_next"].reshape(B * N, -1),
-            cols["done"].repeat_interleave(N, dim=0), cols["goals"])
+            rep_rows(cols["done"], N), cols["goals"])
 
 
 def repeat_indexed_by_n(x, n_agents):
     """[B*N, d] -> [B*N*N, d]: each time step's block of N rows repeated N times (alg_credit.py:621-623, :648-649)."""
     d = x.shape[1:]
-    return x.reshape(-1, n_agents, *d).repeat_interleave(n_agents, dim=0).reshape(-1, *d)
+    return rep_rows(x.reshape(-1, n_agents, *d), n_agents).reshape(-1, *d)
 
 
 def repeat_indexed_by_m(x, n_agents):
     """[B*N, d] -> [B*N*N, d]: every row repeated N times consecutively (alg_credit.py:628-629, :651-652)."""
-    return x.repeat_interleave(n_agents, dim=0)
+    return rep_rows(x, n_agents)
 
 
 # ---- Checkers (alg_credit_checkers.py:375-535) ---------------------------------------------------------------------------
@@ -166,7 +218,7 @@ def process_batch_checkers(cols, l_action=5):
     times, `reward` left per time step (unlike the particle variant), both action columns one-hot."""
     vec = cols["vec"]
     B, N = vec.shape[0], vec.shape[1]
-    rep = lambda x: x.repeat_interleave(N, dim=0)              # noqa: E731
+    rep = lambda x: rep_rows(x, N)                             # noqa: E731
     rows = lambda x: x.reshape(B * N, *x.shape[2:])            # noqa: E731
     a1, ao = process_actions(cols["actions"], l_action)
     prev1 = torch.nn.functional.one_hot(cols["actions_prev"].long(), l_action).reshape(B * N, l_action)
@@ -191,7 +243,8 @@ def _rep_n(x, n):
     return repeat_indexed_by_n(x, n)
 
 
-def train_step_feeds(cols, run, gamma, epsilon, env="particle", use_Q_credit=True, use_V=True, l_action=5, device_tiling=True):
+def train_step_feeds(cols, run, gamma, epsilon, env="particle", use_Q_credit=True, use_V=True, l_action=5, device_tiling=True,
+                     static=None):
     """The data movement of the reference's train_step on the device: builds, in the reference's order, the feed_dict of
     every sess.run -- TD targets, the n x n credit repeats (alg_credit.py:614-658) and the n x n x l_action counterfactual
     tiling (:730-751; Checkers twin alg_credit_checkers.py:590-760) -- from the columns of
@@ -201,7 +254,8 @@ def train_step_feeds(cols, run, gamma, epsilon, env="particle", use_Q_credit=Tru
     "Q_global"]), `feed` a dict keyed by the reference's placeholder attribute names; it returns one tensor per op (None
     for optimiser ops).  Returns the list of (ops, feed) in call order.  Pure gathers / repeats plus the float64 TD
     arithmetic: bit-identical to the arrays the REAL train_step feeds (tests/golden/trainstep_*.npz, recorded by
-    oracle/gen_golden_trainstep.py from the reference code itself under a recording session)."""
+    oracle/gen_golden_trainstep.py from the reference code itself under a recording session).
+    static: this minibatch's entry of phase_static_feeds() -- the static feeds then cost no launch here."""
     checkers = env == "checkers"
     calls = []
 
@@ -219,8 +273,9 @@ def train_step_feeds(cols, run, gamma, epsilon, env="particle", use_Q_credit=Tru
         # float32 columns on the GPU: everything that does not depend on a network output comes from two launches of
         # cm3_rows_tile (particle_static_feeds_device); other inputs (the float64 parity path, host tensors of the CPU tests, N = 1,
         # the variants without Q-credit) go through the torch composition below -- the specification both are tested against
-        S = (particle_static_feeds_device(cols, l_action)
-             if (vg0.is_cuda and vg0.dtype == torch.float32 and vg0.shape[1] > 1 and use_Q_credit and device_tiling) else None)
+        S = static if static is not None else (
+            particle_static_feeds_device(cols, l_action)
+            if (vg0.is_cuda and vg0.dtype == torch.float32 and vg0.shape[1] > 1 and use_Q_credit and device_tiling) else None)
         if S is not None:
             B_, N_ = vg0.shape[0], vg0.shape[1]
             (n_steps, v_global, obs_others, v_local, actions_1hot, actions_others_1hot, reward, reward_local, v_global_next,
@@ -262,25 +317,30 @@ def train_step_feeds(cols, run, gamma, epsilon, env="particle", use_Q_credit=Tru
         acts = call(["action_samples_target"], actor_feed(obs_others_next, obs_self_t_next, obs_self_v_next, actions_1hot))[0]
     else:
         acts = call(["action_samples_target"], actor_feed(obs_others_next, v_local_next))[0]
-    a_next, a_others_next = process_actions(acts.reshape(n_steps, N), l_action)
+    a_next_rep = None
+    if S is not None and acts.is_cuda:    # one launch: both one-hot forms and the rows repeated by m (Q-credit target, :628)
+        a_next, a_others_next, a_next_rep = process_actions_device(acts, n_steps, N, l_action, rep_m=N > 1 and use_Q_credit)
+    else:
+        a_next, a_others_next = process_actions(acts.reshape(n_steps, N), l_action)
     q_t = call(["Q_global_target"], with_env({"v_state_one_agent": one_next, "v_goal": goals_self, "action_one": a_next,
                                               "v_state_other_agents": others_next, "action_others": a_others_next},
                                              state_env_next if checkers else None,
                                              obs_self_t_next if checkers else None, obs_self_v_next if checkers else None))[0]
-    td = reward_local.to(f64) + gamma * q_t.reshape(-1) * not_done
+    td = td_target(reward_local, q_t, not_done, gamma) if S is not None else reward_local.to(f64) + gamma * q_t.reshape(-1) * not_done
     q_res = call(["Q_global_op", "Q_global"],
                  with_env({"Q_global_td_target": td, "v_state_one_agent": one, "v_goal": goals_self, "action_one": actions_1hot,
                            "v_state_other_agents": others, "action_others": actions_others_1hot},
                           state_env if checkers else None, obs_self_t if checkers else None,
                           obs_self_v if checkers else None))[1]
-    q_res_rep = q_res.reshape(n_steps, N).repeat_interleave(N, dim=0)               # :612
+    q_res_rep = rep_rows(q_res.reshape(n_steps, N), N)                              # :612
 
-    rep_m = lambda x: x.repeat_interleave(N, dim=0)                                 # noqa: E731  things indexed by m
+    rep_m = lambda x: rep_rows(x, N)                                                # noqa: E731  things indexed by m
     s_n_rep = s_m_rep = s_others_rep = goals_self_rep = s_env_rep = ot_rep = ov_rep = None
     if N > 1 and use_Q_credit:      # ---- Q_n(s, a^m) (:616-674) ----
         goals_self_rep = _rep_n(goals_self, N) if S is None else S["goals_self_rep"]
         feed = {"v_state_one_agent": _rep_n(one_next, N) if S is None else S["one_next_rep_n"], "v_goal": goals_self_rep,
-                "action_one": rep_m(a_next), "v_state_m": rep_m(one_next) if S is None else S["one_next_rep_m"],
+                "action_one": rep_m(a_next) if a_next_rep is None else a_next_rep,
+                "v_state_m": rep_m(one_next) if S is None else S["one_next_rep_m"],
                 "v_state_other_agents": _rep_n(others_next, N) if S is None else S["others_next_rep_n"]}
         if checkers:
             feed = with_env(feed, rep_m(state_env_next), rep_m(obs_self_t_next), rep_m(obs_self_v_next))
@@ -292,7 +352,7 @@ def train_step_feeds(cols, run, gamma, epsilon, env="particle", use_Q_credit=Tru
         else:
             r_rep, nd_rep = S["r_rep"], S["nd_rep"]
             s_n_rep, s_others_rep, s_m_rep = S["s_n_rep"], S["s_others_rep"], S["s_m_rep"]
-        td_c = r_rep.to(f64) + gamma * qc_t.reshape(-1) * nd_rep
+        td_c = td_target(r_rep, qc_t, nd_rep, gamma) if S is not None else r_rep.to(f64) + gamma * qc_t.reshape(-1) * nd_rep
         feed = {"Q_credit_td_target": td_c, "v_state_one_agent": s_n_rep, "v_goal": goals_self_rep,
                 "action_one": rep_m(actions_1hot) if S is None else S["a1_rep_m"], "v_state_m": s_m_rep,
                 "v_state_other_agents": s_others_rep}
@@ -304,14 +364,14 @@ def train_step_feeds(cols, run, gamma, epsilon, env="particle", use_Q_credit=Tru
     if N > 1 and use_V:             # ---- V_n(s) (:676-699) ----
         v_t = call(["V_target"], with_env({"v_state_one_agent": one_next, "v_goal": goals_self,
                                            "v_state_other_agents": others_next}, state_env_next if checkers else None))[0]
-        td_v = reward_local.to(f64) + gamma * v_t.reshape(-1) * not_done
+        td_v = td_target(reward_local, v_t, not_done, gamma) if S is not None else reward_local.to(f64) + gamma * v_t.reshape(-1) * not_done
         v_res = call(["V_op", "V"], with_env({"V_td_target": td_v, "v_state_one_agent": one, "v_goal": goals_self,
                                               "v_state_other_agents": others}, state_env if checkers else None))[1]
-        v_res_rep = v_res.reshape(n_steps, N).repeat_interleave(N, dim=0)
+        v_res_rep = rep_rows(v_res.reshape(n_steps, N), N)
 
     # ---- policy: probabilities + counterfactual Q for every action (:704-757) ----
     pol_obs = (obs_self_t, obs_self_v, actions_prev_1hot) if checkers else (v_local,)
-    rep_a = lambda x: x.repeat_interleave(l_action, dim=0)                          # noqa: E731
+    rep_a = lambda x: rep_rows(x, l_action)                                         # noqa: E731
     eye = torch.eye(l_action, dtype=f64, device=one.device)                         # self.actions = np.eye(l_action)
     if N == 1:                      # stage 1: Q(s, a = every action, g)
         probs = call(["probs"], actor_feed(obs_others, *pol_obs))[0]
@@ -321,7 +381,7 @@ def train_step_feeds(cols, run, gamma, epsilon, env="particle", use_Q_credit=Tru
             feed = with_env(feed, rep_a(state_env), rep_a(obs_self_t), rep_a(obs_self_v))
         q_cf = call(["Q_global"], feed)[0].reshape(n_steps, l_action)
     elif use_Q_credit:
-        probs = call(["probs"], actor_feed(obs_others, *pol_obs))[0].repeat_interleave(N, dim=0)
+        probs = rep_rows(call(["probs"], actor_feed(obs_others, *pol_obs))[0], N)
         if S is None:
             feed = {"v_state_one_agent": rep_a(s_n_rep), "v_goal": rep_a(goals_self_rep),
                     "action_one": eye.repeat(N * N * n_steps, 1), "v_state_m": rep_a(s_m_rep),

@@ -329,9 +329,38 @@ template <typename I> __global__ void __launch_bounds__(256) k_rows_tile(const T
   }
 }
 
+// TD target of the reference's train_step (alg_credit.py:594, :640, :684): reward + gamma * Q_target * done_multiplier, evaluated in
+// NumPy's order -- (gamma * q) first, times the 0 / 1 multiplier, plus the float64 reward -- with no contraction (the library is built
+// with -ffp-contract=off): the same bits as the torch composition in cm3_amd/batch.py, ONE launch instead of four
+template <typename R> __global__ void __launch_bounds__(256) k_td_target(const R *reward, const double *q, const int64_t *mult, double gamma,
+                                                                         double *out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const double gq = gamma * q[i];
+    out[i] = (double)reward[i] + gq * (double)mult[i];
+  }
+}
+
 }  // namespace cm3
 
 extern "C" {
+int cm3_td_target_f64(const void *reward, int32_t reward_is_f64, const double *q, const int64_t *multiplier, double gamma, double *out,
+                      int64_t n, void *stream) {
+  using namespace cm3;
+  CM3_REQUIRE(n >= 0, "n must be >= 0");
+  if (n == 0) return CM3_OK;
+  CM3_REQUIRE(reward && q && multiplier && out, "td_target: null argument");
+  size_t blocks = ((size_t)n + 255) / 256;
+  blocks = blocks > 2048 ? 2048 : blocks;
+  if (reward_is_f64)
+    hipLaunchKernelGGL(k_td_target<double>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const double *)reward, q, multiplier,
+                       gamma, out, (size_t)n);
+  else
+    hipLaunchKernelGGL(k_td_target<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float *)reward, q, multiplier,
+                       gamma, out, (size_t)n);
+  CM3_HIP_CHECK(hipGetLastError());
+  return CM3_OK;
+}
+
 int cm3_rows_tile(const cm3_tile_col *cols, int32_t n_cols, void *stream) {
   using namespace cm3;
   CM3_REQUIRE(cols && n_cols >= 1 && n_cols <= kMaxRowCols, "rows_tile: 1..%d columns", kMaxRowCols);
@@ -341,7 +370,8 @@ int cm3_rows_tile(const cm3_tile_col *cols, int32_t n_cols, void *stream) {
   size_t most = 0;
   for (int k = 0; k < n_cols; ++k) {
     const cm3_tile_col &q = cols[k];
-    CM3_REQUIRE(q.dst && (q.src || q.kind == CM3_TILE_EYE_F64), "rows_tile: column %d is null", k);
+    // (an EMPTY column may come with null pointers: torch.empty(0).data_ptr() is 0 -- ADVICE r5)
+    CM3_REQUIRE(q.n_rows == 0 || (q.dst && (q.src || q.kind == CM3_TILE_EYE_F64)), "rows_tile: column %d is null", k);
     CM3_REQUIRE(q.kind >= CM3_TILE_COPY && q.kind <= CM3_TILE_NOT_I64, "rows_tile: column %d: unknown kind %d", k, (int)q.kind);
     CM3_REQUIRE(q.elems_per_row >= 1 && q.n_rows >= 0, "rows_tile: column %d: empty rows", k);
     CM3_REQUIRE(q.kind != CM3_TILE_COPY || q.elem_bytes == 1 || q.elem_bytes == 4 || q.elem_bytes == 8,
@@ -392,6 +422,7 @@ int cm3_transitions_gather_f32(const cm3_particle_desc *desc, const cm3_particle
   using namespace cm3;
   CM3_REQUIRE(desc && traj && out && ((tt == nullptr) == (ee == nullptr)), "null argument (tt and ee: both or neither)");
   CM3_REQUIRE(n >= 0, "n must be >= 0");
+  if (n == 0) return CM3_OK;      // (before the pointer checks: the columns of an empty batch are null -- ADVICE r5)
   CM3_REQUIRE(desc->n_agents >= 1 && desc->n_agents <= CM3_MAX_AGENTS, "n_agents out of range");
   CM3_REQUIRE(traj->state && traj->obs_others && traj->actions && traj->reward_n && traj->reward && traj->done && traj->goals,
               "trajectory base pointers are required");
@@ -399,7 +430,6 @@ int cm3_transitions_gather_f32(const cm3_particle_desc *desc, const cm3_particle
   CM3_REQUIRE(out->state && out->obs_others && out->actions && out->reward && out->reward_n && out->next_state && out->next_obs_others &&
                   out->done && out->goals,
               "output columns are required");
-  if (n == 0) return CM3_OK;
   TransParams p;
   memset(&p, 0, sizeof(p));
   p.state = (const float *)traj->state;             p.st_state = traj->state_stride;

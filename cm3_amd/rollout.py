@@ -744,6 +744,13 @@ class ParticleRollout(object):
         transitions) per phase; a vectorised phase holds n_envs episodes.
         All minibatches of the phase are drawn together and exported by ONE launch (round 5: 24 separate samples cost 24 permutations
         of the phase's 1.35 M transitions, 7 ms against the 0.8 ms of collecting them); each yielded dict holds views of that export."""
+        cols, k = self._phase_export(epochs, batch_size, generator)
+        for m in range(int(epochs)):
+            mb = {name: v[m * k:(m + 1) * k] for name, v in cols.items()}
+            yield ({name: v.detach().cpu().numpy() for name, v in mb.items()} if numpy else mb)
+
+    def _phase_export(self, epochs, batch_size, generator):
+        """-> (columns of all `epochs` minibatches back to back [epochs * k, ...], k = transitions per minibatch): one draw, one launch"""
         epochs = int(epochs)
         pos, tt, ee = self._sample_positions(batch_size, epochs, generator)
         self.last_sample_positions = pos          # (tests: which transitions the minibatches hold)
@@ -754,9 +761,22 @@ class ParticleRollout(object):
             cols = self.as_reference_batch(torch.div(flat, E, rounding_mode="floor"), flat % E, numpy=False)
         else:
             cols = self.as_reference_batch(tt[flat], ee[flat], numpy=False)
-        for m in range(epochs):
-            mb = {name: v[m * k:(m + 1) * k] for name, v in cols.items()}
-            yield ({name: v.detach().cpu().numpy() for name, v in mb.items()} if numpy else mb)
+        return cols, k
+
+    def on_policy_phase(self, epochs=24, batch_size=128, generator=None, l_action=5):
+        """The minibatches of on_policy_minibatches() TOGETHER WITH the static feeds of the reference's train_step for each of them
+        (cm3_amd.batch.phase_static_feeds: process_actions / process_global_state, the n x n credit repeats, the n x n x l_action
+        counterfactual tiling of alg_credit.py:406-557, :614-658, :730-751) -- for the whole phase one export launch and one pair of
+        tiling launches; a list of (columns, static) pairs of views, static None where the tiling kernel does not apply (N = 1, float64).
+        Feed them to cm3_amd.batch.train_step_feeds(columns, run, gamma, epsilon, static=static)."""
+        from . import batch as B
+        cols, k = self._phase_export(epochs, batch_size, generator)
+        vg = cols["v_global"]
+        if vg.is_cuda and vg.dtype == torch.float32 and vg.shape[1] > 1:
+            statics = B.phase_static_feeds(cols, int(epochs), l_action)
+        else:
+            statics = [None] * int(epochs)
+        return [({name: v[m * k:(m + 1) * k] for name, v in cols.items()}, statics[m]) for m in range(int(epochs))]
 
 
 def sample_distinct(n, size, rows, generator, device):

@@ -567,6 +567,10 @@ typedef struct cm3_transition_cols {
   int64_t ring_start;     /* ring_size > 0: the columns are REPLAY RINGS of ring_size rows and transition b is written to row */
   int64_t ring_size;      /* (ring_start + b) mod ring_size -- export and replay_buffer.add in one launch; 0: row b */
 } cm3_transition_cols;
+/* INDEX CONTRACT of cm3_rows_scatter / cm3_rows_gather / cm3_transitions_gather_f32: row indices (dst_row, src_row, tt, ee) are
+ * NOT bounds-checked by the launches -- an index outside its array is an out-of-bounds device access.  The host classes that call
+ * them (cm3_amd/replay.py RingIndex, rollout.py) derive every index from sizes they own; a caller of the C ABI must do the same.
+ * n == 0 (or zero rows) returns CM3_OK without touching any pointer. */
 /* Gathers transitions (tt[b], ee[b]), b < n, out of a time-major trajectory (the cm3_particle_traj the collector wrote: state
  * [T+1][N][E][4], obs_others [T+1][E][N][L], actions / reward_n [T][E][N], reward / done [T][E], optional term_* [T][...]) in ONE
  * launch.  goals: traj->goals with goals_stride bytes per slot (stride 0: one live array); goal_slot (optional, int32 with
@@ -617,6 +621,11 @@ typedef struct cm3_tile_col {
   uint32_t div[2], mod[2], mul[2];
 } cm3_tile_col;
 int cm3_rows_tile(const cm3_tile_col *cols, int32_t n_cols, void *stream);
+/* out[i] = (double)reward[i] + (gamma * q[i]) * (double)multiplier[i]  (ABI 7): the TD targets of the reference's train_step
+ * (alg_credit.py:594, :640, :684: reward + gamma * Q_target * done_multiplier), NumPy's evaluation order, no contraction.
+ * reward float32 (reward_is_f64 = 0) or float64 [n], q float64 [n], multiplier int64 [n] (0 / 1), out float64 [n]. */
+int cm3_td_target_f64(const void *reward, int32_t reward_is_f64, const double *q, const int64_t *multiplier, double gamma, double *out,
+                      int64_t n, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Measurement and launch plumbing

@@ -194,3 +194,54 @@ def test_device_tiling_equals_the_torch_composition(source):
             else:
                 assert fa[k] == fb[k]
     assert n >= 40
+
+
+@pytest.mark.gpu
+def test_phase_feeds_equal_per_minibatch_feeds():
+    """Round 6: ParticleRollout.on_policy_phase hands out, per minibatch, views of ONE export and of ONE pair of tiling launches over the
+    whole phase (cm3_amd.batch.phase_static_feeds), and train_step_feeds(static=...) builds the TD targets / sampled-action one-hots with
+    single launches (cm3_td_target_f64, cm3_rows_tile).  Every feed of every sess.run of every minibatch equals the torch
+    composition (device_tiling=False) on the same minibatch -- which tests above pin to the arrays the REAL train_step fed."""
+    from cm3_amd import batch as BR
+    from cm3_amd.particle import VecParticleEnv
+    from cm3_amd.rollout import ParticleRollout
+    from tests.helpers import load_cfg
+    dev = "cuda:0"
+    env = VecParticleEnv(load_cfg("particle_stage2_antipodal.json"), 4, 0.2, 33, 256, device=dev, dtype=torch.float32, auto_reset=True, seed=3)
+    env.reset()
+    ro = ParticleRollout(env, n_ticks=66, use_graph=False).collect()
+    pairs = ro.on_policy_phase(epochs=5, batch_size=37, generator=torch.Generator(device=dev).manual_seed(4))
+    assert len(pairs) == 5 and all(s is not None for _, s in pairs)
+
+    def make_run(n_rows):
+        g = torch.Generator(device=dev).manual_seed(6)
+
+        def run(ops, feed):
+            rows = max([v.shape[0] for v in feed.values() if torch.is_tensor(v) and v.dim() > 0] or [1])
+            outs = []
+            for op in ops:
+                if op.endswith("_op") or op == "list_update_target_ops":
+                    outs.append(None)
+                elif op == "action_samples_target":
+                    outs.append(torch.randint(0, 5, (n_rows * 4,), generator=g, device=dev))
+                elif op == "probs":
+                    outs.append(torch.rand(rows, 5, generator=g, device=dev, dtype=torch.float64))
+                else:
+                    outs.append(torch.rand(rows, generator=g, device=dev, dtype=torch.float64))
+            return outs
+        return run
+    checked = 0
+    for cols, static in pairs:
+        assert cols["v_global"].shape[0] == 37
+        a = BR.train_step_feeds(cols, make_run(37), 0.99, 0.1, static=static)
+        b = BR.train_step_feeds(cols, make_run(37), 0.99, 0.1, device_tiling=False)
+        assert [c[0] for c in a] == [c[0] for c in b]
+        for (ops, fa), (_, fb) in zip(a, b):
+            assert sorted(fa) == sorted(fb), ops
+            for k in fb:
+                if torch.is_tensor(fb[k]):
+                    assert fa[k].dtype == fb[k].dtype and fa[k].shape == fb[k].shape, (ops, k)
+                    assert torch.equal(fa[k], fb[k]), (ops, k)
+                    checked += 1
+    assert checked >= 5 * 40
+    ro.close()

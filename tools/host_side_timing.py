@@ -114,6 +114,40 @@ def measure(device, copy_gbps=None, n_envs=4096, n_agents=4, cfg_name="particle_
         out["train_step_feeds_" + label + "_torch_composition"] = rec(s, _nbytes(c) + fb, "the same feeds as a composition of torch operations")
         s, S = _time(lambda: B.particle_static_feeds_device(c), device, reps=20)
         out["static_feeds_" + label] = rec(s, _nbytes(c) + _nbytes(S), "particle_static_feeds_device alone: 22 feed tensors, two launches")
+    # ---- one on-policy phase END TO END (train_onpolicy.py:302-377): collect 330 ticks, draw + export the 24 minibatches of 128, build
+    # every feed of the 24 train_steps (stand-in session) -- round 5: 0.79 + 0.44 + 24 x 0.32 = ~9 ms, launch latency of the feeds
+    def run128(ops, feed):
+        outs = []
+        for op in ops:
+            if op == "action_samples_target":
+                outs.append(_zeros["acts"])
+            elif op == "probs":
+                outs.append(_zeros["probs"])
+            elif op == "Q_credit":
+                outs.append(_zeros["qcf"])
+            elif op.endswith("_op") or op == "list_update_target_ops":
+                outs.append(None)
+            else:
+                rows = next(v.shape[0] for v in feed.values() if hasattr(v, "shape") and v.dim() > 0)
+                outs.append(_zeros["q"][:rows])
+        return outs
+    _zeros = {"acts": torch.zeros(128 * N, dtype=torch.int64, device=device), "probs": torch.full((128 * N, 5), 0.2, dtype=torch.float64, device=device),
+              "qcf": torch.zeros(128 * N * N * 5, dtype=torch.float64, device=device), "q": torch.zeros(128 * N * N * 5, dtype=torch.float64, device=device)}
+
+    def phase(with_collect=True):
+        if with_collect:
+            ro.collect()
+        n = 0
+        for c_k, s_k in ro.on_policy_phase(epochs=24, batch_size=128, generator=g):
+            n += len(B.train_step_feeds(c_k, run128, 0.99, 0.1, static=s_k))
+        return n
+    s_feeds, n_calls = _time(lambda: phase(False), device, reps=5)
+    s_coll, _ = _time(lambda: ro.collect(), device, reps=5)
+    s_phase, _ = _time(phase, device, reps=5)
+    out["phase_total"] = {"ms": s_phase * 1e3, "collect_ms": s_coll * 1e3, "export_and_feeds_ms": s_feeds * 1e3, "sess_runs": int(n_calls),
+                          "what": "ParticleRollout.collect (330 ticks) + on_policy_phase(24, 128) (one export launch + one pair of tiling "
+                                  "launches for all 24 minibatches) + cm3_amd.batch.train_step_feeds x 24 with a stand-in session whose "
+                                  "outputs are preallocated; round 5: ~9 ms"}
     # (f4) replay: add the whole phase, sample 128
     cols = ro.as_reference_batch(numpy=False)
     B_all = cols["reward"].shape[0]
