@@ -144,7 +144,7 @@ class ParticleStepper(GraphStepper):
     trajectory is stored).  Used for the E-sweep and as the labelled `in_place` extra."""
 
     def __init__(self, cfg, n_agents, n_envs, device, seed=12341, env_id_base=0, max_steps=33, prob_random=0.2,
-                 kernel="auto", fused=False, n_chains=1, tensor_actions=False):
+                 kernel="auto", fused=False, tensor_actions=False):
         import torch
         from cm3_amd import _lib
         from cm3_amd.particle import VecParticleEnv
@@ -171,27 +171,19 @@ class ParticleStepper(GraphStepper):
         t.meta = e._meta.data_ptr()
         t.episode = e._episode.data_ptr()      # all strides stay 0: in place
         self.device = e.device
-        self.n_chains = int(n_chains)
-        self.launches_per_tick = self.n_chains
-        self._side = [torch.cuda.Stream(device=self.device) for _ in range(self.n_chains - 1)]
+        self.launches_per_tick = 1
 
     def enqueue(self, n_ticks, stream=None):
         s = self.stream() if stream is None else stream
-        if self.n_chains > 1:
-            streams = (ctypes.c_void_p * self.n_chains)(s, *[x.cuda_stream for x in self._side])
-            self._lib_mod.check(self.lib.cm3_particle_rollout_chains_f32(ctypes.byref(self.env._desc), ctypes.byref(self.traj),
-                                                                         int(n_ticks), self.n_chains, streams))
-        else:
-            self._lib_mod.check(self.lib.cm3_particle_rollout_f32(ctypes.byref(self.env._desc), ctypes.byref(self.traj),
-                                                                  int(n_ticks), s))
+        self._lib_mod.check(self.lib.cm3_particle_rollout_f32(ctypes.byref(self.env._desc), ctypes.byref(self.traj), int(n_ticks), s))
 
 
 class TrajectoryStepper(object):
     """The headline: cm3_amd.rollout.ParticleRollout over a [phase_ticks + 1]-slot device trajectory with terminal capture
     (continuous collection, train_onpolicy.py:302-350); one collect() = slot copy in, ONE hipGraph replay of phase_ticks
-    step launches (x n_chains independent sub-batch chains), slot copy out."""
+    step launches, slot copy out."""
 
-    def __init__(self, cfg, n_agents, n_envs, device, env_id_base=0, kernel="auto", n_chains=1, phase_ticks=PHASE_TICKS,
+    def __init__(self, cfg, n_agents, n_envs, device, env_id_base=0, kernel="auto", phase_ticks=PHASE_TICKS,
                  use_graph=True, fused=False, live_state=None):
         import torch
         from cm3_amd.particle import VecParticleEnv
@@ -200,10 +192,10 @@ class TrajectoryStepper(object):
         self.env = VecParticleEnv(cfg, n_agents, 0.2, EP_TICKS, n_envs, device=device, dtype=torch.float32, auto_reset=True,
                                   env_id_base=env_id_base, kernel=kernel)
         self.env.reset()
-        self.ro = ParticleRollout(self.env, n_ticks=phase_ticks, use_graph=use_graph, fused=fused, n_chains=n_chains, live_state=live_state)
+        self.ro = ParticleRollout(self.env, n_ticks=phase_ticks, use_graph=use_graph, fused=fused, live_state=live_state)
         self.device = self.env.device
         self.phase_ticks = int(phase_ticks)
-        self.launches_per_tick = int(n_chains)
+        self.launches_per_tick = 1
 
     def capture(self, n_ticks):
         pass                                    # ParticleRollout captures its own graph on first use
@@ -286,7 +278,7 @@ class RolloutAdvStepper(object):
     ten moment triples, one all-gather carries them all).  A bench step stays one rollout + its normalisation; a number of steps
     that is not a multiple of ten finishes on the single-rollout graph of round 3."""
 
-    def __init__(self, cfg, n_agents, n_envs, device, env_id_base=0, kernel="auto", fused=False, n_chains=1,
+    def __init__(self, cfg, n_agents, n_envs, device, env_id_base=0, kernel="auto", fused=False,
                  phase_rollouts=PHASE_EPISODES):
         import torch
         from cm3_amd.particle import VecParticleEnv
@@ -296,15 +288,15 @@ class RolloutAdvStepper(object):
                                   env_id_base=env_id_base, kernel=kernel)
         self.env.reset()
         self.K = int(phase_rollouts)
-        self.ro = ParticleRollout(self.env, n_ticks=EP_TICKS * self.K, use_graph=True, fused=fused, n_chains=n_chains)
-        self.ro1 = ParticleRollout(self.env, n_ticks=EP_TICKS, use_graph=True, fused=fused, n_chains=n_chains)
+        self.ro = ParticleRollout(self.env, n_ticks=EP_TICKS * self.K, use_graph=True, fused=fused)
+        self.ro1 = ParticleRollout(self.env, n_ticks=EP_TICKS, use_graph=True, fused=fused)
         # set-up, not a step: both graphs are captured here, so that no capture (milliseconds) lands in a timed region whatever
         # the warm-up / step counts are
         self.ro.collect_normalized(gamma=0.99, segments=self.K)
         self.ro1.collect_normalized(gamma=0.99)
         self.device = self.env.device
         self.last = None
-        self.launches_per_tick = int(n_chains)
+        self.launches_per_tick = 1
         self.collective_s, self.rollouts = 0.0, 0     # host time inside the all-gather call, summed over rollouts
 
     def capture(self, n_ticks):
@@ -680,7 +672,7 @@ def measure_other_config(name, args, device, steps=20, cpu_budget_s=6.0):
     N = cfg["n_agents"]
     a2 = argparse.Namespace(**vars(args))
     a2.mode, a2.fused, a2.no_graph, a2.kernel, a2.workload = "trajectory", False, False, "auto", name
-    st, tps, bps, dtype_name, mode = build_headline(a2, kind, cfg, N, E, device, 0, 1)
+    st, tps, bps, dtype_name, mode = build_headline(a2, kind, cfg, N, E, device, 0)
     if kind == "particle_adv":
         steps = steps * 10                      # a c4 step is one 33-tick rollout: time as many ticks as the others
     K = steps * tps
@@ -944,7 +936,7 @@ def rccl_report(dist, torch, device, local_rank, world):
     return rep
 
 
-def headline_record(*, world, steps, warm, K, ticks_per_step, wall_max, ev_max, per_rank, E, N, kind, mode, n_chains,
+def headline_record(*, world, steps, warm, K, ticks_per_step, wall_max, ev_max, per_rank, E, N, kind, mode,
                     fused_ticks, launches_per_tick, bytes_per_env_step, dtype_name, wl_desc, no_graph, pinned, live_state,
                     rccl=None):
     """The record rank 0 builds from the timed region, for ANY world size (main() calls it; tests/test_bench_line.py calls it with
@@ -953,7 +945,7 @@ def headline_record(*, world, steps, warm, K, ticks_per_step, wall_max, ev_max, 
     total_env_steps = float(E) * K * world
     value = total_env_steps / wall_max
     launches = K / float(fused_ticks) * launches_per_tick          # step-kernel launches inside the timed region, per rank
-    launch_s = wall_max / launches                                   # time per launch (chains: launches overlap; this is rate^-1)
+    launch_s = wall_max / launches                                   # time per launch
     bytes_per_launch = bytes_per_env_step * E * fused_ticks / float(launches_per_tick)
     achieved = bytes_per_launch / launch_s / 1e9
     if kind == "particle_adv":
@@ -974,10 +966,9 @@ def headline_record(*, world, steps, warm, K, ticks_per_step, wall_max, ev_max, 
                                % (wl_desc, E, mode,
                                   "every tick writes slot t+1 of a [%d+1, E, ...] device trajectory incl. terminal capture"
                                   % ticks_per_step if mode == "trajectory" else "every tick overwrites the live buffers",
-                                  ("one step-kernel launch per tick" if n_chains == 1 else
-                                   "%d independent sub-batch chains, one launch per tick per chain" % n_chains)
+                                  "one step-kernel launch per tick"
                                   if fused_ticks == 1 else "%d ticks fused per launch (random-action branch)" % fused_ticks),
-                   "envs_per_gpu": E, "n_agents": N, "global_envs": E * world, "mode": mode, "chains": n_chains,
+                   "envs_per_gpu": E, "n_agents": N, "global_envs": E * world, "mode": mode,
                    "launch": launch_desc, "ticks_per_launch": fused_ticks, "live_state": live_state,
                    "step_definition": ("one 33-tick rollout + advantage normalisation" if kind == "particle_adv" else
                                        "one collection phase = %d episodes x %d ticks (train_onpolicy.py:359-377)"
@@ -1019,22 +1010,21 @@ def rank0_baselines(out, kind, cfg, N, world, device, no_cpu_baseline=False, mea
     return bw_read, bw_copy
 
 
-def build_headline(args, kind, cfg, N, E, device, rank, n_chains):
+def build_headline(args, kind, cfg, N, E, device, rank):
     """-> (stepper, ticks_per_step, bytes_per_env_step, dtype_name, mode description)"""
     if kind == "particle_adv":
-        st = RolloutAdvStepper(cfg, N, E, device, env_id_base=rank * E, kernel=args.kernel, fused=args.fused, n_chains=n_chains)
+        st = RolloutAdvStepper(cfg, N, E, device, env_id_base=rank * E, kernel=args.kernel, fused=args.fused)
         return st, EP_TICKS, algorithmic_bytes_per_env_step(N), "f32", "trajectory"
     if kind == "particle":
         bps = algorithmic_bytes_per_env_step(N)
         if args.fused:   # state, goals and counters are read once per launch, not once per tick
             bps -= (16 * N + 8 * N + 8) * (EP_TICKS - 1) / float(EP_TICKS)
         if args.mode == "trajectory":
-            st = TrajectoryStepper(cfg, N, E, device, env_id_base=rank * E, kernel=args.kernel, n_chains=n_chains,
+            st = TrajectoryStepper(cfg, N, E, device, env_id_base=rank * E, kernel=args.kernel,
                                    use_graph=not args.no_graph, fused=args.fused,
                                    live_state={"auto": None, "on": True, "off": False}[getattr(args, "live_state", "auto")])
         else:
-            st = ParticleStepper(cfg, N, E, device, env_id_base=rank * E, kernel=args.kernel, fused=args.fused,
-                                 n_chains=n_chains)
+            st = ParticleStepper(cfg, N, E, device, env_id_base=rank * E, kernel=args.kernel, fused=args.fused)
             if not args.no_graph:
                 st.capture(PHASE_TICKS)
         return st, PHASE_TICKS, bps, "f32", args.mode
@@ -1065,9 +1055,6 @@ def main():
     ap.add_argument("--mode", choices=["trajectory", "in-place"], default="trajectory",
                     help="trajectory (default): every tick writes its slot of a device trajectory (the collection loop); "
                          "in-place: every tick overwrites the same live buffers (stepping only)")
-    ap.add_argument("--chains", type=int, default=1,
-                    help="independent sub-batch chains per tick (parallel branches of the hipGraph; 1 = one launch per tick). "
-                         "K > 1 measured 1.2-5x SLOWER on MI355X (profiles/r02_chains_diag.txt): kept to reproduce that")
     ap.add_argument("--envs-per-gpu", type=int, default=0, help="override the workload's batch size")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-sweep", action="store_true", help="skip the E-sweep (extra 'sweep' field)")
@@ -1075,7 +1062,7 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short c3 / c5 / c4 runs that the default c2 line carries as 'other_configs'")
     ap.add_argument("--no-extras", action="store_true",
-                    help="headline only: skip the in-place / chains / fused / policy-rollout / launch-floor extras (clean profiles)")
+                    help="headline only: skip the in-place / fused / policy-rollout / launch-floor extras (clean profiles)")
     ap.add_argument("--live-state", choices=["auto", "on", "off"], default="auto",
                     help="trajectory mode of the particle workloads: step in place on the env's buffers and copy every tick's state to "
                          "its slot (on), chain the ticks through the slots (off), or by size (auto, the product's rule)")
@@ -1136,8 +1123,7 @@ def main():
     N = cfg["n_agents"]
     E = args.envs_per_gpu or default_e
     steps, warm = max(args.steps, 1), max(args.warmup, 0)
-    n_chains = max(1, args.chains) if kind != "checkers" else 1
-    stepper, ticks_per_step, bytes_per_env_step, dtype_name, mode = build_headline(args, kind, cfg, N, E, device, rank, n_chains)
+    stepper, ticks_per_step, bytes_per_env_step, dtype_name, mode = build_headline(args, kind, cfg, N, E, device, rank)
     K, W = steps * ticks_per_step, max(warm, 1) * ticks_per_step      # in ticks
     stepper.run(W)
     torch.cuda.synchronize(device)
@@ -1177,7 +1163,7 @@ def main():
     out = None
     if rank == 0:
         out = headline_record(world=world, steps=steps, warm=warm, K=K, ticks_per_step=ticks_per_step, wall_max=wall_max,
-                              ev_max=ev_max, per_rank=per_rank, E=E, N=N, kind=kind, mode=mode, n_chains=n_chains,
+                              ev_max=ev_max, per_rank=per_rank, E=E, N=N, kind=kind, mode=mode,
                               fused_ticks=fused_ticks, launches_per_tick=stepper.launches_per_tick,
                               bytes_per_env_step=bytes_per_env_step, dtype_name=dtype_name, wl_desc=wl_desc, no_graph=args.no_graph,
                               pinned=pinned, live_state=bool(getattr(getattr(stepper, "ro", None), "_live", False)), rccl=rccl)
@@ -1193,14 +1179,14 @@ def main():
                    ("c3", 8192, "in-place"): "c3_checkers_stage2_n2_e8192", ("c3", 8192, "trajectory"): "c3_trajectory_n2_e8192",
                    ("c5", 8192, "in-place"): "c5_particle_merge8_n8_e8192",
                    ("c5", 8192, "trajectory"): "c5_trajectory_n8_e8192"}.get((args.workload, E, mode))
-    if rank == 0 and traffic_tag and not args.fused and n_chains == 1:
+    if rank == 0 and traffic_tag and not args.fused:
         traffic, rec = pmc_traffic(traffic_tag)
         if traffic is not None:
             out["roofline"]["traffic"] = traffic
             out["roofline"]["traffic_source"] = ("profiles/pmc_traffic.json: %s, %d launches, FETCH_SIZE %.1f KB (x2) + "
                                                  "WRITE_SIZE %.1f KB" % (rec["kernel"], rec["launches"],
                                                                          rec["FETCH_SIZE_KB"], rec["WRITE_SIZE_KB"]))
-    if rank == 0 and not args.fused and n_chains == 1:
+    if rank == 0 and not args.fused:
         rec = span_record("%s_%s" % (args.workload, mode.replace("-", "_")))
         if rec and E == default_e:
             out["roofline"]["kernel_span"] = {
@@ -1217,20 +1203,17 @@ def main():
         stepper = None
         torch.cuda.empty_cache()
         modes = {}
-        # (a) the other storage mode, (b) parallel sub-batch chains, all on the same workload and graph size
-        # (--chains K stays available; K > 1 measured 1.2x - 5x SLOWER than one chain in every form tried on MI355X --
-        # hipGraph branches, eager streams, one graph per chain: profiles/r02_chains_diag.txt -- so it is not run by default)
-        variants = [("in-place" if mode == "trajectory" else "trajectory", 1)]
-        for vmode, vch in variants:
+        # the other storage mode on the same workload and graph size
+        for vmode in ("in-place" if mode == "trajectory" else "trajectory",):
             a2 = argparse.Namespace(**vars(args))
             a2.mode, a2.fused, a2.no_graph = vmode, False, False
-            st, tps, bps, _, _ = build_headline(a2, kind, cfg, N, E, device, 0, vch)
+            st, tps, bps, _, _ = build_headline(a2, kind, cfg, N, E, device, 0)
             st.run(tps * 2)
             torch.cuda.synchronize(device)
             n = tps * max(3, min(steps, 10))
             ms = timed_ticks(st, n)
             us = ms * 1e3 / n
-            modes["%s_chains%d" % (vmode.replace("-", "_"), vch)] = {
+            modes[vmode.replace("-", "_")] = {
                 "us_per_tick": us, "env_steps_per_s": E / us * 1e6,
                 "achieved_GBps": bps * E / (us * 1e-6) / 1e9, "frac_of_peak": bps * E / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS}
             st.close()
@@ -1453,7 +1436,7 @@ def main():
                        "(the others branch of the two-agent network is a table lookup there)")
         out["policy_rollout"] = pol
     if world == 1 and rank == 0 and args.workload == "c2" and mode == "trajectory" and not args.no_other_configs \
-            and not args.no_extras and not args.fused and n_chains == 1 and not args.envs_per_gpu:
+            and not args.no_extras and not args.fused and not args.envs_per_gpu:
         # the other BASELINE workloads, driver-timed in the same run (each a short run of ITS configuration; the headline stays c2)
         if stepper is not None:
             stepper.close()
@@ -1475,7 +1458,7 @@ def main():
             # What one launch per tick cannot go below at this batch: the same number of 256-lane workgroups reading and
             # writing the same algorithmic bytes with NO arithmetic (load -> store skeleton), and an empty launch, both
             # replayed as a hipGraph of the same length.
-            floor = launch_ceiling(device, kind, N, E, bytes_per_launch, launch_s * 1e6 * max(1, n_chains))   # (per whole tick)
+            floor = launch_ceiling(device, kind, N, E, bytes_per_launch, launch_s * 1e6)
             out["roofline"]["ceiling_frac"] = floor["ceiling_frac"]
             out["roofline"]["launch_floor"] = floor
         if not args.no_sweep and kind == "particle":

@@ -167,8 +167,6 @@ SYMBOLS = {
     "cm3_particle_observe_f64": (ctypes.c_int, [P(ParticleDesc), P(ParticleBufs), c_void_p]),
     "cm3_particle_rollout_f32": (ctypes.c_int, [P(ParticleDesc), P(ParticleTraj), c_int32, c_void_p]),
     "cm3_particle_rollout_f64": (ctypes.c_int, [P(ParticleDesc), P(ParticleTraj), c_int32, c_void_p]),
-    "cm3_particle_rollout_chains_f32": (ctypes.c_int, [P(ParticleDesc), P(ParticleTraj), c_int32, c_int32, P(c_void_p)]),
-    "cm3_particle_rollout_chains_f64": (ctypes.c_int, [P(ParticleDesc), P(ParticleTraj), c_int32, c_int32, P(c_void_p)]),
     "cm3_checkers_step": (ctypes.c_int, [P(CheckersDesc), P(CheckersBufs), c_void_p]),
     "cm3_checkers_rollout": (ctypes.c_int, [P(CheckersDesc), P(CheckersTraj), c_int32, c_void_p]),
     "cm3_checkers_reset": (ctypes.c_int, [P(CheckersDesc), P(CheckersBufs), c_void_p, c_void_p]),

@@ -43,7 +43,7 @@ struct ParticleParams {
   int max_steps;
   uint32_t flags;
   int _pad;
-  int E0, EN;     // this launch covers envs [E0, EN) of the arrays (a sub-batch chain of cm3_particle_rollout_chains_*)
+  int E0, EN;     // this launch covers envs [E0, EN) of the arrays (desc->env_offset / env_count: a sub-batch of the arrays)
   int64_t env_id_base;
   uint64_t seed;
   double prob_random, initial_std;
@@ -2049,72 +2049,6 @@ static int particle_rollout(const cm3_particle_desc *d, const cm3_particle_traj 
   return CM3_OK;
 }
 
-// Independent sub-batch chains (envs never interact): chain c = envs [c * chunk, min((c + 1) * chunk, E)) advances through
-// its n_ticks launches on streams[c]; streams[1..] are forked from / joined back into streams[0] with events, so the call
-// is ordered like one launch sequence on streams[0] -- eagerly, or as parallel branches of the hipGraph being captured on
-// streams[0].  The dependent-launch boundary of one chain (~1.5 us on MI355X) then overlaps the bodies of the others.
-// Every launch is still one tick of its envs; RNG keys are global env ids, so results do not depend on n_chains.
-template <typename R>
-static int particle_rollout_chains(const cm3_particle_desc *d, const cm3_particle_traj *t, int32_t n_ticks, int32_t n_chains,
-                                   void *const *streams) {
-  CM3_REQUIRE(d && t && streams, "null desc/traj/streams");
-  CM3_REQUIRE(n_chains >= 1 && n_chains <= 16, "n_chains must be in 1..16 (got %d)", n_chains);
-  CM3_REQUIRE(d->env_offset == 0 && d->env_count == 0, "chains split the whole batch: env_offset / env_count must be 0");
-  CM3_REQUIRE(d->n_envs > 0, "n_envs must be positive");
-  for (int c = 1; c < n_chains; ++c) CM3_REQUIRE(streams[c] && streams[c] != streams[0], "chains need distinct non-NULL streams");
-  // whole workgroups per chain: every mapping's workgroup covers a divisor of 256 consecutive envs
-  size_t chunk = ((size_t)d->n_envs + n_chains - 1) / n_chains;
-  chunk = (chunk + 255) / 256 * 256;
-  hipStream_t s0 = (hipStream_t)streams[0];
-  hipEvent_t fork = nullptr, join[16] = {nullptr};
-  int used = 0;
-  for (int c = 0; c < n_chains; ++c)
-    if ((size_t)c * chunk < (size_t)d->n_envs) used = c + 1;
-  // The first error is remembered and the fork / join epilogue ALWAYS runs for every side stream that was forked: returning from
-  // inside the loop leaked the events and, during hipGraph capture, left side streams un-joined (the capture on streams[0] was
-  // then invalid and had to be aborted by the caller).
-  int rc = CM3_OK;
-  auto note = [&rc](hipError_t e, const char *what) {
-    if (e != hipSuccess && rc == CM3_OK) rc = fail(CM3_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
-  };
-  if (used > 1) {
-    note(hipEventCreateWithFlags(&fork, hipEventDisableTiming), "hipEventCreateWithFlags");
-    if (fork) note(hipEventRecord(fork, s0), "hipEventRecord(fork)");
-  }
-  bool forked[16] = {false};
-  for (int c = 0; c < used; ++c) {
-    hipStream_t sc = (hipStream_t)streams[c];
-    if (c > 0) {
-      if (rc != CM3_OK || !fork) break;          // nothing further is forked after an error
-      const hipError_t e = hipStreamWaitEvent(sc, fork, 0);
-      note(e, "hipStreamWaitEvent(fork)");
-      if (e != hipSuccess) break;
-      forked[c] = true;
-    }
-    if (rc == CM3_OK) {
-      cm3_particle_desc dc = *d;
-      dc.env_offset = (int32_t)((size_t)c * chunk);
-      const size_t end = ((size_t)(c + 1) * chunk < (size_t)d->n_envs) ? (size_t)(c + 1) * chunk : (size_t)d->n_envs;
-      dc.env_count = (int32_t)(end - (size_t)dc.env_offset);
-      const int r = particle_rollout<R>(&dc, t, n_ticks, sc);
-      if (r != CM3_OK && rc == CM3_OK) rc = r;
-    }
-  }
-  for (int c = 1; c < used; ++c) {              // join every forked side stream back into streams[0], error or not
-    if (!forked[c]) continue;
-    hipStream_t sc = (hipStream_t)streams[c];
-    hipError_t e = hipEventCreateWithFlags(&join[c], hipEventDisableTiming);
-    note(e, "hipEventCreateWithFlags");
-    if (e != hipSuccess) continue;
-    note(hipEventRecord(join[c], sc), "hipEventRecord(join)");
-    note(hipStreamWaitEvent(s0, join[c], 0), "hipStreamWaitEvent(join)");
-  }
-  // events may be destroyed once recorded / waited on: the runtime keeps what in-flight work still needs
-  if (fork) (void)hipEventDestroy(fork);
-  for (int c = 1; c < used; ++c)
-    if (join[c]) (void)hipEventDestroy(join[c]);
-  return rc;
-}
 
 }  // namespace cm3
 
@@ -2178,10 +2112,6 @@ int cm3_particle_observe_f32(const cm3_particle_desc *d, const cm3_particle_bufs
 int cm3_particle_rollout_f32(const cm3_particle_desc *d, const cm3_particle_traj *t, int32_t n, void *s) {
   return cm3::particle_rollout<float>(d, t, n, s);
 }
-int cm3_particle_rollout_chains_f32(const cm3_particle_desc *d, const cm3_particle_traj *t, int32_t n, int32_t n_chains,
-                                    void *const *streams) {
-  return cm3::particle_rollout_chains<float>(d, t, n, n_chains, streams);
-}
 #endif
 #ifdef CM3_PARTICLE_F64
 int cm3_particle_step_f64(const cm3_particle_desc *d, const cm3_particle_bufs *b, void *s) {
@@ -2195,10 +2125,6 @@ int cm3_particle_observe_f64(const cm3_particle_desc *d, const cm3_particle_bufs
 }
 int cm3_particle_rollout_f64(const cm3_particle_desc *d, const cm3_particle_traj *t, int32_t n, void *s) {
   return cm3::particle_rollout<double>(d, t, n, s);
-}
-int cm3_particle_rollout_chains_f64(const cm3_particle_desc *d, const cm3_particle_traj *t, int32_t n, int32_t n_chains,
-                                    void *const *streams) {
-  return cm3::particle_rollout_chains<double>(d, t, n, n_chains, streams);
 }
 #endif
 }

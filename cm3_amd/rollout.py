@@ -16,6 +16,7 @@ alg_credit.process_batch (alg_credit.py:458-470) / alg_credit_checkers.process_b
 (alg_credit_checkers.py:427-444), and ``as_reference_rows`` rebuilds the reference's object rows so
 the real ``process_batch`` consumes them unchanged.
 """
+import collections
 import ctypes
 
 import numpy as np
@@ -82,6 +83,9 @@ def _copy_pairs(pairs, stream):
                 d.copy_(s_)
 
 
+_Mode = collections.namedtuple("_Mode", "kind live sparse")
+
+
 class _ActorGraphCache(object):
     """One captured (actor launch, step launch) x T graph per rollout object.  The key is the policy OBJECT (a strong
     reference: `id()` of a collected actor can be reused); epsilon is not part of it -- the actor launches read it from
@@ -119,7 +123,7 @@ class ParticleRollout(object):
         next-state/obs are captured per tick, goals are recorded per slot; every transition is valid.
     """
 
-    def __init__(self, env, n_ticks=None, use_graph=True, fused=False, n_chains=1, record_collisions=True,
+    def __init__(self, env, n_ticks=None, use_graph=True, fused=False, record_collisions=True,
                  fused_policy_tick=False, live_state=None, policy_mode="auto", sparse_goals=None):
         self.env = env
         self.T = int(n_ticks or env.max_steps)
@@ -135,15 +139,11 @@ class ParticleRollout(object):
         #   "episode"  the whole policy-driven episode in ONE launch (csrc/policy.hip) -- the fastest (C2: 5.6 vs 10.6 us per tick);
         #   "tick"     an actor launch and a step launch per tick inside one hipGraph;
         #   "auto"     (default, round 3) "episode" whenever the fused kernel applies -- n_agents in {1, 2, 4, 8}, float32 env,
-        #              actor.seed == env.seed (one Philox key), one chain -- else "tick".  fused=True / fused_policy_tick=True
+        #              actor.seed == env.seed (one Philox key) -- else "tick".  fused=True / fused_policy_tick=True
         #              still force their modes.
         if policy_mode not in ("auto", "episode", "tick"):
             raise Cm3Error("policy_mode must be 'auto', 'episode' or 'tick'")
         self.policy_mode = policy_mode
-        # n_chains > 1: the random-action branch advances n_chains independent sub-batches of envs on their own
-        # streams (parallel branches of the captured hipGraph).  Identical trajectories (cm3_particle_rollout_chains_*),
-        # but MEASURED 1.2-5x SLOWER than one chain on MI355X in every form tried (profiles/r02_chains_diag.txt): the
-        # option exists for reproducing that result, not as an optimisation.
         # live_state: None = by size (see collect); True / False force stepping in place on the env's buffers with slot copies /
         # chaining the ticks through the slots.  Identical trajectories either way (tests/test_gpu_rollout.py).
         self.live_state = live_state
@@ -153,14 +153,10 @@ class ParticleRollout(object):
         # force it.  `goals` (and as_reference_batch) look the same either way: the dense array is filled in on first access.
         self.sparse_goals = sparse_goals
         self._goals_sparse = False
-        self._graph_mode = None          # (live, sparse) the captured graphs were built with
+        self._graph_mode = None          # the _Mode the captured graphs were built with (+ the env's buffer parity when live)
         self.n_captures = 0              # hipGraph captures of the random-action collection so far (tests)
         self._goal_src = None
         self._goal_src32 = self._goal_src32_of = None
-        self.n_chains = int(n_chains)
-        if not (1 <= self.n_chains <= 16):
-            raise Cm3Error("n_chains must be in 1..16")
-        self._chain_streams = [torch.cuda.Stream(device=env.device) for _ in range(self.n_chains - 1)]
         E, N, L, T, dev, dt = env.E, env.n, env.L, self.T, env.device, env.dtype
         z = lambda *s, d=dt: torch.zeros(*s, dtype=d, device=dev)  # noqa: E731
         self.state = z(T + 1, N, E, 4)
@@ -245,18 +241,13 @@ class ParticleRollout(object):
             t.collisions_stride = E * 4
         return t
 
-    def _enqueue(self, t0, n, flags, stream=None, chains=False, live=False, sparse_goals=False):
+    def _enqueue(self, t0, n, flags, stream=None, live=False, sparse_goals=False):
         env = self.env
         env._desc.flags = flags
         traj = self._traj(t0, live, sparse_goals)
         stream = env._stream() if stream is None else stream
-        if chains and self.n_chains > 1:
-            fn = getattr(self._lib, "cm3_particle_rollout_chains_" + env._suffix)
-            streams = (ctypes.c_void_p * self.n_chains)(stream, *[s.cuda_stream for s in self._chain_streams])
-            _lib.check(fn(ctypes.byref(env._desc), ctypes.byref(traj), int(n), self.n_chains, streams))
-        else:
-            fn = getattr(self._lib, "cm3_particle_rollout_" + env._suffix)
-            _lib.check(fn(ctypes.byref(env._desc), ctypes.byref(traj), int(n), stream))
+        fn = getattr(self._lib, "cm3_particle_rollout_" + env._suffix)
+        _lib.check(fn(ctypes.byref(env._desc), ctypes.byref(traj), int(n), stream))
 
     def _enqueue_tick0_from_env(self, flags, stream):
         """Tick 0 as a plain step launch that READS the env's own state / goals buffers (not slot 0) and writes slot 1 and the
@@ -326,6 +317,49 @@ class ParticleRollout(object):
             _lib.check(self._lib.cm3_policy_rollout_f32(ctypes.byref(env._desc), ctypes.byref(traj), ctypes.byref(ad),
                                                         ctypes.byref(actor._wt), None, 0, 1, stream))
 
+    def _mode(self, policy):
+        """How this collect() launches -- the one place that decides it.  -> _Mode(kind, live, sparse):
+          kind    random_fused | random            the reference's random-action branch, all ticks in one launch / a launch per tick
+                  policy_episode                   on-device actor, the whole episode in ONE launch (csrc/policy.hip)
+                  policy_fused_tick | policy_tick  on-device actor, one fused launch / an actor + a step launch per tick
+                  host_policy                      a Python callable per tick
+          live    per-tick step launches step IN PLACE on the env's buffers and copy every tick's state to its slot -- only while a
+                  tick's state is small (<= 1 MiB: the slot copy is extra write traffic, the gain is load latency: C2 2.87 -> 2.74 us)
+                  and the trajectory is streaming-size (>= 128 MB of observation slots: a small trajectory collected over and over stays
+                  cache-resident and the copies only cost); measured in profiles/r02_trajectory_gap_live_state.txt,
+                  r03_live_state_crossover.txt.  live_state = True / False forces it.
+          sparse  goal slots are written only where an env restarts: always with live state (the goals live in place), and for the
+                  random-action branch at streaming sizes (sparse_goals = True / False forces that)."""
+        env = self.env
+        dev_policy = policy is not None and hasattr(policy, "enqueue") and hasattr(policy, "act")
+        if dev_policy and env.dtype != torch.float32:
+            raise Cm3Error("the device actor reads float32 env buffers")
+        same_key = dev_policy and getattr(policy, "seed", None) == env.seed
+        if policy is None:
+            kind = "random_fused" if self.fused else "random"
+        elif not dev_policy:
+            kind = "host_policy"
+        else:
+            episode_ok = env.n in (1, 2, 4, 8) and same_key and not self.fused_policy_tick
+            if self.fused or (self.policy_mode in ("auto", "episode") and episode_ok):
+                kind = "policy_episode"
+            elif self.policy_mode == "episode":
+                raise Cm3Error("policy_mode='episode' needs n_agents in {1, 2, 4, 8} and actor.seed == env.seed")
+            else:
+                kind = "policy_fused_tick" if self.fused_policy_tick else "policy_tick"
+            if kind in ("policy_episode", "policy_fused_tick") and not same_key:
+                raise Cm3Error("fused policy launches need actor.seed == env.seed (one Philox key)")
+        es = self.state.element_size()
+        stream_size = env.E * env.n * env.L * es * self.T >= (128 << 20)
+        small = env.n * env.E * 4 * es <= (1 << 20) and stream_size
+        if self.live_state is not None:
+            small = bool(self.live_state)
+        per_tick_steps = kind in ("random", "policy_tick", "host_policy") and not self.fused
+        live = bool(self._goals_buf is not None and small and per_tick_steps)
+        sparse = bool(self._goals_buf is not None and kind != "random_fused" and (
+            live or (kind == "random" and bool(stream_size if self.sparse_goals is None else self.sparse_goals))))
+        return _Mode(kind, live, sparse)
+
     def collect(self, policy=None, reset=None, epsilon=0.0):
         """Runs T ticks.  policy None = the reference's random-action branch (train_onpolicy.py:305-307,
         drawn in-kernel; the whole rollout is one hipGraph replay); otherwise ``policy(obs_others [E,N,L],
@@ -341,91 +375,53 @@ class ParticleRollout(object):
         self._finished0 = None if self.auto_reset else self._finished.clone()
         self._load_slot0()
         base = (FLAG_AUTO_RESET if self.auto_reset else 0) | env.kernel_flags
-        # per-tick step launches of a slot trajectory step in place on the env's live buffers (see _traj); the launches that
-        # keep the state in registers (fused) or read the slots themselves (fused policy kernels) do not
-        # -- and only while a tick's state is small: the slot copy is extra write traffic, the gain is load latency.  Measured
-        # (tools/trajectory_gap.py, profiles/r02_trajectory_gap_live_state.txt): below ~1 MiB of state per tick live wins by
-        # 4-14 % (C2: 2.87 -> 2.74 us), from there on chaining the ticks through the slots is as fast or faster (C5: 5.53 vs 5.74).
-        # Round 3 (write-through slot copies; profiles/r03_live_state_crossover.txt): live now also wins AT 1 MiB -- C5 5.20 -> 5.06,
-        # N = 4 at 16 384 envs 3.86 -> 3.70 -- ties at 2-4 MiB and loses from 16 MiB on, so the bound is inclusive.  (Marked two-stamp
-        # build at C5: a tick that loads slot t waits 2311 cycles for its state, one that steps in place 1121.)
-        # ... and only for a streaming-size trajectory (the library's criterion for non-temporal observation stores: >= 128 MB of
-        # observation slots): a small trajectory that is collected over and over (C4: 26 MB) stays cache-resident, its slots are
-        # not "fresh", and the copies only cost (3.63 -> 3.70 us per tick at C4)
-        es = self.state.element_size()
-        small = env.n * env.E * 4 * es <= (1 << 20) and env.E * env.n * env.L * es * self.T >= (128 << 20)
-        if self.live_state is not None:
-            small = bool(self.live_state)
-        dev_policy = policy is not None and hasattr(policy, "enqueue") and hasattr(policy, "act")
-        policy_episode = dev_policy and (self.fused or (self.policy_mode in ("auto", "episode") and env.n in (1, 2, 4, 8)
-                                                        and getattr(policy, "seed", None) == env.seed and self.n_chains == 1
-                                                        and not self.fused_policy_tick))
-        live = self._live = (self._goals_buf is not None and small and not self.fused and not policy_episode
-                             and not (self.fused_policy_tick and policy is not None))
-        # sparse goal slots: the random-action branch, one launch per tick, slot-chained, at streaming sizes (or when forced)
-        stream_size = env.E * env.n * env.L * es * self.T >= (128 << 20)
-        #   ... and ALWAYS with the live-state rollout, whoever acts: its goals live in place (ABI 5: the kernels write a goals slot
-        #   only where an env restarts; a device actor reads the live goals array, see _enqueue_actor_rollout)
-        sparse = self._goals_buf is not None and not self.fused and (
-            live or (policy is None and self.n_chains == 1 and bool(stream_size if self.sparse_goals is None else self.sparse_goals)))
-        # the mode the captured graphs were built with is a field of its own: `_goals_sparse` only says whether the goal slots of
-        # the LAST collection still need completing (the `goals` getter clears it), it is not the graphs' key
-        if self._graph_mode is not None and self._graph_mode != (live, sparse):
+        mode = self._mode(policy)
+        live, sparse = mode.live, mode.sparse
+        self._live = live
+        # ONE key for every captured graph of this object: the mode, plus the env's buffer parity where the launches hold the
+        # addresses of the env's current buffers (live state; env.step() flips them)
+        key = (mode, env._cur if live else None)
+        if self._graph_mode is not None and self._graph_mode != key:
             self._drop_graphs()
-        self._graph_mode = (live, sparse)
-        self._goals_sparse, self._goal_src = sparse, None
-        if self._live_cur != env._cur:    # captured graphs may hold the address of the env's current buffers (env.step() flips them)
-            if live:
-                self._drop_graphs()
-            else:
-                self._drop_norm_graph()   # (collect()'s own non-live graphs touch trajectory slots and un-flipped buffers only)
+        self._graph_mode = key
+        if self._live_cur != env._cur:
+            self._drop_norm_graph()       # (collect_normalized's graph reads the env's current buffers in every mode)
             self._live_cur = env._cur
-        if policy is None:
+        # `_goals_sparse` only says whether the goal slots of the LAST collection still need completing (the `goals` getter clears it)
+        self._goals_sparse, self._goal_src = sparse, None
+        stream = env._stream()
+        if mode.kind == "random_fused":
+            self._enqueue(0, self.T, base | FLAG_GEN_ACTIONS | _lib.FLAG_FUSED_TICKS)
+        elif mode.kind == "random":
             flags = base | FLAG_GEN_ACTIONS
-            if self.fused:
-                self._enqueue(0, self.T, flags | _lib.FLAG_FUSED_TICKS, chains=True)
-            elif self.use_graph:
+            if self.use_graph:
                 if self._graph is None:
                     self.n_captures += 1
-                    self._graph = _lib.capture_graph(env.device, lambda s: self._enqueue(0, self.T, flags, s, chains=True, live=live,
-                                                                                         sparse_goals=sparse))
-                _lib.check(self._lib.cm3_graph_launch(self._graph, env._stream()))
+                    self._graph = _lib.capture_graph(env.device, lambda s: self._enqueue(0, self.T, flags, s, live=live, sparse_goals=sparse))
+                _lib.check(self._lib.cm3_graph_launch(self._graph, stream))
             else:
-                self._enqueue(0, self.T, flags, chains=True, live=live, sparse_goals=sparse)
-        elif hasattr(policy, "enqueue") and hasattr(policy, "act"):      # on-device actor (cm3_amd.actor)
-            if env.dtype != torch.float32:
-                raise Cm3Error("the device actor reads float32 env buffers")
-            episode_ok = (env.n in (1, 2, 4, 8) and getattr(policy, "seed", None) == env.seed and self.n_chains == 1
-                          and not self.fused_policy_tick)
-            if self.policy_mode == "episode" and not episode_ok and not self.fused:
-                raise Cm3Error("policy_mode='episode' needs n_agents in {1, 2, 4, 8} and actor.seed == env.seed")
-            whole_episode = self.fused or (self.policy_mode in ("auto", "episode") and episode_ok)
-            if whole_episode:
-                # the whole policy-driven episode in ONE launch (csrc/policy.hip): weights, observation tile and env
-                # state stay in LDS / registers for all T ticks; bit-identical to alternating actor / step launches
-                if policy.seed != env.seed:
-                    raise Cm3Error("fused policy rollouts need actor.seed == env.seed (one Philox key)")
-                env._desc.flags = base & FLAG_AUTO_RESET
-                traj = self._traj(0)
-                ad = policy._desc(env.E, epsilon, env.env_id_base)
-                _lib.check(self._lib.cm3_policy_rollout_f32(ctypes.byref(env._desc), ctypes.byref(traj), ctypes.byref(ad),
-                                                            ctypes.byref(policy._wt), None, 0, self.T, env._stream()))
-            elif self.fused_policy_tick:
-                if policy.seed != env.seed:
-                    raise Cm3Error("fused policy launches need actor.seed == env.seed (one Philox key)")
-                if self.use_graph:      # epsilon is a by-value argument of these launches: part of the graph's key
-                    self._actor_graph.launch(self._lib, policy, epsilon,
-                                             lambda s: self._enqueue_fused_policy_ticks(policy, epsilon, base, s),
-                                             env._stream(), key=("fused_tick", float(epsilon)))
-                else:
-                    self._enqueue_fused_policy_ticks(policy, epsilon, base, env._stream())
-            elif self.use_graph:
+                self._enqueue(0, self.T, flags, live=live, sparse_goals=sparse)
+        elif mode.kind == "policy_episode":
+            # the whole policy-driven episode in ONE launch (csrc/policy.hip): weights, observation tile and env state stay in
+            # LDS / registers for all T ticks; bit-identical to alternating actor / step launches
+            env._desc.flags = base & FLAG_AUTO_RESET
+            traj = self._traj(0)
+            ad = policy._desc(env.E, epsilon, env.env_id_base)
+            _lib.check(self._lib.cm3_policy_rollout_f32(ctypes.byref(env._desc), ctypes.byref(traj), ctypes.byref(ad),
+                                                        ctypes.byref(policy._wt), None, 0, self.T, stream))
+        elif mode.kind == "policy_fused_tick":
+            if self.use_graph:      # epsilon is a by-value argument of these launches: part of the graph's key
+                self._actor_graph.launch(self._lib, policy, epsilon, lambda s: self._enqueue_fused_policy_ticks(policy, epsilon, base, s),
+                                         stream, key=("fused_tick", float(epsilon)))
+            else:
+                self._enqueue_fused_policy_ticks(policy, epsilon, base, stream)
+        elif mode.kind == "policy_tick":
+            if self.use_graph:
                 cache = self._actor_graph
-                cache.launch(self._lib, policy, epsilon,
-                             lambda s: self._enqueue_actor_rollout(policy, cache.eps, base, s), env._stream())
+                cache.launch(self._lib, policy, epsilon, lambda s: self._enqueue_actor_rollout(policy, cache.eps, base, s), stream)
             else:
-                self._enqueue_actor_rollout(policy, epsilon, base, env._stream())
-        else:
+                self._enqueue_actor_rollout(policy, epsilon, base, stream)
+        else:                       # a host policy: one call and one step launch per tick
             for t in range(self.T):
                 goals = (self._goals_buf[t] if (self._goals_buf is not None and not live) else env._goals).permute(1, 0, 2)
                 a = policy(self.obs_others[t], self.state[t].permute(1, 0, 2), goals)
@@ -454,7 +450,7 @@ class ParticleRollout(object):
         from .shard import ReturnsNormalizer, gather_moments
         import torch.distributed as dist
         env = self.env
-        if not self.auto_reset or self.fused or self.n_chains != 1:
+        if not self.auto_reset or self.fused:
             raise Cm3Error("collect_normalized runs the continuous, one-launch-per-tick random-action collection")
         world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         key = (float(gamma), float(eps), bool(normalize), world > 1, int(segments))

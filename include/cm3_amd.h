@@ -46,7 +46,9 @@
 extern "C" {
 #endif
 
-#define CM3_ABI_VERSION 7   /* 7 (round 6): cm3_policy_rollout_checkers; cm3_actor_checkers_packed_bytes grew by the others-branch table; the
+#define CM3_ABI_VERSION 7   /* 7 (round 6): REMOVED cm3_particle_rollout_chains_f32 / _f64 (sub-batch chains on several streams: a tested,
+                               measured regression since round 2 -- profiles/r02_chains_diag.txt; tools/chains_diag.py reproduces it
+                               with desc->env_offset / env_count).  ADDED cm3_td_target_f64, cm3_policy_rollout_checkers; cm3_actor_checkers_packed_bytes grew by the others-branch table; the
                                precision-2 Checkers actor adds branch_others W_others_h2 to h2's accumulators BEFORE branch_self
                                W_self_h2 (probabilities move in the last bits).
                                6: cm3_policy_force_row_tiles, cm3_rows_scatter / cm3_rows_gather / cm3_rows_tile / cm3_transitions_gather_f32 (round 5).
@@ -202,16 +204,6 @@ int cm3_particle_rollout_f32(const cm3_particle_desc *desc, const cm3_particle_t
 int cm3_particle_rollout_f64(const cm3_particle_desc *desc, const cm3_particle_traj *traj, int32_t n_ticks,
                              void *stream);
 
-/* The same collection as n_chains INDEPENDENT sub-batch chains (envs never interact, environment.py:81-123 touches one
- * env): chain c = a contiguous block of envs, its n_ticks step launches go to streams[c].  streams[1..] are forked from
- * and joined back into streams[0] with events, so the call is ordered like one launch sequence on streams[0] -- eagerly,
- * or as parallel branches when streams[0] is being captured into a hipGraph (cm3_graph_begin).  The dependent-launch
- * boundary of one chain then overlaps the kernels of the others.  Every launch is still one tick of its envs; results are
- * bit-identical for every n_chains (1..16; desc->env_offset / env_count must be 0). */
-int cm3_particle_rollout_chains_f32(const cm3_particle_desc *desc, const cm3_particle_traj *traj, int32_t n_ticks,
-                                    int32_t n_chains, void *const *streams);
-int cm3_particle_rollout_chains_f64(const cm3_particle_desc *desc, const cm3_particle_traj *traj, int32_t n_ticks,
-                                    int32_t n_chains, void *const *streams);
 
 /* ------------------------------------------------------------------------------------------
  * Checkers env (env/checkers.py).  Compact live state, reference-shaped outputs.

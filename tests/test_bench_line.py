@@ -69,7 +69,7 @@ def _eight_rank_record(kind, cfg_name, E, with_everything=False):
     bps = bench.CHECKERS_BYTES_PER_ENV_STEP if kind == "checkers" else bench.algorithmic_bytes_per_env_step(N)
     out = bench.headline_record(world=world, steps=steps, warm=5, K=K, ticks_per_step=tps, wall_max=max(w for w, _ in per_rank),
                                 ev_max=max(e for _, e in per_rank), per_rank=per_rank, E=E, N=N, kind=kind, mode="trajectory",
-                                n_chains=1, fused_ticks=1, launches_per_tick=1, bytes_per_env_step=bps, dtype_name="f32",
+                                fused_ticks=1, launches_per_tick=1, bytes_per_env_step=bps, dtype_name="f32",
                                 wl_desc=bench.WORKLOADS["c2"][3], no_graph=False, pinned="0000:05:00.0: NUMA node 0, 96 CPUs",
                                 live_state=True, rccl=rccl)
     if kind == "particle_adv":

@@ -1,6 +1,6 @@
 """GPU: round-2 additions of the collection loop (train_onpolicy.py:281-377).
 
-* independent sub-batch chains produce bit-identical trajectories;
+* rollouts over sub-batches of the envs (env_offset / env_count) produce the whole batch's trajectory;
 * env.step() keeps the reference's counters (they go on counting if an env is stepped after `done`), and the COLLECTOR reads
   scenario.collisions of each episode from the per-tick trajectory slot at the tick that ends it (train_onpolicy.py:302, :356);
   the continuous mode captures that count before the same-launch reset zeroes it;
@@ -31,23 +31,37 @@ TRAJ = ("state", "obs_others", "actions", "reward", "reward_n", "done", "goals",
 
 @pytest.mark.parametrize("kernel,N,cfg", [("pair", 4, "particle_stage2_cross.json"), ("env", 4, "particle_stage2_cross.json"),
                                           ("agent", 8, "particle_merge8.json"), ("auto", 2, "particle_stage2_merge.json")])
-@pytest.mark.parametrize("mode", ["eager", "graph", "fused"])
-def test_chains_equal_single_chain(kernel, N, cfg, mode):
-    """cm3_particle_rollout_chains_*: K sub-batches of envs on K streams (parallel branches when captured) leave exactly
-    the trajectory, terminal captures and live counters of the single launch sequence."""
+@pytest.mark.parametrize("mode", ["eager", "fused"])
+def test_sub_batch_launches_equal_the_whole_batch(kernel, N, cfg, mode):
+    """cm3_particle_desc.env_offset / env_count: three rollouts over sub-batches of the envs (the last one ragged) leave exactly the
+    trajectory, terminal captures and live counters of one rollout over the whole batch -- envs never interact and every RNG draw
+    is keyed by the global env id.  (Until ABI 7 cm3_particle_rollout_chains_* ran such sub-batches on several streams; that
+    entry point was a measured regression and is gone, tools/chains_diag.py reproduces it with these two fields.)"""
+    from cm3_amd import _lib
     from cm3_amd.rollout import ParticleRollout
-    E, T = 1000, 25                                  # 1000 envs: the last chain is ragged
+    E, T = 1000, 25
     outs = []
-    for chains in (1, 3):
+    for parts in (1, 3):
         env = _penv(E, N, cfg=cfg, seed=21, auto_reset=True, max_steps=9, kernel=kernel)
         env.reset()
-        ro = ParticleRollout(env, n_ticks=T, use_graph=(mode == "graph"), fused=(mode == "fused"), n_chains=chains)
-        ro.collect(reset=False)
-        ro.collect(reset=False)                      # second phase: graph replay / continued episodes
+        ro = ParticleRollout(env, n_ticks=T, use_graph=False, fused=(mode == "fused"), live_state=False, sparse_goals=False)
+        chunk = ((E + parts - 1) // parts + 255) // 256 * 256          # whole workgroups per sub-batch
+        for _ in range(2):                                             # second phase: continued episodes
+            ro._load_slot0()
+            flags = _lib.FLAG_AUTO_RESET | _lib.FLAG_GEN_ACTIONS | env.kernel_flags | (_lib.FLAG_FUSED_TICKS if mode == "fused" else 0)
+            for c in range(parts):
+                lo = c * chunk
+                if lo >= E:
+                    break
+                if parts > 1:
+                    env._desc.env_offset, env._desc.env_count = lo, min(chunk, E - lo)
+                ro._enqueue(0, T, flags)
+                env._desc.env_offset, env._desc.env_count = 0, 0
+            ro._store_back(False)
         torch.cuda.synchronize()
         outs.append((ro, env))
     a, b = outs[0][0], outs[1][0]
-    for name in TRAJ:
+    for name in ("state", "obs_others", "actions", "reward", "reward_n", "done", "_goals_buf", "collisions"):
         assert torch.equal(getattr(a, name), getattr(b, name)), name
     d = a.done.bool()
     assert int(d.sum()) > 0
@@ -58,23 +72,6 @@ def test_chains_equal_single_chain(kernel, N, cfg, mode):
     assert torch.equal(ea.global_state, eb.global_state)
     for ro, _ in outs:
         ro.close()
-
-
-def test_chains_in_place_equal_stepwise():
-    """bench.py's in-place stepper with 4 chains == 1 chain (zero strides, hipGraph replays)."""
-    from bench import ParticleStepper
-    cfg = load_cfg("particle_stage2_antipodal.json")
-    a = ParticleStepper(cfg, 4, 4096, "cuda:0", seed=7, n_chains=1)
-    b = ParticleStepper(cfg, 4, 4096, "cuda:0", seed=7, n_chains=4)
-    for st in (a, b):
-        st.capture(33)
-        st.run(99 + 5)
-    torch.cuda.synchronize()
-    assert torch.equal(a.env._state[0], b.env._state[0]) and torch.equal(a.env._obs_others[0], b.env._obs_others[0])
-    assert torch.equal(a.env._meta, b.env._meta) and torch.equal(a.env._episode, b.env._episode)
-    assert torch.equal(a.env._actions[0], b.env._actions[0]) and torch.equal(a.env._reward[0], b.env._reward[0])
-    a.close()
-    b.close()
 
 
 def _two_agent_cfg(gap):
