@@ -105,8 +105,10 @@ class DeviceReplayBuffer(object):
                              v_global_next=nst, obs_others_next=z(N, L), v_local_next=nst, done=z(dt=torch.bool), goals=z(N, 2))
         elif self.cols["v_global"].data_ptr() != self.cols["v_local"].data_ptr():
             return self.add(rollout.as_reference_batch(numpy=False))      # (a ring that add() allocated: separate v_local storage)
-        skip, start, kept = self.ring.plan_add(B)
-        rollout.export_into(self.cols, start, self.maxsize)
+        # (validate and launch FIRST, advance the ring after: an export that raises must not leave idx / len pointing at rows that
+        # were never written -- ADVICE r5)
+        rollout.export_into(self.cols, self.ring.idx, self.maxsize)
+        self.ring.plan_add(B)
 
     def add_at(self, cols, dst_row, n_added):
         """Rows b with dst_row[b] >= 0 go to ring position dst_row[b] (int64 on the device; computed by the caller, e.g. the dual
@@ -126,12 +128,15 @@ class DeviceReplayBuffer(object):
         return out
 
     def all(self):
-        """Everything stored, in storage order (views of the ring: no copy)."""
+        """Everything stored, in storage order: VIEWS of the ring (no copy; the next add() overwrites them in place -- internal use,
+        sample_batch() copies)."""
         return {k: v[:self.len] for k, v in self.cols.items()}
 
     def sample_batch(self, size, generator=None):
         if self.len <= size:
-            return self.all()
+            # a COPY (ADVICE r5): all() hands out views of the ring, which the next add() overwrites in place -- the reference's
+            # np.array(self.memory) is a copy, and a learner may still hold the batch when the next chunk is added
+            return {k: v.clone() for k, v in self.all().items()}
         return self.sample_n(size, generator)
 
     def sample_n(self, n, generator=None):
@@ -180,6 +185,9 @@ class DeviceDualReplayBuffer(object):
         k1, all1, k2, all2 = dual_take(n1, n2, size)
         a = (self.mem1.all() if all1 else self.mem1.sample_n(k1, generator)) if n1 and k1 else None
         b = (self.mem2.all() if all2 else self.mem2.sample_n(k2, generator)) if n2 and k2 else None
+        if a is None or b is None:          # (_cat would hand out the one side as is: ring views when it is "everything")
+            one = a if b is None else b
+            return None if one is None else {k: v.clone() for k, v in one.items()}
         return _cat(a, b)
 
 
@@ -191,14 +199,40 @@ def off_policy_batches(rollout, buffer, n_chunks, batch_size=128, generator=None
     (DeviceReplayBuffer: ONE launch) and one batch is sampled -- yielded as device columns; `collect_kwargs` go to
     rollout.collect() (policy=..., epsilon=..., goals=... for Checkers).  The buffer outlives the chunks: old transitions are
     overwritten only when it is full (replay_buffer.py:11-16)."""
+    dual = isinstance(buffer, DeviceDualReplayBuffer)
+    if dual and not hasattr(rollout, "episode_is_bad"):
+        raise Cm3Error("a dual replay buffer splits by the episodes' flag (scenario.collisions != 0, train_onpolicy.py:356): that is a "
+                       "ParticleRollout's; use a DeviceReplayBuffer here")
     for _ in range(int(n_chunks)):
         rollout.collect(**collect_kwargs)
-        if hasattr(rollout, "export_into") and rollout.auto_reset and rollout.state.dtype == torch.float32 and hasattr(buffer, "add_rollout"):
+        if dual:
+            # every transition carries the flag of the episode it belongs to: the flag is known at the tick that ENDS the episode
+            # (ParticleRollout.episode_is_bad); transitions of episodes still running at the chunk's end take the flag so far
+            cols = rollout.as_reference_batch(numpy=False)
+            buffer.add({k: v.contiguous() for k, v in cols.items()}, _transition_flags(rollout))
+        elif hasattr(rollout, "export_into") and rollout.auto_reset and rollout.state.dtype == torch.float32 and hasattr(buffer, "add_rollout"):
             buffer.add_rollout(rollout)                                   # export + add in one launch
         else:
             cols = rollout.as_reference_batch(numpy=False)
             buffer.add({k: v.contiguous() for k, v in cols.items()})
         yield buffer.sample_batch(batch_size, generator=generator)
+
+
+def _transition_flags(rollout):
+    """bool [T * E] in the order of as_reference_batch() of a continuous collection (time-major): transition (t, e) is "bad" when the
+    episode it belongs to has collided by its end inside this chunk -- or by the chunk's last tick, for an episode that runs on."""
+    coll = rollout.collisions                       # int32 [T, E]: scenario.collisions after every tick (before a same-launch reset)
+    if coll is None:
+        raise Cm3Error("the dual buffer's flag needs the per-tick collision counts (record_collisions=True)")
+    done = rollout.done.bool()
+    T = coll.shape[0]
+    bad_at_end = (coll != 0)
+    flag = torch.empty_like(done)
+    run = bad_at_end[T - 1].clone()                 # episodes still running at the end of the chunk: their count so far
+    for t in range(T - 1, -1, -1):
+        run = torch.where(done[t], bad_at_end[t], run)
+        flag[t] = run
+    return flag.reshape(-1)
 
 
 class CsvLog(object):

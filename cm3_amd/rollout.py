@@ -671,8 +671,13 @@ class ParticleRollout(object):
                             ("reward_n", "reward_local"), ("next_state", "v_global_next"), ("next_obs_others", "obs_others_next"),
                             ("done", "done"), ("goals", "goals")):
             t = columns[name]
-            if not t.is_contiguous() or t.shape[0] != ring_size:
-                raise Cm3Error("export_into: column %s must be contiguous with ring_size rows" % name)
+            want_dt = {"actions": torch.int32, "done": (torch.bool, torch.uint8)}.get(name, torch.float32)
+            want_tail = {"v_global": (env.n, 4), "v_global_next": (env.n, 4), "obs_others": (env.n, env.L), "obs_others_next": (env.n, env.L),
+                         "actions": (env.n,), "reward": (), "reward_local": (env.n,), "done": (), "goals": (env.n, 2)}[name]
+            if (not t.is_contiguous() or t.shape[0] != ring_size or tuple(t.shape[1:]) != want_tail
+                    or (t.dtype not in want_dt if isinstance(want_dt, tuple) else t.dtype != want_dt) or not t.is_cuda):
+                raise Cm3Error("export_into: column %s must be a contiguous device tensor [%d%s] of %s (a wrong layout would be an "
+                               "out-of-bounds device write)" % (name, ring_size, "".join(", %d" % d for d in want_tail), want_dt))
             setattr(out, field, t.data_ptr())
         out.ring_start, out.ring_size = int(ring_start), int(ring_size)
         _lib.check(self._lib.cm3_transitions_gather_f32(ctypes.byref(env._desc), ctypes.byref(traj), _lib.ptr(goal_slot), gs_stride,

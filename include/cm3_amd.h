@@ -311,6 +311,10 @@ int cm3_checkers_rollout(const cm3_checkers_desc *desc, const cm3_checkers_traj 
  * action_block(seed, global env id, 0) of csrc/philox.h.  Once per env object (ABI 6; since round 5 the Checkers kernels draw with
  * the particle kernels' two-stage stream: action = rand5(fmix32((word ^ step) + episode * 0x9E3779B1))). */
 int cm3_checkers_action_blocks(const cm3_checkers_desc *desc, uint32_t *out, void *stream);
+/* SCOPE of that table: it holds Philox call 0 = the words of agents 0..3; with 5..8 agents the second block (agents
+ * 4..7) is still computed in every step launch, so the round-5 gain applies to n_agents <= 4.  The table is a function of
+ * (desc->seed, desc->env_id_base, n_envs): REBUILD it whenever one of them changes -- a step launch cannot check, a stale table
+ * silently draws another action stream (cm3_amd.checkers.VecCheckersEnv builds it once per env object, whose seed and base are fixed). */
 /* Replaces Checkers.step (checkers.py:228-262): agents act sequentially in index order inside one lane. */
 int cm3_checkers_step(const cm3_checkers_desc *desc, const cm3_checkers_bufs *bufs, void *stream);
 /* Replaces Checkers.reset (checkers.py:265-291) for the envs selected by mask (NULL = all). */

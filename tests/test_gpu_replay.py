@@ -375,3 +375,64 @@ def test_row_kernels_against_torch_indexing_on_random_layouts():
     # argument checks
     rc = _lib.RowCols()
     assert _lib.lib().cm3_rows_gather(ctypes.byref(rc), 4, None, stream) != 0
+
+
+def _env(E, n=4, cfg="particle_stage2_cross.json", **kw):
+    from cm3_amd.particle import VecParticleEnv
+    return VecParticleEnv(load_cfg(cfg), n, 0.2, 33, E, device=DEV, dtype=torch.float32, auto_reset=True, seed=11, **kw)
+
+
+def test_sample_batch_of_a_small_buffer_is_a_copy_and_export_checks_its_columns():
+    """sample_batch() with len <= size used to hand out VIEWS of the ring, which the next add() overwrites in place (the
+    reference's np.array(self.memory) is a copy); add_rollout advanced the ring before an export that could raise; export_into
+    checked neither dtype nor trailing shape of caller-supplied columns."""
+    from cm3_amd import Cm3Error
+    from cm3_amd.replay import DeviceReplayBuffer
+    from cm3_amd.rollout import ParticleRollout
+    dev = "cuda:0"
+    buf = DeviceReplayBuffer(size=64, device=dev)
+    a = {"x": torch.arange(10, dtype=torch.float32, device=dev).reshape(10, 1), "y": torch.arange(10, dtype=torch.int32, device=dev)}
+    buf.add(a)
+    got = buf.sample_batch(32)
+    keep = {k: v.clone() for k, v in got.items()}
+    buf.add({"x": torch.full((60, 1), -1.0, device=dev), "y": torch.full((60,), -1, dtype=torch.int32, device=dev)})   # wraps: overwrites rows 0..5
+    assert all(torch.equal(got[k], keep[k]) for k in got)
+    # export_into: a wrong layout is refused before any launch, and the ring does not move
+    env = _env(64)
+    env.reset()
+    ro = ParticleRollout(env, n_ticks=5, use_graph=False).collect()
+    rb = DeviceReplayBuffer(size=5 * 64 * 2, device=dev)
+    rb.add_rollout(ro)
+    idx, ln = rb.idx, rb.len
+    rb.cols["actions"] = rb.cols["actions"].to(torch.int64)             # a ring with a wrong column dtype
+    with pytest.raises(Cm3Error):
+        rb.add_rollout(ro)
+    assert (rb.idx, rb.len) == (idx, ln)
+    ro.close()
+
+
+def test_off_policy_cadence_with_the_dual_buffer():
+    """off_policy_batches with a DeviceDualReplayBuffer fell through to buffer.add(cols) without the flag and raised
+    TypeError.  Now every transition carries the flag of its episode (scenario.collisions != 0 at the tick that ends it,
+    train_onpolicy.py:356): checked against a host recomputation, and the two memories hold exactly the bad / good transitions."""
+    import numpy as np
+    from cm3_amd.replay import DeviceDualReplayBuffer, _transition_flags, off_policy_batches
+    from cm3_amd.rollout import ParticleRollout
+    env = _env(128)
+    env.reset()
+    ro = ParticleRollout(env, n_ticks=40, use_graph=False)
+    dual = DeviceDualReplayBuffer(size=40 * 128 * 4, device="cuda:0")
+    batches = list(off_policy_batches(ro, dual, 2, batch_size=64, generator=torch.Generator(device="cuda:0").manual_seed(0)))
+    assert len(batches) == 2 and all(b["reward"].shape[0] == 64 for b in batches)
+    flag = _transition_flags(ro).reshape(40, 128).cpu().numpy()
+    coll, done = ro.collisions.cpu().numpy(), ro.done.bool().cpu().numpy()
+    want = np.zeros((40, 128), bool)
+    for e in range(128):
+        cur = coll[39, e] != 0
+        for t in range(39, -1, -1):
+            if done[t, e]:
+                cur = coll[t, e] != 0
+            want[t, e] = cur
+    assert np.array_equal(flag, want) and want.any() and (~want).any()
+    assert len(dual.mem1) + len(dual.mem2) == 2 * 40 * 128
+    ro.close()
