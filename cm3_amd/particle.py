@@ -20,6 +20,7 @@ this module only allocates, binds pointers and shapes views.  No CPU fallback ex
 import ctypes
 import weakref
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -108,6 +109,7 @@ class VecParticleEnv(object):
         self._desc_ref = ctypes.byref(self._desc)
         self._step_bufs = {}
         self._step_out = {}
+        self._pin, self._pin_np, self._pin_k = None, None, 0      # pinned staging of host actions (step())
 
     # ---- plumbing --------------------------------------------------------------------------------
     def _fn(self, op):
@@ -174,16 +176,31 @@ class VecParticleEnv(object):
         self._last_actions = self._actions[dst]
         if actions is None:
             flags |= FLAG_GEN_ACTIONS
+        elif isinstance(actions, torch.Tensor) and actions.dtype == torch.int32 and actions.is_cuda and actions.is_contiguous():
+            # device int32 actions (e.g. from ParticleActor.act): the launch reads them where they are
+            if actions.shape != (self.E, self.n):
+                raise Cm3Error("actions must have shape [n_envs, n_agents] = [%d, %d], got %s" % (self.E, self.n, tuple(actions.shape)))
+            direct = actions
+            self._last_actions = actions
+        elif isinstance(actions, np.ndarray) and actions.shape == (self.E, self.n) and actions.dtype.kind in "iu":
+            # host integer actions (np.random.randint, a NumPy policy: train_onpolicy.py:307): converted to int32 into a PINNED
+            # staging buffer and copied asynchronously -- torch.as_tensor(ndarray, device=...) is a pageable, synchronous copy
+            # (33 us per tick at C2, round 6).  A ring of four buffers, each with the event of its last copy.
+            if self._pin is None:
+                self._pin = [(torch.empty(self.E, self.n, dtype=torch.int32).pin_memory(), torch.cuda.Event()) for _ in range(4)]
+                self._pin_np = [b.numpy() for b, _ in self._pin]
+            k = self._pin_k = (self._pin_k + 1) & 3
+            buf, ev = self._pin[k]
+            ev.synchronize()
+            np.copyto(self._pin_np[k], actions, casting="unsafe")
+            self._actions[dst].copy_(buf, non_blocking=True)
+            ev.record()
         else:
             a = torch.as_tensor(actions, device=self.device)
             if a.shape != (self.E, self.n):
                 raise Cm3Error("actions must have shape [n_envs, n_agents] = [%d, %d], got %s"
                                % (self.E, self.n, tuple(a.shape)))
-            if a.dtype == torch.int32 and a.is_contiguous():
-                direct = a                      # device int32 actions (e.g. from ParticleActor.act): no staging copy
-                self._last_actions = a
-            else:
-                self._actions[dst].copy_(a)
+            self._actions[dst].copy_(a)
         self._desc.flags = flags
         b = self._step_bufs.get(dst)
         if b is None:

@@ -537,3 +537,37 @@ def test_f64_free_running_random_configs_all_agent_counts(N, kernel):
         assert _maxabs(_np(rew)[safe] - w_rew[safe]) < 1e-8 * scale
         assert np.array_equal(done.cpu().numpy()[safe], w_done[safe])
         assert np.array_equal(env.steps.cpu().numpy(), orc.steps)
+
+
+def test_step_takes_host_and_device_actions_alike():
+    """VecParticleEnv.step(actions): device int32 tensors are read in place, host integer arrays go through a ring of pinned staging
+    buffers (round 6: the reference's loop hands np.random.randint output to env.step every tick, train_onpolicy.py:307, :321) --
+    ten ticks driven three ways leave the same state, observations and rewards; bad shapes are still refused."""
+    from cm3_amd import Cm3Error
+    from cm3_amd.particle import VecParticleEnv
+    from tests.helpers import load_cfg
+    cfg = load_cfg("particle_stage2_antipodal.json")
+    rng = np.random.default_rng(3)
+    acts = rng.integers(0, 5, (10, 300, 4))
+    outs = []
+    for how in ("device_int32", "host_int64", "host_list"):
+        env = VecParticleEnv(cfg, 4, 0.2, 33, 300, device="cuda:0", seed=5, auto_reset=True)
+        env.reset()
+        for t in range(10):
+            a = acts[t]
+            if how == "device_int32":
+                a = torch.as_tensor(a, dtype=torch.int32, device="cuda:0")
+            elif how == "host_list":
+                a = a.tolist()
+            gs, oo, _, rew, rew_n, done = env.step(a)
+        torch.cuda.synchronize()
+        outs.append((gs.clone(), oo.clone(), rew.clone(), rew_n.clone(), done.clone(), env.last_actions.clone() if hasattr(env, "last_actions") else None))
+    for o in outs[1:]:
+        for x, y in zip(outs[0][:5], o[:5]):
+            assert torch.equal(x, y)
+    env = VecParticleEnv(cfg, 4, 0.2, 33, 300, device="cuda:0", seed=5)
+    env.reset()
+    with pytest.raises(Cm3Error):
+        env.step(np.zeros((300, 3), np.int64))
+    with pytest.raises(Cm3Error):
+        env.step(torch.zeros(299, 4, dtype=torch.int32, device="cuda:0"))
