@@ -211,9 +211,8 @@ __device__ __forceinline__ void ckp_row_flags(const CkState<N> &s, const uint8_t
 // h2's accumulators start from the others-branch table (two agents; stage 1: zeros): row = the OTHER agent's cell.  A lane's
 // accumulators cover 16 agent rows per tile -- read straight from the table that is 16 scattered 64-byte pieces per load, 128
 // cache-line requests per wave and tick, and cost 1.0 - 1.5 us of a 16.5 us tick.  Instead wave w fetches the eight WHOLE table rows
-// of agent rows [8w, 8w + 8) (one coalesced 1 KB load each) behind the conv, parks them in LDS behind conv_linear (row stride 260
-// floats: the 16 rows of a tile start 4 banks apart), and every wave picks its units out of LDS before the h2 pass.
-constexpr int kCkpTabLd = 260;
+// of agent rows [8w, 8w + 8) (one coalesced 1 KB load each) behind the conv, parks them in LDS behind conv_linear, and every wave picks its units out of LDS before the h2 pass.
+constexpr int kCkpTabLd = 256 + CM3_CK_LD_PAD / 2;   // (floats: 8 dwords mod 64 -- the same lane groups read it with 16-byte loads, see kLdHb)
 struct CkpTableHooks {
   const float *tab;     // NULL: stage 1, no others branch
   const float *pk;

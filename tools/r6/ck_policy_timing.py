@@ -8,7 +8,16 @@ import cm3_amd
 from cm3_amd.actor import CheckersActor
 from cm3_amd.checkers import VecCheckersEnv
 from cm3_amd.rollout import CheckersRollout
-from ck_actor_waves_ab import weights
+
+
+def weights(Nc, rng):
+    shapes = {"conv/Conv/weights": (3, 3, 3, 6), "conv/Conv/biases": (6,), "conv_linear/kernel": (150, 32),
+              "conv_linear/bias": (32,), "branch_self/kernel": (43, 256), "branch_self/bias": (256,),
+              "W_self_h2": (256, 256), "stage-2/branch_others/kernel": (2 * max(Nc - 1, 1), 256),
+              "stage-2/branch_others/bias": (256,), "stage-2/W_others_h2": (256, 256), "b": (256,),
+              "actor_out/kernel": (256, 5), "actor_out/bias": (5,)}
+    return {k: (rng.standard_normal(v) * 0.1).astype(np.float32) for k, v in shapes.items()}
+
 
 
 def main():
