@@ -600,7 +600,7 @@ def pmc_traffic(tag):
     return rec["hbm_bytes_per_launch"], rec
 
 
-SPAN_FILE = "r05_kernel_span.json"
+SPAN_FILE = "r06_kernel_span.json"
 
 
 def span_record(tag):
@@ -609,7 +609,7 @@ def span_record(tag):
     start-to-start; None if absent.  rocprofv3's kernel-trace average is not used for this: it exceeds the unprofiled time per
     launch (the profiler stretches every dispatch of a launch-bound graph)."""
     global SPAN_FILE
-    for name in ("r05_kernel_span.json", "r04_kernel_span.json", "r03_kernel_span.json"):
+    for name in ("r06_kernel_span.json", "r05_kernel_span.json", "r04_kernel_span.json", "r03_kernel_span.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             SPAN_FILE = name

@@ -415,13 +415,16 @@ template <int N> __global__ void __launch_bounds__(512) __attribute__((amdgpu_wa
     CM3_STAMP(14, false);
     // ---- env step of the workgroup's envs (checkers.py:228-262): k_checkers_step_fast's tick with the actions just sampled --------
     if (env_wave) {
+#ifdef CM3_SPAN_MARKS
+      unsigned long long span_marks_unused[8];   // (the marks build instruments the STEP kernels; ck_tick_env's marks land here)
+#endif
       const CkLanePlanRaw<N, G> raw = *reinterpret_cast<const CkLanePlanRaw<N, G> *>(&sPlan[g][0]);
       int act[N];
 #pragma unroll
       for (int i = 0; i < N; ++i) act[i] = sAct[row0 + i];
       const bool ended = ck_tick_env<N, true, true>(p, t, e, ec, writer, s, lv, reinterpret_cast<const char *>(lds_tab)
 #ifdef CM3_SPAN_MARKS
-                                                        , nullptr
+                                                        , span_marks_unused
 #endif
                                                         , act);
       CM3_STAMP(9, false);

@@ -4,14 +4,14 @@
 #
 #   tools/ab_builds.sh <base-commit> "c2 trajectory" "c5 in-place" ...      (run on the GPU box, e.g. through gpurun)
 #
-# Builds cm3_amd/libcm3_hip_base.so from <base-commit>'s cm3_amd/csrc + include (same ABI required) if it is not there yet
+# Builds tools/variants/libcm3_hip_base.so from <base-commit>'s cm3_amd/csrc + include (same ABI required) if it is not there yet
 # (hipcc cross-compiles, so do that step in the build container), then alternates `bench.py --no-extras` between the two
 # libraries (CM3_AMD_LIB selects the base one), three rounds, printing us per tick.  Remove the base library afterwards: it is a
 # measurement artefact and must not travel with the product.
 set -u
 R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)}"; cd "$R"
 BASE="$1"; shift
-LIB="$R/cm3_amd/libcm3_hip_base.so"
+LIB="$R/tools/variants/libcm3_hip_base.so"
 if [ ! -f "$LIB" ]; then
   T=$(mktemp -d); mkdir -p "$T/csrc" "$T/include"
   for f in $(git ls-tree --name-only "$BASE" cm3_amd/csrc/); do git show "$BASE:$f" > "$T/csrc/$(basename "$f")"; done

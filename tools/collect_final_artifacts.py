@@ -1,11 +1,11 @@
 #!/usr/bin/env python
-"""Copies what tools/round3_final.sh left under gpurun_out/ into profiles/ (the tracked, judged place).
+"""Copies what tools/round_final.sh left under gpurun_out/ into profiles/ (the tracked, judged place).
 
-    python tools/collect_final_artifacts.py            # after gpurun -- 'bash tools/round3_final.sh'
+    python tools/collect_final_artifacts.py [round = 6]   # after gpurun -- 'bash tools/round_final.sh'
 
-bench lines -> profiles/r03_bench_c{2..5}.json, the two-stamp record -> profiles/r03_kernel_span_c{2,3,4,5}.txt (+ .json),
-PMC summaries -> profiles/r03_pmc_*.txt + profiles/pmc_traffic.json, the rocprofv3 kernel-trace summary ->
-profiles/r03_bench_c2_kernel_stats.txt, the test / smoke tails -> profiles/r03_pytest_gpu_summary.txt.
+bench lines -> profiles/rNN_bench_c{2..5}.json, the two-stamp record -> profiles/rNN_kernel_span_c{2,3,4,5}.txt (+ .json),
+PMC summaries -> profiles/rNN_pmc_*.txt + profiles/pmc_traffic.json, the rocprofv3 kernel-trace summary ->
+profiles/rNN_bench_c2_kernel_stats.txt, the test / smoke tails -> profiles/rNN_pytest_gpu_summary.txt.
 """
 import glob
 import json
@@ -14,9 +14,12 @@ import shutil
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
-O = os.path.join(G, "r3final")
+import sys
+RN = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+RP = "r%02d_" % RN
+O = os.path.join(G, "r%dfinal" % RN)
 
-HEAD = """# Round 3 FINAL build: undisturbed kernel-duration record (tools/kernel_span.py; two-stamp build libcm3_hip_span.so =
+HEAD = """# FINAL build of the round: undisturbed kernel-duration record (tools/kernel_span.py; two-stamp build libcm3_hip_span.so =
 # csrc/build.sh with -DCM3_SPAN_STAMPS, csrc/common.h): every wave stamps s_memrealtime (100 MHz) + s_memtime at its first
 # instruction and after its last store has been acknowledged; bench.py's own 330-launch hipGraph, NOT profiled; stamps of the
 # last of 20 timed replays.  span = first wave in -> last wave out; start-to-start = consecutive first-wave-in; gap = the
@@ -28,17 +31,15 @@ HEAD = """# Round 3 FINAL build: undisturbed kernel-duration record (tools/kerne
 
 
 def first_json(path):
-    for line in open(path):
-        if line.startswith("{"):
-            return json.loads(line)
-    raise SystemExit("no JSON line in " + path)
+    with open(path) as fh:
+        return json.load(fh)            # (round 5: the full record is bench.py's --extras-file, one JSON document)
 
 
 def main():
     bench = {}
     for wl in ("c2", "c3", "c4", "c5"):
         d = bench[wl] = first_json(os.path.join(O, "bench_%s.json" % wl))
-        with open(os.path.join(P, "r03_bench_%s.json" % wl), "w") as f:
+        with open(os.path.join(P, RP + "bench_%s.json" % wl), "w") as f:
             f.write(json.dumps(d) + "\n")
     # the span record: header lines (#) + one block per "== name" section
     lines = open(os.path.join(O, "kernel_span.txt")).read().splitlines()
@@ -52,26 +53,36 @@ def main():
             blocks[cur].append(l)
     for wl in ("c2", "c3", "c4", "c5"):
         d = bench[wl]
-        inpl = d.get("launch_modes", {}).get("in_place_chains1", {}).get("us_per_tick")
+        inpl = d.get("launch_modes", {}).get("in_place", d.get("launch_modes", {}).get("in_place_chains1", {})).get("us_per_tick")
         out = [HEAD.rstrip("\n")] + tool_head
         out.append("# product library, same box, same call: bench.py --workload %s: trajectory mode %.3f us per tick, in place %s"
                    % (wl, d["us_per_tick"], "%.3f" % inpl if inpl else "n/a"))
         for name, b in blocks.items():
             if name.startswith(wl + "_") or (wl == "c2" and name.startswith("floor_")):
                 out += b
-        with open(os.path.join(P, "r03_kernel_span_%s.txt" % wl), "w") as f:
+        with open(os.path.join(P, RP + "kernel_span_%s.txt" % wl), "w") as f:
             f.write("\n".join(out) + "\n")
-    shutil.copy(os.path.join(O, "kernel_span.json"), os.path.join(P, "r03_kernel_span.json"))
+    shutil.copy(os.path.join(O, "kernel_span.json"), os.path.join(P, RP + "kernel_span.json"))
+    if os.path.exists(os.path.join(O, "kernel_span_marks.txt")):
+        with open(os.path.join(P, RP + "kernel_span_marks.txt"), "w") as f:
+            f.write("# FINAL build of the round with -DCM3_SPAN_STAMPS -DCM3_SPAN_MARKS (tools/kernel_span.py c2 c3 c5): per-wave shader-clock marks inside\n"
+                    "# the step kernels (the marks pin the schedule around them and lengthen the kernels a little: read the two-stamp record for\n"
+                    "# durations, this one for where a wave's time goes).\n")
+            f.write("".join(l for l in open(os.path.join(O, "kernel_span_marks.txt")) if "amdgpu.ids" not in l))
     for s in glob.glob(os.path.join(G, "pmc_*_summary.txt")):
         name = os.path.basename(s)[len("pmc_"):-len("_summary.txt")]
-        shutil.copy(s, os.path.join(P, "r03_pmc_%s.txt" % name))
+        shutil.copy(s, os.path.join(P, RP + "pmc_%s.txt" % name))
     if os.path.exists(os.path.join(G, "pmc_traffic_new.json")):
         shutil.copy(os.path.join(G, "pmc_traffic_new.json"), os.path.join(P, "pmc_traffic.json"))
-    shutil.copy(os.path.join(O, "prof_c2_kernel_stats.txt"), os.path.join(P, "r03_bench_c2_kernel_stats.txt"))
-    with open(os.path.join(P, "r03_pytest_gpu_summary.txt"), "w") as f:
-        f.write("# python -m pytest tests -m gpu -q on the MI355X box (tools/round3_final.sh), then __graft_entry__.smoke()\n")
+    shutil.copy(os.path.join(O, "prof_c2_kernel_stats.txt"), os.path.join(P, RP + "bench_c2_kernel_stats.txt"))
+    with open(os.path.join(P, RP + "pytest_gpu_summary.txt"), "w") as f:
+        f.write("# python -m pytest tests -m gpu -q on the MI355X box (tools/round_final.sh), then __graft_entry__.smoke()\n")
         f.write("".join(open(os.path.join(O, "pytest_gpu.log")).readlines()[-12:]))
         f.write("".join(open(os.path.join(O, "smoke.log")).readlines()[-1:]))
+    for wl in bench:
+        shutil.copy(os.path.join(O, "driver_line_%s.json" % wl), os.path.join(P, RP + "driver_line_%s.json" % wl))
+    if os.path.exists(os.path.join(O, "live_state_ab.txt")):
+        shutil.copy(os.path.join(O, "live_state_ab.txt"), os.path.join(P, RP + "live_state_ab_c2.txt"))
     for wl, d in bench.items():
         print(wl, "%.3f us/tick" % d["us_per_tick"], "%.4g %s" % (d["value"], d["unit"]))
 

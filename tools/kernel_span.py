@@ -2,9 +2,9 @@
 """Undisturbed kernel-duration record of the headline step launches.
 
 Runs on the GPU box with the TWO-STAMP build of the library (csrc/common.h CM3_SPAN_STAMPS; built by
-`CM3_EXTRA_FLAGS=-DCM3_SPAN_STAMPS CM3_OUT=cm3_amd/libcm3_hip_span.so bash cm3_amd/csrc/build.sh`):
+`CM3_EXTRA_FLAGS=-DCM3_SPAN_STAMPS CM3_OUT=tools/variants/libcm3_hip_span.so bash cm3_amd/csrc/build.sh`):
 
-    CM3_AMD_LIB=$PWD/cm3_amd/libcm3_hip_span.so python tools/kernel_span.py c2 [c3 c5 floor]
+    CM3_AMD_LIB=$PWD/tools/variants/libcm3_hip_span.so python tools/kernel_span.py c2 [c3 c5 floor]
 
 Every wave of a step launch records s_memrealtime (100 MHz, constant) + s_memtime (shader clock) at its first instruction and
 again after its last store has been acknowledged.  The workload is bench.py's own headline stepper (330 step launches per

@@ -4,7 +4,7 @@ cd "${GRAFT_REPO_ROOT:-.}"
 mkdir -p gpurun_out
 [ -n "${TESTS:-}" ] && timeout 1800 python -m pytest $TESTS -x -q -m gpu 2>&1 | tail -4
 for rep in 1 2 3; do for b in ${LIBS:-base new}; do
-  lib=""; [ $b != new ] && lib="$PWD/cm3_amd/libcm3_hip_$b.so"
+  lib=""; [ $b != new ] && lib="$PWD/tools/variants/libcm3_hip_$b.so"
   CM3_AMD_LIB=$lib timeout 600 python tools/checkers_actor_timing.py 2>/dev/null | grep f16x3 | python -c "
 import json,sys
 for l in sys.stdin:

@@ -1,16 +1,17 @@
 #!/bin/bash
-# Reference artefacts of round 5 on ONE build: full GPU suite, smoke, two-stamp kernel-span record, bench lines for every BASELINE
-# config, PMC passes, rocprofv3 kernel-trace summary.  Run on the GPU box: gpurun -- 'bash tools/round5_final.sh'
-# (cm3_amd/libcm3_hip_span.so must have been built from the same sources: CM3_EXTRA_FLAGS=-DCM3_SPAN_STAMPS CM3_OUT=... build.sh)
+# Reference artefacts of a round (ROUND=6 by default) on ONE build: full GPU suite, smoke, two-stamp kernel-span record, bench lines for every BASELINE
+# config, PMC passes, rocprofv3 kernel-trace summary.  Run on the GPU box: gpurun -- 'bash tools/round_final.sh'
+# (tools/variants/libcm3_hip_span.so [+ _marks.so] must have been built from the same sources:
+#   CM3_EXTRA_FLAGS=-DCM3_SPAN_STAMPS CM3_OUT=$PWD/tools/variants/libcm3_hip_span.so CM3_OBJ_DIR=/tmp/obj_span CM3_SKIP_ISA_LINT=1 bash cm3_amd/csrc/build.sh)
 set -u
-R="${GRAFT_REPO_ROOT:-$PWD}"; O="$R/gpurun_out/r5final"; mkdir -p "$O"; cd "$R"
+RN="${ROUND:-6}"; R="${GRAFT_REPO_ROOT:-$PWD}"; O="$R/gpurun_out/r${RN}final"; mkdir -p "$O"; cd "$R"
 python -c "import __graft_entry__ as g; g.build()" > "$O/build.log" 2>&1
 timeout 2400 python -m pytest tests -m gpu -q > "$O/pytest_gpu.log" 2>&1; echo "suite rc=$?"; grep -E "^FAILED|^ERROR" "$O/pytest_gpu.log" | head; tail -1 "$O/pytest_gpu.log"
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$O/smoke.log" 2>&1; echo "smoke rc=$?"; tail -1 "$O/smoke.log"
 # undisturbed kernel durations (two stamps per wave, unprofiled graph replays)
-CM3_AMD_LIB=$R/cm3_amd/libcm3_hip_span.so timeout 900 python tools/kernel_span.py c2 c3 c4 c5 floor --json > "$O/kernel_span.txt" 2> "$O/kernel_span.err"; echo "span rc=$?"
-grep "^{" "$O/kernel_span.txt" | tail -1 > "$O/kernel_span.json"; cp "$O/kernel_span.json" "$R/profiles/r05_kernel_span.json"
-if [ -f "$R/cm3_amd/libcm3_hip_marks.so" ]; then CM3_AMD_LIB=$R/cm3_amd/libcm3_hip_marks.so timeout 600 python tools/kernel_span.py c2 c3 c5 > "$O/kernel_span_marks.txt" 2>&1; echo "marks rc=$?"; fi
+CM3_AMD_LIB=$R/tools/variants/libcm3_hip_span.so timeout 900 python tools/kernel_span.py c2 c3 c4 c5 floor --json > "$O/kernel_span.txt" 2> "$O/kernel_span.err"; echo "span rc=$?"
+grep "^{" "$O/kernel_span.txt" | tail -1 > "$O/kernel_span.json"; cp "$O/kernel_span.json" "$R/gpurun_out/r0${RN}_kernel_span.json"
+if [ -f "$R/tools/variants/libcm3_hip_marks.so" ]; then CM3_AMD_LIB=$R/tools/variants/libcm3_hip_marks.so timeout 600 python tools/kernel_span.py c2 c3 c5 > "$O/kernel_span_marks.txt" 2>&1; echo "marks rc=$?"; fi
 # (since round 5 the LAST stdout line is the driver's compact record, < 4 KB; the full record goes to --extras-file)
 timeout 1200 python bench.py --extras-file "$O/bench_c2.json" > "$O/bench_c2.stdout" 2> "$O/bench_c2.err"; echo "bench c2 rc=$?"
 tail -1 "$O/bench_c2.stdout" > "$O/driver_line_c2.json"; echo "driver line: $(wc -c < "$O/driver_line_c2.json") bytes"
@@ -39,6 +40,9 @@ for rep in 1 2 3; do for ls in on off; do
   v=$(timeout 300 python bench.py --workload c2 --live-state $ls --no-extras --no-sweep --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; print('%.3f' % json.loads(sys.stdin.readline())['us_per_tick'])")
   echo "c2 trajectory live-state $ls: $v us per tick"
 done; done > "$O/live_state_ab.txt" 2>&1; cat "$O/live_state_ab.txt"
+# the one-launch Checkers policy rollout: kernel-trace stats + PMC groups
+bash tools/pmc_ck_policy.sh > "$O/pmc_ck_policy.log" 2>&1; echo "ck policy pmc rc=$?"
+timeout 120 python bench.py --workload c1 --steps 5 > "$O/bench_c1.stdout" 2>&1; echo "c1 rc=$?"; tail -1 "$O/bench_c1.stdout" | cut -c1-300
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_c2" -o c2 -- python "$R/bench.py" --no-extras --no-sweep --no-cpu-baseline > "$O/prof_c2.log" 2>&1; echo "rocprof rc=$?"
 cd "$R"; python tools/rocprof_summary.py "$O/prof_c2" > "$O/prof_c2_kernel_stats.txt" 2>&1; head -4 "$O/prof_c2_kernel_stats.txt"
