@@ -147,17 +147,6 @@ template <int N> __global__ void __launch_bounds__(256) k_actor_pack(const Actor
 //                that (weights ~3 orders of magnitude above anything a trained policy holds) saturates instead of matching.
 constexpr int kPrecF32 = 0, kPrecBf16 = 1, kPrecF16x3 = 2;
 
-// relu as ONE instruction: fmaxf(x, 0) first canonicalises x (a second v_max_f32 x, x) because the build honours signalling NaNs
-// (v_med3_f32 against 0 and +inf is folded back into the same pair).  On the bit patterns it is a signed-integer maximum: a float
-// with the sign bit set is a negative integer (-0.0 included, a NaN with the sign bit too; a positive NaN stays what it is), every
-// other float is its own non-negative integer.  Plain C rather than inline assembly: the compiler's hazard recogniser does not look
-// into an asm statement, and with the accumulators in architectural VGPRs (build.sh) the operand is the matrix instruction's own
-// destination -- an opaque "v_max_f32" read it before the passes were through (caught by tests/test_gpu_actor.py on the first
-// build with that flag).
-__device__ __forceinline__ float relu_f32(float x) {
-  const int xi = __builtin_bit_cast(int, x);
-  return __builtin_bit_cast(float, xi > 0 ? xi : 0);
-}
 
 // RT = 16-row tiles per workgroup (4: 64 agent rows, the one-tick actor kernel; the fused policy rollout also runs 2 or 1 so that a
 // small batch still puts several workgroups on every CU, see policy.hip)

@@ -743,12 +743,19 @@ template <int RT, int CT> __device__ __forceinline__ void bias_tiles(const float
     for (int c = 0; c < CT; ++c) acc[t][c] = f32x4{bias[c].x, bias[c].y, bias[c].z, bias[c].w};
 }
 
-// v = hi + lo + O(2^-22 v): hi = float16(v), lo = float16(v - hi)
+// v = hi + lo + O(2^-22 v): hi = float16(v), lo = float16(v - hi), two values per conversion instruction (v_cvt_pk_f16_f32; the
+// subtraction stays scalar: packed float32 arithmetic next to matrix instructions is an anti-lever -- and the family the lint watches)
 __device__ __forceinline__ void split4(const float (&v)[4], f16x4 &vh, f16x4 &vl) {
+  typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+  typedef float f2v __attribute__((ext_vector_type(2)));
 #pragma unroll
-  for (int reg = 0; reg < 4; ++reg) {
-    vh[reg] = (_Float16)v[reg];
-    vl[reg] = (_Float16)(v[reg] - (float)vh[reg]);
+  for (int p = 0; p < 2; ++p) {
+    const f2v x = {v[2 * p], v[2 * p + 1]};
+    const h2v hp = __builtin_convertvector(x, h2v);
+    const float r0 = x[0] - (float)hp[0], r1 = x[1] - (float)hp[1];
+    const h2v lp = __builtin_convertvector(f2v{r0, r1}, h2v);
+    vh[2 * p] = hp[0]; vh[2 * p + 1] = hp[1];
+    vl[2 * p] = lp[0]; vl[2 * p + 1] = lp[1];
   }
 }
 
@@ -760,7 +767,8 @@ __device__ __forceinline__ void store_relu_x3b(_Float16 *Oh, _Float16 *Ol, int l
   for (int c = 0; c < CT; ++c) {
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
-      const float v[4] = {fmaxf(acc[t][c][0], 0.0f), fmaxf(acc[t][c][1], 0.0f), fmaxf(acc[t][c][2], 0.0f), fmaxf(acc[t][c][3], 0.0f)};
+      // (relu_f32: ONE integer maximum on the bit pattern; fmaxf is two instructions -- it quiets a NaN first)
+      const float v[4] = {relu_f32(acc[t][c][0]), relu_f32(acc[t][c][1]), relu_f32(acc[t][c][2]), relu_f32(acc[t][c][3])};
       f16x4 vh, vl;
       split4(v, vh, vl);
       const int at = (16 * (rt0 + t) + col) * ldo + 16 * (ct0 + c) + 4 * hi;
@@ -932,8 +940,8 @@ __device__ __forceinline__ void ck_x3_self_chain(const CkX3Planes &L, const floa
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     f16x4 h0, l0, h1, l1;
-    const float v0[4] = {fmaxf(acc2[t][0][0], 0.0f), fmaxf(acc2[t][0][1], 0.0f), fmaxf(acc2[t][0][2], 0.0f), fmaxf(acc2[t][0][3], 0.0f)};
-    const float v1[4] = {fmaxf(acc2[t][1][0], 0.0f), fmaxf(acc2[t][1][1], 0.0f), fmaxf(acc2[t][1][2], 0.0f), fmaxf(acc2[t][1][3], 0.0f)};
+    const float v0[4] = {relu_f32(acc2[t][0][0]), relu_f32(acc2[t][0][1]), relu_f32(acc2[t][0][2]), relu_f32(acc2[t][0][3])};
+    const float v1[4] = {relu_f32(acc2[t][1][0]), relu_f32(acc2[t][1][1]), relu_f32(acc2[t][1][2]), relu_f32(acc2[t][1][3])};
     split4(v0, h0, l0);
     split4(v1, h1, l1);
     const f16x8 ah = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};

@@ -19,6 +19,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
+// relu as ONE instruction: fmaxf(x, 0) first canonicalises x (a second v_max_f32 x, x) because the build honours signalling NaNs
+// (v_med3_f32 against 0 and +inf is folded back into the same pair).  On the bit patterns it is a signed-integer maximum: a float
+// with the sign bit set is a negative integer (-0.0 included, a NaN with the sign bit too; a positive NaN stays what it is), every
+// other float is its own non-negative integer.  Plain C rather than inline assembly: the compiler's hazard recogniser does not look
+// into an asm statement, and with the accumulators in architectural VGPRs (build.sh) the operand is the matrix instruction's own
+// destination -- an opaque "v_max_f32" read it before the passes were through (caught by tests/test_gpu_actor.py on the first
+// build with that flag).
+__device__ __forceinline__ float relu_f32(float x) {
+  const int xi = __builtin_bit_cast(int, x);
+  return __builtin_bit_cast(float, xi > 0 ? xi : 0);
+}
+
 // action ~ multinomial(probs) (alg_credit.py:120): inverse CDF in action order, one uniform per (seed, global env id, episode,
 // step, agent) from the two-stage stream of philox.h -- stage 1 (actor_block_word: the agent's word of the env's Philox block with
 // the policy purpose bit) depends on nothing loaded or computed, so a kernel draws it once, ahead of time (the fused policy rollout:
