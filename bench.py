@@ -884,6 +884,8 @@ def extras_summary(out):
                           if isinstance(v, dict) and "ms" in v}
         if isinstance(out["host_side"].get("phase_total"), dict):
             s["phase_total_ms"] = _sig(out["host_side"]["phase_total"]["ms"], 4)
+        if isinstance(out["host_side"].get("phase_total_graph"), dict):
+            s["phase_total_graph_ms"] = _sig(out["host_side"]["phase_total_graph"]["ms"], 4)
     while len(json.dumps(s)) >= LINE_LIMIT and s.get("sweep"):
         s["sweep"].pop()
     return s

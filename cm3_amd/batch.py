@@ -26,9 +26,13 @@ class _Tiler(object):
     def __init__(self, device):
         self.device, self.specs, self.keep = device, [], []
 
-    def add(self, src, n_rows, epr, dtype, kind, terms=((1, 0, 1), (1, 0, 0)), others=None, shape=None):
+    def add(self, src, n_rows, epr, dtype, kind, terms=((1, 0, 1), (1, 0, 0)), others=None, shape=None, out=None):
         from . import _lib
-        out = torch.empty((n_rows, epr) if shape is None else shape, dtype=dtype, device=self.device)
+        want = tuple((n_rows, epr) if shape is None else shape)
+        if out is None:
+            out = torch.empty(want, dtype=dtype, device=self.device)
+        elif tuple(out.shape) != want or out.dtype != dtype or not out.is_contiguous():
+            raise ValueError("persistent feed tensor has shape %s / %s, expected %s / %s" % (tuple(out.shape), out.dtype, want, dtype))
         c = _lib.TileCol()
         c.dst, c.src, c.n_rows, c.elems_per_row, c.kind = out.data_ptr(), (0 if src is None else src.data_ptr()), n_rows, epr, kind
         c.elem_bytes = src.element_size() if (src is not None and kind == _lib.TILE_COPY) else 0
@@ -51,12 +55,13 @@ class _Tiler(object):
         self.specs, self.keep = [], []
 
 
-def particle_static_feeds_device(cols, l_action=5):
+def particle_static_feeds_device(cols, l_action=5, out=None):
     """Every feed of the reference's train_step that does not depend on a network output (particle env, N > 1, Q-credit variant), from
     the float32 columns of ParticleRollout.as_reference_batch(numpy=False), in TWO launches of cm3_rows_tile: process_actions /
     process_global_state (alg_credit.py:406-443, :528-557), the n x n credit repeats (:614-658), the n x n x l_action counterfactual
     tiling (:730-751).  Values and dtypes are those of the torch composition in train_step_feeds (tests/test_batch.py compares the two
-    and both with the arrays the REAL train_step fed)."""
+    and both with the arrays the REAL train_step fed).  out: the dict an earlier call returned for the same batch size -- the feeds are
+    written into those tensors again (persistent addresses for a captured consumer)."""
     from . import _lib
     vg, vgn = cols["v_global"].contiguous(), cols["v_global_next"].contiguous()
     B, N, l = vg.shape
@@ -71,34 +76,34 @@ def particle_static_feeds_device(cols, l_action=5):
     by_n = lambda outer=1: ((outer * N * N, 0, N), (outer, N, 1))          # noqa: E731  rows (b, m, n[, a]) <- row b N + n
     by_m = lambda outer=1: ((outer * N, 0, 1), (1, 0, 0))                   # noqa: E731  rows (r, m[, a])    <- row r
     t = _Tiler(dev)
-    S = {}
-    S["a1"] = t.add(actions, R, A, i64, _lib.TILE_ONEHOT_I64)
-    S["ao"] = t.add(actions, R * (N - 1), A, f64, _lib.TILE_ONEHOT_F64, others=(N, N * (N - 1), N - 1), shape=(R, N - 1, A))
-    S["reward_rep"] = t.add(reward, R, 1, reward.dtype, _lib.TILE_COPY, terms=by_m(), shape=(R,))
-    S["done_rep"] = t.add(done_u8, R, 1, torch.bool, _lib.TILE_COPY, terms=by_m(), shape=(R,))
-    S["not_done"] = t.add(done_u8, R, 1, i64, _lib.TILE_NOT_I64, terms=by_m(), shape=(R,))
-    S["others"] = t.add(vg, R * (N - 1), l, f64, _lib.TILE_F32_TO_F64, others=(N, N * (N - 1), N - 1), shape=(R, (N - 1) * l))
-    S["others_next"] = t.add(vgn, R * (N - 1), l, f64, _lib.TILE_F32_TO_F64, others=(N, N * (N - 1), N - 1), shape=(R, (N - 1) * l))
-    S["goals_self_rep"] = t.add(goals, R * N, lg, goals.dtype, _lib.TILE_COPY, terms=by_n())
-    S["one_next_rep_n"] = t.add(vgn, R * N, l, vgn.dtype, _lib.TILE_COPY, terms=by_n())
-    S["one_next_rep_m"] = t.add(vgn, R * N, l, vgn.dtype, _lib.TILE_COPY, terms=by_m())
+    S, O = {}, (out or {})
+    S["a1"] = t.add(actions, R, A, i64, _lib.TILE_ONEHOT_I64, out=O.get("a1"))
+    S["ao"] = t.add(actions, R * (N - 1), A, f64, _lib.TILE_ONEHOT_F64, others=(N, N * (N - 1), N - 1), shape=(R, N - 1, A), out=O.get("ao"))
+    S["reward_rep"] = t.add(reward, R, 1, reward.dtype, _lib.TILE_COPY, terms=by_m(), shape=(R,), out=O.get("reward_rep"))
+    S["done_rep"] = t.add(done_u8, R, 1, torch.bool, _lib.TILE_COPY, terms=by_m(), shape=(R,), out=O.get("done_rep"))
+    S["not_done"] = t.add(done_u8, R, 1, i64, _lib.TILE_NOT_I64, terms=by_m(), shape=(R,), out=O.get("not_done"))
+    S["others"] = t.add(vg, R * (N - 1), l, f64, _lib.TILE_F32_TO_F64, others=(N, N * (N - 1), N - 1), shape=(R, (N - 1) * l), out=O.get("others"))
+    S["others_next"] = t.add(vgn, R * (N - 1), l, f64, _lib.TILE_F32_TO_F64, others=(N, N * (N - 1), N - 1), shape=(R, (N - 1) * l), out=O.get("others_next"))
+    S["goals_self_rep"] = t.add(goals, R * N, lg, goals.dtype, _lib.TILE_COPY, terms=by_n(), out=O.get("goals_self_rep"))
+    S["one_next_rep_n"] = t.add(vgn, R * N, l, vgn.dtype, _lib.TILE_COPY, terms=by_n(), out=O.get("one_next_rep_n"))
+    S["one_next_rep_m"] = t.add(vgn, R * N, l, vgn.dtype, _lib.TILE_COPY, terms=by_m(), out=O.get("one_next_rep_m"))
     S["others_next_rep_n"] = t.add(vgn, R * N * (N - 1), l, f64, _lib.TILE_F32_TO_F64, others=(N, N * N * (N - 1), N - 1),
-                                   shape=(R * N, (N - 1) * l))
-    S["r_rep"] = t.add(reward_local, R * N, 1, reward_local.dtype, _lib.TILE_COPY, terms=by_n(), shape=(R * N,))
+                                   shape=(R * N, (N - 1) * l), out=O.get("others_next_rep_n"))
+    S["r_rep"] = t.add(reward_local, R * N, 1, reward_local.dtype, _lib.TILE_COPY, terms=by_n(), shape=(R * N,), out=O.get("r_rep"))
     # (done per time step -> per agent row -> repeated by n: row (b, m, n) <- done[b])
-    S["nd_rep"] = t.add(done_u8, R * N, 1, i64, _lib.TILE_NOT_I64, terms=((N * N, 0, 1), (1, 0, 0)), shape=(R * N,))
-    S["s_n_rep"] = t.add(vg, R * N, l, vg.dtype, _lib.TILE_COPY, terms=by_n())
-    S["s_m_rep"] = t.add(vg, R * N, l, vg.dtype, _lib.TILE_COPY, terms=by_m())
+    S["nd_rep"] = t.add(done_u8, R * N, 1, i64, _lib.TILE_NOT_I64, terms=((N * N, 0, 1), (1, 0, 0)), shape=(R * N,), out=O.get("nd_rep"))
+    S["s_n_rep"] = t.add(vg, R * N, l, vg.dtype, _lib.TILE_COPY, terms=by_n(), out=O.get("s_n_rep"))
+    S["s_m_rep"] = t.add(vg, R * N, l, vg.dtype, _lib.TILE_COPY, terms=by_m(), out=O.get("s_m_rep"))
     S["s_others_rep"] = t.add(vg, R * N * (N - 1), l, f64, _lib.TILE_F32_TO_F64, others=(N, N * N * (N - 1), N - 1),
-                              shape=(R * N, (N - 1) * l))
+                              shape=(R * N, (N - 1) * l), out=O.get("s_others_rep"))
     t.run()
-    S["a1_rep_m"] = t.add(actions, R * N, A, i64, _lib.TILE_ONEHOT_I64, terms=by_m())
-    S["cf_s_n"] = t.add(vg, R * N * A, l, vg.dtype, _lib.TILE_COPY, terms=by_n(A))
-    S["cf_goals"] = t.add(goals, R * N * A, lg, goals.dtype, _lib.TILE_COPY, terms=by_n(A))
-    S["cf_eye"] = t.add(None, R * N * A, A, f64, _lib.TILE_EYE_F64)
-    S["cf_s_m"] = t.add(vg, R * N * A, l, vg.dtype, _lib.TILE_COPY, terms=by_m(A))
+    S["a1_rep_m"] = t.add(actions, R * N, A, i64, _lib.TILE_ONEHOT_I64, terms=by_m(), out=O.get("a1_rep_m"))
+    S["cf_s_n"] = t.add(vg, R * N * A, l, vg.dtype, _lib.TILE_COPY, terms=by_n(A), out=O.get("cf_s_n"))
+    S["cf_goals"] = t.add(goals, R * N * A, lg, goals.dtype, _lib.TILE_COPY, terms=by_n(A), out=O.get("cf_goals"))
+    S["cf_eye"] = t.add(None, R * N * A, A, f64, _lib.TILE_EYE_F64, out=O.get("cf_eye"))
+    S["cf_s_m"] = t.add(vg, R * N * A, l, vg.dtype, _lib.TILE_COPY, terms=by_m(A), out=O.get("cf_s_m"))
     S["cf_s_others"] = t.add(vg, R * N * A * (N - 1), l, f64, _lib.TILE_F32_TO_F64, others=(N, N * N * A * (N - 1), A * (N - 1)),
-                             shape=(R * N * A, (N - 1) * l))
+                             shape=(R * N * A, (N - 1) * l), out=O.get("cf_s_others"))
     t.run()
     return S
 
@@ -118,6 +123,76 @@ def phase_static_feeds(cols_all, n_minibatches, l_action=5):
             d[name] = t[k * r:(k + 1) * r]
         out.append(d)
     return out
+
+
+class OnPolicyPhasePlan(object):
+    """One on-policy phase of the reference's loop (train_onpolicy.py:359-377: after a collection phase, 24 x (sample 128 transitions,
+    train_step)) with PERSISTENT device tensors, so that the data movement of every train_step can be a hipGraph replay:
+
+        plan = OnPolicyPhasePlan(rollout, run, gamma, epsilon)        # once
+        rollout.collect(); plan.refresh(generator)                     # per phase: one export launch + one pair of tiling launches
+        for k in range(plan.epochs): calls = plan.step(k)              # per minibatch: ONE graph replay
+
+    refresh() draws the phase's minibatches and writes their columns and the static feeds of all of them INTO THE SAME tensors every
+    phase; step(k) replays the graph captured from cm3_amd.batch.train_step_feeds(columns_k, run, gamma, epsilon, static=static_k) --
+    every launch that function and `run` enqueue (the session's networks included, if `run` launches them on the current stream
+    into tensors of its own that it keeps) -- and returns the same list of (ops, feed) with this phase's values in the same tensors.
+    `run` is CALLED only while a graph is captured (the first step(k) of each k): it must not synchronise or allocate per call what
+    it does not keep.  Without graphs (use_graph=False) step(k) simply calls train_step_feeds: the specification the replay is
+    tested against (tests/test_batch.py::test_phase_plan_replays_equal_eager_feeds)."""
+
+    def __init__(self, rollout, run, gamma, epsilon, epochs=24, batch_size=128, l_action=5, use_graph=True):
+        self.ro, self.run, self.gamma, self.epsilon = rollout, run, float(gamma), float(epsilon)
+        self.epochs, self.batch_size, self.l_action, self.use_graph = int(epochs), int(batch_size), int(l_action), bool(use_graph)
+        self.cols = self.static = None
+        self.k = 0
+        self._graphs, self._calls = {}, {}
+
+    def refresh(self, generator=None):
+        first = self.cols is None
+        self.cols, self.k = self.ro._phase_export(self.epochs, self.batch_size, generator, out=self.cols)
+        vg = self.cols["v_global"]
+        if not (vg.is_cuda and vg.dtype == torch.float32 and vg.shape[1] > 1):
+            raise ValueError("OnPolicyPhasePlan covers float32 device rollouts with more than one agent (the tiling kernels' case)")
+        self.static = particle_static_feeds_device(self.cols, self.l_action, out=self.static)
+        if first:
+            M, k = self.epochs, self.k
+            self._mb = [({n: v[m * k:(m + 1) * k] for n, v in self.cols.items()},
+                         {n: t[m * (t.shape[0] // M):(m + 1) * (t.shape[0] // M)] for n, t in self.static.items()}) for m in range(M)]
+        return self
+
+    def minibatch(self, k):
+        """(columns, static feeds) of minibatch k: views of the persistent phase tensors"""
+        return self._mb[k]
+
+    def step(self, k):
+        from . import _lib
+        cols, static = self._mb[k]
+        if not self.use_graph:
+            return train_step_feeds(cols, self.run, self.gamma, self.epsilon, l_action=self.l_action, static=static)
+        dev = cols["v_global"].device
+        if k not in self._graphs:
+            # once eagerly (the allocator then holds blocks of every size the capture will ask for), then captured; the tensors the
+            # captured pass created are KEPT (self._calls): a replay writes to their addresses
+            train_step_feeds(cols, self.run, self.gamma, self.epsilon, l_action=self.l_action, static=static)
+            torch.cuda.synchronize(dev)
+            box = {}
+
+            def enqueue(stream):
+                with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=dev)):
+                    box["calls"] = train_step_feeds(cols, self.run, self.gamma, self.epsilon, l_action=self.l_action, static=static)
+            self._graphs[k] = _lib.capture_graph(dev, enqueue)
+            self._calls[k] = box["calls"]
+        _lib.check(_lib.lib().cm3_graph_launch(self._graphs[k], torch.cuda.current_stream(dev).cuda_stream))
+        return self._calls[k]
+
+    def close(self):
+        from . import _lib
+        if self._graphs:
+            torch.cuda.synchronize()
+            for g in self._graphs.values():
+                _lib.lib().cm3_graph_destroy(g)
+        self._graphs, self._calls = {}, {}
 
 
 def td_target(reward, q, multiplier, gamma):

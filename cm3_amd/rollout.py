@@ -610,9 +610,11 @@ class ParticleRollout(object):
         idx = self.valid.nonzero(as_tuple=False)
         return idx[:, 0], idx[:, 1]
 
-    def as_reference_batch(self, tt=None, ee=None, numpy=True):
+    def as_reference_batch(self, tt=None, ee=None, numpy=True, out=None):
         """Columns of the reference's transition batch for the (tick, env) pairs (tt, ee) (default: all valid
         ones), each equal to np.stack(batch[:, k]) in alg_credit.process_batch (alg_credit.py:458-470).
+        out: a dict this call returned earlier for the same number of transitions (float32 path, numpy=False): the columns are
+        written into those tensors again (persistent addresses: what a captured hipGraph of the consumer needs).
         float32 trajectories: ONE launch of cm3_transitions_gather_f32 (csrc/batch.hip) fills all columns; the float64 parity
         instantiation goes through the torch composition below (as_reference_batch_torch: same values, ~25 launches)."""
         everything = tt is None and self.auto_reset and self.state.dtype == torch.float32     # (all T x E transitions are valid)
@@ -625,11 +627,17 @@ class ParticleRollout(object):
             return self.as_reference_batch_torch(tt, ee, numpy)
         env = self.env
         B, N, L, dev = (self.T * env.E if everything else tt.numel()), env.n, env.L, env.device
-        f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)      # noqa: E731
-        state, obs, nstate, nobs = f(B, N, 4), f(B, N, L), f(B, N, 4), f(B, N, L)
-        reward, reward_n, goals = f(B), f(B, N), f(B, N, 2)
-        actions = torch.empty(B, N, dtype=torch.int32, device=dev)
-        done = torch.empty(B, dtype=torch.bool, device=dev)
+        if out is not None:
+            if numpy or out["v_global"].shape[0] != B or out["v_global"].data_ptr() != out["v_local"].data_ptr():
+                raise Cm3Error("as_reference_batch(out=...): pass the dict an earlier call returned for %d transitions (numpy=False)" % B)
+            state, obs, nstate, nobs = out["v_global"], out["obs_others"], out["v_global_next"], out["obs_others_next"]
+            reward, reward_n, goals, actions, done = out["reward"], out["reward_local"], out["goals"], out["actions"], out["done"]
+        else:
+            f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)      # noqa: E731
+            state, obs, nstate, nobs = f(B, N, 4), f(B, N, L), f(B, N, 4), f(B, N, L)
+            reward, reward_n, goals = f(B), f(B, N), f(B, N, 2)
+            actions = torch.empty(B, N, dtype=torch.int32, device=dev)
+            done = torch.empty(B, dtype=torch.bool, device=dev)
         traj = self._traj(0)
         goal_slot, gs_stride = None, 0
         if self._goals_buf is not None and self._goals_sparse:
@@ -750,7 +758,7 @@ class ParticleRollout(object):
             mb = {name: v[m * k:(m + 1) * k] for name, v in cols.items()}
             yield ({name: v.detach().cpu().numpy() for name, v in mb.items()} if numpy else mb)
 
-    def _phase_export(self, epochs, batch_size, generator):
+    def _phase_export(self, epochs, batch_size, generator, out=None):
         """-> (columns of all `epochs` minibatches back to back [epochs * k, ...], k = transitions per minibatch): one draw, one launch"""
         epochs = int(epochs)
         pos, tt, ee = self._sample_positions(batch_size, epochs, generator)
@@ -759,9 +767,9 @@ class ParticleRollout(object):
         flat = pos.reshape(-1)
         if tt is None:
             E = self.env.E
-            cols = self.as_reference_batch(torch.div(flat, E, rounding_mode="floor"), flat % E, numpy=False)
+            cols = self.as_reference_batch(torch.div(flat, E, rounding_mode="floor"), flat % E, numpy=False, out=out)
         else:
-            cols = self.as_reference_batch(tt[flat], ee[flat], numpy=False)
+            cols = self.as_reference_batch(tt[flat], ee[flat], numpy=False, out=out)
         return cols, k
 
     def on_policy_phase(self, epochs=24, batch_size=128, generator=None, l_action=5):

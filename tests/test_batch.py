@@ -245,3 +245,65 @@ def test_phase_feeds_equal_per_minibatch_feeds():
                     checked += 1
     assert checked >= 5 * 40
     ro.close()
+
+
+@pytest.mark.gpu
+def test_phase_plan_replays_equal_eager_feeds():
+    """OnPolicyPhasePlan: the data movement of every train_step of a phase as ONE hipGraph replay over persistent tensors.  Two
+    phases (the second re-uses every tensor and every graph): each replayed minibatch's feeds equal the eager torch composition
+    on that phase's columns; the session stand-in writes pseudo-random outputs that depend on the phase into buffers it keeps."""
+    from cm3_amd import batch as BR
+    from cm3_amd.particle import VecParticleEnv
+    from cm3_amd.rollout import ParticleRollout
+    from tests.helpers import load_cfg
+    dev = "cuda:0"
+    env = VecParticleEnv(load_cfg("particle_stage2_cross.json"), 4, 0.2, 33, 128, device=dev, dtype=torch.float32, auto_reset=True, seed=8)
+    env.reset()
+    ro = ParticleRollout(env, n_ticks=50, use_graph=False)
+    M, K, N = 4, 29, 4
+    R = K * N
+    bufs = {"acts": torch.zeros(R, dtype=torch.int64, device=dev), "probs": torch.zeros(R, 5, dtype=torch.float64, device=dev),
+            "q": torch.zeros(R * N * 5, dtype=torch.float64, device=dev)}
+
+    def run(ops, feed):                      # (outputs live in fixed buffers: a captured consumer reads the same addresses every replay)
+        rows = max([v.shape[0] for v in feed.values() if torch.is_tensor(v) and v.dim() > 0] or [1])
+        outs = []
+        for op in ops:
+            if op.endswith("_op") or op == "list_update_target_ops":
+                outs.append(None)
+            elif op == "action_samples_target":
+                outs.append(bufs["acts"])
+            elif op == "probs":
+                outs.append(bufs["probs"])
+            else:
+                outs.append(bufs["q"][:rows])
+        return outs
+
+    plan = BR.OnPolicyPhasePlan(ro, run, 0.99, 0.1, epochs=M, batch_size=K)
+    g = torch.Generator(device=dev).manual_seed(9)
+    ptrs = None
+    for phase in range(2):
+        ro.collect()
+        bufs["acts"].copy_(torch.randint(0, 5, (R,), generator=g, device=dev))
+        bufs["probs"].copy_(torch.rand(R, 5, generator=g, device=dev, dtype=torch.float64))
+        bufs["q"].copy_(torch.rand(R * N * 5, generator=g, device=dev, dtype=torch.float64))
+        plan.refresh(g)
+        if ptrs is None:
+            ptrs = {k: v.data_ptr() for k, v in plan.cols.items()}
+        assert ptrs == {k: v.data_ptr() for k, v in plan.cols.items()}          # persistent
+        checked = 0
+        for k in range(M):
+            calls = plan.step(k)
+            torch.cuda.synchronize()
+            cols, _ = plan.minibatch(k)
+            want = BR.train_step_feeds({n: v.clone() for n, v in cols.items()}, run, 0.99, 0.1, device_tiling=False)
+            assert [c[0] for c in calls] == [c[0] for c in want]
+            for (ops, fa), (_, fb) in zip(calls, want):
+                for name in fb:
+                    if torch.is_tensor(fb[name]):
+                        assert fa[name].dtype == fb[name].dtype and fa[name].shape == fb[name].shape, (phase, k, ops, name)
+                        assert torch.equal(fa[name], fb[name]), (phase, k, ops, name)
+                        checked += 1
+        assert checked >= M * 40
+    plan.close()
+    ro.close()

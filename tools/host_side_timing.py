@@ -148,6 +148,25 @@ def measure(device, copy_gbps=None, n_envs=4096, n_agents=4, cfg_name="particle_
                           "what": "ParticleRollout.collect (330 ticks) + on_policy_phase(24, 128) (one export launch + one pair of tiling "
                                   "launches for all 24 minibatches) + cm3_amd.batch.train_step_feeds x 24 with a stand-in session whose "
                                   "outputs are preallocated; round 5: ~9 ms"}
+    # ... and with the train_steps' data movement as hipGraph replays over persistent tensors (cm3_amd.batch.OnPolicyPhasePlan)
+    plan = B.OnPolicyPhasePlan(ro, run128, 0.99, 0.1, epochs=24, batch_size=128)
+
+    def phase_graph(with_collect=True):
+        if with_collect:
+            ro.collect()
+        plan.refresh(g)
+        n = 0
+        for k in range(24):
+            n += len(plan.step(k))
+        return n
+    phase_graph()
+    s_pg_feeds, _ = _time(lambda: phase_graph(False), device, reps=5)
+    s_pg, n_calls_g = _time(phase_graph, device, reps=5)
+    out["phase_total_graph"] = {"ms": s_pg * 1e3, "collect_ms": s_coll * 1e3, "export_and_feeds_ms": s_pg_feeds * 1e3, "sess_runs": int(n_calls_g),
+                                "what": "the same phase through OnPolicyPhasePlan: persistent columns / static feeds (refresh: one export launch + "
+                                        "one pair of tiling launches) and ONE hipGraph replay per minibatch for everything train_step_feeds "
+                                        "enqueues; the stand-in session does no GPU work, a real one would be captured with it"}
+    plan.close()
     # (f4) replay: add the whole phase, sample 128
     cols = ro.as_reference_batch(numpy=False)
     B_all = cols["reward"].shape[0]
