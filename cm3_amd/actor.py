@@ -238,8 +238,10 @@ class CheckersActor(object):
 
     def fused_rollout_ok(self, env):
         """cm3_policy_rollout_checkers covers the reference's configurations: split-float16 actor, one agent at stage 1 or two at
-        stage 2, the 3 x 8 band with n_obs 2."""
-        return (self.precision == "f16x3" and env.n == self.n and env.n in (1, 2) and (self.stage > 1) == (env.n > 1)
+        stage 2, the 3 x 8 band with n_obs 2 -- and actor and env must share seed and env_id_base (one Philox key; otherwise
+        collect() falls back to a launch pair per tick, whose actor launch takes its own key)."""
+        same_key = (self.seed & 0xFFFFFFFFFFFFFFFF) == int(env._desc.seed) and self.env_id_base == int(env._desc.env_id_base)
+        return (self.precision == "f16x3" and same_key and env.n == self.n and env.n in (1, 2) and (self.stage > 1) == (env.n > 1)
                 and env.K == 5 and env.R == 3 and env.C == 8 and env.grid_stride % 4 == 0 and env.obst_stride % 4 == 0)
 
     def act(self, env, epsilon, actions_prev=None, return_probs=False):

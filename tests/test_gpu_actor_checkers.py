@@ -473,3 +473,16 @@ def test_checkers_policy_rollout_one_launch_against_the_two_oracles():
     assert worst < 2e-5, worst          # the stated float32 tolerance of the actor rows
     assert ok.mean() > 0.9
     ro.close()
+
+
+def test_checkers_policy_rollout_short_soak():
+    """tools/ck_policy_soak.py for ten seconds per stage: identical rollouts (restarts inside the launch) reproduce the first one bit for
+    bit, launch after launch -- the kernel runs two waves per SIMD through float16 matrix phases next to integer / float64 code, the
+    setting in which round 5 found a chip fault (profiles/r05_policy_fault.txt).  The long soak is profiles/r06_ck_policy_soak.txt."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import ck_policy_soak
+    for stage, E in ((2, 8192), (1, 4096)):
+        r = ck_policy_soak.soak(10.0, E, stage=stage, verbose=False)
+        assert r["launches"] >= 30 and r["mismatching_launches"] == 0, r
