@@ -335,3 +335,44 @@ def test_two_rank_segmented_phase_on_one_gpu(tmp_path):
     tot = parts[0]["moments"] + parts[1]["moments"]
     assert torch.allclose(tot.cuda(), ro._norm.moments, rtol=1e-12, atol=0)
     ro.close()
+
+
+@pytest.mark.parametrize("stage", [2, 1])
+def test_policy_driven_checkers_shards_reproduce_the_single_process_rollout(stage):
+    """The one-launch Checkers policy rollout under env sharding (round 6): rank r holds envs [r E, (r + 1) E) with env_id_base = r E;
+    the sampling uniforms and, for one agent, the per-episode goals are keyed by the GLOBAL env id (actor and env share seed and
+    env_id_base), so two shards on one GPU are, bit for bit, the rollout of one process holding all envs -- actions, probabilities,
+    observations, rewards, terminal captures."""
+    import numpy as np
+    import cm3_amd
+    from cm3_amd.actor import CheckersActor
+    from cm3_amd.checkers import VecCheckersEnv
+    from cm3_amd.rollout import CheckersRollout
+    from oracle import actor_checkers_oracle as AO
+    N = 2 if stage == 2 else 1
+    cfg = cm3_amd.load_config("checkers_stage%d" % stage)
+    w = AO.init_weights(np.random.default_rng(12), N)
+    T, E = 33, 1024 + 96
+    halves = [(0, 512 + 96), (512 + 96, 512)]
+    goals = np.eye(2) if N > 1 else None
+    names = ("actions", "probs", "reward", "local_rewards", "done", "vec", "obs_self_v", "obs_others", "term_vec", "term_obs_self_v", "goal_slots")
+
+    def run(base, n, all_goals):
+        env = VecCheckersEnv(cfg["init"], N, 9, n, device="cuda:0", auto_reset=True, env_id_base=base, seed=4242)
+        actor = CheckersActor(w, N, stage=stage, device="cuda:0", seed=4242, env_id_base=base, precision="f16x3")
+        assert actor.fused_rollout_ok(env)
+        ro = CheckersRollout(env, n_ticks=T, record_probs=True)
+        g = goals if N > 1 else all_goals[base:base + n]
+        ro.collect(g, policy=actor, epsilon=0.2)
+        ro.collect(g, policy=actor, epsilon=0.2)
+        torch.cuda.synchronize()
+        out = {k: getattr(ro, k).clone() for k in names}
+        out["grid"], out["obs_self_t"] = ro.grid.clone(), ro.obs_self_t.clone()
+        ro.close()
+        return out
+    first_goals = np.eye(2)[np.random.default_rng(1).integers(0, 2, (E, 1))]          # stage 1: one random one-hot goal per env
+    whole = run(0, E, first_goals)
+    parts = [run(b, n, first_goals) for b, n in halves]
+    for k in list(names) + ["grid", "obs_self_t"]:
+        assert torch.equal(torch.cat([p[k] for p in parts], dim=1), whole[k]), k
+    assert int(whole["done"].sum()) >= 3 * E
