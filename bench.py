@@ -721,14 +721,14 @@ def measure_other_config(name, args, device, steps=20, cpu_budget_s=6.0):
     floor = launch_ceiling(device, "checkers" if kind == "checkers" else "particle", N, E, bytes_per_launch, launch_s * 1e6)
     rec["roofline"]["launch_floor"] = floor
     rec["roofline"]["ceiling_frac"] = floor["ceiling_frac"]
+    if name == "c3":          # (BEFORE the CPU baseline: six seconds of host-only work let the GPU's clocks drop, and the first
+        rec["policy"] = measure_checkers_policy(cfg, E, device)       # collects after it measured 15.3 us per tick against 13.9)
     if name == "c3" and not args.no_cpu_baseline:
         rec["cpu_baseline_checkers"] = cpu_baseline_checkers(cfg, budget_s=cpu_budget_s)
-    if name == "c3":
-        rec["policy"] = measure_checkers_policy(cfg, E, device)
     return rec
 
 
-def measure_checkers_policy(cfg, E, device, reps=20):
+def measure_checkers_policy(cfg, E, device, reps=40):
     """POLICY-driven Checkers collection at the workload's BASELINE size (train_onpolicy.py:309-347, the branch the reference takes
     after its 50 pretrain episodes): CheckersRollout.collect(goals, policy=actor) with the on-device split-float16 actor (random
     float32 weights of the reference's shapes, epsilon 0.1), full trajectory storage, env reset per collect -- ONE launch per
@@ -751,7 +751,7 @@ def measure_checkers_policy(cfg, E, device, reps=20):
     actor = CheckersActor(wts, Nc, stage=2 if Nc > 1 else 1, device=device, precision="f16x3")
     one = actor.fused_rollout_ok(env)
     ro = CheckersRollout(env, n_ticks=EP_TICKS)
-    for _ in range(3):
+    for _ in range(20):                     # ~10 ms of launches: the clocks are up when the timed collects start
         ro.collect(goals, policy=actor, epsilon=0.1)
     torch.cuda.synchronize(device)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -1047,10 +1047,11 @@ def main():
         return 0
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20,
+    ap.add_argument("--steps", type=int, default=200,
                     help="timed steps; one step = one collection phase of %d ticks (c4: one 33-tick rollout + normalisation)"
                          % PHASE_TICKS)
-    ap.add_argument("--warmup", type=int, default=5, help="untimed warm-up steps")
+    ap.add_argument("--warmup", type=int, default=20, help="untimed warm-up steps (defaults: 200 timed phases = ~0.16 s of launches at C2 -- round 5's "
+                         "20 gave a 16 ms timed region, too short for a coarse GPU-busy sampler to see)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS) + ["c1"], default="c2",
                     help="c2 (default, the configuration BASELINE.json's metric is quoted on) | c3 | c4 | c5 | c1 (stage 1, one agent, one "
                          "env: CPU only -- parity pass / fail against the reference-recorded fixtures + the port's env-steps/s)")
