@@ -1100,7 +1100,7 @@ def main():
                          % (rank, args.gpus, args.gpus, n_visible, local_rank))
         sys.stderr.flush()
         if under_launcher:
-            time.sleep(2.0)     # the launcher ends the other ranks at the first exit: let every rank say which device it lacks
+            time.sleep(6.0)     # the launcher ends the other ranks at the first exit: let every rank say which device it lacks
         raise SystemExit(1)
     if rank == 0:
         graft.build()

@@ -726,6 +726,55 @@ __device__ __forceinline__ void gemm_x3(const _Float16 *Ah, const _Float16 *Al, 
   }
 }
 
+// ALL weights of a short layer (KS <= 5 k-steps) at once, requested by the caller BEFORE the previous layer's epilogue and barrier
+// (round 6): the small layers have 15-48 matrix instructions and could not hide the L2 round trips of a ring -- conv_linear's five
+// k-steps were three exposed round trips (~2.5 k cycles for 240 cycles of matrix work).  Same products in the same order as gemm_x3.
+template <int CT, int KS>
+__device__ __forceinline__ void load_bx_all(const float *Bh, const float *Bl, int ct0, int lane, uint4 (&ball)[KS][2][CT]) {
+#pragma unroll
+  for (int st = 0; st < KS; ++st)
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      ball[st][0][c] = (reinterpret_cast<const uint4 *>(Bh) + CM3_PROBE_BIDX(((size_t)(ct0 + c) * KS + st)) * 64 + lane)[0];
+      ball[st][1][c] = (reinterpret_cast<const uint4 *>(Bl) + CM3_PROBE_BIDX(((size_t)(ct0 + c) * KS + st)) * 64 + lane)[0];
+    }
+}
+
+template <int RT, int CT, int KS, bool ALO>
+__device__ __forceinline__ void gemm_x3_pre(const _Float16 *Ah, const _Float16 *Al, int lda, int rt0, int lane,
+                                            const uint4 (&ball)[KS][2][CT], f32x4 (&acc)[RT][CT]) {
+  const int col = lane & 15, hi = lane >> 4;
+#pragma unroll
+  for (int st = 0; st < KS; ++st) {
+    f16x8 ah[RT], al[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      ah[t] = *reinterpret_cast<const f16x8 *>(Ah + (16 * (rt0 + t) + col) * lda + 32 * st + 8 * hi);
+      if constexpr (ALO) al[t] = *reinterpret_cast<const f16x8 *>(Al + (16 * (rt0 + t) + col) * lda + 32 * st + 8 * hi);
+    }
+    f16x8 wh[CT], wl[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      __builtin_memcpy(&wh[c], &ball[st][0][c], 16);
+      __builtin_memcpy(&wl[c], &ball[st][1][c], 16);
+    }
+    if constexpr (ALO) {
+#pragma unroll
+      for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[c], al[t], acc[t][c], 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+      for (int c = 0; c < CT; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[c], ah[t], acc[t][c], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+      for (int c = 0; c < CT; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[c], ah[t], acc[t][c], 0, 0, 0);
+  }
+}
+
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 // this lane's four bias values per column tile (units 16 (ct0 + c) + 4 (l >> 4) + reg)
@@ -826,12 +875,30 @@ static_assert(2 * 64 * ck_actor::kLhC1 * 2 <= kCkX3HBytes, "the C1 planes must f
 // 22.7 us per launch at 16 384 rows, same bits (profiles/r06_checkers_policy.txt) -- the h2 passes are MFMA-bound now (19 cycles per
 // matrix instruction per SIMD), the rest of the launch is the serial chain of small layers.
 //   tiles (16 x 16) per layer:   conv 4 x 10   lin 4 x 2   branch_self / branch_others / h2 4 x 16   out 4 x 1
-//   per wave:                    conv 1 x 5    lin 1 x 1   4 x 2 (all rows, 32 units)              out: waves 0..3
+//   per wave:                    conv 4 x 1 + 1 x 1   lin 1 x 1   4 x 2 (all rows, 32 units)       out: every wave its 32 units
 // ORDER (round 6): the others branch goes FIRST -- h2's accumulators start with branch_others W_others_h2 (k ascending) and the
 // branch_self terms follow -- so that what the others branch contributes is the accumulators' state after ck_x3_others(): a pure
 // function of a row's v_obs_others.  The whole-episode kernel (policy_checkers.hip) reads that state from a table instead
 // (cm3_actor_checkers_pack builds it with this very function over the 91 cells another agent can stand on), bit for bit.
 constexpr int kCkBCT = 2;   // column tiles per wave in the 256-wide layers
+// The conv's 4 x 10 output tiles over eight waves: wave w takes column tile w for ALL four row tiles and one tile of the last two
+// column tiles (column tile 8 + (w >> 2), row tile w & 3).  (First cut of round 6: row tile w & 3 x five column tiles -- four waves then
+// loaded the SAME 30 KB of weights each, 240 KB per workgroup and tick through a 64 B / clock L1 path for 61 KB of distinct weights; a
+// what-if build without the three small layers showed them costing 6 of a tick's 15 us for 0.7 us of matrix work.  Now 96 KB.)
+typedef uint4 CkConvB[ck_actor::kKConvX / 32][2][2];   // [k-step][hi | lo plane][own column tile | the shared one]
+__device__ __forceinline__ void load_bx_all_into(const float *Bh, const float *Bl, int ct, int lane, int slot, CkConvB &b) {
+  constexpr int KS = ck_actor::kKConvX / 32;
+#pragma unroll
+  for (int st = 0; st < KS; ++st) {
+    b[st][0][slot] = (reinterpret_cast<const uint4 *>(Bh) + CM3_PROBE_BIDX(((size_t)ct * KS + st)) * 64 + lane)[0];
+    b[st][1][slot] = (reinterpret_cast<const uint4 *>(Bl) + CM3_PROBE_BIDX(((size_t)ct * KS + st)) * 64 + lane)[0];
+  }
+}
+// ALL of the conv's weights of wave w (12 sixteen-byte loads)
+__device__ __forceinline__ void ck_x3_load_conv(const float *pk, int w, int lane, CkConvB &b) {
+  load_bx_all_into(pk + ck_actor::kXConvH, pk + ck_actor::kXConvL, w, lane, 0, b);
+  load_bx_all_into(pk + ck_actor::kXConvH, pk + ck_actor::kXConvL, 8 + (w >> 2), lane, 1, b);
+}
 #ifndef CM3_X3_CONV_STAMP
 #define CM3_X3_CONV_STAMP 3   // (probe builds: the timeline slot of "conv done"; the policy probe moves it off ck_tick_env's slot 3)
 #endif
@@ -867,7 +934,7 @@ __device__ __forceinline__ void ck_x3_others(const CkX3Planes &L, const float *p
 }
 
 // conv -> conv_linear -> branch_self -> h2 (+= on acc2) -> actor_out.  Enter with X0 and the tail of X2 visible and the H planes free;
-// b_conv: the conv's first weights, requested by the caller ahead of time.  Leaves the workgroup BEHIND its last barrier with the
+// b_conv: ALL of the conv's weights (load_bx_all), requested by the caller ahead of time.  Leaves the workgroup BEHIND its last barrier with the
 // logits of rows [16w, 16w + 16) written by wave w < 4 (not yet visible to other waves).
 // HOOKS: the whole-episode kernel starts acc2 from the others-branch table and fetches those rows along the way -- after_conv()
 // (behind the conv's barrier: X0 is dead, the conv's 120 registers of weights are gone), after_lin() (behind conv_linear's barrier)
@@ -878,21 +945,35 @@ struct CkNoHooks {
   __device__ __forceinline__ void before_h2(f32x4 (&)[4][kCkBCT]) const {}
 };
 template <class HOOKS = CkNoHooks>
-__device__ __forceinline__ void ck_x3_self_chain(const CkX3Planes &L, const float *pk, int w, int lane, const uint4 (&b_conv)[2][5],
+__device__ __forceinline__ void ck_x3_self_chain(const CkX3Planes &L, const float *pk, int w, int lane, const CkConvB &b_conv,
                                                  f32x4 (&acc2)[4][kCkBCT], HOOKS hooks = HOOKS()) {
   using namespace ck_actor;
   constexpr int BCT = kCkBCT;
   const int s_rt0 = w & 3, s_half = w >> 2;
-  uint4 b_lin[2][1], b_self[2][BCT], b_h2[2][BCT];
+  uint4 b_lin[kKLin / 32][2][1], b_self[kKSelfX / 32][2][BCT], b_h2[2][BCT];
   // ---- conv (Toeplitz): X0 [64][96] -> C1 [64][160], relu ------------------------------------------------------------------------
+#ifndef CM3_PROBE_SKIP_SMALL   // (probe builds only: without conv / conv_linear / branch_self)
   {
-    f32x4 acc[1][5];
-    float4 bias[5];
-    load_bias4<5>(pk + kPConvB, 5 * s_half, lane, bias);
+    constexpr int KS = kKConvX / 32;
+    uint4 b_own[KS][2][1], b_sh[KS][2][1];
+#pragma unroll
+    for (int st = 0; st < KS; ++st)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) {
+        b_own[st][pl][0] = b_conv[st][pl][0];
+        b_sh[st][pl][0] = b_conv[st][pl][1];
+      }
+    f32x4 acc[4][1], acc_sh[1][1];
+    float4 bias[1], bias_sh[1];
+    load_bias4<1>(pk + kPConvB, w, lane, bias);
+    load_bias4<1>(pk + kPConvB, 8 + s_half, lane, bias_sh);
     bias_tiles(bias, acc);
-    gemm_x3<1, 5, kKConvX / 32, false>(L.X0, L.X0, kLhX0, s_rt0, pk + kXConvH, pk + kXConvL, 5 * s_half, lane, b_conv, acc);
-    load_bx<1, kKLin / 32>(pk + kXLinH, pk + kXLinL, s_half, lane, b_lin);
-    store_relu_x3b<1, 5>(L.C1h, L.C1l, kLhC1, s_rt0, 5 * s_half, lane, acc);
+    bias_tiles(bias_sh, acc_sh);
+    gemm_x3_pre<4, 1, KS, false>(L.X0, L.X0, kLhX0, 0, lane, b_own, acc);
+    gemm_x3_pre<1, 1, KS, false>(L.X0, L.X0, kLhX0, s_rt0, lane, b_sh, acc_sh);
+    load_bx_all<1, kKLin / 32>(pk + kXLinH, pk + kXLinL, s_half, lane, b_lin);
+    store_relu_x3b<4, 1>(L.C1h, L.C1l, kLhC1, 0, w, lane, acc);
+    store_relu_x3b<1, 1>(L.C1h, L.C1l, kLhC1, s_rt0, 8 + s_half, lane, acc_sh);
   }
   __syncthreads();
   CM3_STAMP(CM3_X3_CONV_STAMP, false);
@@ -903,8 +984,8 @@ __device__ __forceinline__ void ck_x3_self_chain(const CkX3Planes &L, const floa
     float4 bias[1];
     load_bias4<1>(pk + kPLinB, s_half, lane, bias);
     bias_tiles(bias, acc);
-    gemm_x3<1, 1, kKLin / 32, true>(L.C1h, L.C1l, kLhC1, s_rt0, pk + kXLinH, pk + kXLinL, s_half, lane, b_lin, acc);
-    load_bx<BCT, kKSelfX / 32>(pk + kXSelfH, pk + kXSelfL, BCT * w, lane, b_self);
+    gemm_x3_pre<1, 1, kKLin / 32, true>(L.C1h, L.C1l, kLhC1, s_rt0, lane, b_lin, acc);
+    load_bx_all<BCT, kKSelfX / 32>(pk + kXSelfH, pk + kXSelfL, BCT * w, lane, b_self);
     store_relu_x3b<1, 1>(L.X2h, L.X2l, kLhX2, s_rt0, s_half, lane, acc);
   }
   __syncthreads();
@@ -916,15 +997,25 @@ __device__ __forceinline__ void ck_x3_self_chain(const CkX3Planes &L, const floa
     float4 bias[BCT];
     load_bias4<BCT>(pk + kPSelfB, BCT * w, lane, bias);
     bias_tiles(bias, acc);
-    gemm_x3<4, BCT, kKSelfX / 32, true>(L.X2h, L.X2l, kLhX2, 0, pk + kXSelfH, pk + kXSelfL, BCT * w, lane, b_self, acc);
+    gemm_x3_pre<4, BCT, kKSelfX / 32, true>(L.X2h, L.X2l, kLhX2, 0, lane, b_self, acc);
     load_bx<BCT, 8>(pk + kPH2Sh, pk + kPH2Sl, BCT * w, lane, b_h2);
     store_relu_x3b<4, BCT>(L.Hh, L.Hl, kLdHb, 0, BCT * w, lane, acc);
   }
   __syncthreads();
   CM3_STAMP(5, false);
+#else
+  hooks.after_conv();
+  hooks.after_lin();
+  load_bx<BCT, 8>(pk + kPH2Sh, pk + kPH2Sl, BCT * w, lane, b_h2);
+  __syncthreads();
+#endif
   hooks.before_h2(acc2);
   // ---- h2 = relu(b + branch_others W_others_h2 [both already in acc2] + branch_self W_self_h2) ------------------------------------
+#ifdef CM3_PROBE_H2_KS      // (probe builds only: the h2 pass with fewer k-steps)
+  gemm_x3<4, BCT, CM3_PROBE_H2_KS, true>(L.Hh, L.Hl, kLdHb, 0, pk + kPH2Sh, pk + kPH2Sl, BCT * w, lane, b_h2, acc2);
+#else
   gemm_x3<4, BCT, 8, true>(L.Hh, L.Hl, kLdHb, 0, pk + kPH2Sh, pk + kPH2Sl, BCT * w, lane, b_h2, acc2);
+#endif
   // ---- actor_out, round 6: every wave contracts ITS 32 units of h2 straight from the accumulator registers -- a lane's eight values of
   // an agent row (two column tiles x four units) are the eight consecutive k of one float16 matrix instruction's B operand once the
   // output weights are packed in that unit order (k_ck_actor_pack, layer 6) -- and leaves a partial logit per agent row in LDS; the
@@ -1124,8 +1215,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) k
   const size_t row_base = (size_t)blockIdx.x * 64;
   const float *pk = p.packed;
   CM3_STAMP(0, false);
-  uint4 b_conv[2][5];
-  load_bx<5, kKConvX / 32>(pk + kXConvH, pk + kXConvL, 5 * (w >> 2), lane, b_conv);
+  CkConvB b_conv;
+  ck_x3_load_conv(pk, w, lane, b_conv);
   if (w < 4) ck_x3_stage_inputs(p, L, tid, row_base, rows);
   CM3_STAMP(1, true);
   __syncthreads();

@@ -294,7 +294,7 @@ template <int N> __global__ void __launch_bounds__(512) __attribute__((amdgpu_wa
   const size_t row_base = (size_t)blockIdx.x * 64;
   const bool stage2 = q.stage > 1;
 
-  uint4 b_conv[2][5];
+  CkConvB b_conv;
 
   // ---- the env side: lane (el, g) of the env waves ------------------------------------------------------------------------------
   const bool env_wave = w < ENV_WAVES;                 // (wave-uniform)
@@ -384,7 +384,7 @@ template <int N> __global__ void __launch_bounds__(512) __attribute__((amdgpu_wa
     const float *pkt = (const float *)pkg;
     // (the conv's first weights are requested here, not ahead of the env work: held across it or across the closing barrier they cost
     // the two-agent build 14 spilled registers)
-    load_bx<5, kKConvX / 32>(pkt + kXConvH, pkt + kXConvL, 5 * (w >> 2), lane, b_conv);
+    ck_x3_load_conv(pkt, w, lane, b_conv);
     f32x4 acc2[4][kCkBCT];
     CkpTableHooks hooks;
     hooks.tab = stage2 ? pkt + kPOthTab : nullptr; hooks.pk = pkt; hooks.sCell = sCell; hooks.sT = sT; hooks.w = w; hooks.lane = lane;
@@ -414,6 +414,7 @@ template <int N> __global__ void __launch_bounds__(512) __attribute__((amdgpu_wa
     ckp_barrier_lds();   // actions are in LDS; every wave is done with this tick's inputs and activations
     CM3_STAMP(14, false);
     // ---- env step of the workgroup's envs (checkers.py:228-262): k_checkers_step_fast's tick with the actions just sampled --------
+#ifndef CM3_PROBE_SKIP_ENV   // (probe builds only, tools/r6/ck_whatif.sh: what each part of the tick costs the UNSTAMPED kernel)
     if (env_wave) {
 #ifdef CM3_SPAN_MARKS
       unsigned long long span_marks_unused[8];   // (the marks build instruments the STEP kernels; ck_tick_env's marks land here)
@@ -463,6 +464,7 @@ template <int N> __global__ void __launch_bounds__(512) __attribute__((amdgpu_wa
       if (g == 0) sMeta[el] = make_int2((int)lv.episode, lv.steps);
       CM3_STAMP(15, false);
     }
+#endif
     ckp_barrier_lds();
     CM3_STAMP(8, false);
   }
