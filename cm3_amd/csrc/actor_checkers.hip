@@ -665,10 +665,11 @@ __device__ __forceinline__ void load_bx(const float *Bh, const float *Bl, int ct
 // (4 (l >> 4) + reg of column tile c) of ONE agent row (16 (rt0 + t) + (l & 15)) -- contiguous in the next layer's row-major
 // plane: one 8-byte LDS store per plane and tile instead of four 2-byte stores (the epilogues were a quarter of this kernel).
 // Both operand fragments are "8 consecutive k of index l & 15" in the same registers as before; only their roles swap.
-template <int RT, int CT, int KS, bool ALO>
+// SWZ: the activation planes written by store_relu_x3b<.., true> -- 16-byte chunk q of a row sits at q ^ ((row >> 2) & 1), see there.
+template <int RT, int CT, int KS, bool ALO, bool SWZ = false>
 __device__ __forceinline__ void gemm_x3(const _Float16 *Ah, const _Float16 *Al, int lda, int rt0, const float *Bh, const float *Bl,
                                         int ct0, int lane, const uint4 (&b0)[2][CT], f32x4 (&acc)[RT][CT]) {
-  const int col = lane & 15, hi = lane >> 4;
+  const int col = lane & 15, hi = SWZ ? ((lane >> 4) ^ ((lane >> 2) & 1)) : (lane >> 4);
   const uint4 *bsrc[2][CT];
 #pragma unroll
   for (int c = 0; c < CT; ++c) {
@@ -740,10 +741,10 @@ __device__ __forceinline__ void load_bx_all(const float *Bh, const float *Bl, in
     }
 }
 
-template <int RT, int CT, int KS, bool ALO>
+template <int RT, int CT, int KS, bool ALO, bool SWZ = false>
 __device__ __forceinline__ void gemm_x3_pre(const _Float16 *Ah, const _Float16 *Al, int lda, int rt0, int lane,
                                             const uint4 (&ball)[KS][2][CT], f32x4 (&acc)[RT][CT]) {
-  const int col = lane & 15, hi = lane >> 4;
+  const int col = lane & 15, hi = SWZ ? ((lane >> 4) ^ ((lane >> 2) & 1)) : (lane >> 4);
 #pragma unroll
   for (int st = 0; st < KS; ++st) {
     f16x8 ah[RT], al[RT];
@@ -808,10 +809,14 @@ __device__ __forceinline__ void split4(const float (&v)[4], f16x4 &vh, f16x4 &vl
   }
 }
 
-// O[agent row][unit] = relu(acc) as float16 hi / lo planes, transposed tiles (see gemm_x3); the bias is already in acc (bias_tiles)
-template <int RT, int CT>
+// O[agent row][unit] = relu(acc) as float16 hi / lo planes, transposed tiles (see gemm_x3); the bias is already in acc (bias_tiles).
+// SWZ: lanes 0..15 of an 8-byte store are rows 0..15 at ONE column, and a row stride that keeps the 16-byte reads conflict-free
+// (8 x odd dwords) puts rows r, r + 4, r + 8, r + 12 on the same banks -- a 4-way conflict on every store of every epilogue (224 per
+// workgroup and tick, most of the kernel's SQ_LDS_BANK_CONFLICT).  With the 16-byte chunks of rows 4..7 and 12..15 swapped in pairs
+// (chunk q at q ^ ((row >> 2) & 1)) the stores are 2-way and the reads stay conflict-free; a reader flips the same bit (gemm_x3).
+template <int RT, int CT, bool SWZ = false>
 __device__ __forceinline__ void store_relu_x3b(_Float16 *Oh, _Float16 *Ol, int ldo, int rt0, int ct0, int lane, const f32x4 (&acc)[RT][CT]) {
-  const int col = lane & 15, hi = lane >> 4;
+  const int col = lane & 15, hi = SWZ ? ((lane >> 4) ^ ((lane >> 1) & 2)) : (lane >> 4);
 #pragma unroll
   for (int c = 0; c < CT; ++c) {
 #pragma unroll
@@ -924,11 +929,11 @@ __device__ __forceinline__ void ck_x3_others(const CkX3Planes &L, const float *p
     bias_tiles(bias_oth, acc);
     gemm_x3<4, BCT, 1, true>(L.XOh, L.XOl, kLhXO, 0, pk + kXOthH, pk + kXOthL, BCT * w, lane, b_oth, acc);
     load_bx<BCT, 8>(pk + kPH2Oh, pk + kPH2Ol, BCT * w, lane, b_h2);
-    store_relu_x3b<4, BCT>(L.Hh, L.Hl, kLdHb, 0, BCT * w, lane, acc);
+    store_relu_x3b<4, BCT, true>(L.Hh, L.Hl, kLdHb, 0, BCT * w, lane, acc);
   }
   __syncthreads();
   CM3_STAMP(8, false);
-  gemm_x3<4, BCT, 8, true>(L.Hh, L.Hl, kLdHb, 0, pk + kPH2Oh, pk + kPH2Ol, BCT * w, lane, b_h2, acc2);
+  gemm_x3<4, BCT, 8, true, true>(L.Hh, L.Hl, kLdHb, 0, pk + kPH2Oh, pk + kPH2Ol, BCT * w, lane, b_h2, acc2);
   CM3_STAMP(9, true);
   __syncthreads();
 }
@@ -953,6 +958,7 @@ __device__ __forceinline__ void ck_x3_self_chain(const CkX3Planes &L, const floa
   uint4 b_lin[kKLin / 32][2][1], b_self[kKSelfX / 32][2][BCT], b_h2[2][BCT];
   // ---- conv (Toeplitz): X0 [64][96] -> C1 [64][160], relu ------------------------------------------------------------------------
 #ifndef CM3_PROBE_SKIP_SMALL   // (probe builds only: without conv / conv_linear / branch_self)
+#ifndef CM3_PROBE_SKIP_CONV
   {
     constexpr int KS = kKConvX / 32;
     uint4 b_own[KS][2][1], b_sh[KS][2][1];
@@ -972,26 +978,34 @@ __device__ __forceinline__ void ck_x3_self_chain(const CkX3Planes &L, const floa
     gemm_x3_pre<4, 1, KS, false>(L.X0, L.X0, kLhX0, 0, lane, b_own, acc);
     gemm_x3_pre<1, 1, KS, false>(L.X0, L.X0, kLhX0, s_rt0, lane, b_sh, acc_sh);
     load_bx_all<1, kKLin / 32>(pk + kXLinH, pk + kXLinL, s_half, lane, b_lin);
-    store_relu_x3b<4, 1>(L.C1h, L.C1l, kLhC1, 0, w, lane, acc);
-    store_relu_x3b<1, 1>(L.C1h, L.C1l, kLhC1, s_rt0, 8 + s_half, lane, acc_sh);
+    store_relu_x3b<4, 1, true>(L.C1h, L.C1l, kLhC1, 0, w, lane, acc);
+    store_relu_x3b<1, 1, true>(L.C1h, L.C1l, kLhC1, s_rt0, 8 + s_half, lane, acc_sh);
   }
+#else
+  load_bx_all<1, kKLin / 32>(pk + kXLinH, pk + kXLinL, s_half, lane, b_lin);
+#endif
   __syncthreads();
   CM3_STAMP(CM3_X3_CONV_STAMP, false);
   hooks.after_conv();
   // ---- conv_linear: C1 [64][160] -> X2[:, 0:32], relu ---------------------------------------------------------------------------
+#ifndef CM3_PROBE_SKIP_LIN
   {
     f32x4 acc[1][1];
     float4 bias[1];
     load_bias4<1>(pk + kPLinB, s_half, lane, bias);
     bias_tiles(bias, acc);
-    gemm_x3_pre<1, 1, kKLin / 32, true>(L.C1h, L.C1l, kLhC1, s_rt0, lane, b_lin, acc);
+    gemm_x3_pre<1, 1, kKLin / 32, true, true>(L.C1h, L.C1l, kLhC1, s_rt0, lane, b_lin, acc);
     load_bx_all<BCT, kKSelfX / 32>(pk + kXSelfH, pk + kXSelfL, BCT * w, lane, b_self);
     store_relu_x3b<1, 1>(L.X2h, L.X2l, kLhX2, s_rt0, s_half, lane, acc);
   }
+#else
+  load_bx_all<BCT, kKSelfX / 32>(pk + kXSelfH, pk + kXSelfL, BCT * w, lane, b_self);
+#endif
   __syncthreads();
   CM3_STAMP(4, false);
   hooks.after_lin();
   // ---- branch_self: X2 [64][64] -> H [64][256], relu; wave w owns units [32w, 32w + 32) from here on ---------------------------------
+#ifndef CM3_PROBE_SKIP_SELF
   {
     f32x4 acc[4][BCT];
     float4 bias[BCT];
@@ -999,8 +1013,11 @@ __device__ __forceinline__ void ck_x3_self_chain(const CkX3Planes &L, const floa
     bias_tiles(bias, acc);
     gemm_x3_pre<4, BCT, kKSelfX / 32, true>(L.X2h, L.X2l, kLhX2, 0, lane, b_self, acc);
     load_bx<BCT, 8>(pk + kPH2Sh, pk + kPH2Sl, BCT * w, lane, b_h2);
-    store_relu_x3b<4, BCT>(L.Hh, L.Hl, kLdHb, 0, BCT * w, lane, acc);
+    store_relu_x3b<4, BCT, true>(L.Hh, L.Hl, kLdHb, 0, BCT * w, lane, acc);
   }
+#else
+  load_bx<BCT, 8>(pk + kPH2Sh, pk + kPH2Sl, BCT * w, lane, b_h2);
+#endif
   __syncthreads();
   CM3_STAMP(5, false);
 #else
@@ -1012,9 +1029,9 @@ __device__ __forceinline__ void ck_x3_self_chain(const CkX3Planes &L, const floa
   hooks.before_h2(acc2);
   // ---- h2 = relu(b + branch_others W_others_h2 [both already in acc2] + branch_self W_self_h2) ------------------------------------
 #ifdef CM3_PROBE_H2_KS      // (probe builds only: the h2 pass with fewer k-steps)
-  gemm_x3<4, BCT, CM3_PROBE_H2_KS, true>(L.Hh, L.Hl, kLdHb, 0, pk + kPH2Sh, pk + kPH2Sl, BCT * w, lane, b_h2, acc2);
+  gemm_x3<4, BCT, CM3_PROBE_H2_KS, true, true>(L.Hh, L.Hl, kLdHb, 0, pk + kPH2Sh, pk + kPH2Sl, BCT * w, lane, b_h2, acc2);
 #else
-  gemm_x3<4, BCT, 8, true>(L.Hh, L.Hl, kLdHb, 0, pk + kPH2Sh, pk + kPH2Sl, BCT * w, lane, b_h2, acc2);
+  gemm_x3<4, BCT, 8, true, true>(L.Hh, L.Hl, kLdHb, 0, pk + kPH2Sh, pk + kPH2Sl, BCT * w, lane, b_h2, acc2);
 #endif
   // ---- actor_out, round 6: every wave contracts ITS 32 units of h2 straight from the accumulator registers -- a lane's eight values of
   // an agent row (two column tiles x four units) are the eight consecutive k of one float16 matrix instruction's B operand once the

@@ -57,7 +57,7 @@ def main():
              ("particle_merge8", 8, 8192), ("particle_merge8", 8, 2048), ("particle_stage2_merge", 2, 8192), ("particle_stage1", 1, 16384)]
     print("%-28s %2s %7s %6s | us per tick at RT = 4 / 2 / 1 / auto" % ("config", "N", "envs", "prec"))
     for cfg_name, N, E in cases:
-        for prec in ("f16x3", "f32"):
+        for prec in os.environ.get("ROW_TILES_PRECS", "f16x3,f32").split(","):
             row = []
             for rt in ("4", "2", "1", ""):
                 env = dict(os.environ)
