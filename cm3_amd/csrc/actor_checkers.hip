@@ -652,6 +652,9 @@ __device__ int cm3_probe_zero = 0;   // (a run-time zero: a literal one lets the
 #else
 #define CM3_PROBE_BIDX(x) (x)
 #endif
+#ifndef CM3_CK_A_BUFS
+#define CM3_CK_A_BUFS 1
+#endif
 template <int CT, int KS>
 __device__ __forceinline__ void load_bx(const float *Bh, const float *Bl, int ct0, int lane, uint4 (&b0)[2][CT]) {
 #pragma unroll
@@ -688,6 +691,19 @@ __device__ __forceinline__ void gemm_x3(const _Float16 *Ah, const _Float16 *Al, 
       bq[1][1][c] = bsrc[1][c][CM3_PROBE_BIDX(64)];
     }
   }
+  // The activation fragments of k-step st + 1 are requested BEFORE the matrix instructions of step st (round 6, late: left to itself the
+  // compiler sinks every LDS read to its first use -- read, wait, two matrix instructions, read, wait, ... -- and the 256-deep h2 pass
+  // ran at 52 % of its matrix time; the scheduling barriers pin the order, the registers hold two steps' fragments)
+  constexpr int NB = CM3_CK_A_BUFS;   // 2: fragments of step st + 1 requested before the matrix instructions of step st; 1: of step st, all at once
+  f16x8 ah[NB][RT], al[NB][RT];
+  auto read_a = [&](int st, int buf) {
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      ah[buf][t] = *reinterpret_cast<const f16x8 *>(Ah + (16 * (rt0 + t) + col) * lda + 32 * st + 8 * hi);
+      if constexpr (ALO) al[buf][t] = *reinterpret_cast<const f16x8 *>(Al + (16 * (rt0 + t) + col) * lda + 32 * st + 8 * hi);
+    }
+  };
+  if (NB == 2) read_a(0, 0);
 #pragma unroll
   for (int st = 0; st < KS; ++st) {
     if (st + 2 < KS) {
@@ -697,12 +713,14 @@ __device__ __forceinline__ void gemm_x3(const _Float16 *Ah, const _Float16 *Al, 
         bq[(st + 2) % 3][1][c] = bsrc[1][c][CM3_PROBE_BIDX((st + 2) * 64)];
       }
     }
-    f16x8 ah[RT], al[RT];
-#pragma unroll
-    for (int t = 0; t < RT; ++t) {
-      ah[t] = *reinterpret_cast<const f16x8 *>(Ah + (16 * (rt0 + t) + col) * lda + 32 * st + 8 * hi);
-      if constexpr (ALO) al[t] = *reinterpret_cast<const f16x8 *>(Al + (16 * (rt0 + t) + col) * lda + 32 * st + 8 * hi);
+    if (NB == 1) {
+      read_a(st, 0);
+      if (KS > 1) __builtin_amdgcn_sched_barrier(0);
+    } else if (KS > 1) {
+      if (st + 1 < KS) read_a(st + 1, (st + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
     }
+    const int cur = NB == 2 ? (st & 1) : 0;
     // the three products one after the other over ALL tiles: RT x CT independent accumulators between two MFMAs on the same one
     f16x8 wh[CT], wl[CT];
 #pragma unroll
@@ -714,16 +732,17 @@ __device__ __forceinline__ void gemm_x3(const _Float16 *Ah, const _Float16 *Al, 
 #pragma unroll
       for (int t = 0; t < RT; ++t)
 #pragma unroll
-        for (int c = 0; c < CT; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[c], al[t], acc[t][c], 0, 0, 0);
+        for (int c = 0; c < CT; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[c], al[cur][t], acc[t][c], 0, 0, 0);
     }
 #pragma unroll
     for (int t = 0; t < RT; ++t)
 #pragma unroll
-      for (int c = 0; c < CT; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[c], ah[t], acc[t][c], 0, 0, 0);
+      for (int c = 0; c < CT; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[c], ah[cur][t], acc[t][c], 0, 0, 0);
 #pragma unroll
     for (int t = 0; t < RT; ++t)
 #pragma unroll
-      for (int c = 0; c < CT; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[c], ah[t], acc[t][c], 0, 0, 0);
+      for (int c = 0; c < CT; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[c], ah[cur][t], acc[t][c], 0, 0, 0);
+    if (KS > 1) __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -745,14 +764,19 @@ template <int RT, int CT, int KS, bool ALO, bool SWZ = false>
 __device__ __forceinline__ void gemm_x3_pre(const _Float16 *Ah, const _Float16 *Al, int lda, int rt0, int lane,
                                             const uint4 (&ball)[KS][2][CT], f32x4 (&acc)[RT][CT]) {
   const int col = lane & 15, hi = SWZ ? ((lane >> 4) ^ ((lane >> 2) & 1)) : (lane >> 4);
+  // every activation fragment of the layer first, ONE wait, then the matrix instructions (see gemm_x3: the compiler's own order is
+  // read, wait, two instructions, read, wait, ...)
+  f16x8 ah[KS][RT], al[KS][RT];
 #pragma unroll
-  for (int st = 0; st < KS; ++st) {
-    f16x8 ah[RT], al[RT];
+  for (int st = 0; st < KS; ++st)
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
-      ah[t] = *reinterpret_cast<const f16x8 *>(Ah + (16 * (rt0 + t) + col) * lda + 32 * st + 8 * hi);
-      if constexpr (ALO) al[t] = *reinterpret_cast<const f16x8 *>(Al + (16 * (rt0 + t) + col) * lda + 32 * st + 8 * hi);
+      ah[st][t] = *reinterpret_cast<const f16x8 *>(Ah + (16 * (rt0 + t) + col) * lda + 32 * st + 8 * hi);
+      if constexpr (ALO) al[st][t] = *reinterpret_cast<const f16x8 *>(Al + (16 * (rt0 + t) + col) * lda + 32 * st + 8 * hi);
     }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int st = 0; st < KS; ++st) {
     f16x8 wh[CT], wl[CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
@@ -763,16 +787,16 @@ __device__ __forceinline__ void gemm_x3_pre(const _Float16 *Ah, const _Float16 *
 #pragma unroll
       for (int t = 0; t < RT; ++t)
 #pragma unroll
-        for (int c = 0; c < CT; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[c], al[t], acc[t][c], 0, 0, 0);
+        for (int c = 0; c < CT; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[c], al[st][t], acc[t][c], 0, 0, 0);
     }
 #pragma unroll
     for (int t = 0; t < RT; ++t)
 #pragma unroll
-      for (int c = 0; c < CT; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[c], ah[t], acc[t][c], 0, 0, 0);
+      for (int c = 0; c < CT; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[c], ah[st][t], acc[t][c], 0, 0, 0);
 #pragma unroll
     for (int t = 0; t < RT; ++t)
 #pragma unroll
-      for (int c = 0; c < CT; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[c], ah[t], acc[t][c], 0, 0, 0);
+      for (int c = 0; c < CT; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[c], ah[st][t], acc[t][c], 0, 0, 0);
   }
 }
 
