@@ -407,10 +407,13 @@ __device__ __forceinline__ void ck_actor_probs(const float (&logits)[kA], float 
   float sum = 0.0f;
 #pragma unroll
   for (int a = 0; a < kA; ++a) {
-    o[a] = expf(logits[a] - m);
+    // exp and the reciprocal on the hardware units (v_exp_f32 base 2, v_rcp_f32: ~1 ulp each; arguments <= 0, sum in [1, 5]) like the
+    // particle head (actor.hip): a relative 1e-7 on a probability held to 2e-5.  libm's expf + the IEEE division were ~110 of the 190
+    // instructions of the head that every tick of the whole-episode kernel waits for.
+    o[a] = __builtin_amdgcn_exp2f((logits[a] - m) * 1.44269504088896340736f);
     sum += o[a];
   }
-  const float inv = 1.0f / sum;
+  const float inv = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
   for (int a = 0; a < kA; ++a) pr[a] = (1.0f - eps) * (o[a] * inv) + eps / (float)kA;
 }

@@ -364,6 +364,9 @@ template <int N> __global__ void __launch_bounds__(512) __attribute__((amdgpu_wa
 
   const int n_ticks = p.n_ticks;
   const float *const pk_loop = pk;
+  // epsilon once per launch (inside the loop `q.eps_dev ? *q.eps_dev : q.eps` became a select between a device pointer and the
+  // kernel-argument segment: one flat_load per tick, which also counts on the LDS counter)
+  const float eps_now = q.eps_dev ? *q.eps_dev : q.eps;
 #pragma unroll 1
   for (int t = 0; t < n_ticks; ++t) {
     CkpArgs qt = qa;
@@ -396,7 +399,7 @@ template <int N> __global__ void __launch_bounds__(512) __attribute__((amdgpu_wa
         float o[kA], pr[kA];
 #pragma unroll
         for (int a = 0; a < kA; ++a) o[a] = sLG[row_l][a];
-        ck_actor_probs(o, q.eps_dev ? *q.eps_dev : q.eps, pr);
+        ck_actor_probs(o, eps_now, pr);
         const int2 m = sMeta[el_h];
         const int act = actor_pick(pr, actor_uniform_from(ublock, (uint32_t)m.x, m.y));
         sAct[row_l] = act;
