@@ -658,6 +658,9 @@ __device__ int cm3_probe_zero = 0;   // (a run-time zero: a literal one lets the
 #ifndef CM3_CK_A_BUFS
 #define CM3_CK_A_BUFS 1
 #endif
+#ifndef CM3_CK_SELF_SPLIT
+#define CM3_CK_SELF_SPLIT 1
+#endif
 template <int CT, int KS>
 __device__ __forceinline__ void load_bx(const float *Bh, const float *Bl, int ct0, int lane, uint4 (&b0)[2][CT]) {
 #pragma unroll
@@ -1034,6 +1037,89 @@ __device__ __forceinline__ void ck_x3_self_chain(const CkX3Planes &L, const floa
   // ---- branch_self: X2 [64][64] -> H [64][256], relu; wave w owns units [32w, 32w + 32) from here on ---------------------------------
 #ifndef CM3_PROBE_SKIP_SELF
   {
+#if CM3_CK_SELF_SPLIT
+    // The two column tiles one after the other, the first one's epilogue (relu, float16 split, stores: ~70 vector instructions)
+    // issued BETWEEN the second one's matrix instructions: both waves of a SIMD otherwise run their 48 matrix instructions and then
+    // their ~140 vector instructions at the same time, one pipe idle in each half.  Same products in the same order per accumulator.
+    static_assert(BCT == 2, "two column tiles per wave");
+    constexpr int KS = kKSelfX / 32;
+    f32x4 acc0[4][1], acc1[4][1];
+    float4 bias[BCT];
+    load_bias4<BCT>(pk + kPSelfB, BCT * w, lane, bias);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      acc0[t][0] = f32x4{bias[0].x, bias[0].y, bias[0].z, bias[0].w};
+      acc1[t][0] = f32x4{bias[1].x, bias[1].y, bias[1].z, bias[1].w};
+    }
+    const int col = lane & 15, hi = lane >> 4;
+    f16x8 ah[KS][4], al[KS][4];
+#pragma unroll
+    for (int st = 0; st < KS; ++st)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        ah[st][t] = *reinterpret_cast<const f16x8 *>(L.X2h + (16 * t + col) * kLhX2 + 32 * st + 8 * hi);
+        al[st][t] = *reinterpret_cast<const f16x8 *>(L.X2l + (16 * t + col) * kLhX2 + 32 * st + 8 * hi);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+    auto tile_col = [&](int c, f32x4 (&acc)[4][1]) {
+#pragma unroll
+      for (int st = 0; st < KS; ++st) {
+        f16x8 wh, wl;
+        __builtin_memcpy(&wh, &b_self[st][0][c], 16);
+        __builtin_memcpy(&wl, &b_self[st][1][c], 16);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, al[st][t], acc[t][0], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, ah[st][t], acc[t][0], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, ah[st][t], acc[t][0], 0, 0, 0);
+      }
+    };
+    tile_col(0, acc0);
+    load_bx<BCT, 8>(pk + kPH2Sh, pk + kPH2Sl, BCT * w, lane, b_h2);
+    // second tile: matrix instruction k, then step k of the first tile's epilogue (store_relu_x3b<.., true>'s operations, six steps per
+    // row tile), pinned by a scheduling barrier each (asked for the same order through sched_group_barrier the scheduler gave up
+    // after three groups)
+    {
+      typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+      typedef float f2v __attribute__((ext_vector_type(2)));
+      const int hs = hi ^ ((lane >> 1) & 2);     // the swizzled 8-byte position (store_relu_x3b)
+      float v[4][4];
+      h2v hp[4][2], lp[4][2];
+      float r[4][4];
+#pragma unroll
+      for (int k = 0; k < 24; ++k) {
+        const int st = k / 12, prod = (k / 4) % 3, t = k % 4;
+        f16x8 wh, wl;
+        __builtin_memcpy(&wh, &b_self[st][0][1], 16);
+        __builtin_memcpy(&wl, &b_self[st][1][1], 16);
+        acc1[t][0] = prod == 0   ? __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, al[st][t], acc1[t][0], 0, 0, 0)
+                     : prod == 1 ? __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, ah[st][t], acc1[t][0], 0, 0, 0)
+                                 : __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, ah[st][t], acc1[t][0], 0, 0, 0);
+        const int et = k / 6, part = k % 6;
+        if (part < 2) {
+          v[et][2 * part] = relu_f32(acc0[et][0][2 * part]);
+          v[et][2 * part + 1] = relu_f32(acc0[et][0][2 * part + 1]);
+          hp[et][part] = __builtin_convertvector(f2v{v[et][2 * part], v[et][2 * part + 1]}, h2v);
+        } else if (part < 4) {
+          const int pp = part - 2;
+          r[et][2 * pp] = v[et][2 * pp] - (float)hp[et][pp][0];
+          r[et][2 * pp + 1] = v[et][2 * pp + 1] - (float)hp[et][pp][1];
+        } else if (part == 4) {
+          lp[et][0] = __builtin_convertvector(f2v{r[et][0], r[et][1]}, h2v);
+          lp[et][1] = __builtin_convertvector(f2v{r[et][2], r[et][3]}, h2v);
+        } else {
+          const f16x4 vh = {hp[et][0][0], hp[et][0][1], hp[et][1][0], hp[et][1][1]};
+          const f16x4 vl = {lp[et][0][0], lp[et][0][1], lp[et][1][0], lp[et][1][1]};
+          const int at = (16 * et + col) * kLdHb + 16 * (BCT * w) + 4 * hs;
+          *reinterpret_cast<f16x4 *>(L.Hh + at) = vh;
+          *reinterpret_cast<f16x4 *>(L.Hl + at) = vl;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    store_relu_x3b<4, 1, true>(L.Hh, L.Hl, kLdHb, 0, BCT * w + 1, lane, acc1);
+#else
     f32x4 acc[4][BCT];
     float4 bias[BCT];
     load_bias4<BCT>(pk + kPSelfB, BCT * w, lane, bias);
@@ -1041,6 +1127,7 @@ __device__ __forceinline__ void ck_x3_self_chain(const CkX3Planes &L, const floa
     gemm_x3_pre<4, BCT, kKSelfX / 32, true>(L.X2h, L.X2l, kLhX2, 0, lane, b_self, acc);
     load_bx<BCT, 8>(pk + kPH2Sh, pk + kPH2Sl, BCT * w, lane, b_h2);
     store_relu_x3b<4, BCT, true>(L.Hh, L.Hl, kLdHb, 0, BCT * w, lane, acc);
+#endif
   }
 #else
   load_bx<BCT, 8>(pk + kPH2Sh, pk + kPH2Sl, BCT * w, lane, b_h2);
