@@ -975,6 +975,7 @@ __device__ __forceinline__ void ck_x3_others(const CkX3Planes &L, const float *p
 // (behind the conv's barrier: X0 is dead, the conv's 120 registers of weights are gone), after_lin() (behind conv_linear's barrier)
 // and before_h2(acc2) (behind branch_self's barrier, ahead of the h2 pass); the stand-alone kernel passes none.
 struct CkNoHooks {
+  __device__ __forceinline__ void mid_conv() const {}
   __device__ __forceinline__ void after_conv() const {}
   __device__ __forceinline__ void after_lin() const {}
   __device__ __forceinline__ void before_h2(f32x4 (&)[4][kCkBCT]) const {}
@@ -1007,6 +1008,7 @@ __device__ __forceinline__ void ck_x3_self_chain(const CkX3Planes &L, const floa
     bias_tiles(bias_sh, acc_sh);
     gemm_x3_pre<4, 1, KS, false>(L.X0, L.X0, kLhX0, 0, lane, b_own, acc);
     gemm_x3_pre<1, 1, KS, false>(L.X0, L.X0, kLhX0, s_rt0, lane, b_sh, acc_sh);
+    hooks.mid_conv();
     load_bx_all<1, kKLin / 32>(pk + kXLinH, pk + kXLinL, s_half, lane, b_lin);
     store_relu_x3b<4, 1, true>(L.C1h, L.C1l, kLhC1, 0, w, lane, acc);
     store_relu_x3b<1, 1, true>(L.C1h, L.C1l, kLhC1, s_rt0, 8 + s_half, lane, acc_sh);

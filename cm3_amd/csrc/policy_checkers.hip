@@ -211,7 +211,13 @@ __device__ __forceinline__ void ckp_row_flags(const CkState<N> &s, const uint8_t
 // h2's accumulators start from the others-branch table (two agents; stage 1: zeros): row = the OTHER agent's cell.  A lane's
 // accumulators cover 16 agent rows per tile -- read straight from the table that is 16 scattered 64-byte pieces per load, 128
 // cache-line requests per wave and tick, and cost 1.0 - 1.5 us of a 16.5 us tick.  Instead wave w fetches the eight WHOLE table rows
-// of agent rows [8w, 8w + 8) (one coalesced 1 KB load each) behind the conv, parks them in LDS behind conv_linear, and every wave picks its units out of LDS before the h2 pass.
+// of agent rows [8w, 8w + 8), one coalesced 1 KB request each, STRAIGHT INTO LDS (global_load_lds_dwordx4: wave-uniform LDS base + 16
+// bytes per lane = a row of sT) in the middle of the conv phase -- behind the conv's own matrix instructions: the compiler waits for EVERY
+// vector-memory operation in flight at the next use of a loaded register once an LDS-direct load is among them, and at the top of the tick that
+// made the conv wait for the rows too -- and every wave picks its units out of LDS before the h2 pass.  (Until late
+// round 6 the rows went through 32 registers per lane -- requested behind the conv because X0 shared sT's storage, parked behind
+// conv_linear -- and one of them through scratch memory.)  The rows are ordered for the readers by the conv's closing barrier: the
+// compiler drains the vector-memory counter ahead of every barrier while an LDS-direct load is in flight.
 constexpr int kCkpTabLd = 256 + CM3_CK_LD_PAD / 2;   // (floats: 8 dwords mod 64 -- the same lane groups read it with 16-byte loads, see kLdHb)
 struct CkpTableHooks {
   const float *tab;     // NULL: stage 1, no others branch
@@ -219,23 +225,21 @@ struct CkpTableHooks {
   const int32_t *sCell;
   float *sT;
   int w, lane;
-  float4 rows[8];
-  __device__ __forceinline__ void after_conv() {
-#ifndef CM3_PROBE_NO_TABLE
+  __device__ __forceinline__ void mid_conv() {
+#if !defined(CM3_PROBE_NO_TABLE) && defined(__HIP_DEVICE_COMPILE__)
     if (tab) {
+      typedef const __attribute__((address_space(1))) void *GlobalPtr;
+      typedef __attribute__((address_space(3))) void *LdsPtr;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) rows[j] = reinterpret_cast<const float4 *>(tab + (size_t)sCell[8 * w + j] * ck_actor::kH2)[lane];
+      for (int j = 0; j < 8; ++j) {
+        const float *src = tab + (size_t)sCell[8 * w + j] * ck_actor::kH2 + 4 * lane;
+        __builtin_amdgcn_global_load_lds((GlobalPtr)src, (LdsPtr)(sT + (8 * w + j) * kCkpTabLd), 16, 0, 0);
+      }
     }
 #endif
   }
-  __device__ __forceinline__ void after_lin() {
-#ifndef CM3_PROBE_NO_TABLE
-    if (tab) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) *reinterpret_cast<float4 *>(sT + (8 * w + j) * kCkpTabLd + 4 * lane) = rows[j];
-    }
-#endif
-  }
+  __device__ __forceinline__ void after_conv() {}
+  __device__ __forceinline__ void after_lin() {}
   __device__ __forceinline__ void before_h2(f32x4 (&acc2)[4][kCkBCT]) {
 #ifndef CM3_PROBE_NO_TABLE
     if (tab) {
@@ -271,10 +275,11 @@ template <int N> __global__ void __launch_bounds__(512) __attribute__((amdgpu_wa
   const CkPolicyParams &q = *(const CkPolicyParams *)qa;
   const CheckersParams &p = q.ck;
   __shared__ __attribute__((aligned(16))) _Float16 sH[kCkX3HBytes / 2];
-  __shared__ __attribute__((aligned(16))) float sT[64 * kCkpTabLd];    // the tick's 64 table rows; X0 lives in its first 13 KB
-                                                                       // (dead once the conv has run, rewritten by the env phase)
-  static_assert(kCkX3X0Bytes <= (int)sizeof(sT), "X0 inside the table staging");
-  _Float16 *sX0 = reinterpret_cast<_Float16 *>(sT);
+  __shared__ __attribute__((aligned(16))) float sT[64 * kCkpTabLd];    // the tick's 64 table rows
+  // X0 lives in the H storage BEHIND the C1 planes: written by the env phase (nothing else touches the H storage between the h2 pass's
+  // partial logits, its first 16 KB, and the conv), read by the conv (whose epilogue writes C1 below it), dead when branch_self writes H
+  static_assert(2 * 64 * kLhC1 * 2 + kCkX3X0Bytes <= kCkX3HBytes && 8 * 64 * 8 * 4 <= 2 * 64 * kLhC1 * 2, "X0 behind C1 inside the H storage");
+  _Float16 *sX0 = sH + 2 * 64 * kLhC1;
   __shared__ __attribute__((aligned(16))) _Float16 sX2[kCkX3X2Bytes / 2];
   __shared__ float sLG[64][8];
   __shared__ __attribute__((aligned(16))) uint4 lds_tab[48];           // board / norm table (CkBoardTab), one copy per workgroup
