@@ -697,9 +697,10 @@ __device__ __forceinline__ void gemm_x3(const _Float16 *Ah, const _Float16 *Al, 
       bq[1][1][c] = bsrc[1][c][CM3_PROBE_BIDX(64)];
     }
   }
-  // The activation fragments of k-step st + 1 are requested BEFORE the matrix instructions of step st (round 6, late: left to itself the
-  // compiler sinks every LDS read to its first use -- read, wait, two matrix instructions, read, wait, ... -- and the 256-deep h2 pass
-  // ran at 52 % of its matrix time; the scheduling barriers pin the order, the registers hold two steps' fragments)
+  // All activation fragments of a k-step are requested BEFORE its matrix instructions, behind a scheduling barrier (round 6, late: left to
+  // itself the compiler sinks every LDS read to its first use -- read, wait, two matrix instructions, read, wait, ... -- and the 256-deep
+  // h2 pass ran at 52 % of its matrix time).  CM3_CK_A_BUFS = 2 requests step st + 1's fragments ahead of step st's instructions (two
+  // register sets): measured twice, with 24 and with 10 spilled registers, the same time both times -- the default stays 1.
   constexpr int NB = CM3_CK_A_BUFS;   // 2: fragments of step st + 1 requested before the matrix instructions of step st; 1: of step st, all at once
   f16x8 ah[NB][RT], al[NB][RT];
   auto read_a = [&](int st, int buf) {
