@@ -239,7 +239,14 @@ struct CkpTableHooks {
 #endif
   }
   __device__ __forceinline__ void after_conv() {}
-  __device__ __forceinline__ void after_lin() {}
+  // Behind conv_linear's barrier, ahead of branch_self's: this wave's rows have landed (vmcnt(0), written out: today the compiler's own
+  // wait at conv_linear's first use of a loaded weight already drains the counter, but nothing obliges it to) -- with the barrier that
+  // follows, that is what orders LDS-direct data for the other waves' reads in before_h2()
+  __device__ __forceinline__ void after_lin() {
+#if !defined(CM3_PROBE_NO_TABLE) && defined(__HIP_DEVICE_COMPILE__)
+    if (tab) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), the other counters untouched
+#endif
+  }
   __device__ __forceinline__ void before_h2(f32x4 (&acc2)[4][kCkBCT]) {
 #ifndef CM3_PROBE_NO_TABLE
     if (tab) {
