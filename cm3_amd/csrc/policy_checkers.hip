@@ -11,13 +11,15 @@
 // hipGraph: 29.6 us per tick at 8192 envs x 2 agents -- 23.4 us of actor launch, of which ~8 k of 45 k cycles stage the observation the
 // step launch has just written to memory and ~11 k run the others branch, plus two launch boundaries and the step launch per tick.
 // Here a 512-thread workgroup owns 64 agent rows = 64 / N whole envs for all T ticks:
-//   * the env state (collected mask, packed agent words, counters, goals) lives in the registers of the env's 8 lanes (the mapping of
-//     k_checkers_step_fast: every lane runs the short sequential update, each produces 1/8 of the env's outputs);
+//   * the env state (collected mask, packed agent words, counters, goals) lives in the registers of the env's 8 N lanes (the mapping of
+//     k_checkers_step_fast, twice the lanes for two agents: every lane runs the short sequential update, each produces its share of
+//     the env's outputs);
 //   * after a tick those lanes write the NEXT tick's network inputs straight into LDS (window bytes as float16, the normalised
 //     vector, the one-hots of the actions just taken and of the goal) next to the trajectory slot in memory;
 //   * the others branch (two agents: v_obs_others = the normalised cell of the ONE other agent, 91 possible values) is a table
 //     lookup: h2's accumulators start from the row cm3_actor_checkers_pack built with the forward pass's own function
-//     (k_ck_actor_others_table), bit for bit what the unfused actor computes;
+//     (k_ck_actor_others_table), bit for bit what the unfused actor computes; the tick's 64 rows come straight into LDS
+//     (global_load_lds_dwordx4, CkpTableHooks);
 //   * conv -> conv_linear -> branch_self -> h2 -> actor_out as in the stand-alone kernel (ck_x3_self_chain), weights streamed from L2.
 // Trajectories (every array of CheckersRollout, actions and probabilities included) are bit-identical to the alternating launches
 // (tests/test_gpu_actor_checkers.py::test_checkers_policy_rollout_equals_launch_per_tick).  Precision 2 (split float16) only; N = 1
@@ -125,8 +127,8 @@ __device__ __forceinline__ void ckp_windows_to_x0(const CkState<N> &s, const CkL
   }
 }
 
-// the k padding of an X0 row (window bytes 75 .. 95 of the 96 the conv contracts over): X0 shares its storage with the table rows of the
-// h2 pass, which overwrite it every tick -- and 0 x (whatever they left) must be 0
+// the k padding of an X0 row (window bytes 75 .. 95 of the 96 the conv contracts over): X0 lives inside the H storage, which branch_self's
+// output overwrites every tick -- and 0 x (whatever it left) must be 0
 __device__ __forceinline__ void ckp_zero_x0_pad(_Float16 *X0, int row) {
   using namespace ck_actor;
   static_assert(kObs == 75 && kKConvX == 96 && (kLhX0 * 2) % 8 == 0, "one 2-byte and five 8-byte stores per row");
