@@ -1178,7 +1178,9 @@ __device__ __forceinline__ void ck_x3_self_chain(const CkX3Planes &L, const floa
     po[t] = acc;
   }
   CM3_STAMP(6, true);
+#ifndef CM3_PROBE_NO_TAIL_BARRIERS   // (probe builds only: what the three barriers between the h2 pass and the env phase cost)
   __syncthreads();  // every wave is done reading branch_self: the H storage takes the partial logits, float [8 waves][64 rows][8]
+#endif
   CM3_STAMP(10, false);
   float *part = reinterpret_cast<float *>(L.Hh);
   {
@@ -1189,7 +1191,9 @@ __device__ __forceinline__ void ck_x3_self_chain(const CkX3Planes &L, const floa
         *reinterpret_cast<float4 *>(part + ((size_t)w * 64 + 16 * t + col) * 8 + 4 * hi) = make_float4(po[t][0], po[t][1], po[t][2], po[t][3]);
     }
   }
+#ifndef CM3_PROBE_NO_TAIL_BARRIERS
   __syncthreads();
+#endif
   CM3_STAMP(11, false);
   if (w < 4 && lane < 16) {   // logits of agent row 16 w + lane: b_out + the eight partials in wave order
     float lg[kA];

@@ -428,7 +428,9 @@ template <int N> __global__ void __launch_bounds__(512) __attribute__((amdgpu_wa
       }
     }
     CM3_STAMP(13, false);
+#ifndef CM3_PROBE_NO_TAIL_BARRIERS
     ckp_barrier_lds();   // actions are in LDS; every wave is done with this tick's inputs and activations
+#endif
     CM3_STAMP(14, false);
     // ---- env step of the workgroup's envs (checkers.py:228-262): k_checkers_step_fast's tick with the actions just sampled --------
 #ifndef CM3_PROBE_SKIP_ENV   // (probe builds only, tools/r6/ck_whatif.sh: what each part of the tick costs the UNSTAMPED kernel)

@@ -3,7 +3,7 @@
 # probe macro of policy_checkers.hip (results are wrong by construction; only the time matters).  Build here, run on the GPU box:
 #   bash tools/r6/ck_whatif.sh build ; gpurun -- 'bash tools/r6/ck_whatif.sh run'
 R="$(cd "$(dirname "${BASH_SOURCE[0]}")/../.." && pwd)"; cd "$R"
-V="${WHATIF:-skipenv:-DCM3_PROBE_SKIP_ENV h2ks1:-DCM3_PROBE_H2_KS=1 skipsmall:-DCM3_PROBE_SKIP_SMALL notable:-DCM3_PROBE_NO_TABLE skipconv:-DCM3_PROBE_SKIP_CONV skiplin:-DCM3_PROBE_SKIP_LIN skipself:-DCM3_PROBE_SKIP_SELF}"
+V="${WHATIF:-skipenv:-DCM3_PROBE_SKIP_ENV h2ks1:-DCM3_PROBE_H2_KS=1 skipsmall:-DCM3_PROBE_SKIP_SMALL notable:-DCM3_PROBE_NO_TABLE skipconv:-DCM3_PROBE_SKIP_CONV skiplin:-DCM3_PROBE_SKIP_LIN skipself:-DCM3_PROBE_SKIP_SELF notail:-DCM3_PROBE_NO_TAIL_BARRIERS}"
 if [ "${1:-run}" = build ]; then
   mkdir -p tools/variants /tmp/obj_whatif
   O="$R/cm3_amd/csrc/_obj"
