@@ -278,8 +278,14 @@ __device__ __forceinline__ void actor_load_b(const float *packed, int w, int lan
 // (B[k = l>>4][j = l&15]), read from the unit-major first-layer tables in LDS.
 template <int N> struct ActorFirstB {
   static constexpr int L4 = (4 * (N > 1 ? N - 1 : 1)) / 4;
+  // kPrecF16x3 with 16 <= L <= 32 inputs (N = 8: 28): actor_others runs in split float16 like the second layer -- ONE k-step of 32 and three
+  // matrix instructions of 16 cycles per 16 x 16 tile instead of L / 4 = 7 exact-f32 ones of 32 cycles (round 6, late: a build without
+  // the phase showed the first layers costing 5.8 of C5's 15.2 us per tick; with one k-step of seven 11.9).  The other precisions and the
+  // smaller observations keep the exact-f32 form (at N = 4 the split of the inputs costs what the three k-steps do).
+  static constexpr bool kF16Oth = 4 * L4 >= 16 && 4 * L4 <= 32;   // (N = 5 .. 9; N = 10's 36 inputs would need a second k-step)
   float bs[2], bias_s[4];       // bias of units 16w + 4 (l>>4) + reg: the TRANSPOSED C tile holds four units of one row per lane
   float bo[2][L4], bias_o[2][4];
+  f16x8 boh[2], bol[2];         // kF16Oth: A[i = unit l&15][k = 8 (l>>4) + q] = W_others[k][unit], hi and scaled lo parts (kLoScale), 0 for k >= L
 };
 
 template <int N, typename T>
@@ -299,6 +305,16 @@ __device__ __forceinline__ void actor_first_b(const T *self_tab, const T *oth_ta
     for (int s = 0; s < ActorFirstB<N>::L4; ++s) f.bo[cq][s] = stage2 ? oth_tab[uo * PL::OW + 4 * s + hi] : 0.0f;
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) f.bias_o[cq][reg] = stage2 ? oth_tab[(32 * w + 16 * cq + 4 * hi + reg) * PL::OW + PL::L] : 0.0f;
+    if constexpr (ActorFirstB<N>::kF16Oth) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int k = 8 * hi + q;
+        const float wv = (stage2 && k < PL::L) ? (float)oth_tab[uo * PL::OW + (k < PL::L ? k : 0)] : 0.0f;
+        const _Float16 h = (_Float16)wv;
+        f.boh[cq][q] = h;
+        f.bol[cq][q] = (_Float16)((wv - (float)h) * kLoScale);
+      }
+    }
   }
 }
 
@@ -383,6 +399,53 @@ __device__ __forceinline__ void actor_mlp(const ActorLds<N, PREC, RT> &lds, cons
         put4(16 * t + col, 16 * w + 4 * hi, h);
       }
     }
+    if constexpr (PREC == kPrecF16x3 && ActorFirstB<N>::kF16Oth) {
+      // actor_others in split float16 (ActorFirstB::kF16Oth): B[k = 8 (l>>4) + q][j = l&15] = input k of row 16t + (l&15), split per tick
+      // into hi = f16(x) and lo' = f16((x - hi) 2^11) like the second layer's activations (put4); inputs k >= L are masked to zero (the
+      // reads run past the row), the weights there are zero too.  Two accumulators per tile: hi x hi on the bias, the small terms apart.
+      typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+      typedef float f2 __attribute__((ext_vector_type(2)));
+      f16x8 xh[RT], xl[RT];
+#pragma unroll
+      for (int t = 0; t < RT; ++t) {
+        float x[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) x[q] = lds.xs[16 * t + col][6 + 8 * hi + q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) x[q] = (8 * hi + q < L) ? x[q] : 0.0f;
+#pragma unroll
+        for (int p2 = 0; p2 < 4; ++p2) {
+          const f2 xv = f2{x[2 * p2], x[2 * p2 + 1]};
+          const h2 hp = __builtin_convertvector(xv, h2);
+          const f2 res = __builtin_elementwise_fma(__builtin_convertvector(hp, f2), f2{-kLoScale, -kLoScale}, xv * kLoScale);
+          const h2 lp = __builtin_convertvector(res, h2);
+          xh[t][2 * p2] = hp[0]; xh[t][2 * p2 + 1] = hp[1];
+          xl[t][2 * p2] = lp[0]; xl[t][2 * p2 + 1] = lp[1];
+        }
+      }
+#pragma unroll
+      for (int cq = 0; cq < 2; ++cq) {
+        f32x4 d[RT], ds[RT];
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+          d[t] = f32x4{f1.bias_o[cq][0], f1.bias_o[cq][1], f1.bias_o[cq][2], f1.bias_o[cq][3]};
+          ds[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+#pragma unroll
+        for (int t = 0; t < RT; ++t) ds[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f1.bol[cq], xh[t], ds[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < RT; ++t) d[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f1.boh[cq], xh[t], d[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < RT; ++t) ds[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f1.boh[cq], xl[t], ds[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+          float h[4];
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) h[reg] = relu_f32(fmaf(ds[t][reg], kLoUnscale, d[t][reg]));
+          put4(16 * t + col, kH1S + 32 * w + 16 * cq + 4 * hi, h);
+        }
+      }
+    } else {
 #pragma unroll
     for (int cq = 0; cq < 2; ++cq) {  // actor_others: two 16-unit tiles, units 32w + 16cq .. + 15 (stage 1: exactly 0, no others branch)
       f32x4 d[RT];
@@ -399,6 +462,7 @@ __device__ __forceinline__ void actor_mlp(const ActorLds<N, PREC, RT> &lds, cons
         for (int reg = 0; reg < 4; ++reg) h[reg] = relu_f32(d[t][reg]);
         put4(16 * t + col, kH1S + 32 * w + 16 * cq + 4 * hi, h);
       }
+    }
     }
   }
   CM3_STAMP(3, true);

@@ -346,12 +346,13 @@ def test_device_actor_matches_vectors_from_the_reference_function_body(tag, N, s
 
 @pytest.mark.parametrize("precision", ["f32", "f16x3"])
 @pytest.mark.parametrize("w2_scale,w1_scale", [(1e-3, 60.0), (3e-5, 300.0), (0.05, 1.0)])
-def test_actor_split_precision_with_small_weights_and_large_activations(precision, w2_scale, w1_scale):
+@pytest.mark.parametrize("N,cfg", [(4, "particle_stage2_antipodal.json"), (8, "particle_merge8.json")])   # (N = 8: actor_others in split float16 too)
+def test_actor_split_precision_with_small_weights_and_large_activations(precision, w2_scale, w1_scale, N, cfg):
     """the float16 split x = hi + lo loses its residual to float16's subnormals once |x| < 0.125 unless the residual
     is kept scaled (csrc/actor.hip kLoScale).  Second-layer weights of 1e-3 / 3e-5 against first-layer activations of 1e2 / 1e3
     (logits still O(1)), and the reference's own scale: every probability within 2e-5 of a FLOAT64 evaluation of the network."""
     from cm3_amd.actor import ParticleActor
-    N, E, seed = 4, 512, 5
+    E, seed = 512, 5
     rng = np.random.default_rng(17)
     w = AO.init_weights(rng, N, stage=2, scale=1.0)
     for k in ("actor_branch_self/kernel", "actor_branch_self/bias", "stage-2/actor_others/kernel", "stage-2/actor_others/bias"):
@@ -359,7 +360,7 @@ def test_actor_split_precision_with_small_weights_and_large_activations(precisio
     for k in ("W_branch_self_h2", "stage-2/W_others_h2"):
         w[k] = (w[k] * w2_scale / (w1_scale * 4.0)).astype(np.float32) if w2_scale >= 0.05 else (w[k] * w2_scale).astype(np.float32)
     w["b"] = (w["b"] * 0.1).astype(np.float32)
-    env = _env(E, N, "particle_stage2_antipodal.json", seed=seed)
+    env = _env(E, N, cfg, seed=seed)
     env.reset()
     for _ in range(3):
         env.step()
