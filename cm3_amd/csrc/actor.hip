@@ -276,13 +276,16 @@ __device__ __forceinline__ void actor_load_b(const float *packed, int w, int lan
 
 // Phase-A B operands of one lane: unit 16w + col of branch_self and units 32w + 16cq + col of actor_others, k = 4s + hi
 // (B[k = l>>4][j = l&15]), read from the unit-major first-layer tables in LDS.
+#ifndef CM3_F16OTH_MIN
+#define CM3_F16OTH_MIN 16
+#endif
 template <int N> struct ActorFirstB {
   static constexpr int L4 = (4 * (N > 1 ? N - 1 : 1)) / 4;
   // kPrecF16x3 with 16 <= L <= 32 inputs (N = 8: 28): actor_others runs in split float16 like the second layer -- ONE k-step of 32 and three
   // matrix instructions of 16 cycles per 16 x 16 tile instead of L / 4 = 7 exact-f32 ones of 32 cycles (round 6, late: a build without
   // the phase showed the first layers costing 5.8 of C5's 15.2 us per tick; with one k-step of seven 11.9).  The other precisions and the
   // smaller observations keep the exact-f32 form (at N = 4 the split of the inputs costs what the three k-steps do).
-  static constexpr bool kF16Oth = 4 * L4 >= 16 && 4 * L4 <= 32;   // (N = 5 .. 9; N = 10's 36 inputs would need a second k-step)
+  static constexpr bool kF16Oth = 4 * L4 >= CM3_F16OTH_MIN && 4 * L4 <= 32;   // (N = 5 .. 9; N = 10's 36 inputs would need a second k-step)
   float bs[2], bias_s[4];       // bias of units 16w + 4 (l>>4) + reg: the TRANSPOSED C tile holds four units of one row per lane
   float bo[2][L4], bias_o[2][4];
   f16x8 boh[2], bol[2];         // kF16Oth: A[i = unit l&15][k = 8 (l>>4) + q] = W_others[k][unit], hi and scaled lo parts (kLoScale), 0 for k >= L
