@@ -334,6 +334,7 @@ __device__ __forceinline__ void actor_mlp(const ActorLds<N, PREC, RT> &lds, cons
   const int col = lane & 15, hi = lane >> 4, c0 = 16 * w;
   (void)stage2;   // (f1 = the lane's first-layer operands, actor_first_b: read from the LDS tables ONCE per launch by the caller)
   // ---- phase A: dense(6 -> 64) units [16w, 16w+16) and dense(L -> 128) units [32w, 32w+32) (networks.py:520-529) ------
+#ifndef CM3_PROBE_P_NO_PHASEA   // (probe builds only, tools/r6/policy_whatif.sh: what a part of the tick costs; results are wrong by construction)
   {
     float ax[RT][2], ao[RT][L / 4];
 #pragma unroll
@@ -454,8 +455,13 @@ __device__ __forceinline__ void actor_mlp(const ActorLds<N, PREC, RT> &lds, cons
       f32x4 d[RT];
 #pragma unroll
       for (int t = 0; t < RT; ++t) d[t] = f32x4{f1.bias_o[cq][0], f1.bias_o[cq][1], f1.bias_o[cq][2], f1.bias_o[cq][3]};
+#ifdef CM3_PROBE_P_PHASEA_KS1   // (probe builds only: the exact-f32 others layer with ONE k-step)
+      constexpr int KSO = 1;
+#else
+      constexpr int KSO = L / 4;
+#endif
 #pragma unroll
-      for (int s = 0; s < L / 4; ++s)
+      for (int s = 0; s < KSO; ++s)
 #pragma unroll
         for (int t = 0; t < RT; ++t) d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(f1.bo[cq][s], ao[t][s], d[t], 0, 0, 0);
 #pragma unroll
@@ -468,6 +474,7 @@ __device__ __forceinline__ void actor_mlp(const ActorLds<N, PREC, RT> &lds, cons
     }
     }
   }
+#endif
   CM3_STAMP(3, true);
   __syncthreads();
   CM3_STAMP(4, false);
@@ -483,6 +490,7 @@ __device__ __forceinline__ void actor_mlp(const ActorLds<N, PREC, RT> &lds, cons
   f32x4 acc[RT];
 #pragma unroll
   for (int t = 0; t < RT; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#ifndef CM3_PROBE_P_NO_PHASEB
   if constexpr (PREC == kPrecF16x3) {
     f32x4 accs[RT];   // hi x lo' + lo' x hi, scaled by 2^11 (kLoScale)
 #pragma unroll
@@ -525,6 +533,7 @@ __device__ __forceinline__ void actor_mlp(const ActorLds<N, PREC, RT> &lds, cons
         acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(lds.h1s[16 * t + col][4 * s + hi], b.bw[s], acc[t], 0, 0, 0);
     }
   }
+#endif
   CM3_STAMP(5, true);
   if constexpr (!G::H2SEP) __syncthreads();  // all waves have consumed h1: its storage becomes h2
   // ---- h2 = relu(add_n + b) (networks.py:533-534): C tile -> LDS rows --------------------------------------------------

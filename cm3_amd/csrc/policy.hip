@@ -132,7 +132,11 @@ template <int N, int BF16, int RT> __global__ void CM3_MATRIX_KERNEL k_policy_ro
     __builtin_amdgcn_s_setprio(2);
     float pr[kA];
     const float u = actor_uniform_from(ublock, episode, steps);
+#ifndef CM3_PROBE_P_NO_HEAD   // (probe builds only, tools/r6/policy_whatif.sh)
     actor_head_probs(lds.h2s, hb, wr, lane, q.eps, pr);
+#else
+    for (int a = 0; a < kA; ++a) pr[a] = 0.2f;
+#endif
     // (the head leaves the row's probabilities in lanes 0..15 only; lanes 16..63 repeat the physics of lane l & 15 and get its
     // action so that they take the same branches -- nothing they compute is stored: see the exchange slot below)
     const int act = bcast_row0(actor_pick(pr, u));
@@ -149,6 +153,7 @@ template <int N, int BF16, int RT> __global__ void CM3_MATRIX_KERNEL k_policy_ro
     if (act == 3) uy = -1.0f;
     if (act == 4) uy = +1.0f;
     float Fx = ux * 5.0f + 0.0f, Fy = uy * 5.0f + 0.0f;
+#ifndef CM3_PROBE_P_NO_PHYS
 #pragma unroll
     for (int k = 0; k < N - 1; ++k) {  // the reference's accumulation order: other agents ascending (core.py:145-155)
       const int j = k < i ? k : k + 1;
@@ -158,6 +163,7 @@ template <int N, int BF16, int RT> __global__ void CM3_MATRIX_KERNEL k_policy_ro
       Fx = f_x + Fx;
       Fy = f_y + Fy;
     }
+#endif
     si.x = si.x * kKeep;
     si.y = si.y * kKeep;
     si.x = si.x + (Fx / 1.0f) * kDt;
@@ -283,6 +289,7 @@ template <int N, int BF16, int RT> __global__ void CM3_MATRIX_KERNEL k_policy_ro
     CM3_STAMP(10, false);
     // ---- trajectory stores + the LDS tile of the next tick ---------------------------------------------------------------------
     if (part0) {
+#ifndef CM3_PROBE_P_NO_STORES
       if (row_ok) {   // every per-row store of the tick in ONE exec region (the action, its probabilities and the reward used to have
                       // regions of their own further up: ~6 scalar instructions and a branch each on the row waves' path)
         tick_ptr(p.actions, p.st_actions, t)[r] = act;
@@ -296,13 +303,16 @@ template <int N, int BF16, int RT> __global__ void CM3_MATRIX_KERNEL k_policy_ro
         if (p.goals_out != p.goals_in || was_reset)
           reinterpret_cast<V2 *>(tick_ptr(p.goals_out, p.st_goals, t))[(size_t)i * E + e] = gl;
       }
+#endif
       V4 *o = reinterpret_cast<V4 *>(tick_ptr(p.obs_others, p.st_obs, t)) + r * NO;
 #pragma unroll
       for (int k = 0; k < NO; ++k) {  // observation (multi-goal_spread.py:145-154)
         const int j = (N > 1) ? (k < i ? k : k + 1) : 0;
         (void)j;
         const V4 d = sub4<float, V4>(oth[k], si);
+#ifndef CM3_PROBE_P_NO_STORES
         if (row_ok) o[k] = d;
+#endif
         lds.xs[rl][6 + 4 * k + 0] = d.x; lds.xs[rl][6 + 4 * k + 1] = d.y;
         lds.xs[rl][6 + 4 * k + 2] = d.z; lds.xs[rl][6 + 4 * k + 3] = d.w;
       }
