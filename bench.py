@@ -44,7 +44,8 @@ MFMA_F16_PEAK_TFLOPS = 2500.0  # same guide: FP16 / BF16 MFMA, dense (the 5 PF f
 def particle_actor_mfma_work(n_agents, precision):
     """EXECUTED matrix-core work of one agent row and tick of the particle actor (csrc/actor.hip), per pipe, in MACs -- the
     padded tiles as the instructions run them, not the network's own 6*64 + L*128 + 192*64 + 64*5:
-      first layers   v_mfma_f32_16x16x4_f32: K = 6 -> 8 for branch_self (64 units), K = L for actor_others (128 units)
+      first layers   v_mfma_f32_16x16x4_f32: K = 6 -> 8 for branch_self (64 units), K = L for actor_others (128 units) -- f16x3 with
+                     16 <= L <= 32 (N = 5..9, ActorFirstB::kF16Oth): actor_others as THREE float16 passes with K = 32
       second layer   f32: 192 x 64 on the f32 pipe; f16x3: THREE float16 passes (hi hi + hi lo + lo hi) on the f16 pipe; bf16: one
       output layer   v_mfma_f32_16x16x4_f32: 64 x 16 (5 actions padded to a 16-column tile)
     -> (f32 MACs, f16/bf16 MACs, network MACs)"""
@@ -54,6 +55,8 @@ def particle_actor_mfma_work(n_agents, precision):
     net = 6 * 64 + L * 128 + second + 64 * 5
     if precision == "f32":
         return f32 + second, 0, net
+    if precision == "f16x3" and 16 <= L <= 32:
+        return 64 * 8 + 64 * 16, (second + 128 * 32) * 3, net
     return f32, second * (3 if precision == "f16x3" else 1), net
 
 
