@@ -54,7 +54,8 @@ class ParticleActor(object):
         "f16x3"   split float16: activations and weights as hi + lo float16 pairs, three f16 MFMA passes (hi hi + hi lo +
                   lo hi), float32 accumulation.  22 of the 24 significand bits per factor: probabilities within the same 2e-5
                   of the float64 oracle as "f32" (tests/test_gpu_actor.py), ~5x fewer matrix-core cycles.  First-layer
-                  activations must stay below float16's 65504 (three orders of magnitude above a trained policy's);
+                  activations must stay below float16's 65504 (three orders of magnitude above a trained policy's).  With 5..9
+                  agents (16..32 others inputs) actor_others runs in the same split float16 (csrc/actor.hip ActorFirstB::kF16Oth);
         "bf16"    plain bf16 operands: fastest, probabilities within ~1e-2 -- not a parity path."""
         self.device = _lib.require_gpu(device)
         if precision not in PRECISIONS:

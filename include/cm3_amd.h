@@ -346,7 +346,9 @@ typedef struct cm3_actor_particle_desc {
                           by up to ~1e-2).  2: SPLIT float16 -- activations and W2 as hi + lo float16 pairs, three f16 MFMA
                           passes (hi hi + hi lo + lo hi), float32 accumulation (22 of 24 significand bits per factor):
                           probabilities within the 2e-5 of the float64 oracle that precision 0 is held to, ~5x fewer
-                          matrix-core cycles; first-layer activations must stay below 65504 */
+                          matrix-core cycles; first-layer activations must stay below 65504.  With 16..32 others inputs (5..9
+                          agents) actor_others runs in the same split float16 (inputs and weights split alike; inputs below
+                          65504 too: they are relative positions / velocities) */
   int32_t _pad;
   int64_t env_id_base;
   uint64_t seed;
