@@ -124,7 +124,11 @@ template <int N, int BF16, int RT> __global__ void CM3_MATRIX_KERNEL k_policy_ro
     // ---- policy: forward pass, probabilities and the sampled action of row rl (alg_credit.py:113-122) -----------------
     CM3_STAMP(0, false);
     actor_mlp<N, BF16, RT>(lds, b, f1, w, lane, q.stage > 1);
+#ifdef CM3_PROBE_P_NO_ROWS   // (probe builds only: the matrix phases and the barriers alone)
+    if (false) {
+#else
     if (row_wave) {   // (wave-uniform; no workgroup barrier inside)
+#endif
     // The head, the physics and the stores of the rows are the part of the tick only this wave can do while its workgroup waits at
     // the closing barrier: it goes first on its SIMD, ahead of the matrix phases of the workgroup that shares the CU (measured,
     // same box, three alternating rounds: 4.31 -> 4.15 us per tick at 4 096 x 4, 45.1 -> 44.6 at 65 536 x 4; levels 1, 2, 3 are
@@ -254,7 +258,11 @@ template <int N, int BF16, int RT> __global__ void CM3_MATRIX_KERNEL k_policy_ro
     CM3_STAMP(9, false);
     // ---- same-tick re-initialisation of finished episodes (CM3_FLAG_AUTO_RESET) ------------------------------------------------
     bool was_reset = false;
+#ifdef CM3_PROBE_P_NO_RESET   // (probe builds only)
+    if (false) {
+#else
     if (auto_reset && done) {
+#endif
       void *term_state = tick_ptr(p.term_state, p.st_term_state, t);
       void *term_obs = tick_ptr(p.term_obs_others, p.st_term_obs, t);
       if (writer && term_state) reinterpret_cast<V4 *>(term_state)[(size_t)i * E + e] = si;

@@ -3,7 +3,7 @@
 # the product in ONE probe macro of policy.hip / actor.hip (results wrong by construction; only the time matters).
 #   bash tools/r6/policy_whatif.sh build ; gpurun -- 'bash tools/r6/policy_whatif.sh run'
 R="$(cd "$(dirname "${BASH_SOURCE[0]}")/../.." && pwd)"; cd "$R"
-V="${WHATIF:-nophasea:-DCM3_PROBE_P_NO_PHASEA nophaseb:-DCM3_PROBE_P_NO_PHASEB nohead:-DCM3_PROBE_P_NO_HEAD nophys:-DCM3_PROBE_P_NO_PHYS nostores:-DCM3_PROBE_P_NO_STORES}"
+V="${WHATIF:-nophasea:-DCM3_PROBE_P_NO_PHASEA nophaseb:-DCM3_PROBE_P_NO_PHASEB nohead:-DCM3_PROBE_P_NO_HEAD nophys:-DCM3_PROBE_P_NO_PHYS nostores:-DCM3_PROBE_P_NO_STORES norows:-DCM3_PROBE_P_NO_ROWS noreset:-DCM3_PROBE_P_NO_RESET ks1:-DCM3_PROBE_P_PHASEA_KS1}"
 if [ "${1:-run}" = build ]; then
   mkdir -p tools/variants /tmp/obj_pwhatif
   O="$R/cm3_amd/csrc/_obj"
